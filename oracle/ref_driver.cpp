@@ -1,0 +1,188 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into, imported by or shipped with the product.
+//
+// Thin C driver around the *unmodified* reference kernel translation units, which are compiled
+// from where they lie under /root/reference by oracle/Makefile (target `ref`):
+//     src/kernel_generic.cpp, src/amd64/kernel_amd64_{sse42,avx2,avx512f,avx512f_bf16}.cpp
+// Each unit exports one function  piquant::install_quant_<isa>()  returning a kernel_registry of three
+// plain function pointers (reference src/kernels/kernels.inl:198-204, src/piquant_internal.hpp:30-39).
+// All of the path's arithmetic lives in those units.  What is NOT built: src/piquant.cpp and
+// src/capi.cpp -- they include the un-vendored submodule header <pithreadpool/threadpool.hpp>
+// (reference .gitmodules:5-7) and are therefore unbuildable here; no stand-in header is written.
+// The only symbol those units need from piquant.cpp is the abort hook piquant::panic
+// (src/piquant_internal.hpp:8), which this driver provides as a plain "print + abort".
+//
+// The driver calls  registry.quant_kernel(in, out, numel, descriptor)  on ONE contiguous range,
+// i.e. what the reference does per pool thread (src/piquant.cpp:159-169), so results correspond to
+// a reference context created with num_threads == 1.  ref_*_mt entry points re-apply the
+// reference's own static partition rule (src/piquant.cpp:145-157) over std::threads so that the
+// reference kernels can be timed on several host cores (bench.py cpu_baseline kind "reference").
+
+#include <piquant.hpp>
+#include "piquant_internal.hpp"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace piquant {
+    [[noreturn]] void panic(const char* msg, ...) {
+        std::va_list ap;
+        va_start(ap, msg);
+        std::fputs("[oracle/_ref] reference kernel panic: ", stderr);
+        std::vfprintf(stderr, msg, ap);
+        std::fputc('\n', stderr);
+        va_end(ap);
+        std::abort();
+    }
+    [[nodiscard]] extern auto install_quant_generic() noexcept -> kernel_registry;
+    [[nodiscard]] extern auto install_quant_amd64_sse42() noexcept -> kernel_registry;
+    [[nodiscard]] extern auto install_quant_amd64_avx2() noexcept -> kernel_registry;
+    [[nodiscard]] extern auto install_quant_amd64_avx512f() noexcept -> kernel_registry;
+    [[nodiscard]] extern auto install_quant_amd64_avx512f_bf16() noexcept -> kernel_registry;
+}
+
+namespace {
+    using piquant::kernel_registry;
+    using desc_t = piquant::context::quant_descriptor;
+
+    enum isa_id { ISA_GENERIC = 0, ISA_SSE42, ISA_AVX2, ISA_AVX512F, ISA_AVX512F_BF16, ISA_COUNT };
+    const char* const isa_names[ISA_COUNT] = {"generic", "sse42", "avx2", "avx512f", "avx512f_bf16"};
+
+    bool isa_ok(int isa) {
+        __builtin_cpu_init();
+        switch (isa) {
+            case ISA_GENERIC: return true;
+            case ISA_SSE42: return __builtin_cpu_supports("sse4.2");
+            case ISA_AVX2: return __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+            case ISA_AVX512F: return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw");
+            case ISA_AVX512F_BF16:
+                return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw")
+                    && __builtin_cpu_supports("avx512bf16");
+            default: return false;
+        }
+    }
+
+    kernel_registry registry_of(int isa) {
+        if (!isa_ok(isa)) {
+            std::fprintf(stderr, "[oracle/_ref] ISA %d not supported by this CPU\n", isa);
+            std::abort();
+        }
+        switch (isa) {
+            case ISA_SSE42: return piquant::install_quant_amd64_sse42();
+            case ISA_AVX2: return piquant::install_quant_amd64_avx2();
+            case ISA_AVX512F: return piquant::install_quant_amd64_avx512f();
+            case ISA_AVX512F_BF16: return piquant::install_quant_amd64_avx512f_bf16();
+            default: return piquant::install_quant_generic();
+        }
+    }
+
+    // The reference's static range split for pool thread t of T (src/piquant.cpp:139-157).
+    bool split(std::int64_t n, std::int64_t t, std::int64_t T, std::int64_t pack, std::int64_t& begin, std::int64_t& len) {
+        std::int64_t b = n * t / T, e = n * (t + 1) / T;
+        if (pack > 1) {
+            b -= b % pack;
+            if (t + 1 != T) e -= e % pack;
+        }
+        begin = b;
+        len = e - b;
+        return len > 0;
+    }
+
+    void run_mt(const kernel_registry& reg, const desc_t& d, int threads) {
+        const auto bits_in = static_cast<std::int64_t>(piquant::dtype_info_of(d.dt_in).bit_size);
+        const auto bits_out = static_cast<std::int64_t>(piquant::dtype_info_of(d.dt_out).bit_size);
+        const std::int64_t packed_bits = d.type == piquant::context::command_type::quant ? bits_out : bits_in;
+        const std::int64_t pack = packed_bits < 8 ? 8 / packed_bits : 1;
+        auto job = [&](int t) {
+            std::int64_t b, n;
+            if (!split(d.numel, t, threads, pack, b, n)) return;
+            reg.quant_kernel(d.in + bits_in * b / 8, d.out + bits_out * b / 8, n, d);
+        };
+        if (threads <= 1) { job(0); return; }
+        std::vector<std::thread> pool;
+        pool.reserve(threads);
+        for (int t = 0; t < threads; ++t) pool.emplace_back(job, t);
+        for (auto& th : pool) th.join();
+    }
+}
+
+extern "C" {
+
+int ref_isa_count(void) { return ISA_COUNT; }
+const char* ref_isa_name(int isa) { return isa >= 0 && isa < ISA_COUNT ? isa_names[isa] : "?"; }
+int ref_isa_supported(int isa) { return isa_ok(isa) ? 1 : 0; }
+
+// Highest ISA this CPU runs, in the reference's own preference order (src/piquant.cpp:183-186).
+int ref_isa_best(void) {
+    for (int isa = ISA_COUNT - 1; isa > 0; --isa)
+        if (isa_ok(isa)) return isa;
+    return ISA_GENERIC;
+}
+
+void ref_quantize(int isa, const void* in, int dt_in, void* out, int dt_out, long long numel,
+                  float scale, long long zero_point, int round_mode, float rnd_threshold, int threads) {
+    desc_t d {};
+    d.type = piquant::context::command_type::quant;
+    d.in = static_cast<const std::byte*>(in);
+    d.out = static_cast<std::byte*>(out);
+    d.numel = numel;
+    d.scale = scale;
+    d.zero_point = zero_point;
+    d.dt_in = static_cast<piquant::dtype>(dt_in);
+    d.dt_out = static_cast<piquant::dtype>(dt_out);
+    d.rounding = static_cast<piquant::round_mode>(round_mode);
+    d.rnd_threshold = rnd_threshold;
+    run_mt(registry_of(isa), d, threads);
+}
+
+void ref_dequantize(int isa, const void* in, int dt_in, void* out, int dt_out, long long numel,
+                    float scale, long long zero_point, int reduce_op, int threads) {
+    desc_t d {};
+    d.type = piquant::context::command_type::dequant;
+    d.in = static_cast<const std::byte*>(in);
+    d.out = static_cast<std::byte*>(out);
+    d.numel = numel;
+    d.scale = scale;
+    d.zero_point = zero_point;
+    d.dt_in = static_cast<piquant::dtype>(dt_in);
+    d.dt_out = static_cast<piquant::dtype>(dt_out);
+    d.reducing = static_cast<piquant::reduce_op>(reduce_op);
+    run_mt(registry_of(isa), d, threads);
+}
+
+// {min,max} of one contiguous span, or of `threads` equal spans folded in double like
+// src/piquant.cpp:238-244.
+void ref_minmax_f32(int isa, const float* x, long long n, int threads, float* out_min_max) {
+    const kernel_registry reg = registry_of(isa);
+    if (threads <= 1) {
+        const auto r = reg.find_min_max_float32(std::span<const float>{x, static_cast<std::size_t>(n)});
+        out_min_max[0] = r[0];
+        out_min_max[1] = r[1];
+        return;
+    }
+    std::vector<std::array<float, 2>> part(threads, {std::numeric_limits<float>::max(), std::numeric_limits<float>::lowest()});
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t)
+        pool.emplace_back([&, t] {
+            const long long b = n * t / threads, e = n * (t + 1) / threads;
+            if (e > b) part[t] = reg.find_min_max_float32(std::span<const float>{x + b, static_cast<std::size_t>(e - b)});
+        });
+    for (auto& th : pool) th.join();
+    double lo = std::numeric_limits<double>::max(), hi = std::numeric_limits<double>::lowest();
+    for (auto& p : part) { lo = std::min(lo, double(p[0])); hi = std::max(hi, double(p[1])); }
+    out_min_max[0] = static_cast<float>(lo);
+    out_min_max[1] = static_cast<float>(hi);
+}
+
+void ref_minmax_bf16(int isa, const unsigned short* x, long long n, float* out_min_max) {
+    const kernel_registry reg = registry_of(isa);
+    const auto r = reg.find_min_max_bfloat16(
+        std::span<const piquant::bfp16_t>{reinterpret_cast<const piquant::bfp16_t*>(x), static_cast<std::size_t>(n)});
+    out_min_max[0] = r[0];
+    out_min_max[1] = r[1];
+}
+
+}   // extern "C"
