@@ -1,0 +1,69 @@
+/* piquant_hip.h -- additive, optional entry points of the MI355X-native libpiquant.so.
+ *
+ * Nothing here exists in the reference; a caller that only knows piquant.h never needs it.  These
+ * functions expose what a GPU data path needs and the reference's synchronous host-only API cannot
+ * express: the HIP stream to enqueue on, asynchronous completion, a reproducible stochastic threshold,
+ * and the two halves of compute_quant_params (device-side min/max scan, host-side epilogue) between which
+ * a multi-GPU caller performs its one collective (an 8-byte MIN all-reduce over RCCL/xGMI).
+ */
+#ifndef PIQUANT_HIP_H
+#define PIQUANT_HIP_H
+
+#include "piquant.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* HIP stream (a hipStream_t passed as void*) that the context enqueues kernels on; NULL selects the
+ * context's own non-blocking stream (the default).  PyTorch callers pass
+ * torch.cuda.current_stream().cuda_stream so that work is ordered with the tensors' producers. */
+PIQUANT_EXPORT void piquant_hip_set_stream(piquant_context_t* ctx, void* hip_stream);
+
+/* blocking != 0 (default): every piquant.h call returns after its work has completed on the GPU -- the
+ * reference's semantics (its calls join the thread pool before returning, src/piquant.cpp:210,237).
+ * blocking == 0: piquant_quantize / piquant_dequantize on DEVICE pointers only enqueue; completion follows
+ * stream order.  Host-pointer calls and compute_quant_params always complete before returning. */
+PIQUANT_EXPORT void piquant_hip_set_blocking(piquant_context_t* ctx, int blocking);
+
+/* Stochastic rounding control.  The reference draws ONE threshold in [0,1) per call from an unseeded
+ * thread-local mt19937_64 (src/piquant.cpp:194-201) and compares every element's fractional part with it
+ * (src/kernels/quantize.inl:8-19).  Default here: the same, drawn per call from a context-owned
+ * mt19937_64.
+ *   piquant_hip_set_stochastic_threshold(ctx, t): 0 <= t < 1 pins the per-call threshold (reproducible,
+ *       bit-comparable with the reference kernels driven with the same threshold); t < 0 restores drawing.
+ *   piquant_hip_set_stochastic_seed(ctx, seed): reseeds the context's generator.
+ *   piquant_hip_set_stochastic_per_element(ctx, on, seed, index_base): opt-in extension -- an independent
+ *       threshold per element from a counter hash of (seed, index_base + element index); shard-invariant
+ *       when each shard passes its global element offset as index_base. */
+PIQUANT_EXPORT void piquant_hip_set_stochastic_threshold(piquant_context_t* ctx, float threshold);
+PIQUANT_EXPORT void piquant_hip_set_stochastic_seed(piquant_context_t* ctx, uint64_t seed);
+PIQUANT_EXPORT void piquant_hip_set_stochastic_per_element(piquant_context_t* ctx, int enabled, uint64_t seed,
+                                                           uint64_t index_base);
+
+/* First half of compute_quant_params: scan n elements of x (dtype F32 or BF16, device or host pointer)
+ * and fold {min, -max} into two order-preserving int32 keys in DEVICE memory with atomic MIN, enqueued on
+ * the context's stream (asynchronous).  init != 0 first resets both keys to the identity (+FLT_MAX), so
+ * several scans with init == 0 accumulate into one result.  Because both keys reduce with MIN, a
+ * multi-GPU caller needs exactly one MIN all-reduce of 2 x int32 (torch.distributed / RCCL) between this
+ * call and the epilogue.  Restates reference src/kernels/kernels_specialized.inl:1418-1607 + the block fold
+ * of src/piquant.cpp:230-244. */
+PIQUANT_EXPORT void piquant_hip_minmax_keys(piquant_context_t* ctx, const void* x, piquant_dtype_t dtype, size_t n,
+                                            int32_t* device_keys, int init);
+
+/* Host helpers: key <-> float, and the (min,max) -> (scale, zero_point) epilogue in double precision
+ * (reference src/piquant.cpp:213-220, 245-258).  keys[0] encodes min, keys[1] encodes -max. */
+PIQUANT_EXPORT void piquant_hip_decode_minmax_keys(const int32_t keys[2], float* out_min, float* out_max);
+PIQUANT_EXPORT void piquant_hip_quant_params_from_minmax(float min, float max, piquant_dtype_t target_quant_dtype,
+                                                         float* out_scale, int64_t* out_zero_point);
+
+/* HIP device ordinal the context is bound to. */
+PIQUANT_EXPORT int piquant_hip_device(const piquant_context_t* ctx);
+
+/* "piquant-hip <version> gfx950" */
+PIQUANT_EXPORT const char* piquant_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIQUANT_HIP_H */

@@ -1,0 +1,442 @@
+// Host layer behind the piquant.h C ABI: argument validation, pointer classification, the per-call
+// stochastic threshold, PCIe staging for host buffers, and the quantization-parameter epilogue.
+// It replaces the reference's context/pimpl (src/piquant.cpp:107-381) and capi (src/capi.cpp:15-104);
+// the thread pool and its static range split disappear -- a HIP grid covers the whole range in one launch.
+//
+// There is no CPU compute path in this library: every element is processed by a HIP kernel.
+#include "piquant.h"
+#include "piquant_hip.h"
+
+#include "device_math.hpp"
+#include "dequant_kernels.hpp"   // OP_* enum only (host side)
+#include "launch.hpp"
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <limits>
+#include <mutex>
+#include <random>
+
+namespace pq {
+
+// Reference convention (src/piquant.cpp:88-98): red message on stderr, then abort().
+void panic(const char* fmt, ...) {
+    std::va_list ap;
+    va_start(ap, fmt);
+    std::fputs("\x1b[31m", stderr);
+    std::vfprintf(stderr, fmt, ap);
+    std::fputs("\x1b[0m\n", stderr);
+    std::fflush(stderr);
+    va_end(ap);
+    std::abort();
+}
+
+void check_hip(hipError_t e, const char* what, const char* file, int line) {
+    if (e != hipSuccess) panic("%s:%d HIP call failed: %s -> %s", file, line, what, hipGetErrorString(e));
+}
+
+namespace {
+
+struct dtype_row {
+    const char* name;
+    int bits;
+    bool quant;
+};
+// include/piquant.hpp:144-150 of the reference
+constexpr dtype_row kDtypes[5] = {{"f32", 32, false}, {"bf16", 16, false}, {"uint2", 2, true}, {"uint4", 4, true}, {"uint8", 8, true}};
+
+const dtype_row& dtype_of(int dt) {
+    if (dt < 0 || dt > 4) panic("invalid dtype code %d", dt);
+    return kDtypes[dt];
+}
+
+// Bytes holding `numel` elements: numel*stride for float/uint8, ceil(numel/(8/bits)) for packed types
+// (reference src/capi.cpp:41-42,69-70, src/piquant_internal.hpp:41-44).
+size_t span_bytes(size_t numel, int dt) {
+    const int bits = dtype_of(dt).bits;
+    if (bits >= 8) return numel * static_cast<size_t>(bits / 8);
+    const size_t per = 8 / bits;
+    return (numel + per - 1) / per;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        PQ_HIP(hipGetDevice(&prev));
+        if (prev != dev) PQ_HIP(hipSetDevice(dev));
+        else prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// Where a caller's buffer lives.
+struct Resolved {
+    bool pageable;     // plain host memory: must be staged through device scratch
+    void* dev;         // device-accessible address when !pageable
+};
+
+Resolved resolve(const void* p) {
+    hipPointerAttribute_t a {};
+    const hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();   // unknown to the runtime == ordinary host memory
+        return {true, nullptr};
+    }
+    switch (a.type) {
+        case hipMemoryTypeDevice:
+        case hipMemoryTypeManaged: return {false, const_cast<void*>(p)};
+        case hipMemoryTypeHost: return {false, a.devicePointer ? a.devicePointer : const_cast<void*>(p)};   // pinned: read over PCIe in place
+        default: return {true, nullptr};
+    }
+}
+
+}  // namespace
+}  // namespace pq
+
+using namespace pq;
+
+struct piquant_context_t {
+    int device = 0;
+    int num_cu = 256;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;          // stream work is enqueued on (own_stream unless the caller set one)
+    hipStream_t stage_stream[2] = {nullptr, nullptr};
+    bool blocking = true;
+
+    int32_t* d_keys = nullptr;             // 2 x int32 on the device
+    int32_t* h_keys = nullptr;             // pinned mirror
+
+    // device scratch for host-pointer calls, grown on demand
+    void* stage_in[2] = {nullptr, nullptr};
+    void* stage_out[2] = {nullptr, nullptr};
+    size_t stage_in_cap = 0, stage_out_cap = 0;
+
+    std::mt19937_64 rng;
+    float fixed_threshold = -1.0f;
+    bool per_element = false;
+    uint64_t elem_seed = 0, elem_base = 0;
+    std::mutex mu;
+
+    void ensure_stage(size_t in_bytes, size_t out_bytes) {
+        if (in_bytes > stage_in_cap) {
+            for (auto& p : stage_in) {
+                if (p) PQ_HIP(hipFree(p));
+                PQ_HIP(hipMalloc(&p, in_bytes));
+            }
+            stage_in_cap = in_bytes;
+        }
+        if (out_bytes > stage_out_cap) {
+            for (auto& p : stage_out) {
+                if (p) PQ_HIP(hipFree(p));
+                PQ_HIP(hipMalloc(&p, out_bytes));
+            }
+            stage_out_cap = out_bytes;
+        }
+        for (auto& s : stage_stream)
+            if (!s) PQ_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    }
+};
+
+namespace {
+
+// Host buffers are processed in chunks of this many elements: a multiple of every tile size and pack
+// factor, so chunk boundaries never split a packed byte or a 16-byte vector.
+constexpr size_t kStageChunkElems = size_t{1} << 24;
+
+float draw_threshold(piquant_context_t* ctx) {
+    if (ctx->fixed_threshold >= 0.0f) return ctx->fixed_threshold;
+    return std::uniform_real_distribution<float>{0.0f, 1.0f}(ctx->rng);   // reference src/piquant.cpp:199-200
+}
+
+}  // namespace
+
+extern "C" {
+
+piquant_context_t* piquant_context_create(size_t num_threads) {
+    (void)num_threads;   // sized the reference's CPU pool (src/piquant.cpp:178-181); the GPU grid replaces it
+    int count = 0;
+    const hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        panic("piquant_context_create: no HIP device available (%s) -- this library has no CPU path",
+              e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    auto* ctx = new piquant_context_t;
+    PQ_HIP(hipGetDevice(&ctx->device));
+    PQ_HIP(hipDeviceGetAttribute(&ctx->num_cu, hipDeviceAttributeMultiprocessorCount, ctx->device));
+    PQ_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    PQ_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_keys), 2 * sizeof(int32_t)));
+    PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_keys), 2 * sizeof(int32_t), hipHostMallocDefault));
+    std::random_device rd;
+    ctx->rng.seed((static_cast<uint64_t>(rd()) << 32) ^ rd());
+    return ctx;
+}
+
+void piquant_context_destroy(piquant_context_t* ctx) {
+    if (!ctx) return;
+    {
+        DeviceGuard g(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        for (auto& s : ctx->stage_stream)
+            if (s) (void)hipStreamDestroy(s);
+        for (auto& p : ctx->stage_in)
+            if (p) (void)hipFree(p);
+        for (auto& p : ctx->stage_out)
+            if (p) (void)hipFree(p);
+        if (ctx->d_keys) (void)hipFree(ctx->d_keys);
+        if (ctx->h_keys) (void)hipHostFree(ctx->h_keys);
+        if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    }
+    delete ctx;
+}
+
+void piquant_quantize(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out,
+                      size_t numel, float scale, int64_t zero_point, piquant_round_mode_t mode) {
+    if (!ctx) panic("piquant_quantize: context is NULL");
+    const dtype_row& dti = dtype_of(dtype_in);
+    const dtype_row& dto = dtype_of(dtype_out);
+    // reference src/piquant.cpp:288-289
+    if (dti.quant) panic("quantize: input dtype (%s) must be a dequantized type", dti.name);
+    if (!dto.quant) panic("quantize: output dtype (%s) must be a quantized type", dto.name);
+    if (mode != PIQUANT_NEAREST && mode != PIQUANT_STOCHASTIC) panic("quantize: invalid round mode %d", static_cast<int>(mode));
+    if (numel == 0) return;
+    if (!in || !out) panic("quantize: NULL buffer");
+
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+
+    QuantLaunch q {};
+    q.dt_in = dtype_in;
+    q.dt_out = dtype_out;
+    q.inv_scale = 1.0f / scale;                         // fp32 division on the host, as the reference (kernels_specialized.inl:42)
+    q.zero_point = zero_point;
+    if (mode == PIQUANT_NEAREST) q.round_mode = RM_NEAREST_FAST;
+    else if (ctx->per_element) {
+        q.round_mode = RM_STOCH_ELEM;
+        q.seed = ctx->elem_seed;
+        q.index_base = ctx->elem_base;
+    } else {
+        q.round_mode = RM_STOCH_CALL;
+        q.threshold = draw_threshold(ctx);              // one threshold per call (src/piquant.cpp:197-201)
+    }
+
+    const Resolved rin = resolve(in), rout = resolve(out);
+    if (!rin.pageable && !rout.pageable) {
+        q.in = rin.dev;
+        q.out = rout.dev;
+        q.numel = static_cast<int64_t>(numel);
+        launch_quantize(q, ctx->stream, ctx->num_cu);
+        if (ctx->blocking) PQ_HIP(hipStreamSynchronize(ctx->stream));
+        return;
+    }
+
+    // Host buffers: chunked H2D -> kernel -> D2H on two alternating streams (copy/compute overlap).
+    PQ_HIP(hipStreamSynchronize(ctx->stream));
+    const size_t chunk = std::min(numel, kStageChunkElems);
+    ctx->ensure_stage(rin.pageable ? span_bytes(chunk, dtype_in) : 0, rout.pageable ? span_bytes(chunk, dtype_out) : 0);
+    const uint64_t base0 = q.index_base;
+    int slot = 0;
+    for (size_t off = 0; off < numel; off += chunk, slot ^= 1) {
+        const size_t n = std::min(chunk, numel - off);
+        hipStream_t s = ctx->stage_stream[slot];
+        const size_t in_off = span_bytes(off, dtype_in), out_off = span_bytes(off, dtype_out);
+        if (rin.pageable) {
+            PQ_HIP(hipMemcpyAsync(ctx->stage_in[slot], static_cast<const char*>(in) + in_off, span_bytes(n, dtype_in), hipMemcpyHostToDevice, s));
+            q.in = ctx->stage_in[slot];
+        } else q.in = static_cast<const char*>(rin.dev) + in_off;
+        q.out = rout.pageable ? ctx->stage_out[slot] : static_cast<void*>(static_cast<char*>(rout.dev) + out_off);
+        q.numel = static_cast<int64_t>(n);
+        q.index_base = base0 + off;
+        launch_quantize(q, s, ctx->num_cu);
+        if (rout.pageable)
+            PQ_HIP(hipMemcpyAsync(static_cast<char*>(out) + out_off, ctx->stage_out[slot], span_bytes(n, dtype_out), hipMemcpyDeviceToHost, s));
+    }
+    for (auto& s : ctx->stage_stream) PQ_HIP(hipStreamSynchronize(s));
+}
+
+void piquant_dequantize(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out,
+                        size_t numel, float scale, int64_t zero_point, piquant_reduce_op_t op) {
+    if (!ctx) panic("piquant_dequantize: context is NULL");
+    const dtype_row& dti = dtype_of(dtype_in);
+    const dtype_row& dto = dtype_of(dtype_out);
+    // reference src/piquant.cpp:321-322
+    if (!dti.quant) panic("dequantize: input dtype (%s) must be a quantized type", dti.name);
+    if (dto.quant) panic("dequantize: output dtype (%s) must be a dequantized type", dto.name);
+    if (op != PIQUANT_REDUCE_OP_SET && op != PIQUANT_REDUCE_OP_ADD) panic("dequantize: invalid reduce op %d", static_cast<int>(op));
+    if (numel == 0) return;
+    if (!in || !out) panic("dequantize: NULL buffer");
+
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+
+    DequantLaunch d {};
+    d.dt_in = dtype_in;
+    d.dt_out = dtype_out;
+    d.op = op == PIQUANT_REDUCE_OP_ADD ? OP_ADD : OP_SET;
+    d.scale = scale;
+    d.zero_point = zero_point;
+    // fp32 product on the host exactly as the reference forms it (kernels_specialized.inl:1204,1325)
+    d.bias = -static_cast<float>(static_cast<int32_t>(static_cast<uint32_t>(static_cast<uint64_t>(zero_point)))) * scale;
+
+    const Resolved rin = resolve(in), rout = resolve(out);
+    if (!rin.pageable && !rout.pageable) {
+        d.in = rin.dev;
+        d.out = rout.dev;
+        d.numel = static_cast<int64_t>(numel);
+        launch_dequantize(d, ctx->stream, ctx->num_cu);
+        if (ctx->blocking) PQ_HIP(hipStreamSynchronize(ctx->stream));
+        return;
+    }
+
+    PQ_HIP(hipStreamSynchronize(ctx->stream));
+    const size_t chunk = std::min(numel, kStageChunkElems);
+    ctx->ensure_stage(rin.pageable ? span_bytes(chunk, dtype_in) : 0, rout.pageable ? span_bytes(chunk, dtype_out) : 0);
+    int slot = 0;
+    for (size_t off = 0; off < numel; off += chunk, slot ^= 1) {
+        const size_t n = std::min(chunk, numel - off);
+        hipStream_t s = ctx->stage_stream[slot];
+        const size_t in_off = span_bytes(off, dtype_in), out_off = span_bytes(off, dtype_out);
+        if (rin.pageable) {
+            PQ_HIP(hipMemcpyAsync(ctx->stage_in[slot], static_cast<const char*>(in) + in_off, span_bytes(n, dtype_in), hipMemcpyHostToDevice, s));
+            d.in = ctx->stage_in[slot];
+        } else d.in = static_cast<const char*>(rin.dev) + in_off;
+        if (rout.pageable) {
+            if (d.op == OP_ADD)   // the accumulator has to travel too
+                PQ_HIP(hipMemcpyAsync(ctx->stage_out[slot], static_cast<char*>(out) + out_off, span_bytes(n, dtype_out), hipMemcpyHostToDevice, s));
+            d.out = ctx->stage_out[slot];
+        } else d.out = static_cast<char*>(rout.dev) + out_off;
+        d.numel = static_cast<int64_t>(n);
+        launch_dequantize(d, s, ctx->num_cu);
+        if (rout.pageable)
+            PQ_HIP(hipMemcpyAsync(static_cast<char*>(out) + out_off, ctx->stage_out[slot], span_bytes(n, dtype_out), hipMemcpyDeviceToHost, s));
+    }
+    for (auto& s : ctx->stage_stream) PQ_HIP(hipStreamSynchronize(s));
+}
+
+void piquant_hip_minmax_keys(piquant_context_t* ctx, const void* x, piquant_dtype_t dtype, size_t n, int32_t* device_keys, int init) {
+    if (!ctx) panic("piquant_hip_minmax_keys: context is NULL");
+    if (dtype != PIQUANT_DTYPE_F32 && dtype != PIQUANT_DTYPE_BF16) panic("min/max scan needs f32 or bf16 input, got %s", dtype_of(dtype).name);
+    if (!device_keys) panic("piquant_hip_minmax_keys: NULL key buffer");
+    if (n != 0 && !x) panic("piquant_hip_minmax_keys: NULL input");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    // identity: key(+FLT_MAX) for min and for -max (reference kernels_specialized.inl:1422-1423)
+    if (init) PQ_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(device_keys), float_to_key(std::numeric_limits<float>::max()), 2, ctx->stream));
+    if (n == 0) return;
+    const Resolved r = resolve(x);
+    if (!r.pageable) {
+        launch_minmax(r.dev, dtype, static_cast<int64_t>(n), device_keys, ctx->stream, ctx->num_cu);
+        return;
+    }
+    // host input: stream it through device scratch, all chunks fold into the same two keys
+    PQ_HIP(hipStreamSynchronize(ctx->stream));
+    const size_t chunk = std::min(n, kStageChunkElems);
+    ctx->ensure_stage(span_bytes(chunk, dtype), 0);
+    int slot = 0;
+    for (size_t off = 0; off < n; off += chunk, slot ^= 1) {
+        const size_t m = std::min(chunk, n - off);
+        hipStream_t s = ctx->stage_stream[slot];
+        PQ_HIP(hipMemcpyAsync(ctx->stage_in[slot], static_cast<const char*>(x) + span_bytes(off, dtype), span_bytes(m, dtype), hipMemcpyHostToDevice, s));
+        launch_minmax(ctx->stage_in[slot], dtype, static_cast<int64_t>(m), device_keys, s, ctx->num_cu);
+    }
+    for (auto& s : ctx->stage_stream) PQ_HIP(hipStreamSynchronize(s));
+}
+
+void piquant_hip_decode_minmax_keys(const int32_t keys[2], float* out_min, float* out_max) {
+    *out_min = key_to_float(keys[0]);
+    *out_max = -key_to_float(keys[1]);
+}
+
+// reference src/piquant.cpp:213-220 (type max) and :245-258 (epilogue), all in double
+void piquant_hip_quant_params_from_minmax(float min, float max, piquant_dtype_t target_quant_dtype, float* out_scale, int64_t* out_zero_point) {
+    const dtype_row& dt = dtype_of(target_quant_dtype);
+    if (!dt.quant) panic("type %s is not a quantization type", dt.name);
+    const uint64_t type_max = (uint64_t{1} << dt.bits) - 1;
+    const int64_t type_min = 0;   // only unsigned quantized types exist
+    const double r_min = static_cast<double>(min), r_max = static_cast<double>(max);
+    if (r_max == r_min) {
+        *out_scale = 1.0f;
+        *out_zero_point = static_cast<int64_t>((type_max + static_cast<uint64_t>(type_min)) >> 1);
+        return;
+    }
+    const double q_min = static_cast<double>(type_min), q_max = static_cast<double>(type_max);
+    const double scale = (r_max - r_min) / (q_max - q_min);
+    double zp = q_min - r_min / scale;
+    zp = std::max(std::min(static_cast<double>(static_cast<int64_t>(std::round(zp))), q_max), q_min);
+    *out_scale = static_cast<float>(scale);
+    *out_zero_point = static_cast<int64_t>(zp);
+}
+
+static void compute_params(piquant_context_t* ctx, const void* x, piquant_dtype_t dt, size_t n, piquant_dtype_t target, float* out_scale,
+                           int64_t* out_zero_point) {
+    if (!ctx) panic("piquant_compute_quant_params: context is NULL");
+    if (!out_scale || !out_zero_point) panic("piquant_compute_quant_params: NULL result pointer");
+    if (!dtype_of(target).quant) panic("type %s is not a quantization type", dtype_of(target).name);
+    piquant_hip_minmax_keys(ctx, x, dt, n, ctx->d_keys, 1);
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        DeviceGuard guard(ctx->device);
+        PQ_HIP(hipMemcpyAsync(ctx->h_keys, ctx->d_keys, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        PQ_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    float lo, hi;
+    piquant_hip_decode_minmax_keys(ctx->h_keys, &lo, &hi);
+    piquant_hip_quant_params_from_minmax(lo, hi, target, out_scale, out_zero_point);
+    // reference src/piquant.cpp:373,379
+    if (std::isnan(*out_scale) || !(*out_scale >= 0.0f)) panic("compute_quant_params: scale must be positive (got %g)", static_cast<double>(*out_scale));
+}
+
+void piquant_compute_quant_params_float32(piquant_context_t* ctx, const float* x, size_t n, piquant_dtype_t target_quant_dtype, float* out_scale,
+                                          int64_t* out_zero_point) {
+    compute_params(ctx, x, PIQUANT_DTYPE_F32, n, target_quant_dtype, out_scale, out_zero_point);
+}
+
+void piquant_compute_quant_params_bfloat16(piquant_context_t* ctx, const uint16_t* x, size_t n, piquant_dtype_t target_quant_dtype,
+                                           float* out_scale, int64_t* out_zero_point) {
+    compute_params(ctx, x, PIQUANT_DTYPE_BF16, n, target_quant_dtype, out_scale, out_zero_point);
+}
+
+void piquant_hip_set_stream(piquant_context_t* ctx, void* hip_stream) {
+    if (!ctx) panic("piquant_hip_set_stream: context is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+}
+
+void piquant_hip_set_blocking(piquant_context_t* ctx, int blocking) {
+    if (!ctx) panic("piquant_hip_set_blocking: context is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->blocking = blocking != 0;
+}
+
+void piquant_hip_set_stochastic_threshold(piquant_context_t* ctx, float threshold) {
+    if (!ctx) panic("piquant_hip_set_stochastic_threshold: context is NULL");
+    if (threshold >= 1.0f || std::isnan(threshold)) panic("stochastic threshold must be < 1 (or negative to draw per call), got %g", static_cast<double>(threshold));
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->fixed_threshold = threshold;
+}
+
+void piquant_hip_set_stochastic_seed(piquant_context_t* ctx, uint64_t seed) {
+    if (!ctx) panic("piquant_hip_set_stochastic_seed: context is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->rng.seed(seed);
+}
+
+void piquant_hip_set_stochastic_per_element(piquant_context_t* ctx, int enabled, uint64_t seed, uint64_t index_base) {
+    if (!ctx) panic("piquant_hip_set_stochastic_per_element: context is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->per_element = enabled != 0;
+    ctx->elem_seed = seed;
+    ctx->elem_base = index_base;
+}
+
+int piquant_hip_device(const piquant_context_t* ctx) { return ctx ? ctx->device : -1; }
+
+const char* piquant_hip_version(void) { return "piquant-hip 0.1.0 gfx950"; }
+
+}  // extern "C"

@@ -1,0 +1,163 @@
+// Dequantize kernels for gfx950: uint8 / packed uint4 / packed uint2  ->  fp32 / bf16, SET or ADD store.
+//
+// Mirror image of quant_kernels.hpp, organised around the OUTPUT (the large side of the traffic): a wave
+// owns U*64 consecutive 16-byte output vectors (4 fp32 or 8 bf16 each).  Output vector (k, lane) needs
+// IB = 4,2,1 (fp32 out) or 8,4,2 (bf16 out) packed input bytes.  With STAGE the wave fetches its U*64*IB
+// input bytes with wide coalesced loads into its own LDS slice and every lane reads back the IB bytes it
+// needs; without STAGE each lane loads its IB bytes directly.  ADD reads the old output vector with the
+// same coalesced 16-byte access, adds in fp32 and (bf16) rounds once -- the reference's SIMD-body
+// behaviour (src/kernels/kernels_specialized.inl:753-758, 953-971, 1244-1284).
+#pragma once
+
+#include "quant_kernels.hpp"
+
+namespace pq {
+
+enum : int { OP_SET = 0, OP_ADD = 1 };
+
+template <int BITS, int DT_OUT>
+struct DequantForm {
+    static constexpr int value = DT_OUT == DT_F32 ? (BITS == 2 ? DQ_I64 : DQ_SUBMUL) : (BITS == 8 ? DQ_SUBMUL : DQ_FMA);
+};
+
+template <int BITS, int DT_OUT, int OP>
+__device__ __forceinline__ void dequant_store_scalar(const uint8_t* in, void* out, int64_t i, const DequantParams& p) {
+    constexpr int PACK = 8 / BITS;
+    constexpr int FORM = DequantForm<BITS, DT_OUT>::value;
+    const uint32_t q = (in[i / PACK] >> ((i % PACK) * BITS)) & ((1u << BITS) - 1u);
+    float f = dequant_one<FORM>(q, p);
+    if constexpr (DT_OUT == DT_F32) {
+        float* o = static_cast<float*>(out);
+        if constexpr (OP == OP_ADD) f = __fadd_rn(f, o[i]);
+        o[i] = f;
+    } else {
+        uint16_t* o = static_cast<uint16_t*>(out);
+        if constexpr (OP == OP_ADD) f = __fadd_rn(f, bf16_bits_to_f32(o[i]));
+        o[i] = static_cast<uint16_t>(f32_to_bf16_bits(f));
+    }
+}
+
+template <int BITS, int DT_OUT, int OP>
+__global__ void __launch_bounds__(256) dequantize_scalar_kernel(const uint8_t* in, void* out, int64_t numel, DequantParams p) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < numel; i += stride)
+        dequant_store_scalar<BITS, DT_OUT, OP>(in, out, i, p);
+}
+
+template <int BITS, int DT_OUT, int U, int BLOCK>
+struct DequantTile {
+    static constexpr int EPV = DT_OUT == DT_F32 ? 4 : 8;       // elements per 16-byte output vector
+    static constexpr int IB = EPV * BITS / 8;                  // packed input bytes per output vector
+    static constexpr int WAVES = BLOCK / 64;
+    static constexpr int WAVE_VECS = U * 64;
+    static constexpr int WAVE_IN_BYTES = WAVE_VECS * IB;
+    static constexpr int LANE_IN_BYTES = U * IB;
+    static constexpr int64_t BLOCK_ELEMS = static_cast<int64_t>(WAVES) * WAVE_VECS * EPV;
+};
+
+template <int BITS, int DT_OUT, int OP, int U, bool STAGE, bool NT, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int64_t n_tiles, DequantParams p) {
+    using T = DequantTile<BITS, DT_OUT, U, BLOCK>;
+    constexpr int EPV = T::EPV, IB = T::IB;
+    constexpr int WORDS = IB > 4 ? 2 : 1;
+    constexpr int FORM = DequantForm<BITS, DT_OUT>::value;
+
+    __shared__ __attribute__((aligned(16))) uint8_t lds[STAGE ? T::WAVES * T::WAVE_IN_BYTES : 16];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    u32x4* out16 = static_cast<u32x4*>(out);
+
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t v0 = (tile * T::WAVES + wave) * T::WAVE_VECS;     // first output vector of this wave tile
+        const uint8_t* src = in + v0 * IB;
+
+        u32x4 old[OP == OP_ADD ? U : 1];
+        if constexpr (OP == OP_ADD) {
+#pragma unroll
+            for (int k = 0; k < U; ++k) old[k] = ld<NT>(out16 + v0 + k * 64 + lane);
+        }
+
+        uint32_t w[U][WORDS];
+        if constexpr (!STAGE) {
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const uint8_t* s = src + static_cast<int64_t>(k * 64 + lane) * IB;
+                if constexpr (IB == 1) w[k][0] = ld<NT>(s);
+                else if constexpr (IB == 2) w[k][0] = ld<NT>(reinterpret_cast<const uint16_t*>(s));
+                else if constexpr (IB == 4) w[k][0] = ld<NT>(reinterpret_cast<const uint32_t*>(s));
+                else {
+                    const u32x2 t = ld<NT>(reinterpret_cast<const u32x2*>(s));
+                    w[k][0] = t[0];
+                    w[k][WORDS - 1] = t[1];
+                }
+            }
+        } else {
+            uint8_t* s = lds + wave * T::WAVE_IN_BYTES;
+            if constexpr (T::LANE_IN_BYTES >= 16) {
+#pragma unroll
+                for (int j = 0; j < T::LANE_IN_BYTES / 16; ++j)
+                    reinterpret_cast<u32x4*>(s)[j * 64 + lane] = ld<NT>(reinterpret_cast<const u32x4*>(src) + j * 64 + lane);
+            } else if constexpr (T::LANE_IN_BYTES == 8) {
+                reinterpret_cast<u32x2*>(s)[lane] = ld<NT>(reinterpret_cast<const u32x2*>(src) + lane);
+            } else if constexpr (T::LANE_IN_BYTES == 4) {
+                reinterpret_cast<uint32_t*>(s)[lane] = ld<NT>(reinterpret_cast<const uint32_t*>(src) + lane);
+            } else {
+                reinterpret_cast<uint16_t*>(s)[lane] = ld<NT>(reinterpret_cast<const uint16_t*>(src) + lane);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const uint8_t* r = s + (k * 64 + lane) * IB;
+                if constexpr (IB == 1) w[k][0] = *r;
+                else if constexpr (IB == 2) w[k][0] = *reinterpret_cast<const uint16_t*>(r);
+                else if constexpr (IB == 4) w[k][0] = *reinterpret_cast<const uint32_t*>(r);
+                else {
+                    const u32x2 t = *reinterpret_cast<const u32x2*>(r);
+                    w[k][0] = t[0];
+                    w[k][WORDS - 1] = t[1];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            float f[EPV];
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                const uint32_t q = (w[k][(e * BITS) >> 5] >> ((e * BITS) & 31)) & ((1u << BITS) - 1u);
+                f[e] = dequant_one<FORM>(q, p);
+            }
+            u32x4 r;
+            if constexpr (DT_OUT == DT_F32) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if constexpr (OP == OP_ADD) f[e] = __fadd_rn(f[e], __uint_as_float(old[k][e]));
+                    r[e] = __float_as_uint(f[e]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if constexpr (OP == OP_ADD) {
+                        f[2 * e] = __fadd_rn(f[2 * e], __uint_as_float(old[k][e] << 16));
+                        f[2 * e + 1] = __fadd_rn(f[2 * e + 1], __uint_as_float(old[k][e] & 0xffff0000u));
+                    }
+                    r[e] = f32_to_bf16_bits(f[2 * e]) | (f32_to_bf16_bits(f[2 * e + 1]) << 16);
+                }
+            }
+            st<NT>(out16 + v0 + k * 64 + lane, r);
+        }
+    }
+
+    const int64_t done = n_tiles * T::BLOCK_ELEMS;
+    if (done < numel && blockIdx.x == gridDim.x - 1) {
+        for (int64_t i = done + threadIdx.x; i < numel; i += BLOCK) dequant_store_scalar<BITS, DT_OUT, OP>(in, out, i, p);
+    }
+}
+
+}  // namespace pq

@@ -1,0 +1,157 @@
+// Per-element arithmetic of the quantize / dequantize path, written for gfx950 VALU.
+//
+// Every function states which reference lines define the bit pattern it must reproduce.  Products and
+// sums that the reference rounds separately use __fmul_rn/__fadd_rn so the compiler can never contract
+// them into an FMA (hipcc defaults to -ffp-contract=fast); the one place the reference itself uses an FMA
+// (uint4/uint2 -> bf16) uses __fmaf_rn.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pq {
+
+enum : int { DT_F32 = 0, DT_BF16 = 1, DT_UINT2 = 2, DT_UINT4 = 3, DT_UINT8 = 4 };
+
+// How a float is turned into a quantized integer.
+//   RM_NEAREST_FAST : the reference's SIMD fast-path formula, trunc(p + copysign-ish 0.5) in int32
+//   RM_NEAREST_I64  : the reference's generic scalar formula, std::round in int64 (only f32 -> uint2 has no fast path)
+//   RM_STOCH_CALL   : stochastic, one threshold per call (the reference's behaviour)
+//   RM_STOCH_ELEM   : stochastic, counter-hash threshold per element (extension)
+enum : int { RM_NEAREST_FAST = 0, RM_NEAREST_I64 = 1, RM_STOCH_CALL = 2, RM_STOCH_ELEM = 3 };
+
+struct QuantParams {
+    float inv_scale;      // 1.0f / scale, divided on the host in fp32 (kernels_specialized.inl:42, quantize.inl:129)
+    int32_t zp32;         // zero point narrowed to int32 as at the fast-path call sites (quantize.inl:111)
+    int64_t zp64;         // zero point as passed (generic + stochastic paths keep int64, quantize.inl:15,24)
+    float threshold;      // RM_STOCH_CALL
+    uint32_t seed_lo;     // RM_STOCH_ELEM
+    uint32_t seed_hi;
+    uint64_t index_base;  // RM_STOCH_ELEM: global index of element 0 of this launch
+};
+
+struct DequantParams {
+    float scale;
+    float bias;           // -(float)zp32 * scale, multiplied on the host (kernels_specialized.inl:1204,1325)
+    int32_t zp32;
+    int64_t zp64;
+};
+
+// bf16 <-> f32: include/piquant.hpp:86-95
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+    const uint32_t u = __float_as_uint(f);
+    const uint32_t rne = (u + (0x7fffu + ((u >> 16) & 1u))) >> 16;
+    const uint32_t qnan = (u >> 16) | 64u;
+    return ((u & 0x7fffffffu) > 0x7f800000u) ? qnan : rne;
+}
+
+// x86 cvttps2dq: truncate; NaN and anything outside [-2^31, 2^31) give INT32_MIN.  The float is clamped
+// into range before the conversion so the fptosi is always defined.
+__device__ __forceinline__ int32_t cvtt_i32_x86(float a) {
+    const float c = __builtin_fminf(__builtin_fmaxf(a, -2147483648.0f), 2147483520.0f);   // NaN -> -2^31
+    const int32_t t = static_cast<int32_t>(c);
+    return (a >= -2147483648.0f && a < 2147483648.0f) ? t : INT32_MIN;
+}
+
+// x86 cvttss2si r64, same convention with INT64_MIN.  r is integral-valued or small here; the wide
+// conversion only runs for |r| >= 2^31 (wave-uniformly skipped on sane data).
+__device__ __forceinline__ int64_t cvtt_i64_x86(float r) {
+    if (__builtin_fabsf(r) < 2147483648.0f) return static_cast<int64_t>(static_cast<int32_t>(r));
+    if (r >= -9223372036854775808.0f && r < 9223372036854775808.0f) return static_cast<int64_t>(r);
+    return INT64_MIN;
+}
+
+__device__ __forceinline__ uint32_t clamp_i64(int64_t v, int32_t qmax) {
+    return static_cast<uint32_t>(v < 0 ? 0 : (v > qmax ? qmax : v));
+}
+
+// kernels_specialized.inl:62-77 (and the same shape at :207-222, :347-361, :514-528, :682-693)
+template <int QMAX>
+__device__ __forceinline__ uint32_t quant_nearest_fast(float x, const QuantParams& p) {
+    const float prod = __fmul_rn(x, p.inv_scale);
+    const float adj = __fadd_rn(prod, prod >= 0.0f ? 0.5f : -0.5f);
+    const int32_t q = static_cast<int32_t>(static_cast<uint32_t>(cvtt_i32_x86(adj)) + static_cast<uint32_t>(p.zp32));
+    return static_cast<uint32_t>(min(max(q, 0), QMAX));   // v_med3_i32
+}
+
+// quantize.inl:21-26
+template <int QMAX>
+__device__ __forceinline__ uint32_t quant_nearest_i64(float x, const QuantParams& p) {
+    const float r = roundf(__fmul_rn(x, p.inv_scale));
+    const int64_t v = static_cast<int64_t>(static_cast<uint64_t>(cvtt_i64_x86(r)) + static_cast<uint64_t>(p.zp64));
+    return clamp_i64(v, QMAX);
+}
+
+// quantize.inl:8-19
+template <int QMAX>
+__device__ __forceinline__ uint32_t quant_stochastic(float x, const QuantParams& p, float threshold) {
+    const float r = __fmul_rn(x, p.inv_scale);
+    const float tr = truncf(r);
+    const float dec = __builtin_fabsf(__fsub_rn(r, tr));
+    float adj = threshold < dec ? 1.0f : 0.0f;
+    if (r < 0.0f) adj = -adj;
+    const float s = __fadd_rn(tr, adj);
+    const int64_t v = static_cast<int64_t>(static_cast<uint64_t>(cvtt_i64_x86(s)) + static_cast<uint64_t>(p.zp64));
+    return clamp_i64(v, QMAX);
+}
+
+// Counter hash for RM_STOCH_ELEM (extension; restated in oracle/piquant_oracle.c orc_element_threshold).
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x21f0aaadu;
+    h ^= h >> 15;
+    h *= 0x735a2d97u;
+    h ^= h >> 15;
+    return h;
+}
+
+__device__ __forceinline__ float element_threshold(const QuantParams& p, uint64_t idx) {
+    const uint32_t key = mix32(static_cast<uint32_t>(idx >> 32) ^ p.seed_hi) + p.seed_lo;
+    const uint32_t h = mix32(static_cast<uint32_t>(idx) ^ key);
+    return static_cast<float>(h >> 8) * (1.0f / 16777216.0f);
+}
+
+template <int MODE, int QMAX>
+__device__ __forceinline__ uint32_t quant_one(float x, const QuantParams& p, uint64_t elem_index) {
+    if constexpr (MODE == RM_NEAREST_FAST) return quant_nearest_fast<QMAX>(x, p);
+    else if constexpr (MODE == RM_NEAREST_I64) return quant_nearest_i64<QMAX>(x, p);
+    else if constexpr (MODE == RM_STOCH_CALL) return quant_stochastic<QMAX>(x, p, p.threshold);
+    else return quant_stochastic<QMAX>(x, p, element_threshold(p, p.index_base + elem_index));
+}
+
+// Dequantization forms.
+//   DQ_SUBMUL : float(int32(q) - zp32) * scale       u8->f32 :745-752, u4->f32 :1031-1045, u8->bf16 :945-952
+//   DQ_FMA    : fma(float(q), scale, -float(zp)*scale) u4->bf16 :1236-1243, u2->bf16 :1361
+//   DQ_I64    : float(int64(q) - zp64) * scale        u2->f32, generic dequantize.inl:8-11
+enum : int { DQ_SUBMUL = 0, DQ_FMA = 1, DQ_I64 = 2 };
+
+template <int FORM>
+__device__ __forceinline__ float dequant_one(uint32_t q, const DequantParams& p) {
+    if constexpr (FORM == DQ_SUBMUL) {
+        const int32_t d = static_cast<int32_t>(q - static_cast<uint32_t>(p.zp32));
+        return __fmul_rn(static_cast<float>(d), p.scale);
+    } else if constexpr (FORM == DQ_FMA) {
+        return __fmaf_rn(static_cast<float>(q), p.scale, p.bias);
+    } else {
+        const int64_t d = static_cast<int64_t>(static_cast<uint64_t>(q) - static_cast<uint64_t>(p.zp64));
+        return __fmul_rn(static_cast<float>(d), p.scale);
+    }
+}
+
+// Order-preserving float <-> int32 key (signed compare of keys == numeric compare of floats).
+__device__ __host__ __forceinline__ int32_t float_to_key(float f) {
+    int32_t b;
+    __builtin_memcpy(&b, &f, 4);
+    return b >= 0 ? b : (b ^ 0x7fffffff);
+}
+
+__device__ __host__ __forceinline__ float key_to_float(int32_t k) {
+    const int32_t b = k >= 0 ? k : (k ^ 0x7fffffff);
+    float f;
+    __builtin_memcpy(&f, &b, 4);
+    return f;
+}
+
+}  // namespace pq

@@ -1,0 +1,164 @@
+// Instantiation and launch of the gfx950 kernels.  Replaces the reference's kernel dispatch tables
+// (src/kernels/kernels.inl:108-173): the same legality matrix -- float -> quantized for quantize,
+// quantized -> float for dequantize, 12 + 12 combinations -- selects a template instance here.
+#include "launch.hpp"
+
+#include "dequant_kernels.hpp"
+#include "minmax_kernels.hpp"
+#include "quant_kernels.hpp"
+#include "tuning.hpp"
+
+#include <algorithm>
+
+namespace pq {
+
+namespace {
+
+constexpr int bits_index(int bits) { return bits == 8 ? 0 : (bits == 4 ? 1 : 2); }
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+inline unsigned capped_grid(int64_t want, int blocks_per_cu, int num_cu) {
+    int64_t g = want;
+    if (blocks_per_cu > 0) g = std::min<int64_t>(g, static_cast<int64_t>(blocks_per_cu) * num_cu);
+    g = std::min<int64_t>(g, 0x7fffffff);
+    return static_cast<unsigned>(std::max<int64_t>(g, 1));
+}
+
+template <int DT_IN, int BITS, int MODE>
+void quantize_t(const QuantLaunch& q, const QuantParams& p, hipStream_t stream, int num_cu) {
+    constexpr KernelTune t = kQuantTune[DT_IN][bits_index(BITS)];
+    using Tile = QuantTile<DT_IN, BITS, t.u, kBlock>;
+    uint8_t* out = static_cast<uint8_t*>(q.out);
+    if (!aligned16(q.in) || !aligned16(q.out)) {
+        constexpr int PACK = 8 / BITS;
+        const int64_t nbytes = (q.numel + PACK - 1) / PACK;
+        const unsigned grid = capped_grid((nbytes + kBlock - 1) / kBlock, 16, num_cu);
+        hipLaunchKernelGGL((quantize_scalar_kernel<DT_IN, BITS, MODE>), dim3(grid), dim3(kBlock), 0, stream, q.in, out, q.numel, p);
+        return;
+    }
+    const int64_t n_tiles = q.numel / Tile::BLOCK_ELEMS;
+    const unsigned grid = capped_grid(n_tiles, t.blocks_per_cu, num_cu);
+    hipLaunchKernelGGL((quantize_kernel<DT_IN, BITS, MODE, t.u, t.stage, t.nt, kBlock>), dim3(grid), dim3(kBlock), 0, stream,
+                       q.in, out, q.numel, n_tiles, p);
+}
+
+template <int DT_IN, int BITS>
+void quantize_mode(const QuantLaunch& q, const QuantParams& p, hipStream_t stream, int num_cu) {
+    switch (q.round_mode) {
+        case RM_NEAREST_FAST:
+        case RM_NEAREST_I64:
+            // f32 -> uint2 is the one nearest pair without a SIMD fast path in the reference (quantize.inl:105-127)
+            if constexpr (DT_IN == DT_F32 && BITS == 2) quantize_t<DT_IN, BITS, RM_NEAREST_I64>(q, p, stream, num_cu);
+            else quantize_t<DT_IN, BITS, RM_NEAREST_FAST>(q, p, stream, num_cu);
+            return;
+        case RM_STOCH_CALL: quantize_t<DT_IN, BITS, RM_STOCH_CALL>(q, p, stream, num_cu); return;
+        case RM_STOCH_ELEM: quantize_t<DT_IN, BITS, RM_STOCH_ELEM>(q, p, stream, num_cu); return;
+        default: panic("invalid rounding mode %d", q.round_mode);
+    }
+}
+
+template <int DT_IN>
+void quantize_bits(const QuantLaunch& q, const QuantParams& p, hipStream_t stream, int num_cu) {
+    switch (q.dt_out) {
+        case DT_UINT8: quantize_mode<DT_IN, 8>(q, p, stream, num_cu); return;
+        case DT_UINT4: quantize_mode<DT_IN, 4>(q, p, stream, num_cu); return;
+        case DT_UINT2: quantize_mode<DT_IN, 2>(q, p, stream, num_cu); return;
+        default: panic("invalid quantization types: %d -> %d", q.dt_in, q.dt_out);
+    }
+}
+
+template <int BITS, int DT_OUT, int OP>
+void dequantize_t(const DequantLaunch& d, const DequantParams& p, hipStream_t stream, int num_cu) {
+    constexpr KernelTune t = kDequantTune[DT_OUT][bits_index(BITS)];
+    using Tile = DequantTile<BITS, DT_OUT, t.u, kBlock>;
+    const uint8_t* in = static_cast<const uint8_t*>(d.in);
+    if (!aligned16(d.in) || !aligned16(d.out)) {
+        const unsigned grid = capped_grid((d.numel + kBlock - 1) / kBlock, 16, num_cu);
+        hipLaunchKernelGGL((dequantize_scalar_kernel<BITS, DT_OUT, OP>), dim3(grid), dim3(kBlock), 0, stream, in, d.out, d.numel, p);
+        return;
+    }
+    const int64_t n_tiles = d.numel / Tile::BLOCK_ELEMS;
+    const unsigned grid = capped_grid(n_tiles, t.blocks_per_cu, num_cu);
+    hipLaunchKernelGGL((dequantize_kernel<BITS, DT_OUT, OP, t.u, t.stage, t.nt, kBlock>), dim3(grid), dim3(kBlock), 0, stream, in,
+                       d.out, d.numel, n_tiles, p);
+}
+
+template <int BITS, int DT_OUT>
+void dequantize_op(const DequantLaunch& d, const DequantParams& p, hipStream_t stream, int num_cu) {
+    switch (d.op) {
+        case OP_SET: dequantize_t<BITS, DT_OUT, OP_SET>(d, p, stream, num_cu); return;
+        case OP_ADD: dequantize_t<BITS, DT_OUT, OP_ADD>(d, p, stream, num_cu); return;
+        default: panic("invalid reduce op %d", d.op);
+    }
+}
+
+template <int BITS>
+void dequantize_out(const DequantLaunch& d, const DequantParams& p, hipStream_t stream, int num_cu) {
+    switch (d.dt_out) {
+        case DT_F32: dequantize_op<BITS, DT_F32>(d, p, stream, num_cu); return;
+        case DT_BF16: dequantize_op<BITS, DT_BF16>(d, p, stream, num_cu); return;
+        default: panic("invalid dequantization types: %d -> %d", d.dt_in, d.dt_out);
+    }
+}
+
+template <int DT_IN>
+void minmax_t(const void* in, int64_t numel, int32_t* keys, hipStream_t stream, int num_cu) {
+    constexpr int EPV = InVec<DT_IN>::EPV;
+    if (!aligned16(in)) {
+        const unsigned grid = capped_grid((numel + kBlock - 1) / kBlock, kMinmaxBlocksPerCU, num_cu);
+        hipLaunchKernelGGL((minmax_scalar_kernel<DT_IN, kBlock>), dim3(grid), dim3(kBlock), 0, stream, in, numel, keys);
+        return;
+    }
+    const int64_t per_block = static_cast<int64_t>(kBlock) * kMinmaxU * EPV;
+    const unsigned grid = capped_grid((numel + per_block - 1) / per_block, kMinmaxBlocksPerCU, num_cu);
+    hipLaunchKernelGGL((minmax_kernel<DT_IN, kMinmaxU, kMinmaxNT, kBlock>), dim3(grid), dim3(kBlock), 0, stream, in, numel, keys);
+}
+
+}  // namespace
+
+void launch_quantize(const QuantLaunch& q, hipStream_t stream, int num_cu) {
+    if (q.numel <= 0) return;
+    QuantParams p {};
+    p.inv_scale = q.inv_scale;
+    p.zp64 = q.zero_point;
+    p.zp32 = static_cast<int32_t>(static_cast<uint32_t>(static_cast<uint64_t>(q.zero_point)));
+    p.threshold = q.threshold;
+    p.seed_lo = static_cast<uint32_t>(q.seed);
+    p.seed_hi = static_cast<uint32_t>(q.seed >> 32);
+    p.index_base = q.index_base;
+    switch (q.dt_in) {
+        case DT_F32: quantize_bits<DT_F32>(q, p, stream, num_cu); break;
+        case DT_BF16: quantize_bits<DT_BF16>(q, p, stream, num_cu); break;
+        default: panic("invalid quantization types: %d -> %d", q.dt_in, q.dt_out);
+    }
+    PQ_HIP(hipGetLastError());
+}
+
+void launch_dequantize(const DequantLaunch& d, hipStream_t stream, int num_cu) {
+    if (d.numel <= 0) return;
+    DequantParams p {};
+    p.scale = d.scale;
+    p.bias = d.bias;
+    p.zp64 = d.zero_point;
+    p.zp32 = static_cast<int32_t>(static_cast<uint32_t>(static_cast<uint64_t>(d.zero_point)));
+    switch (d.dt_in) {
+        case DT_UINT8: dequantize_out<8>(d, p, stream, num_cu); break;
+        case DT_UINT4: dequantize_out<4>(d, p, stream, num_cu); break;
+        case DT_UINT2: dequantize_out<2>(d, p, stream, num_cu); break;
+        default: panic("invalid dequantization types: %d -> %d", d.dt_in, d.dt_out);
+    }
+    PQ_HIP(hipGetLastError());
+}
+
+void launch_minmax(const void* in, int dt_in, int64_t numel, int32_t* device_keys, hipStream_t stream, int num_cu) {
+    if (numel <= 0) return;
+    switch (dt_in) {
+        case DT_F32: minmax_t<DT_F32>(in, numel, device_keys, stream, num_cu); break;
+        case DT_BF16: minmax_t<DT_BF16>(in, numel, device_keys, stream, num_cu); break;
+        default: panic("min/max scan needs a float dtype, got %d", dt_in);
+    }
+    PQ_HIP(hipGetLastError());
+}
+
+}  // namespace pq

@@ -1,0 +1,46 @@
+// Host-visible launch interface of the HIP kernels (implemented in kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+namespace pq {
+
+struct QuantLaunch {
+    const void* in;        // device-accessible
+    void* out;             // device-accessible
+    int64_t numel;
+    int dt_in;             // DT_F32 / DT_BF16
+    int dt_out;            // DT_UINT2/4/8
+    int round_mode;        // RM_* (device_math.hpp)
+    float inv_scale;
+    int64_t zero_point;
+    float threshold;
+    uint64_t seed;
+    uint64_t index_base;
+};
+
+struct DequantLaunch {
+    const void* in;
+    void* out;
+    int64_t numel;
+    int dt_in;             // DT_UINT2/4/8
+    int dt_out;            // DT_F32 / DT_BF16
+    int op;                // OP_SET / OP_ADD
+    float scale;
+    float bias;
+    int64_t zero_point;
+};
+
+// All launches are asynchronous on `stream`; num_cu sizes capped grids.
+void launch_quantize(const QuantLaunch& q, hipStream_t stream, int num_cu);
+void launch_dequantize(const DequantLaunch& d, hipStream_t stream, int num_cu);
+void launch_minmax(const void* in, int dt_in, int64_t numel, int32_t* device_keys, hipStream_t stream, int num_cu);
+
+// Aborts with the reference's panic convention (red message on stderr, abort()) on a HIP error.
+void check_hip(hipError_t e, const char* what, const char* file, int line);
+[[noreturn]] void panic(const char* fmt, ...);
+
+#define PQ_HIP(expr) ::pq::check_hip((expr), #expr, __FILE__, __LINE__)
+
+}  // namespace pq

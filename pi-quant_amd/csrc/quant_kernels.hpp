@@ -1,0 +1,184 @@
+// Quantize kernels for gfx950: fp32 / bf16  ->  uint8 / packed uint4 / packed uint2.
+//
+// Data layout in HBM: the input is a flat, contiguous array; the output is the flat packed byte array
+// the reference defines (src/kernels/quantize.inl:36-50: lower element index in the lower bits).
+//
+// Work decomposition ("wave tiles"): a wave owns U*64 consecutive 16-byte input vectors (U KiB).
+// Load k of lane l reads vector (tile_base + k*64 + l): every wave-instruction is one fully coalesced
+// 1 KiB global_load_dwordx4, and U of them are in flight per lane before the first use.  A 16-byte input
+// vector yields OB = 4,2,1 (fp32 -> u8,u4,u2) or 8,4,2 (bf16) packed output bytes, so the natural per-lane
+// store would be narrow.  With STAGE the wave transposes its U*64*OB output bytes through its own LDS slice
+// (no block barrier: same-wave DS operations execute in order) so that each lane stores 16 contiguous
+// bytes (global_store_dwordx4, 1 KiB per wave-instruction) -- the "LDS-staged int4 packing" of the design.
+// Without STAGE each lane stores its OB bytes directly (still contiguous across the wave).
+//
+// The kernel is a grid-stride loop over block tiles (WAVES wave tiles); the ragged tail (numel not a
+// multiple of the block tile) is finished by the last block with a guarded per-byte path inside the SAME
+// launch, so a call is always exactly one kernel (a second launch would cost ~1.5 us on a ~20 us kernel).
+#pragma once
+
+#include "device_math.hpp"
+
+namespace pq {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+template <bool NT, typename T>
+__device__ __forceinline__ T ld(const T* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+
+template <bool NT, typename T>
+__device__ __forceinline__ void st(T* p, T v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+template <int DT_IN>
+struct InVec {
+    static constexpr int EPV = DT_IN == DT_F32 ? 4 : 8;   // elements per 16-byte vector
+    static __device__ __forceinline__ void unpack(const u32x4& raw, float (&v)[EPV]) {
+        if constexpr (DT_IN == DT_F32) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __uint_as_float(raw[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[2 * e] = __uint_as_float(raw[e] << 16);               // low half = lower index
+                v[2 * e + 1] = __uint_as_float(raw[e] & 0xffff0000u);
+            }
+        }
+    }
+    static __device__ __forceinline__ float load_scalar(const void* in, int64_t i) {
+        if constexpr (DT_IN == DT_F32) return static_cast<const float*>(in)[i];
+        else return bf16_bits_to_f32(static_cast<const uint16_t*>(in)[i]);
+    }
+};
+
+// Guarded path: one output byte per iteration, any alignment, any numel.  Used for the ragged tail of the
+// vector kernel and, through quantize_scalar_kernel, for misaligned buffers.
+template <int DT_IN, int BITS, int MODE>
+__device__ __forceinline__ void quantize_bytes_guarded(const void* in, uint8_t* out, int64_t numel, int64_t byte_begin,
+                                                       int64_t byte_end, const QuantParams& p, int64_t tid,
+                                                       int64_t nthreads) {
+    constexpr int PACK = 8 / BITS;
+    constexpr int QMAX = (1 << BITS) - 1;
+    for (int64_t b = byte_begin + tid; b < byte_end; b += nthreads) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < PACK; ++k) {
+            const int64_t i = b * PACK + k;
+            if (i < numel) acc |= quant_one<MODE, QMAX>(InVec<DT_IN>::load_scalar(in, i), p, static_cast<uint64_t>(i)) << (k * BITS);
+        }
+        out[b] = static_cast<uint8_t>(acc);
+    }
+}
+
+template <int DT_IN, int BITS, int MODE>
+__global__ void __launch_bounds__(256) quantize_scalar_kernel(const void* in, uint8_t* out, int64_t numel, QuantParams p) {
+    constexpr int PACK = 8 / BITS;
+    const int64_t nbytes = (numel + PACK - 1) / PACK;
+    quantize_bytes_guarded<DT_IN, BITS, MODE>(in, out, numel, 0, nbytes, p,
+                                              static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x,
+                                              static_cast<int64_t>(gridDim.x) * blockDim.x);
+}
+
+template <int DT_IN, int BITS, int U, int BLOCK>
+struct QuantTile {
+    static constexpr int EPV = InVec<DT_IN>::EPV;
+    static constexpr int OB = EPV * BITS / 8;                   // packed bytes per input vector
+    static constexpr int WAVES = BLOCK / 64;
+    static constexpr int WAVE_VECS = U * 64;
+    static constexpr int WAVE_OUT_BYTES = WAVE_VECS * OB;
+    static constexpr int LANE_OUT_BYTES = U * OB;
+    static constexpr int64_t BLOCK_ELEMS = static_cast<int64_t>(WAVES) * WAVE_VECS * EPV;
+};
+
+template <int DT_IN, int BITS, int MODE, int U, bool STAGE, bool NT, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t numel, int64_t n_tiles, QuantParams p) {
+    using T = QuantTile<DT_IN, BITS, U, BLOCK>;
+    constexpr int EPV = T::EPV, OB = T::OB, QMAX = (1 << BITS) - 1;
+    constexpr int WORDS = OB > 4 ? 2 : 1;
+
+    __shared__ __attribute__((aligned(16))) uint8_t lds[STAGE ? T::WAVES * T::WAVE_OUT_BYTES : 16];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const u32x4* __restrict__ in16 = static_cast<const u32x4*>(in);
+
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t v0 = (tile * T::WAVES + wave) * T::WAVE_VECS;   // first input vector of this wave tile
+
+        u32x4 raw[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) raw[k] = ld<NT>(in16 + v0 + k * 64 + lane);
+
+        uint32_t w[U][WORDS];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            float v[EPV];
+            InVec<DT_IN>::unpack(raw[k], v);
+#pragma unroll
+            for (int j = 0; j < WORDS; ++j) w[k][j] = 0;
+            const uint64_t e0 = static_cast<uint64_t>(v0 + k * 64 + lane) * EPV;
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                const uint32_t q = quant_one<MODE, QMAX>(v[e], p, e0 + e);
+                w[k][(e * BITS) >> 5] |= q << ((e * BITS) & 31);
+            }
+        }
+
+        uint8_t* o = out + v0 * OB;                                    // output of this wave tile
+        if constexpr (!STAGE) {
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                uint8_t* dst = o + static_cast<int64_t>(k * 64 + lane) * OB;
+                if constexpr (OB == 1) st<NT>(dst, static_cast<uint8_t>(w[k][0]));
+                else if constexpr (OB == 2) st<NT>(reinterpret_cast<uint16_t*>(dst), static_cast<uint16_t>(w[k][0]));
+                else if constexpr (OB == 4) st<NT>(reinterpret_cast<uint32_t*>(dst), w[k][0]);
+                else st<NT>(reinterpret_cast<u32x2*>(dst), u32x2{w[k][0], w[k][1]});
+            }
+        } else {
+            uint8_t* s = lds + wave * T::WAVE_OUT_BYTES;
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                uint8_t* dst = s + (k * 64 + lane) * OB;
+                if constexpr (OB == 1) *dst = static_cast<uint8_t>(w[k][0]);
+                else if constexpr (OB == 2) *reinterpret_cast<uint16_t*>(dst) = static_cast<uint16_t>(w[k][0]);
+                else if constexpr (OB == 4) *reinterpret_cast<uint32_t*>(dst) = w[k][0];
+                else *reinterpret_cast<u32x2*>(dst) = u32x2{w[k][0], w[k][1]};
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if constexpr (T::LANE_OUT_BYTES >= 16) {
+#pragma unroll
+                for (int j = 0; j < T::LANE_OUT_BYTES / 16; ++j) {
+                    const u32x4 r = reinterpret_cast<const u32x4*>(s)[j * 64 + lane];
+                    st<NT>(reinterpret_cast<u32x4*>(o) + j * 64 + lane, r);
+                }
+            } else if constexpr (T::LANE_OUT_BYTES == 8) {
+                st<NT>(reinterpret_cast<u32x2*>(o) + lane, reinterpret_cast<const u32x2*>(s)[lane]);
+            } else if constexpr (T::LANE_OUT_BYTES == 4) {
+                st<NT>(reinterpret_cast<uint32_t*>(o) + lane, reinterpret_cast<const uint32_t*>(s)[lane]);
+            } else {
+                st<NT>(reinterpret_cast<uint16_t*>(o) + lane, reinterpret_cast<const uint16_t*>(s)[lane]);
+            }
+            // the next iteration's LDS writes must not pass this iteration's reads
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+
+    // ragged tail, finished by the last block of the same launch
+    const int64_t done = n_tiles * T::BLOCK_ELEMS;
+    if (done < numel && blockIdx.x == gridDim.x - 1) {
+        constexpr int PACK = 8 / BITS;
+        quantize_bytes_guarded<DT_IN, BITS, MODE>(in, out, numel, done / PACK, (numel + PACK - 1) / PACK, p, threadIdx.x, BLOCK);
+    }
+}
+
+}  // namespace pq

@@ -1,0 +1,186 @@
+"""piquant -- MI355X-native drop-in for pi-quant's Python package.
+
+Same public names as the reference package (reference ``python/src/piquant/__init__.py:20-142``):
+``RoundMode``, ``ReduceOp``, ``DataType``, ``Context`` with ``quantize_ptr`` / ``dequantize_ptr`` /
+``compute_quant_params_ptr_float32`` / ``compute_quant_params_ptr_bfloat16``, and the ``piquant.torch``
+module.  Behind it every call lands in hand-written HIP kernels through the C ABI of ``libpiquant.so``.
+Pointers may be device pointers (PyTorch-ROCm ``tensor.data_ptr()``) or host pointers (staged over PCIe).
+"""
+from __future__ import annotations
+
+__version__ = '0.1.0'
+
+import ctypes as _C
+import importlib.util
+import weakref
+from enum import Enum, unique
+from typing import Dict, Optional, Tuple, Union
+
+from . import _bootstrap as _b
+from ._bootstrap import C_LIB as C
+
+
+@unique
+class RoundMode(Enum):
+    NEAREST = _b.PIQUANT_NEAREST
+    STOCHASTIC = _b.PIQUANT_STOCHASTIC
+
+
+@unique
+class ReduceOp(Enum):
+    SET = _b.PIQUANT_REDUCE_OP_SET
+    ADD = _b.PIQUANT_REDUCE_OP_ADD
+
+
+@unique
+class DataType(Enum):
+    F32 = _b.PIQUANT_DTYPE_F32
+    BF16 = _b.PIQUANT_DTYPE_BF16
+    UINT2 = _b.PIQUANT_DTYPE_UINT2
+    UINT4 = _b.PIQUANT_DTYPE_UINT4
+    UINT8 = _b.PIQUANT_DTYPE_UINT8
+
+    @property
+    def bit_size(self) -> int:
+        return {DataType.F32: 32, DataType.BF16: 16, DataType.UINT2: 2, DataType.UINT4: 4, DataType.UINT8: 8}[self]
+
+    @property
+    def is_quantized(self) -> bool:
+        return self in (DataType.UINT2, DataType.UINT4, DataType.UINT8)
+
+    @property
+    def is_dequantized(self) -> bool:
+        return self in (DataType.F32, DataType.BF16)
+
+    @property
+    def stride(self) -> int:
+        """Bytes per storage unit (packed types live in bytes)."""
+        return max(8, self.bit_size) >> 3
+
+    def packed_nbytes(self, numel: int) -> int:
+        """Bytes that hold ``numel`` elements (reference src/piquant_internal.hpp:41-44)."""
+        if self.bit_size >= 8:
+            return numel * (self.bit_size >> 3)
+        per = 8 // self.bit_size
+        return (numel + per - 1) // per
+
+
+class Context:
+    """Owns one native context, bound to the HIP device that is current at construction.
+
+    ``num_threads`` is accepted for source compatibility with the reference (it sized the CPU thread
+    pool there, ``__init__.py:65-70``) and ignored: the GPU grid does the partitioning.
+    """
+
+    _defaults: Dict[int, 'Context'] = {}
+
+    def __init__(self, num_threads: Union[int, None] = None) -> None:
+        self._num_threads = 0 if num_threads is None else int(num_threads)
+        self._ctx = C.piquant_context_create(self._num_threads)
+        assert self._ctx, 'piquant_context_create returned NULL'
+        self._finalizer = weakref.finalize(self, C.piquant_context_destroy, self._ctx)
+
+    @staticmethod
+    def get(device_index: Optional[int] = None) -> 'Context':
+        """Default context (one per HIP device, created on first use)."""
+        if device_index is None:
+            device_index = _current_device()
+        ctx = Context._defaults.get(device_index)
+        if ctx is None:
+            ctx = _make_on_device(device_index)
+            Context._defaults[device_index] = ctx
+        return ctx
+
+    @property
+    def device(self) -> int:
+        return int(C.piquant_hip_device(self._ctx))
+
+    # ---- reference surface (python/src/piquant/__init__.py:82-142) ---------------------------------
+    def quantize_ptr(self, ptr_in: int, dtype_in: DataType, ptr_out: int, dtype_out: DataType, numel: int, scale: float,
+                     zero_point: int, round_mode: RoundMode) -> None:
+        assert dtype_in.is_dequantized, f'Input dtype must be a dequantized type, but is: {dtype_in}'
+        assert dtype_out.is_quantized, f'Output dtype must be a quantized type, but is: {dtype_out}'
+        assert numel == 0 or ptr_in != 0, 'Input arr pointer must not be NULL'
+        assert numel == 0 or ptr_out != 0, 'Output arr pointer must not be NULL'
+        C.piquant_quantize(self._ctx, ptr_in, dtype_in.value, ptr_out, dtype_out.value, numel, scale, zero_point, round_mode.value)
+
+    def dequantize_ptr(self, ptr_in: int, dtype_in: DataType, ptr_out: int, dtype_out: DataType, numel: int, scale: float,
+                       zero_point: int, reduce_op: ReduceOp) -> None:
+        assert dtype_in.is_quantized, f'Input dtype must be a quantized type, but is: {dtype_in}'
+        assert dtype_out.is_dequantized, f'Output dtype must be a dequantized type, but is: {dtype_out}'
+        assert numel == 0 or ptr_in != 0, 'Input arr pointer must not be NULL'
+        assert numel == 0 or ptr_out != 0, 'Output arr pointer must not be NULL'
+        C.piquant_dequantize(self._ctx, ptr_in, dtype_in.value, ptr_out, dtype_out.value, numel, scale, zero_point, reduce_op.value)
+
+    def compute_quant_params_ptr_float32(self, ptr: int, target_quant_dtype: DataType, numel: int) -> Tuple[float, int]:
+        assert target_quant_dtype.is_quantized, f'Target dtype must be a quantized type, but is: {target_quant_dtype}'
+        assert ptr != 0, 'Input arr pointer must not be NULL'
+        scale, zero_point = _C.c_float(), _C.c_int64()
+        C.piquant_compute_quant_params_float32(self._ctx, ptr, numel, target_quant_dtype.value, _C.byref(scale), _C.byref(zero_point))
+        return scale.value, zero_point.value
+
+    def compute_quant_params_ptr_bfloat16(self, ptr: int, target_quant_dtype: DataType, numel: int) -> Tuple[float, int]:
+        assert target_quant_dtype.is_quantized, f'Target dtype must be a quantized type, but is: {target_quant_dtype}'
+        assert ptr != 0, 'Input arr pointer must not be NULL'
+        scale, zero_point = _C.c_float(), _C.c_int64()
+        C.piquant_compute_quant_params_bfloat16(self._ctx, ptr, numel, target_quant_dtype.value, _C.byref(scale), _C.byref(zero_point))
+        return scale.value, zero_point.value
+
+    # ---- additive GPU controls (include/piquant_hip.h) ----------------------------------------------
+    def set_stream(self, hip_stream: int) -> None:
+        """Enqueue on this hipStream_t (e.g. ``torch.cuda.current_stream().cuda_stream``); 0 = own stream."""
+        C.piquant_hip_set_stream(self._ctx, hip_stream or None)
+
+    def set_blocking(self, blocking: bool) -> None:
+        """True (native default): calls return after completion, like the reference.  False: stream-ordered."""
+        C.piquant_hip_set_blocking(self._ctx, 1 if blocking else 0)
+
+    def set_stochastic_threshold(self, threshold: Optional[float]) -> None:
+        """Pin the per-call stochastic threshold in [0,1) (None: draw a fresh one per call, the default)."""
+        C.piquant_hip_set_stochastic_threshold(self._ctx, -1.0 if threshold is None else float(threshold))
+
+    def set_stochastic_seed(self, seed: int) -> None:
+        C.piquant_hip_set_stochastic_seed(self._ctx, seed & 0xFFFFFFFFFFFFFFFF)
+
+    def set_stochastic_per_element(self, enabled: bool, seed: int = 0, index_base: int = 0) -> None:
+        """Opt-in: an independent threshold per element (counter hash of seed and global element index)."""
+        C.piquant_hip_set_stochastic_per_element(self._ctx, 1 if enabled else 0, seed & 0xFFFFFFFFFFFFFFFF, index_base)
+
+    def minmax_keys_ptr(self, ptr: int, dtype: DataType, numel: int, device_keys_ptr: int, init: bool = True) -> None:
+        """Asynchronously fold {min, -max} of the buffer into two int32 keys in device memory (atomic MIN)."""
+        assert dtype.is_dequantized
+        C.piquant_hip_minmax_keys(self._ctx, ptr, dtype.value, numel, device_keys_ptr, 1 if init else 0)
+
+
+def decode_minmax_keys(k_min: int, k_negmax: int) -> Tuple[float, float]:
+    keys = (_C.c_int32 * 2)(k_min, k_negmax)
+    lo, hi = _C.c_float(), _C.c_float()
+    C.piquant_hip_decode_minmax_keys(keys, _C.byref(lo), _C.byref(hi))
+    return lo.value, hi.value
+
+
+def quant_params_from_minmax(r_min: float, r_max: float, target_quant_dtype: DataType) -> Tuple[float, int]:
+    """The reference's (min,max) -> (scale, zero_point) epilogue (src/piquant.cpp:245-258), host side."""
+    assert target_quant_dtype.is_quantized
+    scale, zero_point = _C.c_float(), _C.c_int64()
+    C.piquant_hip_quant_params_from_minmax(r_min, r_max, target_quant_dtype.value, _C.byref(scale), _C.byref(zero_point))
+    return scale.value, zero_point.value
+
+
+def _current_device() -> int:
+    import torch as _torch
+
+    if not _torch.cuda.is_available():
+        raise RuntimeError('piquant needs a HIP device: torch.cuda.is_available() is False and there is no CPU path')
+    return _torch.cuda.current_device()
+
+
+def _make_on_device(device_index: int) -> Context:
+    import torch as _torch
+
+    with _torch.cuda.device(device_index):
+        return Context()
+
+
+if importlib.util.find_spec('torch') is not None:
+    from . import torch  # noqa: E402,F401

@@ -1,0 +1,200 @@
+"""``piquant.torch`` -- the reference's tensor-level API on PyTorch-ROCm tensors.
+
+Same functions and keyword arguments as the reference module (``python/src/piquant/torch.py:40-129``):
+``torch_to_piquant_dtype``, ``piquant_to_torch_dtype``, ``compute_quant_params``, ``quantize``,
+``dequantize``.  Differences, all additive:
+
+* tensors may live on a ROCm device; the output is allocated on ``tensor.device`` and the kernels are
+  enqueued on the current PyTorch stream (ordinary PyTorch stream semantics, no host sync);
+* CPU tensors still work (their host pointers are staged through the GPU over PCIe);
+* ``out=`` lets ``reduce_op='add'`` accumulate into an existing tensor -- the reference allocates a fresh
+  uninitialised output (``torch.py:117``), which makes ADD unusable through its tensor API;
+* ``ctx=None`` resolves to the default context of the tensor's device at call time (the reference evaluates
+  ``Context.get()`` once, at import).
+
+Packed sub-byte results: ``torch.quint4x2`` / ``torch.quint2x4`` tensors cannot be allocated on a ROCm
+device by ``torch.empty``, so device-side packed results are returned as a 1-D ``torch.uint8`` tensor of
+``ceil(numel*bits/8)`` bytes tagged with the logical shape and quantized dtype (``PackedTensor``).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import Context, DataType, ReduceOp, RoundMode
+
+_TORCH_DTYPE_MAP: dict[torch.dtype, DataType] = {
+    torch.float32: DataType.F32,
+    torch.bfloat16: DataType.BF16,
+    torch.quint2x4: DataType.UINT2,
+    torch.quint4x2: DataType.UINT4,
+    torch.quint8: DataType.UINT8,
+    torch.uint8: DataType.UINT8,
+}
+
+_QUANT_TYPES: set[torch.dtype] = {torch.quint2x4, torch.quint4x2, torch.quint8, torch.uint8}
+_DEQUANT_TYPES: set[torch.dtype] = {torch.float32, torch.bfloat16}
+_ROUND_MODES: dict[str, RoundMode] = {'nearest': RoundMode.NEAREST, 'stochastic': RoundMode.STOCHASTIC}
+_REDUCE_OPS: dict[str, ReduceOp] = {'set': ReduceOp.SET, 'add': ReduceOp.ADD}
+
+
+def torch_to_piquant_dtype(dtype: torch.dtype) -> DataType:
+    if dtype not in _TORCH_DTYPE_MAP:
+        raise ValueError(f'Unsupported quant_dtype: {dtype}')
+    return _TORCH_DTYPE_MAP[dtype]
+
+
+def piquant_to_torch_dtype(dtype: DataType) -> torch.dtype:
+    """First torch dtype mapped to ``dtype`` (the intent of reference ``torch.py:46-50``)."""
+    for torch_dtype, piquant_dtype in _TORCH_DTYPE_MAP.items():
+        if piquant_dtype == dtype:
+            return torch_dtype
+    raise ValueError(f'Unsupported quantized dtype: {dtype}')
+
+
+class PackedTensor(torch.Tensor):
+    """A 1-D uint8 tensor of packed uint4/uint2 values that remembers its logical shape and dtype."""
+
+    quant_dtype: torch.dtype
+    logical_shape: torch.Size
+    # results of torch ops on a PackedTensor (.cpu(), slicing, ...) are plain tensors
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    @staticmethod
+    def wrap(raw: torch.Tensor, quant_dtype: torch.dtype, shape) -> 'PackedTensor':
+        t = raw.as_subclass(PackedTensor)
+        t.quant_dtype = quant_dtype
+        t.logical_shape = torch.Size(shape)
+        return t
+
+
+def _ctx_for(tensor: torch.Tensor, ctx: Optional[Context]) -> Context:
+    """Default context of the tensor's device, with the current PyTorch stream attached for device tensors."""
+    if tensor.is_cuda:
+        index = tensor.device.index if tensor.device.index is not None else torch.cuda.current_device()
+        if ctx is None:
+            ctx = Context.get(index)
+        elif ctx.device != index:
+            raise ValueError(f'context is bound to device {ctx.device} but the tensor lives on device {index}')
+        ctx.set_stream(torch.cuda.current_stream(index).cuda_stream)
+        ctx.set_blocking(False)   # stream-ordered, like every other PyTorch device op
+    else:
+        if ctx is None:
+            ctx = Context.get()
+        ctx.set_stream(0)
+        ctx.set_blocking(True)
+    return ctx
+
+
+def _alloc_quantized(shape, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
+    qdt = torch_to_piquant_dtype(dtype)
+    numel = 1
+    for s in shape:
+        numel *= int(s)
+    if dtype == torch.uint8:
+        return torch.empty(shape, dtype=torch.uint8, device=device)
+    if device.type == 'cpu':
+        return torch.empty(shape, dtype=dtype)          # exactly what the reference returns (torch.py:87)
+    if dtype == torch.quint8:
+        # byte-per-element: a plain uint8 tensor of the logical shape carries it on the device
+        return PackedTensor.wrap(torch.empty(shape, dtype=torch.uint8, device=device), dtype, shape)
+    raw = torch.empty(qdt.packed_nbytes(numel), dtype=torch.uint8, device=device)
+    return PackedTensor.wrap(raw, dtype, shape)
+
+
+def _quant_meta(tensor: torch.Tensor, quant_dtype: Optional[torch.dtype], shape) -> Tuple[DataType, torch.Size]:
+    if isinstance(tensor, PackedTensor):
+        return torch_to_piquant_dtype(tensor.quant_dtype), tensor.logical_shape
+    if quant_dtype is not None:
+        assert shape is not None, 'shape= is required together with quant_dtype= for raw packed buffers'
+        return torch_to_piquant_dtype(quant_dtype), torch.Size(shape)
+    return torch_to_piquant_dtype(tensor.dtype), tensor.shape
+
+
+def compute_quant_params(tensor: torch.Tensor, *, dtype: torch.dtype, ctx: Optional[Context] = None) -> Tuple[float, int]:
+    """(scale, zero_point) from the tensor's min/max (reference ``torch.py:53-67``)."""
+    assert dtype in _QUANT_TYPES, f'Unsupported quantized dtype: {dtype}. Must be one of {list(_QUANT_TYPES)}'
+    if not tensor.is_contiguous():
+        tensor = tensor.contiguous()
+    ctx = _ctx_for(tensor, ctx)
+    if tensor.dtype == torch.bfloat16:
+        return ctx.compute_quant_params_ptr_bfloat16(tensor.data_ptr(), torch_to_piquant_dtype(dtype), tensor.numel())
+    assert tensor.dtype == torch.float32, f'compute_quant_params needs float32 or bfloat16, got {tensor.dtype}'
+    return ctx.compute_quant_params_ptr_float32(tensor.data_ptr(), torch_to_piquant_dtype(dtype), tensor.numel())
+
+
+def quantize(
+    tensor: torch.Tensor,
+    *,
+    scale: float,
+    zero_point: int,
+    dtype: torch.dtype,
+    round_mode: str = 'nearest',
+    ctx: Optional[Context] = None,
+    out: Optional[torch.Tensor] = None,
+) -> torch.Tensor:
+    """Reference ``torch.py:70-99``; the result lives on ``tensor.device``."""
+    assert dtype in _QUANT_TYPES, f'Unsupported quantized dtype: {dtype}. Must be one of {list(_QUANT_TYPES)}'
+    if not tensor.is_contiguous():
+        tensor = tensor.contiguous()
+    dtype_in = torch_to_piquant_dtype(tensor.dtype)
+    dtype_out = torch_to_piquant_dtype(dtype)
+    if out is None:
+        out = _alloc_quantized(tensor.shape, dtype, tensor.device)
+    else:
+        assert out.is_contiguous() and out.device == tensor.device
+        assert out.numel() * out.element_size() >= dtype_out.packed_nbytes(tensor.numel()), 'out= is too small'
+    ctx = _ctx_for(tensor, ctx)
+    ctx.quantize_ptr(
+        tensor.data_ptr(),
+        dtype_in,
+        out.data_ptr(),
+        dtype_out,
+        numel=tensor.numel(),
+        scale=scale,
+        zero_point=zero_point,
+        round_mode=_ROUND_MODES[round_mode],
+    )
+    return out
+
+
+def dequantize(
+    tensor: torch.Tensor,
+    *,
+    scale: float,
+    zero_point: int,
+    dtype: torch.dtype,
+    reduce_op: str = 'set',
+    ctx: Optional[Context] = None,
+    out: Optional[torch.Tensor] = None,
+    quant_dtype: Optional[torch.dtype] = None,
+    shape=None,
+) -> torch.Tensor:
+    """Reference ``torch.py:102-129``.  ``out=`` (same shape, ``dtype``) is the accumulator for ``reduce_op='add'``."""
+    if dtype not in _DEQUANT_TYPES:
+        raise ValueError(f'Unsupported dequantized dtype: {dtype}. Must be one of {list(_DEQUANT_TYPES)}')
+    if not tensor.is_contiguous():
+        tensor = tensor.contiguous()
+    dtype_in, logical_shape = _quant_meta(tensor, quant_dtype, shape)
+    numel = 1
+    for s in logical_shape:
+        numel *= int(s)
+    if out is None:
+        if reduce_op == 'add':
+            raise ValueError("reduce_op='add' accumulates into out=; pass the accumulator tensor")
+        out = torch.empty(logical_shape, dtype=dtype, device=tensor.device)
+    else:
+        assert out.dtype == dtype and out.is_contiguous() and out.device == tensor.device and out.numel() == numel
+    ctx = _ctx_for(tensor, ctx)
+    ctx.dequantize_ptr(
+        tensor.data_ptr(),
+        dtype_in,
+        out.data_ptr(),
+        torch_to_piquant_dtype(out.dtype),
+        numel=numel,
+        scale=scale,
+        zero_point=zero_point,
+        reduce_op=_REDUCE_OPS[reduce_op],
+    )
+    return out

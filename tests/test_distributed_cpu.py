@@ -1,0 +1,93 @@
+"""CPU, world_size 2, gloo: the multi-GPU structure of compute_quant_params and of the shard split.
+
+The HIP min/max scan cannot run here (no GPU), so the per-rank scan is injected from the oracle; everything
+else is the product code: shard_range, the int32 key encoding contract, the single all_reduce(MIN), the host
+epilogue in libpiquant.so.  Result must equal the single-process answer on the unsharded tensor.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _key(f):
+    b = int(np.float32(f).view(np.int32))
+    return b if b >= 0 else b ^ 0x7FFFFFFF
+
+
+def _worker(rank, world, port, numel, seed, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle as O
+        import piquant.distributed as D
+
+        x = np.random.default_rng(seed).uniform(-1, 1, numel).astype(np.float32)
+        x[numel // 3] = -7.5        # global min lives in one shard ...
+        x[2 * numel // 3 + 5] = 9.25   # ... global max in another
+        res = {}
+        for tdt, bits in ((torch.quint8, 8), (torch.quint4x2, 4), (torch.quint2x4, 2)):
+            b, e = D.shard_range(numel, rank, world, bits)
+            shard = torch.from_numpy(x[b:e].copy())
+
+            def scan(t, ctx):   # stands in for the HIP scan: same contract, int32 {key(min), key(-max)}
+                lo, hi = O.minmax(t.numpy(), O.F32) if t.numel() else (np.float32(3.4028235e38), np.float32(-3.4028235e38))
+                return torch.tensor([_key(lo), _key(-np.float32(hi))], dtype=torch.int32)
+
+            res[bits] = D.compute_quant_params(shard, dtype=tdt, _scan=scan)
+        out_q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_quant_params_equal_single_process(oracle_mod, world):
+    O = oracle_mod
+    numel, seed = 100_003, 11
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, numel, seed, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    x = np.random.default_rng(seed).uniform(-1, 1, numel).astype(np.float32)
+    x[numel // 3] = -7.5
+    x[2 * numel // 3 + 5] = 9.25
+    for bits, odt in ((8, O.UINT8), (4, O.UINT4), (2, O.UINT2)):
+        want = O.compute_quant_params(x, O.F32, odt)
+        for r in range(world):
+            assert results[r][bits] == want, (bits, r, results[r][bits], want)
+
+
+def test_shard_range_is_the_reference_split(oracle_mod):
+    import piquant.distributed as D
+
+    O = oracle_mod
+    for n in (0, 1, 5, 1000, 1003, 27_264_000, 2**30):
+        for world in (1, 2, 4, 8):
+            for bits in (8, 4, 2):
+                end_prev = 0
+                for r in range(world):
+                    b, e = D.shard_range(n, r, world, bits)
+                    want = O.partition(n, r, world, bits)
+                    if want is None:
+                        assert b == e
+                    else:
+                        assert (b, e - b) == want
+                        assert b == end_prev
+                        end_prev = e
+                assert end_prev == n or n == 0

@@ -1,0 +1,393 @@
+"""GPU: the HIP path against the oracle, bit for bit, through the C ABI of libpiquant.so.
+
+Every call goes piquant.Context.*_ptr -> ctypes -> libpiquant.so -> HIP kernel on device pointers (or host
+pointers for the staging tests).  The expected values come from the oracle's FORM_UNIFORM (the position-
+independent formula the kernels implement) and from the committed vectors produced by the reference's own
+kernels.  Integer outputs must be identical; float outputs must be bit-identical (any-NaN == any-NaN).
+"""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from helpers import gpu_dequantize, gpu_quantize, load_golden, same_floats, to_device
+
+pytestmark = pytest.mark.gpu
+
+N1 = 27_264_000   # BASELINE.json configs 1-4
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import piquant
+    import torch
+
+    assert torch.cuda.is_available(), "gpu tests need a ROCm device"
+    return piquant.Context()
+
+
+@pytest.fixture(scope="module")
+def O(oracle_mod):
+    return oracle_mod
+
+
+# block tile = 4096 (f32) / 8192 (bf16) elements for quantize; boundaries around them, odd and ragged sizes
+SIZES = [1, 2, 3, 5, 63, 64, 65, 1000, 4095, 4096, 4097, 8191, 8192, 8193, 12289, 65536 + 17, 1_000_003]
+
+
+# ---------------------------------------------------------------------------------------------------
+# golden vectors (outputs of the reference's own kernels)
+# ---------------------------------------------------------------------------------------------------
+def test_golden_quantize(ctx):
+    cases, get = load_golden()
+    n = 0
+    for c in cases:
+        if c["kind"] != "quantize":
+            continue
+        ctx.set_stochastic_threshold(c["tau"] if c["round_mode"] else None)
+        got = gpu_quantize(ctx, get(c["name"], "x"), c["dt_in"], c["dt_out"], c["scale"], c["zp"], c["round_mode"])
+        assert np.array_equal(got, get(c["name"], "uniform")), c
+        n += 1
+    ctx.set_stochastic_threshold(None)
+    assert n > 500
+
+
+def test_golden_dequantize(ctx):
+    cases, get = load_golden()
+    n = 0
+    for c in cases:
+        if c["kind"] != "dequantize":
+            continue
+        got = gpu_dequantize(ctx, get(c["name"], "q"), c["dt_in"], c["dt_out"], c["numel"], c["scale"], c["zp"], c["op"],
+                             prev=get(c["name"], "prev"))
+        assert same_floats(got, get(c["name"], "uniform")), c
+        n += 1
+    assert n > 400
+
+
+def test_golden_minmax(ctx):
+    import piquant
+
+    cases, get = load_golden()
+    for c in cases:
+        if c["kind"] != "minmax":
+            continue
+        for field, dt, lo, hi in (("x", piquant.DataType.F32, c["min_f32"], c["max_f32"]), ("xb", piquant.DataType.BF16, c["min_bf16"], c["max_bf16"])):
+            _, ptr = keep = to_device(get(c["name"], field))
+            import torch
+
+            keys = torch.empty(2, dtype=torch.int32, device="cuda")
+            ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            ctx.minmax_keys_ptr(ptr, dt, c["numel"], keys.data_ptr(), init=True)
+            k = keys.cpu()
+            assert piquant.decode_minmax_keys(int(k[0]), int(k[1])) == (lo, hi), c
+            del keep
+
+
+# ---------------------------------------------------------------------------------------------------
+# randomized parity, all 12 + 12 combinations
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt_in", [0, 1], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dt_out", [4, 3, 2], ids=["u8", "u4", "u2"])
+@pytest.mark.parametrize("round_mode", [0, 1], ids=["nearest", "stochastic"])
+def test_quantize_random(ctx, O, dt_in, dt_out, round_mode):
+    rng = np.random.default_rng(100 * dt_in + 10 * dt_out + round_mode)
+    qmax = {4: 255, 3: 15, 2: 3}[dt_out]
+    for n in SIZES:
+        x = rng.uniform(-1, 1, n).astype(np.float32)
+        if n > 100:
+            x[rng.choice(n, 6, replace=False)] = [np.nan, np.inf, -np.inf, 1e30, -1e30, 0.0]
+        xin = x if dt_in == 0 else O.f32_to_bf16(x)
+        scale = float(np.float32(2.0 / qmax))
+        for zp in (qmax // 2, -3, qmax + 10):
+            tau = float(rng.uniform(0, 1)) if round_mode else 0.0
+            ctx.set_stochastic_threshold(tau if round_mode else None)
+            got = gpu_quantize(ctx, xin, dt_in, dt_out, scale, zp, round_mode)
+            want = O.quantize(xin, dt_in, dt_out, scale, zp, round_mode, tau, form=O.FORM_UNIFORM)
+            assert np.array_equal(got, want), (n, zp, np.nonzero(got != want)[0][:5])
+    ctx.set_stochastic_threshold(None)
+
+
+@pytest.mark.parametrize("dt_q", [4, 3, 2], ids=["u8", "u4", "u2"])
+@pytest.mark.parametrize("dt_f", [0, 1], ids=["f32", "bf16"])
+@pytest.mark.parametrize("op", [0, 1], ids=["set", "add"])
+def test_dequantize_random(ctx, O, dt_q, dt_f, op):
+    rng = np.random.default_rng(1000 + 100 * dt_q + 10 * dt_f + op)
+    for n in SIZES:
+        q = rng.integers(0, 256, O.packed_numel(n, dt_q)).astype(np.uint8)
+        prev = rng.uniform(-4, 4, n).astype(np.float32)
+        prev = prev if dt_f == 0 else O.f32_to_bf16(prev)
+        for scale, zp in ((0.0078431377, 127), (0.37, -5), (1e-3, 300)):
+            got = gpu_dequantize(ctx, q, dt_q, dt_f, n, scale, zp, op, prev=prev)
+            want = O.dequantize(q, dt_q, dt_f, n, scale, zp, op, form=O.FORM_UNIFORM, out=prev.copy())
+            assert same_floats(got, want), (n, scale, zp)
+
+
+def test_extreme_zero_points_wrap_like_the_reference(ctx, O):
+    """int64 zero points are narrowed to int32 on the fast paths and kept on the generic ones (quantize.inl:111 vs :15)."""
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-100, 100, 5000).astype(np.float32)
+    x[:4] = [np.nan, np.inf, -np.inf, 3e9]
+    for zp in (2**31 - 1, -2**31, 2**32 + 5, -2**40, 2**62):
+        for dt_out in (4, 3, 2):
+            for rm, tau in ((0, 0.0), (1, 0.3)):
+                ctx.set_stochastic_threshold(tau if rm else None)
+                got = gpu_quantize(ctx, x, 0, dt_out, 0.5, zp, rm)
+                assert np.array_equal(got, O.quantize(x, 0, dt_out, 0.5, zp, rm, tau)), (zp, dt_out, rm)
+    ctx.set_stochastic_threshold(None)
+    q = rng.integers(0, 256, 5000).astype(np.uint8)
+    for zp in (2**31 - 1, -2**31, 2**32 + 5):
+        for dt_q, dt_f in ((4, 0), (3, 1), (2, 0), (2, 1)):
+            n = 5000 * (8 // {4: 8, 3: 4, 2: 2}[dt_q])
+            got = gpu_dequantize(ctx, q, dt_q, dt_f, n, 0.5, zp)
+            assert same_floats(got, O.dequantize(q, dt_q, dt_f, n, 0.5, zp)), (zp, dt_q, dt_f)
+
+
+# ---------------------------------------------------------------------------------------------------
+# pointer flavours: misaligned device buffers (guarded scalar kernels) and host buffers (PCIe staging)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("off_in,off_out", [(4, 0), (0, 1), (8, 3), (2, 2)])
+def test_misaligned_device_pointers(ctx, O, off_in, off_out):
+    rng = np.random.default_rng(off_in * 16 + off_out)
+    n = 70_001
+    x = rng.uniform(-1, 1, n).astype(np.float32)
+    for dt_in, xin in ((0, x), (1, O.f32_to_bf16(x))):
+        if dt_in == 0 and off_in % 4:
+            continue   # an fp32 array is at least 4-byte aligned
+        for dt_out in (4, 3, 2):
+            got = gpu_quantize(ctx, xin, dt_in, dt_out, 0.01, 7, 0, offset_in=off_in, offset_out=off_out)
+            assert np.array_equal(got, O.quantize(xin, dt_in, dt_out, 0.01, 7))
+    q = rng.integers(0, 256, n).astype(np.uint8)
+    prev = rng.uniform(-1, 1, n).astype(np.float32)
+    for dt_f, off in ((0, (off_out // 4) * 4 + 4), (1, (off_out // 2) * 2 + 2)):
+        p = prev if dt_f == 0 else O.f32_to_bf16(prev)
+        got = gpu_dequantize(ctx, q, 4, dt_f, n, 0.02, 9, 1, prev=p, offset_in=off_in, offset_out=off)
+        assert same_floats(got, O.dequantize(q, 4, dt_f, n, 0.02, 9, 1, out=p.copy()))
+
+
+def test_host_pointers_are_staged_through_the_gpu(ctx, O):
+    """The reference's callers pass host memory; the drop-in stages it over PCIe in 2^24-element chunks."""
+    rng = np.random.default_rng(77)
+    n = (1 << 24) + 12_345     # two chunks
+    x = rng.uniform(-1, 1, n).astype(np.float32)
+    got = gpu_quantize(ctx, x, 0, 4, 0.0078431377, 127, 0, host=True)
+    want = O.quantize(x, 0, 4, 0.0078431377, 127)
+    assert np.array_equal(got, want)
+    acc = rng.uniform(-1, 1, n).astype(np.float32)
+    back = gpu_dequantize(ctx, got, 4, 0, n, 0.0078431377, 127, 1, prev=acc, host=True)
+    assert same_floats(back, O.dequantize(want, 4, 0, n, 0.0078431377, 127, 1, out=acc.copy()))
+    xb = O.f32_to_bf16(x[:100_001])
+    assert np.array_equal(gpu_quantize(ctx, xb, 1, 3, 0.13, 7, 0, host=True), O.quantize(xb, 1, 3, 0.13, 7))
+    import piquant
+
+    assert ctx.compute_quant_params_ptr_float32(x.ctypes.data, piquant.DataType.UINT8, n) == O.compute_quant_params(x, 0, 4)
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE configs at full size
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def big_x():
+    return np.random.default_rng(0).uniform(-1, 1, N1).astype(np.float32)
+
+
+def test_config2_f32_to_u8_nearest_full_size_bit_exact(ctx, O, big_x):
+    """BASELINE config 2: fp32 -> uint8 nearest, numel 27 264 000, bit-exact vs the CPU algorithm."""
+    import piquant
+    import torch
+
+    xd = torch.from_numpy(big_x).cuda()
+    scale, zp = piquant.torch.compute_quant_params(xd, dtype=torch.quint8)
+    assert (scale, zp) == O.compute_quant_params(big_x, 0, 4)
+    q = piquant.torch.quantize(xd, scale=scale, zero_point=zp, dtype=torch.uint8)
+    want = O.quantize(big_x, 0, 4, scale, zp)
+    assert np.array_equal(q.cpu().numpy(), want)
+    if O.ref_available():   # and against the reference kernels themselves where the prebuilt checker exists
+        assert np.array_equal(want, O.Ref().quantize(big_x, 0, 4, scale, zp, threads=os.cpu_count() or 1))
+    # shard invariance: quantizing two aligned halves gives the same bytes (no position dependence)
+    half = (N1 // 2) // 4096 * 4096
+    a = piquant.torch.quantize(xd[:half], scale=scale, zero_point=zp, dtype=torch.uint8)
+    b = piquant.torch.quantize(xd[half:], scale=scale, zero_point=zp, dtype=torch.uint8)
+    assert torch.equal(torch.cat([a, b]), q)
+
+
+def test_config3_bf16_to_u4_round_trip_full_size(ctx, O, big_x):
+    """BASELINE config 3: bf16 -> packed uint4 and back (SET); |x' - x| <= 0.5*scale (+1 bf16 ulp)."""
+    import piquant
+    import torch
+
+    xb = O.f32_to_bf16(big_x)
+    xd = torch.from_numpy(xb.view(np.int16)).cuda().view(torch.bfloat16)
+    scale, zp = piquant.torch.compute_quant_params(xd, dtype=torch.quint4x2)
+    assert (scale, zp) == O.compute_quant_params(xb, 1, 3)
+    q = piquant.torch.quantize(xd, scale=scale, zero_point=zp, dtype=torch.quint4x2)
+    qn = q.cpu().numpy().view(np.uint8)
+    assert qn.size == (N1 + 1) // 2
+    assert np.array_equal(qn, O.quantize(xb, 1, 3, scale, zp))
+    back = piquant.torch.dequantize(q, scale=scale, zero_point=zp, dtype=torch.bfloat16)
+    bn = back.view(torch.int16).cpu().numpy().view(np.uint16)
+    assert np.array_equal(bn, O.dequantize(qn, 3, 1, N1, scale, zp))
+    err = np.abs(O.bf16_to_f32(bn).astype(np.float64) - O.bf16_to_f32(xb).astype(np.float64))
+    assert err.max() <= 0.5 * scale + 2.0 ** -8       # values <= 1: one bf16 ulp is at most 2^-8
+
+
+def test_config4_stochastic_and_add_store_full_size(ctx, O, big_x):
+    """BASELINE config 4: fp32 -> uint8 stochastic, then dequantize with the ADD store into an accumulator."""
+    import piquant
+    import torch
+
+    xd = torch.from_numpy(big_x).cuda()
+    scale, zp = O.compute_quant_params(big_x, 0, 4)
+    near = O.quantize(big_x, 0, 4, scale, zp)
+    c = piquant.Context()
+    # reference behaviour: one hidden threshold per call -> |q_st - q_near| <= 1, and the threshold changes per call
+    fracs = []
+    for _ in range(3):
+        q = piquant.torch.quantize(xd, scale=scale, zero_point=zp, dtype=torch.uint8, round_mode="stochastic", ctx=c).cpu().numpy()
+        d = q.astype(np.int16) - near.astype(np.int16)
+        assert d.min() >= -1 and d.max() <= 1
+        fracs.append(float((d != 0).mean()))
+    assert len(set(fracs)) > 1
+    # pinned threshold: bit-exact vs the reference algorithm
+    c.set_stochastic_threshold(0.37)
+    q = piquant.torch.quantize(xd, scale=scale, zero_point=zp, dtype=torch.uint8, round_mode="stochastic", ctx=c)
+    want = O.quantize(big_x, 0, 4, scale, zp, 1, 0.37)
+    assert np.array_equal(q.cpu().numpy(), want)
+    acc = torch.ones(N1, dtype=torch.float32, device="cuda")
+    piquant.torch.dequantize(q, scale=scale, zero_point=zp, dtype=torch.float32, reduce_op="add", out=acc, ctx=c)
+    want_acc = O.dequantize(want, 4, 0, N1, scale, zp, 1, out=np.ones(N1, dtype=np.float32))
+    got_acc = acc.cpu().numpy()
+    assert same_floats(got_acc, want_acc)
+    assert np.abs((got_acc - 1.0) - big_x).max() <= scale * 1.0001 + 1e-6
+
+
+def test_per_element_stochastic_extension(ctx, O):
+    import piquant
+
+    rng = np.random.default_rng(9)
+    n = 1_000_003
+    x = rng.uniform(-1, 1, n).astype(np.float32)
+    c = piquant.Context()
+    for dt_in, xin in ((0, x), (1, O.f32_to_bf16(x))):
+        for dt_out, scale, zp in ((4, 0.0078431377, 127), (3, 0.13333334, 7), (2, 0.6666667, 1)):
+            c.set_stochastic_per_element(True, seed=0x1234_5678_9ABC_DEF0, index_base=0)
+            got = gpu_quantize(c, xin, dt_in, dt_out, scale, zp, 1)
+            assert np.array_equal(got, O.quantize_per_element(xin, dt_in, dt_out, scale, zp, 0x1234_5678_9ABC_DEF0, 0))
+    # shard invariance with index_base, and a base beyond 2^32
+    base = (1 << 32) - 4096 * 3
+    c.set_stochastic_per_element(True, seed=42, index_base=base)
+    whole = gpu_quantize(c, x, 0, 4, 0.0078431377, 127, 1)
+    assert np.array_equal(whole, O.quantize_per_element(x, 0, 4, 0.0078431377, 127, 42, base))
+    cut = 4096 * 100
+    c.set_stochastic_per_element(True, seed=42, index_base=base + cut)
+    assert np.array_equal(gpu_quantize(c, x[cut:], 0, 4, 0.0078431377, 127, 1), whole[cut:])
+    # unbiased: E[q] - zp == x/scale
+    q = whole.astype(np.float64) - 127
+    assert abs((q - x.astype(np.float64) / 0.0078431377).mean()) < 2e-3
+
+
+# ---------------------------------------------------------------------------------------------------
+# compute_quant_params
+# ---------------------------------------------------------------------------------------------------
+def test_compute_quant_params_matches_oracle(ctx, O):
+    import piquant
+    import torch
+
+    rng = np.random.default_rng(21)
+    for n in (1, 2, 7, 64, 1023, 1024, 4097, 1_000_003, 5_000_000):
+        x = rng.normal(size=n).astype(np.float32)
+        for pos_lo, pos_hi in ((0, n - 1), (n - 1, 0), (n // 2, n // 3)):
+            y = x.copy()
+            y[pos_lo] = -11.0
+            if pos_hi != pos_lo:
+                y[pos_hi] = 13.0
+            yd = torch.from_numpy(y).cuda()
+            yb = O.f32_to_bf16(y)
+            ybd = torch.from_numpy(yb.view(np.int16)).cuda().view(torch.bfloat16)
+            for tdt, odt in ((torch.quint8, 4), (torch.quint4x2, 3), (torch.quint2x4, 2)):
+                assert piquant.torch.compute_quant_params(yd, dtype=tdt) == O.compute_quant_params(y, 0, odt), (n, pos_lo)
+                assert piquant.torch.compute_quant_params(ybd, dtype=tdt) == O.compute_quant_params(yb, 1, odt), (n, pos_lo)
+    # degenerate range -> (1.0, mid)   (reference src/piquant.cpp:249-252, test/quant.cpp:198-217)
+    const = torch.full((1000,), 42.0, device="cuda")
+    assert [piquant.torch.compute_quant_params(const, dtype=d) for d in (torch.quint8, torch.quint4x2, torch.quint2x4)] == [(1.0, 127), (1.0, 7), (1.0, 1)]
+    # misaligned view
+    base = torch.from_numpy(rng.normal(size=10_001).astype(np.float32)).cuda()
+    assert piquant.torch.compute_quant_params(base[1:], dtype=torch.quint8) == O.compute_quant_params(base[1:].cpu().numpy(), 0, 4)
+
+
+def test_minmax_keys_accumulate_across_calls(ctx, O):
+    """init=0 folds further scans into the same keys: the building block of the multi-GPU reduction."""
+    import piquant
+    import torch
+
+    rng = np.random.default_rng(4)
+    parts = [rng.normal(size=n).astype(np.float32) for n in (1000, 77, 123_456)]
+    keys = torch.empty(2, dtype=torch.int32, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    keep = []
+    for i, p in enumerate(parts):
+        t = torch.from_numpy(p).cuda()
+        keep.append(t)
+        ctx.minmax_keys_ptr(t.data_ptr(), piquant.DataType.F32, t.numel(), keys.data_ptr(), init=(i == 0))
+    k = keys.cpu()
+    assert piquant.decode_minmax_keys(int(k[0]), int(k[1])) == O.minmax(np.concatenate(parts), 0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# API semantics
+# ---------------------------------------------------------------------------------------------------
+def test_blocking_default_and_stream_ordering(O):
+    """A fresh context behaves like the reference: the call returns when the result is complete."""
+    import piquant
+    import torch
+
+    c = piquant.Context()
+    x = np.random.default_rng(3).uniform(-1, 1, 3_000_000).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    out = torch.zeros(x.size, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    c.quantize_ptr(xd.data_ptr(), piquant.DataType.F32, out.data_ptr(), piquant.DataType.UINT8, x.size, 0.0078431377, 127, piquant.RoundMode.NEAREST)
+    # no torch-side synchronisation: the blocking context already waited on its own stream
+    got = out.cpu().numpy()
+    assert np.array_equal(got, O.quantize(x, 0, 4, 0.0078431377, 127))
+    # stream-ordered mode on a side stream
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        y = xd * 2.0
+        q = piquant.torch.quantize(y, scale=0.0157, zero_point=127, dtype=torch.uint8, ctx=c)
+        back = piquant.torch.dequantize(q, scale=0.0157, zero_point=127, dtype=torch.float32, ctx=c)
+    s.synchronize()
+    assert np.array_equal(q.cpu().numpy(), O.quantize((x * np.float32(2.0)), 0, 4, 0.0157, 127))
+    assert float((back - y).abs().max()) <= 0.0157 * 0.5 + 1e-6
+
+
+def test_empty_inputs_are_no_ops(ctx):
+    import piquant
+
+    ctx.quantize_ptr(0, piquant.DataType.F32, 0, piquant.DataType.UINT4, 0, 1.0, 0, piquant.RoundMode.NEAREST)
+    ctx.dequantize_ptr(0, piquant.DataType.UINT2, 0, piquant.DataType.BF16, 0, 1.0, 0, piquant.ReduceOp.ADD)
+
+
+@pytest.mark.parametrize("snippet,needle", [
+    ("C.piquant_quantize(ctx, p, 4, p, 4, 16, 1.0, 0, 0)", "must be a dequantized type"),
+    ("C.piquant_quantize(ctx, p, 0, p, 1, 16, 1.0, 0, 0)", "must be a quantized type"),
+    ("C.piquant_dequantize(ctx, p, 0, p, 0, 16, 1.0, 0, 0)", "must be a quantized type"),
+    ("C.piquant_dequantize(ctx, p, 3, p, 4, 16, 1.0, 0, 0)", "must be a dequantized type"),
+])
+def test_contract_violations_abort_like_the_reference(snippet, needle):
+    """reference src/piquant.cpp:88-98,288-289,321-322: message on stderr, then abort()."""
+    code = textwrap.dedent(f"""
+        import sys; sys.path.insert(0, {str(os.path.join(os.path.dirname(__file__), '..', 'pi-quant_amd'))!r})
+        import torch, piquant
+        from piquant._bootstrap import C_LIB as C
+        t = torch.zeros(64, device='cuda'); p = t.data_ptr()
+        ctx = C.piquant_context_create(1)
+        {snippet}
+        print('survived')
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == -6, (r.returncode, r.stderr[-500:])   # SIGABRT
+    assert needle in r.stderr and "survived" not in r.stdout

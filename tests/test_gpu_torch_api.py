@@ -1,0 +1,113 @@
+"""GPU: the tensor-level API, mirroring the reference's own Python tests (python/tests/test_torch.py:23-53)
+with the same seed, value range and tolerances -- but on ROCm device tensors.  torch.quantize_per_tensor
+runs on the CPU copy as the independent comparison the reference test uses."""
+import math
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TORCH_FLOAT_TYPES = [torch.bfloat16, torch.float32]
+TORCH_QUANT_TYPES = [torch.quint8, torch.quint4x2, torch.quint2x4]
+
+random.seed(128)
+gen = torch.manual_seed(128)
+
+
+def shape4():
+    while True:   # reference: four dims in [1, 128]; bounded here so the CPU-side torch comparison stays quick
+        s = [random.randint(1, 128) for _ in range(4)]
+        if s[0] * s[1] * s[2] * s[3] <= 24_000_000:
+            return s
+
+
+@pytest.mark.parametrize("dtype_in", TORCH_FLOAT_TYPES)
+@pytest.mark.parametrize("dtype_quantized", TORCH_QUANT_TYPES)
+def test_compute_quant_config(dtype_in, dtype_quantized):
+    import piquant
+
+    tensor = torch.empty(*shape4(), dtype=dtype_in)
+    tensor.uniform_(-1.0, 1.0, generator=gen)
+    scale, zero_point = piquant.torch.compute_quant_params(tensor.cuda(), dtype=dtype_quantized)
+    assert scale > 0
+    assert not math.isnan(scale)
+    assert not math.isinf(scale)
+    assert isinstance(zero_point, int)
+
+
+@pytest.mark.parametrize("dtype_in", TORCH_FLOAT_TYPES)
+@pytest.mark.parametrize("dtype_quantized", TORCH_QUANT_TYPES)
+def test_quantize_roundtrip(dtype_in, dtype_quantized):
+    import piquant
+
+    inp = torch.empty(*shape4(), dtype=dtype_in)
+    inp.uniform_(-1.0, 1.0, generator=gen)
+    dev = inp.cuda()
+    scale, zero_point = piquant.torch.compute_quant_params(dev, dtype=dtype_quantized)
+    quantized_torch = torch.quantize_per_tensor(inp.float(), scale=scale, zero_point=zero_point, dtype=dtype_quantized)
+    quantized_pi = piquant.torch.quantize(dev, zero_point=zero_point, scale=scale, dtype=dtype_quantized)
+    assert quantized_pi.is_cuda
+
+    dequantized_torch = quantized_torch.dequantize().to(dtype_in)
+    dequantized_pi = piquant.torch.dequantize(quantized_pi, scale=scale, zero_point=zero_point, dtype=dtype_in)
+    assert dequantized_pi.is_cuda and dequantized_pi.shape == inp.shape
+    dequantized_pi = dequantized_pi.cpu()
+    assert dequantized_torch.dtype == dequantized_pi.dtype
+    assert dequantized_pi.dtype == inp.dtype
+    # reference tolerances (test_torch.py:51-53)
+    assert torch.allclose(dequantized_torch, dequantized_pi, atol=1e-3)
+    assert torch.allclose(dequantized_torch, inp, atol=scale * 0.5 + 1e-3)
+    assert torch.allclose(dequantized_pi, inp, atol=scale * 0.5 + 1e-3)
+
+
+def test_cpu_tensors_round_trip_through_the_gpu():
+    """A reference user passing CPU tensors keeps working: same call, host pointers staged over PCIe."""
+    import piquant
+
+    x = torch.empty(257, 33).uniform_(-1, 1, generator=gen)
+    scale, zp = piquant.torch.compute_quant_params(x, dtype=torch.quint8)
+    q = piquant.torch.quantize(x, scale=scale, zero_point=zp, dtype=torch.quint8)
+    assert q.dtype == torch.quint8 and not q.is_cuda and q.shape == x.shape
+    ref = torch.quantize_per_tensor(x, scale=scale, zero_point=zp, dtype=torch.quint8)
+    assert torch.equal(q.int_repr(), ref.int_repr()) or (q.int_repr().int() - ref.int_repr().int()).abs().max() <= 1
+    back = piquant.torch.dequantize(q, scale=scale, zero_point=zp, dtype=torch.float32)
+    assert torch.allclose(back, x, atol=scale * 0.5 + 1e-6)
+
+
+def test_add_store_needs_and_uses_an_accumulator():
+    import piquant
+
+    x = torch.empty(10_000, device="cuda").uniform_(-1, 1)
+    scale, zp = piquant.torch.compute_quant_params(x, dtype=torch.uint8)
+    q = piquant.torch.quantize(x, scale=scale, zero_point=zp, dtype=torch.uint8)
+    with pytest.raises(ValueError):
+        piquant.torch.dequantize(q, scale=scale, zero_point=zp, dtype=torch.float32, reduce_op="add")
+    acc = torch.full_like(x, 5.0)
+    piquant.torch.dequantize(q, scale=scale, zero_point=zp, dtype=torch.float32, reduce_op="add", out=acc)
+    assert torch.allclose(acc - 5.0, x, atol=scale * 0.5 + 1e-5)
+
+
+def test_identity_requant_of_constant_tensor():
+    """reference test/quant.cpp:198-217: const 42 -> params (1.0, 127) -> quant -> dequant(ADD into zeros) == 42."""
+    import piquant
+
+    x = torch.full((8192,), 42.0, device="cuda")
+    scale, zp = piquant.torch.compute_quant_params(x, dtype=torch.uint8)
+    assert (scale, zp) == (1.0, 127)
+    q = piquant.torch.quantize(x, scale=scale, zero_point=zp, dtype=torch.uint8)
+    acc = torch.zeros_like(x)
+    piquant.torch.dequantize(q, scale=scale, zero_point=zp, dtype=torch.float32, reduce_op="add", out=acc)
+    assert float((acc - 42.0).abs().max()) <= 1e-6
+
+
+def test_non_contiguous_input_is_made_contiguous():
+    import piquant
+
+    x = torch.empty(300, 70, device="cuda").uniform_(-1, 1).t()
+    assert not x.is_contiguous()
+    q = piquant.torch.quantize(x, scale=0.0078431377, zero_point=127, dtype=torch.uint8)
+    q2 = piquant.torch.quantize(x.contiguous(), scale=0.0078431377, zero_point=127, dtype=torch.uint8)
+    assert torch.equal(q, q2) and q.shape == x.shape

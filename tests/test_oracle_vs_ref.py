@@ -1,0 +1,82 @@
+"""CPU: oracle (FORM_REFERENCE) vs the reference's own kernels (oracle/_ref) on fresh random inputs.
+
+Needs oracle/_ref/libpiquant_ref.so, which oracle/Makefile builds only where /root/reference is mounted; the
+committed golden vectors (test_oracle_golden.py) carry the same pin everywhere else.
+"""
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def both(oracle_mod):
+    if not oracle_mod.ref_available():
+        pytest.skip("oracle/_ref not built on this box (no /root/reference); golden vectors cover the pin")
+    return oracle_mod, oracle_mod.Ref()
+
+
+SIZES = [0, 1, 3, 17, 64, 65, 129, 257, 1000, 4099, 100_003]
+
+
+@pytest.mark.parametrize("isa_name", ["avx512f", "avx512f_bf16"])
+def test_quantize_all_pairs(both, isa_name):
+    O, R = both
+    isa = {"avx512f": O.Ref.AVX512F, "avx512f_bf16": O.Ref.AVX512F_BF16}[isa_name]
+    if not R.supported(isa):
+        pytest.skip(f"CPU lacks {isa_name}")
+    rng = np.random.default_rng(7)
+    for dt_in in (O.F32, O.BF16):
+        for dt_out in (O.UINT8, O.UINT4, O.UINT2):
+            for rm in (O.NEAREST, O.STOCHASTIC):
+                for n in SIZES:
+                    x = rng.uniform(-3, 3, n).astype(np.float32)
+                    if n > 20:
+                        x[[3, 5, 7, 9]] = [np.nan, np.inf, -np.inf, 1e30]
+                    xin = x if dt_in == O.F32 else O.f32_to_bf16(x)
+                    for scale, zp in ((0.05, 60), (0.0234, -3), (1.0, 0)):
+                        tau = float(rng.uniform(0, 1)) if rm else 0.0
+                        a = O.quantize(xin, dt_in, dt_out, scale, zp, rm, tau, form=O.FORM_REFERENCE)
+                        b = R.quantize(xin, dt_in, dt_out, scale, zp, rm, tau, isa=isa)
+                        assert np.array_equal(a, b), (dt_in, dt_out, rm, n, scale, zp)
+
+
+def test_dequantize_all_pairs(both):
+    O, R = both
+    isa = O.Ref.AVX512F
+    if not R.supported(isa):
+        pytest.skip("CPU lacks avx512f")
+    rng = np.random.default_rng(8)
+    for dt_q in (O.UINT8, O.UINT4, O.UINT2):
+        for dt_f in (O.F32, O.BF16):
+            for op in (O.SET, O.ADD):
+                for n in SIZES:
+                    q = rng.integers(0, 256, O.packed_numel(n, dt_q)).astype(np.uint8)
+                    prev = rng.uniform(-5, 5, n).astype(np.float32)
+                    if dt_f == O.BF16:
+                        prev = O.f32_to_bf16(prev)
+                    for scale, zp in ((0.05, 60), (0.0234, -3), (1e-3, 200)):
+                        a = O.dequantize(q, dt_q, dt_f, n, scale, zp, op, form=O.FORM_REFERENCE, out=prev.copy())
+                        b = R.dequantize(q, dt_q, dt_f, n, scale, zp, op, isa=isa, out=prev.copy())
+                        assert np.array_equal(a, b), (dt_q, dt_f, op, n, scale, zp)
+
+
+def test_threaded_partition_matches_reference_kernels_run_per_partition(both):
+    """The reference with T pool threads == its kernels run on each partition (src/piquant.cpp:159-169)."""
+    O, R = both
+    rng = np.random.default_rng(9)
+    x = rng.uniform(-1, 1, 10_007).astype(np.float32)
+    for dt_out in (O.UINT8, O.UINT4, O.UINT2):
+        for T in (2, 3, 7):
+            a = O.quantize(x, O.F32, dt_out, 0.01, 50, form=O.FORM_REFERENCE, threads=T)
+            b = R.quantize(x, O.F32, dt_out, 0.01, 50, isa=O.Ref.AVX512F, threads=T)
+            assert np.array_equal(a, b)
+
+
+def test_headline_config_uniform_equals_reference(both):
+    """BASELINE config 1 at reduced size (2^21 elements): on U(-1,1) data with min/max parameters the
+    position-independent formula of the HIP kernels is bit-identical to the reference."""
+    O, R = both
+    x = np.random.default_rng(0).uniform(-1, 1, 1 << 21).astype(np.float32)
+    scale, zp = O.compute_quant_params(x, O.F32, O.UINT8)
+    ref = R.quantize(x, O.F32, O.UINT8, scale, zp)
+    assert np.array_equal(ref, O.quantize(x, O.F32, O.UINT8, scale, zp, form=O.FORM_UNIFORM))
+    assert np.array_equal(ref, R.quantize(x, O.F32, O.UINT8, scale, zp, threads=8))

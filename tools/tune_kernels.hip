@@ -1,0 +1,270 @@
+// Kernel geometry sweep on a real MI355X (development tool, not part of the product library).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Ipi-quant_amd/csrc tools/tune_kernels.hip -o tools/tune_kernels
+//   ./tools/tune_kernels [numel] [reps] > gpurun_out/tune.csv
+// For every variant: `reps` back-to-back launches between two hipEvents, rotating over SETS distinct buffer
+// sets (> 256 MiB in total, so reads come from HBM, not the Infinity Cache); prints average us per launch and
+// algorithmic GB/s.  The winners are copied into csrc/tuning.hpp by hand, with the CSV kept under profiles/.
+#include "dequant_kernels.hpp"
+#include "minmax_kernels.hpp"
+#include "quant_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <string>
+#include <vector>
+
+using namespace pq;
+
+#define CK(x)                                                                                  \
+    do {                                                                                       \
+        hipError_t e_ = (x);                                                                   \
+        if (e_ != hipSuccess) {                                                                \
+            std::fprintf(stderr, "%s:%d %s -> %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+            std::exit(1);                                                                      \
+        }                                                                                      \
+    } while (0)
+
+constexpr int SETS = 6;
+
+struct Bufs {
+    void* in[SETS];
+    void* out[SETS];
+};
+
+__global__ void fill_uniform(float* p, int64_t n, uint32_t seed) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t h = mix32(static_cast<uint32_t>(i) ^ seed);
+        p[i] = static_cast<float>(h >> 8) * (2.0f / 16777216.0f) - 1.0f;
+    }
+}
+
+// reference points: plain streaming kernels with the same traffic shape
+template <bool NT>
+__global__ void __launch_bounds__(256) copy_5B_kernel(const u32x4* __restrict__ in, uint32_t* __restrict__ out, int64_t nvec) {
+    // reads 16 B, writes 4 B per thread-iteration: the fp32->uint8 traffic ratio with no arithmetic
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        const u32x4 v = ld<NT>(in + i);
+        st<NT>(out + i, v[0] ^ v[1] ^ v[2] ^ v[3]);
+    }
+}
+
+template <bool NT>
+__global__ void __launch_bounds__(256) read_only_kernel(const u32x4* __restrict__ in, uint32_t* __restrict__ out, int64_t nvec) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    uint32_t acc = 0;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        const u32x4 v = ld<NT>(in + i);
+        acc ^= v[0] ^ v[1] ^ v[2] ^ v[3];
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+static hipStream_t g_stream;
+static int g_reps = 200;
+
+static double time_us(const std::function<void(int)>& launch) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (int i = 0; i < 20; ++i) launch(i);
+    CK(hipStreamSynchronize(g_stream));
+    CK(hipEventRecord(e0, g_stream));
+    for (int i = 0; i < g_reps; ++i) launch(i);
+    CK(hipEventRecord(e1, g_stream));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipGetLastError());
+    CK(hipEventDestroy(e0));
+    CK(hipEventDestroy(e1));
+    return ms * 1e3 / g_reps;
+}
+
+static void report(const char* family, const std::string& variant, double us, double bytes) {
+    std::printf("%s,%s,%.3f,%.1f,%.4f\n", family, variant.c_str(), us, bytes / us * 1e-3, bytes / us * 1e-3 / 8000.0);
+    std::fflush(stdout);
+}
+
+static QuantParams qparams() {
+    QuantParams p {};
+    p.inv_scale = 1.0f / 0.0078431377f;
+    p.zp32 = 127;
+    p.zp64 = 127;
+    p.threshold = 0.37f;
+    return p;
+}
+
+template <int DT_IN, int BITS, int MODE, int U, bool STAGE, bool NT, int BLOCK>
+static void run_quant(const Bufs& b, int64_t numel, int num_cu, double bytes_per_elem) {
+    using T = QuantTile<DT_IN, BITS, U, BLOCK>;
+    const int64_t n_tiles = numel / T::BLOCK_ELEMS;
+    const QuantParams p = qparams();
+    for (int cap : {0, 2, 4, 8, 16}) {
+        const int64_t g = cap == 0 ? n_tiles : std::min<int64_t>(n_tiles, static_cast<int64_t>(cap) * num_cu);
+        const unsigned grid = static_cast<unsigned>(std::max<int64_t>(g, 1));
+        const double us = time_us([&](int i) {
+            hipLaunchKernelGGL((quantize_kernel<DT_IN, BITS, MODE, U, STAGE, NT, BLOCK>), dim3(grid), dim3(BLOCK), 0, g_stream, b.in[i % SETS],
+                               static_cast<uint8_t*>(b.out[i % SETS]), numel, n_tiles, p);
+        });
+        char name[160];
+        std::snprintf(name, sizeof name, "in=%s bits=%d mode=%d U=%d stage=%d nt=%d block=%d cap=%d grid=%u", DT_IN == DT_F32 ? "f32" : "bf16", BITS, MODE, U,
+                      STAGE ? 1 : 0, NT ? 1 : 0, BLOCK, cap, grid);
+        report("quantize", name, us, bytes_per_elem * numel);
+    }
+}
+
+template <int BITS, int DT_OUT, int OP, int U, bool STAGE, bool NT, int BLOCK>
+static void run_dequant(const Bufs& b, int64_t numel, int num_cu, double bytes_per_elem) {
+    using T = DequantTile<BITS, DT_OUT, U, BLOCK>;
+    const int64_t n_tiles = numel / T::BLOCK_ELEMS;
+    DequantParams p {};
+    p.scale = 0.0078431377f;
+    p.zp32 = 127;
+    p.zp64 = 127;
+    p.bias = -127.0f * p.scale;
+    for (int cap : {0, 4, 8, 16}) {
+        const int64_t g = cap == 0 ? n_tiles : std::min<int64_t>(n_tiles, static_cast<int64_t>(cap) * num_cu);
+        const unsigned grid = static_cast<unsigned>(std::max<int64_t>(g, 1));
+        // roles swapped: the small buffer (b.out) is the packed input, the big one (b.in) the float output
+        const double us = time_us([&](int i) {
+            hipLaunchKernelGGL((dequantize_kernel<BITS, DT_OUT, OP, U, STAGE, NT, BLOCK>), dim3(grid), dim3(BLOCK), 0, g_stream,
+                               static_cast<const uint8_t*>(b.out[i % SETS]), b.in[i % SETS], numel, n_tiles, p);
+        });
+        char name[160];
+        std::snprintf(name, sizeof name, "bits=%d out=%s op=%d U=%d stage=%d nt=%d block=%d cap=%d grid=%u", BITS, DT_OUT == DT_F32 ? "f32" : "bf16", OP, U,
+                      STAGE ? 1 : 0, NT ? 1 : 0, BLOCK, cap, grid);
+        report("dequantize", name, us, bytes_per_elem * numel);
+    }
+}
+
+template <int DT_IN, int U, bool NT, int BLOCK>
+static void run_minmax(const Bufs& b, int64_t numel, int num_cu, int32_t* keys) {
+    for (int cap : {2, 4, 8, 16, 32}) {
+        const unsigned grid = static_cast<unsigned>(cap * num_cu);
+        const double us = time_us([&](int i) {
+            hipLaunchKernelGGL((minmax_kernel<DT_IN, U, NT, BLOCK>), dim3(grid), dim3(BLOCK), 0, g_stream, b.in[i % SETS], numel, keys);
+        });
+        char name[160];
+        std::snprintf(name, sizeof name, "in=%s U=%d nt=%d block=%d cap=%d grid=%u", DT_IN == DT_F32 ? "f32" : "bf16", U, NT ? 1 : 0, BLOCK, cap, grid);
+        report("minmax", name, us, (DT_IN == DT_F32 ? 4.0 : 2.0) * numel);
+    }
+}
+
+int main(int argc, char** argv) {
+    const int64_t numel = argc > 1 ? std::atoll(argv[1]) : 27264000;
+    g_reps = argc > 2 ? std::atoi(argv[2]) : 200;
+    const std::string only = argc > 3 ? argv[3] : "all";
+    int dev = 0, num_cu = 0;
+    CK(hipGetDevice(&dev));
+    CK(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    CK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, dev));
+    std::fprintf(stderr, "device %s, %d CUs, numel %lld, reps %d\n", prop.name, num_cu, static_cast<long long>(numel), g_reps);
+
+    Bufs b {};
+    for (int s = 0; s < SETS; ++s) {
+        CK(hipMalloc(&b.in[s], numel * 4 + 4096));
+        CK(hipMalloc(&b.out[s], numel + 4096));
+        hipLaunchKernelGGL(fill_uniform, dim3(4096), dim3(256), 0, g_stream, static_cast<float*>(b.in[s]), numel, 0x9e3779b9u * (s + 1));
+        CK(hipMemsetAsync(b.out[s], 0x5a, numel, g_stream));
+    }
+    int32_t* keys = nullptr;
+    CK(hipMalloc(reinterpret_cast<void**>(&keys), 8));
+    CK(hipMemsetAsync(keys, 0x7f, 8, g_stream));
+    CK(hipStreamSynchronize(g_stream));
+
+    std::printf("family,variant,us_per_launch,algo_GBps,frac_of_8TBps\n");
+
+    if (only == "all" || only == "ref") {
+        const int64_t nvec = numel / 4;
+        for (int cap : {0, 4, 8, 16, 32}) {
+            const unsigned grid = cap == 0 ? static_cast<unsigned>((nvec + 255) / 256) : static_cast<unsigned>(cap * num_cu);
+            double us = time_us([&](int i) {
+                hipLaunchKernelGGL((copy_5B_kernel<true>), dim3(grid), dim3(256), 0, g_stream, static_cast<const u32x4*>(b.in[i % SETS]),
+                                   static_cast<uint32_t*>(b.out[i % SETS]), nvec);
+            });
+            report("ref", "copy16to4 nt cap=" + std::to_string(cap), us, 5.0 * numel);
+            us = time_us([&](int i) {
+                hipLaunchKernelGGL((copy_5B_kernel<false>), dim3(grid), dim3(256), 0, g_stream, static_cast<const u32x4*>(b.in[i % SETS]),
+                                   static_cast<uint32_t*>(b.out[i % SETS]), nvec);
+            });
+            report("ref", "copy16to4 plain cap=" + std::to_string(cap), us, 5.0 * numel);
+            us = time_us([&](int i) {
+                hipLaunchKernelGGL((read_only_kernel<true>), dim3(grid), dim3(256), 0, g_stream, static_cast<const u32x4*>(b.in[i % SETS]),
+                                   static_cast<uint32_t*>(b.out[i % SETS]), nvec);
+            });
+            report("ref", "read_only nt cap=" + std::to_string(cap), us, 4.0 * numel);
+            us = time_us([&](int i) {
+                hipLaunchKernelGGL((read_only_kernel<false>), dim3(grid), dim3(256), 0, g_stream, static_cast<const u32x4*>(b.in[i % SETS]),
+                                   static_cast<uint32_t*>(b.out[i % SETS]), nvec);
+            });
+            report("ref", "read_only plain cap=" + std::to_string(cap), us, 4.0 * numel);
+        }
+    }
+
+    if (only == "all" || only == "q8") {
+        // headline: fp32 -> uint8 nearest
+        run_quant<DT_F32, 8, RM_NEAREST_FAST, 2, true, true, 256>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, true, 256>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_NEAREST_FAST, 8, true, true, 256>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, false, true, 256>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_NEAREST_FAST, 8, false, true, 256>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, false, 256>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, false, false, 256>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, true, 512>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, true, 1024>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_NEAREST_FAST, 2, true, true, 1024>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, true, 128>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_NEAREST_FAST, 8, true, true, 128>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, true, 64>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_NEAREST_FAST, 8, true, true, 64>(b, numel, num_cu, 5);
+    }
+    if (only == "all" || only == "qother") {
+        run_quant<DT_F32, 8, RM_STOCH_CALL, 4, true, true, 256>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_STOCH_ELEM, 4, true, true, 256>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 4, RM_NEAREST_FAST, 4, true, true, 256>(b, numel, num_cu, 4.5);
+        run_quant<DT_F32, 4, RM_NEAREST_FAST, 4, false, true, 256>(b, numel, num_cu, 4.5);
+        run_quant<DT_F32, 4, RM_NEAREST_FAST, 8, true, true, 256>(b, numel, num_cu, 4.5);
+        run_quant<DT_F32, 2, RM_NEAREST_I64, 4, true, true, 256>(b, numel, num_cu, 4.25);
+        // bf16 input: the same 109 MB buffer holds 2*numel bf16 values
+        run_quant<DT_BF16, 4, RM_NEAREST_FAST, 2, true, true, 256>(b, 2 * numel, num_cu, 2.5);
+        run_quant<DT_BF16, 4, RM_NEAREST_FAST, 4, true, true, 256>(b, 2 * numel, num_cu, 2.5);
+        run_quant<DT_BF16, 4, RM_NEAREST_FAST, 4, false, true, 256>(b, 2 * numel, num_cu, 2.5);
+        run_quant<DT_BF16, 4, RM_NEAREST_FAST, 8, true, true, 256>(b, 2 * numel, num_cu, 2.5);
+        run_quant<DT_BF16, 8, RM_NEAREST_FAST, 4, true, true, 256>(b, numel, num_cu, 3);
+        run_quant<DT_BF16, 2, RM_NEAREST_FAST, 4, true, true, 256>(b, 2 * numel, num_cu, 2.25);
+    }
+    if (only == "all" || only == "dq") {
+        run_dequant<8, DT_F32, OP_SET, 4, true, true, 256>(b, numel, num_cu, 5);
+        run_dequant<8, DT_F32, OP_SET, 4, false, true, 256>(b, numel, num_cu, 5);
+        run_dequant<8, DT_F32, OP_SET, 8, true, true, 256>(b, numel, num_cu, 5);
+        run_dequant<8, DT_F32, OP_SET, 4, true, false, 256>(b, numel, num_cu, 5);
+        run_dequant<8, DT_F32, OP_ADD, 4, true, true, 256>(b, numel, num_cu, 9);
+        run_dequant<8, DT_F32, OP_ADD, 4, false, true, 256>(b, numel, num_cu, 9);
+        run_dequant<8, DT_F32, OP_ADD, 8, true, true, 256>(b, numel, num_cu, 9);
+        run_dequant<8, DT_F32, OP_ADD, 4, true, false, 256>(b, numel, num_cu, 9);
+        run_dequant<4, DT_BF16, OP_SET, 4, true, true, 256>(b, 2 * numel, num_cu, 2.5);
+        run_dequant<4, DT_BF16, OP_SET, 4, false, true, 256>(b, 2 * numel, num_cu, 2.5);
+        run_dequant<4, DT_BF16, OP_SET, 8, true, true, 256>(b, 2 * numel, num_cu, 2.5);
+        run_dequant<4, DT_BF16, OP_ADD, 4, true, true, 256>(b, 2 * numel, num_cu, 4.5);
+        run_dequant<4, DT_F32, OP_SET, 4, true, true, 256>(b, numel, num_cu, 4.5);
+        run_dequant<2, DT_BF16, OP_SET, 4, true, true, 256>(b, 2 * numel, num_cu, 2.25);
+        run_dequant<2, DT_F32, OP_SET, 4, true, true, 256>(b, numel, num_cu, 4.25);
+    }
+    if (only == "all" || only == "mm") {
+        run_minmax<DT_F32, 2, true, 256>(b, numel, num_cu, keys);
+        run_minmax<DT_F32, 4, true, 256>(b, numel, num_cu, keys);
+        run_minmax<DT_F32, 8, true, 256>(b, numel, num_cu, keys);
+        run_minmax<DT_F32, 4, false, 256>(b, numel, num_cu, keys);
+        run_minmax<DT_F32, 4, true, 512>(b, numel, num_cu, keys);
+        run_minmax<DT_BF16, 4, true, 256>(b, 2 * numel, num_cu, keys);
+        run_minmax<DT_BF16, 8, true, 256>(b, 2 * numel, num_cu, keys);
+    }
+    return 0;
+}
