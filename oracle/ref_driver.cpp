@@ -13,9 +13,9 @@
 //
 // The driver calls  registry.quant_kernel(in, out, numel, descriptor)  on ONE contiguous range,
 // i.e. what the reference does per pool thread (src/piquant.cpp:159-169), so results correspond to
-// a reference context created with num_threads == 1.  ref_*_mt entry points re-apply the
-// reference's own static partition rule (src/piquant.cpp:145-157) over std::threads so that the
-// reference kernels can be timed on several host cores (bench.py cpu_baseline kind "reference").
+// a reference context created with num_threads == 1.  With threads > 1 the driver re-applies the
+// reference's own static partition rule (src/piquant.cpp:145-157) over a persistent std::thread pool so
+// that the reference kernels can be timed on several host cores (bench.py cpu_baseline kind "reference").
 
 #include <piquant.hpp>
 #include "piquant_internal.hpp"
@@ -24,6 +24,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -91,6 +94,62 @@ namespace {
         return len > 0;
     }
 
+    // Persistent worker pool (the reference keeps its pool threads alive between calls too,
+    // src/piquant.cpp:178-181); created on first use with the requested size, re-created if the size changes.
+    class Pool {
+    public:
+        void run(int threads, const std::function<void(int)>& job) {
+            std::unique_lock<std::mutex> lk(m_);
+            if (static_cast<int>(workers_.size()) != threads - 1) resize(lk, threads - 1);
+            job_ = &job;
+            pending_ = threads - 1;
+            ++generation_;
+            cv_start_.notify_all();
+            lk.unlock();
+            job(0);                                   // the caller is thread 0
+            lk.lock();
+            cv_done_.wait(lk, [&] { return pending_ == 0; });
+            job_ = nullptr;
+        }
+        ~Pool() {
+            std::unique_lock<std::mutex> lk(m_);
+            resize(lk, 0);
+        }
+    private:
+        void resize(std::unique_lock<std::mutex>& lk, int n) {
+            stop_ = true;
+            ++generation_;
+            cv_start_.notify_all();
+            lk.unlock();
+            for (auto& t : workers_) t.join();
+            lk.lock();
+            workers_.clear();
+            stop_ = false;
+            for (int i = 0; i < n; ++i) workers_.emplace_back([this, i, gen = generation_]() mutable { loop(i + 1, gen); });
+        }
+        void loop(int index, unsigned long seen) {
+            std::unique_lock<std::mutex> lk(m_);
+            for (;;) {
+                cv_start_.wait(lk, [&] { return generation_ != seen; });
+                seen = generation_;
+                if (stop_) return;
+                const auto* job = job_;
+                lk.unlock();
+                (*job)(index);
+                lk.lock();
+                if (--pending_ == 0) cv_done_.notify_one();
+            }
+        }
+        std::mutex m_;
+        std::condition_variable cv_start_, cv_done_;
+        std::vector<std::thread> workers_;
+        const std::function<void(int)>* job_ = nullptr;
+        unsigned long generation_ = 0;
+        int pending_ = 0;
+        bool stop_ = false;
+    };
+    Pool g_pool;
+
     void run_mt(const kernel_registry& reg, const desc_t& d, int threads) {
         const auto bits_in = static_cast<std::int64_t>(piquant::dtype_info_of(d.dt_in).bit_size);
         const auto bits_out = static_cast<std::int64_t>(piquant::dtype_info_of(d.dt_out).bit_size);
@@ -102,10 +161,7 @@ namespace {
             reg.quant_kernel(d.in + bits_in * b / 8, d.out + bits_out * b / 8, n, d);
         };
         if (threads <= 1) { job(0); return; }
-        std::vector<std::thread> pool;
-        pool.reserve(threads);
-        for (int t = 0; t < threads; ++t) pool.emplace_back(job, t);
-        for (auto& th : pool) th.join();
+        g_pool.run(threads, job);
     }
 }
 

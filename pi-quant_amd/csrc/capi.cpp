@@ -110,8 +110,11 @@ struct piquant_context_t {
     hipStream_t stage_stream[2] = {nullptr, nullptr};
     bool blocking = true;
 
-    int32_t* d_keys = nullptr;             // 2 x int32 on the device
-    int32_t* h_keys = nullptr;             // pinned mirror
+    // Two {min,-max} key pairs on the device.  compute_quant_params alternates between them: the scan that
+    // fills one pair re-arms the other (idle) one, so no memset launch precedes the scan.
+    int32_t* d_keys = nullptr;             // 4 x int32
+    int key_slot = 0;
+    int32_t* h_keys = nullptr;             // pinned mirror of the pair just read
 
     // device scratch for host-pointer calls, grown on demand
     void* stage_in[2] = {nullptr, nullptr};
@@ -171,7 +174,8 @@ piquant_context_t* piquant_context_create(size_t num_threads) {
     PQ_HIP(hipDeviceGetAttribute(&ctx->num_cu, hipDeviceAttributeMultiprocessorCount, ctx->device));
     PQ_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
-    PQ_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_keys), 2 * sizeof(int32_t)));
+    PQ_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_keys), 4 * sizeof(int32_t)));
+    PQ_HIP(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(ctx->d_keys), float_to_key(std::numeric_limits<float>::max()), 4));
     PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_keys), 2 * sizeof(int32_t), hipHostMallocDefault));
     std::random_device rd;
     ctx->rng.seed((static_cast<uint64_t>(rd()) << 32) ^ rd());
@@ -319,11 +323,9 @@ void piquant_dequantize(piquant_context_t* ctx, const void* in, piquant_dtype_t 
     for (auto& s : ctx->stage_stream) PQ_HIP(hipStreamSynchronize(s));
 }
 
-void piquant_hip_minmax_keys(piquant_context_t* ctx, const void* x, piquant_dtype_t dtype, size_t n, int32_t* device_keys, int init) {
-    if (!ctx) panic("piquant_hip_minmax_keys: context is NULL");
-    if (dtype != PIQUANT_DTYPE_F32 && dtype != PIQUANT_DTYPE_BF16) panic("min/max scan needs f32 or bf16 input, got %s", dtype_of(dtype).name);
-    if (!device_keys) panic("piquant_hip_minmax_keys: NULL key buffer");
-    if (n != 0 && !x) panic("piquant_hip_minmax_keys: NULL input");
+// Scan into `device_keys`.  init: 0 = accumulate, 1 = reset the keys first (memset node), reset_keys != nullptr =
+// the keys are known to be armed already and the scan re-arms `reset_keys` for later (internal fast path).
+static void minmax_into(piquant_context_t* ctx, const void* x, piquant_dtype_t dtype, size_t n, int32_t* device_keys, int init, int32_t* reset_keys) {
     std::lock_guard<std::mutex> lock(ctx->mu);
     DeviceGuard guard(ctx->device);
     // identity: key(+FLT_MAX) for min and for -max (reference kernels_specialized.inl:1422-1423)
@@ -331,7 +333,7 @@ void piquant_hip_minmax_keys(piquant_context_t* ctx, const void* x, piquant_dtyp
     if (n == 0) return;
     const Resolved r = resolve(x);
     if (!r.pageable) {
-        launch_minmax(r.dev, dtype, static_cast<int64_t>(n), device_keys, ctx->stream, ctx->num_cu);
+        launch_minmax(r.dev, dtype, static_cast<int64_t>(n), device_keys, reset_keys, ctx->stream, ctx->num_cu);
         return;
     }
     // host input: stream it through device scratch, all chunks fold into the same two keys
@@ -343,9 +345,17 @@ void piquant_hip_minmax_keys(piquant_context_t* ctx, const void* x, piquant_dtyp
         const size_t m = std::min(chunk, n - off);
         hipStream_t s = ctx->stage_stream[slot];
         PQ_HIP(hipMemcpyAsync(ctx->stage_in[slot], static_cast<const char*>(x) + span_bytes(off, dtype), span_bytes(m, dtype), hipMemcpyHostToDevice, s));
-        launch_minmax(ctx->stage_in[slot], dtype, static_cast<int64_t>(m), device_keys, s, ctx->num_cu);
+        launch_minmax(ctx->stage_in[slot], dtype, static_cast<int64_t>(m), device_keys, off == 0 ? reset_keys : nullptr, s, ctx->num_cu);
     }
     for (auto& s : ctx->stage_stream) PQ_HIP(hipStreamSynchronize(s));
+}
+
+void piquant_hip_minmax_keys(piquant_context_t* ctx, const void* x, piquant_dtype_t dtype, size_t n, int32_t* device_keys, int init) {
+    if (!ctx) panic("piquant_hip_minmax_keys: context is NULL");
+    if (dtype != PIQUANT_DTYPE_F32 && dtype != PIQUANT_DTYPE_BF16) panic("min/max scan needs f32 or bf16 input, got %s", dtype_of(dtype).name);
+    if (!device_keys) panic("piquant_hip_minmax_keys: NULL key buffer");
+    if (n != 0 && !x) panic("piquant_hip_minmax_keys: NULL input");
+    minmax_into(ctx, x, dtype, n, device_keys, init, nullptr);
 }
 
 void piquant_hip_decode_minmax_keys(const int32_t keys[2], float* out_min, float* out_max) {
@@ -378,11 +388,17 @@ static void compute_params(piquant_context_t* ctx, const void* x, piquant_dtype_
     if (!ctx) panic("piquant_compute_quant_params: context is NULL");
     if (!out_scale || !out_zero_point) panic("piquant_compute_quant_params: NULL result pointer");
     if (!dtype_of(target).quant) panic("type %s is not a quantization type", dtype_of(target).name);
-    piquant_hip_minmax_keys(ctx, x, dt, n, ctx->d_keys, 1);
-    {
+    if (n != 0 && !x) panic("piquant_compute_quant_params: NULL input");
+    if (n == 0) {   // nothing to scan: the identities (reference kernels_specialized.inl:1422-1423)
+        ctx->h_keys[0] = ctx->h_keys[1] = float_to_key(std::numeric_limits<float>::max());
+    } else {
+        int32_t* cur = ctx->d_keys + 2 * ctx->key_slot;
+        int32_t* idle = ctx->d_keys + 2 * (ctx->key_slot ^ 1);
+        ctx->key_slot ^= 1;
+        minmax_into(ctx, x, dt, n, cur, 0, idle);   // `cur` was armed by the previous call (or at creation)
         std::lock_guard<std::mutex> lock(ctx->mu);
         DeviceGuard guard(ctx->device);
-        PQ_HIP(hipMemcpyAsync(ctx->h_keys, ctx->d_keys, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        PQ_HIP(hipMemcpyAsync(ctx->h_keys, cur, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
         PQ_HIP(hipStreamSynchronize(ctx->stream));
     }
     float lo, hi;

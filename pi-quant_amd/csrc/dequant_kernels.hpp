@@ -55,13 +55,14 @@ struct DequantTile {
     static constexpr int64_t BLOCK_ELEMS = static_cast<int64_t>(WAVES) * WAVE_VECS * EPV;
 };
 
-template <int BITS, int DT_OUT, int OP, int U, bool STAGE, bool NT, int BLOCK>
+template <int BITS, int DT_OUT, int OP, int U, bool STAGE, int NT, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int64_t n_tiles, DequantParams p) {
     using T = DequantTile<BITS, DT_OUT, U, BLOCK>;
     constexpr int EPV = T::EPV, IB = T::IB;
     constexpr int WORDS = IB > 4 ? 2 : 1;
     constexpr int FORM = DequantForm<BITS, DT_OUT>::value;
+    constexpr bool NT_LD = (NT & 1) != 0, NT_ST = (NT & 2) != 0;   // non-temporal loads / stores
 
     __shared__ __attribute__((aligned(16))) uint8_t lds[STAGE ? T::WAVES * T::WAVE_IN_BYTES : 16];
 
@@ -76,7 +77,7 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
         u32x4 old[OP == OP_ADD ? U : 1];
         if constexpr (OP == OP_ADD) {
 #pragma unroll
-            for (int k = 0; k < U; ++k) old[k] = ld<NT>(out16 + v0 + k * 64 + lane);
+            for (int k = 0; k < U; ++k) old[k] = ld<NT_LD>(out16 + v0 + k * 64 + lane);
         }
 
         uint32_t w[U][WORDS];
@@ -84,11 +85,11 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
 #pragma unroll
             for (int k = 0; k < U; ++k) {
                 const uint8_t* s = src + static_cast<int64_t>(k * 64 + lane) * IB;
-                if constexpr (IB == 1) w[k][0] = ld<NT>(s);
-                else if constexpr (IB == 2) w[k][0] = ld<NT>(reinterpret_cast<const uint16_t*>(s));
-                else if constexpr (IB == 4) w[k][0] = ld<NT>(reinterpret_cast<const uint32_t*>(s));
+                if constexpr (IB == 1) w[k][0] = ld<NT_LD>(s);
+                else if constexpr (IB == 2) w[k][0] = ld<NT_LD>(reinterpret_cast<const uint16_t*>(s));
+                else if constexpr (IB == 4) w[k][0] = ld<NT_LD>(reinterpret_cast<const uint32_t*>(s));
                 else {
-                    const u32x2 t = ld<NT>(reinterpret_cast<const u32x2*>(s));
+                    const u32x2 t = ld<NT_LD>(reinterpret_cast<const u32x2*>(s));
                     w[k][0] = t[0];
                     w[k][WORDS - 1] = t[1];
                 }
@@ -98,13 +99,13 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
             if constexpr (T::LANE_IN_BYTES >= 16) {
 #pragma unroll
                 for (int j = 0; j < T::LANE_IN_BYTES / 16; ++j)
-                    reinterpret_cast<u32x4*>(s)[j * 64 + lane] = ld<NT>(reinterpret_cast<const u32x4*>(src) + j * 64 + lane);
+                    reinterpret_cast<u32x4*>(s)[j * 64 + lane] = ld<NT_LD>(reinterpret_cast<const u32x4*>(src) + j * 64 + lane);
             } else if constexpr (T::LANE_IN_BYTES == 8) {
-                reinterpret_cast<u32x2*>(s)[lane] = ld<NT>(reinterpret_cast<const u32x2*>(src) + lane);
+                reinterpret_cast<u32x2*>(s)[lane] = ld<NT_LD>(reinterpret_cast<const u32x2*>(src) + lane);
             } else if constexpr (T::LANE_IN_BYTES == 4) {
-                reinterpret_cast<uint32_t*>(s)[lane] = ld<NT>(reinterpret_cast<const uint32_t*>(src) + lane);
+                reinterpret_cast<uint32_t*>(s)[lane] = ld<NT_LD>(reinterpret_cast<const uint32_t*>(src) + lane);
             } else {
-                reinterpret_cast<uint16_t*>(s)[lane] = ld<NT>(reinterpret_cast<const uint16_t*>(src) + lane);
+                reinterpret_cast<uint16_t*>(s)[lane] = ld<NT_LD>(reinterpret_cast<const uint16_t*>(src) + lane);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -150,7 +151,7 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
                     r[e] = f32_to_bf16_bits(f[2 * e]) | (f32_to_bf16_bits(f[2 * e + 1]) << 16);
                 }
             }
-            st<NT>(out16 + v0 + k * 64 + lane, r);
+            st<NT_ST>(out16 + v0 + k * 64 + lane, r);
         }
     }
 

@@ -103,16 +103,16 @@ void dequantize_out(const DequantLaunch& d, const DequantParams& p, hipStream_t 
 }
 
 template <int DT_IN>
-void minmax_t(const void* in, int64_t numel, int32_t* keys, hipStream_t stream, int num_cu) {
+void minmax_t(const void* in, int64_t numel, int32_t* keys, int32_t* reset_keys, hipStream_t stream, int num_cu) {
     constexpr int EPV = InVec<DT_IN>::EPV;
     if (!aligned16(in)) {
         const unsigned grid = capped_grid((numel + kBlock - 1) / kBlock, kMinmaxBlocksPerCU, num_cu);
-        hipLaunchKernelGGL((minmax_scalar_kernel<DT_IN, kBlock>), dim3(grid), dim3(kBlock), 0, stream, in, numel, keys);
+        hipLaunchKernelGGL((minmax_scalar_kernel<DT_IN, kBlock>), dim3(grid), dim3(kBlock), 0, stream, in, numel, keys, reset_keys);
         return;
     }
     const int64_t per_block = static_cast<int64_t>(kBlock) * kMinmaxU * EPV;
     const unsigned grid = capped_grid((numel + per_block - 1) / per_block, kMinmaxBlocksPerCU, num_cu);
-    hipLaunchKernelGGL((minmax_kernel<DT_IN, kMinmaxU, kMinmaxNT, kBlock>), dim3(grid), dim3(kBlock), 0, stream, in, numel, keys);
+    hipLaunchKernelGGL((minmax_kernel<DT_IN, kMinmaxU, kMinmaxNT, kBlock>), dim3(grid), dim3(kBlock), 0, stream, in, numel, keys, reset_keys);
 }
 
 }  // namespace
@@ -151,11 +151,11 @@ void launch_dequantize(const DequantLaunch& d, hipStream_t stream, int num_cu) {
     PQ_HIP(hipGetLastError());
 }
 
-void launch_minmax(const void* in, int dt_in, int64_t numel, int32_t* device_keys, hipStream_t stream, int num_cu) {
+void launch_minmax(const void* in, int dt_in, int64_t numel, int32_t* device_keys, int32_t* reset_keys, hipStream_t stream, int num_cu) {
     if (numel <= 0) return;
     switch (dt_in) {
-        case DT_F32: minmax_t<DT_F32>(in, numel, device_keys, stream, num_cu); break;
-        case DT_BF16: minmax_t<DT_BF16>(in, numel, device_keys, stream, num_cu); break;
+        case DT_F32: minmax_t<DT_F32>(in, numel, device_keys, reset_keys, stream, num_cu); break;
+        case DT_BF16: minmax_t<DT_BF16>(in, numel, device_keys, reset_keys, stream, num_cu); break;
         default: panic("min/max scan needs a float dtype, got %d", dt_in);
     }
     PQ_HIP(hipGetLastError());

@@ -35,7 +35,8 @@ struct DequantLaunch {
 // All launches are asynchronous on `stream`; num_cu sizes capped grids.
 void launch_quantize(const QuantLaunch& q, hipStream_t stream, int num_cu);
 void launch_dequantize(const DequantLaunch& d, hipStream_t stream, int num_cu);
-void launch_minmax(const void* in, int dt_in, int64_t numel, int32_t* device_keys, hipStream_t stream, int num_cu);
+// reset_keys (nullable): a second, idle key pair that block 0 re-initialises to the identity for a later call.
+void launch_minmax(const void* in, int dt_in, int64_t numel, int32_t* device_keys, int32_t* reset_keys, hipStream_t stream, int num_cu);
 
 // Aborts with the reference's panic convention (red message on stderr, abort()) on a HIP error.
 void check_hip(hipError_t e, const char* what, const char* file, int line);

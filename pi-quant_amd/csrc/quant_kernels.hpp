@@ -96,12 +96,13 @@ struct QuantTile {
     static constexpr int64_t BLOCK_ELEMS = static_cast<int64_t>(WAVES) * WAVE_VECS * EPV;
 };
 
-template <int DT_IN, int BITS, int MODE, int U, bool STAGE, bool NT, int BLOCK>
+template <int DT_IN, int BITS, int MODE, int U, bool STAGE, int NT, int BLOCK, bool XCD = false>
 __global__ void __launch_bounds__(BLOCK)
 quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t numel, int64_t n_tiles, QuantParams p) {
     using T = QuantTile<DT_IN, BITS, U, BLOCK>;
     constexpr int EPV = T::EPV, OB = T::OB, QMAX = (1 << BITS) - 1;
     constexpr int WORDS = OB > 4 ? 2 : 1;
+    constexpr bool NT_LD = (NT & 1) != 0, NT_ST = (NT & 2) != 0;   // non-temporal loads / stores
 
     __shared__ __attribute__((aligned(16))) uint8_t lds[STAGE ? T::WAVES * T::WAVE_OUT_BYTES : 16];
 
@@ -109,12 +110,20 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
     const int wave = threadIdx.x >> 6;
     const u32x4* __restrict__ in16 = static_cast<const u32x4*>(in);
 
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // XCD: blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8); with the remap each XCD
+    // streams one contiguous eighth of the tensor instead of every eighth tile (a speed experiment only).
+    const int64_t per_xcd = (n_tiles + 7) / 8;
+    const int64_t t_first = XCD ? (blockIdx.x >> 3) : blockIdx.x;
+    const int64_t t_step = XCD ? (gridDim.x >> 3) : gridDim.x;
+    const int64_t t_end = XCD ? per_xcd : n_tiles;
+    for (int64_t t = t_first; t < t_end; t += t_step) {
+        const int64_t tile = XCD ? (blockIdx.x & 7) * per_xcd + t : t;
+        if (XCD && tile >= n_tiles) break;
         const int64_t v0 = (tile * T::WAVES + wave) * T::WAVE_VECS;   // first input vector of this wave tile
 
         u32x4 raw[U];
 #pragma unroll
-        for (int k = 0; k < U; ++k) raw[k] = ld<NT>(in16 + v0 + k * 64 + lane);
+        for (int k = 0; k < U; ++k) raw[k] = ld<NT_LD>(in16 + v0 + k * 64 + lane);
 
         uint32_t w[U][WORDS];
 #pragma unroll
@@ -136,10 +145,10 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
 #pragma unroll
             for (int k = 0; k < U; ++k) {
                 uint8_t* dst = o + static_cast<int64_t>(k * 64 + lane) * OB;
-                if constexpr (OB == 1) st<NT>(dst, static_cast<uint8_t>(w[k][0]));
-                else if constexpr (OB == 2) st<NT>(reinterpret_cast<uint16_t*>(dst), static_cast<uint16_t>(w[k][0]));
-                else if constexpr (OB == 4) st<NT>(reinterpret_cast<uint32_t*>(dst), w[k][0]);
-                else st<NT>(reinterpret_cast<u32x2*>(dst), u32x2{w[k][0], w[k][1]});
+                if constexpr (OB == 1) st<NT_ST>(dst, static_cast<uint8_t>(w[k][0]));
+                else if constexpr (OB == 2) st<NT_ST>(reinterpret_cast<uint16_t*>(dst), static_cast<uint16_t>(w[k][0]));
+                else if constexpr (OB == 4) st<NT_ST>(reinterpret_cast<uint32_t*>(dst), w[k][0]);
+                else st<NT_ST>(reinterpret_cast<u32x2*>(dst), u32x2{w[k][0], w[k][1]});
             }
         } else {
             uint8_t* s = lds + wave * T::WAVE_OUT_BYTES;
@@ -158,14 +167,14 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
 #pragma unroll
                 for (int j = 0; j < T::LANE_OUT_BYTES / 16; ++j) {
                     const u32x4 r = reinterpret_cast<const u32x4*>(s)[j * 64 + lane];
-                    st<NT>(reinterpret_cast<u32x4*>(o) + j * 64 + lane, r);
+                    st<NT_ST>(reinterpret_cast<u32x4*>(o) + j * 64 + lane, r);
                 }
             } else if constexpr (T::LANE_OUT_BYTES == 8) {
-                st<NT>(reinterpret_cast<u32x2*>(o) + lane, reinterpret_cast<const u32x2*>(s)[lane]);
+                st<NT_ST>(reinterpret_cast<u32x2*>(o) + lane, reinterpret_cast<const u32x2*>(s)[lane]);
             } else if constexpr (T::LANE_OUT_BYTES == 4) {
-                st<NT>(reinterpret_cast<uint32_t*>(o) + lane, reinterpret_cast<const uint32_t*>(s)[lane]);
+                st<NT_ST>(reinterpret_cast<uint32_t*>(o) + lane, reinterpret_cast<const uint32_t*>(s)[lane]);
             } else {
-                st<NT>(reinterpret_cast<uint16_t*>(o) + lane, reinterpret_cast<const uint16_t*>(s)[lane]);
+                st<NT_ST>(reinterpret_cast<uint16_t*>(o) + lane, reinterpret_cast<const uint16_t*>(s)[lane]);
             }
             // the next iteration's LDS writes must not pass this iteration's reads
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -7,7 +7,7 @@ namespace pq {
 struct KernelTune {
     int u;             // 16-byte vectors in flight per lane per tile
     bool stage;        // transpose the narrow side through LDS for 16-byte accesses
-    bool nt;           // non-temporal (streaming) loads and stores
+    int nt;            // bit 0: non-temporal loads, bit 1: non-temporal stores
     int blocks_per_cu; // grid cap = blocks_per_cu * CU count (grid-stride beyond); 0 = one tile per block
 };
 
@@ -15,14 +15,14 @@ constexpr int kBlock = 256;
 
 // quantize, indexed [dt_in: f32,bf16][bits: 8,4,2]
 constexpr KernelTune kQuantTune[2][3] = {
-    {{4, true, true, 0}, {4, true, true, 0}, {4, true, true, 0}},
-    {{4, true, true, 0}, {4, true, true, 0}, {4, true, true, 0}},
+    {{4, true, 3, 0}, {4, true, 3, 0}, {4, true, 3, 0}},
+    {{4, true, 3, 0}, {4, true, 3, 0}, {4, true, 3, 0}},
 };
 
 // dequantize, indexed [dt_out: f32,bf16][bits: 8,4,2]
 constexpr KernelTune kDequantTune[2][3] = {
-    {{4, true, true, 0}, {4, true, true, 0}, {4, true, true, 0}},
-    {{4, true, true, 0}, {4, true, true, 0}, {4, true, true, 0}},
+    {{4, true, 3, 0}, {4, true, 3, 0}, {4, true, 3, 0}},
+    {{4, true, 3, 0}, {4, true, 3, 0}, {4, true, 3, 0}},
 };
 
 // min/max scan

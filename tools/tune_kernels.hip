@@ -64,29 +64,53 @@ __global__ void __launch_bounds__(256) read_only_kernel(const u32x4* __restrict_
     if (acc == 0x12345678u) out[0] = acc;
 }
 
+template <bool NT>
+__global__ void __launch_bounds__(256) write_only_kernel(u32x4* __restrict__ out, int64_t nvec) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < nvec; i += stride)
+        st<NT>(out + i, u32x4{static_cast<uint32_t>(i), 1u, 2u, 3u});
+}
+
+template <bool NT>
+__global__ void __launch_bounds__(256) copy_16B_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, int64_t nvec) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < nvec; i += stride) st<NT>(out + i, ld<NT>(in + i));
+}
+
 static hipStream_t g_stream;
 static int g_reps = 200;
 
+static int g_rounds = 3;
+static double g_last_max = 0;
+
+// best (minimum) of g_rounds timed batches; the slowest batch is kept in g_last_max as a noise indicator
 static double time_us(const std::function<void(int)>& launch) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     for (int i = 0; i < 20; ++i) launch(i);
     CK(hipStreamSynchronize(g_stream));
-    CK(hipEventRecord(e0, g_stream));
-    for (int i = 0; i < g_reps; ++i) launch(i);
-    CK(hipEventRecord(e1, g_stream));
-    CK(hipEventSynchronize(e1));
-    float ms = 0;
-    CK(hipEventElapsedTime(&ms, e0, e1));
+    double best = 1e30, worst = 0;
+    for (int r = 0; r < g_rounds; ++r) {
+        CK(hipEventRecord(e0, g_stream));
+        for (int i = 0; i < g_reps; ++i) launch(i);
+        CK(hipEventRecord(e1, g_stream));
+        CK(hipEventSynchronize(e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1e3 / g_reps;
+        best = std::min(best, us);
+        worst = std::max(worst, us);
+    }
     CK(hipGetLastError());
     CK(hipEventDestroy(e0));
     CK(hipEventDestroy(e1));
-    return ms * 1e3 / g_reps;
+    g_last_max = worst;
+    return best;
 }
 
 static void report(const char* family, const std::string& variant, double us, double bytes) {
-    std::printf("%s,%s,%.3f,%.1f,%.4f\n", family, variant.c_str(), us, bytes / us * 1e-3, bytes / us * 1e-3 / 8000.0);
+    std::printf("%s,%s,%.3f,%.1f,%.4f,%.3f\n", family, variant.c_str(), us, bytes / us * 1e-3, bytes / us * 1e-3 / 8000.0, g_last_max);
     std::fflush(stdout);
 }
 
@@ -99,26 +123,27 @@ static QuantParams qparams() {
     return p;
 }
 
-template <int DT_IN, int BITS, int MODE, int U, bool STAGE, bool NT, int BLOCK>
+template <int DT_IN, int BITS, int MODE, int U, bool STAGE, int NT, int BLOCK, bool XCD = false>
 static void run_quant(const Bufs& b, int64_t numel, int num_cu, double bytes_per_elem) {
     using T = QuantTile<DT_IN, BITS, U, BLOCK>;
     const int64_t n_tiles = numel / T::BLOCK_ELEMS;
     const QuantParams p = qparams();
     for (int cap : {0, 2, 4, 8, 16}) {
-        const int64_t g = cap == 0 ? n_tiles : std::min<int64_t>(n_tiles, static_cast<int64_t>(cap) * num_cu);
+        int64_t g = cap == 0 ? n_tiles : std::min<int64_t>(n_tiles, static_cast<int64_t>(cap) * num_cu);
+        if (XCD) g = cap == 0 ? 8 * ((n_tiles + 7) / 8) : (g + 7) / 8 * 8;
         const unsigned grid = static_cast<unsigned>(std::max<int64_t>(g, 1));
         const double us = time_us([&](int i) {
-            hipLaunchKernelGGL((quantize_kernel<DT_IN, BITS, MODE, U, STAGE, NT, BLOCK>), dim3(grid), dim3(BLOCK), 0, g_stream, b.in[i % SETS],
+            hipLaunchKernelGGL((quantize_kernel<DT_IN, BITS, MODE, U, STAGE, NT, BLOCK, XCD>), dim3(grid), dim3(BLOCK), 0, g_stream, b.in[i % SETS],
                                static_cast<uint8_t*>(b.out[i % SETS]), numel, n_tiles, p);
         });
         char name[160];
-        std::snprintf(name, sizeof name, "in=%s bits=%d mode=%d U=%d stage=%d nt=%d block=%d cap=%d grid=%u", DT_IN == DT_F32 ? "f32" : "bf16", BITS, MODE, U,
-                      STAGE ? 1 : 0, NT ? 1 : 0, BLOCK, cap, grid);
+        std::snprintf(name, sizeof name, "in=%s bits=%d mode=%d U=%d stage=%d nt=%d block=%d xcd=%d cap=%d grid=%u", DT_IN == DT_F32 ? "f32" : "bf16", BITS, MODE, U,
+                      STAGE ? 1 : 0, NT, BLOCK, XCD ? 1 : 0, cap, grid);
         report("quantize", name, us, bytes_per_elem * numel);
     }
 }
 
-template <int BITS, int DT_OUT, int OP, int U, bool STAGE, bool NT, int BLOCK>
+template <int BITS, int DT_OUT, int OP, int U, bool STAGE, int NT, int BLOCK>
 static void run_dequant(const Bufs& b, int64_t numel, int num_cu, double bytes_per_elem) {
     using T = DequantTile<BITS, DT_OUT, U, BLOCK>;
     const int64_t n_tiles = numel / T::BLOCK_ELEMS;
@@ -137,7 +162,7 @@ static void run_dequant(const Bufs& b, int64_t numel, int num_cu, double bytes_p
         });
         char name[160];
         std::snprintf(name, sizeof name, "bits=%d out=%s op=%d U=%d stage=%d nt=%d block=%d cap=%d grid=%u", BITS, DT_OUT == DT_F32 ? "f32" : "bf16", OP, U,
-                      STAGE ? 1 : 0, NT ? 1 : 0, BLOCK, cap, grid);
+                      STAGE ? 1 : 0, NT, BLOCK, cap, grid);
         report("dequantize", name, us, bytes_per_elem * numel);
     }
 }
@@ -147,7 +172,7 @@ static void run_minmax(const Bufs& b, int64_t numel, int num_cu, int32_t* keys) 
     for (int cap : {2, 4, 8, 16, 32}) {
         const unsigned grid = static_cast<unsigned>(cap * num_cu);
         const double us = time_us([&](int i) {
-            hipLaunchKernelGGL((minmax_kernel<DT_IN, U, NT, BLOCK>), dim3(grid), dim3(BLOCK), 0, g_stream, b.in[i % SETS], numel, keys);
+            hipLaunchKernelGGL((minmax_kernel<DT_IN, U, NT, BLOCK>), dim3(grid), dim3(BLOCK), 0, g_stream, b.in[i % SETS], numel, keys, static_cast<int32_t*>(nullptr));
         });
         char name[160];
         std::snprintf(name, sizeof name, "in=%s U=%d nt=%d block=%d cap=%d grid=%u", DT_IN == DT_F32 ? "f32" : "bf16", U, NT ? 1 : 0, BLOCK, cap, grid);
@@ -179,7 +204,7 @@ int main(int argc, char** argv) {
     CK(hipMemsetAsync(keys, 0x7f, 8, g_stream));
     CK(hipStreamSynchronize(g_stream));
 
-    std::printf("family,variant,us_per_launch,algo_GBps,frac_of_8TBps\n");
+    std::printf("family,variant,us_per_launch_best,algo_GBps,frac_of_8TBps,us_per_launch_worst\n");
 
     if (only == "all" || only == "ref") {
         const int64_t nvec = numel / 4;
@@ -205,57 +230,75 @@ int main(int argc, char** argv) {
                                    static_cast<uint32_t*>(b.out[i % SETS]), nvec);
             });
             report("ref", "read_only plain cap=" + std::to_string(cap), us, 4.0 * numel);
+            // write-only: fills the big buffer; copy 16->16: first half of the big buffer into its second half
+            us = time_us([&](int i) {
+                hipLaunchKernelGGL((write_only_kernel<true>), dim3(grid), dim3(256), 0, g_stream, static_cast<u32x4*>(b.in[i % SETS]), nvec);
+            });
+            report("ref", "write_only nt cap=" + std::to_string(cap), us, 4.0 * numel);
+            us = time_us([&](int i) {
+                hipLaunchKernelGGL((copy_16B_kernel<true>), dim3(grid), dim3(256), 0, g_stream, static_cast<const u32x4*>(b.in[i % SETS]),
+                                   static_cast<u32x4*>(b.in[i % SETS]) + nvec / 2, nvec / 2);
+            });
+            report("ref", "copy16to16 nt cap=" + std::to_string(cap), us, 4.0 * numel);
         }
     }
 
+    // the write-only reference kernels clobbered the inputs: restore U(-1,1) data (values affect power/clock)
+    for (int s = 0; s < SETS; ++s)
+        hipLaunchKernelGGL(fill_uniform, dim3(4096), dim3(256), 0, g_stream, static_cast<float*>(b.in[s]), numel, 0x9e3779b9u * (s + 1));
+    CK(hipStreamSynchronize(g_stream));
+
     if (only == "all" || only == "q8") {
         // headline: fp32 -> uint8 nearest
-        run_quant<DT_F32, 8, RM_NEAREST_FAST, 2, true, true, 256>(b, numel, num_cu, 5);
-        run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, true, 256>(b, numel, num_cu, 5);
-        run_quant<DT_F32, 8, RM_NEAREST_FAST, 8, true, true, 256>(b, numel, num_cu, 5);
-        run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, false, true, 256>(b, numel, num_cu, 5);
-        run_quant<DT_F32, 8, RM_NEAREST_FAST, 8, false, true, 256>(b, numel, num_cu, 5);
-        run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, false, 256>(b, numel, num_cu, 5);
-        run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, false, false, 256>(b, numel, num_cu, 5);
-        run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, true, 512>(b, numel, num_cu, 5);
-        run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, true, 1024>(b, numel, num_cu, 5);
-        run_quant<DT_F32, 8, RM_NEAREST_FAST, 2, true, true, 1024>(b, numel, num_cu, 5);
-        run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, true, 128>(b, numel, num_cu, 5);
-        run_quant<DT_F32, 8, RM_NEAREST_FAST, 8, true, true, 128>(b, numel, num_cu, 5);
-        run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, true, 64>(b, numel, num_cu, 5);
-        run_quant<DT_F32, 8, RM_NEAREST_FAST, 8, true, true, 64>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, 3, 256>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, 1, 256>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, 2, 256>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, 0, 256>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, false, 3, 256>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_NEAREST_FAST, 2, true, 3, 256>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_NEAREST_FAST, 8, true, 3, 256>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, 3, 256, true>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_NEAREST_FAST, 2, true, 3, 1024, true>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, 3, 512>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_NEAREST_FAST, 2, true, 3, 512>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, 3, 1024>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_NEAREST_FAST, 2, true, 3, 1024>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_NEAREST_FAST, 1, true, 3, 1024>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, 3, 128>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, 3, 64>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_NEAREST_FAST, 8, true, 3, 64>(b, numel, num_cu, 5);
     }
     if (only == "all" || only == "qother") {
-        run_quant<DT_F32, 8, RM_STOCH_CALL, 4, true, true, 256>(b, numel, num_cu, 5);
-        run_quant<DT_F32, 8, RM_STOCH_ELEM, 4, true, true, 256>(b, numel, num_cu, 5);
-        run_quant<DT_F32, 4, RM_NEAREST_FAST, 4, true, true, 256>(b, numel, num_cu, 4.5);
-        run_quant<DT_F32, 4, RM_NEAREST_FAST, 4, false, true, 256>(b, numel, num_cu, 4.5);
-        run_quant<DT_F32, 4, RM_NEAREST_FAST, 8, true, true, 256>(b, numel, num_cu, 4.5);
-        run_quant<DT_F32, 2, RM_NEAREST_I64, 4, true, true, 256>(b, numel, num_cu, 4.25);
+        run_quant<DT_F32, 8, RM_STOCH_CALL, 4, true, 3, 256>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 8, RM_STOCH_ELEM, 4, true, 3, 256>(b, numel, num_cu, 5);
+        run_quant<DT_F32, 4, RM_NEAREST_FAST, 4, true, 3, 256>(b, numel, num_cu, 4.5);
+        run_quant<DT_F32, 4, RM_NEAREST_FAST, 4, false, 3, 256>(b, numel, num_cu, 4.5);
+        run_quant<DT_F32, 4, RM_NEAREST_FAST, 8, true, 3, 256>(b, numel, num_cu, 4.5);
+        run_quant<DT_F32, 2, RM_NEAREST_I64, 4, true, 3, 256>(b, numel, num_cu, 4.25);
         // bf16 input: the same 109 MB buffer holds 2*numel bf16 values
-        run_quant<DT_BF16, 4, RM_NEAREST_FAST, 2, true, true, 256>(b, 2 * numel, num_cu, 2.5);
-        run_quant<DT_BF16, 4, RM_NEAREST_FAST, 4, true, true, 256>(b, 2 * numel, num_cu, 2.5);
-        run_quant<DT_BF16, 4, RM_NEAREST_FAST, 4, false, true, 256>(b, 2 * numel, num_cu, 2.5);
-        run_quant<DT_BF16, 4, RM_NEAREST_FAST, 8, true, true, 256>(b, 2 * numel, num_cu, 2.5);
-        run_quant<DT_BF16, 8, RM_NEAREST_FAST, 4, true, true, 256>(b, numel, num_cu, 3);
-        run_quant<DT_BF16, 2, RM_NEAREST_FAST, 4, true, true, 256>(b, 2 * numel, num_cu, 2.25);
+        run_quant<DT_BF16, 4, RM_NEAREST_FAST, 2, true, 3, 256>(b, 2 * numel, num_cu, 2.5);
+        run_quant<DT_BF16, 4, RM_NEAREST_FAST, 4, true, 3, 256>(b, 2 * numel, num_cu, 2.5);
+        run_quant<DT_BF16, 4, RM_NEAREST_FAST, 4, false, 3, 256>(b, 2 * numel, num_cu, 2.5);
+        run_quant<DT_BF16, 4, RM_NEAREST_FAST, 8, true, 3, 256>(b, 2 * numel, num_cu, 2.5);
+        run_quant<DT_BF16, 8, RM_NEAREST_FAST, 4, true, 3, 256>(b, numel, num_cu, 3);
+        run_quant<DT_BF16, 2, RM_NEAREST_FAST, 4, true, 3, 256>(b, 2 * numel, num_cu, 2.25);
     }
     if (only == "all" || only == "dq") {
-        run_dequant<8, DT_F32, OP_SET, 4, true, true, 256>(b, numel, num_cu, 5);
-        run_dequant<8, DT_F32, OP_SET, 4, false, true, 256>(b, numel, num_cu, 5);
-        run_dequant<8, DT_F32, OP_SET, 8, true, true, 256>(b, numel, num_cu, 5);
-        run_dequant<8, DT_F32, OP_SET, 4, true, false, 256>(b, numel, num_cu, 5);
-        run_dequant<8, DT_F32, OP_ADD, 4, true, true, 256>(b, numel, num_cu, 9);
-        run_dequant<8, DT_F32, OP_ADD, 4, false, true, 256>(b, numel, num_cu, 9);
-        run_dequant<8, DT_F32, OP_ADD, 8, true, true, 256>(b, numel, num_cu, 9);
-        run_dequant<8, DT_F32, OP_ADD, 4, true, false, 256>(b, numel, num_cu, 9);
-        run_dequant<4, DT_BF16, OP_SET, 4, true, true, 256>(b, 2 * numel, num_cu, 2.5);
-        run_dequant<4, DT_BF16, OP_SET, 4, false, true, 256>(b, 2 * numel, num_cu, 2.5);
-        run_dequant<4, DT_BF16, OP_SET, 8, true, true, 256>(b, 2 * numel, num_cu, 2.5);
-        run_dequant<4, DT_BF16, OP_ADD, 4, true, true, 256>(b, 2 * numel, num_cu, 4.5);
-        run_dequant<4, DT_F32, OP_SET, 4, true, true, 256>(b, numel, num_cu, 4.5);
-        run_dequant<2, DT_BF16, OP_SET, 4, true, true, 256>(b, 2 * numel, num_cu, 2.25);
-        run_dequant<2, DT_F32, OP_SET, 4, true, true, 256>(b, numel, num_cu, 4.25);
+        run_dequant<8, DT_F32, OP_SET, 4, true, 3, 256>(b, numel, num_cu, 5);
+        run_dequant<8, DT_F32, OP_SET, 4, false, 3, 256>(b, numel, num_cu, 5);
+        run_dequant<8, DT_F32, OP_SET, 8, true, 3, 256>(b, numel, num_cu, 5);
+        run_dequant<8, DT_F32, OP_SET, 4, true, 0, 256>(b, numel, num_cu, 5);
+        run_dequant<8, DT_F32, OP_ADD, 4, true, 3, 256>(b, numel, num_cu, 9);
+        run_dequant<8, DT_F32, OP_ADD, 4, false, 3, 256>(b, numel, num_cu, 9);
+        run_dequant<8, DT_F32, OP_ADD, 8, true, 3, 256>(b, numel, num_cu, 9);
+        run_dequant<8, DT_F32, OP_ADD, 4, true, 0, 256>(b, numel, num_cu, 9);
+        run_dequant<4, DT_BF16, OP_SET, 4, true, 3, 256>(b, 2 * numel, num_cu, 2.5);
+        run_dequant<4, DT_BF16, OP_SET, 4, false, 3, 256>(b, 2 * numel, num_cu, 2.5);
+        run_dequant<4, DT_BF16, OP_SET, 8, true, 3, 256>(b, 2 * numel, num_cu, 2.5);
+        run_dequant<4, DT_BF16, OP_ADD, 4, true, 3, 256>(b, 2 * numel, num_cu, 4.5);
+        run_dequant<4, DT_F32, OP_SET, 4, true, 3, 256>(b, numel, num_cu, 4.5);
+        run_dequant<2, DT_BF16, OP_SET, 4, true, 3, 256>(b, 2 * numel, num_cu, 2.25);
+        run_dequant<2, DT_F32, OP_SET, 4, true, 3, 256>(b, numel, num_cu, 4.25);
     }
     if (only == "all" || only == "mm") {
         run_minmax<DT_F32, 2, true, 256>(b, numel, num_cu, keys);
