@@ -110,11 +110,13 @@ struct piquant_context_t {
     hipStream_t stage_stream[2] = {nullptr, nullptr};
     bool blocking = true;
 
-    // Two {min,-max} key pairs on the device.  compute_quant_params alternates between them: the scan that
-    // fills one pair re-arms the other (idle) one, so no memset launch precedes the scan.
-    int32_t* d_keys = nullptr;             // 4 x int32
-    int key_slot = 0;
-    int32_t* h_keys = nullptr;             // pinned mirror of the pair just read
+    // Min/max scan state: two slot buffers on the device (see minmax_kernels.hpp).  Calls alternate between them;
+    // the scan that fills one re-arms the other (idle) one, so no separate initialisation launch precedes a scan.
+    // Invariant: d_slots[slot] is armed (all identity) whenever no scan is in flight.
+    int32_t* d_slots[2] = {nullptr, nullptr};
+    int slot = 0;
+    int32_t* h_slots = nullptr;            // pinned mirror of the buffer just scanned
+    hipStream_t scan_stream = nullptr;     // stream of the previous scan (re-arming relies on stream order)
 
     // device scratch for host-pointer calls, grown on demand
     void* stage_in[2] = {nullptr, nullptr};
@@ -174,9 +176,12 @@ piquant_context_t* piquant_context_create(size_t num_threads) {
     PQ_HIP(hipDeviceGetAttribute(&ctx->num_cu, hipDeviceAttributeMultiprocessorCount, ctx->device));
     PQ_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
-    PQ_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_keys), 4 * sizeof(int32_t)));
-    PQ_HIP(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(ctx->d_keys), float_to_key(std::numeric_limits<float>::max()), 4));
-    PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_keys), 2 * sizeof(int32_t), hipHostMallocDefault));
+    const size_t slot_bytes = static_cast<size_t>(minmax_slot_ints()) * sizeof(int32_t);
+    for (auto& p : ctx->d_slots) {
+        PQ_HIP(hipMalloc(reinterpret_cast<void**>(&p), slot_bytes));
+        PQ_HIP(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p), float_to_key(std::numeric_limits<float>::max()), minmax_slot_ints()));
+    }
+    PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_slots), slot_bytes, hipHostMallocDefault));
     std::random_device rd;
     ctx->rng.seed((static_cast<uint64_t>(rd()) << 32) ^ rd());
     return ctx;
@@ -193,8 +198,9 @@ void piquant_context_destroy(piquant_context_t* ctx) {
             if (p) (void)hipFree(p);
         for (auto& p : ctx->stage_out)
             if (p) (void)hipFree(p);
-        if (ctx->d_keys) (void)hipFree(ctx->d_keys);
-        if (ctx->h_keys) (void)hipHostFree(ctx->h_keys);
+        for (auto& p : ctx->d_slots)
+            if (p) (void)hipFree(p);
+        if (ctx->h_slots) (void)hipHostFree(ctx->h_slots);
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     }
     delete ctx;
@@ -323,31 +329,33 @@ void piquant_dequantize(piquant_context_t* ctx, const void* in, piquant_dtype_t 
     for (auto& s : ctx->stage_stream) PQ_HIP(hipStreamSynchronize(s));
 }
 
-// Scan into `device_keys`.  init: 0 = accumulate, 1 = reset the keys first (memset node), reset_keys != nullptr =
-// the keys are known to be armed already and the scan re-arms `reset_keys` for later (internal fast path).
-static void minmax_into(piquant_context_t* ctx, const void* x, piquant_dtype_t dtype, size_t n, int32_t* device_keys, int init, int32_t* reset_keys) {
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    DeviceGuard guard(ctx->device);
-    // identity: key(+FLT_MAX) for min and for -max (reference kernels_specialized.inl:1422-1423)
-    if (init) PQ_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(device_keys), float_to_key(std::numeric_limits<float>::max()), 2, ctx->stream));
-    if (n == 0) return;
+// Scans x into the context's armed slot buffer (re-arming the idle one for the next call) and returns the buffer
+// that now holds the per-slot {key(min), key(-max)} pairs.  Caller holds ctx->mu and the device guard.
+static int32_t* scan_into_slots(piquant_context_t* ctx, const void* x, piquant_dtype_t dtype, size_t n) {
+    // the previous scan re-armed this call's buffer in ITS stream: keep that ordering if the stream changed
+    if (ctx->scan_stream && ctx->scan_stream != ctx->stream) PQ_HIP(hipStreamSynchronize(ctx->scan_stream));
+    int32_t* cur = ctx->d_slots[ctx->slot];
+    int32_t* idle = ctx->d_slots[ctx->slot ^ 1];
+    ctx->slot ^= 1;
+    ctx->scan_stream = ctx->stream;
     const Resolved r = resolve(x);
     if (!r.pageable) {
-        launch_minmax(r.dev, dtype, static_cast<int64_t>(n), device_keys, reset_keys, ctx->stream, ctx->num_cu);
-        return;
+        launch_minmax(r.dev, dtype, static_cast<int64_t>(n), cur, idle, ctx->stream, ctx->num_cu);
+        return cur;
     }
-    // host input: stream it through device scratch, all chunks fold into the same two keys
+    // host input: stream it through device scratch; all chunks fold into the same slots
     PQ_HIP(hipStreamSynchronize(ctx->stream));
     const size_t chunk = std::min(n, kStageChunkElems);
     ctx->ensure_stage(span_bytes(chunk, dtype), 0);
-    int slot = 0;
-    for (size_t off = 0; off < n; off += chunk, slot ^= 1) {
+    int s_i = 0;
+    for (size_t off = 0; off < n; off += chunk, s_i ^= 1) {
         const size_t m = std::min(chunk, n - off);
-        hipStream_t s = ctx->stage_stream[slot];
-        PQ_HIP(hipMemcpyAsync(ctx->stage_in[slot], static_cast<const char*>(x) + span_bytes(off, dtype), span_bytes(m, dtype), hipMemcpyHostToDevice, s));
-        launch_minmax(ctx->stage_in[slot], dtype, static_cast<int64_t>(m), device_keys, off == 0 ? reset_keys : nullptr, s, ctx->num_cu);
+        hipStream_t s = ctx->stage_stream[s_i];
+        PQ_HIP(hipMemcpyAsync(ctx->stage_in[s_i], static_cast<const char*>(x) + span_bytes(off, dtype), span_bytes(m, dtype), hipMemcpyHostToDevice, s));
+        launch_minmax(ctx->stage_in[s_i], dtype, static_cast<int64_t>(m), cur, off == 0 ? idle : nullptr, s, ctx->num_cu);
     }
     for (auto& s : ctx->stage_stream) PQ_HIP(hipStreamSynchronize(s));
+    return cur;
 }
 
 void piquant_hip_minmax_keys(piquant_context_t* ctx, const void* x, piquant_dtype_t dtype, size_t n, int32_t* device_keys, int init) {
@@ -355,7 +363,14 @@ void piquant_hip_minmax_keys(piquant_context_t* ctx, const void* x, piquant_dtyp
     if (dtype != PIQUANT_DTYPE_F32 && dtype != PIQUANT_DTYPE_BF16) panic("min/max scan needs f32 or bf16 input, got %s", dtype_of(dtype).name);
     if (!device_keys) panic("piquant_hip_minmax_keys: NULL key buffer");
     if (n != 0 && !x) panic("piquant_hip_minmax_keys: NULL input");
-    minmax_into(ctx, x, dtype, n, device_keys, init, nullptr);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    if (n == 0) {   // nothing to scan: an armed buffer folds to the identity (reference kernels_specialized.inl:1422-1423)
+        if (init) launch_fold_slots(ctx->d_slots[ctx->slot], device_keys, true, ctx->stream);
+        return;
+    }
+    const int32_t* slots = scan_into_slots(ctx, x, dtype, n);
+    launch_fold_slots(slots, device_keys, init != 0, ctx->stream);
 }
 
 void piquant_hip_decode_minmax_keys(const int32_t keys[2], float* out_min, float* out_max) {
@@ -389,20 +404,19 @@ static void compute_params(piquant_context_t* ctx, const void* x, piquant_dtype_
     if (!out_scale || !out_zero_point) panic("piquant_compute_quant_params: NULL result pointer");
     if (!dtype_of(target).quant) panic("type %s is not a quantization type", dtype_of(target).name);
     if (n != 0 && !x) panic("piquant_compute_quant_params: NULL input");
+    int32_t keys[2];
     if (n == 0) {   // nothing to scan: the identities (reference kernels_specialized.inl:1422-1423)
-        ctx->h_keys[0] = ctx->h_keys[1] = float_to_key(std::numeric_limits<float>::max());
+        keys[0] = keys[1] = float_to_key(std::numeric_limits<float>::max());
     } else {
-        int32_t* cur = ctx->d_keys + 2 * ctx->key_slot;
-        int32_t* idle = ctx->d_keys + 2 * (ctx->key_slot ^ 1);
-        ctx->key_slot ^= 1;
-        minmax_into(ctx, x, dt, n, cur, 0, idle);   // `cur` was armed by the previous call (or at creation)
         std::lock_guard<std::mutex> lock(ctx->mu);
         DeviceGuard guard(ctx->device);
-        PQ_HIP(hipMemcpyAsync(ctx->h_keys, cur, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        const int32_t* slots = scan_into_slots(ctx, x, dt, n);
+        PQ_HIP(hipMemcpyAsync(ctx->h_slots, slots, static_cast<size_t>(minmax_slot_ints()) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
         PQ_HIP(hipStreamSynchronize(ctx->stream));
+        fold_slots_host(ctx->h_slots, keys);
     }
     float lo, hi;
-    piquant_hip_decode_minmax_keys(ctx->h_keys, &lo, &hi);
+    piquant_hip_decode_minmax_keys(keys, &lo, &hi);
     piquant_hip_quant_params_from_minmax(lo, hi, target, out_scale, out_zero_point);
     // reference src/piquant.cpp:373,379
     if (std::isnan(*out_scale) || !(*out_scale >= 0.0f)) panic("compute_quant_params: scale must be positive (got %g)", static_cast<double>(*out_scale));

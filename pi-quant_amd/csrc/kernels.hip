@@ -28,18 +28,18 @@ inline unsigned capped_grid(int64_t want, int blocks_per_cu, int num_cu) {
 template <int DT_IN, int BITS, int MODE>
 void quantize_t(const QuantLaunch& q, const QuantParams& p, hipStream_t stream, int num_cu) {
     constexpr KernelTune t = kQuantTune[DT_IN][bits_index(BITS)];
-    using Tile = QuantTile<DT_IN, BITS, t.u, kBlock>;
+    using Tile = QuantTile<DT_IN, BITS, t.u, t.block>;
     uint8_t* out = static_cast<uint8_t*>(q.out);
     if (!aligned16(q.in) || !aligned16(q.out)) {
         constexpr int PACK = 8 / BITS;
         const int64_t nbytes = (q.numel + PACK - 1) / PACK;
-        const unsigned grid = capped_grid((nbytes + kBlock - 1) / kBlock, 16, num_cu);
-        hipLaunchKernelGGL((quantize_scalar_kernel<DT_IN, BITS, MODE>), dim3(grid), dim3(kBlock), 0, stream, q.in, out, q.numel, p);
+        const unsigned grid = capped_grid((nbytes + kScalarBlock - 1) / kScalarBlock, 16, num_cu);
+        hipLaunchKernelGGL((quantize_scalar_kernel<DT_IN, BITS, MODE>), dim3(grid), dim3(kScalarBlock), 0, stream, q.in, out, q.numel, p);
         return;
     }
     const int64_t n_tiles = q.numel / Tile::BLOCK_ELEMS;
     const unsigned grid = capped_grid(n_tiles, t.blocks_per_cu, num_cu);
-    hipLaunchKernelGGL((quantize_kernel<DT_IN, BITS, MODE, t.u, t.stage, t.nt, kBlock>), dim3(grid), dim3(kBlock), 0, stream,
+    hipLaunchKernelGGL((quantize_kernel<DT_IN, BITS, MODE, t.u, t.stage, t.nt, t.block>), dim3(grid), dim3(t.block), 0, stream,
                        q.in, out, q.numel, n_tiles, p);
 }
 
@@ -71,16 +71,16 @@ void quantize_bits(const QuantLaunch& q, const QuantParams& p, hipStream_t strea
 template <int BITS, int DT_OUT, int OP>
 void dequantize_t(const DequantLaunch& d, const DequantParams& p, hipStream_t stream, int num_cu) {
     constexpr KernelTune t = kDequantTune[DT_OUT][bits_index(BITS)];
-    using Tile = DequantTile<BITS, DT_OUT, t.u, kBlock>;
+    using Tile = DequantTile<BITS, DT_OUT, t.u, t.block>;
     const uint8_t* in = static_cast<const uint8_t*>(d.in);
     if (!aligned16(d.in) || !aligned16(d.out)) {
-        const unsigned grid = capped_grid((d.numel + kBlock - 1) / kBlock, 16, num_cu);
-        hipLaunchKernelGGL((dequantize_scalar_kernel<BITS, DT_OUT, OP>), dim3(grid), dim3(kBlock), 0, stream, in, d.out, d.numel, p);
+        const unsigned grid = capped_grid((d.numel + kScalarBlock - 1) / kScalarBlock, 16, num_cu);
+        hipLaunchKernelGGL((dequantize_scalar_kernel<BITS, DT_OUT, OP>), dim3(grid), dim3(kScalarBlock), 0, stream, in, d.out, d.numel, p);
         return;
     }
     const int64_t n_tiles = d.numel / Tile::BLOCK_ELEMS;
     const unsigned grid = capped_grid(n_tiles, t.blocks_per_cu, num_cu);
-    hipLaunchKernelGGL((dequantize_kernel<BITS, DT_OUT, OP, t.u, t.stage, t.nt, kBlock>), dim3(grid), dim3(kBlock), 0, stream, in,
+    hipLaunchKernelGGL((dequantize_kernel<BITS, DT_OUT, OP, t.u, t.stage, t.nt, t.block>), dim3(grid), dim3(t.block), 0, stream, in,
                        d.out, d.numel, n_tiles, p);
 }
 
@@ -103,16 +103,17 @@ void dequantize_out(const DequantLaunch& d, const DequantParams& p, hipStream_t 
 }
 
 template <int DT_IN>
-void minmax_t(const void* in, int64_t numel, int32_t* keys, int32_t* reset_keys, hipStream_t stream, int num_cu) {
+void minmax_t(const void* in, int64_t numel, int32_t* slots, int32_t* rearm_slots, hipStream_t stream, int num_cu) {
     constexpr int EPV = InVec<DT_IN>::EPV;
     if (!aligned16(in)) {
-        const unsigned grid = capped_grid((numel + kBlock - 1) / kBlock, kMinmaxBlocksPerCU, num_cu);
-        hipLaunchKernelGGL((minmax_scalar_kernel<DT_IN, kBlock>), dim3(grid), dim3(kBlock), 0, stream, in, numel, keys, reset_keys);
+        const unsigned grid = capped_grid((numel + kMinmaxBlock - 1) / kMinmaxBlock, 8, num_cu);
+        hipLaunchKernelGGL((minmax_scalar_kernel<DT_IN, kMinmaxBlock>), dim3(grid), dim3(kMinmaxBlock), 0, stream, in, numel, slots, rearm_slots);
         return;
     }
-    const int64_t per_block = static_cast<int64_t>(kBlock) * kMinmaxU * EPV;
+    const int64_t per_block = static_cast<int64_t>(kMinmaxBlock) * kMinmaxU * EPV;
     const unsigned grid = capped_grid((numel + per_block - 1) / per_block, kMinmaxBlocksPerCU, num_cu);
-    hipLaunchKernelGGL((minmax_kernel<DT_IN, kMinmaxU, kMinmaxNT, kBlock>), dim3(grid), dim3(kBlock), 0, stream, in, numel, keys, reset_keys);
+    hipLaunchKernelGGL((minmax_kernel<DT_IN, kMinmaxU, kMinmaxNT, kMinmaxBlock>), dim3(grid), dim3(kMinmaxBlock), 0, stream, in, numel, slots,
+                       rearm_slots);
 }
 
 }  // namespace
@@ -151,11 +152,33 @@ void launch_dequantize(const DequantLaunch& d, hipStream_t stream, int num_cu) {
     PQ_HIP(hipGetLastError());
 }
 
-void launch_minmax(const void* in, int dt_in, int64_t numel, int32_t* device_keys, int32_t* reset_keys, hipStream_t stream, int num_cu) {
+void launch_arm_slots(int32_t* slots, hipStream_t stream) {
+    hipLaunchKernelGGL(arm_slots_kernel, dim3(1), dim3(64), 0, stream, slots);
+    PQ_HIP(hipGetLastError());
+}
+
+void launch_fold_slots(const int32_t* slots, int32_t* device_keys, bool overwrite, hipStream_t stream) {
+    hipLaunchKernelGGL(fold_slots_kernel, dim3(1), dim3(64), 0, stream, slots, device_keys, overwrite ? 1 : 0);
+    PQ_HIP(hipGetLastError());
+}
+
+void fold_slots_host(const int32_t* slots, int32_t out_keys[2]) {
+    int32_t k0 = slots[0], k1 = slots[1];
+    for (int s = 1; s < kMinmaxSlots; ++s) {
+        k0 = std::min(k0, slots[s * kMinmaxSlotStride + 0]);
+        k1 = std::min(k1, slots[s * kMinmaxSlotStride + 1]);
+    }
+    out_keys[0] = k0;
+    out_keys[1] = k1;
+}
+
+int minmax_slot_ints() { return kMinmaxSlotInts; }
+
+void launch_minmax(const void* in, int dt_in, int64_t numel, int32_t* slots, int32_t* rearm_slots, hipStream_t stream, int num_cu) {
     if (numel <= 0) return;
     switch (dt_in) {
-        case DT_F32: minmax_t<DT_F32>(in, numel, device_keys, reset_keys, stream, num_cu); break;
-        case DT_BF16: minmax_t<DT_BF16>(in, numel, device_keys, reset_keys, stream, num_cu); break;
+        case DT_F32: minmax_t<DT_F32>(in, numel, slots, rearm_slots, stream, num_cu); break;
+        case DT_BF16: minmax_t<DT_BF16>(in, numel, slots, rearm_slots, stream, num_cu); break;
         default: panic("min/max scan needs a float dtype, got %d", dt_in);
     }
     PQ_HIP(hipGetLastError());

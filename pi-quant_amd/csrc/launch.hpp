@@ -35,8 +35,15 @@ struct DequantLaunch {
 // All launches are asynchronous on `stream`; num_cu sizes capped grids.
 void launch_quantize(const QuantLaunch& q, hipStream_t stream, int num_cu);
 void launch_dequantize(const DequantLaunch& d, hipStream_t stream, int num_cu);
-// reset_keys (nullable): a second, idle key pair that block 0 re-initialises to the identity for a later call.
-void launch_minmax(const void* in, int dt_in, int64_t numel, int32_t* device_keys, int32_t* reset_keys, hipStream_t stream, int num_cu);
+// Min/max scan into a slot buffer (kMinmaxSlotInts int32, armed with the identity beforehand); rearm_slots
+// (nullable) is a second, idle slot buffer that the scan re-arms for a later call.
+void launch_minmax(const void* in, int dt_in, int64_t numel, int32_t* slots, int32_t* rearm_slots, hipStream_t stream, int num_cu);
+void launch_arm_slots(int32_t* slots, hipStream_t stream);
+// Fold a slot buffer into a {key(min), key(-max)} pair in device memory (overwrite or accumulate with MIN).
+void launch_fold_slots(const int32_t* slots, int32_t* device_keys, bool overwrite, hipStream_t stream);
+// Host-side fold of a slot buffer copied back from the device.
+void fold_slots_host(const int32_t* slots, int32_t out_keys[2]);
+int minmax_slot_ints();
 
 // Aborts with the reference's panic convention (red message on stderr, abort()) on a HIP error.
 void check_hip(hipError_t e, const char* what, const char* file, int line);

@@ -3,11 +3,17 @@
 // Pure read stream, 4 B/elem (fp32) or 2 B/elem (bf16): grid-stride loop, U coalesced 16-byte loads in
 // flight per lane, v_min_f32/v_max_f32 per element, then a wave64 butterfly (__shfl_xor, lowered to DPP /
 // ds_swizzle), an LDS fold across the block's waves and at most ONE atomicMin per block on each of two int32
-// keys (skipped when the block cannot improve the key, see fold_keys).
-// keys[0] = key(min), keys[1] = key(-max): both reduce with MIN, which is also the only collective a
-// multi-GPU caller needs (one 2 x int32 MIN all-reduce).  Device-scope atomics are coherent across the 8
-// XCDs' L2s; the result is read after the kernel boundary.  NaNs are ignored (v_min/v_max return the
-// non-NaN operand); the reference leaves NaN inputs unspecified.
+// keys of the block's SLOT.  Keys are order-preserving int32 images of floats; a slot holds {key(min),
+// key(-max)} so that both reduce with MIN -- which is also the only collective a multi-GPU caller needs (one
+// 2 x int32 MIN all-reduce).
+//
+// Why slots: atomics on ONE address serialise at ~11 ns each on MI355X (measured: with a single key pair the
+// scan time grew linearly with the block count, 2048 blocks = +45 us on an 18 us scan, because all blocks of
+// an evenly split scan finish together).  The blocks therefore fold into kMinmaxSlots key pairs, each on its
+// own 128-byte line (slot = blockIdx % slots), and the slots are folded afterwards: by fold_slots_kernel (one
+// wave) for the asynchronous API, or on the host after the D2H copy for compute_quant_params.
+// Device-scope atomics are coherent across the 8 XCDs' L2s; results are read after the kernel boundary.
+// NaNs are ignored (v_min/v_max return the non-NaN operand); the reference leaves NaN inputs unspecified.
 #pragma once
 
 #include "quant_kernels.hpp"
@@ -26,19 +32,50 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// One block's {min,max} into the two global keys.  Atomics on one address serialise at ~11 ns each on
-// MI355X (measured: scan time grew linearly with the block count), so a block first looks at the current key
-// with a relaxed device-scope load and only issues the atomic when it would lower it.  Keys only ever
-// decrease, so a stale (older, larger) value can cause a redundant atomic but never a missed one; on random
-// data the expected number of atomics per key is O(log #blocks).
+constexpr int kMinmaxSlots = 64;          // key pairs per slot buffer
+constexpr int kMinmaxSlotStride = 32;     // int32 per slot: one 128-byte line each
+constexpr int kMinmaxSlotInts = kMinmaxSlots * kMinmaxSlotStride;
+
+// One block's {min,max} into its slot.  The block first looks at the slot with a relaxed device-scope load and
+// only issues the atomic when it would lower the key: keys only ever decrease, so a stale (older, larger)
+// value can cause a redundant atomic but never a missed one.
 __device__ __forceinline__ void fold_keys(int32_t* keys, float lo, float hi) {
     const int32_t k_lo = float_to_key(lo), k_hi = float_to_key(-hi);
     if (k_lo < __hip_atomic_load(keys + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(keys + 0, k_lo);
     if (k_hi < __hip_atomic_load(keys + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(keys + 1, k_hi);
 }
 
+// Arms a slot buffer with the identity (+FLT_MAX for min and for -max).
+__global__ void __launch_bounds__(64) arm_slots_kernel(int32_t* slots) {
+    if (threadIdx.x < kMinmaxSlots) {
+        slots[threadIdx.x * kMinmaxSlotStride + 0] = float_to_key(3.402823466e+38f);
+        slots[threadIdx.x * kMinmaxSlotStride + 1] = float_to_key(3.402823466e+38f);
+    }
+}
+
+// One wave folds the slots into the caller's key pair: overwrite != 0 stores, otherwise atomicMin (accumulate).
+__global__ void __launch_bounds__(64) fold_slots_kernel(const int32_t* slots, int32_t* keys, int overwrite) {
+    static_assert(kMinmaxSlots == 64, "one lane per slot");
+    int32_t k0 = slots[threadIdx.x * kMinmaxSlotStride + 0];
+    int32_t k1 = slots[threadIdx.x * kMinmaxSlotStride + 1];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        k0 = min(k0, __shfl_xor(k0, off, 64));
+        k1 = min(k1, __shfl_xor(k1, off, 64));
+    }
+    if (threadIdx.x == 0) {
+        if (overwrite) {
+            keys[0] = k0;
+            keys[1] = k1;
+        } else {
+            atomicMin(keys + 0, k0);
+            atomicMin(keys + 1, k1);
+        }
+    }
+}
+
 template <int DT_IN, int U, bool NT, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) minmax_kernel(const void* __restrict__ in, int64_t numel, int32_t* keys, int32_t* reset_keys) {
+__global__ void __launch_bounds__(BLOCK) minmax_kernel(const void* __restrict__ in, int64_t numel, int32_t* slots, int32_t* rearm_slots) {
     constexpr int EPV = InVec<DT_IN>::EPV;
     constexpr int WAVES = BLOCK / 64;
     const u32x4* __restrict__ in16 = static_cast<const u32x4*>(in);
@@ -96,17 +133,17 @@ __global__ void __launch_bounds__(BLOCK) minmax_kernel(const void* __restrict__ 
             lo = __builtin_fminf(lo, s_lo[w]);
             hi = __builtin_fmaxf(hi, s_hi[w]);
         }
-        fold_keys(keys, lo, hi);
-        if (reset_keys != nullptr && blockIdx.x == 0) {   // re-arm the context's idle key pair for its next call
-            reset_keys[0] = float_to_key(3.402823466e+38f);
-            reset_keys[1] = float_to_key(3.402823466e+38f);
-        }
+        fold_keys(slots + (blockIdx.x % kMinmaxSlots) * kMinmaxSlotStride, lo, hi);
+    }
+    if (rearm_slots != nullptr && blockIdx.x == 0 && threadIdx.x < kMinmaxSlots) {   // re-arm the idle slot buffer for a later call
+        rearm_slots[threadIdx.x * kMinmaxSlotStride + 0] = float_to_key(3.402823466e+38f);
+        rearm_slots[threadIdx.x * kMinmaxSlotStride + 1] = float_to_key(3.402823466e+38f);
     }
 }
 
 // Same scan for buffers that are not 16-byte aligned.
 template <int DT_IN, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) minmax_scalar_kernel(const void* __restrict__ in, int64_t numel, int32_t* keys, int32_t* reset_keys) {
+__global__ void __launch_bounds__(BLOCK) minmax_scalar_kernel(const void* __restrict__ in, int64_t numel, int32_t* slots, int32_t* rearm_slots) {
     constexpr int WAVES = BLOCK / 64;
     float lo = 3.402823466e+38f, hi = -3.402823466e+38f;
     const int64_t nthreads = static_cast<int64_t>(gridDim.x) * BLOCK;
@@ -130,11 +167,11 @@ __global__ void __launch_bounds__(BLOCK) minmax_scalar_kernel(const void* __rest
             lo = __builtin_fminf(lo, s_lo[w]);
             hi = __builtin_fmaxf(hi, s_hi[w]);
         }
-        fold_keys(keys, lo, hi);
-        if (reset_keys != nullptr && blockIdx.x == 0) {   // re-arm the context's idle key pair for its next call
-            reset_keys[0] = float_to_key(3.402823466e+38f);
-            reset_keys[1] = float_to_key(3.402823466e+38f);
-        }
+        fold_keys(slots + (blockIdx.x % kMinmaxSlots) * kMinmaxSlotStride, lo, hi);
+    }
+    if (rearm_slots != nullptr && blockIdx.x == 0 && threadIdx.x < kMinmaxSlots) {   // re-arm the idle slot buffer for a later call
+        rearm_slots[threadIdx.x * kMinmaxSlotStride + 0] = float_to_key(3.402823466e+38f);
+        rearm_slots[threadIdx.x * kMinmaxSlotStride + 1] = float_to_key(3.402823466e+38f);
     }
 }
 

@@ -19,11 +19,11 @@ for ph in $PHASES; do
     tests) timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/session.log; tail -40 $OUT/pytest_gpu.log ;;
     tune)  timeout 900 ./tools/tune_kernels 27264000 200 ${TUNE_ONLY:-all} > $OUT/tune.csv 2> $OUT/tune.err; echo "tune rc=$?" | tee -a $OUT/session.log; tail -3 $OUT/tune.err ;;
     bench) timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" | tee -a $OUT/session.log; cat $OUT/bench.json; tail -5 $OUT/bench.err ;;
-    prof)  rm -rf $OUT/prof; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof" -o bench -- python "$OLDPWD/bench.py" --steps 300 --warmup 30 --no-cpu-baseline --no-extras > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err"); echo "prof rc=$?" | tee -a $OUT/session.log
+    prof)  rm -rf $OUT/prof; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -f csv -d "$OLDPWD/$OUT/prof" -o bench -- python "$OLDPWD/bench.py" --steps 300 --warmup 30 --no-cpu-baseline --no-extras > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err"); echo "prof rc=$?" | tee -a $OUT/session.log
            find $OUT/prof -name "*stats*" | head; f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 "$f" ;;
     pmc)   rm -rf $OUT/pmc_fetch $OUT/pmc_write
-           (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OLDPWD/$OUT/pmc_fetch" -o pmc -- python "$OLDPWD/bench.py" --steps 60 --warmup 10 --no-cpu-baseline --no-extras > /dev/null 2> "$OLDPWD/$OUT/pmc_fetch.err"); echo "pmc fetch rc=$?" | tee -a $OUT/session.log
-           (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OLDPWD/$OUT/pmc_write" -o pmc -- python "$OLDPWD/bench.py" --steps 60 --warmup 10 --no-cpu-baseline --no-extras > /dev/null 2> "$OLDPWD/$OUT/pmc_write.err"); echo "pmc write rc=$?" | tee -a $OUT/session.log
+           (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d "$OLDPWD/$OUT/pmc_fetch" -o pmc -- python "$OLDPWD/bench.py" --steps 60 --warmup 10 --no-cpu-baseline --no-extras > /dev/null 2> "$OLDPWD/$OUT/pmc_fetch.err"); echo "pmc fetch rc=$?" | tee -a $OUT/session.log
+           (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d "$OLDPWD/$OUT/pmc_write" -o pmc -- python "$OLDPWD/bench.py" --steps 60 --warmup 10 --no-cpu-baseline --no-extras > /dev/null 2> "$OLDPWD/$OUT/pmc_write.err"); echo "pmc write rc=$?" | tee -a $OUT/session.log
            python tools/summarize_pmc.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_summary.json 2> $OUT/pmc_summary.err; cat $OUT/pmc_summary.json ;;
   esac
 done

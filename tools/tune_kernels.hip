@@ -172,7 +172,9 @@ static void run_minmax(const Bufs& b, int64_t numel, int num_cu, int32_t* keys) 
     for (int cap : {2, 4, 8, 16, 32}) {
         const unsigned grid = static_cast<unsigned>(cap * num_cu);
         const double us = time_us([&](int i) {
-            hipLaunchKernelGGL((minmax_kernel<DT_IN, U, NT, BLOCK>), dim3(grid), dim3(BLOCK), 0, g_stream, b.in[i % SETS], numel, keys, static_cast<int32_t*>(nullptr));
+            // production protocol: cold (armed) slots every launch, the idle buffer re-armed by the scan itself
+            hipLaunchKernelGGL((minmax_kernel<DT_IN, U, NT, BLOCK>), dim3(grid), dim3(BLOCK), 0, g_stream, b.in[i % SETS], numel,
+                               keys + (i & 1) * kMinmaxSlotInts, keys + ((i & 1) ^ 1) * kMinmaxSlotInts);
         });
         char name[160];
         std::snprintf(name, sizeof name, "in=%s U=%d nt=%d block=%d cap=%d grid=%u", DT_IN == DT_F32 ? "f32" : "bf16", U, NT ? 1 : 0, BLOCK, cap, grid);
@@ -200,8 +202,8 @@ int main(int argc, char** argv) {
         CK(hipMemsetAsync(b.out[s], 0x5a, numel, g_stream));
     }
     int32_t* keys = nullptr;
-    CK(hipMalloc(reinterpret_cast<void**>(&keys), 8));
-    CK(hipMemsetAsync(keys, 0x7f, 8, g_stream));
+    CK(hipMalloc(reinterpret_cast<void**>(&keys), 2 * kMinmaxSlotInts * sizeof(int32_t)));
+    CK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(keys), float_to_key(3.402823466e+38f), 2 * kMinmaxSlotInts, g_stream));
     CK(hipStreamSynchronize(g_stream));
 
     std::printf("family,variant,us_per_launch_best,algo_GBps,frac_of_8TBps,us_per_launch_worst\n");
