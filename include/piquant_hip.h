@@ -15,10 +15,12 @@
 extern "C" {
 #endif
 
-/* HIP stream (a hipStream_t passed as void*) that the context enqueues kernels on; NULL selects the
- * context's own non-blocking stream (the default).  PyTorch callers pass
- * torch.cuda.current_stream().cuda_stream so that work is ordered with the tensors' producers. */
+/* HIP stream (a hipStream_t passed as void*) that the context enqueues its kernels on from now on.  As in every
+ * HIP API, NULL names the legacy default stream -- which is what PyTorch-ROCm's default stream is, so PyTorch
+ * callers simply pass torch.cuda.current_stream().cuda_stream and the work is ordered with the tensors' producers
+ * and consumers.  A new context enqueues on a private non-blocking stream; piquant_hip_reset_stream returns to it. */
 PIQUANT_EXPORT void piquant_hip_set_stream(piquant_context_t* ctx, void* hip_stream);
+PIQUANT_EXPORT void piquant_hip_reset_stream(piquant_context_t* ctx);
 
 /* blocking != 0 (default): every piquant.h call returns after its work has completed on the GPU -- the
  * reference's semantics (its calls join the thread pool before returning, src/piquant.cpp:210,237).

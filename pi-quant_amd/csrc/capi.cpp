@@ -182,6 +182,7 @@ piquant_context_t* piquant_context_create(size_t num_threads) {
         PQ_HIP(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p), float_to_key(std::numeric_limits<float>::max()), minmax_slot_ints()));
     }
     PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_slots), slot_bytes, hipHostMallocDefault));
+    PQ_HIP(hipDeviceSynchronize());   // the arming memsets ran on the null stream; scans may run on any stream
     std::random_device rd;
     ctx->rng.seed((static_cast<uint64_t>(rd()) << 32) ^ rd());
     return ctx;
@@ -435,7 +436,13 @@ void piquant_compute_quant_params_bfloat16(piquant_context_t* ctx, const uint16_
 void piquant_hip_set_stream(piquant_context_t* ctx, void* hip_stream) {
     if (!ctx) panic("piquant_hip_set_stream: context is NULL");
     std::lock_guard<std::mutex> lock(ctx->mu);
-    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    ctx->stream = static_cast<hipStream_t>(hip_stream);   // NULL == the legacy default stream, as everywhere in HIP
+}
+
+void piquant_hip_reset_stream(piquant_context_t* ctx) {
+    if (!ctx) panic("piquant_hip_reset_stream: context is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->stream = ctx->own_stream;
 }
 
 void piquant_hip_set_blocking(piquant_context_t* ctx, int blocking) {

@@ -128,8 +128,13 @@ class Context:
 
     # ---- additive GPU controls (include/piquant_hip.h) ----------------------------------------------
     def set_stream(self, hip_stream: int) -> None:
-        """Enqueue on this hipStream_t (e.g. ``torch.cuda.current_stream().cuda_stream``); 0 = own stream."""
+        """Enqueue on this hipStream_t, e.g. ``torch.cuda.current_stream().cuda_stream``.  0 is HIP's legacy default
+        stream (PyTorch's default stream), not "no stream"; see ``reset_stream``."""
         C.piquant_hip_set_stream(self._ctx, hip_stream or None)
+
+    def reset_stream(self) -> None:
+        """Back to the context's private non-blocking stream (the state of a new context)."""
+        C.piquant_hip_reset_stream(self._ctx)
 
     def set_blocking(self, blocking: bool) -> None:
         """True (native default): calls return after completion, like the reference.  False: stream-ordered."""

@@ -26,6 +26,7 @@ _DECLS = [
     ('piquant_compute_quant_params_bfloat16', None, [_vp, _vp, _sz, _int, C.POINTER(_f32), C.POINTER(_i64)]),
     # --- piquant_hip.h: additive extensions ---------------------------------------------------------
     ('piquant_hip_set_stream', None, [_vp, _vp]),
+    ('piquant_hip_reset_stream', None, [_vp]),
     ('piquant_hip_set_blocking', None, [_vp, _int]),
     ('piquant_hip_set_stochastic_threshold', None, [_vp, _f32]),
     ('piquant_hip_set_stochastic_seed', None, [_vp, C.c_uint64]),

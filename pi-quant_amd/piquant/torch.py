@@ -82,7 +82,7 @@ def _ctx_for(tensor: torch.Tensor, ctx: Optional[Context]) -> Context:
     else:
         if ctx is None:
             ctx = Context.get()
-        ctx.set_stream(0)
+        ctx.reset_stream()        # host buffers: staged on the context's own streams, complete on return
         ctx.set_blocking(True)
     return ctx
 

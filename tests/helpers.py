@@ -59,7 +59,7 @@ def gpu_quantize(ctx, x, dt_in, dt_out, scale, zp, round_mode=0, offset_in=0, of
     if host:
         out = np.full(nbytes, 0xAA, dtype=np.uint8)
         xin = np.ascontiguousarray(x)
-        ctx.set_stream(0)
+        ctx.reset_stream()
         ctx.set_blocking(True)
         if n:
             ctx.quantize_ptr(xin.ctypes.data, piquant.DataType(dt_in), out.ctypes.data, piquant.DataType(dt_out), n, scale, zp,
@@ -90,7 +90,7 @@ def gpu_dequantize(ctx, q, dt_in, dt_out, numel, scale, zp, op=0, prev=None, off
     if host:
         out = prev.copy()
         qin = np.ascontiguousarray(q)
-        ctx.set_stream(0)
+        ctx.reset_stream()
         ctx.set_blocking(True)
         if numel:
             ctx.dequantize_ptr(qin.ctypes.data, piquant.DataType(dt_in), out.ctypes.data, piquant.DataType(dt_out), numel, scale, zp,

@@ -364,6 +364,28 @@ def test_blocking_default_and_stream_ordering(O):
     assert float((back - y).abs().max()) <= 0.0157 * 0.5 + 1e-6
 
 
+def test_default_stream_ordering_without_explicit_sync(O):
+    """PyTorch's default stream is HIP's legacy NULL stream (cuda_stream == 0): work enqueued through piquant.torch
+    must be ordered behind the tensor's producer and ahead of its consumer with no synchronize() in between."""
+    import piquant
+    import torch
+
+    n = 8_000_000
+    base = torch.empty(n, device="cuda").uniform_(-1, 1)
+    ref_in = (base * 0.5 + 0.25).cpu().numpy()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        x = base
+        for _ in range(40):          # a long producer chain on the default stream
+            x = x * 1.0
+        x = x * 0.5 + 0.25
+        q = piquant.torch.quantize(x, scale=0.0078431377, zero_point=64, dtype=torch.uint8)
+        keys_scale = piquant.torch.compute_quant_params(x, dtype=torch.quint8)
+        got = q.cpu().numpy()        # consumer on the default stream, no explicit sync
+        assert np.array_equal(got, O.quantize(ref_in, 0, 4, 0.0078431377, 64))
+        assert keys_scale == O.compute_quant_params(ref_in, 0, 4)
+
+
 def test_empty_inputs_are_no_ops(ctx):
     import piquant
 
