@@ -43,6 +43,15 @@ PIQUANT_EXPORT void piquant_hip_set_stochastic_seed(piquant_context_t* ctx, uint
 PIQUANT_EXPORT void piquant_hip_set_stochastic_per_element(piquant_context_t* ctx, int enabled, uint64_t seed,
                                                            uint64_t index_base);
 
+/* Fused quantize -> dequantize: out[i] (op)= dequantize(quantize(in[i])) without materialising the quantized tensor;
+ * dtype_in_out (F32 or BF16) is the type of BOTH buffers, quant_dtype (UINT2/4/8) the type passed through; `out` may
+ * alias `in`.  This is the reference's C++-only context::quantize_dequantize_fused (include/piquant.hpp:276-285,
+ * src/piquant.cpp:342-369, kernels src/kernels/kernels.inl:30-52), which its C ABI does not export.  Device pointers
+ * only.  Every element takes the reference's generic scalar steps (there is no SIMD fast path for this command). */
+PIQUANT_EXPORT void piquant_hip_quantize_dequantize(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in_out, void* out,
+                                                    piquant_dtype_t quant_dtype, size_t numel, float scale, int64_t zero_point,
+                                                    piquant_round_mode_t mode, piquant_reduce_op_t op);
+
 /* First half of compute_quant_params: scan n elements of x (dtype F32 or BF16, device or host pointer)
  * and fold {min, -max} into two order-preserving int32 keys in DEVICE memory with atomic MIN, enqueued on
  * the context's stream (asynchronous).  init != 0 first resets both keys to the identity (+FLT_MAX), so

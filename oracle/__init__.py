@@ -32,5 +32,6 @@ from .oracle import (  # noqa: F401
     quant_params_from_minmax,
     quantize,
     quantize_per_element,
+    requantize,
     ref_available,
 )

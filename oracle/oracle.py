@@ -52,6 +52,7 @@ def _load() -> C.CDLL:
         lib.orc_dequantize.argtypes = [vp, ci, vp, ci, i64, f32, i64, ci, ci]
         lib.orc_quantize_threads.argtypes = [vp, ci, vp, ci, i64, f32, i64, ci, f32, ci, ci]
         lib.orc_dequantize_threads.argtypes = [vp, ci, vp, ci, i64, f32, i64, ci, ci, ci]
+        lib.orc_requantize.argtypes = [vp, ci, vp, ci, i64, f32, i64, ci, f32, ci]
         lib.orc_partition.restype = ci
         lib.orc_partition.argtypes = [i64, i64, i64, ci, C.POINTER(i64), C.POINTER(i64)]
         lib.orc_minmax_f32.argtypes = [vp, i64, C.POINTER(f32)]
@@ -125,6 +126,19 @@ def dequantize(q, dt_in, dt_out, numel, scale, zero_point, reduce_op=SET, form=F
     return out
 
 
+def requantize(x, dt_inout, quant_dtype, scale, zero_point, round_mode=NEAREST, rnd_threshold=0.0, reduce_op=SET, out=None) -> np.ndarray:
+    """Fused quantize->dequantize; `out` (same float dtype) is required for ADD and returned."""
+    lib = _load()
+    x = _check_in(x, dt_inout)
+    if out is None:
+        assert reduce_op == SET, "ADD needs an accumulator"
+        out = np.zeros(x.size, dtype=_NP_OF[dt_inout])
+    assert out.dtype == _NP_OF[dt_inout] and out.size == x.size and out.flags.c_contiguous
+    lib.orc_requantize(x.ctypes.data, dt_inout, out.ctypes.data, quant_dtype, x.size, scale, int(zero_point), round_mode,
+                       rnd_threshold, reduce_op)
+    return out
+
+
 def partition(numel: int, ti: int, tc: int, packed_bits: int):
     b, n = C.c_int64(), C.c_int64()
     ok = _load().orc_partition(numel, ti, tc, packed_bits, C.byref(b), C.byref(n))
@@ -184,6 +198,7 @@ class Ref:
         lib.ref_isa_name.restype = C.c_char_p
         lib.ref_quantize.argtypes = [ci, vp, ci, vp, ci, i64, f32, i64, ci, f32, ci]
         lib.ref_dequantize.argtypes = [ci, vp, ci, vp, ci, i64, f32, i64, ci, ci]
+        lib.ref_requantize.argtypes = [ci, vp, ci, vp, ci, i64, f32, i64, ci, f32, ci]
         lib.ref_minmax_f32.argtypes = [ci, vp, i64, ci, C.POINTER(f32)]
         lib.ref_minmax_bf16.argtypes = [ci, vp, i64, C.POINTER(f32)]
         self.lib = lib
@@ -219,6 +234,17 @@ class Ref:
             out = np.zeros(numel, dtype=_NP_OF[dt_out])
         self.lib.ref_dequantize(isa, qpad.ctypes.data, dt_in, out.ctypes.data, dt_out, numel, scale, int(zero_point),
                                 reduce_op, threads)
+        return out
+
+    def requantize(self, x, dt_inout, quant_dtype, scale, zero_point, round_mode=NEAREST, rnd_threshold=0.0, reduce_op=SET,
+                   isa=None, out=None) -> np.ndarray:
+        isa = self.best_isa() if isa is None else isa
+        x = _check_in(x, dt_inout)
+        if out is None:
+            assert reduce_op == SET
+            out = np.zeros(x.size, dtype=_NP_OF[dt_inout])
+        self.lib.ref_requantize(isa, x.ctypes.data, dt_inout, out.ctypes.data, quant_dtype, x.size, scale, int(zero_point),
+                                round_mode, rnd_threshold, reduce_op)
         return out
 
     def minmax(self, x, dt, isa=None, threads=1):

@@ -251,6 +251,37 @@ void orc_dequantize(const void* in, int dt_in, void* out, int dt_out, int64_t nu
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * fused quantize -> dequantize: src/kernels/kernels.inl:30-52
+ * ---------------------------------------------------------------------------------------------- */
+void orc_requantize(const void* in, int dt_inout, void* out, int quant_dtype, int64_t numel, float scale,
+                    int64_t zero_point, int round_mode, float rnd_threshold, int reduce_op) {
+    int bits = orc_bit_size(quant_dtype);
+    int64_t qmax = (1 << bits) - 1;
+    float inv = 1.0f / scale;                                   /* kernels.inl:41 */
+    for (int64_t i = 0; i < numel; ++i) {
+        float x = load_in(in, dt_inout, i);
+        /* quant_step_scalar (quantize.inl:28-34): generic nearest = std::round in int64, or the stochastic step */
+        unsigned q = round_mode == ORC_STOCHASTIC ? q_stochastic64(x, inv, zero_point, qmax, rnd_threshold)
+                                                  : q_nearest_generic64(x, inv, zero_point, qmax);
+        int64_t d = wrap_sub64((int64_t)q, zero_point);         /* dequant_step (dequantize.inl:8-11) */
+        if (dt_inout == ORC_F32) {
+            float* o = (float*)out;
+            float r = (float)d * scale;
+            o[i] = reduce_op == ORC_ADD ? o[i] + r : r;         /* kernels.inl:42-51 */
+        } else {
+            /* Out = bfp16_t: static_cast<bfp16_t>(int64) * scale goes through bfp16_t's converting constructor on
+             * BOTH operands and its operator* (include/piquant.hpp:86-90,111-113): every intermediate is bf16. */
+            uint16_t* o = (uint16_t*)out;
+            float a = orc_bf16_to_f32(orc_f32_to_bf16((float)d));
+            float b = orc_bf16_to_f32(orc_f32_to_bf16(scale));
+            uint16_t r = orc_f32_to_bf16(a * b);
+            if (reduce_op == ORC_ADD) o[i] = orc_f32_to_bf16(orc_bf16_to_f32(o[i]) + orc_bf16_to_f32(r));   /* operator+= :97-103 */
+            else o[i] = r;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
  * thread partition: src/piquant.cpp:132-176
  * ---------------------------------------------------------------------------------------------- */
 int orc_partition(int64_t numel, int64_t ti, int64_t tc, int packed_bits, int64_t* begin, int64_t* len) {

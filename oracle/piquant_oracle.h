@@ -51,6 +51,12 @@ void orc_quantize(const void* in, int dt_in, void* out, int dt_out, int64_t nume
 void orc_dequantize(const void* in, int dt_in, void* out, int dt_out, int64_t numel, float scale,
                     int64_t zero_point, int reduce_op, int form);
 
+/* Fused quantize -> dequantize ("requant"), float type in == float type out, never materialising the quantized
+ * tensor: src/kernels/kernels.inl:30-52 (requant_generic) over the generic scalar steps quantize.inl:8-26 and
+ * dequantize.inl:8-11; C++ API include/piquant.hpp:276-285.  One formula for every element (no SIMD fast path). */
+void orc_requantize(const void* in, int dt_inout, void* out, int quant_dtype, int64_t numel, float scale,
+                    int64_t zero_point, int round_mode, float rnd_threshold, int reduce_op);
+
 /* The static range split of src/piquant.cpp:139-157; returns 0 when the thread gets nothing. */
 int orc_partition(int64_t numel, int64_t ti, int64_t tc, int packed_bits, int64_t* begin, int64_t* len);
 /* Whole call as a context with `threads` pool threads would run it (src/piquant.cpp:159-169, 203-210). */

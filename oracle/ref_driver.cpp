@@ -209,6 +209,25 @@ void ref_dequantize(int isa, const void* in, int dt_in, void* out, int dt_out, l
     run_mt(registry_of(isa), d, threads);
 }
 
+// Fused quantize -> dequantize (command_type::quant_dequant, src/kernels/kernels.inl:175-187); dt_in is the float
+// type of input AND output, dt_out the quantized type passed through.
+void ref_requantize(int isa, const void* in, int dt_inout, void* out, int quant_dtype, long long numel, float scale,
+                    long long zero_point, int round_mode, float rnd_threshold, int reduce_op) {
+    desc_t d {};
+    d.type = piquant::context::command_type::quant_dequant;
+    d.in = static_cast<const std::byte*>(in);
+    d.out = static_cast<std::byte*>(out);
+    d.numel = numel;
+    d.scale = scale;
+    d.zero_point = zero_point;
+    d.dt_in = static_cast<piquant::dtype>(dt_inout);
+    d.dt_out = static_cast<piquant::dtype>(quant_dtype);
+    d.rounding = static_cast<piquant::round_mode>(round_mode);
+    d.reducing = static_cast<piquant::reduce_op>(reduce_op);
+    d.rnd_threshold = rnd_threshold;
+    registry_of(isa).quant_kernel(in, out, numel, d);
+}
+
 // {min,max} of one contiguous span, or of `threads` equal spans folded in double like
 // src/piquant.cpp:238-244.
 void ref_minmax_f32(int isa, const float* x, long long n, int threads, float* out_min_max) {

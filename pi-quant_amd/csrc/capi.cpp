@@ -330,6 +330,50 @@ void piquant_dequantize(piquant_context_t* ctx, const void* in, piquant_dtype_t 
     for (auto& s : ctx->stage_stream) PQ_HIP(hipStreamSynchronize(s));
 }
 
+void piquant_hip_quantize_dequantize(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in_out, void* out, piquant_dtype_t quant_dtype,
+                                     size_t numel, float scale, int64_t zero_point, piquant_round_mode_t mode, piquant_reduce_op_t op) {
+    if (!ctx) panic("piquant_hip_quantize_dequantize: context is NULL");
+    // reference src/piquant.cpp:353-355
+    if (dtype_of(dtype_in_out).quant) panic("quantize_dequantize: input dtype must be a dequantized type");
+    if (!dtype_of(quant_dtype).quant) panic("quantize_dequantize: quant dtype must be a quantized type");
+    if (mode != PIQUANT_NEAREST && mode != PIQUANT_STOCHASTIC) panic("quantize_dequantize: invalid round mode %d", static_cast<int>(mode));
+    if (op != PIQUANT_REDUCE_OP_SET && op != PIQUANT_REDUCE_OP_ADD) panic("quantize_dequantize: invalid reduce op %d", static_cast<int>(op));
+    if (numel == 0) return;
+    if (!in || !out) panic("quantize_dequantize: NULL buffer");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    const Resolved rin = resolve(in), rout = resolve(out);
+    if (rin.pageable || rout.pageable) panic("quantize_dequantize: device (or pinned) buffers required");
+    RequantLaunch r {};
+    r.in = rin.dev;
+    r.out = rout.dev;
+    r.numel = static_cast<int64_t>(numel);
+    r.dt_inout = dtype_in_out;
+    r.quant_dtype = quant_dtype;
+    r.op = op == PIQUANT_REDUCE_OP_ADD ? OP_ADD : OP_SET;
+    r.scale = scale;
+    {   // bfp16_t(scale): round to nearest even, NaN quieted (reference include/piquant.hpp:86-90)
+        uint32_t u;
+        __builtin_memcpy(&u, &scale, 4);
+        uint32_t b = (u & 0x7fffffffu) > 0x7f800000u ? ((u >> 16) | 64u) : ((u + (0x7fffu + ((u >> 16) & 1u))) >> 16);
+        b <<= 16;
+        __builtin_memcpy(&r.scale_bf16, &b, 4);
+    }
+    r.inv_scale = 1.0f / scale;
+    r.zero_point = zero_point;
+    if (mode == PIQUANT_NEAREST) r.round_mode = RM_NEAREST_I64;
+    else if (ctx->per_element) {
+        r.round_mode = RM_STOCH_ELEM;
+        r.seed = ctx->elem_seed;
+        r.index_base = ctx->elem_base;
+    } else {
+        r.round_mode = RM_STOCH_CALL;
+        r.threshold = draw_threshold(ctx);
+    }
+    launch_requantize(r, ctx->stream, ctx->num_cu);
+    if (ctx->blocking) PQ_HIP(hipStreamSynchronize(ctx->stream));
+}
+
 // Scans x into the context's armed slot buffer (re-arming the idle one for the next call) and returns the buffer
 // that now holds the per-slot {key(min), key(-max)} pairs.  Caller holds ctx->mu and the device guard.
 static int32_t* scan_into_slots(piquant_context_t* ctx, const void* x, piquant_dtype_t dtype, size_t n) {

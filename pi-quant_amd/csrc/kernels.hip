@@ -6,6 +6,7 @@
 #include "dequant_kernels.hpp"
 #include "minmax_kernels.hpp"
 #include "quant_kernels.hpp"
+#include "requant_kernels.hpp"
 #include "tuning.hpp"
 
 #include <algorithm>
@@ -148,6 +149,75 @@ void launch_dequantize(const DequantLaunch& d, hipStream_t stream, int num_cu) {
         case DT_UINT4: dequantize_out<4>(d, p, stream, num_cu); break;
         case DT_UINT2: dequantize_out<2>(d, p, stream, num_cu); break;
         default: panic("invalid dequantization types: %d -> %d", d.dt_in, d.dt_out);
+    }
+    PQ_HIP(hipGetLastError());
+}
+
+namespace {
+
+template <int DT, int BITS, int MODE, int OP>
+void requantize_t(const RequantLaunch& r, const QuantParams& qp, const DequantParams& dp, float scale_bf16, hipStream_t stream, int num_cu) {
+    constexpr KernelTune t = kRequantTune;
+    constexpr int EPV = InVec<DT>::EPV;
+    if (!aligned16(r.in) || !aligned16(r.out)) {
+        const unsigned grid = capped_grid((r.numel + kScalarBlock - 1) / kScalarBlock, 16, num_cu);
+        hipLaunchKernelGGL((requantize_scalar_kernel<DT, BITS, MODE, OP>), dim3(grid), dim3(kScalarBlock), 0, stream, r.in, r.out, r.numel, qp, dp,
+                           scale_bf16);
+        return;
+    }
+    const int64_t n_tiles = r.numel / (static_cast<int64_t>(t.block) * t.u * EPV);
+    const unsigned grid = capped_grid(n_tiles, t.blocks_per_cu, num_cu);
+    hipLaunchKernelGGL((requantize_kernel<DT, BITS, MODE, OP, t.u, t.nt, t.block>), dim3(grid), dim3(t.block), 0, stream, r.in, r.out, r.numel,
+                       n_tiles, qp, dp, scale_bf16);
+}
+
+template <int DT, int BITS, int MODE>
+void requantize_op(const RequantLaunch& r, const QuantParams& qp, const DequantParams& dp, float sb, hipStream_t stream, int num_cu) {
+    if (r.op == OP_ADD) requantize_t<DT, BITS, MODE, OP_ADD>(r, qp, dp, sb, stream, num_cu);
+    else requantize_t<DT, BITS, MODE, OP_SET>(r, qp, dp, sb, stream, num_cu);
+}
+
+template <int DT, int BITS>
+void requantize_mode(const RequantLaunch& r, const QuantParams& qp, const DequantParams& dp, float sb, hipStream_t stream, int num_cu) {
+    switch (r.round_mode) {
+        case RM_NEAREST_FAST:
+        case RM_NEAREST_I64: requantize_op<DT, BITS, RM_NEAREST_I64>(r, qp, dp, sb, stream, num_cu); return;   // generic std::round step only
+        case RM_STOCH_CALL: requantize_op<DT, BITS, RM_STOCH_CALL>(r, qp, dp, sb, stream, num_cu); return;
+        case RM_STOCH_ELEM: requantize_op<DT, BITS, RM_STOCH_ELEM>(r, qp, dp, sb, stream, num_cu); return;
+        default: panic("invalid rounding mode %d", r.round_mode);
+    }
+}
+
+template <int DT>
+void requantize_bits(const RequantLaunch& r, const QuantParams& qp, const DequantParams& dp, float sb, hipStream_t stream, int num_cu) {
+    switch (r.quant_dtype) {
+        case DT_UINT8: requantize_mode<DT, 8>(r, qp, dp, sb, stream, num_cu); return;
+        case DT_UINT4: requantize_mode<DT, 4>(r, qp, dp, sb, stream, num_cu); return;
+        case DT_UINT2: requantize_mode<DT, 2>(r, qp, dp, sb, stream, num_cu); return;
+        default: panic("invalid requantization types: %d -> %d", r.dt_inout, r.quant_dtype);
+    }
+}
+
+}  // namespace
+
+void launch_requantize(const RequantLaunch& r, hipStream_t stream, int num_cu) {
+    if (r.numel <= 0) return;
+    QuantParams qp {};
+    qp.inv_scale = r.inv_scale;
+    qp.zp64 = r.zero_point;
+    qp.zp32 = static_cast<int32_t>(static_cast<uint32_t>(static_cast<uint64_t>(r.zero_point)));
+    qp.threshold = r.threshold;
+    qp.seed_lo = static_cast<uint32_t>(r.seed);
+    qp.seed_hi = static_cast<uint32_t>(r.seed >> 32);
+    qp.index_base = r.index_base;
+    DequantParams dp {};
+    dp.scale = r.scale;
+    dp.zp64 = r.zero_point;
+    dp.zp32 = qp.zp32;
+    switch (r.dt_inout) {
+        case DT_F32: requantize_bits<DT_F32>(r, qp, dp, r.scale_bf16, stream, num_cu); break;
+        case DT_BF16: requantize_bits<DT_BF16>(r, qp, dp, r.scale_bf16, stream, num_cu); break;
+        default: panic("invalid requantization types: %d -> %d", r.dt_inout, r.quant_dtype);
     }
     PQ_HIP(hipGetLastError());
 }

@@ -32,9 +32,27 @@ struct DequantLaunch {
     int64_t zero_point;
 };
 
+struct RequantLaunch {
+    const void* in;        // may equal out (in-place)
+    void* out;
+    int64_t numel;
+    int dt_inout;          // DT_F32 / DT_BF16 (input and output type)
+    int quant_dtype;       // DT_UINT2/4/8 (the type passed through)
+    int round_mode;        // RM_*
+    int op;                // OP_SET / OP_ADD
+    float scale;
+    float scale_bf16;      // scale rounded to bf16 and widened back (bf16 path multiplies by this)
+    float inv_scale;
+    int64_t zero_point;
+    float threshold;
+    uint64_t seed;
+    uint64_t index_base;
+};
+
 // All launches are asynchronous on `stream`; num_cu sizes capped grids.
 void launch_quantize(const QuantLaunch& q, hipStream_t stream, int num_cu);
 void launch_dequantize(const DequantLaunch& d, hipStream_t stream, int num_cu);
+void launch_requantize(const RequantLaunch& r, hipStream_t stream, int num_cu);
 // Min/max scan into a slot buffer (kMinmaxSlotInts int32, armed with the identity beforehand); rearm_slots
 // (nullable) is a second, idle slot buffer that the scan re-arms for a later call.
 void launch_minmax(const void* in, int dt_in, int64_t numel, int32_t* slots, int32_t* rearm_slots, hipStream_t stream, int num_cu);

@@ -26,6 +26,9 @@ constexpr KernelTune kDequantTune[2][3] = {
     {{4, true, 3, 256, 0}, {4, true, 3, 256, 0}, {4, true, 3, 256, 0}},
 };
 
+// fused quantize->dequantize: plain 16-byte streams both ways, no LDS staging
+constexpr KernelTune kRequantTune = {4, false, 3, 256, 0};
+
 // min/max scan: few, long-lived blocks -- the end-of-block atomics serialise (~11 ns each), the read stream
 // itself saturates from 2 blocks per CU (18.0 us at numel 27 264 000 = 6.07 TB/s).
 constexpr int kMinmaxU = 4;

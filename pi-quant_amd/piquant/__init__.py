@@ -151,6 +151,13 @@ class Context:
         """Opt-in: an independent threshold per element (counter hash of seed and global element index)."""
         C.piquant_hip_set_stochastic_per_element(self._ctx, 1 if enabled else 0, seed & 0xFFFFFFFFFFFFFFFF, index_base)
 
+    def quantize_dequantize_ptr(self, ptr_in: int, dtype_in_out: DataType, ptr_out: int, quant_dtype: DataType, numel: int, scale: float,
+                                zero_point: int, round_mode: RoundMode, reduce_op: ReduceOp) -> None:
+        """Fused quantize->dequantize (the reference's C++-only ``quantize_dequantize_fused``, piquant.hpp:276-285)."""
+        assert dtype_in_out.is_dequantized and quant_dtype.is_quantized
+        C.piquant_hip_quantize_dequantize(self._ctx, ptr_in, dtype_in_out.value, ptr_out, quant_dtype.value, numel, scale, zero_point,
+                                          round_mode.value, reduce_op.value)
+
     def minmax_keys_ptr(self, ptr: int, dtype: DataType, numel: int, device_keys_ptr: int, init: bool = True) -> None:
         """Asynchronously fold {min, -max} of the buffer into two int32 keys in device memory (atomic MIN)."""
         assert dtype.is_dequantized

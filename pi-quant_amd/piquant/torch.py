@@ -198,3 +198,32 @@ def dequantize(
         reduce_op=_REDUCE_OPS[reduce_op],
     )
     return out
+
+
+def quantize_dequantize(
+    tensor: torch.Tensor,
+    *,
+    scale: float,
+    zero_point: int,
+    quant_dtype: torch.dtype,
+    round_mode: str = 'nearest',
+    reduce_op: str = 'set',
+    ctx: Optional[Context] = None,
+    out: Optional[torch.Tensor] = None,
+) -> torch.Tensor:
+    """out (op)= dequantize(quantize(tensor)) in one pass over HBM -- the reference's C++-only
+    ``context::quantize_dequantize_fused`` (``include/piquant.hpp:276-285``); ``out`` may be ``tensor`` (in place)."""
+    assert quant_dtype in _QUANT_TYPES, f'Unsupported quantized dtype: {quant_dtype}'
+    assert tensor.dtype in _DEQUANT_TYPES and tensor.is_cuda, 'quantize_dequantize needs a float32/bfloat16 device tensor'
+    if not tensor.is_contiguous():
+        tensor = tensor.contiguous()
+    if out is None:
+        if reduce_op == 'add':
+            raise ValueError("reduce_op='add' accumulates into out=; pass the accumulator tensor")
+        out = torch.empty_like(tensor)
+    else:
+        assert out.dtype == tensor.dtype and out.is_contiguous() and out.device == tensor.device and out.numel() == tensor.numel()
+    ctx = _ctx_for(tensor, ctx)
+    ctx.quantize_dequantize_ptr(tensor.data_ptr(), torch_to_piquant_dtype(tensor.dtype), out.data_ptr(), torch_to_piquant_dtype(quant_dtype),
+                                tensor.numel(), scale, zero_point, _ROUND_MODES[round_mode], _REDUCE_OPS[reduce_op])
+    return out

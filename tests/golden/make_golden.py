@@ -110,6 +110,26 @@ def main():
     add("dequantize", "d_known_add", dict(dt_in=O.UINT8, dt_out=O.F32, op=O.ADD, scale=0.5, zp=3, numel=70),
         q=q, prev=prev, ref=ref, uniform=O.dequantize(q, O.UINT8, O.F32, 70, 0.5, 3, O.ADD, out=prev.copy()))
 
+    # ---------------- fused quantize->dequantize (reference kernels.inl:30-52, command quant_dequant) ----------------
+    for dt in (O.F32, O.BF16):
+        for qd in (O.UINT8, O.UINT4, O.UINT2):
+            for rm, tau in ((O.NEAREST, 0.0), (O.STOCHASTIC, 0.25)):
+                for op in (O.SET, O.ADD):
+                    for (scale, zp) in params[qd]:
+                        for n in (0, 1, 5, 17, 65, 257, 1000):
+                            x = rng.uniform(-1.2, 1.2, n).astype(np.float32)
+                            if n >= 64:
+                                ev = edge_values(scale)
+                                pos = rng.choice(n, size=min(len(ev), n), replace=False)
+                                x[pos] = ev[: len(pos)]
+                            xin = x if dt == O.F32 else O.f32_to_bf16(x)
+                            prev = rng.uniform(-4, 4, n).astype(np.float32)
+                            prev_in = prev if dt == O.F32 else O.f32_to_bf16(prev)
+                            ref = R.requantize(xin, dt, qd, scale, zp, rm, tau, op, isa=isa, out=prev_in.copy())
+                            name = f"r_{F32_NAMES[dt]}_{Q_NAMES[qd]}_{'st' if rm else 'nr'}_{'add' if op else 'set'}_{len(manifest)}"
+                            add("requantize", name, dict(dt=dt, quant_dtype=qd, round_mode=rm, tau=tau, op=op, scale=scale, zp=zp, numel=n),
+                                x=xin, prev=prev_in, ref=ref)
+
     # ---------------- min/max ----------------
     for n in (1, 2, 63, 64, 65, 1000, 4099):
         x = rng.normal(size=n).astype(np.float32)

@@ -290,6 +290,87 @@ def test_per_element_stochastic_extension(ctx, O):
 
 
 # ---------------------------------------------------------------------------------------------------
+# fused quantize -> dequantize ("requant", reference C++ API only; piquant_hip_quantize_dequantize here)
+# ---------------------------------------------------------------------------------------------------
+def gpu_requantize(ctx, x, dt, qd, scale, zp, rm, op, prev, in_place=False):
+    import piquant
+    import torch
+
+    odt = np.float32 if dt == 0 else np.uint16
+    _, pin = keep = to_device(x)
+    obuf = torch.full((prev.nbytes + 64,), 0xAA, dtype=torch.uint8, device="cuda")
+    out = obuf[: prev.nbytes]
+    if prev.nbytes:
+        out.copy_(torch.from_numpy(prev.view(np.uint8).reshape(-1)))
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_blocking(False)
+    if in_place:
+        ctx.quantize_dequantize_ptr(pin, piquant.DataType(dt), pin, piquant.DataType(qd), x.size, scale, zp, piquant.RoundMode(rm), piquant.ReduceOp(op))
+        torch.cuda.synchronize()
+        return keep[0].cpu().numpy().view(odt).copy()
+    ctx.quantize_dequantize_ptr(pin, piquant.DataType(dt), out.data_ptr(), piquant.DataType(qd), x.size, scale, zp, piquant.RoundMode(rm),
+                                piquant.ReduceOp(op))
+    torch.cuda.synchronize()
+    assert bool((obuf[prev.nbytes:] == 0xAA).all())
+    return out.cpu().numpy().view(odt).copy()
+
+
+def test_golden_requantize(ctx):
+    cases, get = load_golden()
+    n = 0
+    for c in cases:
+        if c["kind"] != "requantize" or c["numel"] == 0:
+            continue
+        ctx.set_stochastic_threshold(c["tau"] if c["round_mode"] else None)
+        got = gpu_requantize(ctx, get(c["name"], "x"), c["dt"], c["quant_dtype"], c["scale"], c["zp"], c["round_mode"], c["op"], get(c["name"], "prev"))
+        assert same_floats(got, get(c["name"], "ref")), c
+        n += 1
+    ctx.set_stochastic_threshold(None)
+    assert n > 250
+
+
+@pytest.mark.parametrize("dt", [0, 1], ids=["f32", "bf16"])
+@pytest.mark.parametrize("qd", [4, 3, 2], ids=["u8", "u4", "u2"])
+def test_requantize_random_and_reference_tolerances(ctx, O, dt, qd):
+    """Bit-exact vs the oracle, plus the reference's own round-trip test (test/requant.cpp:19-63: params from data,
+    fused requant with SET and ADD, tolerance 0.1 / 0.2 / 0.7 for uint8 / uint4 / uint2)."""
+    rng = np.random.default_rng(40 + 10 * dt + qd)
+    tol = {4: 0.1, 3: 0.2, 2: 0.7}[qd]
+    for n in (1, 1000, 4096, 4097, 1_000_003):
+        x = rng.uniform(-1, 1, n).astype(np.float32)
+        xin = x if dt == 0 else O.f32_to_bf16(x)
+        scale, zp = O.compute_quant_params(xin, dt, qd)
+        for rm, tau in ((0, 0.0), (1, 0.41)):
+            ctx.set_stochastic_threshold(tau if rm else None)
+            for op in (0, 1):
+                prev = rng.uniform(-1, 1, n).astype(np.float32)
+                prev = prev if dt == 0 else O.f32_to_bf16(prev)
+                got = gpu_requantize(ctx, xin, dt, qd, scale, zp, rm, op, prev)
+                want = O.requantize(xin, dt, qd, scale, zp, rm, tau, op, out=prev.copy())
+                assert same_floats(got, want), (n, rm, op)
+                if dt == 0 and rm == 0 and n > 1:
+                    err = np.abs(got - (prev if op else 0) - x)
+                    assert err.max() <= tol, (n, op, err.max())
+            if dt == 0:   # in place (out aliases in)
+                got = gpu_requantize(ctx, xin, dt, qd, scale, zp, rm, 0, np.zeros(n, np.float32), in_place=True)
+                assert same_floats(got, O.requantize(xin, dt, qd, scale, zp, rm, tau, 0))
+    ctx.set_stochastic_threshold(None)
+
+
+def test_requantize_torch_api(O):
+    import piquant
+    import torch
+
+    x = torch.empty(300_001, device="cuda").uniform_(-1, 1)
+    scale, zp = piquant.torch.compute_quant_params(x, dtype=torch.quint4x2)
+    y = piquant.torch.quantize_dequantize(x, scale=scale, zero_point=zp, quant_dtype=torch.quint4x2)
+    q = piquant.torch.quantize(x, scale=scale, zero_point=zp, dtype=torch.quint4x2)
+    z = piquant.torch.dequantize(q, scale=scale, zero_point=zp, dtype=torch.float32)
+    assert float((y - z).abs().max()) <= 1e-6      # same values as the two-pass route on ordinary data
+    assert np.array_equal(y.cpu().numpy(), O.requantize(x.cpu().numpy(), 0, 3, scale, zp))
+
+
+# ---------------------------------------------------------------------------------------------------
 # compute_quant_params
 # ---------------------------------------------------------------------------------------------------
 def test_compute_quant_params_matches_oracle(ctx, O):

@@ -59,6 +59,39 @@ def test_dequantize_all_pairs(both):
                         assert np.array_equal(a, b), (dt_q, dt_f, op, n, scale, zp)
 
 
+def test_requantize_all_pairs(both):
+    """fused quantize->dequantize: every float type x quantized type x rounding x store op (24 combinations,
+    reference kernels.inl:139-149), generic and AVX-512 units."""
+    O, R = both
+    rng = np.random.default_rng(10)
+    for isa in (O.Ref.GENERIC, O.Ref.AVX512F):
+        if not R.supported(isa):
+            continue
+        for dt in (O.F32, O.BF16):
+            for qd in (O.UINT8, O.UINT4, O.UINT2):
+                for rm in (O.NEAREST, O.STOCHASTIC):
+                    for op in (O.SET, O.ADD):
+                        for n in (0, 1, 17, 129, 4099):
+                            x = rng.uniform(-2, 2, n).astype(np.float32)
+                            if n > 20:
+                                x[[3, 5, 7, 9]] = [np.nan, np.inf, -np.inf, 1e30]
+                            xin = x if dt == O.F32 else O.f32_to_bf16(x)
+                            prev = rng.uniform(-3, 3, n).astype(np.float32)
+                            prev = prev if dt == O.F32 else O.f32_to_bf16(prev)
+                            tau = float(rng.uniform(0, 1)) if rm else 0.0
+                            a = O.requantize(xin, dt, qd, 0.05, 7, rm, tau, op, out=prev.copy())
+                            b = R.requantize(xin, dt, qd, 0.05, 7, rm, tau, op, isa=isa, out=prev.copy())
+                            assert same(a, b), (dt, qd, rm, op, n)
+
+
+def same(a, b):
+    nan_a = np.isnan(a) if a.dtype == np.float32 else (a & 0x7FFF) > 0x7F80
+    nan_b = np.isnan(b) if b.dtype == np.float32 else (b & 0x7FFF) > 0x7F80
+    ua = a.view(np.uint32) if a.dtype == np.float32 else a
+    ub = b.view(np.uint32) if b.dtype == np.float32 else b
+    return np.array_equal(nan_a, nan_b) and np.array_equal(ua[~nan_a], ub[~nan_b])
+
+
 def test_threaded_partition_matches_reference_kernels_run_per_partition(both):
     """The reference with T pool threads == its kernels run on each partition (src/piquant.cpp:159-169)."""
     O, R = both
