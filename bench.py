@@ -131,13 +131,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU: the product has no CPU path"
-    if world > 1:
-        assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-        torch.cuda.set_device(local_rank)
+    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ      # launched by torch.distributed.run (any N, also N=1)
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: for N > 1 launch through torch.distributed.run"
+    torch.cuda.set_device(local_rank if use_dist else 0)
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        assert args.gpus == 1, "for --gpus N > 1 launch through torch.distributed.run (one process per GPU)"
-        torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
 
     import piquant
@@ -175,14 +173,14 @@ def main():
         for i in range(args.warmup):
             step(i)
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         wall, ev = time_loop(step, args.steps, stream)
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     t = torch.tensor([wall, ev], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max, ev_max = float(t[0]), float(t[1])
 
@@ -292,7 +290,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -62,7 +62,8 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
     constexpr int EPV = T::EPV, IB = T::IB;
     constexpr int WORDS = IB > 4 ? 2 : 1;
     constexpr int FORM = DequantForm<BITS, DT_OUT>::value;
-    constexpr bool NT_LD = (NT & 1) != 0, NT_ST = (NT & 2) != 0;   // non-temporal loads / stores
+    constexpr bool NT_LD = (NT & 1) != 0;   // see mem_policy()
+    constexpr int NT_ST = NT >> 1;
 
     __shared__ __attribute__((aligned(16))) uint8_t lds[STAGE ? T::WAVES * T::WAVE_IN_BYTES : 16];
 

@@ -24,16 +24,35 @@ namespace pq {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
+// Cache policy of the streaming accesses.  A kernel's NT template argument packs both: bit 0 = loads non-temporal,
+// bits 1-2 = store policy.  Measured on MI355X for fp32->uint8 (profiles/r01_tune_experiments.csv): nt loads are
+// worth ~6 % over plain loads; for the stores write-through (`sc0 sc1`) beats nt by ~7 % and plain by ~6 %: a
+// write-back store leaves its line dirty in the XCD's L2 and the whole output is flushed at the kernel boundary,
+// a write-through store goes to HBM while the loads are still streaming.
+enum : int { ST_PLAIN = 0, ST_NT = 1, ST_WT = 2 };
+constexpr int mem_policy(bool nt_loads, int store_policy) { return (nt_loads ? 1 : 0) | (store_policy << 1); }
+
 template <bool NT, typename T>
 __device__ __forceinline__ T ld(const T* p) {
     if constexpr (NT) return __builtin_nontemporal_load(p);
     else return *p;
 }
 
-template <bool NT, typename T>
+// Stores are the last use of their data and nothing in these kernels reads the stored bytes back, so the asm forms
+// need no waitcnt bookkeeping (the hardware drains outstanding stores before the wave ends).
+template <int POLICY, typename T>
 __device__ __forceinline__ void st(T* p, T v) {
-    if constexpr (NT) __builtin_nontemporal_store(v, p);
-    else *p = v;
+    if constexpr (POLICY == ST_NT) {
+        __builtin_nontemporal_store(v, p);
+    } else if constexpr (POLICY == ST_WT) {
+        if constexpr (sizeof(T) == 16) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+        else if constexpr (sizeof(T) == 8) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+        else if constexpr (sizeof(T) == 4) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+        else if constexpr (sizeof(T) == 2) asm volatile("global_store_short %0, %1, off sc0 sc1" ::"v"(p), "v"(static_cast<uint32_t>(v)) : "memory");
+        else asm volatile("global_store_byte %0, %1, off sc0 sc1" ::"v"(p), "v"(static_cast<uint32_t>(v)) : "memory");
+    } else {
+        *p = v;
+    }
 }
 
 template <int DT_IN>
@@ -96,13 +115,14 @@ struct QuantTile {
     static constexpr int64_t BLOCK_ELEMS = static_cast<int64_t>(WAVES) * WAVE_VECS * EPV;
 };
 
-template <int DT_IN, int BITS, int MODE, int U, bool STAGE, int NT, int BLOCK, bool XCD = false>
+template <int DT_IN, int BITS, int MODE, int U, bool STAGE, int NT, int BLOCK, bool PF = false>
 __global__ void __launch_bounds__(BLOCK)
 quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t numel, int64_t n_tiles, QuantParams p) {
     using T = QuantTile<DT_IN, BITS, U, BLOCK>;
     constexpr int EPV = T::EPV, OB = T::OB, QMAX = (1 << BITS) - 1;
     constexpr int WORDS = OB > 4 ? 2 : 1;
-    constexpr bool NT_LD = (NT & 1) != 0, NT_ST = (NT & 2) != 0;   // non-temporal loads / stores
+    constexpr bool NT_LD = (NT & 1) != 0;   // see mem_policy()
+    constexpr int NT_ST = NT >> 1;
 
     __shared__ __attribute__((aligned(16))) uint8_t lds[STAGE ? T::WAVES * T::WAVE_OUT_BYTES : 16];
 
@@ -110,20 +130,35 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
     const int wave = threadIdx.x >> 6;
     const u32x4* __restrict__ in16 = static_cast<const u32x4*>(in);
 
-    // XCD: blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8); with the remap each XCD
-    // streams one contiguous eighth of the tensor instead of every eighth tile (a speed experiment only).
-    const int64_t per_xcd = (n_tiles + 7) / 8;
-    const int64_t t_first = XCD ? (blockIdx.x >> 3) : blockIdx.x;
-    const int64_t t_step = XCD ? (gridDim.x >> 3) : gridDim.x;
-    const int64_t t_end = XCD ? per_xcd : n_tiles;
-    for (int64_t t = t_first; t < t_end; t += t_step) {
-        const int64_t tile = XCD ? (blockIdx.x & 7) * per_xcd + t : t;
-        if (XCD && tile >= n_tiles) break;
+    // PF (software prefetch, for persistent grids): the loads of the wave's NEXT tile are issued before the current
+    // tile is converted and stored, so a wave always has U loads in flight instead of idling its memory pipe while
+    // it computes.
+    int64_t tile = blockIdx.x;
+    u32x4 nxt[PF ? U : 1];
+    if constexpr (PF) {
+        if (tile < n_tiles) {
+            const int64_t vn = (tile * T::WAVES + wave) * T::WAVE_VECS;
+#pragma unroll
+            for (int k = 0; k < U; ++k) nxt[k] = ld<NT_LD>(in16 + vn + k * 64 + lane);
+        }
+    }
+    for (; tile < n_tiles; tile += gridDim.x) {
         const int64_t v0 = (tile * T::WAVES + wave) * T::WAVE_VECS;   // first input vector of this wave tile
 
         u32x4 raw[U];
+        if constexpr (PF) {
 #pragma unroll
-        for (int k = 0; k < U; ++k) raw[k] = ld<NT_LD>(in16 + v0 + k * 64 + lane);
+            for (int k = 0; k < U; ++k) raw[k] = nxt[k];
+            const int64_t tn = tile + gridDim.x;
+            if (tn < n_tiles) {
+                const int64_t vn = (tn * T::WAVES + wave) * T::WAVE_VECS;
+#pragma unroll
+                for (int k = 0; k < U; ++k) nxt[k] = ld<NT_LD>(in16 + vn + k * 64 + lane);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < U; ++k) raw[k] = ld<NT_LD>(in16 + v0 + k * 64 + lane);
+        }
 
         uint32_t w[U][WORDS];
 #pragma unroll

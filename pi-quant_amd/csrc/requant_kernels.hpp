@@ -85,7 +85,8 @@ template <int DT, int BITS, int MODE, int OP, int U, int NT, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 requantize_kernel(const void* in, void* out, int64_t numel, int64_t n_tiles, QuantParams qp, DequantParams dp, float scale_bf16) {
     constexpr int EPV = InVec<DT>::EPV;
-    constexpr bool NT_LD = (NT & 1) != 0, NT_ST = (NT & 2) != 0;
+    constexpr bool NT_LD = (NT & 1) != 0;
+    constexpr int NT_ST = NT >> 1;
     constexpr int64_t TILE_VECS = static_cast<int64_t>(BLOCK) * U;
     const u32x4* in16 = static_cast<const u32x4*>(in);
     u32x4* out16 = static_cast<u32x4*>(out);

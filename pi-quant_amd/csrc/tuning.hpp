@@ -7,27 +7,31 @@ namespace pq {
 struct KernelTune {
     int u;             // 16-byte vectors in flight per lane per tile
     bool stage;        // transpose the narrow side through LDS for 16-byte accesses
-    int nt;            // bit 0: non-temporal loads, bit 1: non-temporal stores
+    int nt;            // mem_policy(): bit 0 = non-temporal loads, bits 1-2 = store policy (ST_PLAIN / ST_NT / ST_WT)
     int block;         // threads per workgroup
     int blocks_per_cu; // grid cap = blocks_per_cu * CU count (grid-stride beyond); 0 = one tile per block
 };
 
+// nt loads + write-through stores: the measured best for every kernel of the path (quant_kernels.hpp, st<>)
+constexpr int kStream = 1 | (2 << 1);
+
 // quantize, indexed [dt_in: f32,bf16][bits: 8,4,2].
-// fp32->uint8 (the headline): every geometry lands within 5 % (22.8-24.1 us at numel 27 264 000); 1024-thread
-// blocks with two vectors in flight per lane were the repeatable best in two sweeps (profiles/tune_r01_*.csv).
+// Interleaved A/B sweeps on MI355X (profiles/r01_tune_finals_*.csv, numel 27 264 000, one tile per block): small
+// tiles win -- one or two waves per block with two vectors in flight per lane (fp32->uint8: 21.55 us against 22.2 us
+// for 256-thread/U=4 blocks and 22.0 us for 1024-thread blocks); persistent grids and software prefetch lose.
 constexpr KernelTune kQuantTune[2][3] = {
-    {{2, true, 3, 1024, 0}, {4, true, 3, 256, 0}, {4, true, 3, 256, 0}},
-    {{4, true, 3, 256, 0}, {4, true, 3, 256, 0}, {4, true, 3, 256, 0}},
+    {{2, true, kStream, 128, 0}, {2, true, kStream, 64, 0}, {2, true, kStream, 64, 0}},
+    {{2, true, kStream, 64, 0}, {4, true, kStream, 64, 0}, {4, true, kStream, 64, 0}},
 };
 
 // dequantize, indexed [dt_out: f32,bf16][bits: 8,4,2]
 constexpr KernelTune kDequantTune[2][3] = {
-    {{4, true, 3, 256, 0}, {4, true, 3, 256, 0}, {4, true, 3, 256, 0}},
-    {{4, true, 3, 256, 0}, {4, true, 3, 256, 0}, {4, true, 3, 256, 0}},
+    {{2, true, kStream, 128, 0}, {4, true, kStream, 256, 0}, {4, true, kStream, 256, 0}},
+    {{4, true, kStream, 128, 0}, {2, true, kStream, 128, 0}, {2, true, kStream, 128, 0}},
 };
 
 // fused quantize->dequantize: plain 16-byte streams both ways, no LDS staging
-constexpr KernelTune kRequantTune = {4, false, 3, 256, 0};
+constexpr KernelTune kRequantTune = {4, false, kStream, 256, 0};
 
 // min/max scan: few, long-lived blocks -- the end-of-block atomics serialise (~11 ns each), the read stream
 // itself saturates from 2 blocks per CU (18.0 us at numel 27 264 000 = 6.07 TB/s).
