@@ -38,15 +38,18 @@ __device__ __forceinline__ T ld(const T* p) {
     else return *p;
 }
 
-// Stores are the last use of their data and nothing in these kernels reads the stored bytes back, so the asm forms
-// need no waitcnt bookkeeping (the hardware drains outstanding stores before the wave ends).
+// Nothing in these kernels reads the stored bytes back, so the asm forms need no waitcnt bookkeeping (the hardware
+// drains outstanding stores before the wave ends).  hipcc does not pad hazards inside an asm statement: a store of
+// more than 64 bits must be followed by `s_nop 1` inside the string, or the next VALU instruction may overwrite the
+// data registers before the store has read them (guides/cdna_hip_programming.md §5.7 item 1) -- without it the
+// fused requant kernel, which recomputes `res` right after the store, wrote corrupted vectors.
 template <int POLICY, typename T>
 __device__ __forceinline__ void st(T* p, T v) {
     if constexpr (POLICY == ST_NT) {
         __builtin_nontemporal_store(v, p);
     } else if constexpr (POLICY == ST_WT) {
-        if constexpr (sizeof(T) == 16) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-        else if constexpr (sizeof(T) == 8) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+        if constexpr (sizeof(T) == 16) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+        else if constexpr (sizeof(T) == 8) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
         else if constexpr (sizeof(T) == 4) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
         else if constexpr (sizeof(T) == 2) asm volatile("global_store_short %0, %1, off sc0 sc1" ::"v"(p), "v"(static_cast<uint32_t>(v)) : "memory");
         else asm volatile("global_store_byte %0, %1, off sc0 sc1" ::"v"(p), "v"(static_cast<uint32_t>(v)) : "memory");
