@@ -12,9 +12,9 @@ Same functions and keyword arguments as the reference module (``python/src/piqua
 * ``ctx=None`` resolves to the default context of the tensor's device at call time (the reference evaluates
   ``Context.get()`` once, at import).
 
-Packed sub-byte results: ``torch.quint4x2`` / ``torch.quint2x4`` tensors cannot be allocated on a ROCm
-device by ``torch.empty``, so device-side packed results are returned as a 1-D ``torch.uint8`` tensor of
-``ceil(numel*bits/8)`` bytes tagged with the logical shape and quantized dtype (``PackedTensor``).
+Quantized results are real ``torch.quint8`` / ``torch.quint4x2`` / ``torch.quint2x4`` tensors of the input's shape,
+exactly as in the reference; PyTorch-ROCm can allocate them on the device (``torch.empty(shape, dtype=torch.quint4x2,
+device='cuda')``) even though it implements hardly any operator on them -- ``packed_bytes`` gives the raw bytes.
 """
 from __future__ import annotations
 
@@ -53,20 +53,13 @@ def piquant_to_torch_dtype(dtype: DataType) -> torch.dtype:
     raise ValueError(f'Unsupported quantized dtype: {dtype}')
 
 
-class PackedTensor(torch.Tensor):
-    """A 1-D uint8 tensor of packed uint4/uint2 values that remembers its logical shape and dtype."""
-
-    quant_dtype: torch.dtype
-    logical_shape: torch.Size
-    # results of torch ops on a PackedTensor (.cpu(), slicing, ...) are plain tensors
-    __torch_function__ = torch._C._disabled_torch_function_impl
-
-    @staticmethod
-    def wrap(raw: torch.Tensor, quant_dtype: torch.dtype, shape) -> 'PackedTensor':
-        t = raw.as_subclass(PackedTensor)
-        t.quant_dtype = quant_dtype
-        t.logical_shape = torch.Size(shape)
-        return t
+def packed_bytes(tensor: torch.Tensor) -> torch.Tensor:
+    """1-D uint8 view of the bytes that hold a quantized tensor: ``ceil(numel * bits / 8)`` of them, lower element
+    index in the lower bits (PyTorch's own packing for quint4x2 / quint2x4 and the reference's)."""
+    dt = torch_to_piquant_dtype(tensor.dtype)
+    raw = torch.empty(0, dtype=torch.uint8, device=tensor.device).set_(tensor.untyped_storage())
+    first = tensor.storage_offset() * max(dt.bit_size, 8) // 8
+    return raw[first: first + dt.packed_nbytes(tensor.numel())]
 
 
 def _ctx_for(tensor: torch.Tensor, ctx: Optional[Context]) -> Context:
@@ -87,26 +80,11 @@ def _ctx_for(tensor: torch.Tensor, ctx: Optional[Context]) -> Context:
     return ctx
 
 
-def _alloc_quantized(shape, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
-    qdt = torch_to_piquant_dtype(dtype)
-    numel = 1
-    for s in shape:
-        numel *= int(s)
-    if dtype == torch.uint8:
-        return torch.empty(shape, dtype=torch.uint8, device=device)
-    if device.type == 'cpu':
-        return torch.empty(shape, dtype=dtype)          # exactly what the reference returns (torch.py:87)
-    if dtype == torch.quint8:
-        # byte-per-element: a plain uint8 tensor of the logical shape carries it on the device
-        return PackedTensor.wrap(torch.empty(shape, dtype=torch.uint8, device=device), dtype, shape)
-    raw = torch.empty(qdt.packed_nbytes(numel), dtype=torch.uint8, device=device)
-    return PackedTensor.wrap(raw, dtype, shape)
-
-
 def _quant_meta(tensor: torch.Tensor, quant_dtype: Optional[torch.dtype], shape) -> Tuple[DataType, torch.Size]:
-    if isinstance(tensor, PackedTensor):
-        return torch_to_piquant_dtype(tensor.quant_dtype), tensor.logical_shape
-    if quant_dtype is not None:
+    """Quantized dtype and logical shape of a dequantize input: from the tensor itself, or -- for a raw uint8 buffer of
+    packed bytes -- from the ``quant_dtype=`` / ``shape=`` keywords."""
+    if quant_dtype is not None and quant_dtype != tensor.dtype:
+        assert tensor.dtype == torch.uint8, 'quant_dtype= reinterprets a raw uint8 byte buffer'
         assert shape is not None, 'shape= is required together with quant_dtype= for raw packed buffers'
         return torch_to_piquant_dtype(quant_dtype), torch.Size(shape)
     return torch_to_piquant_dtype(tensor.dtype), tensor.shape
@@ -141,10 +119,10 @@ def quantize(
     dtype_in = torch_to_piquant_dtype(tensor.dtype)
     dtype_out = torch_to_piquant_dtype(dtype)
     if out is None:
-        out = _alloc_quantized(tensor.shape, dtype, tensor.device)
+        out = torch.empty(tensor.shape, dtype=dtype, device=tensor.device)   # reference torch.py:87, plus the device
     else:
         assert out.is_contiguous() and out.device == tensor.device
-        assert out.numel() * out.element_size() >= dtype_out.packed_nbytes(tensor.numel()), 'out= is too small'
+        assert out.untyped_storage().nbytes() >= dtype_out.packed_nbytes(tensor.numel()), 'out= is too small'
     ctx = _ctx_for(tensor, ctx)
     ctx.quantize_ptr(
         tensor.data_ptr(),

@@ -224,7 +224,8 @@ def test_config3_bf16_to_u4_round_trip_full_size(ctx, O, big_x):
     scale, zp = piquant.torch.compute_quant_params(xd, dtype=torch.quint4x2)
     assert (scale, zp) == O.compute_quant_params(xb, 1, 3)
     q = piquant.torch.quantize(xd, scale=scale, zero_point=zp, dtype=torch.quint4x2)
-    qn = q.cpu().numpy().view(np.uint8)
+    assert q.dtype == torch.quint4x2 and q.is_cuda and q.shape == xd.shape
+    qn = piquant.torch.packed_bytes(q).cpu().numpy()
     assert qn.size == (N1 + 1) // 2
     assert np.array_equal(qn, O.quantize(xb, 1, 3, scale, zp))
     back = piquant.torch.dequantize(q, scale=scale, zero_point=zp, dtype=torch.bfloat16)
@@ -262,6 +263,50 @@ def test_config4_stochastic_and_add_store_full_size(ctx, O, big_x):
     got_acc = acc.cpu().numpy()
     assert same_floats(got_acc, want_acc)
     assert np.abs((got_acc - 1.0) - big_x).max() <= scale * 1.0001 + 1e-6
+
+
+def test_more_than_2_pow_32_elements(O):
+    """Maximum sizes: 64-bit element indexing end to end (numel > 2^32: 17 GB of fp32 in HBM).  The oracle checks
+    windows around 0, 2^31, 2^32 and the ragged end; shard invariance (whole == three unequal chunks) covers the rest."""
+    import piquant
+    import torch
+
+    n = (1 << 32) + 4099
+    if torch.cuda.get_device_properties(0).total_memory < 80 * 2**30:
+        pytest.skip("needs ~50 GB of HBM")
+    x = torch.empty(n, dtype=torch.float32, device="cuda").uniform_(-1, 1)
+    x[(1 << 32) + 77] = -3.5          # global extremes live beyond the 32-bit index range
+    x[(1 << 31) + 5] = 2.75
+    windows = [(0, 1 << 20), ((1 << 31) - (1 << 19), (1 << 31) + (1 << 19)), ((1 << 32) - (1 << 19), n)]
+
+    scale, zp = piquant.torch.compute_quant_params(x, dtype=torch.quint8)
+    assert (scale, zp) == O.quant_params_from_minmax(-3.5, 2.75, 4)
+    q = piquant.torch.quantize(x, scale=scale, zero_point=zp, dtype=torch.uint8)
+    for a, b in windows:
+        assert np.array_equal(q[a:b].cpu().numpy(), O.quantize(x[a:b].cpu().numpy(), 0, 4, scale, zp)), (a, b)
+    cuts = [0, (1 << 31) + 4096 * 3, (1 << 32) - 4096 * 5, n]
+    q2 = torch.empty_like(q)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        piquant.torch.quantize(x[a:b], scale=scale, zero_point=zp, dtype=torch.uint8, out=q2[a:b])
+    assert torch.equal(q, q2)
+    del q2
+
+    # packed uint4 from the same data (2 elements per byte: byte index = element index / 2 beyond 2^31)
+    s4, z4 = piquant.torch.compute_quant_params(x, dtype=torch.quint4x2)
+    q4 = piquant.torch.packed_bytes(piquant.torch.quantize(x, scale=s4, zero_point=z4, dtype=torch.quint4x2))
+    assert q4.numel() == (n + 1) // 2
+    for a, b in windows:
+        assert a % 2 == 0
+        assert np.array_equal(q4[a // 2: (b + 1) // 2].cpu().numpy(), O.quantize(x[a:b].cpu().numpy(), 0, 3, s4, z4)), (a, b)
+    del q4
+
+    # dequantize with the ADD store back over the whole range
+    acc = torch.zeros(n, dtype=torch.float32, device="cuda")
+    piquant.torch.dequantize(q, scale=scale, zero_point=zp, dtype=torch.float32, reduce_op="add", out=acc)
+    for a, b in windows:
+        want = O.dequantize(q[a:b].cpu().numpy(), 4, 0, b - a, scale, zp, 1, out=np.zeros(b - a, np.float32))
+        assert same_floats(acc[a:b].cpu().numpy(), want), (a, b)
+    assert float((acc - x).abs().max()) <= 0.5 * scale * 1.0001 + 1e-6
 
 
 def test_per_element_stochastic_extension(ctx, O):
