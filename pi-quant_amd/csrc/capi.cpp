@@ -115,7 +115,10 @@ struct piquant_context_t {
     // Invariant: d_slots[slot] is armed (all identity) whenever no scan is in flight.
     int32_t* d_slots[2] = {nullptr, nullptr};
     int slot = 0;
-    int32_t* h_slots = nullptr;            // pinned mirror of the buffer just scanned
+    int32_t* h_slots = nullptr;            // pinned mirror of the buffer just scanned (fallback path)
+    MinmaxMailboxHost* mailbox = nullptr;  // pinned fine-grained host memory the fold kernel publishes into
+    void* mailbox_dev = nullptr;           // its device-visible address
+    uint32_t mailbox_seq = 0;
     hipStream_t scan_stream = nullptr;     // stream of the previous scan (re-arming relies on stream order)
 
     // device scratch for host-pointer calls, grown on demand
@@ -182,6 +185,14 @@ piquant_context_t* piquant_context_create(size_t num_threads) {
         PQ_HIP(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p), float_to_key(std::numeric_limits<float>::max()), minmax_slot_ints()));
     }
     PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_slots), slot_bytes, hipHostMallocDefault));
+    if (hipHostMalloc(reinterpret_cast<void**>(&ctx->mailbox), sizeof(MinmaxMailboxHost), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+        hipHostGetDevicePointer(&ctx->mailbox_dev, ctx->mailbox, 0) == hipSuccess) {
+        ctx->mailbox->keys[0] = ctx->mailbox->keys[1] = 0;
+        ctx->mailbox->seq = 0;
+    } else {
+        (void)hipGetLastError();
+        ctx->mailbox_dev = nullptr;   // no fine-grained host memory: compute_quant_params falls back to D2H + sync
+    }
     PQ_HIP(hipDeviceSynchronize());   // the arming memsets ran on the null stream; scans may run on any stream
     std::random_device rd;
     ctx->rng.seed((static_cast<uint64_t>(rd()) << 32) ^ rd());
@@ -202,6 +213,7 @@ void piquant_context_destroy(piquant_context_t* ctx) {
         for (auto& p : ctx->d_slots)
             if (p) (void)hipFree(p);
         if (ctx->h_slots) (void)hipHostFree(ctx->h_slots);
+        if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     }
     delete ctx;
@@ -456,9 +468,34 @@ static void compute_params(piquant_context_t* ctx, const void* x, piquant_dtype_
         std::lock_guard<std::mutex> lock(ctx->mu);
         DeviceGuard guard(ctx->device);
         const int32_t* slots = scan_into_slots(ctx, x, dt, n);
-        PQ_HIP(hipMemcpyAsync(ctx->h_slots, slots, static_cast<size_t>(minmax_slot_ints()) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-        PQ_HIP(hipStreamSynchronize(ctx->stream));
-        fold_slots_host(ctx->h_slots, keys);
+        bool have = false;
+        if (ctx->mailbox_dev) {
+            // one-wave fold kernel publishes {keys, seq} straight into pinned host memory; spin on seq
+            const uint32_t seq = ++ctx->mailbox_seq;
+            launch_fold_publish(slots, ctx->mailbox_dev, seq, ctx->stream);
+            volatile uint32_t* flag = &ctx->mailbox->seq;
+            for (uint32_t spins = 0; spins < (1u << 22); ++spins) {
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) {
+                    have = true;
+                    break;
+                }
+                if ((spins & 0xfff) == 0xfff && hipStreamQuery(ctx->stream) != hipErrorNotReady) break;   // finished or failed
+                __builtin_ia32_pause();
+            }
+            if (!have) {   // stream drained (or spin budget spent) without the flag becoming visible: make sure, then read
+                PQ_HIP(hipStreamSynchronize(ctx->stream));
+                have = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq;
+            }
+            if (have) {
+                keys[0] = ctx->mailbox->keys[0];
+                keys[1] = ctx->mailbox->keys[1];
+            }
+        }
+        if (!have) {
+            PQ_HIP(hipMemcpyAsync(ctx->h_slots, slots, static_cast<size_t>(minmax_slot_ints()) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+            PQ_HIP(hipStreamSynchronize(ctx->stream));
+            fold_slots_host(ctx->h_slots, keys);
+        }
     }
     float lo, hi;
     piquant_hip_decode_minmax_keys(keys, &lo, &hi);

@@ -232,6 +232,12 @@ void launch_fold_slots(const int32_t* slots, int32_t* device_keys, bool overwrit
     PQ_HIP(hipGetLastError());
 }
 
+void launch_fold_publish(const int32_t* slots, void* mailbox_device_ptr, uint32_t seq, hipStream_t stream) {
+    static_assert(sizeof(MinmaxMailbox) == sizeof(MinmaxMailboxHost), "mailbox layout");
+    hipLaunchKernelGGL(fold_publish_kernel, dim3(1), dim3(64), 0, stream, slots, static_cast<MinmaxMailbox*>(mailbox_device_ptr), seq);
+    PQ_HIP(hipGetLastError());
+}
+
 void fold_slots_host(const int32_t* slots, int32_t out_keys[2]) {
     int32_t k0 = slots[0], k1 = slots[1];
     for (int s = 1; s < kMinmaxSlots; ++s) {

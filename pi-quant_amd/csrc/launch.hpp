@@ -59,6 +59,13 @@ void launch_minmax(const void* in, int dt_in, int64_t numel, int32_t* slots, int
 void launch_arm_slots(int32_t* slots, hipStream_t stream);
 // Fold a slot buffer into a {key(min), key(-max)} pair in device memory (overwrite or accumulate with MIN).
 void launch_fold_slots(const int32_t* slots, int32_t* device_keys, bool overwrite, hipStream_t stream);
+// Fold a slot buffer and publish {keys, seq} to a pinned fine-grained host mailbox (device-visible address given).
+struct MinmaxMailboxHost {
+    int32_t keys[2];
+    uint32_t seq;
+    uint32_t pad;
+};
+void launch_fold_publish(const int32_t* slots, void* mailbox_device_ptr, uint32_t seq, hipStream_t stream);
 // Host-side fold of a slot buffer copied back from the device.
 void fold_slots_host(const int32_t* slots, int32_t out_keys[2]);
 int minmax_slot_ints();

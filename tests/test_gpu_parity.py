@@ -444,6 +444,29 @@ def test_compute_quant_params_matches_oracle(ctx, O):
     assert piquant.torch.compute_quant_params(base[1:], dtype=torch.quint8) == O.compute_quant_params(base[1:].cpu().numpy(), 0, 4)
 
 
+def test_compute_quant_params_back_to_back(O):
+    """The result travels through a pinned host mailbox tagged with a sequence number and the scan alternates between
+    two slot buffers: hammer it with alternating tensors, dtypes and streams -- every answer must be the tensor's own."""
+    import piquant
+    import torch
+
+    rng = np.random.default_rng(8)
+    tensors = []
+    for i in range(6):
+        x = (rng.normal(size=200_000 + 1000 * i) * (i + 1)).astype(np.float32)
+        tensors.append((torch.from_numpy(x).cuda(), O.compute_quant_params(x, 0, 4), O.compute_quant_params(x, 0, 3)))
+    side = torch.cuda.Stream()
+    for it in range(300):
+        t, want8, want4 = tensors[it % len(tensors)]
+        if it % 3 == 2:
+            with torch.cuda.stream(side):
+                got = piquant.torch.compute_quant_params(t, dtype=torch.quint8)
+        else:
+            got = piquant.torch.compute_quant_params(t, dtype=torch.quint8 if it % 2 else torch.quint4x2)
+            want8 = want8 if it % 2 else want4
+        assert got == want8, it
+
+
 def test_minmax_keys_accumulate_across_calls(ctx, O):
     """init=0 folds further scans into the same keys: the building block of the multi-GPU reduction."""
     import piquant
