@@ -266,7 +266,7 @@ def main():
             for i in range(50):
                 piquant.torch.compute_quant_params(xs[i % nsets], dtype=torch.quint8)
             extras["compute_quant_params_f32_call"] = {"ms_per_call": round((time.perf_counter() - t0) / 50 * 1e3, 5),
-                                                       "note": "full C-ABI call: scan + 8-byte D2H + host sync + double epilogue"}
+                                                       "note": "full C-ABI call through piquant.torch: scan + fold/publish kernel into a pinned host mailbox + host spin + double epilogue"}
             ctx.set_stream(stream.cuda_stream)
             ctx.set_blocking(False)
         # the reference's own calling convention: host buffers in, host buffers out (staged over PCIe, never `value`)

