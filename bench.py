@@ -259,6 +259,12 @@ def main():
             extras["quantize_f32_u8_stochastic"] = {"GB/s": gbs(5, e, reps), "avg_launch_us": round(e / reps * 1e6, 3)}
             _, e = time_loop(lambda i: ctx.dequantize_ptr(ptr_out[i % nsets], DataType.UINT8, ptr_in[i % nsets], DataType.F32, n, scale, zp, piquant.ReduceOp.ADD), reps, stream)
             extras["dequantize_u8_f32_add"] = {"GB/s": gbs(9, e, reps), "avg_launch_us": round(e / reps * 1e6, 3)}
+            y = [torch.empty_like(x) for x in xs[:3]]
+            _, e = time_loop(lambda i: ctx.quantize_dequantize_ptr(ptr_in[i % 3], DataType.F32, y[i % 3].data_ptr(), DataType.UINT8, n, scale, zp,
+                                                                    RoundMode.NEAREST, piquant.ReduceOp.SET), reps, stream)
+            extras["requantize_f32_u8_set"] = {"GB/s": gbs(8, e, reps), "avg_launch_us": round(e / reps * 1e6, 3),
+                                               "note": "fused quantize->dequantize, 4 B read + 4 B written per element"}
+            del y
             keys = torch.empty(2, dtype=torch.int32, device=dev)
             _, e = time_loop(lambda i: ctx.minmax_keys_ptr(ptr_in[i % nsets], DataType.F32, n, keys.data_ptr(), True), reps, stream)
             extras["minmax_f32"] = {"GB/s": gbs(4, e, reps), "avg_launch_us": round(e / reps * 1e6, 3), "note": "init kernel + scan per call (piquant_hip_minmax_keys)"}
