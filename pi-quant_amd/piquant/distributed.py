@@ -61,3 +61,148 @@ def compute_quant_params(
     k = keys.cpu()
     r_min, r_max = decode_minmax_keys(int(k[0]), int(k[1]))
     return quant_params_from_minmax(r_min, r_max, torch_to_piquant_dtype(dtype))
+
+
+# -----------------------------------------------------------------------------------------------------------------
+# Quantized ring all-reduce: the caller pattern the reference's SET/ADD store operators were
+# designed for ("useful for ring-reduction operations", reference README.md:29), built from the path's primitives.
+# -----------------------------------------------------------------------------------------------------------------
+class _DeviceOps:
+    """The three primitives on ROCm device tensors (HIP kernels through libpiquant.so)."""
+
+    def __init__(self, ctx: Optional[Context]):
+        self.ctx = ctx
+
+    def params(self, x: torch.Tensor, qdtype: torch.dtype) -> Tuple[float, int]:
+        from .torch import compute_quant_params as _cqp
+
+        return _cqp(x, dtype=qdtype, ctx=self.ctx)
+
+    def quantize(self, x, payload, scale, zp, qdtype, round_mode):
+        from .torch import quantize as _q
+
+        _q(x, scale=scale, zero_point=zp, dtype=qdtype, round_mode=round_mode, ctx=self.ctx, out=payload)
+
+    def dequantize(self, payload, out, scale, zp, qdtype, reduce_op):
+        from .torch import dequantize as _dq
+
+        _dq(payload, scale=scale, zero_point=zp, dtype=out.dtype, reduce_op=reduce_op, ctx=self.ctx, out=out, quant_dtype=qdtype,
+            shape=out.shape)
+
+
+_HEADER_BYTES = 16   # wire header per hop: float32 scale, int32 zero point, 8 bytes reserved (keeps the payload 16-byte aligned)
+
+
+def _pack_header(buf: torch.Tensor, scale: float, zp: int) -> None:
+    import struct
+
+    buf[:_HEADER_BYTES].copy_(torch.frombuffer(bytearray(struct.pack('<fiq', scale, zp, 0)), dtype=torch.uint8), non_blocking=False)
+
+
+def _unpack_header(buf: torch.Tensor) -> Tuple[float, int]:
+    import struct
+
+    scale, zp, _ = struct.unpack('<fiq', bytes(buf[:_HEADER_BYTES].cpu().numpy().tobytes()))
+    return scale, zp
+
+
+def _exchange(send: torch.Tensor, recv: torch.Tensor, nxt: int, prv: int, group) -> None:
+    """Send `send` to the next rank of the ring while receiving `recv` from the previous one.  RCCL (backend nccl)
+    moves device buffers directly over xGMI; other backends (gloo, used in tests) are staged through host memory."""
+    if dist.get_backend(group) == 'nccl':
+        ops = [dist.P2POp(dist.isend, send, nxt, group), dist.P2POp(dist.irecv, recv, prv, group)]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        return
+    s_host = send.cpu()
+    r_host = torch.empty(recv.shape, dtype=recv.dtype)
+    req_s = dist.isend(s_host, nxt, group=group)
+    req_r = dist.irecv(r_host, prv, group=group)
+    req_s.wait()
+    req_r.wait()
+    recv.copy_(r_host)
+
+
+def ring_chunks(numel: int, world_size: int, packed_bits: int = 8, align: int = 4096):
+    """Chunk boundaries of the ring: `world_size` contiguous chunks; interior boundaries are multiples of `align` elements
+    (whole packed bytes and 16-byte vectors on both sides of every kernel); the last chunk keeps the ragged end."""
+    assert align % (8 // packed_bits if packed_bits < 8 else 1) == 0
+    per = -(-numel // world_size)
+    per = -(-per // align) * align
+    bounds = [min(i * per, numel) for i in range(world_size)] + [numel]
+    return [(bounds[i], bounds[i + 1]) for i in range(world_size)]
+
+
+def quantized_all_reduce(
+    tensor: torch.Tensor,
+    *,
+    quant_dtype: torch.dtype = torch.uint8,
+    round_mode: str = 'nearest',
+    group: Optional[dist.ProcessGroup] = None,
+    ctx: Optional[Context] = None,
+    _ops=None,
+) -> torch.Tensor:
+    """In-place SUM all-reduce of a contiguous float32/bfloat16 tensor whose wire format is quantized.
+
+    Ring reduce-scatter: at every hop a rank quantizes the chunk it forwards with parameters taken from that chunk's
+    current partial sum (``compute_quant_params``), sends ``header + packed bytes`` to its successor, and accumulates what it
+    receives with ``dequantize(reduce_op='add')`` -- the ADD store operator's purpose.  Ring all-gather: the owner of a
+    finished chunk quantizes it once; the bytes travel round the ring unchanged and every rank (the owner included)
+    stores ``dequantize(..., 'set')`` of the same bytes, so all ranks end bit-identical.  Wire traffic per element is
+    1 byte (uint8) / 0.5 (uint4) instead of 4, over the same 2(G-1)/G ring schedule; each xGMI link carries one
+    point-to-point stream, which is what the per-link (not NVSwitch-style) bandwidth of MI355X wants.
+    """
+    assert tensor.is_contiguous() and tensor.dtype in (torch.float32, torch.bfloat16)
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        return tensor
+    ops = _ops or _DeviceOps(ctx)
+    qdt = torch_to_piquant_dtype(quant_dtype)
+    flat = tensor.view(-1)
+    chunks = ring_chunks(flat.numel(), world, qdt.bit_size)
+    nxt = dist.get_global_rank(group, (rank + 1) % world) if group is not None else (rank + 1) % world
+    prv = dist.get_global_rank(group, (rank - 1) % world) if group is not None else (rank - 1) % world
+    max_bytes = max(qdt.packed_nbytes(e - b) for b, e in chunks) + _HEADER_BYTES
+    send = torch.empty(max_bytes, dtype=torch.uint8, device=tensor.device)
+    recv = torch.empty(max_bytes, dtype=torch.uint8, device=tensor.device)
+
+    def wire(idx):
+        b, e = chunks[idx]
+        return flat[b:e], _HEADER_BYTES + qdt.packed_nbytes(e - b)
+
+    # ---- reduce-scatter: after G-1 hops rank r owns the complete sum of chunk (r+1) % G ----
+    for step in range(world - 1):
+        x_send, n_send = wire((rank - step) % world)
+        x_recv, n_recv = wire((rank - step - 1) % world)
+        if x_send.numel():
+            scale, zp = ops.params(x_send, quant_dtype)
+            ops.quantize(x_send, send[_HEADER_BYTES:n_send], scale, zp, quant_dtype, round_mode)
+        else:
+            scale, zp = 1.0, 0
+        _pack_header(send, scale, zp)
+        _exchange(send[:n_send], recv[:n_recv], nxt, prv, group)
+        if x_recv.numel():
+            r_scale, r_zp = _unpack_header(recv)
+            ops.dequantize(recv[_HEADER_BYTES:n_recv], x_recv, r_scale, r_zp, quant_dtype, 'add')
+
+    # ---- all-gather: the finished chunk's bytes circulate unchanged ----
+    own = (rank + 1) % world
+    x_own, n_own = wire(own)
+    if x_own.numel():
+        scale, zp = ops.params(x_own, quant_dtype)
+        ops.quantize(x_own, send[_HEADER_BYTES:n_own], scale, zp, quant_dtype, round_mode)
+        ops.dequantize(send[_HEADER_BYTES:n_own], x_own, scale, zp, quant_dtype, 'set')   # owner keeps what everyone else will see
+    else:
+        scale, zp = 1.0, 0
+    _pack_header(send, scale, zp)
+    n_cur = n_own
+    for step in range(world - 1):
+        x_recv, n_recv = wire((rank - step) % world)
+        _exchange(send[:n_cur], recv[:n_recv], nxt, prv, group)
+        if x_recv.numel():
+            r_scale, r_zp = _unpack_header(recv)
+            ops.dequantize(recv[_HEADER_BYTES:n_recv], x_recv, r_scale, r_zp, quant_dtype, 'set')
+        send, recv = recv, send          # forward the received bytes as they are
+        n_cur = n_recv
+    return tensor

@@ -1,0 +1,76 @@
+"""Reference simulation (numpy + oracle) of piquant.distributed.quantized_all_reduce for G ranks, run in one process.
+Used by the CPU (gloo, oracle-backed ops) and GPU (gloo between processes sharing the GPU, real HIP ops) ring tests."""
+import numpy as np
+
+
+def simulate(O, xs, qd, chunks, round_mode=0):
+    """xs: list of G float32 arrays (one per rank).  Returns the list of final arrays (all equal)."""
+    G = len(xs)
+    xs = [x.copy() for x in xs]
+
+    def seg(r, idx):
+        b, e = chunks[idx]
+        return xs[r][b:e]
+
+    for step in range(G - 1):
+        msgs = []
+        for r in range(G):
+            s = seg(r, (r - step) % G)
+            if s.size:
+                scale, zp = O.compute_quant_params(s, O.F32, qd)
+                msgs.append((O.quantize(s, O.F32, qd, scale, zp, round_mode), scale, zp))
+            else:
+                msgs.append((None, 1.0, 0))
+        for r in range(G):
+            q, scale, zp = msgs[(r - 1) % G]
+            d = seg(r, (r - step - 1) % G)
+            if d.size:
+                d[:] = O.dequantize(q, qd, O.F32, d.size, scale, zp, O.ADD, out=d.copy())
+    wire = []
+    for r in range(G):
+        s = seg(r, (r + 1) % G)
+        if s.size:
+            scale, zp = O.compute_quant_params(s, O.F32, qd)
+            q = O.quantize(s, O.F32, qd, scale, zp, round_mode)
+            s[:] = O.dequantize(q, qd, O.F32, s.size, scale, zp)
+            wire.append((q, scale, zp))
+        else:
+            wire.append((None, 1.0, 0))
+    for step in range(G - 1):
+        new = []
+        for r in range(G):
+            q, scale, zp = wire[(r - 1) % G]
+            d = seg(r, (r - step) % G)
+            if d.size:
+                d[:] = O.dequantize(q, qd, O.F32, d.size, scale, zp)
+            new.append((q, scale, zp))
+        wire = new
+    return xs
+
+
+class OracleOps:
+    """quantize / dequantize / params on CPU torch tensors through the oracle: stands in for the HIP ops where there is no GPU."""
+
+    def __init__(self, O):
+        self.O = O
+
+    def _qd(self, qdtype):
+        import torch
+
+        return {torch.uint8: 4, torch.quint8: 4, torch.quint4x2: 3, torch.quint2x4: 2}[qdtype]
+
+    def params(self, x, qdtype):
+        return self.O.compute_quant_params(x.numpy(), self.O.F32, self._qd(qdtype))
+
+    def quantize(self, x, payload, scale, zp, qdtype, round_mode):
+        import torch
+
+        q = self.O.quantize(x.numpy(), self.O.F32, self._qd(qdtype), scale, zp, 0)
+        payload.copy_(torch.from_numpy(q))
+
+    def dequantize(self, payload, out, scale, zp, qdtype, reduce_op):
+        import torch
+
+        res = self.O.dequantize(payload.numpy(), self._qd(qdtype), self.O.F32, out.numel(), scale, zp, 1 if reduce_op == 'add' else 0,
+                                out=out.numpy().copy())
+        out.copy_(torch.from_numpy(res))

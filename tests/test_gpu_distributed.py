@@ -53,3 +53,62 @@ def test_keys_fold_like_an_all_reduce(pg, oracle_mod):
     whole = D.local_minmax_keys(xd).cpu()
     assert torch.equal(folded, whole)
     assert piquant.decode_minmax_keys(int(folded[0]), int(folded[1])) == O.minmax(x, O.F32)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# quantized ring all-reduce with the real HIP ops: two (three) processes share the box's single GPU, the transport is
+# gloo staged through host memory (RCCL refuses two ranks on one device); the schedule and every kernel are the real
+# ones, so each rank must reproduce the oracle simulation bit for bit.
+# ---------------------------------------------------------------------------------------------------------------
+def _ring_gpu_worker(rank, world, port, numel, qname, out_q):
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    for p in (str(root), str(root / "pi-quant_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import piquant.distributed as D
+
+        torch.cuda.set_device(0)
+        x = torch.from_numpy(np.random.default_rng(100 + rank).uniform(-1, 1, numel).astype(np.float32)).cuda()
+        D.quantized_all_reduce(x, quant_dtype=getattr(torch, qname))
+        torch.cuda.synchronize()
+        out_q.put((rank, x.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,numel,qname", [(2, 1_000_003, "uint8"), (3, 300_000, "quint4x2")])
+def test_quantized_ring_all_reduce_with_hip_kernels(oracle_mod, world, numel, qname):
+    import sys
+
+    import torch.multiprocessing as mp
+
+    sys.path.insert(0, os.path.dirname(__file__))
+    import piquant.distributed as D
+    from ring_sim import simulate
+
+    O = oracle_mod
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ring_gpu_worker, args=(r, world, port, numel, qname, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    xs = [np.random.default_rng(100 + r).uniform(-1, 1, numel).astype(np.float32) for r in range(world)]
+    qd, bits = {"uint8": (O.UINT8, 8), "quint4x2": (O.UINT4, 4)}[qname]
+    want = simulate(O, xs, qd, D.ring_chunks(numel, world, bits))
+    for r in range(world):
+        assert np.array_equal(results[r], want[r]), r
+    exact = np.sum(xs, axis=0)
+    assert np.abs(results[0] - exact).max() <= world * (2.0 * world / ((1 << bits) - 1)) * 0.5 + 1e-5
