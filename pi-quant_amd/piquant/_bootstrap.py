@@ -50,6 +50,14 @@ def library_path() -> Path:
 
 
 def _load_native_module() -> C.CDLL:
+    # One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 (torch/lib, found through an
+    # $ORIGIN rpath under the unversioned name), libpiquant.so needs `libamdhip64.so.7`.  If PyTorch is loaded first the
+    # dynamic loader satisfies our dependency with PyTorch's already-loaded runtime (same SONAME); in the other order
+    # the process would end up with two runtimes that cannot see each other's devices and allocations.  So: torch first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     assert sys.platform.startswith('linux'), f'Unsupported platform: {sys.platform} (MI355X / ROCm is Linux-only)'
     lib_path = library_path()
     if not lib_path.exists():

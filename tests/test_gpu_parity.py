@@ -535,6 +535,42 @@ def test_default_stream_ordering_without_explicit_sync(O):
         assert keys_scale == O.compute_quant_params(ref_in, 0, 4)
 
 
+def test_calls_are_capturable_in_a_hip_graph(O):
+    """Stream-ordered calls on device pointers enqueue kernels and nothing else (no allocation, no synchronisation), so a
+    quantize -> dequantize(ADD) -> requant chain can be captured once into a hipGraph and replayed on new data."""
+    import piquant
+    import torch
+
+    n = 2_000_003
+    x = torch.zeros(n, device="cuda")
+    q = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    acc = torch.zeros(n, device="cuda")
+    y = torch.zeros(n, device="cuda")
+    c = piquant.Context()
+    scale, zp = 0.0078431377, 128
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        piquant.torch.quantize(x, scale=scale, zero_point=zp, dtype=torch.uint8, ctx=c, out=q)     # warm-up outside capture
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            piquant.torch.quantize(x, scale=scale, zero_point=zp, dtype=torch.uint8, ctx=c, out=q)
+            piquant.torch.dequantize(q, scale=scale, zero_point=zp, dtype=torch.float32, reduce_op="add", ctx=c, out=acc)
+            piquant.torch.quantize_dequantize(x, scale=scale, zero_point=zp, quant_dtype=torch.quint4x2, ctx=c, out=y)
+    rng = np.random.default_rng(12)
+    want_acc = np.zeros(n, dtype=np.float32)
+    for _ in range(3):
+        data = rng.uniform(-1, 1, n).astype(np.float32)
+        x.copy_(torch.from_numpy(data))
+        g.replay()
+        torch.cuda.synchronize()
+        wq = O.quantize(data, 0, 4, scale, zp)
+        want_acc = O.dequantize(wq, 4, 0, n, scale, zp, 1, out=want_acc)
+        assert np.array_equal(q.cpu().numpy(), wq)
+        assert same_floats(acc.cpu().numpy(), want_acc)
+        assert same_floats(y.cpu().numpy(), O.requantize(data, 0, 3, scale, zp))
+
+
 def test_empty_inputs_are_no_ops(ctx):
     import piquant
 
