@@ -62,6 +62,28 @@ PIQUANT_EXPORT void piquant_hip_quantize_dequantize(piquant_context_t* ctx, cons
 PIQUANT_EXPORT void piquant_hip_minmax_keys(piquant_context_t* ctx, const void* x, piquant_dtype_t dtype, size_t n,
                                             int32_t* device_keys, int init);
 
+/* Device-resident quantization parameters ("dynamic" path): (scale, zero_point) are derived on the GPU and consumed by
+ * the next kernels without visiting the host, so compute-params -> quantize -> (send) -> dequantize is one asynchronous
+ * stream of launches (capturable in a hipGraph).  The record is 16 bytes of device memory, e.g. the header of a wire
+ * buffer.  piquant_hip_compute_quant_params_device = min/max scan + a one-wave kernel running the reference's
+ * double-precision epilogue (src/piquant.cpp:245-258; results are bit-identical to piquant_compute_quant_params_*,
+ * except that a NaN / negative scale cannot abort from the device).  The *_dp calls are piquant_quantize /
+ * piquant_dequantize with scale and zero_point read from the record.  Device (or pinned) buffers only. */
+typedef struct piquant_hip_params_t {
+    float scale;
+    float inv_scale;    /* 1.0f / scale */
+    int64_t zero_point;
+} piquant_hip_params_t;
+
+PIQUANT_EXPORT void piquant_hip_compute_quant_params_device(piquant_context_t* ctx, const void* x, piquant_dtype_t dtype, size_t n,
+                                                            piquant_dtype_t target_quant_dtype, piquant_hip_params_t* device_params);
+PIQUANT_EXPORT void piquant_hip_quantize_dp(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in, void* out,
+                                            piquant_dtype_t dtype_out, size_t numel, const piquant_hip_params_t* device_params,
+                                            piquant_round_mode_t mode);
+PIQUANT_EXPORT void piquant_hip_dequantize_dp(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in, void* out,
+                                              piquant_dtype_t dtype_out, size_t numel, const piquant_hip_params_t* device_params,
+                                              piquant_reduce_op_t op);
+
 /* Host helpers: key <-> float, and the (min,max) -> (scale, zero_point) epilogue in double precision
  * (reference src/piquant.cpp:213-220, 245-258).  keys[0] encodes min, keys[1] encodes -max. */
 PIQUANT_EXPORT void piquant_hip_decode_minmax_keys(const int32_t keys[2], float* out_min, float* out_max);

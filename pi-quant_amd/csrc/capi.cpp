@@ -223,8 +223,8 @@ void piquant_context_destroy(piquant_context_t* ctx) {
     delete ctx;
 }
 
-void piquant_quantize(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out,
-                      size_t numel, float scale, int64_t zero_point, piquant_round_mode_t mode) {
+static void quantize_impl(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out, size_t numel,
+                          float scale, int64_t zero_point, piquant_round_mode_t mode, const void* dyn_params) {
     if (!ctx) panic("piquant_quantize: context is NULL");
     const dtype_row& dti = dtype_of(dtype_in);
     const dtype_row& dto = dtype_of(dtype_out);
@@ -254,6 +254,11 @@ void piquant_quantize(piquant_context_t* ctx, const void* in, piquant_dtype_t dt
     }
 
     const Resolved rin = resolve(in), rout = resolve(out);
+    if (dyn_params) {
+        const Resolved rp = resolve(dyn_params);
+        if (rin.pageable || rout.pageable || rp.pageable) panic("quantize with device-resident parameters needs device (or pinned) buffers");
+        q.dyn_params = rp.dev;
+    }
     if (!rin.pageable && !rout.pageable) {
         q.in = rin.dev;
         q.out = rout.dev;
@@ -287,8 +292,19 @@ void piquant_quantize(piquant_context_t* ctx, const void* in, piquant_dtype_t dt
     for (auto& s : ctx->stage_stream) PQ_HIP(hipStreamSynchronize(s));
 }
 
-void piquant_dequantize(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out,
-                        size_t numel, float scale, int64_t zero_point, piquant_reduce_op_t op) {
+void piquant_quantize(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out,
+                      size_t numel, float scale, int64_t zero_point, piquant_round_mode_t mode) {
+    quantize_impl(ctx, in, dtype_in, out, dtype_out, numel, scale, zero_point, mode, nullptr);
+}
+
+void piquant_hip_quantize_dp(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out, size_t numel,
+                             const piquant_hip_params_t* device_params, piquant_round_mode_t mode) {
+    if (!device_params) panic("piquant_hip_quantize_dp: NULL parameter record");
+    quantize_impl(ctx, in, dtype_in, out, dtype_out, numel, 1.0f, 0, mode, device_params);
+}
+
+static void dequantize_impl(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out, size_t numel,
+                            float scale, int64_t zero_point, piquant_reduce_op_t op, const void* dyn_params) {
     if (!ctx) panic("piquant_dequantize: context is NULL");
     const dtype_row& dti = dtype_of(dtype_in);
     const dtype_row& dto = dtype_of(dtype_out);
@@ -312,6 +328,11 @@ void piquant_dequantize(piquant_context_t* ctx, const void* in, piquant_dtype_t 
     d.bias = -static_cast<float>(static_cast<int32_t>(static_cast<uint32_t>(static_cast<uint64_t>(zero_point)))) * scale;
 
     const Resolved rin = resolve(in), rout = resolve(out);
+    if (dyn_params) {
+        const Resolved rp = resolve(dyn_params);
+        if (rin.pageable || rout.pageable || rp.pageable) panic("dequantize with device-resident parameters needs device (or pinned) buffers");
+        d.dyn_params = rp.dev;
+    }
     if (!rin.pageable && !rout.pageable) {
         d.in = rin.dev;
         d.out = rout.dev;
@@ -344,6 +365,17 @@ void piquant_dequantize(piquant_context_t* ctx, const void* in, piquant_dtype_t 
             PQ_HIP(hipMemcpyAsync(static_cast<char*>(out) + out_off, ctx->stage_out[slot], span_bytes(n, dtype_out), hipMemcpyDeviceToHost, s));
     }
     for (auto& s : ctx->stage_stream) PQ_HIP(hipStreamSynchronize(s));
+}
+
+void piquant_dequantize(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out,
+                        size_t numel, float scale, int64_t zero_point, piquant_reduce_op_t op) {
+    dequantize_impl(ctx, in, dtype_in, out, dtype_out, numel, scale, zero_point, op, nullptr);
+}
+
+void piquant_hip_dequantize_dp(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out, size_t numel,
+                               const piquant_hip_params_t* device_params, piquant_reduce_op_t op) {
+    if (!device_params) panic("piquant_hip_dequantize_dp: NULL parameter record");
+    dequantize_impl(ctx, in, dtype_in, out, dtype_out, numel, 1.0f, 0, op, device_params);
 }
 
 void piquant_hip_quantize_dequantize(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in_out, void* out, piquant_dtype_t quant_dtype,
@@ -432,6 +464,22 @@ void piquant_hip_minmax_keys(piquant_context_t* ctx, const void* x, piquant_dtyp
     }
     const int32_t* slots = scan_into_slots(ctx, x, dtype, n);
     launch_fold_slots(slots, device_keys, init != 0, ctx->stream);
+}
+
+void piquant_hip_compute_quant_params_device(piquant_context_t* ctx, const void* x, piquant_dtype_t dtype, size_t n, piquant_dtype_t target_quant_dtype,
+                                             piquant_hip_params_t* device_params) {
+    if (!ctx) panic("piquant_hip_compute_quant_params_device: context is NULL");
+    if (dtype != PIQUANT_DTYPE_F32 && dtype != PIQUANT_DTYPE_BF16) panic("min/max scan needs f32 or bf16 input, got %s", dtype_of(dtype).name);
+    if (!dtype_of(target_quant_dtype).quant) panic("type %s is not a quantization type", dtype_of(target_quant_dtype).name);
+    if (!device_params) panic("piquant_hip_compute_quant_params_device: NULL parameter record");
+    if (n != 0 && !x) panic("piquant_hip_compute_quant_params_device: NULL input");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    const Resolved rp = resolve(device_params);
+    if (rp.pageable) panic("piquant_hip_compute_quant_params_device: the parameter record must live in device (or pinned) memory");
+    // n == 0: an armed slot buffer folds to the identities, like the synchronous call
+    const int32_t* slots = n == 0 ? ctx->d_slots[ctx->slot] : scan_into_slots(ctx, x, dtype, n);
+    launch_params_from_slots(slots, dtype_of(target_quant_dtype).bits, rp.dev, ctx->stream);
 }
 
 void piquant_hip_decode_minmax_keys(const int32_t keys[2], float* out_min, float* out_max) {

@@ -38,7 +38,8 @@ __device__ __forceinline__ void dequant_store_scalar(const uint8_t* in, void* ou
 }
 
 template <int BITS, int DT_OUT, int OP>
-__global__ void __launch_bounds__(256) dequantize_scalar_kernel(const uint8_t* in, void* out, int64_t numel, DequantParams p) {
+__global__ void __launch_bounds__(256) dequantize_scalar_kernel(const uint8_t* in, void* out, int64_t numel, DequantParams p_arg) {
+    const DequantParams p = resolved(p_arg);
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < numel; i += stride)
         dequant_store_scalar<BITS, DT_OUT, OP>(in, out, i, p);
@@ -57,7 +58,8 @@ struct DequantTile {
 
 template <int BITS, int DT_OUT, int OP, int U, bool STAGE, int NT, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
-dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int64_t n_tiles, DequantParams p) {
+dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int64_t n_tiles, DequantParams p_arg) {
+    const DequantParams p = resolved(p_arg);
     using T = DequantTile<BITS, DT_OUT, U, BLOCK>;
     constexpr int EPV = T::EPV, IB = T::IB;
     constexpr int WORDS = IB > 4 ? 2 : 1;

@@ -20,6 +20,15 @@ enum : int { DT_F32 = 0, DT_BF16 = 1, DT_UINT2 = 2, DT_UINT4 = 3, DT_UINT8 = 4 }
 //   RM_STOCH_ELEM   : stochastic, counter-hash threshold per element (extension)
 enum : int { RM_NEAREST_FAST = 0, RM_NEAREST_I64 = 1, RM_STOCH_CALL = 2, RM_STOCH_ELEM = 3 };
 
+// Quantization parameters living in DEVICE memory (16 bytes), written by params_from_slots_kernel and read by the
+// kernels when QuantParams::dyn / DequantParams::dyn is set: the "dynamic" path, where (scale, zero_point) never
+// visit the host between the min/max scan and the quantize / dequantize that use them.
+struct ParamRecord {
+    float scale;
+    float inv_scale;      // 1.0f / scale, correctly rounded fp32 division (as the host computes it)
+    int64_t zero_point;
+};
+
 struct QuantParams {
     float inv_scale;      // 1.0f / scale, divided on the host in fp32 (kernels_specialized.inl:42, quantize.inl:129)
     int32_t zp32;         // zero point narrowed to int32 as at the fast-path call sites (quantize.inl:111)
@@ -28,6 +37,7 @@ struct QuantParams {
     uint32_t seed_lo;     // RM_STOCH_ELEM
     uint32_t seed_hi;
     uint64_t index_base;  // RM_STOCH_ELEM: global index of element 0 of this launch
+    const ParamRecord* dyn;   // nullable: take inv_scale / zero point from device memory instead of the fields above
 };
 
 struct DequantParams {
@@ -35,7 +45,28 @@ struct DequantParams {
     float bias;           // -(float)zp32 * scale, multiplied on the host (kernels_specialized.inl:1204,1325)
     int32_t zp32;
     int64_t zp64;
+    const ParamRecord* dyn;   // nullable, as in QuantParams
 };
+
+// Kernel-entry resolution of the dynamic parameters (wave-uniform scalar loads; a no-op when dyn is null).
+__device__ __forceinline__ QuantParams resolved(QuantParams p) {
+    if (p.dyn != nullptr) {
+        p.inv_scale = p.dyn->inv_scale;
+        p.zp64 = p.dyn->zero_point;
+        p.zp32 = static_cast<int32_t>(static_cast<uint32_t>(static_cast<uint64_t>(p.zp64)));
+    }
+    return p;
+}
+
+__device__ __forceinline__ DequantParams resolved(DequantParams p) {
+    if (p.dyn != nullptr) {
+        p.scale = p.dyn->scale;
+        p.zp64 = p.dyn->zero_point;
+        p.zp32 = static_cast<int32_t>(static_cast<uint32_t>(static_cast<uint64_t>(p.zp64)));
+        p.bias = __fmul_rn(-static_cast<float>(p.zp32), p.scale);   // as the host forms it (kernels_specialized.inl:1204)
+    }
+    return p;
+}
 
 // bf16 <-> f32: include/piquant.hpp:86-95
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }

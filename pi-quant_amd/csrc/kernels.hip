@@ -129,6 +129,7 @@ void launch_quantize(const QuantLaunch& q, hipStream_t stream, int num_cu) {
     p.seed_lo = static_cast<uint32_t>(q.seed);
     p.seed_hi = static_cast<uint32_t>(q.seed >> 32);
     p.index_base = q.index_base;
+    p.dyn = static_cast<const ParamRecord*>(q.dyn_params);
     switch (q.dt_in) {
         case DT_F32: quantize_bits<DT_F32>(q, p, stream, num_cu); break;
         case DT_BF16: quantize_bits<DT_BF16>(q, p, stream, num_cu); break;
@@ -144,6 +145,7 @@ void launch_dequantize(const DequantLaunch& d, hipStream_t stream, int num_cu) {
     p.bias = d.bias;
     p.zp64 = d.zero_point;
     p.zp32 = static_cast<int32_t>(static_cast<uint32_t>(static_cast<uint64_t>(d.zero_point)));
+    p.dyn = static_cast<const ParamRecord*>(d.dyn_params);
     switch (d.dt_in) {
         case DT_UINT8: dequantize_out<8>(d, p, stream, num_cu); break;
         case DT_UINT4: dequantize_out<4>(d, p, stream, num_cu); break;
@@ -235,6 +237,11 @@ void launch_fold_slots(const int32_t* slots, int32_t* device_keys, bool overwrit
 void launch_fold_publish(const int32_t* slots, void* mailbox_device_ptr, uint32_t seq, hipStream_t stream) {
     static_assert(sizeof(MinmaxMailbox) == sizeof(MinmaxMailboxHost), "mailbox layout");
     hipLaunchKernelGGL(fold_publish_kernel, dim3(1), dim3(64), 0, stream, slots, static_cast<MinmaxMailbox*>(mailbox_device_ptr), seq);
+    PQ_HIP(hipGetLastError());
+}
+
+void launch_params_from_slots(const int32_t* slots, int bits, void* device_param_record, hipStream_t stream) {
+    hipLaunchKernelGGL(params_from_slots_kernel, dim3(1), dim3(64), 0, stream, slots, bits, static_cast<ParamRecord*>(device_param_record));
     PQ_HIP(hipGetLastError());
 }
 

@@ -18,6 +18,7 @@ struct QuantLaunch {
     float threshold;
     uint64_t seed;
     uint64_t index_base;
+    const void* dyn_params;   // nullable: 16-byte device ParamRecord overriding inv_scale / zero_point
 };
 
 struct DequantLaunch {
@@ -30,6 +31,7 @@ struct DequantLaunch {
     float scale;
     float bias;
     int64_t zero_point;
+    const void* dyn_params;   // nullable: 16-byte device ParamRecord overriding scale / bias / zero_point
 };
 
 struct RequantLaunch {
@@ -66,6 +68,8 @@ struct MinmaxMailboxHost {
     uint32_t pad;
 };
 void launch_fold_publish(const int32_t* slots, void* mailbox_device_ptr, uint32_t seq, hipStream_t stream);
+// Fold a slot buffer and write the (scale, 1/scale, zero_point) ParamRecord for `bits`-wide quantization to device memory.
+void launch_params_from_slots(const int32_t* slots, int bits, void* device_param_record, hipStream_t stream);
 // Host-side fold of a slot buffer copied back from the device.
 void fold_slots_host(const int32_t* slots, int32_t out_keys[2]);
 int minmax_slot_ints();

@@ -98,6 +98,42 @@ __global__ void __launch_bounds__(64) fold_publish_kernel(const int32_t* slots, 
     }
 }
 
+// The (min,max) -> (scale, zero_point) epilogue on the device, for the dynamic path: one wave folds the slots, lane 0
+// runs the reference's double-precision formula (src/piquant.cpp:245-258) -- IEEE f64 division/round and a correctly
+// rounded fp32 reciprocal, so the record is bit-identical to what the host epilogue would produce -- and writes the
+// 16-byte ParamRecord.  A degenerate range gives (1.0, qmax >> 1) as in the reference (:249-252); a NaN or negative
+// scale cannot abort from here and is written as is.
+__global__ void __launch_bounds__(64) params_from_slots_kernel(const int32_t* slots, int bits, ParamRecord* out) {
+    int32_t k0 = slots[threadIdx.x * kMinmaxSlotStride + 0];
+    int32_t k1 = slots[threadIdx.x * kMinmaxSlotStride + 1];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        k0 = min(k0, __shfl_xor(k0, off, 64));
+        k1 = min(k1, __shfl_xor(k1, off, 64));
+    }
+    if (threadIdx.x == 0) {
+        const double r_min = static_cast<double>(key_to_float(k0));
+        const double r_max = static_cast<double>(-key_to_float(k1));
+        const uint64_t type_max = (uint64_t{1} << bits) - 1;
+        float scale;
+        int64_t zp;
+        if (r_max == r_min) {
+            scale = 1.0f;
+            zp = static_cast<int64_t>(type_max >> 1);
+        } else {
+            const double q_max = static_cast<double>(type_max);
+            const double s = (r_max - r_min) / q_max;
+            double z = 0.0 - r_min / s;
+            z = fmax(fmin(static_cast<double>(static_cast<int64_t>(round(z))), q_max), 0.0);
+            scale = static_cast<float>(s);
+            zp = static_cast<int64_t>(z);
+        }
+        out->scale = scale;
+        out->inv_scale = __fdiv_rn(1.0f, scale);
+        out->zero_point = zp;
+    }
+}
+
 template <int DT_IN, int U, bool NT, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) minmax_kernel(const void* __restrict__ in, int64_t numel, int32_t* slots, int32_t* rearm_slots) {
     constexpr int EPV = InVec<DT_IN>::EPV;

@@ -99,7 +99,8 @@ __device__ __forceinline__ void quantize_bytes_guarded(const void* in, uint8_t* 
 }
 
 template <int DT_IN, int BITS, int MODE>
-__global__ void __launch_bounds__(256) quantize_scalar_kernel(const void* in, uint8_t* out, int64_t numel, QuantParams p) {
+__global__ void __launch_bounds__(256) quantize_scalar_kernel(const void* in, uint8_t* out, int64_t numel, QuantParams p_arg) {
+    const QuantParams p = resolved(p_arg);
     constexpr int PACK = 8 / BITS;
     const int64_t nbytes = (numel + PACK - 1) / PACK;
     quantize_bytes_guarded<DT_IN, BITS, MODE>(in, out, numel, 0, nbytes, p,
@@ -120,7 +121,8 @@ struct QuantTile {
 
 template <int DT_IN, int BITS, int MODE, int U, bool STAGE, int NT, int BLOCK, bool PF = false>
 __global__ void __launch_bounds__(BLOCK)
-quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t numel, int64_t n_tiles, QuantParams p) {
+quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t numel, int64_t n_tiles, QuantParams p_arg) {
+    const QuantParams p = resolved(p_arg);
     using T = QuantTile<DT_IN, BITS, U, BLOCK>;
     constexpr int EPV = T::EPV, OB = T::OB, QMAX = (1 << BITS) - 1;
     constexpr int WORDS = OB > 4 ? 2 : 1;

@@ -158,6 +158,21 @@ class Context:
         C.piquant_hip_quantize_dequantize(self._ctx, ptr_in, dtype_in_out.value, ptr_out, quant_dtype.value, numel, scale, zero_point,
                                           round_mode.value, reduce_op.value)
 
+    # device-resident parameters: a 16-byte record {float scale, float 1/scale, int64 zero_point} in device memory
+    def compute_quant_params_device_ptr(self, ptr: int, dtype: DataType, numel: int, target_quant_dtype: DataType, params_ptr: int) -> None:
+        assert dtype.is_dequantized and target_quant_dtype.is_quantized and params_ptr != 0
+        C.piquant_hip_compute_quant_params_device(self._ctx, ptr, dtype.value, numel, target_quant_dtype.value, params_ptr)
+
+    def quantize_dp_ptr(self, ptr_in: int, dtype_in: DataType, ptr_out: int, dtype_out: DataType, numel: int, params_ptr: int,
+                        round_mode: RoundMode) -> None:
+        assert dtype_in.is_dequantized and dtype_out.is_quantized and params_ptr != 0
+        C.piquant_hip_quantize_dp(self._ctx, ptr_in, dtype_in.value, ptr_out, dtype_out.value, numel, params_ptr, round_mode.value)
+
+    def dequantize_dp_ptr(self, ptr_in: int, dtype_in: DataType, ptr_out: int, dtype_out: DataType, numel: int, params_ptr: int,
+                          reduce_op: ReduceOp) -> None:
+        assert dtype_in.is_quantized and dtype_out.is_dequantized and params_ptr != 0
+        C.piquant_hip_dequantize_dp(self._ctx, ptr_in, dtype_in.value, ptr_out, dtype_out.value, numel, params_ptr, reduce_op.value)
+
     def minmax_keys_ptr(self, ptr: int, dtype: DataType, numel: int, device_keys_ptr: int, init: bool = True) -> None:
         """Asynchronously fold {min, -max} of the buffer into two int32 keys in device memory (atomic MIN)."""
         assert dtype.is_dequantized

@@ -67,43 +67,27 @@ def compute_quant_params(
 # Quantized ring all-reduce: the caller pattern the reference's SET/ADD store operators were
 # designed for ("useful for ring-reduction operations", reference README.md:29), built from the path's primitives.
 # -----------------------------------------------------------------------------------------------------------------
+_HEADER_BYTES = 16   # wire header per hop == the device parameter record {float scale, float 1/scale, int64 zero_point}
+
+
 class _DeviceOps:
-    """The three primitives on ROCm device tensors (HIP kernels through libpiquant.so)."""
+    """Wire encode / decode on ROCm device tensors (HIP kernels through libpiquant.so).  The parameters are derived on
+    the device straight into the buffer's header and read back from it by the receiver's dequantize kernel: a hop
+    needs no host synchronisation at all."""
 
     def __init__(self, ctx: Optional[Context]):
         self.ctx = ctx
 
-    def params(self, x: torch.Tensor, qdtype: torch.dtype) -> Tuple[float, int]:
-        from .torch import compute_quant_params as _cqp
+    def encode(self, x: torch.Tensor, buf: torch.Tensor, qdtype: torch.dtype, round_mode: str) -> None:
+        from .torch import quantize_dynamic
 
-        return _cqp(x, dtype=qdtype, ctx=self.ctx)
+        quantize_dynamic(x, dtype=qdtype, round_mode=round_mode, ctx=self.ctx, out=buf[_HEADER_BYTES:], params=buf[:_HEADER_BYTES])
 
-    def quantize(self, x, payload, scale, zp, qdtype, round_mode):
-        from .torch import quantize as _q
+    def decode(self, buf: torch.Tensor, out: torch.Tensor, qdtype: torch.dtype, reduce_op: str) -> None:
+        from .torch import dequantize_dynamic
 
-        _q(x, scale=scale, zero_point=zp, dtype=qdtype, round_mode=round_mode, ctx=self.ctx, out=payload)
-
-    def dequantize(self, payload, out, scale, zp, qdtype, reduce_op):
-        from .torch import dequantize as _dq
-
-        _dq(payload, scale=scale, zero_point=zp, dtype=out.dtype, reduce_op=reduce_op, ctx=self.ctx, out=out, quant_dtype=qdtype,
-            shape=out.shape)
-
-
-_HEADER_BYTES = 16   # wire header per hop: float32 scale, int32 zero point, 8 bytes reserved (keeps the payload 16-byte aligned)
-
-
-def _pack_header(buf: torch.Tensor, scale: float, zp: int) -> None:
-    import struct
-
-    buf[:_HEADER_BYTES].copy_(torch.frombuffer(bytearray(struct.pack('<fiq', scale, zp, 0)), dtype=torch.uint8), non_blocking=False)
-
-
-def _unpack_header(buf: torch.Tensor) -> Tuple[float, int]:
-    import struct
-
-    scale, zp, _ = struct.unpack('<fiq', bytes(buf[:_HEADER_BYTES].cpu().numpy().tobytes()))
-    return scale, zp
+        dequantize_dynamic(buf[_HEADER_BYTES:], buf[:_HEADER_BYTES], dtype=out.dtype, reduce_op=reduce_op, ctx=self.ctx, out=out,
+                           quant_dtype=qdtype, shape=out.shape)
 
 
 def _exchange(send: torch.Tensor, recv: torch.Tensor, nxt: int, prv: int, group) -> None:
@@ -146,7 +130,9 @@ def quantized_all_reduce(
 
     Ring reduce-scatter: at every hop a rank quantizes the chunk it forwards with parameters taken from that chunk's
     current partial sum (``compute_quant_params``), sends ``header + packed bytes`` to its successor, and accumulates what it
-    receives with ``dequantize(reduce_op='add')`` -- the ADD store operator's purpose.  Ring all-gather: the owner of a
+    receives with ``dequantize(reduce_op='add')`` -- the ADD store operator's purpose.  The parameters are computed on the
+    device into the 16-byte wire header and consumed from it on the other side, so a hop costs no host round trip.
+    Ring all-gather: the owner of a
     finished chunk quantizes it once; the bytes travel round the ring unchanged and every rank (the owner included)
     stores ``dequantize(..., 'set')`` of the same bytes, so all ranks end bit-identical.  Wire traffic per element is
     1 byte (uint8) / 0.5 (uint4) instead of 4, over the same 2(G-1)/G ring schedule; each xGMI link carries one
@@ -176,33 +162,22 @@ def quantized_all_reduce(
         x_send, n_send = wire((rank - step) % world)
         x_recv, n_recv = wire((rank - step - 1) % world)
         if x_send.numel():
-            scale, zp = ops.params(x_send, quant_dtype)
-            ops.quantize(x_send, send[_HEADER_BYTES:n_send], scale, zp, quant_dtype, round_mode)
-        else:
-            scale, zp = 1.0, 0
-        _pack_header(send, scale, zp)
+            ops.encode(x_send, send[:n_send], quant_dtype, round_mode)
         _exchange(send[:n_send], recv[:n_recv], nxt, prv, group)
         if x_recv.numel():
-            r_scale, r_zp = _unpack_header(recv)
-            ops.dequantize(recv[_HEADER_BYTES:n_recv], x_recv, r_scale, r_zp, quant_dtype, 'add')
+            ops.decode(recv[:n_recv], x_recv, quant_dtype, 'add')
 
     # ---- all-gather: the finished chunk's bytes circulate unchanged ----
-    own = (rank + 1) % world
-    x_own, n_own = wire(own)
+    x_own, n_own = wire((rank + 1) % world)
     if x_own.numel():
-        scale, zp = ops.params(x_own, quant_dtype)
-        ops.quantize(x_own, send[_HEADER_BYTES:n_own], scale, zp, quant_dtype, round_mode)
-        ops.dequantize(send[_HEADER_BYTES:n_own], x_own, scale, zp, quant_dtype, 'set')   # owner keeps what everyone else will see
-    else:
-        scale, zp = 1.0, 0
-    _pack_header(send, scale, zp)
+        ops.encode(x_own, send[:n_own], quant_dtype, round_mode)
+        ops.decode(send[:n_own], x_own, quant_dtype, 'set')   # the owner keeps exactly what everyone else will see
     n_cur = n_own
     for step in range(world - 1):
         x_recv, n_recv = wire((rank - step) % world)
         _exchange(send[:n_cur], recv[:n_recv], nxt, prv, group)
         if x_recv.numel():
-            r_scale, r_zp = _unpack_header(recv)
-            ops.dequantize(recv[_HEADER_BYTES:n_recv], x_recv, r_scale, r_zp, quant_dtype, 'set')
+            ops.decode(recv[:n_recv], x_recv, quant_dtype, 'set')
         send, recv = recv, send          # forward the received bytes as they are
         n_cur = n_recv
     return tensor

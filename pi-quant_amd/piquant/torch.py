@@ -205,3 +205,67 @@ def quantize_dequantize(
     ctx.quantize_dequantize_ptr(tensor.data_ptr(), torch_to_piquant_dtype(tensor.dtype), out.data_ptr(), torch_to_piquant_dtype(quant_dtype),
                                 tensor.numel(), scale, zero_point, _ROUND_MODES[round_mode], _REDUCE_OPS[reduce_op])
     return out
+
+
+# -----------------------------------------------------------------------------------------------------------------
+# Device-resident parameters (additive): no host round trip between the min/max scan and its consumers.
+# -----------------------------------------------------------------------------------------------------------------
+PARAMS_NBYTES = 16   # piquant_hip_params_t: float scale, float 1/scale, int64 zero_point
+
+
+def params_to_host(params: torch.Tensor) -> Tuple[float, int]:
+    """(scale, zero_point) of a device parameter record (synchronises)."""
+    import struct
+
+    scale, _inv, zp = struct.unpack('<ffq', bytes(params[:PARAMS_NBYTES].cpu().numpy().tobytes()))
+    return scale, zp
+
+
+def compute_quant_params_device(tensor: torch.Tensor, *, dtype: torch.dtype, ctx: Optional[Context] = None,
+                                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Like ``compute_quant_params`` but asynchronous: the result is a 16-byte uint8 device tensor (the parameter record)."""
+    assert dtype in _QUANT_TYPES and tensor.is_cuda and tensor.dtype in _DEQUANT_TYPES
+    if not tensor.is_contiguous():
+        tensor = tensor.contiguous()
+    if out is None:
+        out = torch.empty(PARAMS_NBYTES, dtype=torch.uint8, device=tensor.device)
+    assert out.dtype == torch.uint8 and out.numel() >= PARAMS_NBYTES and out.data_ptr() % 8 == 0
+    ctx = _ctx_for(tensor, ctx)
+    ctx.compute_quant_params_device_ptr(tensor.data_ptr(), torch_to_piquant_dtype(tensor.dtype), tensor.numel(), torch_to_piquant_dtype(dtype),
+                                        out.data_ptr())
+    return out
+
+
+def quantize_dynamic(tensor: torch.Tensor, *, dtype: torch.dtype, round_mode: str = 'nearest', ctx: Optional[Context] = None,
+                     out: Optional[torch.Tensor] = None, params: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """scan -> parameters -> quantize, all on the device and all asynchronous.  Returns (quantized, parameter record)."""
+    params = compute_quant_params_device(tensor, dtype=dtype, ctx=ctx, out=params)
+    if not tensor.is_contiguous():
+        tensor = tensor.contiguous()
+    if out is None:
+        out = torch.empty(tensor.shape, dtype=dtype, device=tensor.device)
+    ctx = _ctx_for(tensor, ctx)
+    ctx.quantize_dp_ptr(tensor.data_ptr(), torch_to_piquant_dtype(tensor.dtype), out.data_ptr(), torch_to_piquant_dtype(dtype), tensor.numel(),
+                        params.data_ptr(), _ROUND_MODES[round_mode])
+    return out, params
+
+
+def dequantize_dynamic(tensor: torch.Tensor, params: torch.Tensor, *, dtype: torch.dtype, reduce_op: str = 'set',
+                       ctx: Optional[Context] = None, out: Optional[torch.Tensor] = None, quant_dtype: Optional[torch.dtype] = None,
+                       shape=None) -> torch.Tensor:
+    """``dequantize`` with (scale, zero_point) read from a device parameter record."""
+    assert dtype in _DEQUANT_TYPES and tensor.is_cuda and params.is_cuda
+    if not tensor.is_contiguous():
+        tensor = tensor.contiguous()
+    dtype_in, logical_shape = _quant_meta(tensor, quant_dtype, shape)
+    numel = 1
+    for s in logical_shape:
+        numel *= int(s)
+    if out is None:
+        if reduce_op == 'add':
+            raise ValueError("reduce_op='add' accumulates into out=; pass the accumulator tensor")
+        out = torch.empty(logical_shape, dtype=dtype, device=tensor.device)
+    ctx = _ctx_for(tensor, ctx)
+    ctx.dequantize_dp_ptr(tensor.data_ptr(), dtype_in, out.data_ptr(), torch_to_piquant_dtype(out.dtype), numel, params.data_ptr(),
+                          _REDUCE_OPS[reduce_op])
+    return out

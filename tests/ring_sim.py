@@ -49,7 +49,8 @@ def simulate(O, xs, qd, chunks, round_mode=0):
 
 
 class OracleOps:
-    """quantize / dequantize / params on CPU torch tensors through the oracle: stands in for the HIP ops where there is no GPU."""
+    """Wire encode / decode on CPU torch tensors through the oracle: stands in for the HIP ops where there is no GPU.
+    Same wire format: 16-byte header {float scale, float 1/scale, int64 zero_point} + packed bytes."""
 
     def __init__(self, O):
         self.O = O
@@ -59,18 +60,22 @@ class OracleOps:
 
         return {torch.uint8: 4, torch.quint8: 4, torch.quint4x2: 3, torch.quint2x4: 2}[qdtype]
 
-    def params(self, x, qdtype):
-        return self.O.compute_quant_params(x.numpy(), self.O.F32, self._qd(qdtype))
+    def encode(self, x, buf, qdtype, round_mode):
+        import struct
 
-    def quantize(self, x, payload, scale, zp, qdtype, round_mode):
         import torch
 
-        q = self.O.quantize(x.numpy(), self.O.F32, self._qd(qdtype), scale, zp, 0)
-        payload.copy_(torch.from_numpy(q))
+        scale, zp = self.O.compute_quant_params(x.numpy(), self.O.F32, self._qd(qdtype))
+        inv = float(np.float32(1.0) / np.float32(scale))
+        buf[:16].copy_(torch.frombuffer(bytearray(struct.pack("<ffq", scale, inv, zp)), dtype=torch.uint8))
+        buf[16:].copy_(torch.from_numpy(self.O.quantize(x.numpy(), self.O.F32, self._qd(qdtype), scale, zp, 0)))
 
-    def dequantize(self, payload, out, scale, zp, qdtype, reduce_op):
+    def decode(self, buf, out, qdtype, reduce_op):
+        import struct
+
         import torch
 
-        res = self.O.dequantize(payload.numpy(), self._qd(qdtype), self.O.F32, out.numel(), scale, zp, 1 if reduce_op == 'add' else 0,
+        scale, _inv, zp = struct.unpack("<ffq", buf[:16].numpy().tobytes())
+        res = self.O.dequantize(buf[16:].numpy(), self._qd(qdtype), self.O.F32, out.numel(), scale, zp, 1 if reduce_op == "add" else 0,
                                 out=out.numpy().copy())
         out.copy_(torch.from_numpy(res))

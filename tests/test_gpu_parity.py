@@ -467,6 +467,81 @@ def test_compute_quant_params_back_to_back(O):
         assert got == want8, it
 
 
+def test_device_resident_params_match_the_host_epilogue(O):
+    """piquant_hip_compute_quant_params_device: the double-precision epilogue runs in a one-wave kernel; scale, 1/scale and
+    zero point must be bit-identical to the host path (and to the oracle) on ordinary, degenerate and extreme ranges."""
+    import struct
+
+    import piquant
+    import torch
+
+    rng = np.random.default_rng(31)
+    cases = [rng.normal(size=n).astype(np.float32) * s for n in (1, 2, 1000, 70_001) for s in (1.0, 1e-3, 1e4, 1e-30, 1e30)]
+    cases += [np.full(1000, 42.0, np.float32), np.array([2.0, 6.0], np.float32), np.array([-6.0, -2.0], np.float32),
+              np.array([-1.0, 1.0], np.float32), np.linspace(-1, 3, 1001).astype(np.float32), np.array([0.0, 1e-45], np.float32),
+              np.array([-3.4e38, 3.4e38], np.float32)]
+    for x in cases:
+        xd = torch.from_numpy(x).cuda()
+        for tdt, odt in ((torch.quint8, 4), (torch.quint4x2, 3), (torch.quint2x4, 2)):
+            rec = piquant.torch.compute_quant_params_device(xd, dtype=tdt)
+            scale, inv, zp = struct.unpack("<ffq", rec.cpu().numpy().tobytes())
+            want = O.compute_quant_params(x, 0, odt)
+            host = piquant.torch.compute_quant_params(xd, dtype=tdt) if want[0] >= 0 and not np.isnan(want[0]) else want
+            assert (np.float32(scale).tobytes(), zp) == (np.float32(want[0]).tobytes(), want[1]) == (np.float32(host[0]).tobytes(), host[1]), (x[:3], tdt)
+            with np.errstate(divide="ignore", over="ignore"):
+                assert np.float32(inv).tobytes() == (np.float32(1.0) / np.float32(want[0])).tobytes()
+            assert piquant.torch.params_to_host(rec) == (scale, zp)
+
+
+def test_dynamic_pipeline_equals_the_two_step_path_and_is_graph_capturable(O):
+    import piquant
+    import torch
+
+    rng = np.random.default_rng(32)
+    n = 3_000_001
+    for dt_name, tdt, odt, qd in (("f32", torch.quint8, 4, 4), ("bf16", torch.quint4x2, 3, 3), ("f32", torch.quint2x4, 2, 2)):
+        x = rng.uniform(-2, 3, n).astype(np.float32)
+        xin = x if dt_name == "f32" else O.f32_to_bf16(x)
+        xd = torch.from_numpy(xin).cuda() if dt_name == "f32" else torch.from_numpy(xin.view(np.int16)).cuda().view(torch.bfloat16)
+        fdt = torch.float32 if dt_name == "f32" else torch.bfloat16
+        q, rec = piquant.torch.quantize_dynamic(xd, dtype=tdt)
+        scale, zp = piquant.torch.params_to_host(rec)
+        assert (scale, zp) == O.compute_quant_params(xin, 0 if dt_name == "f32" else 1, odt)
+        want_q = O.quantize(xin, 0 if dt_name == "f32" else 1, qd, scale, zp)
+        assert np.array_equal(piquant.torch.packed_bytes(q).cpu().numpy(), want_q)
+        acc = torch.ones(n, dtype=fdt, device="cuda")
+        piquant.torch.dequantize_dynamic(q, rec, dtype=fdt, reduce_op="add", out=acc)
+        ones = np.ones(n, np.float32) if dt_name == "f32" else O.f32_to_bf16(np.ones(n, np.float32))
+        want_acc = O.dequantize(want_q, qd, 0 if dt_name == "f32" else 1, n, scale, zp, 1, out=ones)
+        got_acc = acc.cpu().numpy() if dt_name == "f32" else acc.view(torch.int16).cpu().numpy().view(np.uint16)
+        assert same_floats(got_acc, want_acc)
+
+    # whole dynamic pipeline in one hipGraph: new data -> replay -> parameters, bytes and reconstruction follow, no host sync inside
+    x = torch.zeros(n, device="cuda")
+    q = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    rec = torch.zeros(16, dtype=torch.uint8, device="cuda")
+    y = torch.zeros(n, device="cuda")
+    c = piquant.Context()
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        piquant.torch.quantize_dynamic(x, dtype=torch.uint8, ctx=c, out=q, params=rec)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            piquant.torch.quantize_dynamic(x, dtype=torch.uint8, ctx=c, out=q, params=rec)
+            piquant.torch.dequantize_dynamic(q, rec, dtype=torch.float32, ctx=c, out=y)
+    for k in range(3):
+        data = (rng.normal(size=n) * (k + 1)).astype(np.float32)
+        x.copy_(torch.from_numpy(data))
+        g.replay()
+        torch.cuda.synchronize()
+        scale, zp = piquant.torch.params_to_host(rec)
+        assert (scale, zp) == O.compute_quant_params(data, 0, 4)
+        wq = O.quantize(data, 0, 4, scale, zp)
+        assert np.array_equal(q.cpu().numpy(), wq)
+        assert same_floats(y.cpu().numpy(), O.dequantize(wq, 4, 0, n, scale, zp))
+
+
 def test_minmax_keys_accumulate_across_calls(ctx, O):
     """init=0 folds further scans into the same keys: the building block of the multi-GPU reduction."""
     import piquant
