@@ -265,6 +265,13 @@ def main():
             extras["requantize_f32_u8_set"] = {"GB/s": gbs(8, e, reps), "avg_launch_us": round(e / reps * 1e6, 3),
                                                "note": "fused quantize->dequantize, 4 B read + 4 B written per element"}
             del y
+            rec = torch.empty(16, dtype=torch.uint8, device=dev)
+            _, e = time_loop(lambda i: piquant.torch.quantize_dynamic(xs[i % nsets], dtype=torch.uint8, ctx=ctx, out=outs[i % nsets], params=rec),
+                             reps, stream)
+            extras["quantize_dynamic_f32_u8"] = {"GB/s": gbs(9, e, reps), "avg_us_per_call": round(e / reps * 1e6, 3),
+                                                 "note": "min/max scan + on-device epilogue + quantize, three launches, no host sync (9 B/elem: x read twice)"}
+            ctx.set_stream(stream.cuda_stream)
+            ctx.set_blocking(False)
             keys = torch.empty(2, dtype=torch.int32, device=dev)
             _, e = time_loop(lambda i: ctx.minmax_keys_ptr(ptr_in[i % nsets], DataType.F32, n, keys.data_ptr(), True), reps, stream)
             extras["minmax_f32"] = {"GB/s": gbs(4, e, reps), "avg_launch_us": round(e / reps * 1e6, 3), "note": "init kernel + scan per call (piquant_hip_minmax_keys)"}
