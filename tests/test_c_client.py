@@ -1,0 +1,57 @@
+"""The C99 header is valid C and a plain C program (gcc, host buffers, no HIP headers) drives the library exactly as a
+user of the reference's C API would.  Compile checks run on CPU; the run itself needs the GPU."""
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+SRC = ROOT / "tests" / "c_abi_client.c"
+LIBDIR = ROOT / "pi-quant_amd" / "piquant"
+
+
+def _build(tmp_path):
+    exe = tmp_path / "c_abi_client"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-O2", f"-I{ROOT / 'include'}", str(SRC), f"-L{LIBDIR}",
+                    "-lpiquant", f"-Wl,-rpath,{LIBDIR}", "-o", str(exe)], check=True)
+    return exe
+
+
+def test_headers_are_valid_c99_and_client_links(tmp_path):
+    for header in ("piquant.h", "piquant_hip.h"):
+        tu = tmp_path / f"use_{header}.c"
+        tu.write_text(f'#include "{header}"\nint main(void) {{ return 0; }}\n')
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", f"-I{ROOT / 'include'}", str(tu)], check=True)
+    assert _build(tmp_path).exists()
+
+
+def _fnv1a(b: bytes) -> int:
+    h = 1469598103934665603
+    for chunk in np.frombuffer(b, dtype=np.uint8).tolist():
+        h = ((h ^ chunk) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+@pytest.mark.gpu
+def test_c_client_results_match_oracle(tmp_path, oracle_mod):
+    O = oracle_mod
+    n = 100_003
+    out = subprocess.run([str(_build(tmp_path)), str(n)], check=True, capture_output=True, text=True, timeout=300).stdout.split()
+    s = np.uint32(12345)
+    x = np.empty(n, dtype=np.float32)
+    with np.errstate(over="ignore"):
+        for i in range(n):
+            s ^= np.uint32(s << np.uint32(13))
+            s ^= np.uint32(s >> np.uint32(17))
+            s ^= np.uint32(s << np.uint32(5))
+            x[i] = np.float32(int(s) >> 8) * np.float32(2.0 / 16777216.0) - np.float32(1.0)
+    s8, z8 = O.compute_quant_params(x, O.F32, O.UINT8)
+    s4, z4 = O.compute_quant_params(x, O.F32, O.UINT4)
+    assert (np.float32(float(out[0])), int(out[1]), np.float32(float(out[2])), int(out[3])) == (np.float32(s8), z8, np.float32(s4), z4)
+    q8 = O.quantize(x, O.F32, O.UINT8, s8, z8)
+    q4 = O.quantize(x, O.F32, O.UINT4, s4, z4)
+    back = O.dequantize(q8, O.UINT8, O.F32, n, s8, z8, O.ADD, out=np.ones(n, np.float32))
+    assert int(out[4], 16) == _fnv1a(q8.tobytes())
+    assert int(out[5], 16) == _fnv1a(q4.tobytes())
+    assert int(out[6], 16) == _fnv1a(back.tobytes())
