@@ -79,11 +79,13 @@ __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
 }
 
 // x86 cvttps2dq: truncate; NaN and anything outside [-2^31, 2^31) give INT32_MIN.  The float is clamped
-// into range before the conversion so the fptosi is always defined.
+// into [-2^31, 2^31) before the conversion so the fptosi is always defined (one v_med3_f32; NaN -> -2^31).  Everything
+// at or below -2^31 then converts to INT32_MIN by itself, so only "a >= 2^31 or NaN" needs the explicit select -- one
+// ordered compare, false for NaN.
 __device__ __forceinline__ int32_t cvtt_i32_x86(float a) {
-    const float c = __builtin_fminf(__builtin_fmaxf(a, -2147483648.0f), 2147483520.0f);   // NaN -> -2^31
+    const float c = __builtin_fminf(__builtin_fmaxf(a, -2147483648.0f), 2147483520.0f);
     const int32_t t = static_cast<int32_t>(c);
-    return (a >= -2147483648.0f && a < 2147483648.0f) ? t : INT32_MIN;
+    return a < 2147483648.0f ? t : INT32_MIN;
 }
 
 // x86 cvttss2si r64, same convention with INT64_MIN.  r is integral-valued or small here; the wide
@@ -98,13 +100,36 @@ __device__ __forceinline__ uint32_t clamp_i64(int64_t v, int32_t qmax) {
     return static_cast<uint32_t>(v < 0 ? 0 : (v > qmax ? qmax : v));
 }
 
-// kernels_specialized.inl:62-77 (and the same shape at :207-222, :347-361, :514-528, :682-693)
+// kernels_specialized.inl:62-77 (and the same shape at :207-222, :347-361, :514-528, :682-693).
+// The reference's blend `p >= 0 ? 0.5 : -0.5` is written as copysign(0.5, p) (one v_bfi_b32): it differs from the blend
+// only for p == -0.0 (gives -0.5 -> trunc -> 0, the same integer as +0.5 -> 0) and for NaN (sum is NaN either way).
+template <int QMAX>
+__device__ __forceinline__ uint32_t quant_nearest_finish(float adj, const QuantParams& p) {
+    const int32_t q = static_cast<int32_t>(static_cast<uint32_t>(cvtt_i32_x86(adj)) + static_cast<uint32_t>(p.zp32));
+    return static_cast<uint32_t>(min(max(q, 0), QMAX));   // v_med3_i32
+}
+
 template <int QMAX>
 __device__ __forceinline__ uint32_t quant_nearest_fast(float x, const QuantParams& p) {
     const float prod = __fmul_rn(x, p.inv_scale);
-    const float adj = __fadd_rn(prod, prod >= 0.0f ? 0.5f : -0.5f);
-    const int32_t q = static_cast<int32_t>(static_cast<uint32_t>(cvtt_i32_x86(adj)) + static_cast<uint32_t>(p.zp32));
-    return static_cast<uint32_t>(min(max(q, 0), QMAX));   // v_med3_i32
+    const float adj = __fadd_rn(prod, __builtin_copysignf(0.5f, prod));
+    return quant_nearest_finish<QMAX>(adj, p);
+}
+
+// Two elements at once: the product and the sum are packed-fp32 instructions (v_pk_mul_f32 / v_pk_add_f32, each
+// element rounded exactly like the scalar op).  Contraction must stay off: a fused multiply-add would skip the
+// rounding of the product that the reference performs.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int QMAX>
+__device__ __forceinline__ void quant_nearest_fast2(float x0, float x1, const QuantParams& p, uint32_t& q0, uint32_t& q1) {
+#pragma clang fp contract(off)
+    const f32x2 x = {x0, x1};
+    const f32x2 prod = x * p.inv_scale;
+    const f32x2 half = {__builtin_copysignf(0.5f, prod[0]), __builtin_copysignf(0.5f, prod[1])};
+    const f32x2 adj = prod + half;
+    q0 = quant_nearest_finish<QMAX>(adj[0], p);
+    q1 = quant_nearest_finish<QMAX>(adj[1], p);
 }
 
 // quantize.inl:21-26
@@ -138,10 +163,31 @@ __device__ __forceinline__ uint32_t mix32(uint32_t h) {
     return h;
 }
 
+__device__ __forceinline__ uint32_t element_key(const QuantParams& p, uint32_t idx_hi) { return mix32(idx_hi ^ p.seed_hi) + p.seed_lo; }
+
+__device__ __forceinline__ float threshold_from_key(uint32_t key, uint32_t idx_lo) {
+    return static_cast<float>(mix32(idx_lo ^ key) >> 8) * (1.0f / 16777216.0f);
+}
+
 __device__ __forceinline__ float element_threshold(const QuantParams& p, uint64_t idx) {
-    const uint32_t key = mix32(static_cast<uint32_t>(idx >> 32) ^ p.seed_hi) + p.seed_lo;
-    const uint32_t h = mix32(static_cast<uint32_t>(idx) ^ key);
-    return static_cast<float>(h >> 8) * (1.0f / 16777216.0f);
+    return threshold_from_key(element_key(p, static_cast<uint32_t>(idx >> 32)), static_cast<uint32_t>(idx));
+}
+
+// The key depends only on the upper 32 bits of the global element index, which is the same for (nearly) every element a
+// thread touches: a tile derives the keys of its first index's upper half and of the next one once, and each element
+// picks between them -- one multiply-heavy mix32 per element instead of two (the kernel went from VALU- to HBM-bound).
+struct ElementKeys {
+    uint32_t hi0, key0, key1;
+};
+
+__device__ __forceinline__ ElementKeys element_keys_for(const QuantParams& p, uint64_t first_idx) {
+    const uint32_t hi0 = static_cast<uint32_t>(first_idx >> 32);
+    return {hi0, element_key(p, hi0), element_key(p, hi0 + 1u)};
+}
+
+__device__ __forceinline__ float element_threshold(const ElementKeys& k, uint64_t idx) {
+    const uint32_t key = static_cast<uint32_t>(idx >> 32) == k.hi0 ? k.key0 : k.key1;   // a tile spans far less than 2^32 elements
+    return threshold_from_key(key, static_cast<uint32_t>(idx));
 }
 
 template <int MODE, int QMAX>

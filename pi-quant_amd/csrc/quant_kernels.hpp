@@ -166,6 +166,8 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
         }
 
         uint32_t w[U][WORDS];
+        [[maybe_unused]] ElementKeys keys {};
+        if constexpr (MODE == RM_STOCH_ELEM) keys = element_keys_for(p, p.index_base + static_cast<uint64_t>(v0 + lane) * EPV);
 #pragma unroll
         for (int k = 0; k < U; ++k) {
             float v[EPV];
@@ -173,10 +175,25 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
 #pragma unroll
             for (int j = 0; j < WORDS; ++j) w[k][j] = 0;
             const uint64_t e0 = static_cast<uint64_t>(v0 + k * 64 + lane) * EPV;
+            if constexpr (MODE == RM_NEAREST_FAST) {
 #pragma unroll
-            for (int e = 0; e < EPV; ++e) {
-                const uint32_t q = quant_one<MODE, QMAX>(v[e], p, e0 + e);
-                w[k][(e * BITS) >> 5] |= q << ((e * BITS) & 31);
+                for (int e = 0; e < EPV; e += 2) {
+                    uint32_t q0, q1;
+                    quant_nearest_fast2<QMAX>(v[e], v[e + 1], p, q0, q1);
+                    w[k][(e * BITS) >> 5] |= (q0 | (q1 << BITS)) << ((e * BITS) & 31);
+                }
+            } else if constexpr (MODE == RM_STOCH_ELEM) {
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                    const uint32_t q = quant_stochastic<QMAX>(v[e], p, element_threshold(keys, p.index_base + e0 + e));
+                    w[k][(e * BITS) >> 5] |= q << ((e * BITS) & 31);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                    const uint32_t q = quant_one<MODE, QMAX>(v[e], p, e0 + e);
+                    w[k][(e * BITS) >> 5] |= q << ((e * BITS) & 31);
+                }
             }
         }
 
