@@ -207,7 +207,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32->u8",
+        "dtype": "f32",
         "data": "synthetic",
         "config": {
             "workload": "BASELINE configs[1]: fp32->uint8 nearest-round on MI355X, numel=27264000 per GPU, inputs resident in HBM, "

@@ -28,6 +28,12 @@ PIQUANT_EXPORT void piquant_hip_reset_stream(piquant_context_t* ctx);
  * stream order.  Host-pointer calls and compute_quant_params always complete before returning. */
 PIQUANT_EXPORT void piquant_hip_set_blocking(piquant_context_t* ctx, int blocking);
 
+/* Pointer classification.  By default every buffer is classified with hipPointerGetAttributes (device / pinned: used in
+ * place; pageable host: staged over PCIe).  A binding that already knows its buffers are device memory (PyTorch device
+ * tensors) sets assume != 0 to skip the two runtime queries per call -- they are a visible share of the ~10 us a small
+ * call costs.  With assume set, passing a pageable host pointer is undefined behaviour. */
+PIQUANT_EXPORT void piquant_hip_assume_device_pointers(piquant_context_t* ctx, int assume);
+
 /* Stochastic rounding control.  The reference draws ONE threshold in [0,1) per call from an unseeded
  * thread-local mt19937_64 (src/piquant.cpp:194-201) and compares every element's fractional part with it
  * (src/kernels/quantize.inl:8-19).  Default here: the same, drawn per call from a context-owned

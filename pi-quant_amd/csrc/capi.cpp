@@ -109,6 +109,7 @@ struct piquant_context_t {
     hipStream_t stream = nullptr;          // stream work is enqueued on (own_stream unless the caller set one)
     hipStream_t stage_stream[2] = {nullptr, nullptr};
     bool blocking = true;
+    bool assume_device = false;            // skip hipPointerGetAttributes (piquant_hip_assume_device_pointers)
 
     // Min/max scan state: two slot buffers on the device (see minmax_kernels.hpp).  Calls alternate between them;
     // the scan that fills one re-arms the other (idle) one, so no separate initialisation launch precedes a scan.
@@ -131,6 +132,8 @@ struct piquant_context_t {
     bool per_element = false;
     uint64_t elem_seed = 0, elem_base = 0;
     std::mutex mu;
+
+    Resolved resolve_ptr(const void* p) const { return assume_device ? Resolved{false, const_cast<void*>(p)} : resolve(p); }
 
     void ensure_stage(size_t in_bytes, size_t out_bytes) {
         if (in_bytes > stage_in_cap) {
@@ -253,7 +256,7 @@ static void quantize_impl(piquant_context_t* ctx, const void* in, piquant_dtype_
         q.threshold = draw_threshold(ctx);              // one threshold per call (src/piquant.cpp:197-201)
     }
 
-    const Resolved rin = resolve(in), rout = resolve(out);
+    const Resolved rin = ctx->resolve_ptr(in), rout = ctx->resolve_ptr(out);
     if (dyn_params) {
         const Resolved rp = resolve(dyn_params);
         if (rin.pageable || rout.pageable || rp.pageable) panic("quantize with device-resident parameters needs device (or pinned) buffers");
@@ -327,7 +330,7 @@ static void dequantize_impl(piquant_context_t* ctx, const void* in, piquant_dtyp
     // fp32 product on the host exactly as the reference forms it (kernels_specialized.inl:1204,1325)
     d.bias = -static_cast<float>(static_cast<int32_t>(static_cast<uint32_t>(static_cast<uint64_t>(zero_point)))) * scale;
 
-    const Resolved rin = resolve(in), rout = resolve(out);
+    const Resolved rin = ctx->resolve_ptr(in), rout = ctx->resolve_ptr(out);
     if (dyn_params) {
         const Resolved rp = resolve(dyn_params);
         if (rin.pageable || rout.pageable || rp.pageable) panic("dequantize with device-resident parameters needs device (or pinned) buffers");
@@ -390,7 +393,7 @@ void piquant_hip_quantize_dequantize(piquant_context_t* ctx, const void* in, piq
     if (!in || !out) panic("quantize_dequantize: NULL buffer");
     std::lock_guard<std::mutex> lock(ctx->mu);
     DeviceGuard guard(ctx->device);
-    const Resolved rin = resolve(in), rout = resolve(out);
+    const Resolved rin = ctx->resolve_ptr(in), rout = ctx->resolve_ptr(out);
     if (rin.pageable || rout.pageable) panic("quantize_dequantize: device (or pinned) buffers required");
     RequantLaunch r {};
     r.in = rin.dev;
@@ -431,7 +434,7 @@ static int32_t* scan_into_slots(piquant_context_t* ctx, const void* x, piquant_d
     int32_t* idle = ctx->d_slots[ctx->slot ^ 1];
     ctx->slot ^= 1;
     ctx->scan_stream = ctx->stream;
-    const Resolved r = resolve(x);
+    const Resolved r = ctx->resolve_ptr(x);
     if (!r.pageable) {
         launch_minmax(r.dev, dtype, static_cast<int64_t>(n), cur, idle, ctx->stream, ctx->num_cu);
         return cur;
@@ -576,6 +579,12 @@ void piquant_hip_reset_stream(piquant_context_t* ctx) {
     if (!ctx) panic("piquant_hip_reset_stream: context is NULL");
     std::lock_guard<std::mutex> lock(ctx->mu);
     ctx->stream = ctx->own_stream;
+}
+
+void piquant_hip_assume_device_pointers(piquant_context_t* ctx, int assume) {
+    if (!ctx) panic("piquant_hip_assume_device_pointers: context is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->assume_device = assume != 0;
 }
 
 void piquant_hip_set_blocking(piquant_context_t* ctx, int blocking) {

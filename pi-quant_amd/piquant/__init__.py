@@ -79,6 +79,11 @@ class Context:
         self._ctx = C.piquant_context_create(self._num_threads)
         assert self._ctx, 'piquant_context_create returned NULL'
         self._finalizer = weakref.finalize(self, C.piquant_context_destroy, self._ctx)
+        self._device = int(C.piquant_hip_device(self._ctx))
+        # last values pushed to the native context: the setters below only cross the FFI when something changes
+        self._stream: object = 'own'
+        self._blocking = True
+        self._assume_device = False
 
     @staticmethod
     def get(device_index: Optional[int] = None) -> 'Context':
@@ -93,36 +98,40 @@ class Context:
 
     @property
     def device(self) -> int:
-        return int(C.piquant_hip_device(self._ctx))
+        return self._device
 
     # ---- reference surface (python/src/piquant/__init__.py:82-142) ---------------------------------
     def quantize_ptr(self, ptr_in: int, dtype_in: DataType, ptr_out: int, dtype_out: DataType, numel: int, scale: float,
-                     zero_point: int, round_mode: RoundMode) -> None:
+                     zero_point: int, round_mode: RoundMode, _device_ptrs: bool = False) -> None:
         assert dtype_in.is_dequantized, f'Input dtype must be a dequantized type, but is: {dtype_in}'
         assert dtype_out.is_quantized, f'Output dtype must be a quantized type, but is: {dtype_out}'
         assert numel == 0 or ptr_in != 0, 'Input arr pointer must not be NULL'
         assert numel == 0 or ptr_out != 0, 'Output arr pointer must not be NULL'
+        self.assume_device_pointers(_device_ptrs)
         C.piquant_quantize(self._ctx, ptr_in, dtype_in.value, ptr_out, dtype_out.value, numel, scale, zero_point, round_mode.value)
 
     def dequantize_ptr(self, ptr_in: int, dtype_in: DataType, ptr_out: int, dtype_out: DataType, numel: int, scale: float,
-                       zero_point: int, reduce_op: ReduceOp) -> None:
+                       zero_point: int, reduce_op: ReduceOp, _device_ptrs: bool = False) -> None:
         assert dtype_in.is_quantized, f'Input dtype must be a quantized type, but is: {dtype_in}'
         assert dtype_out.is_dequantized, f'Output dtype must be a dequantized type, but is: {dtype_out}'
         assert numel == 0 or ptr_in != 0, 'Input arr pointer must not be NULL'
         assert numel == 0 or ptr_out != 0, 'Output arr pointer must not be NULL'
+        self.assume_device_pointers(_device_ptrs)
         C.piquant_dequantize(self._ctx, ptr_in, dtype_in.value, ptr_out, dtype_out.value, numel, scale, zero_point, reduce_op.value)
 
-    def compute_quant_params_ptr_float32(self, ptr: int, target_quant_dtype: DataType, numel: int) -> Tuple[float, int]:
+    def compute_quant_params_ptr_float32(self, ptr: int, target_quant_dtype: DataType, numel: int, _device_ptrs: bool = False) -> Tuple[float, int]:
         assert target_quant_dtype.is_quantized, f'Target dtype must be a quantized type, but is: {target_quant_dtype}'
         assert ptr != 0, 'Input arr pointer must not be NULL'
         scale, zero_point = _C.c_float(), _C.c_int64()
+        self.assume_device_pointers(_device_ptrs)
         C.piquant_compute_quant_params_float32(self._ctx, ptr, numel, target_quant_dtype.value, _C.byref(scale), _C.byref(zero_point))
         return scale.value, zero_point.value
 
-    def compute_quant_params_ptr_bfloat16(self, ptr: int, target_quant_dtype: DataType, numel: int) -> Tuple[float, int]:
+    def compute_quant_params_ptr_bfloat16(self, ptr: int, target_quant_dtype: DataType, numel: int, _device_ptrs: bool = False) -> Tuple[float, int]:
         assert target_quant_dtype.is_quantized, f'Target dtype must be a quantized type, but is: {target_quant_dtype}'
         assert ptr != 0, 'Input arr pointer must not be NULL'
         scale, zero_point = _C.c_float(), _C.c_int64()
+        self.assume_device_pointers(_device_ptrs)
         C.piquant_compute_quant_params_bfloat16(self._ctx, ptr, numel, target_quant_dtype.value, _C.byref(scale), _C.byref(zero_point))
         return scale.value, zero_point.value
 
@@ -130,15 +139,29 @@ class Context:
     def set_stream(self, hip_stream: int) -> None:
         """Enqueue on this hipStream_t, e.g. ``torch.cuda.current_stream().cuda_stream``.  0 is HIP's legacy default
         stream (PyTorch's default stream), not "no stream"; see ``reset_stream``."""
-        C.piquant_hip_set_stream(self._ctx, hip_stream or None)
+        if self._stream != hip_stream:
+            C.piquant_hip_set_stream(self._ctx, hip_stream or None)
+            self._stream = hip_stream
 
     def reset_stream(self) -> None:
         """Back to the context's private non-blocking stream (the state of a new context)."""
-        C.piquant_hip_reset_stream(self._ctx)
+        if self._stream != 'own':
+            C.piquant_hip_reset_stream(self._ctx)
+            self._stream = 'own'
 
     def set_blocking(self, blocking: bool) -> None:
         """True (native default): calls return after completion, like the reference.  False: stream-ordered."""
-        C.piquant_hip_set_blocking(self._ctx, 1 if blocking else 0)
+        if self._blocking != bool(blocking):
+            C.piquant_hip_set_blocking(self._ctx, 1 if blocking else 0)
+            self._blocking = bool(blocking)
+
+    def assume_device_pointers(self, assume: bool) -> None:
+        """Skip the native pointer classification for the calls that follow (all buffers are device or pinned memory).
+        The ``*_ptr`` methods set it per call from their ``_device_ptrs`` argument (False unless the torch binding knows
+        better), so raw-pointer users always get the classifying, host-pointer-safe behaviour."""
+        if self._assume_device != bool(assume):
+            C.piquant_hip_assume_device_pointers(self._ctx, 1 if assume else 0)
+            self._assume_device = bool(assume)
 
     def set_stochastic_threshold(self, threshold: Optional[float]) -> None:
         """Pin the per-call stochastic threshold in [0,1) (None: draw a fresh one per call, the default)."""
@@ -152,30 +175,35 @@ class Context:
         C.piquant_hip_set_stochastic_per_element(self._ctx, 1 if enabled else 0, seed & 0xFFFFFFFFFFFFFFFF, index_base)
 
     def quantize_dequantize_ptr(self, ptr_in: int, dtype_in_out: DataType, ptr_out: int, quant_dtype: DataType, numel: int, scale: float,
-                                zero_point: int, round_mode: RoundMode, reduce_op: ReduceOp) -> None:
+                                zero_point: int, round_mode: RoundMode, reduce_op: ReduceOp, _device_ptrs: bool = False) -> None:
         """Fused quantize->dequantize (the reference's C++-only ``quantize_dequantize_fused``, piquant.hpp:276-285)."""
         assert dtype_in_out.is_dequantized and quant_dtype.is_quantized
+        self.assume_device_pointers(_device_ptrs)
         C.piquant_hip_quantize_dequantize(self._ctx, ptr_in, dtype_in_out.value, ptr_out, quant_dtype.value, numel, scale, zero_point,
                                           round_mode.value, reduce_op.value)
 
     # device-resident parameters: a 16-byte record {float scale, float 1/scale, int64 zero_point} in device memory
-    def compute_quant_params_device_ptr(self, ptr: int, dtype: DataType, numel: int, target_quant_dtype: DataType, params_ptr: int) -> None:
+    def compute_quant_params_device_ptr(self, ptr: int, dtype: DataType, numel: int, target_quant_dtype: DataType, params_ptr: int, _device_ptrs: bool = False) -> None:
         assert dtype.is_dequantized and target_quant_dtype.is_quantized and params_ptr != 0
+        self.assume_device_pointers(_device_ptrs)
         C.piquant_hip_compute_quant_params_device(self._ctx, ptr, dtype.value, numel, target_quant_dtype.value, params_ptr)
 
     def quantize_dp_ptr(self, ptr_in: int, dtype_in: DataType, ptr_out: int, dtype_out: DataType, numel: int, params_ptr: int,
-                        round_mode: RoundMode) -> None:
+                        round_mode: RoundMode, _device_ptrs: bool = False) -> None:
         assert dtype_in.is_dequantized and dtype_out.is_quantized and params_ptr != 0
+        self.assume_device_pointers(_device_ptrs)
         C.piquant_hip_quantize_dp(self._ctx, ptr_in, dtype_in.value, ptr_out, dtype_out.value, numel, params_ptr, round_mode.value)
 
     def dequantize_dp_ptr(self, ptr_in: int, dtype_in: DataType, ptr_out: int, dtype_out: DataType, numel: int, params_ptr: int,
-                          reduce_op: ReduceOp) -> None:
+                          reduce_op: ReduceOp, _device_ptrs: bool = False) -> None:
         assert dtype_in.is_quantized and dtype_out.is_dequantized and params_ptr != 0
+        self.assume_device_pointers(_device_ptrs)
         C.piquant_hip_dequantize_dp(self._ctx, ptr_in, dtype_in.value, ptr_out, dtype_out.value, numel, params_ptr, reduce_op.value)
 
-    def minmax_keys_ptr(self, ptr: int, dtype: DataType, numel: int, device_keys_ptr: int, init: bool = True) -> None:
+    def minmax_keys_ptr(self, ptr: int, dtype: DataType, numel: int, device_keys_ptr: int, init: bool = True, _device_ptrs: bool = False) -> None:
         """Asynchronously fold {min, -max} of the buffer into two int32 keys in device memory (atomic MIN)."""
         assert dtype.is_dequantized
+        self.assume_device_pointers(_device_ptrs)
         C.piquant_hip_minmax_keys(self._ctx, ptr, dtype.value, numel, device_keys_ptr, 1 if init else 0)
 
 

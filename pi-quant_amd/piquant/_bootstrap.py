@@ -28,6 +28,7 @@ _DECLS = [
     ('piquant_hip_set_stream', None, [_vp, _vp]),
     ('piquant_hip_reset_stream', None, [_vp]),
     ('piquant_hip_set_blocking', None, [_vp, _int]),
+    ('piquant_hip_assume_device_pointers', None, [_vp, _int]),
     ('piquant_hip_set_stochastic_threshold', None, [_vp, _f32]),
     ('piquant_hip_set_stochastic_seed', None, [_vp, C.c_uint64]),
     ('piquant_hip_set_stochastic_per_element', None, [_vp, _int, C.c_uint64, C.c_uint64]),

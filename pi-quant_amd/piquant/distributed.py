@@ -41,7 +41,7 @@ def local_minmax_keys(tensor: torch.Tensor, ctx: Optional[Context] = None) -> to
         tensor = tensor.contiguous()
     ctx = _ctx_for(tensor, ctx)
     keys = torch.empty(2, dtype=torch.int32, device=tensor.device)
-    ctx.minmax_keys_ptr(tensor.data_ptr(), torch_to_piquant_dtype(tensor.dtype), tensor.numel(), keys.data_ptr(), init=True)
+    ctx.minmax_keys_ptr(tensor.data_ptr(), torch_to_piquant_dtype(tensor.dtype), tensor.numel(), keys.data_ptr(), init=True, _device_ptrs=True)
     return keys
 
 

@@ -97,9 +97,9 @@ def compute_quant_params(tensor: torch.Tensor, *, dtype: torch.dtype, ctx: Optio
         tensor = tensor.contiguous()
     ctx = _ctx_for(tensor, ctx)
     if tensor.dtype == torch.bfloat16:
-        return ctx.compute_quant_params_ptr_bfloat16(tensor.data_ptr(), torch_to_piquant_dtype(dtype), tensor.numel())
+        return ctx.compute_quant_params_ptr_bfloat16(tensor.data_ptr(), torch_to_piquant_dtype(dtype), tensor.numel(), _device_ptrs=tensor.is_cuda)
     assert tensor.dtype == torch.float32, f'compute_quant_params needs float32 or bfloat16, got {tensor.dtype}'
-    return ctx.compute_quant_params_ptr_float32(tensor.data_ptr(), torch_to_piquant_dtype(dtype), tensor.numel())
+    return ctx.compute_quant_params_ptr_float32(tensor.data_ptr(), torch_to_piquant_dtype(dtype), tensor.numel(), _device_ptrs=tensor.is_cuda)
 
 
 def quantize(
@@ -133,6 +133,7 @@ def quantize(
         scale=scale,
         zero_point=zero_point,
         round_mode=_ROUND_MODES[round_mode],
+        _device_ptrs=tensor.is_cuda,
     )
     return out
 
@@ -174,6 +175,7 @@ def dequantize(
         scale=scale,
         zero_point=zero_point,
         reduce_op=_REDUCE_OPS[reduce_op],
+        _device_ptrs=tensor.is_cuda,
     )
     return out
 
@@ -203,7 +205,7 @@ def quantize_dequantize(
         assert out.dtype == tensor.dtype and out.is_contiguous() and out.device == tensor.device and out.numel() == tensor.numel()
     ctx = _ctx_for(tensor, ctx)
     ctx.quantize_dequantize_ptr(tensor.data_ptr(), torch_to_piquant_dtype(tensor.dtype), out.data_ptr(), torch_to_piquant_dtype(quant_dtype),
-                                tensor.numel(), scale, zero_point, _ROUND_MODES[round_mode], _REDUCE_OPS[reduce_op])
+                                tensor.numel(), scale, zero_point, _ROUND_MODES[round_mode], _REDUCE_OPS[reduce_op], _device_ptrs=True)
     return out
 
 
@@ -232,7 +234,7 @@ def compute_quant_params_device(tensor: torch.Tensor, *, dtype: torch.dtype, ctx
     assert out.dtype == torch.uint8 and out.numel() >= PARAMS_NBYTES and out.data_ptr() % 8 == 0
     ctx = _ctx_for(tensor, ctx)
     ctx.compute_quant_params_device_ptr(tensor.data_ptr(), torch_to_piquant_dtype(tensor.dtype), tensor.numel(), torch_to_piquant_dtype(dtype),
-                                        out.data_ptr())
+                                        out.data_ptr(), _device_ptrs=True)
     return out
 
 
@@ -246,7 +248,7 @@ def quantize_dynamic(tensor: torch.Tensor, *, dtype: torch.dtype, round_mode: st
         out = torch.empty(tensor.shape, dtype=dtype, device=tensor.device)
     ctx = _ctx_for(tensor, ctx)
     ctx.quantize_dp_ptr(tensor.data_ptr(), torch_to_piquant_dtype(tensor.dtype), out.data_ptr(), torch_to_piquant_dtype(dtype), tensor.numel(),
-                        params.data_ptr(), _ROUND_MODES[round_mode])
+                        params.data_ptr(), _ROUND_MODES[round_mode], _device_ptrs=True)
     return out, params
 
 
@@ -267,5 +269,5 @@ def dequantize_dynamic(tensor: torch.Tensor, params: torch.Tensor, *, dtype: tor
         out = torch.empty(logical_shape, dtype=dtype, device=tensor.device)
     ctx = _ctx_for(tensor, ctx)
     ctx.dequantize_dp_ptr(tensor.data_ptr(), dtype_in, out.data_ptr(), torch_to_piquant_dtype(out.dtype), numel, params.data_ptr(),
-                          _REDUCE_OPS[reduce_op])
+                          _REDUCE_OPS[reduce_op], _device_ptrs=True)
     return out

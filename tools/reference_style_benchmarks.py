@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""The reference's two Python benchmark scripts, re-stated for ROCm device tensors.
+
+  python/benchmark/benchmark.py      torch.quantize_per_tensor vs piquant.torch.quantize, NUMEL = 1e6, 1000 runs, total
+                                     wall seconds per quantized dtype (the bars of python/quant_benchmark.png)
+  python/benchmark/throughput_avg.py GiB/s of bf16 <-> quint4x2 / quint2x4 over a large tensor, 10 iterations
+
+Same measurement conventions (wall clock around the Python-level call, result allocation included; here with a device
+synchronisation inside the timed region so the GPU work is counted).  torch.quantize_per_tensor runs on the same GPU for
+quint8 (PyTorch-ROCm implements it); for the packed dtypes PyTorch has no device kernel, so the torch column is measured
+on the host CPU like the reference does.  No plot is drawn (matplotlib is not part of this image); one JSON document is
+printed.  Usage: python tools/reference_style_benchmarks.py [--gib 8] > profiles/rNN_reference_style.json
+"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "pi-quant_amd"))
+
+import torch  # noqa: E402
+
+import piquant  # noqa: E402
+
+NUM_RUNS = 1000
+NUMEL = 1_000_000
+
+
+def torch_vs_piquant():
+    rows = []
+    for qdt in (torch.quint8, torch.quint4x2, torch.quint2x4):
+        x = torch.rand(NUMEL, dtype=torch.float32, device="cuda")
+        scale, zp = piquant.torch.compute_quant_params(x, dtype=qdt)
+        on_gpu = qdt == torch.quint8
+        xt = x if on_gpu else x.cpu()
+        torch.quantize_per_tensor(xt, scale=scale, zero_point=zp, dtype=qdt)
+        piquant.torch.quantize(x, scale=scale, zero_point=zp, dtype=qdt)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(NUM_RUNS):
+            torch.quantize_per_tensor(xt, scale=scale, zero_point=zp, dtype=qdt)
+        torch.cuda.synchronize()
+        t_torch = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for _ in range(NUM_RUNS):
+            piquant.torch.quantize(x, scale=scale, zero_point=zp, dtype=qdt)
+        torch.cuda.synchronize()
+        t_pi = time.perf_counter() - t0
+        # same check as the reference script: dequantized results agree within 1e-1
+        dq_t = torch.quantize_per_tensor(xt, scale=scale, zero_point=zp, dtype=qdt).dequantize().cpu()
+        dq_p = piquant.torch.dequantize(piquant.torch.quantize(x, scale=scale, zero_point=zp, dtype=qdt), scale=scale, zero_point=zp,
+                                        dtype=torch.float32).cpu()
+        rows.append({"dtype": str(qdt).replace("torch.", ""), "torch_s_per_1000": round(t_torch, 6), "piquant_s_per_1000": round(t_pi, 6),
+                     "torch_device": "cuda" if on_gpu else "cpu (no device kernel in PyTorch for this dtype)",
+                     "results_allclose_1e-1": bool(torch.allclose(dq_t, dq_p, atol=1e-1))})
+    return rows
+
+
+def throughput(total_gib: float):
+    rows = []
+    for dq_type, q_type in ((torch.bfloat16, torch.quint4x2), (torch.bfloat16, torch.quint2x4), (torch.float32, torch.quint8)):
+        bpe = torch.tensor([], dtype=dq_type).element_size()
+        n = int(total_gib * (1 << 30)) // bpe
+        x = torch.rand(n, dtype=torch.float32, device="cuda").to(dq_type) if dq_type != torch.float32 else torch.rand(n, device="cuda")
+        scale, zp = piquant.torch.compute_quant_params(x, dtype=q_type)
+        q = piquant.torch.quantize(x, scale=scale, zero_point=zp, dtype=q_type)
+        piquant.torch.dequantize(q, scale=scale, zero_point=zp, dtype=dq_type)
+        torch.cuda.synchronize()
+        qs, dqs = [], []
+        for _ in range(10):
+            t0 = time.perf_counter()
+            q = piquant.torch.quantize(x, scale=scale, zero_point=zp, dtype=q_type)
+            torch.cuda.synchronize()
+            qs.append(total_gib / (time.perf_counter() - t0))
+            t0 = time.perf_counter()
+            y = piquant.torch.dequantize(q, scale=scale, zero_point=zp, dtype=dq_type)
+            torch.cuda.synchronize()
+            dqs.append(total_gib / (time.perf_counter() - t0))      # GiB of float data produced (the reference divides the packed size)
+            del y
+        rows.append({"pair": f"{str(dq_type).replace('torch.', '')} <-> {str(q_type).replace('torch.', '')}", "numel": n,
+                     "quantize_GiB/s_of_float_input": round(sum(qs) / len(qs), 1), "dequantize_GiB/s_of_float_output": round(sum(dqs) / len(dqs), 1)})
+        del x, q
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gib", type=float, default=8.0, help="size of the float tensor for the throughput part (reference: 32)")
+    args = ap.parse_args()
+    out = {"device": torch.cuda.get_device_name(0), "benchmark_py (NUMEL=1e6, 1000 runs)": torch_vs_piquant(),
+           f"throughput_avg_py ({args.gib} GiB float tensor, 10 iterations, allocation + sync inside the timed call)": throughput(args.gib)}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
