@@ -62,6 +62,10 @@ def packed_bytes(tensor: torch.Tensor) -> torch.Tensor:
     return raw[first: first + dt.packed_nbytes(tensor.numel())]
 
 
+# torch.cuda.current_stream(i).cuda_stream builds a Stream object per call (~1.2 us); the raw getter is ~5x cheaper
+_current_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None) or (lambda index: torch.cuda.current_stream(index).cuda_stream)
+
+
 def _ctx_for(tensor: torch.Tensor, ctx: Optional[Context]) -> Context:
     """Default context of the tensor's device, with the current PyTorch stream attached for device tensors."""
     if tensor.is_cuda:
@@ -70,7 +74,7 @@ def _ctx_for(tensor: torch.Tensor, ctx: Optional[Context]) -> Context:
             ctx = Context.get(index)
         elif ctx.device != index:
             raise ValueError(f'context is bound to device {ctx.device} but the tensor lives on device {index}')
-        ctx.set_stream(torch.cuda.current_stream(index).cuda_stream)
+        ctx.set_stream(_current_raw_stream(index))
         ctx.set_blocking(False)   # stream-ordered, like every other PyTorch device op
     else:
         if ctx is None:
