@@ -76,6 +76,7 @@ class Context:
 
     def __init__(self, num_threads: Union[int, None] = None) -> None:
         self._num_threads = 0 if num_threads is None else int(num_threads)
+        _require_device()   # a Python exception instead of the native abort when there is no GPU
         self._ctx = C.piquant_context_create(self._num_threads)
         assert self._ctx, 'piquant_context_create returned NULL'
         self._finalizer = weakref.finalize(self, C.piquant_context_destroy, self._ctx)
@@ -222,11 +223,19 @@ def quant_params_from_minmax(r_min: float, r_max: float, target_quant_dtype: Dat
     return scale.value, zero_point.value
 
 
-def _current_device() -> int:
+def _require_device() -> None:
+    if importlib.util.find_spec('torch') is None:
+        return   # no torch to ask: the native library reports a missing device itself (message + abort)
     import torch as _torch
 
     if not _torch.cuda.is_available():
         raise RuntimeError('piquant needs a HIP device: torch.cuda.is_available() is False and there is no CPU path')
+
+
+def _current_device() -> int:
+    import torch as _torch
+
+    _require_device()
     return _torch.cuda.current_device()
 
 

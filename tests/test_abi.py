@@ -97,3 +97,18 @@ def test_minmax_key_codec_is_order_preserving():
         assert np.float32(lo).tobytes() == np.float32(v).tobytes() or (v == 0 and lo == 0)
         assert hi == v
     assert lib.piquant_hip_version is not None
+
+
+def test_no_gpu_is_a_loud_python_error_not_a_fallback():
+    """On a box without a GPU the package imports (the library loads) but creating a context or quantizing raises --
+    there is no CPU compute path to fall back to."""
+    import torch
+
+    import piquant
+
+    if torch.cuda.is_available():
+        pytest.skip("this box has a GPU")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        piquant.Context()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        piquant.torch.quantize(torch.zeros(16), scale=1.0, zero_point=0, dtype=torch.quint8)
