@@ -309,6 +309,27 @@ def test_more_than_2_pow_32_elements(O):
     assert float((acc - x).abs().max()) <= 0.5 * scale * 1.0001 + 1e-6
 
 
+def test_stochastic_seed_makes_the_per_call_thresholds_reproducible(O):
+    """The reference's per-call threshold comes from an unseedable thread-local generator (piquant.cpp:194-201); here the
+    context owns the generator and piquant_hip_set_stochastic_seed makes a run repeatable: same seed -> same sequence of
+    thresholds -> identical outputs call by call; each output equals the oracle for SOME threshold."""
+    import piquant
+
+    x = np.random.default_rng(2).uniform(-1, 1, 300_001).astype(np.float32)
+    outs = []
+    for _ in range(2):
+        c = piquant.Context()
+        c.set_stochastic_seed(1234)
+        outs.append([gpu_quantize(c, x, 0, 4, 0.0078431377, 127, 1) for _ in range(4)])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    assert not np.array_equal(outs[0][0], outs[0][1])          # consecutive calls draw different thresholds
+    near = O.quantize(x, 0, 4, 0.0078431377, 127).astype(np.int16)
+    for a in outs[0]:
+        d = a.astype(np.int16) - near
+        assert d.min() >= -1 and d.max() <= 1
+
+
 def test_per_element_stochastic_extension(ctx, O):
     import piquant
 
