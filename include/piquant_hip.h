@@ -90,6 +90,16 @@ PIQUANT_EXPORT void piquant_hip_dequantize_dp(piquant_context_t* ctx, const void
                                               piquant_dtype_t dtype_out, size_t numel, const piquant_hip_params_t* device_params,
                                               piquant_reduce_op_t op);
 
+/* compute_quant_params of a tensor whose shards live on several GPUs, for C / C++ hosts (one process per GPU): every
+ * rank passes its local shard and its RCCL communicator (an ncclComm_t as void*).  Local HIP scan -> {key(min), key(-max)}
+ * -> ONE ncclAllReduce(2 x int32, ncclMin) over xGMI on the context's stream -> identical double-precision epilogue on
+ * every rank.  RCCL is resolved at run time from the copy already loaded in the process (the symbol ncclAllReduce), so
+ * libpiquant.so does not link it; the call aborts with a message if no RCCL is loaded.  Synchronous like
+ * piquant_compute_quant_params_*. */
+PIQUANT_EXPORT void piquant_hip_compute_quant_params_dist(piquant_context_t* ctx, const void* local_shard, piquant_dtype_t dtype,
+                                                          size_t n_local, piquant_dtype_t target_quant_dtype, void* nccl_comm,
+                                                          float* out_scale, int64_t* out_zero_point);
+
 /* Host helpers: key <-> float, and the (min,max) -> (scale, zero_point) epilogue in double precision
  * (reference src/piquant.cpp:213-220, 245-258).  keys[0] encodes min, keys[1] encodes -max. */
 PIQUANT_EXPORT void piquant_hip_decode_minmax_keys(const int32_t keys[2], float* out_min, float* out_max);

@@ -13,6 +13,8 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -120,6 +122,7 @@ struct piquant_context_t {
     MinmaxMailboxHost* mailbox = nullptr;  // pinned fine-grained host memory the fold kernel publishes into
     void* mailbox_dev = nullptr;           // its device-visible address
     uint32_t mailbox_seq = 0;
+    int32_t* d_dist_keys = nullptr;        // {key(min), key(-max)} buffer the RCCL all-reduce of the *_dist call runs on
     hipStream_t scan_stream = nullptr;     // stream of the previous scan (re-arming relies on stream order)
 
     // device scratch for host-pointer calls, grown on demand
@@ -221,6 +224,7 @@ void piquant_context_destroy(piquant_context_t* ctx) {
             if (p) (void)hipFree(p);
         if (ctx->h_slots) (void)hipHostFree(ctx->h_slots);
         if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
+        if (ctx->d_dist_keys) (void)hipFree(ctx->d_dist_keys);
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     }
     delete ctx;
@@ -483,6 +487,57 @@ void piquant_hip_compute_quant_params_device(piquant_context_t* ctx, const void*
     // n == 0: an armed slot buffer folds to the identities, like the synchronous call
     const int32_t* slots = n == 0 ? ctx->d_slots[ctx->slot] : scan_into_slots(ctx, x, dtype, n);
     launch_params_from_slots(slots, dtype_of(target_quant_dtype).bits, rp.dev, ctx->stream);
+}
+
+// RCCL's ncclAllReduce, looked up once in whatever RCCL the process has loaded (PyTorch's bundled one, /opt/rocm's, ...).
+// Signature and enum values from <rccl/rccl.h>: ncclInt32 = 2, ncclMin = 3, ncclSuccess = 0.
+using nccl_allreduce_fn = int (*)(const void* sendbuff, void* recvbuff, size_t count, int datatype, int op, void* comm, hipStream_t stream);
+
+static nccl_allreduce_fn find_nccl_allreduce() {
+    static nccl_allreduce_fn fn = [] {
+        void* sym = dlsym(RTLD_DEFAULT, "ncclAllReduce");
+        if (!sym) {
+            for (const char* name : {"librccl.so", "librccl.so.1"}) {
+                if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+                    sym = dlsym(h, "ncclAllReduce");
+                    if (sym) break;
+                }
+            }
+        }
+        return reinterpret_cast<nccl_allreduce_fn>(sym);
+    }();
+    return fn;
+}
+
+void piquant_hip_compute_quant_params_dist(piquant_context_t* ctx, const void* local_shard, piquant_dtype_t dtype, size_t n_local,
+                                           piquant_dtype_t target_quant_dtype, void* nccl_comm, float* out_scale, int64_t* out_zero_point) {
+    if (!ctx) panic("piquant_hip_compute_quant_params_dist: context is NULL");
+    if (!nccl_comm) panic("piquant_hip_compute_quant_params_dist: NULL communicator");
+    if (!out_scale || !out_zero_point) panic("piquant_hip_compute_quant_params_dist: NULL result pointer");
+    if (dtype != PIQUANT_DTYPE_F32 && dtype != PIQUANT_DTYPE_BF16) panic("min/max scan needs f32 or bf16 input, got %s", dtype_of(dtype).name);
+    if (!dtype_of(target_quant_dtype).quant) panic("type %s is not a quantization type", dtype_of(target_quant_dtype).name);
+    if (n_local != 0 && !local_shard) panic("piquant_hip_compute_quant_params_dist: NULL input");
+    const nccl_allreduce_fn all_reduce = find_nccl_allreduce();
+    if (!all_reduce) panic("piquant_hip_compute_quant_params_dist: no RCCL (ncclAllReduce) found in this process");
+    int32_t keys[2];
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        DeviceGuard guard(ctx->device);
+        if (!ctx->d_dist_keys) PQ_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_dist_keys), 2 * sizeof(int32_t)));
+        // an empty local shard contributes the identities: fold of an armed slot buffer
+        const int32_t* slots = n_local == 0 ? ctx->d_slots[ctx->slot] : scan_into_slots(ctx, local_shard, dtype, n_local);
+        launch_fold_slots(slots, ctx->d_dist_keys, true, ctx->stream);
+        const int rc = all_reduce(ctx->d_dist_keys, ctx->d_dist_keys, 2, /*ncclInt32*/ 2, /*ncclMin*/ 3, nccl_comm, ctx->stream);
+        if (rc != 0) panic("piquant_hip_compute_quant_params_dist: ncclAllReduce failed with code %d", rc);
+        PQ_HIP(hipMemcpyAsync(ctx->h_slots, ctx->d_dist_keys, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        PQ_HIP(hipStreamSynchronize(ctx->stream));
+        keys[0] = ctx->h_slots[0];
+        keys[1] = ctx->h_slots[1];
+    }
+    float lo, hi;
+    piquant_hip_decode_minmax_keys(keys, &lo, &hi);
+    piquant_hip_quant_params_from_minmax(lo, hi, target_quant_dtype, out_scale, out_zero_point);
+    if (std::isnan(*out_scale) || !(*out_scale >= 0.0f)) panic("compute_quant_params: scale must be positive (got %g)", static_cast<double>(*out_scale));
 }
 
 void piquant_hip_decode_minmax_keys(const int32_t keys[2], float* out_min, float* out_max) {

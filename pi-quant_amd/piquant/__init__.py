@@ -201,6 +201,16 @@ class Context:
         self.assume_device_pointers(_device_ptrs)
         C.piquant_hip_dequantize_dp(self._ctx, ptr_in, dtype_in.value, ptr_out, dtype_out.value, numel, params_ptr, reduce_op.value)
 
+    def compute_quant_params_dist_ptr(self, ptr: int, dtype: DataType, numel: int, target_quant_dtype: DataType, nccl_comm: int,
+                                      _device_ptrs: bool = False) -> Tuple[float, int]:
+        """Sharded ``compute_quant_params`` with the all-reduce done natively: ``nccl_comm`` is an ``ncclComm_t`` (RCCL)."""
+        assert dtype.is_dequantized and target_quant_dtype.is_quantized and nccl_comm
+        scale, zero_point = _C.c_float(), _C.c_int64()
+        self.assume_device_pointers(_device_ptrs)
+        C.piquant_hip_compute_quant_params_dist(self._ctx, ptr, dtype.value, numel, target_quant_dtype.value, nccl_comm, _C.byref(scale),
+                                                _C.byref(zero_point))
+        return scale.value, zero_point.value
+
     def minmax_keys_ptr(self, ptr: int, dtype: DataType, numel: int, device_keys_ptr: int, init: bool = True, _device_ptrs: bool = False) -> None:
         """Asynchronously fold {min, -max} of the buffer into two int32 keys in device memory (atomic MIN)."""
         assert dtype.is_dequantized

@@ -36,6 +36,7 @@ _DECLS = [
     ('piquant_hip_compute_quant_params_device', None, [_vp, _vp, _int, _sz, _int, _vp]),
     ('piquant_hip_quantize_dp', None, [_vp, _vp, _int, _vp, _int, _sz, _vp, _int]),
     ('piquant_hip_dequantize_dp', None, [_vp, _vp, _int, _vp, _int, _sz, _vp, _int]),
+    ('piquant_hip_compute_quant_params_dist', None, [_vp, _vp, _int, _sz, _int, _vp, C.POINTER(_f32), C.POINTER(_i64)]),
     ('piquant_hip_minmax_keys', None, [_vp, _vp, _int, _sz, _vp, _int]),
     ('piquant_hip_decode_minmax_keys', None, [C.POINTER(C.c_int32), C.POINTER(_f32), C.POINTER(_f32)]),
     ('piquant_hip_quant_params_from_minmax', None, [_f32, _f32, _int, C.POINTER(_f32), C.POINTER(_i64)]),

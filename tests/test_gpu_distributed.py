@@ -112,3 +112,37 @@ def test_quantized_ring_all_reduce_with_hip_kernels(oracle_mod, world, numel, qn
         assert np.array_equal(results[r], want[r]), r
     exact = np.sum(xs, axis=0)
     assert np.abs(results[0] - exact).max() <= world * (2.0 * world / ((1 << bits) - 1)) * 0.5 + 1e-5
+
+
+def test_native_rccl_all_reduce_entry_point(oracle_mod):
+    """piquant_hip_compute_quant_params_dist: the C-level sharded call that runs ncclAllReduce itself (RCCL resolved from the
+    copy already loaded in the process).  One rank here -- the box has one GPU -- which still drives the whole path: scan,
+    fold, ncclAllReduce(2 x int32, ncclMin) on the context's stream, epilogue."""
+    import ctypes
+
+    import piquant
+
+    O = oracle_mod
+    rccl = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+
+    rccl.ncclGetUniqueId.argtypes = [ctypes.POINTER(UniqueId)]
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    torch.cuda.set_device(0)
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    try:
+        ctx = piquant.Context()
+        for n in (1, 1000, 3_000_001):
+            x = np.random.default_rng(n).normal(size=n).astype(np.float32)
+            xd = torch.from_numpy(x).cuda()
+            for dt, odt in ((piquant.DataType.UINT8, O.UINT8), (piquant.DataType.UINT4, O.UINT4)):
+                got = ctx.compute_quant_params_dist_ptr(xd.data_ptr(), piquant.DataType.F32, n, dt, comm.value)
+                assert got == O.compute_quant_params(x, O.F32, odt), (n, dt)
+    finally:
+        rccl.ncclCommDestroy(comm)
