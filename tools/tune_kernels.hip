@@ -153,6 +153,7 @@ static int g_reps = 200;
 
 static int g_rounds = 3;
 static std::vector<int> g_caps = {0, 2, 4, 8, 16};
+static unsigned g_dyn_lds = 0;   // extra dynamic LDS per block: an occupancy throttle for experiments
 static double g_last_max = 0;
 
 // best (minimum) of g_rounds timed batches; the slowest batch is kept in g_last_max as a noise indicator
@@ -204,12 +205,12 @@ static void run_quant(const Bufs& b, int64_t numel, int num_cu, double bytes_per
         int64_t g = cap == 0 ? n_tiles : std::min<int64_t>(n_tiles, static_cast<int64_t>(cap) * num_cu);
         const unsigned grid = static_cast<unsigned>(std::max<int64_t>(g, 1));
         const double us = time_us([&](int i) {
-            hipLaunchKernelGGL((quantize_kernel<DT_IN, BITS, MODE, U, STAGE, NT, BLOCK, PF>), dim3(grid), dim3(BLOCK), 0, g_stream, b.in[i % SETS],
+            hipLaunchKernelGGL((quantize_kernel<DT_IN, BITS, MODE, U, STAGE, NT, BLOCK, PF>), dim3(grid), dim3(BLOCK), g_dyn_lds, g_stream, b.in[i % SETS],
                                static_cast<uint8_t*>(b.out[i % SETS]), numel, n_tiles, p);
         });
         char name[160];
-        std::snprintf(name, sizeof name, "in=%s bits=%d mode=%d U=%d stage=%d nt=%d block=%d pf=%d cap=%d grid=%u", DT_IN == DT_F32 ? "f32" : "bf16", BITS, MODE, U,
-                      STAGE ? 1 : 0, NT, BLOCK, PF ? 1 : 0, cap, grid);
+        std::snprintf(name, sizeof name, "in=%s bits=%d mode=%d U=%d stage=%d nt=%d block=%d pf=%d lds=%u cap=%d grid=%u", DT_IN == DT_F32 ? "f32" : "bf16", BITS, MODE, U,
+                      STAGE ? 1 : 0, NT, BLOCK, PF ? 1 : 0, g_dyn_lds, cap, grid);
         report("quantize", name, us, bytes_per_elem * numel);
     }
 }
@@ -365,6 +366,22 @@ int main(int argc, char** argv) {
             });
             report("policy", "asm ld=nt st=sc0sc1 U=4 block=256", us, 5.0 * numel);
         }
+        g_caps = {0, 2, 4, 8, 16};
+        g_rounds = 3;
+    }
+    if (only == "occ") {
+        // occupancy throttle: dynamic LDS per block limits resident blocks per CU (160 KiB / request)
+        g_rounds = 1;
+        g_caps = {0};
+        for (int pass = 0; pass < 4; ++pass) {
+            for (unsigned lds : {0u, 9000u, 12000u, 19000u, 26000u, 39000u, 52000u, 79000u}) {
+                g_dyn_lds = lds;
+                run_quant<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 128>(b, numel, num_cu, 5);
+                run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, 5, 128>(b, numel, num_cu, 5);
+                run_quant<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 64>(b, numel, num_cu, 5);
+            }
+        }
+        g_dyn_lds = 0;
         g_caps = {0, 2, 4, 8, 16};
         g_rounds = 3;
     }
