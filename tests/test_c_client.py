@@ -26,6 +26,18 @@ def test_headers_are_valid_c99_and_client_links(tmp_path):
     assert _build(tmp_path).exists()
 
 
+def _build_cpp(tmp_path):
+    exe = tmp_path / "cpp_api_client"
+    subprocess.run(["g++", "-std=c++20", "-Wall", "-Wextra", "-O2", f"-I{ROOT / 'include'}", str(ROOT / "tests" / "cpp_api_client.cpp"), f"-L{LIBDIR}",
+                    "-lpiquant", f"-Wl,-rpath,{LIBDIR}", "-o", str(exe)], check=True)
+    return exe
+
+
+def test_cpp_header_compiles_and_links(tmp_path):
+    """include/piquant.hpp: the reference's C++ spellings (piquant::context, spans, *_generic) as inline forwards to the C ABI."""
+    assert _build_cpp(tmp_path).exists()
+
+
 def _fnv1a(b: bytes) -> int:
     h = 1469598103934665603
     for chunk in np.frombuffer(b, dtype=np.uint8).tolist():
@@ -34,10 +46,12 @@ def _fnv1a(b: bytes) -> int:
 
 
 @pytest.mark.gpu
-def test_c_client_results_match_oracle(tmp_path, oracle_mod):
+@pytest.mark.parametrize("client", ["c99", "cpp20"])
+def test_c_client_results_match_oracle(tmp_path, oracle_mod, client):
     O = oracle_mod
     n = 100_003
-    out = subprocess.run([str(_build(tmp_path)), str(n)], check=True, capture_output=True, text=True, timeout=300).stdout.split()
+    exe = _build(tmp_path) if client == "c99" else _build_cpp(tmp_path)
+    out = subprocess.run([str(exe), str(n)], check=True, capture_output=True, text=True, timeout=300).stdout.split()
     s = np.uint32(12345)
     x = np.empty(n, dtype=np.float32)
     with np.errstate(over="ignore"):
