@@ -126,6 +126,45 @@ def test_dequantize_random(ctx, O, dt_q, dt_f, op):
             assert same_floats(got, want), (n, scale, zp)
 
 
+def _fuzz_values(rng, n):
+    """floats over the whole exponent range plus specials: denormals, +-0, +-inf, NaN, integers, half-way cases"""
+    bits = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    x = bits.view(np.float32).copy()
+    k = max(1, n // 8)
+    x[rng.choice(n, k)] = rng.integers(-300, 300, k).astype(np.float32) + np.float32(0.5)
+    x[rng.choice(n, k)] = rng.uniform(-4, 4, k).astype(np.float32)
+    x[rng.choice(n, min(n, 6))] = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45], np.float32)[: min(n, 6)]
+    return x
+
+
+def test_fuzz_all_pairs_over_the_whole_float_range(ctx, O):
+    """300 random configurations: any fp32 bit pattern as input, scales from 1e-30 to 1e30, zero points from the whole
+    int64 range, every dtype pair / rounding mode / store op, ragged sizes -- the HIP result must equal the oracle bit for bit."""
+    rng = np.random.default_rng(2025)
+    for it in range(300):
+        n = int(rng.integers(1, 20_000))
+        x = _fuzz_values(rng, n)
+        scale = float(np.float32(10.0 ** rng.uniform(-30, 30)))
+        zp = int(rng.integers(-2**63, 2**63 - 1)) if it % 3 == 0 else int(rng.integers(-300, 300))
+        dt_f = int(rng.integers(0, 2))
+        dt_q = int(rng.integers(2, 5))
+        xin = x if dt_f == 0 else O.f32_to_bf16(x)
+        rm = int(rng.integers(0, 2))
+        tau = float(rng.uniform(0, 1)) if rm else 0.0
+        ctx.set_stochastic_threshold(tau if rm else None)
+        got = gpu_quantize(ctx, xin, dt_f, dt_q, scale, zp, rm)
+        want = O.quantize(xin, dt_f, dt_q, scale, zp, rm, tau)
+        assert np.array_equal(got, want), ("quantize", it, n, scale, zp, dt_f, dt_q, rm, np.nonzero(got != want)[0][:4])
+        op = int(rng.integers(0, 2))
+        q = rng.integers(0, 256, O.packed_numel(n, dt_q)).astype(np.uint8)
+        prev = _fuzz_values(rng, n) if it % 2 else rng.uniform(-5, 5, n).astype(np.float32)
+        prev = prev if dt_f == 0 else O.f32_to_bf16(prev)
+        got = gpu_dequantize(ctx, q, dt_q, dt_f, n, scale, zp, op, prev=prev)
+        want = O.dequantize(q, dt_q, dt_f, n, scale, zp, op, out=prev.copy())
+        assert same_floats(got, want), ("dequantize", it, n, scale, zp, dt_q, dt_f, op)
+    ctx.set_stochastic_threshold(None)
+
+
 def test_extreme_zero_points_wrap_like_the_reference(ctx, O):
     """int64 zero points are narrowed to int32 on the fast paths and kept on the generic ones (quantize.inl:111 vs :15)."""
     rng = np.random.default_rng(5)

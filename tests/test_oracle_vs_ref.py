@@ -59,6 +59,34 @@ def test_dequantize_all_pairs(both):
                         assert np.array_equal(a, b), (dt_q, dt_f, op, n, scale, zp)
 
 
+def test_fuzz_whole_float_range_against_reference_kernels(both):
+    """Any fp32 bit pattern, scales 1e-30..1e30, zero points over the whole int64 range, every pair/mode/op, ragged sizes:
+    oracle (FORM_REFERENCE) == reference kernels."""
+    O, R = both
+    isa = O.Ref.AVX512F
+    if not R.supported(isa):
+        pytest.skip("CPU lacks avx512f")
+    rng = np.random.default_rng(77)
+    for it in range(400):
+        n = int(rng.integers(1, 3000))
+        x = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32).view(np.float32).copy()
+        x[rng.choice(n, max(1, n // 6))] = (rng.integers(-300, 300, max(1, n // 6)) + 0.5).astype(np.float32)
+        scale = float(np.float32(10.0 ** rng.uniform(-30, 30)))
+        zp = int(rng.integers(-2**63, 2**63 - 1)) if it % 3 == 0 else int(rng.integers(-300, 300))
+        dt_f, dt_q, rm, op = int(rng.integers(0, 2)), int(rng.integers(2, 5)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        xin = x if dt_f == 0 else O.f32_to_bf16(x)
+        tau = float(rng.uniform(0, 1)) if rm else 0.0
+        a = O.quantize(xin, dt_f, dt_q, scale, zp, rm, tau, form=O.FORM_REFERENCE)
+        b = R.quantize(xin, dt_f, dt_q, scale, zp, rm, tau, isa=isa)
+        assert np.array_equal(a, b), ("quantize", it, n, scale, zp, dt_f, dt_q, rm)
+        q = rng.integers(0, 256, O.packed_numel(n, dt_q)).astype(np.uint8)
+        prev = rng.uniform(-5, 5, n).astype(np.float32)
+        prev = prev if dt_f == 0 else O.f32_to_bf16(prev)
+        a = O.dequantize(q, dt_q, dt_f, n, scale, zp, op, form=O.FORM_REFERENCE, out=prev.copy())
+        b = R.dequantize(q, dt_q, dt_f, n, scale, zp, op, isa=isa, out=prev.copy())
+        assert same(a, b), ("dequantize", it, n, scale, zp, dt_q, dt_f, op)
+
+
 def test_requantize_all_pairs(both):
     """fused quantize->dequantize: every float type x quantized type x rounding x store op (24 combinations,
     reference kernels.inl:139-149), generic and AVX-512 units."""
