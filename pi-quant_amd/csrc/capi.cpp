@@ -118,6 +118,7 @@ struct piquant_context_t {
     // Invariant: d_slots[slot] is armed (all identity) whenever no scan is in flight.
     int32_t* d_slots[2] = {nullptr, nullptr};
     int slot = 0;
+    int32_t* d_slots_capture = nullptr;    // slot buffer of scans recorded into a hipGraph (armed by a node of the graph itself)
     int32_t* h_slots = nullptr;            // pinned mirror of the buffer just scanned (fallback path)
     MinmaxMailboxHost* mailbox = nullptr;  // pinned fine-grained host memory the fold kernel publishes into
     void* mailbox_dev = nullptr;           // its device-visible address
@@ -194,6 +195,7 @@ piquant_context_t* piquant_context_create(size_t num_threads) {
         PQ_HIP(hipMalloc(reinterpret_cast<void**>(&p), slot_bytes));
         PQ_HIP(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p), float_to_key(std::numeric_limits<float>::max()), minmax_slot_ints()));
     }
+    PQ_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_slots_capture), slot_bytes));
     PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_slots), slot_bytes, hipHostMallocDefault));
     if (hipHostMalloc(reinterpret_cast<void**>(&ctx->mailbox), sizeof(MinmaxMailboxHost), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
         hipHostGetDevicePointer(&ctx->mailbox_dev, ctx->mailbox, 0) == hipSuccess) {
@@ -222,6 +224,7 @@ void piquant_context_destroy(piquant_context_t* ctx) {
             if (p) (void)hipFree(p);
         for (auto& p : ctx->d_slots)
             if (p) (void)hipFree(p);
+        if (ctx->d_slots_capture) (void)hipFree(ctx->d_slots_capture);
         if (ctx->h_slots) (void)hipHostFree(ctx->h_slots);
         if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
         if (ctx->d_dist_keys) (void)hipFree(ctx->d_dist_keys);
@@ -432,6 +435,21 @@ void piquant_hip_quantize_dequantize(piquant_context_t* ctx, const void* in, piq
 // Scans x into the context's armed slot buffer (re-arming the idle one for the next call) and returns the buffer
 // that now holds the per-slot {key(min), key(-max)} pairs.  Caller holds ctx->mu and the device guard.
 static int32_t* scan_into_slots(piquant_context_t* ctx, const void* x, piquant_dtype_t dtype, size_t n) {
+    // A scan recorded into a hipGraph is replayed many times with the pointers it was recorded with, so it cannot take part
+    // in the alternating re-arm scheme below (its slot buffer would still hold the previous replay's extremes): a captured
+    // scan uses a buffer of its own and the graph starts with a node that arms it.
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx->stream, &capture) != hipSuccess) {
+        (void)hipGetLastError();
+        capture = hipStreamCaptureStatusNone;
+    }
+    if (capture == hipStreamCaptureStatusActive) {
+        const Resolved rc = ctx->resolve_ptr(x);
+        if (rc.pageable) panic("a min/max scan of host memory cannot be captured into a hipGraph (it needs staging copies and synchronisation)");
+        launch_arm_slots(ctx->d_slots_capture, ctx->stream);
+        launch_minmax(rc.dev, dtype, static_cast<int64_t>(n), ctx->d_slots_capture, nullptr, ctx->stream, ctx->num_cu);
+        return ctx->d_slots_capture;
+    }
     // the previous scan re-armed this call's buffer in ITS stream: keep that ordering if the stream changed
     if (ctx->scan_stream && ctx->scan_stream != ctx->stream) PQ_HIP(hipStreamSynchronize(ctx->scan_stream));
     int32_t* cur = ctx->d_slots[ctx->slot];

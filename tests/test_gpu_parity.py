@@ -590,8 +590,8 @@ def test_dynamic_pipeline_equals_the_two_step_path_and_is_graph_capturable(O):
         with torch.cuda.graph(g, stream=s):
             piquant.torch.quantize_dynamic(x, dtype=torch.uint8, ctx=c, out=q, params=rec)
             piquant.torch.dequantize_dynamic(q, rec, dtype=torch.float32, ctx=c, out=y)
-    for k in range(3):
-        data = (rng.normal(size=n) * (k + 1)).astype(np.float32)
+    for k in (3.0, 0.25, 1.0, 0.5):     # the range shrinks and grows between replays: a replay must not see the previous one's extremes
+        data = (rng.normal(size=n) * k).astype(np.float32)
         x.copy_(torch.from_numpy(data))
         g.replay()
         torch.cuda.synchronize()
