@@ -43,7 +43,9 @@ PIQUANT_EXPORT void piquant_hip_assume_device_pointers(piquant_context_t* ctx, i
  *   piquant_hip_set_stochastic_seed(ctx, seed): reseeds the context's generator.
  *   piquant_hip_set_stochastic_per_element(ctx, on, seed, index_base): opt-in extension -- an independent
  *       threshold per element from a counter hash of (seed, index_base + element index); shard-invariant
- *       when each shard passes its global element offset as index_base. */
+ *       when each shard passes its global element offset as index_base.
+ * Under hipGraph capture the threshold (or seed / index_base) drawn at capture time is part of the recorded launch and is
+ * replayed unchanged. */
 PIQUANT_EXPORT void piquant_hip_set_stochastic_threshold(piquant_context_t* ctx, float threshold);
 PIQUANT_EXPORT void piquant_hip_set_stochastic_seed(piquant_context_t* ctx, uint64_t seed);
 PIQUANT_EXPORT void piquant_hip_set_stochastic_per_element(piquant_context_t* ctx, int enabled, uint64_t seed,
