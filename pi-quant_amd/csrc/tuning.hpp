@@ -18,16 +18,18 @@ constexpr int kStream = 1 | (2 << 1);
 // quantize, indexed [dt_in: f32,bf16][bits: 8,4,2].
 // Interleaved A/B sweeps on MI355X (profiles/r01_tune_finals_*.csv, numel 27 264 000, one tile per block): small
 // tiles win -- one or two waves per block with two vectors in flight per lane (fp32->uint8: 21.55 us against 22.2 us
-// for 256-thread/U=4 blocks and 22.0 us for 1024-thread blocks); persistent grids and software prefetch lose.
+// for 256-thread/U=4 blocks and 22.0 us for 1024-thread blocks); persistent grids and software prefetch lose.  The bf16
+// entries were chosen to be near-best at both 27 264 000 elements (BASELINE config 3) and twice that
+// (profiles/r01_tune_finals_other*.csv).
 constexpr KernelTune kQuantTune[2][3] = {
     {{2, true, kStream, 128, 0}, {2, true, kStream, 64, 0}, {2, true, kStream, 64, 0}},
-    {{2, true, kStream, 64, 0}, {4, true, kStream, 64, 0}, {4, true, kStream, 64, 0}},
+    {{2, true, kStream, 64, 0}, {2, true, kStream, 64, 0}, {4, true, kStream, 256, 0}},
 };
 
 // dequantize, indexed [dt_out: f32,bf16][bits: 8,4,2]
 constexpr KernelTune kDequantTune[2][3] = {
     {{2, true, kStream, 128, 0}, {4, true, kStream, 256, 0}, {4, true, kStream, 256, 0}},
-    {{4, true, kStream, 128, 0}, {2, true, kStream, 128, 0}, {2, true, kStream, 128, 0}},
+    {{4, true, kStream, 128, 0}, {2, true, kStream, 64, 0}, {2, true, kStream, 128, 0}},
 };
 
 // fused quantize->dequantize: plain 16-byte streams both ways, no LDS staging
