@@ -100,6 +100,29 @@ __device__ __forceinline__ uint32_t clamp_i64(int64_t v, int32_t qmax) {
     return static_cast<uint32_t>(v < 0 ? 0 : (v > qmax ? qmax : v));
 }
 
+// The reference's generic steps do their integer arithmetic in int64 (quantize.inl:15,24, dequantize.inl:10).  gfx950 has no
+// 64-bit integer VALU, so int64 add/compare/convert cost several instructions each; whenever the zero point (wave-uniform)
+// and the rounded value are both below 2^30 in magnitude the same integers are obtained in int32 -- the sum cannot overflow
+// and the conversions are exact -- and the int64 path only runs for lanes with out-of-range values (skipped wave-uniformly
+// on ordinary data).
+__device__ __forceinline__ bool zp_fits_i32_path(int64_t zp64) { return zp64 >= -(int64_t{1} << 30) && zp64 <= (int64_t{1} << 30); }
+
+template <int QMAX>
+__device__ __forceinline__ uint32_t add_zp_clamp_i64(float r, int64_t zp64) {   // r is integral-valued (or NaN/inf)
+    if (zp_fits_i32_path(zp64) && __builtin_fabsf(r) < 1073741824.0f) {
+        const int32_t v = static_cast<int32_t>(r) + static_cast<int32_t>(zp64);
+        return static_cast<uint32_t>(min(max(v, 0), QMAX));
+    }
+    const int64_t v = static_cast<int64_t>(static_cast<uint64_t>(cvtt_i64_x86(r)) + static_cast<uint64_t>(zp64));
+    return clamp_i64(v, QMAX);
+}
+
+// float(int64(q) - zp64), q < 256
+__device__ __forceinline__ float sub_zp_to_float_i64(uint32_t q, int64_t zp64) {
+    if (zp_fits_i32_path(zp64)) return static_cast<float>(static_cast<int32_t>(q) - static_cast<int32_t>(zp64));
+    return static_cast<float>(static_cast<int64_t>(static_cast<uint64_t>(q) - static_cast<uint64_t>(zp64)));
+}
+
 // kernels_specialized.inl:62-77 (and the same shape at :207-222, :347-361, :514-528, :682-693).
 // The reference's blend `p >= 0 ? 0.5 : -0.5` is written as copysign(0.5, p) (one v_bfi_b32): it differs from the blend
 // only for p == -0.0 (gives -0.5 -> trunc -> 0, the same integer as +0.5 -> 0) and for NaN (sum is NaN either way).
@@ -136,8 +159,7 @@ __device__ __forceinline__ void quant_nearest_fast2(float x0, float x1, const Qu
 template <int QMAX>
 __device__ __forceinline__ uint32_t quant_nearest_i64(float x, const QuantParams& p) {
     const float r = roundf(__fmul_rn(x, p.inv_scale));
-    const int64_t v = static_cast<int64_t>(static_cast<uint64_t>(cvtt_i64_x86(r)) + static_cast<uint64_t>(p.zp64));
-    return clamp_i64(v, QMAX);
+    return add_zp_clamp_i64<QMAX>(r, p.zp64);
 }
 
 // quantize.inl:8-19
@@ -149,8 +171,7 @@ __device__ __forceinline__ uint32_t quant_stochastic(float x, const QuantParams&
     float adj = threshold < dec ? 1.0f : 0.0f;
     if (r < 0.0f) adj = -adj;
     const float s = __fadd_rn(tr, adj);
-    const int64_t v = static_cast<int64_t>(static_cast<uint64_t>(cvtt_i64_x86(s)) + static_cast<uint64_t>(p.zp64));
-    return clamp_i64(v, QMAX);
+    return add_zp_clamp_i64<QMAX>(s, p.zp64);
 }
 
 // Counter hash for RM_STOCH_ELEM (extension; restated in oracle/piquant_oracle.c orc_element_threshold).
@@ -212,8 +233,7 @@ __device__ __forceinline__ float dequant_one(uint32_t q, const DequantParams& p)
     } else if constexpr (FORM == DQ_FMA) {
         return __fmaf_rn(static_cast<float>(q), p.scale, p.bias);
     } else {
-        const int64_t d = static_cast<int64_t>(static_cast<uint64_t>(q) - static_cast<uint64_t>(p.zp64));
-        return __fmul_rn(static_cast<float>(d), p.scale);
+        return __fmul_rn(sub_zp_to_float_i64(q, p.zp64), p.scale);
     }
 }
 

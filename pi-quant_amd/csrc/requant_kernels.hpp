@@ -28,11 +28,11 @@ __device__ __forceinline__ void requant_vec(const u32x4& raw, const u32x4& old, 
 #pragma unroll
     for (int e = 0; e < EPV; ++e) {
         const uint32_t q = quant_one<MODE, QMAX>(v[e], qp, e0 + e);
-        const int64_t d = static_cast<int64_t>(static_cast<uint64_t>(q) - static_cast<uint64_t>(dp.zp64));
+        const float d = sub_zp_to_float_i64(q, dp.zp64);
         if constexpr (DT == DT_F32) {
-            r[e] = __fmul_rn(static_cast<float>(d), dp.scale);
+            r[e] = __fmul_rn(d, dp.scale);
         } else {
-            const float a = bf16_bits_to_f32(f32_to_bf16_bits(static_cast<float>(d)));
+            const float a = bf16_bits_to_f32(f32_to_bf16_bits(d));
             r[e] = bf16_bits_to_f32(f32_to_bf16_bits(__fmul_rn(a, scale_bf16)));
         }
     }
@@ -59,14 +59,14 @@ __device__ __forceinline__ void requant_scalar(const void* in, void* out, int64_
                                                float scale_bf16) {
     constexpr int QMAX = (1 << BITS) - 1;
     const uint32_t q = quant_one<MODE, QMAX>(InVec<DT>::load_scalar(in, i), qp, static_cast<uint64_t>(i));
-    const int64_t d = static_cast<int64_t>(static_cast<uint64_t>(q) - static_cast<uint64_t>(dp.zp64));
+    const float d = sub_zp_to_float_i64(q, dp.zp64);
     if constexpr (DT == DT_F32) {
         float* o = static_cast<float*>(out);
-        const float r = __fmul_rn(static_cast<float>(d), dp.scale);
+        const float r = __fmul_rn(d, dp.scale);
         o[i] = OP == OP_ADD ? __fadd_rn(o[i], r) : r;
     } else {
         uint16_t* o = static_cast<uint16_t*>(out);
-        const float a = bf16_bits_to_f32(f32_to_bf16_bits(static_cast<float>(d)));
+        const float a = bf16_bits_to_f32(f32_to_bf16_bits(d));
         const uint32_t r = f32_to_bf16_bits(__fmul_rn(a, scale_bf16));
         o[i] = static_cast<uint16_t>(OP == OP_ADD ? f32_to_bf16_bits(__fadd_rn(bf16_bits_to_f32(o[i]), bf16_bits_to_f32(r))) : r);
     }

@@ -33,7 +33,7 @@ constexpr KernelTune kDequantTune[2][3] = {
 };
 
 // fused quantize->dequantize: plain 16-byte streams both ways, no LDS staging
-constexpr KernelTune kRequantTune = {4, false, kStream, 256, 0};
+constexpr KernelTune kRequantTune = {2, false, kStream, 64, 0};   // profiles/r01_tune_requant.csv
 
 // min/max scan: few, long-lived blocks -- the end-of-block atomics serialise (~11 ns each), the read stream
 // itself saturates from 2 blocks per CU (18.0 us at numel 27 264 000 = 6.07 TB/s).
