@@ -51,6 +51,19 @@ PIQUANT_EXPORT void piquant_hip_set_stochastic_seed(piquant_context_t* ctx, uint
 PIQUANT_EXPORT void piquant_hip_set_stochastic_per_element(piquant_context_t* ctx, int enabled, uint64_t seed,
                                                            uint64_t index_base);
 
+/* Reference-layout mode (off by default).  The kernels apply ONE formula to every element -- the one of the reference's
+ * AVX-512 SIMD body -- which makes results independent of pointer alignment, length and sharding.  The reference's own
+ * output also depends on WHERE an element sits: its scalar head (fp32 -> uint8 only: elements before the output pointer
+ * is 16-byte aligned, kernels_specialized.inl:52) and scalar tails (the last numel mod 64 / 16 elements when quantizing,
+ * mod 64 / 128 / 256 when dequantizing to bf16) use std::round and a second bf16 rounding, which differ from the body on
+ * a few corner inputs (|x/scale| = 0.49999997, odd |x/scale| >= 2^23, bf16 ADD ties), and the
+ * 1-3 element tail of uint2 -> f32 ADD stores instead of adding (dequantize.inl:72-86).  With this mode on, those
+ * positions use the reference's scalar formulas, so every output byte equals what the reference's AVX-512 build writes
+ * from a context with ONE pool thread (with T threads the reference's positions depend on its partition; not modelled).
+ * Costs nothing on aligned bulk data (only the guarded tail path looks at it); a non-zero head sends the whole fp32 ->
+ * uint8 call through the guarded (slower) kernel.  For golden-file regression against reference output, not production. */
+PIQUANT_EXPORT void piquant_hip_set_reference_layout(piquant_context_t* ctx, int enabled);
+
 /* Fused quantize -> dequantize: out[i] (op)= dequantize(quantize(in[i])) without materialising the quantized tensor;
  * dtype_in_out (F32 or BF16) is the type of BOTH buffers, quant_dtype (UINT2/4/8) the type passed through; `out` may
  * alias `in`.  This is the reference's C++-only context::quantize_dequantize_fused (include/piquant.hpp:276-285,

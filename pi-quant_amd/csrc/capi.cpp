@@ -134,6 +134,7 @@ struct piquant_context_t {
     std::mt19937_64 rng;
     float fixed_threshold = -1.0f;
     bool per_element = false;
+    bool reference_layout = false;
     uint64_t elem_seed = 0, elem_base = 0;
     std::mutex mu;
 
@@ -263,6 +264,13 @@ static void quantize_impl(piquant_context_t* ctx, const void* in, piquant_dtype_
         q.threshold = draw_threshold(ctx);              // one threshold per call (src/piquant.cpp:197-201)
     }
 
+    if (ctx->reference_layout) {
+        q.ref_layout = true;
+        q.ref_total = static_cast<int64_t>(numel);
+        // kernels_specialized.inl:52: fp32 -> uint8 peels scalar elements until the OUTPUT pointer (as the caller passed it) is 16-byte aligned
+        if (dtype_in == PIQUANT_DTYPE_F32 && dtype_out == PIQUANT_DTYPE_UINT8 && mode == PIQUANT_NEAREST)
+            q.ref_head = static_cast<int>(std::min<size_t>(numel, (16u - (reinterpret_cast<uintptr_t>(out) & 15u)) & 15u));
+    }
     const Resolved rin = ctx->resolve_ptr(in), rout = ctx->resolve_ptr(out);
     if (dyn_params) {
         const Resolved rp = resolve(dyn_params);
@@ -295,6 +303,7 @@ static void quantize_impl(piquant_context_t* ctx, const void* in, piquant_dtype_
         q.out = rout.pageable ? ctx->stage_out[slot] : static_cast<void*>(static_cast<char*>(rout.dev) + out_off);
         q.numel = static_cast<int64_t>(n);
         q.index_base = base0 + off;
+        q.ref_index0 = static_cast<int64_t>(off);
         launch_quantize(q, s, ctx->num_cu);
         if (rout.pageable)
             PQ_HIP(hipMemcpyAsync(static_cast<char*>(out) + out_off, ctx->stage_out[slot], span_bytes(n, dtype_out), hipMemcpyDeviceToHost, s));
@@ -337,6 +346,8 @@ static void dequantize_impl(piquant_context_t* ctx, const void* in, piquant_dtyp
     // fp32 product on the host exactly as the reference forms it (kernels_specialized.inl:1204,1325)
     d.bias = -static_cast<float>(static_cast<int32_t>(static_cast<uint32_t>(static_cast<uint64_t>(zero_point)))) * scale;
 
+    d.ref_layout = ctx->reference_layout;
+    d.ref_total = static_cast<int64_t>(numel);
     const Resolved rin = ctx->resolve_ptr(in), rout = ctx->resolve_ptr(out);
     if (dyn_params) {
         const Resolved rp = resolve(dyn_params);
@@ -370,6 +381,7 @@ static void dequantize_impl(piquant_context_t* ctx, const void* in, piquant_dtyp
             d.out = ctx->stage_out[slot];
         } else d.out = static_cast<char*>(rout.dev) + out_off;
         d.numel = static_cast<int64_t>(n);
+        d.ref_index0 = static_cast<int64_t>(off);
         launch_dequantize(d, s, ctx->num_cu);
         if (rout.pageable)
             PQ_HIP(hipMemcpyAsync(static_cast<char*>(out) + out_off, ctx->stage_out[slot], span_bytes(n, dtype_out), hipMemcpyDeviceToHost, s));
@@ -677,6 +689,12 @@ void piquant_hip_set_stochastic_seed(piquant_context_t* ctx, uint64_t seed) {
     if (!ctx) panic("piquant_hip_set_stochastic_seed: context is NULL");
     std::lock_guard<std::mutex> lock(ctx->mu);
     ctx->rng.seed(seed);
+}
+
+void piquant_hip_set_reference_layout(piquant_context_t* ctx, int enabled) {
+    if (!ctx) panic("piquant_hip_set_reference_layout: context is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->reference_layout = enabled != 0;
 }
 
 void piquant_hip_set_stochastic_per_element(piquant_context_t* ctx, int enabled, uint64_t seed, uint64_t index_base) {

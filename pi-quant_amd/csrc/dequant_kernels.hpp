@@ -25,6 +25,30 @@ __device__ __forceinline__ void dequant_store_scalar(const uint8_t* in, void* ou
     constexpr int PACK = 8 / BITS;
     constexpr int FORM = DequantForm<BITS, DT_OUT>::value;
     const uint32_t q = (in[i / PACK] >> ((i % PACK) * BITS)) & ((1u << BITS) - 1u);
+    if (p.ref_layout) {
+        // Reference-layout mode: element g of the call sits in the reference's scalar tail when it is past the last whole
+        // SIMD block (64 / 128 / 256 elements for uint8 / uint4 / uint2->bf16; groups of 4 for the generic uint2->f32).
+        const int64_t g = p.ref_index0 + i;
+        constexpr int64_t BLK = BITS == 8 ? 64 : (BITS == 4 ? 128 : (DT_OUT == DT_BF16 ? 256 : 4));
+        if (g >= (p.ref_total / BLK) * BLK) {
+            if constexpr (DT_OUT == DT_F32) {
+                if constexpr (BITS == 2) {   // dequantize.inl:72-86: the 1-3 element tail always stores, ADD is ignored
+                    static_cast<float*>(out)[i] = dequant_one<FORM>(q, p);
+                    return;
+                }
+            } else {
+                // kernels_specialized.inl:977-981, 1290-1303, 1388-1415: (q - zp) * scale, rounded to bf16; ADD goes through
+                // bfp16_t::operator+= (include/piquant.hpp:97-103) and rounds a second time
+                float dq;
+                if constexpr (BITS == 2) dq = __fmul_rn(__fsub_rn(static_cast<float>(q), static_cast<float>(p.zp32)), p.scale);
+                else dq = dequant_one<DQ_SUBMUL>(q, p);
+                uint16_t* o = static_cast<uint16_t*>(out);
+                const uint32_t d16 = f32_to_bf16_bits(dq);
+                o[i] = static_cast<uint16_t>(OP == OP_ADD ? f32_to_bf16_bits(__fadd_rn(bf16_bits_to_f32(o[i]), bf16_bits_to_f32(d16))) : d16);
+                return;
+            }
+        }
+    }
     float f = dequant_one<FORM>(q, p);
     if constexpr (DT_OUT == DT_F32) {
         float* o = static_cast<float*>(out);

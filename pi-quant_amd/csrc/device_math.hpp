@@ -38,6 +38,13 @@ struct QuantParams {
     uint32_t seed_hi;
     uint64_t index_base;  // RM_STOCH_ELEM: global index of element 0 of this launch
     const ParamRecord* dyn;   // nullable: take inv_scale / zero point from device memory instead of the fields above
+    // Opt-in "reference layout" (piquant_hip_set_reference_layout): reproduce WHERE the reference's AVX-512 build applies its
+    // scalar head/tail formula instead of the SIMD-body formula, for a context with one pool thread.  Positions are global
+    // (ref_index0 = global index of this launch's element 0) so that chunked host staging keeps the layout of the whole call.
+    int32_t ref_layout;
+    int32_t ref_head;         // leading elements processed by the scalar head loop (fp32 -> uint8 only, kernels_specialized.inl:52)
+    int64_t ref_total;        // numel of the whole call
+    int64_t ref_index0;
 };
 
 struct DequantParams {
@@ -46,6 +53,9 @@ struct DequantParams {
     int32_t zp32;
     int64_t zp64;
     const ParamRecord* dyn;   // nullable, as in QuantParams
+    int32_t ref_layout;       // as in QuantParams (tail formulas of the bf16 kernels, the uint2 -> f32 tail)
+    int64_t ref_total;
+    int64_t ref_index0;
 };
 
 // Kernel-entry resolution of the dynamic parameters (wave-uniform scalar loads; a no-op when dyn is null).
@@ -153,6 +163,20 @@ __device__ __forceinline__ void quant_nearest_fast2(float x0, float x1, const Qu
     const f32x2 adj = prod + half;
     q0 = quant_nearest_finish<QMAX>(adj[0], p);
     q1 = quant_nearest_finish<QMAX>(adj[1], p);
+}
+
+// The scalar head/tail step of the reference's nearest fast paths (kernels_specialized.inl:52-56, 178-182, 468-472, 711-716):
+// std::round, then int32 arithmetic.  Used only in reference-layout mode.
+template <int QMAX>
+__device__ __forceinline__ uint32_t quant_nearest_tail32(float x, const QuantParams& p) {
+    const float r = roundf(__fmul_rn(x, p.inv_scale));
+    return quant_nearest_finish<QMAX>(r, p);
+}
+
+// true when global element g of a call lies in the reference's scalar head or tail (block = SIMD block of the kernel)
+__device__ __forceinline__ bool ref_scalar_position(const QuantParams& p, int64_t g, int64_t block) {
+    const int64_t body_end = p.ref_head + ((p.ref_total - p.ref_head) / block) * block;
+    return g < p.ref_head || g >= body_end;
 }
 
 // quantize.inl:21-26

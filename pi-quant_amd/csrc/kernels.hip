@@ -31,7 +31,7 @@ void quantize_t(const QuantLaunch& q, const QuantParams& p, hipStream_t stream, 
     constexpr KernelTune t = kQuantTune[DT_IN][bits_index(BITS)];
     using Tile = QuantTile<DT_IN, BITS, t.u, t.block>;
     uint8_t* out = static_cast<uint8_t*>(q.out);
-    if (!aligned16(q.in) || !aligned16(q.out)) {
+    if (!aligned16(q.in) || !aligned16(q.out) || (q.ref_layout && q.ref_head != 0)) {   // a scalar head shifts every SIMD block: guarded kernel
         constexpr int PACK = 8 / BITS;
         const int64_t nbytes = (q.numel + PACK - 1) / PACK;
         const unsigned grid = capped_grid((nbytes + kScalarBlock - 1) / kScalarBlock, 16, num_cu);
@@ -130,6 +130,10 @@ void launch_quantize(const QuantLaunch& q, hipStream_t stream, int num_cu) {
     p.seed_hi = static_cast<uint32_t>(q.seed >> 32);
     p.index_base = q.index_base;
     p.dyn = static_cast<const ParamRecord*>(q.dyn_params);
+    p.ref_layout = q.ref_layout ? 1 : 0;
+    p.ref_head = q.ref_head;
+    p.ref_total = q.ref_total;
+    p.ref_index0 = q.ref_index0;
     switch (q.dt_in) {
         case DT_F32: quantize_bits<DT_F32>(q, p, stream, num_cu); break;
         case DT_BF16: quantize_bits<DT_BF16>(q, p, stream, num_cu); break;
@@ -146,6 +150,9 @@ void launch_dequantize(const DequantLaunch& d, hipStream_t stream, int num_cu) {
     p.zp64 = d.zero_point;
     p.zp32 = static_cast<int32_t>(static_cast<uint32_t>(static_cast<uint64_t>(d.zero_point)));
     p.dyn = static_cast<const ParamRecord*>(d.dyn_params);
+    p.ref_layout = d.ref_layout ? 1 : 0;
+    p.ref_total = d.ref_total;
+    p.ref_index0 = d.ref_index0;
     switch (d.dt_in) {
         case DT_UINT8: dequantize_out<8>(d, p, stream, num_cu); break;
         case DT_UINT4: dequantize_out<4>(d, p, stream, num_cu); break;

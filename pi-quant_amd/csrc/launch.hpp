@@ -19,6 +19,10 @@ struct QuantLaunch {
     uint64_t seed;
     uint64_t index_base;
     const void* dyn_params;   // nullable: 16-byte device ParamRecord overriding inv_scale / zero_point
+    bool ref_layout;          // reference-layout mode (see QuantParams)
+    int ref_head;
+    int64_t ref_total;
+    int64_t ref_index0;
 };
 
 struct DequantLaunch {
@@ -32,6 +36,9 @@ struct DequantLaunch {
     float bias;
     int64_t zero_point;
     const void* dyn_params;   // nullable: 16-byte device ParamRecord overriding scale / bias / zero_point
+    bool ref_layout;
+    int64_t ref_total;
+    int64_t ref_index0;
 };
 
 struct RequantLaunch {

@@ -175,6 +175,11 @@ class Context:
         """Opt-in: an independent threshold per element (counter hash of seed and global element index)."""
         C.piquant_hip_set_stochastic_per_element(self._ctx, 1 if enabled else 0, seed & 0xFFFFFFFFFFFFFFFF, index_base)
 
+    def set_reference_layout(self, enabled: bool) -> None:
+        """Opt-in: reproduce the reference's scalar head/tail formulas at the positions where its single-thread AVX-512 build
+        uses them (include/piquant_hip.h); off, every element takes the SIMD-body formula."""
+        C.piquant_hip_set_reference_layout(self._ctx, 1 if enabled else 0)
+
     def quantize_dequantize_ptr(self, ptr_in: int, dtype_in_out: DataType, ptr_out: int, quant_dtype: DataType, numel: int, scale: float,
                                 zero_point: int, round_mode: RoundMode, reduce_op: ReduceOp, _device_ptrs: bool = False) -> None:
         """Fused quantize->dequantize (the reference's C++-only ``quantize_dequantize_fused``, piquant.hpp:276-285)."""

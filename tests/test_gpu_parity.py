@@ -733,3 +733,76 @@ def test_contract_violations_abort_like_the_reference(snippet, needle):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == -6, (r.returncode, r.stderr[-500:])   # SIGABRT
     assert needle in r.stderr and "survived" not in r.stdout
+
+
+# ---------------------------------------------------------------------------------------------------
+# reference-layout mode: scalar head/tail formulas at the reference's positions -> equals golden `ref` byte for byte
+# ---------------------------------------------------------------------------------------------------
+def test_reference_layout_matches_golden_ref(ctx):
+    cases, get = load_golden()
+    ctx.set_reference_layout(True)
+    try:
+        nq = nd = differing = 0
+        for c in cases:
+            if c["kind"] == "quantize":
+                ctx.set_stochastic_threshold(c["tau"] if c["round_mode"] else None)
+                got = gpu_quantize(ctx, get(c["name"], "x"), c["dt_in"], c["dt_out"], c["scale"], c["zp"], c["round_mode"])
+                assert np.array_equal(got, get(c["name"], "ref")), c
+                differing += int(not np.array_equal(get(c["name"], "ref"), get(c["name"], "uniform")))
+                nq += 1
+            elif c["kind"] == "dequantize":
+                got = gpu_dequantize(ctx, get(c["name"], "q"), c["dt_in"], c["dt_out"], c["numel"], c["scale"], c["zp"], c["op"],
+                                     prev=get(c["name"], "prev"))
+                assert same_floats(got, get(c["name"], "ref")), c
+                differing += int(not same_floats(get(c["name"], "ref"), get(c["name"], "uniform")))
+                nd += 1
+        assert nq > 500 and nd > 400
+        assert differing > 20       # the mode is exercised: these cases differ between the two forms
+    finally:
+        ctx.set_stochastic_threshold(None)
+        ctx.set_reference_layout(False)
+
+
+def test_reference_layout_head_and_host_chunks(ctx, O):
+    """fp32 -> uint8 with a misaligned output pointer (scalar head, kernels_specialized.inl:52), device and host buffers; and a
+    host call longer than one staging chunk whose tail sits in the last chunk."""
+    rng = np.random.default_rng(77)
+    ctx.set_reference_layout(True)
+    try:
+        for n in (1, 7, 15, 16, 64, 100, 1000, 4097, 70_001):
+            x = rng.uniform(-1.2, 1.2, n).astype(np.float32)
+            x[rng.choice(n, max(1, n // 3))] = np.float32(0.49999997) * np.float32(0.01)   # p = 0.49999997 up to rounding
+            x[rng.choice(n, max(1, n // 5))] = np.float32(-0.49999997)
+            for off in (0, 1, 5, 15):
+                for scale, zp in ((1.0, 3), (0.01, 0)):
+                    want_buf = np.zeros(n + 16 + off, dtype=np.uint8)
+                    base = (-want_buf.ctypes.data) % 16
+                    want = O.quantize(x, O.F32, O.UINT8, scale, zp, form=O.FORM_REFERENCE, out=want_buf[base + off: base + off + n])
+                    got = gpu_quantize(ctx, x, O.F32, O.UINT8, scale, zp, offset_out=off)
+                    assert np.array_equal(got, want), (n, off, scale)
+        # host pointers: alignment of the HOST output pointer decides the head
+        import piquant
+        n = (1 << 24) + 1000 + 37
+        x = rng.uniform(-1.2, 1.2, n).astype(np.float32)
+        x[-37:] = np.float32(0.49999997)
+        x[:20] = np.float32(0.49999997)
+        for off in (0, 3):
+            buf = np.zeros(n + 32, dtype=np.uint8)
+            base = (-buf.ctypes.data) % 16
+            out = buf[base + off: base + off + n]
+            ctx.reset_stream()
+            ctx.set_blocking(True)
+            ctx.quantize_ptr(x.ctypes.data, piquant.DataType.F32, out.ctypes.data, piquant.DataType.UINT8, n, 1.0, 0, piquant.RoundMode.NEAREST)
+            wbuf = np.zeros(n + 32, dtype=np.uint8)
+            wbase = (-wbuf.ctypes.data) % 16
+            want = O.quantize(x, O.F32, O.UINT8, 1.0, 0, form=O.FORM_REFERENCE, out=wbuf[wbase + off: wbase + off + n])
+            assert np.array_equal(out, want), off
+            if off == 0:
+                assert out[-1] == 0 and out[0] == 1     # tail of 13: the scalar formula rounds 0.49999997 down; no head, body rounds up
+            else:
+                assert out[0] == 0 and out[-1] == 1     # head of 13 scalar elements, and (n - 13) % 64 == 0: no tail
+    finally:
+        ctx.set_reference_layout(False)
+    # with the mode off every position rounds it up, like the SIMD body
+    got = gpu_quantize(ctx, np.full(37, 0.49999997, dtype=np.float32), O.F32, O.UINT8, 1.0, 0)
+    assert (got == 1).all()
