@@ -105,6 +105,19 @@ PIQUANT_EXPORT void piquant_hip_dequantize_dp(piquant_context_t* ctx, const void
                                               piquant_dtype_t dtype_out, size_t numel, const piquant_hip_params_t* device_params,
                                               piquant_reduce_op_t op);
 
+/* compute_quant_params + quantize as ONE call: out = quantize(in) with (scale, zero_point) computed from `in` itself (the
+ * reference's Python flow piquant.torch.compute_quant_params -> quantize, python/src/piquant/torch.py:54-100), the
+ * parameters left in *device_params (16-byte record in device memory) for the dequantizing side.  Stream-ordered, no host
+ * round trip, hipGraph-capturable.  When the tensor fits on the chip (<= ~113 MB of fp32 / bf16 input on a 256-CU MI355X,
+ * 16-byte aligned buffers) this is a single kernel launch that reads the tensor ONCE: every CU keeps its share in vector
+ * registers and LDS between the min/max pass and the quantization pass (5 B/elem of HBM traffic for fp32 -> uint8 instead
+ * of 9).  Larger or misaligned tensors take scan + parameter kernel + quantize (three launches); the output bytes and the
+ * record are identical either way.  piquant_hip_set_fusion(ctx, 0) forces the three-launch form (A/B measurements). */
+PIQUANT_EXPORT void piquant_hip_quantize_dynamic(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in, void* out,
+                                                 piquant_dtype_t dtype_out, size_t numel, piquant_hip_params_t* device_params,
+                                                 piquant_round_mode_t mode);
+PIQUANT_EXPORT void piquant_hip_set_fusion(piquant_context_t* ctx, int enabled);
+
 /* compute_quant_params of a tensor whose shards live on several GPUs, for C / C++ hosts (one process per GPU): every
  * rank passes its local shard and its RCCL communicator (an ncclComm_t as void*).  Local HIP scan -> {key(min), key(-max)}
  * -> ONE ncclAllReduce(2 x int32, ncclMin) over xGMI on the context's stream -> identical double-precision epilogue on

@@ -125,6 +125,8 @@ struct piquant_context_t {
     uint32_t mailbox_seq = 0;
     int32_t* d_dist_keys = nullptr;        // {key(min), key(-max)} buffer the RCCL all-reduce of the *_dist call runs on
     hipStream_t scan_stream = nullptr;     // stream of the previous scan (re-arming relies on stream order)
+    void* d_fused = nullptr;               // FusedState of the one-launch params + quantize kernel (fused_kernels.hpp)
+    bool fusion = true;                    // piquant_hip_set_fusion
 
     // device scratch for host-pointer calls, grown on demand
     void* stage_in[2] = {nullptr, nullptr};
@@ -197,6 +199,8 @@ piquant_context_t* piquant_context_create(size_t num_threads) {
         PQ_HIP(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p), float_to_key(std::numeric_limits<float>::max()), minmax_slot_ints()));
     }
     PQ_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_slots_capture), slot_bytes));
+    PQ_HIP(hipMalloc(&ctx->d_fused, fused_state_bytes()));
+    init_fused_state(ctx->d_fused, nullptr);
     PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_slots), slot_bytes, hipHostMallocDefault));
     if (hipHostMalloc(reinterpret_cast<void**>(&ctx->mailbox), sizeof(MinmaxMailboxHost), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
         hipHostGetDevicePointer(&ctx->mailbox_dev, ctx->mailbox, 0) == hipSuccess) {
@@ -226,12 +230,26 @@ void piquant_context_destroy(piquant_context_t* ctx) {
         for (auto& p : ctx->d_slots)
             if (p) (void)hipFree(p);
         if (ctx->d_slots_capture) (void)hipFree(ctx->d_slots_capture);
+        if (ctx->d_fused) (void)hipFree(ctx->d_fused);
         if (ctx->h_slots) (void)hipHostFree(ctx->h_slots);
         if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
         if (ctx->d_dist_keys) (void)hipFree(ctx->d_dist_keys);
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     }
     delete ctx;
+}
+
+// round-mode fields of a launch: NEAREST, one threshold per call (src/piquant.cpp:197-201) or the per-element extension
+static void fill_round_mode(piquant_context_t* ctx, QuantLaunch& q, piquant_round_mode_t mode) {
+    if (mode == PIQUANT_NEAREST) q.round_mode = RM_NEAREST_FAST;
+    else if (ctx->per_element) {
+        q.round_mode = RM_STOCH_ELEM;
+        q.seed = ctx->elem_seed;
+        q.index_base = ctx->elem_base;
+    } else {
+        q.round_mode = RM_STOCH_CALL;
+        q.threshold = draw_threshold(ctx);
+    }
 }
 
 static void quantize_impl(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out, size_t numel,
@@ -254,15 +272,7 @@ static void quantize_impl(piquant_context_t* ctx, const void* in, piquant_dtype_
     q.dt_out = dtype_out;
     q.inv_scale = 1.0f / scale;                         // fp32 division on the host, as the reference (kernels_specialized.inl:42)
     q.zero_point = zero_point;
-    if (mode == PIQUANT_NEAREST) q.round_mode = RM_NEAREST_FAST;
-    else if (ctx->per_element) {
-        q.round_mode = RM_STOCH_ELEM;
-        q.seed = ctx->elem_seed;
-        q.index_base = ctx->elem_base;
-    } else {
-        q.round_mode = RM_STOCH_CALL;
-        q.threshold = draw_threshold(ctx);              // one threshold per call (src/piquant.cpp:197-201)
-    }
+    fill_round_mode(ctx, q, mode);
 
     if (ctx->reference_layout) {
         q.ref_layout = true;
@@ -517,6 +527,59 @@ void piquant_hip_compute_quant_params_device(piquant_context_t* ctx, const void*
     // n == 0: an armed slot buffer folds to the identities, like the synchronous call
     const int32_t* slots = n == 0 ? ctx->d_slots[ctx->slot] : scan_into_slots(ctx, x, dtype, n);
     launch_params_from_slots(slots, dtype_of(target_quant_dtype).bits, rp.dev, ctx->stream);
+}
+
+void piquant_hip_quantize_dynamic(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out, size_t numel,
+                                  piquant_hip_params_t* device_params, piquant_round_mode_t mode) {
+    if (!ctx) panic("piquant_hip_quantize_dynamic: context is NULL");
+    const dtype_row& dti = dtype_of(dtype_in);
+    const dtype_row& dto = dtype_of(dtype_out);
+    if (dti.quant) panic("quantize: input dtype (%s) must be a dequantized type", dti.name);
+    if (!dto.quant) panic("quantize: output dtype (%s) must be a quantized type", dto.name);
+    if (mode != PIQUANT_NEAREST && mode != PIQUANT_STOCHASTIC) panic("quantize: invalid round mode %d", static_cast<int>(mode));
+    if (!device_params) panic("piquant_hip_quantize_dynamic: NULL parameter record");
+    if (numel != 0 && (!in || !out)) panic("quantize: NULL buffer");
+
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    const Resolved rp = resolve(device_params);
+    if (rp.pageable) panic("piquant_hip_quantize_dynamic: the parameter record must live in device (or pinned) memory");
+    if (numel == 0) {   // parameters of an empty tensor: the identities fold to the degenerate range, as in the synchronous call
+        launch_params_from_slots(ctx->d_slots[ctx->slot], dto.bits, rp.dev, ctx->stream);
+        if (ctx->blocking) wait_stream(ctx->stream);
+        return;
+    }
+    const Resolved rin = ctx->resolve_ptr(in), rout = ctx->resolve_ptr(out);
+    if (rin.pageable || rout.pageable) panic("piquant_hip_quantize_dynamic needs device (or pinned) buffers");
+
+    QuantLaunch q {};
+    q.in = rin.dev;
+    q.out = rout.dev;
+    q.numel = static_cast<int64_t>(numel);
+    q.dt_in = dtype_in;
+    q.dt_out = dtype_out;
+    fill_round_mode(ctx, q, mode);
+    if (ctx->reference_layout) {
+        q.ref_layout = true;
+        q.ref_total = q.numel;
+        if (dtype_in == PIQUANT_DTYPE_F32 && dtype_out == PIQUANT_DTYPE_UINT8 && mode == PIQUANT_NEAREST)
+            q.ref_head = static_cast<int>(std::min<size_t>(numel, (16u - (reinterpret_cast<uintptr_t>(out) & 15u)) & 15u));
+    }
+    // One launch with the tensor held on chip between the scan and the quantization when it fits; otherwise (or with fusion
+    // switched off) the same result from three launches: scan, parameter epilogue, quantize reading the record.
+    if (!(ctx->fusion && launch_fused_params_quantize(q, ctx->d_fused, rp.dev, ctx->stream, ctx->num_cu))) {
+        const int32_t* slots = scan_into_slots(ctx, rin.dev, dtype_in, numel);
+        launch_params_from_slots(slots, dto.bits, rp.dev, ctx->stream);
+        q.dyn_params = rp.dev;
+        launch_quantize(q, ctx->stream, ctx->num_cu);
+    }
+    if (ctx->blocking) wait_stream(ctx->stream);
+}
+
+void piquant_hip_set_fusion(piquant_context_t* ctx, int enabled) {
+    if (!ctx) panic("piquant_hip_set_fusion: context is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->fusion = enabled != 0;
 }
 
 // RCCL's ncclAllReduce, looked up once in whatever RCCL the process has loaded (PyTorch's bundled one, /opt/rocm's, ...).

@@ -165,6 +165,23 @@ __device__ __forceinline__ void quant_nearest_fast2(float x0, float x1, const Qu
     q1 = quant_nearest_finish<QMAX>(adj[1], p);
 }
 
+// The same nearest step for a caller that has PROVED two things: every non-NaN element satisfies abs(x * inv_scale) + 0.5 <
+// 2^31 (so cvttps2dq never returns its indefinite for a number), and 0 <= zero point <= QMAX.  Then
+//     clamp(trunc(adj) + zp, 0, QMAX) == trunc(clamp(adj, -zp, QMAX - zp)) + zp
+// because trunc is monotone and leaves integers alone; and a NaN takes the lower bound through fmax (the non-NaN operand),
+// giving 0 -- which is what the reference's INT_MIN + zp clamps to.  Three instructions (v_med3_f32, v_cvt_i32_f32, add)
+// instead of six; used by the fused params+quantize kernel, which knows the data range before it quantizes.
+struct BoundedStep {
+    float lo, hi;    // float(-zp), float(QMAX - zp)
+    uint32_t zp_word;   // zp replicated into every BITS-wide field of a 32-bit word
+};
+
+// trunc(clamp(adj)) as a signed offset from the zero point, in [-zp, QMAX - zp].  v_med3_f32 returns min3 of its operands
+// when one of them is a NaN, and min ignores the NaN: med3(NaN, lo, hi) = lo, the value the fmax/fmin pair would give.
+__device__ __forceinline__ int32_t quant_nearest_bounded_offset(float adj, const BoundedStep& b) {
+    return static_cast<int32_t>(__builtin_amdgcn_fmed3f(adj, b.lo, b.hi));
+}
+
 // The scalar head/tail step of the reference's nearest fast paths (kernels_specialized.inl:52-56, 178-182, 468-472, 711-716):
 // std::round, then int32 arithmetic.  Used only in reference-layout mode.
 template <int QMAX>

@@ -1,0 +1,368 @@
+// compute_quant_params + quantize in ONE launch with ONE read of the tensor.
+//
+// The reference's Python flow is always two passes over x: compute_quant_params (min/max scan, piquant.cpp:222-259) and
+// then quantize (piquant.cpp:277-308).  On a CPU both passes stream from DRAM.  An MI355X has 128 MiB of vector
+// registers and 40 MiB of LDS (256 CUs x (4 x 128 KiB + 160 KiB)) -- more than the 109 MB of the headline tensor -- so
+// a persistent grid of one block per CU can KEEP its share of x on chip between the two passes:
+//
+//   phase 1  every thread loads its vectors (R_REG of them stay in VGPRs, R_LDS more in the block's LDS) and folds
+//            min/max on the way; block result -> 64 slot pairs in device memory (conditional atomicMin, as minmax_kernel)
+//   barrier  grid-wide: one arrival counter + a generation word (device-scope atomics; all blocks are co-resident because
+//            the grid never exceeds the CU count)
+//   phase 2  every wave folds the 64 slots, every lane runs the reference's double-precision (min,max)->(scale,zp) epilogue
+//            (bit-identical on all lanes), block 0 publishes the 16-byte ParamRecord for the caller / the dequantizing side
+//   phase 3  the resident vectors are quantized straight from registers / LDS and stored: the only HBM traffic of this
+//            phase is the packed output
+//
+// HBM traffic: 4 B/elem read once + the packed bytes written = 5 B/elem for fp32 -> uint8 instead of 9 for scan + quantize.
+// The arithmetic is the same code as the two-pass path (minmax keys, params epilogue, quant_nearest_fast2 / quant_one), so
+// the output bytes and the record are identical to compute_quant_params_device + quantize_dp -- tests compare them.
+//
+// Capacity: (R_REG + R_LDS) x 16 B x BLOCK threads x grid blocks (121.6 MB at 256 CUs).  The host launches this kernel
+// only when the tensor fits and both pointers are 16-byte aligned, and otherwise takes the three-launch path.
+//
+// State in device memory (FusedState) is self-maintaining, so that a launch needs no host-side reset and replays
+// unchanged inside a hipGraph: the generation word picks which of two slot buffers this launch folds into and the other
+// one is re-armed for the next launch; the last block to arrive resets the counter before it bumps the generation.
+#pragma once
+
+#include "minmax_kernels.hpp"
+
+#include <type_traits>
+
+namespace pq {
+
+struct FusedState {
+    uint32_t arrived;
+    uint32_t pad0[31];
+    uint32_t generation;
+    uint32_t pad1[31];
+    unsigned long long published;   // tag(generation + 1) << 41 | bounded << 40 | zero_point << 32 | bits of scale: what waiting blocks spin on
+    uint32_t pad2[30];
+    int32_t slots[2][kMinmaxSlotInts];
+    uint64_t* stamps;     // TIMING builds (tools/tune_kernels.hip): 8 x 100 MHz wall clock readings per block at the phase boundaries
+};
+
+// one 16-byte input vector -> WORDS packed 32-bit words (OB = EPV*BITS/8 bytes of output)
+template <int DT_IN, int BITS, int MODE>
+__device__ __forceinline__ void quantize_vec(const u32x4& raw, const QuantParams& p, const ElementKeys& keys, uint64_t e0,
+                                             uint32_t (&w)[(InVec<DT_IN>::EPV * BITS / 8) > 4 ? 2 : 1]) {
+    constexpr int EPV = InVec<DT_IN>::EPV, QMAX = (1 << BITS) - 1, WORDS = (EPV * BITS / 8) > 4 ? 2 : 1;
+    float v[EPV];
+    InVec<DT_IN>::unpack(raw, v);
+#pragma unroll
+    for (int j = 0; j < WORDS; ++j) w[j] = 0;
+    if constexpr (MODE == RM_NEAREST_FAST) {
+#pragma unroll
+        for (int e = 0; e < EPV; e += 2) {
+            uint32_t q0, q1;
+            quant_nearest_fast2<QMAX>(v[e], v[e + 1], p, q0, q1);
+            w[(e * BITS) >> 5] |= (q0 | (q1 << BITS)) << ((e * BITS) & 31);
+        }
+    } else if constexpr (MODE == RM_STOCH_ELEM) {
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+            const uint32_t q = quant_stochastic<QMAX>(v[e], p, element_threshold(keys, p.index_base + e0 + e));
+            w[(e * BITS) >> 5] |= q << ((e * BITS) & 31);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+            const uint32_t q = quant_one<MODE, QMAX>(v[e], p, e0 + e);
+            w[(e * BITS) >> 5] |= q << ((e * BITS) & 31);
+        }
+    }
+}
+
+// The nearest step for a call whose data range is known (device_math.hpp, BoundedStep): per element a packed multiply and
+// add, the copysign, one v_med3_f32 and one v_cvt_i32_f32 give the signed offset t = q - zp; the fields are then assembled
+// by Horner steps w = (w << BITS) + t (v_lshl_add_u32, negative t borrow from the field above and the borrow is repaid
+// exactly when zp is added to every field at once): 4 integer instructions per four elements instead of 4 adds + 3 packs.
+template <int DT_IN, int BITS>
+__device__ __forceinline__ void quantize_vec_bounded(const u32x4& raw, float inv_scale, const BoundedStep& b,
+                                                     uint32_t (&w)[(InVec<DT_IN>::EPV * BITS / 8) > 4 ? 2 : 1]) {
+#pragma clang fp contract(off)
+    constexpr int EPV = InVec<DT_IN>::EPV, WORDS = (EPV * BITS / 8) > 4 ? 2 : 1, EPW = EPV / WORDS;
+    float v[EPV];
+    InVec<DT_IN>::unpack(raw, v);
+    int32_t t[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; e += 2) {
+        const f32x2 x = {v[e], v[e + 1]};
+        const f32x2 prod = x * inv_scale;
+        const f32x2 half = {__builtin_copysignf(0.5f, prod[0]), __builtin_copysignf(0.5f, prod[1])};
+        const f32x2 adj = prod + half;
+        t[e] = quant_nearest_bounded_offset(adj[0], b);
+        t[e + 1] = quant_nearest_bounded_offset(adj[1], b);
+    }
+#pragma unroll
+    for (int j = 0; j < WORDS; ++j) {
+        uint32_t acc = static_cast<uint32_t>(t[j * EPW + EPW - 1]);
+#pragma unroll
+        for (int e = EPW - 2; e >= 0; --e) acc = (acc << BITS) + static_cast<uint32_t>(t[j * EPW + e]);
+        w[j] = acc + b.zp_word;
+    }
+}
+
+template <int OB, int POLICY>
+__device__ __forceinline__ void store_packed(uint8_t* dst, const uint32_t (&w)[OB > 4 ? 2 : 1]) {
+    if constexpr (OB == 1) st<POLICY>(dst, static_cast<uint8_t>(w[0]));
+    else if constexpr (OB == 2) st<POLICY>(reinterpret_cast<uint16_t*>(dst), static_cast<uint16_t>(w[0]));
+    else if constexpr (OB == 4) st<POLICY>(reinterpret_cast<uint32_t*>(dst), w[0]);
+    else st<POLICY>(reinterpret_cast<u32x2*>(dst), u32x2 {w[0], w[1]});
+}
+
+// src/piquant.cpp:245-258 in IEEE double, as params_from_slots_kernel
+__device__ __forceinline__ void quant_params_epilogue(int32_t k_min, int32_t k_negmax, int bits, float& scale, int64_t& zp) {
+    const double r_min = static_cast<double>(key_to_float(k_min));
+    const double r_max = static_cast<double>(-key_to_float(k_negmax));
+    const uint64_t type_max = (uint64_t {1} << bits) - 1;
+    if (r_max == r_min) {
+        scale = 1.0f;
+        zp = static_cast<int64_t>(type_max >> 1);
+    } else {
+        const double q_max = static_cast<double>(type_max);
+        const double s = (r_max - r_min) / q_max;
+        double z = 0.0 - r_min / s;
+        z = fmax(fmin(static_cast<double>(static_cast<int64_t>(round(z))), q_max), 0.0);
+        scale = static_cast<float>(s);
+        zp = static_cast<int64_t>(z);
+    }
+}
+
+// rounds of BLOCK vectors in one block's share when n_vec vectors are split evenly over G blocks
+__host__ __device__ inline int fused_rounds(int64_t n_vec, int64_t G, int64_t block) {
+    const int64_t per_block = (n_vec + G - 1) / G;
+    return static_cast<int>((per_block + block - 1) / block);
+}
+
+template <int DT_IN>
+__device__ __forceinline__ void minmax_vec(const u32x4& raw, bool valid, float& lo, float& hi) {
+    constexpr int EPV = InVec<DT_IN>::EPV;
+    float f[EPV];
+    InVec<DT_IN>::unpack(raw, f);
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+        lo = __builtin_fminf(lo, valid ? f[e] : lo);
+        hi = __builtin_fmaxf(hi, valid ? f[e] : hi);
+    }
+}
+
+// A block owns ONE contiguous share of the tensor (rounds * BLOCK vectors; 426 KiB at the headline size) and walks it in
+// rounds of BLOCK consecutive vectors: vector of thread `tid` in round k = share_begin + k * BLOCK + tid, a coalesced 1 KiB
+// per wave instruction.  (Interleaving the blocks' rounds across the whole tensor instead -- every block touching a new
+// 2 MiB-strided 8 KiB piece per round, ~46 of them in flight per wave -- measured 2.9 TB/s in the load phase and a 2x
+// spread between the fastest and the slowest block: tens of thousands of concurrent 1 KiB streams leave no DRAM locality.)
+template <int DT_IN, int BITS, int MODE, int R_REG, int R_LDS, int LDS_BATCH, int BLOCK, int ST_POLICY = ST_WT, bool TIMING = false>
+__global__ void __launch_bounds__(BLOCK)
+fused_params_quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t numel, QuantParams p_arg, FusedState* st,
+                             ParamRecord* params_out) {
+    static_assert(R_LDS % LDS_BATCH == 0, "the LDS-resident rounds are loaded in whole batches");
+    constexpr int EPV = InVec<DT_IN>::EPV, OB = EPV * BITS / 8, WAVES = BLOCK / 64;
+    constexpr int WORDS = OB > 4 ? 2 : 1;
+    __shared__ u32x4 resident[R_LDS * BLOCK];
+    __shared__ float s_lo[WAVES], s_hi[WAVES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t G = gridDim.x;
+    const int64_t n_vec = numel / EPV;
+    constexpr int64_t round_vecs = BLOCK;
+    const int rounds = fused_rounds(n_vec, G, BLOCK);                             // <= R_REG + R_LDS (host guarantees)
+    const int64_t v_first = static_cast<int64_t>(blockIdx.x) * rounds * BLOCK + tid;
+    const int64_t v_last = n_vec > 0 ? n_vec - 1 : 0;
+    const u32x4* __restrict__ in16 = static_cast<const u32x4*>(in);
+
+    auto stamp = [&](int i) {
+        if constexpr (TIMING) {
+            if (tid == 0) st->stamps[blockIdx.x * 8 + i] = wall_clock64();
+        }
+    };
+    stamp(0);
+    const uint32_t gen = __hip_atomic_load(&st->generation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int32_t* slots = st->slots[gen & 1];
+    if (blockIdx.x == 0 && tid < kMinmaxSlots) {   // the other buffer was read by the previous launch, which has completed
+        int32_t* idle = st->slots[(gen & 1) ^ 1];
+        idle[tid * kMinmaxSlotStride + 0] = float_to_key(3.402823466e+38f);
+        idle[tid * kMinmaxSlotStride + 1] = float_to_key(3.402823466e+38f);
+    }
+
+    // ---- phase 1: load everything once; rounds [0, R_REG) stay in registers, [R_REG, R_REG + R_LDS) in LDS -------------
+    float lo = 3.402823466e+38f, hi = -3.402823466e+38f;
+    u32x4 r[R_REG];
+    if (n_vec > 0) {
+#pragma unroll
+        for (int k = 0; k < R_REG; ++k) {
+            if (k < rounds) {   // uniform
+                const int64_t v = v_first + k * round_vecs;
+                r[k] = ld<true>(in16 + (v < n_vec ? v : v_last));   // clamped address: all loads issue before the first use
+            }
+        }
+#pragma unroll 1
+        for (int j0 = 0; j0 < R_LDS && R_REG + j0 < rounds; j0 += LDS_BATCH) {
+            u32x4 t[LDS_BATCH];
+#pragma unroll
+            for (int j = 0; j < LDS_BATCH; ++j) {
+                const int64_t v = v_first + (R_REG + j0 + j) * round_vecs;
+                t[j] = ld<true>(in16 + (v < n_vec ? v : v_last));
+            }
+#pragma unroll
+            for (int j = 0; j < LDS_BATCH; ++j) {
+                const int64_t v = v_first + (R_REG + j0 + j) * round_vecs;
+                minmax_vec<DT_IN>(t[j], v < n_vec, lo, hi);
+                resident[(j0 + j) * BLOCK + tid] = t[j];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < R_REG; ++k) {
+            if (k < rounds) minmax_vec<DT_IN>(r[k], v_first + k * round_vecs < n_vec, lo, hi);
+        }
+    }
+    if (blockIdx.x == 0 && tid < numel - n_vec * EPV) {   // the numel % EPV scalar elements
+        const float x = InVec<DT_IN>::load_scalar(in, n_vec * EPV + tid);
+        lo = __builtin_fminf(lo, x);
+        hi = __builtin_fmaxf(hi, x);
+    }
+
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+    if (lane == 0) {
+        s_lo[wave] = lo;
+        s_hi[wave] = hi;
+    }
+    __syncthreads();
+    stamp(1);
+    // ---- grid barrier + phase 2, by wave 0 of every block ------------------------------------------------------------------
+    // The LAST block to arrive folds the 64 slots (one lane each), runs the (min,max) -> (scale, zero point) epilogue once
+    // and publishes {generation tag, zero point (< 256), scale bits} in ONE 64-bit word; everybody else spins on that word,
+    // so a waiting block has its parameters the moment it sees the barrier open -- no second round trip for a record.
+    __shared__ unsigned long long s_pub;
+    if (wave == 0) {
+        uint32_t before = 0;
+        if (lane == 0) {
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) {
+                lo = __builtin_fminf(lo, s_lo[w]);
+                hi = __builtin_fmaxf(hi, s_hi[w]);
+            }
+            // No fences anywhere in this barrier: the only data that crosses blocks travels in device-scope atomics (slot keys,
+            // arrival count, published word), and a release/acquire fence at agent scope costs an L2 write-back / invalidate
+            // per block (measured: 13-17 us of barrier).  What IS needed is that this block's slot atomics are performed
+            // before its arrival is counted: they return their old value and the arrival increment is made to depend on it.
+            int32_t* my = slots + (blockIdx.x % kMinmaxSlots) * kMinmaxSlotStride;
+            const int32_t k_lo = float_to_key(lo), k_hi = float_to_key(-hi);
+            int32_t seen0 = k_lo, seen1 = k_hi;
+            if (k_lo < __hip_atomic_load(my + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                seen0 = __hip_atomic_fetch_min(my + 0, k_lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (k_hi < __hip_atomic_load(my + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                seen1 = __hip_atomic_fetch_min(my + 1, k_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t one = 1u;
+            asm volatile("" : "+v"(one) : "v"(seen0), "v"(seen1));
+            before = __hip_atomic_fetch_add(&st->arrived, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        before = __builtin_amdgcn_readfirstlane(before);
+        const unsigned long long tag = static_cast<unsigned long long>((gen + 1u) & 0x7fffffu) << 41;
+        unsigned long long pub;
+        if (before == static_cast<uint32_t>(G) - 1u) {
+            static_assert(kMinmaxSlots == 64, "one lane per slot");
+            int32_t k0 = __hip_atomic_load(slots + lane * kMinmaxSlotStride + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int32_t k1 = __hip_atomic_load(slots + lane * kMinmaxSlotStride + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                k0 = min(k0, __shfl_xor(k0, off, 64));
+                k1 = min(k1, __shfl_xor(k1, off, 64));
+            }
+            float scale;
+            int64_t zp;
+            quant_params_epilogue(k0, k1, BITS, scale, zp);       // 0 <= zp <= 2^BITS - 1
+            // can every element take the bounded step?  abs(x) <= max(abs(min), abs(max)), products are monotone
+            const float reach = __fmul_rn(__builtin_fmaxf(__builtin_fabsf(key_to_float(k0)), __builtin_fabsf(key_to_float(k1))), __fdiv_rn(1.0f, scale));
+            const unsigned long long bounded = reach < 1.0e9f ? 1ull : 0ull;
+            pub = tag | (bounded << 40) | (static_cast<unsigned long long>(zp) << 32) | __float_as_uint(scale);
+            if (lane == 0) {
+                params_out->scale = scale;
+                params_out->inv_scale = __fdiv_rn(1.0f, scale);
+                params_out->zero_point = zp;
+                __hip_atomic_store(&st->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&st->generation, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&st->published, pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            pub = 0;
+            if (lane == 0) {
+                uint32_t spins = 0;
+                while (((pub = __hip_atomic_load(&st->published, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 41) != (tag >> 41)) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 21)) __builtin_trap();   // ~1 s: a block that never arrives must fail the launch, not hang the device
+                }
+            }
+        }
+        if (lane == 0) s_pub = pub;
+    }
+    __syncthreads();
+    stamp(2);
+    // Every load of phase 1 has long been consumed, but the compiler's wait-count bookkeeping loses that across the guarded,
+    // unrolled rounds and would put `s_waitcnt vmcnt(0)` in front of each resident vector of phase 3 -- which on gfx9 also
+    // waits for the previous STORE to be acknowledged and turns phase 3 into a chain of store round trips (measured: 9.4 us
+    // at 16 waves per CU, 28 us at 4).  One explicit wait here tells it that nothing is pending.
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0), expcnt/lgkmcnt untouched
+    const unsigned long long pub = s_pub;
+    const float scale = __uint_as_float(static_cast<uint32_t>(pub));
+    const int64_t zp = static_cast<int64_t>((pub >> 32) & 0xff);
+    const bool bounded_ok = ((pub >> 40) & 1) != 0;
+    QuantParams p = p_arg;
+    p.inv_scale = __fdiv_rn(1.0f, scale);
+    p.zp64 = zp;
+    p.zp32 = static_cast<int32_t>(zp);
+    p.dyn = nullptr;
+
+    // ---- phase 3: quantize the resident vectors --------------------------------------------------------------------------
+    stamp(3);
+    // per-element RNG keys: all indices of this thread lie in [first, first + 2^32) -- the resident tensor is far smaller
+    [[maybe_unused]] ElementKeys keys {};
+    if constexpr (MODE == RM_STOCH_ELEM) keys = element_keys_for(p, p.index_base + static_cast<uint64_t>(v_first) * EPV);
+    constexpr int FIELDS = 32 / BITS < EPV ? 32 / BITS : EPV;    // fields of a packed word that one vector fills
+    uint32_t zp_word = 0;
+#pragma unroll
+    for (int i = 0; i < FIELDS; ++i) zp_word |= static_cast<uint32_t>(p.zp32) << (i * BITS);
+    const BoundedStep bstep {-static_cast<float>(p.zp32), static_cast<float>(((1 << BITS) - 1) - p.zp32), zp_word};
+    // A block whose whole share lies inside the tensor (all but the last one or two) needs no per-vector bounds check.
+    const bool full_share = (static_cast<int64_t>(blockIdx.x) + 1) * rounds * BLOCK <= n_vec;
+    auto emit = [&](auto bounded_tag, auto full_tag) {
+        constexpr bool BOUNDED = decltype(bounded_tag)::value, FULL = decltype(full_tag)::value;
+        auto one = [&](const u32x4& raw, int64_t v) {
+            if (FULL || v < n_vec) {
+                uint32_t w[WORDS];
+                if constexpr (BOUNDED) quantize_vec_bounded<DT_IN, BITS>(raw, p.inv_scale, bstep, w);
+                else quantize_vec<DT_IN, BITS, MODE>(raw, p, keys, static_cast<uint64_t>(v) * EPV, w);
+                store_packed<OB, ST_POLICY>(out + v * OB, w);
+            }
+        };
+#pragma unroll
+        for (int k = 0; k < R_REG; ++k) {
+            if (k < rounds) one(r[k], v_first + k * round_vecs);
+        }
+#pragma unroll 2
+        for (int j = 0; j < R_LDS; ++j) {
+            if (R_REG + j >= rounds) break;
+            one(resident[j * BLOCK + tid], v_first + (R_REG + j) * round_vecs);
+        }
+    };
+    // grid-uniform: the data range decides whether the short step is exact for every element of this call
+    if (MODE == RM_NEAREST_FAST && bounded_ok) {
+        if (full_share) emit(std::true_type {}, std::true_type {});
+        else emit(std::true_type {}, std::false_type {});
+    } else {
+        emit(std::false_type {}, std::false_type {});
+    }
+    if (blockIdx.x == gridDim.x - 1 && n_vec * EPV < numel) {
+        constexpr int PACK = 8 / BITS;
+        quantize_bytes_guarded<DT_IN, BITS, MODE>(in, out, numel, n_vec * EPV / PACK, (numel + PACK - 1) / PACK, p, tid, BLOCK);
+    }
+    if constexpr (TIMING) {
+        __builtin_amdgcn_s_waitcnt(0);   // stores issued (not necessarily landed)
+        __syncthreads();
+        stamp(4);
+    }
+}
+
+}  // namespace pq

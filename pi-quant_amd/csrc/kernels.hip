@@ -4,6 +4,7 @@
 #include "launch.hpp"
 
 #include "dequant_kernels.hpp"
+#include "fused_kernels.hpp"
 #include "minmax_kernels.hpp"
 #include "quant_kernels.hpp"
 #include "requant_kernels.hpp"
@@ -140,6 +141,71 @@ void launch_quantize(const QuantLaunch& q, hipStream_t stream, int num_cu) {
         default: panic("invalid quantization types: %d -> %d", q.dt_in, q.dt_out);
     }
     PQ_HIP(hipGetLastError());
+}
+
+namespace {
+
+template <int DT_IN, int BITS, int MODE>
+void fused_launch(const QuantLaunch& q, const QuantParams& p, FusedState* st, ParamRecord* rec, hipStream_t stream, unsigned grid) {
+    hipLaunchKernelGGL((fused_params_quantize_kernel<DT_IN, BITS, MODE, kFusedRegRounds, kFusedLdsRounds, kFusedLdsRounds, kFusedBlock>), dim3(grid),
+                       dim3(kFusedBlock), 0, stream, q.in, static_cast<uint8_t*>(q.out), q.numel, p, st, rec);
+}
+
+template <int DT_IN, int BITS>
+void fused_mode(const QuantLaunch& q, const QuantParams& p, FusedState* st, ParamRecord* rec, hipStream_t stream, unsigned grid) {
+    switch (q.round_mode) {
+        case RM_NEAREST_FAST:
+            // fp32 -> uint2 has no SIMD fast path in the reference: generic int64 step everywhere, as in launch_quantize
+            if constexpr (DT_IN == DT_F32 && BITS == 2) fused_launch<DT_IN, BITS, RM_NEAREST_I64>(q, p, st, rec, stream, grid);
+            else fused_launch<DT_IN, BITS, RM_NEAREST_FAST>(q, p, st, rec, stream, grid);
+            return;
+        case RM_STOCH_CALL: fused_launch<DT_IN, BITS, RM_STOCH_CALL>(q, p, st, rec, stream, grid); return;
+        case RM_STOCH_ELEM: fused_launch<DT_IN, BITS, RM_STOCH_ELEM>(q, p, st, rec, stream, grid); return;
+        default: panic("invalid round mode %d", q.round_mode);
+    }
+}
+
+template <int DT_IN>
+void fused_bits(const QuantLaunch& q, const QuantParams& p, FusedState* st, ParamRecord* rec, hipStream_t stream, unsigned grid) {
+    switch (q.dt_out) {
+        case DT_UINT8: fused_mode<DT_IN, 8>(q, p, st, rec, stream, grid); return;
+        case DT_UINT4: fused_mode<DT_IN, 4>(q, p, st, rec, stream, grid); return;
+        case DT_UINT2: fused_mode<DT_IN, 2>(q, p, st, rec, stream, grid); return;
+        default: panic("invalid quantization types: %d -> %d", q.dt_in, q.dt_out);
+    }
+}
+
+}  // namespace
+
+size_t fused_state_bytes() { return sizeof(FusedState); }
+
+void init_fused_state(void* state, hipStream_t stream) {
+    PQ_HIP(hipMemsetAsync(state, 0, sizeof(FusedState), stream));
+    FusedState* st = static_cast<FusedState*>(state);
+    launch_arm_slots(&st->slots[0][0], stream);
+    launch_arm_slots(&st->slots[1][0], stream);
+}
+
+bool launch_fused_params_quantize(const QuantLaunch& q, void* state, void* device_param_record, hipStream_t stream, int num_cu) {
+    if (q.numel <= 0 || q.ref_layout || !aligned16(q.in) || !aligned16(q.out)) return false;
+    if (q.dt_in != DT_F32 && q.dt_in != DT_BF16) panic("invalid quantization types: %d -> %d", q.dt_in, q.dt_out);
+    const int64_t n_vec = q.numel / (q.dt_in == DT_F32 ? 4 : 8);
+    if (fused_rounds(n_vec, num_cu, kFusedBlock) > kFusedRegRounds + kFusedLdsRounds) return false;   // does not fit on chip
+    QuantParams p {};
+    p.threshold = q.threshold;
+    p.seed_lo = static_cast<uint32_t>(q.seed);
+    p.seed_hi = static_cast<uint32_t>(q.seed >> 32);
+    p.index_base = q.index_base;
+    FusedState* st = static_cast<FusedState*>(state);
+    ParamRecord* rec = static_cast<ParamRecord*>(device_param_record);
+    // One block per CU: the grid barrier needs every block resident, and a 1024-thread block with 144 KiB of LDS owns its CU.
+    const unsigned grid = static_cast<unsigned>(num_cu);
+    switch (q.dt_in) {
+        case DT_F32: fused_bits<DT_F32>(q, p, st, rec, stream, grid); break;
+        default: fused_bits<DT_BF16>(q, p, st, rec, stream, grid); break;
+    }
+    PQ_HIP(hipGetLastError());
+    return true;
 }
 
 void launch_dequantize(const DequantLaunch& d, hipStream_t stream, int num_cu) {

@@ -77,6 +77,14 @@ struct MinmaxMailboxHost {
 void launch_fold_publish(const int32_t* slots, void* mailbox_device_ptr, uint32_t seq, hipStream_t stream);
 // Fold a slot buffer and write the (scale, 1/scale, zero_point) ParamRecord for `bits`-wide quantization to device memory.
 void launch_params_from_slots(const int32_t* slots, int bits, void* device_param_record, hipStream_t stream);
+// compute_quant_params + quantize in one launch with the tensor resident on chip between the two passes (fused_kernels.hpp).
+// q.inv_scale / q.zero_point / q.dyn_params are ignored: the parameters come from the data and are also written to
+// device_param_record.  `state` is a fused_state_bytes() device buffer prepared once with init_fused_state().  Returns false
+// without launching when the call does not qualify (tensor larger than the chip holds, misaligned buffers, reference-layout
+// mode): the caller then runs scan -> params -> quantize as three launches, with identical results.
+bool launch_fused_params_quantize(const QuantLaunch& q, void* state, void* device_param_record, hipStream_t stream, int num_cu);
+size_t fused_state_bytes();
+void init_fused_state(void* state, hipStream_t stream);
 // Host-side fold of a slot buffer copied back from the device.
 void fold_slots_host(const int32_t* slots, int32_t out_keys[2]);
 int minmax_slot_ints();

@@ -200,6 +200,18 @@ class Context:
         self.assume_device_pointers(_device_ptrs)
         C.piquant_hip_quantize_dp(self._ctx, ptr_in, dtype_in.value, ptr_out, dtype_out.value, numel, params_ptr, round_mode.value)
 
+    def quantize_dynamic_ptr(self, ptr_in: int, dtype_in: DataType, ptr_out: int, dtype_out: DataType, numel: int, params_ptr: int,
+                             round_mode: RoundMode, _device_ptrs: bool = False) -> None:
+        """compute_quant_params + quantize as one stream-ordered call; one kernel launch reading the tensor once when it fits on
+        the chip (include/piquant_hip.h, piquant_hip_quantize_dynamic).  The parameter record is written to ``params_ptr``."""
+        assert dtype_in.is_dequantized and dtype_out.is_quantized and params_ptr != 0
+        self.assume_device_pointers(_device_ptrs)
+        C.piquant_hip_quantize_dynamic(self._ctx, ptr_in, dtype_in.value, ptr_out, dtype_out.value, numel, params_ptr, round_mode.value)
+
+    def set_fusion(self, enabled: bool) -> None:
+        """False: ``quantize_dynamic`` always runs scan, parameter kernel and quantize as three launches (for A/B timing)."""
+        C.piquant_hip_set_fusion(self._ctx, 1 if enabled else 0)
+
     def dequantize_dp_ptr(self, ptr_in: int, dtype_in: DataType, ptr_out: int, dtype_out: DataType, numel: int, params_ptr: int,
                           reduce_op: ReduceOp, _device_ptrs: bool = False) -> None:
         assert dtype_in.is_quantized and dtype_out.is_dequantized and params_ptr != 0

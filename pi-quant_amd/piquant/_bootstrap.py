@@ -36,6 +36,8 @@ _DECLS = [
     ('piquant_hip_quantize_dequantize', None, [_vp, _vp, _int, _vp, _int, _sz, _f32, _i64, _int, _int]),
     ('piquant_hip_compute_quant_params_device', None, [_vp, _vp, _int, _sz, _int, _vp]),
     ('piquant_hip_quantize_dp', None, [_vp, _vp, _int, _vp, _int, _sz, _vp, _int]),
+    ('piquant_hip_quantize_dynamic', None, [_vp, _vp, _int, _vp, _int, _sz, _vp, _int]),
+    ('piquant_hip_set_fusion', None, [_vp, _int]),
     ('piquant_hip_dequantize_dp', None, [_vp, _vp, _int, _vp, _int, _sz, _vp, _int]),
     ('piquant_hip_compute_quant_params_dist', None, [_vp, _vp, _int, _sz, _int, _vp, C.POINTER(_f32), C.POINTER(_i64)]),
     ('piquant_hip_minmax_keys', None, [_vp, _vp, _int, _sz, _vp, _int]),

@@ -244,15 +244,20 @@ def compute_quant_params_device(tensor: torch.Tensor, *, dtype: torch.dtype, ctx
 
 def quantize_dynamic(tensor: torch.Tensor, *, dtype: torch.dtype, round_mode: str = 'nearest', ctx: Optional[Context] = None,
                      out: Optional[torch.Tensor] = None, params: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """scan -> parameters -> quantize, all on the device and all asynchronous.  Returns (quantized, parameter record)."""
-    params = compute_quant_params_device(tensor, dtype=dtype, ctx=ctx, out=params)
+    """``compute_quant_params`` + ``quantize`` in one asynchronous call, parameters computed and kept on the device.  Returns
+    (quantized, parameter record).  A tensor that fits on the chip (up to ~113 MB on an MI355X) is read from HBM once, by a single
+    kernel that keeps it in registers / LDS between the min/max pass and the quantization; larger ones take three launches."""
+    assert dtype in _QUANT_TYPES and tensor.is_cuda and tensor.dtype in _DEQUANT_TYPES
     if not tensor.is_contiguous():
         tensor = tensor.contiguous()
+    if params is None:
+        params = torch.empty(PARAMS_NBYTES, dtype=torch.uint8, device=tensor.device)
+    assert params.dtype == torch.uint8 and params.numel() >= PARAMS_NBYTES and params.data_ptr() % 8 == 0
     if out is None:
         out = torch.empty(tensor.shape, dtype=dtype, device=tensor.device)
     ctx = _ctx_for(tensor, ctx)
-    ctx.quantize_dp_ptr(tensor.data_ptr(), torch_to_piquant_dtype(tensor.dtype), out.data_ptr(), torch_to_piquant_dtype(dtype), tensor.numel(),
-                        params.data_ptr(), _ROUND_MODES[round_mode], _device_ptrs=True)
+    ctx.quantize_dynamic_ptr(tensor.data_ptr(), torch_to_piquant_dtype(tensor.dtype), out.data_ptr(), torch_to_piquant_dtype(dtype), tensor.numel(),
+                             params.data_ptr(), _ROUND_MODES[round_mode], _device_ptrs=True)
     return out, params
 
 

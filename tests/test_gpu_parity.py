@@ -806,3 +806,113 @@ def test_reference_layout_head_and_host_chunks(ctx, O):
     # with the mode off every position rounds it up, like the SIMD body
     got = gpu_quantize(ctx, np.full(37, 0.49999997, dtype=np.float32), O.F32, O.UINT8, 1.0, 0)
     assert (got == 1).all()
+
+
+# ---------------------------------------------------------------------------------------------------
+# compute_quant_params + quantize as one launch, tensor resident on chip (piquant_hip_quantize_dynamic, fused_kernels.hpp)
+# ---------------------------------------------------------------------------------------------------
+def gpu_quantize_dynamic(ctx, x, dt_in, dt_out, round_mode=0, offset_in=0):
+    """-> (packed bytes, (scale, zero_point)) through the C ABI, with guard bytes around the output checked."""
+    import struct
+
+    import piquant
+    import torch
+
+    n = x.size
+    nbytes = piquant.DataType(dt_out).packed_nbytes(n)
+    xin, pin = to_device(x, offset_in)
+    obuf = torch.full((nbytes + 128,), 0xAA, dtype=torch.uint8, device="cuda")
+    out = obuf[64: 64 + nbytes]
+    rec = torch.zeros(16, dtype=torch.uint8, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_blocking(False)
+    ctx.quantize_dynamic_ptr(pin if n else 0, piquant.DataType(dt_in), out.data_ptr() if n else 0, piquant.DataType(dt_out), n, rec.data_ptr(),
+                             piquant.RoundMode(round_mode))
+    torch.cuda.synchronize()
+    assert bool((obuf[:64] == 0xAA).all()) and bool((obuf[64 + nbytes:] == 0xAA).all()), "kernel wrote outside the output"
+    scale, _inv, zp = struct.unpack("<ffq", rec.cpu().numpy().tobytes())
+    return out.cpu().numpy(), (scale, zp)
+
+
+def _dynamic_cases(rng, n):
+    base = rng.uniform(-2, 3, n).astype(np.float32)
+    yield "uniform", base
+    with_nan = base.copy()
+    with_nan[rng.choice(n, max(1, n // 50))] = np.nan
+    with_nan[rng.choice(n, max(1, n // 70))] = -np.nan
+    if not np.isnan(with_nan).all():
+        yield "nan", with_nan
+    yield "constant", np.full(n, 42.0, np.float32)
+    yield "far from zero", (np.float32(1e12) + rng.uniform(0, 1e6, n)).astype(np.float32)     # x/scale beyond 2^31: every step hits the x86 indefinite
+    yield "all negative", rng.uniform(-6, -2, n).astype(np.float32)
+    yield "huge range", (rng.normal(size=n) * 1e30).astype(np.float32)
+
+
+def test_fused_dynamic_quantize_matches_oracle_and_three_launch_path(O):
+    import piquant
+
+    rng = np.random.default_rng(2024)
+    fused, plain = piquant.Context(), piquant.Context()
+    plain.set_fusion(False)
+    checked = 0
+    for n in (1, 2, 3, 5, 63, 64, 65, 1000, 4097, 262_144 * 4, 262_144 * 4 + 5, 1_000_003):
+        for dt_in in (0, 1):
+            for dt_out in (4, 3, 2):
+                for name, x in _dynamic_cases(rng, n):
+                    if n > 5000 and name not in ("uniform", "nan", "far from zero"):
+                        continue
+                    xin = x if dt_in == 0 else O.f32_to_bf16(x)
+                    # the scan ignores NaNs (v_min/v_max return the other operand); the reference leaves them unspecified
+                    finite = xin[~np.isnan(x)] if name == "nan" else xin
+                    want_p = O.compute_quant_params(finite, dt_in, dt_out)
+                    if not (want_p[0] > 0) or np.isinf(want_p[0]):
+                        continue          # the reference aborts on such a scale; nothing to compare
+                    want = O.quantize(xin, dt_in, dt_out, want_p[0], want_p[1])
+                    got, got_p = gpu_quantize_dynamic(fused, xin, dt_in, dt_out)
+                    assert (np.float32(got_p[0]).tobytes(), got_p[1]) == (np.float32(want_p[0]).tobytes(), want_p[1]), (n, dt_in, dt_out, name)
+                    assert np.array_equal(got, want), (n, dt_in, dt_out, name)
+                    got3, got3_p = gpu_quantize_dynamic(plain, xin, dt_in, dt_out)
+                    assert got3_p == got_p and np.array_equal(got3, got), (n, dt_in, dt_out, name)
+                    checked += 1
+    assert checked > 300
+
+
+def test_fused_dynamic_quantize_stochastic_modes(O):
+    import piquant
+
+    rng = np.random.default_rng(2025)
+    c = piquant.Context()
+    for n in (7, 1000, 300_001):
+        x = rng.uniform(-2, 3, n).astype(np.float32)
+        for dt_in in (0, 1):
+            xin = x if dt_in == 0 else O.f32_to_bf16(x)
+            for dt_out in (4, 3, 2):
+                scale, zp = O.compute_quant_params(xin, dt_in, dt_out)
+                c.set_stochastic_per_element(False)
+                c.set_stochastic_threshold(0.3125)
+                got, p = gpu_quantize_dynamic(c, xin, dt_in, dt_out, 1)
+                assert p == (scale, zp) and np.array_equal(got, O.quantize(xin, dt_in, dt_out, scale, zp, 1, 0.3125)), (n, dt_in, dt_out)
+                c.set_stochastic_threshold(None)
+                c.set_stochastic_per_element(True, seed=99, index_base=(1 << 32) - 1000)
+                got, p = gpu_quantize_dynamic(c, xin, dt_in, dt_out, 1)
+                assert p == (scale, zp) and np.array_equal(got, O.quantize_per_element(xin, dt_in, dt_out, scale, zp, 99, (1 << 32) - 1000)), (n, dt_in, dt_out)
+
+
+def test_fused_dynamic_quantize_capacity_boundary_headline_size_and_misalignment(O):
+    """The largest tensor the chip holds (27 rounds x 1024 threads x 16 B per CU), one vector more (three-launch fallback), the
+    BASELINE size, and a misaligned input (fallback): all equal the oracle."""
+    import piquant
+    import torch
+
+    c = piquant.Context()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    fits = 27 * 1024 * cus * 4
+    rng = np.random.default_rng(5)
+    for n, off in ((fits, 0), (fits + 4, 0), (fits + 3, 0), (N1, 0), (100_003, 4)):
+        x = rng.uniform(-1, 1, n).astype(np.float32)
+        x[n // 3] = 1.5
+        x[n // 2] = -1.25
+        scale, zp = O.compute_quant_params(x, 0, 4)
+        got, p = gpu_quantize_dynamic(c, x, 0, 4, offset_in=off)
+        assert p == (scale, zp), (n, off)
+        assert np.array_equal(got, O.quantize(x, 0, 4, scale, zp)), (n, off)

@@ -5,12 +5,15 @@
 // sets (> 256 MiB in total, so reads come from HBM, not the Infinity Cache); prints average us per launch and
 // algorithmic GB/s.  The winners are copied into csrc/tuning.hpp by hand, with the CSV kept under profiles/.
 #include "dequant_kernels.hpp"
+#include "fused_kernels.hpp"
 #include "minmax_kernels.hpp"
 #include "quant_kernels.hpp"
 #include "requant_kernels.hpp"
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
@@ -273,6 +276,87 @@ static void run_minmax(const Bufs& b, int64_t numel, int num_cu, int32_t* keys) 
         std::snprintf(name, sizeof name, "in=%s U=%d nt=%d block=%d cap=%d grid=%u", DT_IN == DT_F32 ? "f32" : "bf16", U, NT ? 1 : 0, BLOCK, cap, grid);
         report("minmax", name, us, (DT_IN == DT_F32 ? 4.0 : 2.0) * numel);
     }
+}
+
+
+// fused compute_quant_params + quantize (one launch, tensor resident on chip) against the three-launch path
+struct FusedBufs {
+    FusedState* st;
+    ParamRecord* rec;
+    ParamRecord* rec_ref;
+    uint8_t* out_ref;
+    uint64_t* stamps;
+};
+
+template <int R_REG, int R_LDS, int LDS_BATCH, int BLOCK, int STP = ST_WT>
+static void run_fused(const Bufs& b, const FusedBufs& f, int64_t numel, int num_cu, int32_t* slots) {
+    const int64_t n_vec = numel / 4;
+    char name[128];
+    std::snprintf(name, sizeof name, "f32->u8 fused R_REG=%d R_LDS=%d batch=%d block=%d st=%s", R_REG, R_LDS, LDS_BATCH, BLOCK,
+                  STP == ST_WT ? "wt" : (STP == ST_NT ? "nt" : "plain"));
+    if (fused_rounds(n_vec, num_cu, BLOCK) > R_REG + R_LDS) {
+        std::fprintf(stderr, "%s: tensor does not fit (%d rounds)\n", name, fused_rounds(n_vec, num_cu, BLOCK));
+        return;
+    }
+    QuantParams p {};
+    auto launch = [&](int i) {
+        hipLaunchKernelGGL((fused_params_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, R_REG, R_LDS, LDS_BATCH, BLOCK, STP>), dim3(num_cu), dim3(BLOCK), 0,
+                           g_stream, b.in[i % SETS], static_cast<uint8_t*>(b.out[i % SETS]), numel, p, f.st, f.rec);
+    };
+    // correctness first: same bytes and record as scan -> params -> quantize
+    CK(hipMemsetAsync(b.out[0], 0x5a, numel, g_stream));
+    launch(0);
+    CK(hipStreamSynchronize(g_stream));
+    CK(hipGetLastError());
+    {
+        int32_t* s0 = slots;
+        hipLaunchKernelGGL(arm_slots_kernel, dim3(1), dim3(64), 0, g_stream, s0);
+        hipLaunchKernelGGL((minmax_kernel<DT_F32, 4, true, 256>), dim3(2 * num_cu), dim3(256), 0, g_stream, static_cast<const void*>(b.in[0]), numel, s0,
+                           static_cast<int32_t*>(nullptr));
+        hipLaunchKernelGGL(params_from_slots_kernel, dim3(1), dim3(64), 0, g_stream, static_cast<const int32_t*>(s0), 8, f.rec_ref);
+        QuantParams pd {};
+        pd.dyn = f.rec_ref;
+        using T = QuantTile<DT_F32, 8, 2, 128>;
+        const int64_t n_tiles = numel / T::BLOCK_ELEMS;
+        hipLaunchKernelGGL((quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, 2, true, mem_policy(true, ST_WT), 128>), dim3(static_cast<unsigned>(std::max<int64_t>(n_tiles, 1))),
+                           dim3(128), 0, g_stream, static_cast<const void*>(b.in[0]), f.out_ref, numel, n_tiles, pd);
+        CK(hipStreamSynchronize(g_stream));
+        std::vector<uint8_t> a(numel), c(numel);
+        ParamRecord ra, rc;
+        CK(hipMemcpy(a.data(), b.out[0], numel, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(c.data(), f.out_ref, numel, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(&ra, f.rec, sizeof ra, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(&rc, f.rec_ref, sizeof rc, hipMemcpyDeviceToHost));
+        int64_t bad = 0;
+        for (int64_t i = 0; i < numel; ++i) bad += a[i] != c[i];
+        std::fprintf(stderr, "%s: %lld byte(s) differ; record {%.9g,%.9g,%lld} vs {%.9g,%.9g,%lld}\n", name, static_cast<long long>(bad), ra.scale,
+                     ra.inv_scale, static_cast<long long>(ra.zero_point), rc.scale, rc.inv_scale, static_cast<long long>(rc.zero_point));
+    }
+    const double us = time_us(launch);
+    report("fused", name, us, 5.0 * numel);
+    // where block 0 spends its time (100 MHz wall clock): one launch on a quiet device
+    CK(hipStreamSynchronize(g_stream));
+    hipLaunchKernelGGL((fused_params_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, R_REG, R_LDS, LDS_BATCH, BLOCK, STP, true>), dim3(num_cu), dim3(BLOCK), 0, g_stream,
+                       b.in[3], static_cast<uint8_t*>(b.out[3]), numel, p, f.st, f.rec);
+    CK(hipStreamSynchronize(g_stream));
+    std::vector<uint64_t> t(static_cast<size_t>(num_cu) * 8);
+    CK(hipMemcpy(t.data(), f.stamps, t.size() * 8, hipMemcpyDeviceToHost));
+    uint64_t t_begin = ~0ull;
+    for (int b = 0; b < num_cu; ++b) t_begin = std::min(t_begin, t[b * 8]);
+    auto stats = [&](const char* what, auto get) {
+        std::vector<double> v;
+        for (int b = 0; b < num_cu; ++b) v.push_back(get(b) * 0.01);
+        std::vector<double> sorted = v;
+        std::sort(sorted.begin(), sorted.end());
+        std::fprintf(stderr, "  %-28s min %6.2f  p10 %6.2f  median %6.2f  p90 %6.2f  max %6.2f us   (block 0 %6.2f, 1 %6.2f, 8 %6.2f, 128 %6.2f, last %6.2f)\n", what,
+                     sorted.front(), sorted[sorted.size() / 10], sorted[sorted.size() / 2], sorted[sorted.size() * 9 / 10], sorted.back(), v[0], v[1], v[8],
+                     v[128 % num_cu], v[num_cu - 1]);
+    };
+    stats("start skew", [&](int b) { return static_cast<double>(t[b * 8] - t_begin); });
+    stats("load + minmax", [&](int b) { return static_cast<double>(t[b * 8 + 1] - t[b * 8]); });
+    stats("barrier wait + params", [&](int b) { return static_cast<double>(t[b * 8 + 2] - t[b * 8 + 1]); });
+    stats("quantize + store issue", [&](int b) { return static_cast<double>(t[b * 8 + 4] - t[b * 8 + 3]); });
+    stats("end (since first start)", [&](int b) { return static_cast<double>(t[b * 8 + 4] - t_begin); });
 }
 
 int main(int argc, char** argv) {
@@ -575,6 +659,42 @@ int main(int argc, char** argv) {
         run_minmax<DT_F32, 4, true, 512>(b, numel, num_cu, keys);
         run_minmax<DT_BF16, 4, true, 256>(b, 2 * numel, num_cu, keys);
         run_minmax<DT_BF16, 8, true, 256>(b, 2 * numel, num_cu, keys);
+    }
+
+    if (only == "fused") {
+        FusedBufs f {};
+        CK(hipMalloc(reinterpret_cast<void**>(&f.st), sizeof(FusedState)));
+        CK(hipMemset(f.st, 0, sizeof(FusedState)));
+        CK(hipMalloc(reinterpret_cast<void**>(&f.rec), 64));
+        CK(hipMalloc(reinterpret_cast<void**>(&f.rec_ref), 64));
+        CK(hipMalloc(reinterpret_cast<void**>(&f.out_ref), numel + 4096));
+        CK(hipMalloc(reinterpret_cast<void**>(&f.stamps), static_cast<size_t>(num_cu) * 64));
+        CK(hipMemcpy(reinterpret_cast<char*>(f.st) + offsetof(FusedState, stamps), &f.stamps, sizeof(void*), hipMemcpyHostToDevice));
+        CK(hipStreamSynchronize(g_stream));
+        // the three-launch path it replaces, timed the same way
+        {
+            QuantParams pd {};
+            pd.dyn = f.rec_ref;
+            using T = QuantTile<DT_F32, 8, 2, 128>;
+            const int64_t n_tiles = numel / T::BLOCK_ELEMS;
+            int flip = 0;
+            const double us = time_us([&](int i) {
+                int32_t* s0 = keys + (flip & 1) * kMinmaxSlotInts;
+                int32_t* s1 = keys + ((flip ^ 1) & 1) * kMinmaxSlotInts;
+                ++flip;
+                hipLaunchKernelGGL((minmax_kernel<DT_F32, 4, true, 256>), dim3(2 * num_cu), dim3(256), 0, g_stream, static_cast<const void*>(b.in[i % SETS]), numel,
+                                   s0, s1);
+                hipLaunchKernelGGL(params_from_slots_kernel, dim3(1), dim3(64), 0, g_stream, static_cast<const int32_t*>(s0), 8, f.rec_ref);
+                hipLaunchKernelGGL((quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, 2, true, mem_policy(true, ST_WT), 128>), dim3(static_cast<unsigned>(std::max<int64_t>(n_tiles, 1))),
+                                   dim3(128), 0, g_stream, static_cast<const void*>(b.in[i % SETS]), static_cast<uint8_t*>(b.out[i % SETS]), numel, n_tiles, pd);
+            });
+            report("fused", "f32->u8 three launches (scan, params, quantize)", us, 9.0 * numel);
+        }
+        run_fused<40, 18, 18, 512>(b, f, numel, num_cu, keys);
+        run_fused<18, 9, 9, 1024>(b, f, numel, num_cu, keys);
+        run_fused<18, 9, 9, 1024, ST_NT>(b, f, numel, num_cu, keys);
+        run_fused<19, 8, 8, 1024>(b, f, numel, num_cu, keys);
+        run_fused<20, 8, 8, 1024>(b, f, numel, num_cu, keys);
     }
     return 0;
 }
