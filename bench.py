@@ -320,8 +320,15 @@ def main():
             rec = torch.empty(16, dtype=torch.uint8, device=dev)
             _, e = time_loop(lambda i: piquant.torch.quantize_dynamic(xs[i % nsets], dtype=torch.uint8, ctx=ctx, out=outs[i % nsets], params=rec),
                              reps, stream)
-            extras["quantize_dynamic_f32_u8"] = {"GB/s": gbs(9, e, reps), "avg_us_per_call": round(e / reps * 1e6, 3),
-                                                 "note": "min/max scan + on-device epilogue + quantize, three launches, no host sync (9 B/elem: x read twice)"}
+            extras["quantize_dynamic_f32_u8"] = {"GB/s": gbs(5, e, reps), "avg_us_per_call": round(e / reps * 1e6, 3),
+                                                 "note": "compute_quant_params + quantize as ONE launch: the tensor stays in VGPRs/LDS between the min/max pass and "
+                                                         "the quantization (5 B/elem of HBM traffic, x read once); no host sync"}
+            ctx.set_fusion(False)
+            _, e = time_loop(lambda i: piquant.torch.quantize_dynamic(xs[i % nsets], dtype=torch.uint8, ctx=ctx, out=outs[i % nsets], params=rec),
+                             reps, stream)
+            ctx.set_fusion(True)
+            extras["quantize_dynamic_f32_u8_three_launches"] = {"GB/s": gbs(9, e, reps), "avg_us_per_call": round(e / reps * 1e6, 3),
+                                                                "note": "same call with fusion off: scan + on-device epilogue + quantize (9 B/elem: x read twice)"}
             ctx.set_stream(stream.cuda_stream)
             ctx.set_blocking(False)
             keys = torch.empty(2, dtype=torch.int32, device=dev)

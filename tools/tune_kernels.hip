@@ -665,6 +665,8 @@ int main(int argc, char** argv) {
         FusedBufs f {};
         CK(hipMalloc(reinterpret_cast<void**>(&f.st), sizeof(FusedState)));
         CK(hipMemset(f.st, 0, sizeof(FusedState)));
+        hipLaunchKernelGGL(arm_slots_kernel, dim3(1), dim3(64), 0, g_stream, &f.st->slots[0][0]);
+        hipLaunchKernelGGL(arm_slots_kernel, dim3(1), dim3(64), 0, g_stream, &f.st->slots[1][0]);
         CK(hipMalloc(reinterpret_cast<void**>(&f.rec), 64));
         CK(hipMalloc(reinterpret_cast<void**>(&f.rec_ref), 64));
         CK(hipMalloc(reinterpret_cast<void**>(&f.out_ref), numel + 4096));
@@ -690,11 +692,15 @@ int main(int argc, char** argv) {
             });
             report("fused", "f32->u8 three launches (scan, params, quantize)", us, 9.0 * numel);
         }
-        run_fused<40, 18, 18, 512>(b, f, numel, num_cu, keys);
         run_fused<18, 9, 9, 1024>(b, f, numel, num_cu, keys);
         run_fused<18, 9, 9, 1024, ST_NT>(b, f, numel, num_cu, keys);
-        run_fused<19, 8, 8, 1024>(b, f, numel, num_cu, keys);
+        run_fused<18, 9, 9, 1024, ST_PLAIN>(b, f, numel, num_cu, keys);
+        run_fused<18, 9, 3, 1024>(b, f, numel, num_cu, keys);
         run_fused<20, 8, 8, 1024>(b, f, numel, num_cu, keys);
+        run_fused<40, 18, 18, 512>(b, f, numel, num_cu, keys);
+        run_fused<40, 18, 6, 512>(b, f, numel, num_cu, keys);
+        run_fused<48, 10, 10, 512>(b, f, numel, num_cu, keys);
+        run_fused<80, 36, 12, 256>(b, f, numel, num_cu, keys);
     }
     return 0;
 }
