@@ -172,6 +172,53 @@ constexpr size_t kStageChunkElems = size_t{1} << 24;
 // blocking fp32->uint8 call at numel 27 264 000.)
 void wait_stream(hipStream_t stream) { PQ_HIP(hipStreamSynchronize(stream)); }
 
+// Two grid-barrier kernels dispatched at the same moment from different streams could each take part of the CUs and wait
+// forever for the rest (fused_kernels.hpp).  Launches on ONE stream are ordered by the stream.  The first time a second
+// stream issues a fused launch on a device, the device is synchronised once and from then on every fused launch records an
+// event that the next fused launch on a different stream waits for.  A process that keeps to one stream pays nothing.
+struct FusedOrder {
+    std::mutex mu;
+    hipStream_t last_stream = nullptr;
+    bool seen = false;
+    bool multi_stream = false;
+    hipEvent_t last = nullptr;
+};
+
+FusedOrder& fused_order(int device) {
+    static FusedOrder per_device[64];
+    return per_device[device & 63];
+}
+
+bool stream_is_capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+}
+
+// call before a fused launch on `stream`; returns true if an event must be recorded after it (fused_order_after)
+bool fused_order_before(int device, hipStream_t stream) {
+    if (stream_is_capturing(stream)) return false;   // a graph is replayed as a unit; its launches are ordered inside it
+    FusedOrder& o = fused_order(device);
+    std::lock_guard<std::mutex> lock(o.mu);
+    if (o.seen && o.last_stream != stream) {
+        if (!o.multi_stream) {
+            PQ_HIP(hipDeviceSynchronize());
+            PQ_HIP(hipEventCreateWithFlags(&o.last, hipEventDisableTiming));
+            o.multi_stream = true;
+        } else {
+            PQ_HIP(hipStreamWaitEvent(stream, o.last, 0));
+        }
+    }
+    o.seen = true;
+    o.last_stream = stream;
+    return o.multi_stream;
+}
+
+void fused_order_after(int device, hipStream_t stream) {
+    FusedOrder& o = fused_order(device);
+    std::lock_guard<std::mutex> lock(o.mu);
+    PQ_HIP(hipEventRecord(o.last, stream));
+}
+
 float draw_threshold(piquant_context_t* ctx) {
     if (ctx->fixed_threshold >= 0.0f) return ctx->fixed_threshold;
     return std::uniform_real_distribution<float>{0.0f, 1.0f}(ctx->rng);   // reference src/piquant.cpp:199-200
@@ -211,6 +258,7 @@ piquant_context_t* piquant_context_create(size_t num_threads) {
         ctx->mailbox_dev = nullptr;   // no fine-grained host memory: compute_quant_params falls back to D2H + sync
     }
     PQ_HIP(hipDeviceSynchronize());   // the arming memsets ran on the null stream; scans may run on any stream
+    if (const char* env = std::getenv("PIQUANT_HIP_FUSION")) ctx->fusion = !(env[0] == '0' && env[1] == '\0');
     std::random_device rd;
     ctx->rng.seed((static_cast<uint64_t>(rd()) << 32) ^ rd());
     return ctx;
@@ -567,7 +615,13 @@ void piquant_hip_quantize_dynamic(piquant_context_t* ctx, const void* in, piquan
     }
     // One launch with the tensor held on chip between the scan and the quantization when it fits; otherwise (or with fusion
     // switched off) the same result from three launches: scan, parameter epilogue, quantize reading the record.
-    if (!(ctx->fusion && launch_fused_params_quantize(q, ctx->d_fused, rp.dev, ctx->stream, ctx->num_cu))) {
+    bool fused = false;
+    if (ctx->fusion && fused_launch_applies(q, ctx->num_cu)) {
+        const bool record = fused_order_before(ctx->device, ctx->stream);
+        fused = launch_fused_params_quantize(q, ctx->d_fused, rp.dev, ctx->stream, ctx->num_cu);
+        if (fused && record) fused_order_after(ctx->device, ctx->stream);
+    }
+    if (!fused) {
         const int32_t* slots = scan_into_slots(ctx, rin.dev, dtype_in, numel);
         launch_params_from_slots(slots, dto.bits, rp.dev, ctx->stream);
         q.dyn_params = rp.dev;

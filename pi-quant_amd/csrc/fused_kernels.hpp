@@ -18,6 +18,12 @@
 // The arithmetic is the same code as the two-pass path (minmax keys, params epilogue, quant_nearest_fast2 / quant_one), so
 // the output bytes and the record are identical to compute_quant_params_device + quantize_dp -- tests compare them.
 //
+// Co-residency: the barrier needs all blocks on the chip at once.  A block takes a whole CU (144 KiB of LDS), the grid never
+// exceeds the CU count, and kernels that do not wait on this one only delay it.  What must not happen is TWO barrier kernels
+// being dispatched at the same instant, each getting part of the CUs and waiting for the rest: within a process the host
+// layer orders fused launches of different streams behind one another (capi.cpp, FusedOrder); processes that share one GPU
+// must switch the fused path off (PIQUANT_HIP_FUSION=0 / piquant_hip_set_fusion) -- the design rule is one process per GPU.
+//
 // Capacity: (R_REG + R_LDS) x 16 B x BLOCK threads x grid blocks (121.6 MB at 256 CUs).  The host launches this kernel
 // only when the tensor fits and both pointers are 16-byte aligned, and otherwise takes the three-launch path.
 //
@@ -292,7 +298,7 @@ fused_params_quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ 
                 uint32_t spins = 0;
                 while (((pub = __hip_atomic_load(&st->published, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 41) != (tag >> 41)) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 21)) __builtin_trap();   // ~1 s: a block that never arrives must fail the launch, not hang the device
+                    if (++spins > (1u << 23)) __builtin_trap();   // several seconds: a block that never arrives must fail the launch, not hang the device
                 }
             }
         }

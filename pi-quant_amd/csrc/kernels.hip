@@ -186,11 +186,15 @@ void init_fused_state(void* state, hipStream_t stream) {
     launch_arm_slots(&st->slots[1][0], stream);
 }
 
-bool launch_fused_params_quantize(const QuantLaunch& q, void* state, void* device_param_record, hipStream_t stream, int num_cu) {
+bool fused_launch_applies(const QuantLaunch& q, int num_cu) {
     if (q.numel <= 0 || q.ref_layout || !aligned16(q.in) || !aligned16(q.out)) return false;
     if (q.dt_in != DT_F32 && q.dt_in != DT_BF16) panic("invalid quantization types: %d -> %d", q.dt_in, q.dt_out);
     const int64_t n_vec = q.numel / (q.dt_in == DT_F32 ? 4 : 8);
-    if (fused_rounds(n_vec, num_cu, kFusedBlock) > kFusedRegRounds + kFusedLdsRounds) return false;   // does not fit on chip
+    return fused_rounds(n_vec, num_cu, kFusedBlock) <= kFusedRegRounds + kFusedLdsRounds;   // does the tensor fit on the chip?
+}
+
+bool launch_fused_params_quantize(const QuantLaunch& q, void* state, void* device_param_record, hipStream_t stream, int num_cu) {
+    if (!fused_launch_applies(q, num_cu)) return false;
     QuantParams p {};
     p.threshold = q.threshold;
     p.seed_lo = static_cast<uint32_t>(q.seed);

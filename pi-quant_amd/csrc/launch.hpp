@@ -83,6 +83,7 @@ void launch_params_from_slots(const int32_t* slots, int bits, void* device_param
 // without launching when the call does not qualify (tensor larger than the chip holds, misaligned buffers, reference-layout
 // mode): the caller then runs scan -> params -> quantize as three launches, with identical results.
 bool launch_fused_params_quantize(const QuantLaunch& q, void* state, void* device_param_record, hipStream_t stream, int num_cu);
+bool fused_launch_applies(const QuantLaunch& q, int num_cu);   // the test launch_fused_params_quantize makes, without launching
 size_t fused_state_bytes();
 void init_fused_state(void* state, hipStream_t stream);
 // Host-side fold of a slot buffer copied back from the device.

@@ -916,3 +916,29 @@ def test_fused_dynamic_quantize_capacity_boundary_headline_size_and_misalignment
         got, p = gpu_quantize_dynamic(c, x, 0, 4, offset_in=off)
         assert p == (scale, zp), (n, off)
         assert np.array_equal(got, O.quantize(x, 0, 4, scale, zp)), (n, off)
+
+
+def test_fused_dynamic_quantize_from_two_streams_and_contexts(O):
+    """Fused launches carry a grid barrier; launches issued on different streams are ordered behind one another by the library.
+    Interleave two contexts on two streams without synchronising in between and check every result."""
+    import piquant
+    import torch
+
+    rng = np.random.default_rng(77)
+    n = 2_000_003
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    ctxs = [piquant.Context(), piquant.Context()]
+    xs = [rng.uniform(-1 - i, 2 + i, n).astype(np.float32) for i in range(6)]
+    xd = [torch.from_numpy(x).cuda() for x in xs]
+    outs = [torch.empty(n, dtype=torch.uint8, device="cuda") for _ in xs]
+    recs = [torch.zeros(16, dtype=torch.uint8, device="cuda") for _ in xs]
+    torch.cuda.synchronize()
+    for rep in range(20):
+        for i in range(len(xs)):
+            with torch.cuda.stream(streams[i % 2]):
+                piquant.torch.quantize_dynamic(xd[i], dtype=torch.uint8, ctx=ctxs[i % 2], out=outs[i], params=recs[i])
+    torch.cuda.synchronize()
+    for i, x in enumerate(xs):
+        scale, zp = O.compute_quant_params(x, 0, 4)
+        assert piquant.torch.params_to_host(recs[i]) == (scale, zp)
+        assert np.array_equal(outs[i].cpu().numpy(), O.quantize(x, 0, 4, scale, zp))
