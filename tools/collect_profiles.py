@@ -52,6 +52,14 @@ def main():
                       f"reported; raw summaries in profiles/{rnd}_pmc_summary.json"}}
         (PROF / "hbm_traffic.json").write_text(json.dumps(traffic, indent=1))
         done.append("hbm_traffic.json")
+    dyn = OUT / "dyn_summary.json"
+    if dyn.exists() and dyn.stat().st_size:
+        doc = {"command": "rocprofv3 --kernel-trace {--stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE} -- python tools/dynamic_quantize_workload.py "
+                          "(60 fused calls, then 60 calls with fusion off; fp32 -> uint8, numel 27 264 000, 6 rotating buffer sets)",
+               "units": "per launch: median HBM MB from the counters (FETCH_SIZE KiB x2 on gfx950, WRITE_SIZE KiB), average duration from --stats",
+               "kernels": json.loads(dyn.read_text())}
+        (PROF / f"{rnd}_dynamic_quantize_pmc.json").write_text(json.dumps(doc, indent=1))
+        done.append(f"{rnd}_dynamic_quantize_pmc.json")
     print("updated:", ", ".join(done))
 
 

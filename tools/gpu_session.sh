@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session: smoke, GPU tests, kernel sweep, bench, rocprof.  Usage (from the repo root, via gpurun):
-#   gpurun --timeout 1800 -- 'bash tools/gpu_session.sh [phases...]'      phases: smoke tests tune bench prof pmc
+#   gpurun --timeout 1800 -- 'bash tools/gpu_session.sh [phases...]'      phases: smoke tests tune bench prof pmc dyn
 # Everything is written under gpurun_out/ (merged back by gpurun).
 set -u
 cd "$(dirname "$0")/.."
@@ -25,6 +25,11 @@ for ph in $PHASES; do
            (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d "$OLDPWD/$OUT/pmc_fetch" -o pmc -- python "$OLDPWD/bench.py" --steps 60 --warmup 10 --no-cpu-baseline --no-extras > /dev/null 2> "$OLDPWD/$OUT/pmc_fetch.err"); echo "pmc fetch rc=$?" | tee -a $OUT/session.log
            (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d "$OLDPWD/$OUT/pmc_write" -o pmc -- python "$OLDPWD/bench.py" --steps 60 --warmup 10 --no-cpu-baseline --no-extras > /dev/null 2> "$OLDPWD/$OUT/pmc_write.err"); echo "pmc write rc=$?" | tee -a $OUT/session.log
            python tools/summarize_pmc.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_summary.json 2> $OUT/pmc_summary.err; cat $OUT/pmc_summary.json ;;
+    dyn)   rm -rf $OUT/dyn_stats $OUT/dyn_fetch $OUT/dyn_write
+           (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d "$OLDPWD/$OUT/dyn_stats" -o dyn -- python "$OLDPWD/tools/dynamic_quantize_workload.py" > /dev/null 2> "$OLDPWD/$OUT/dyn_stats.err"); echo "dyn stats rc=$?" | tee -a $OUT/session.log
+           (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d "$OLDPWD/$OUT/dyn_fetch" -o dyn -- python "$OLDPWD/tools/dynamic_quantize_workload.py" > /dev/null 2> "$OLDPWD/$OUT/dyn_fetch.err"); echo "dyn fetch rc=$?" | tee -a $OUT/session.log
+           (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d "$OLDPWD/$OUT/dyn_write" -o dyn -- python "$OLDPWD/tools/dynamic_quantize_workload.py" > /dev/null 2> "$OLDPWD/$OUT/dyn_write.err"); echo "dyn write rc=$?" | tee -a $OUT/session.log
+           python tools/summarize_pmc_by_kernel.py $OUT/dyn_fetch $OUT/dyn_write "$(find $OUT/dyn_stats -name '*kernel_stats.csv' | head -1)" > $OUT/dyn_summary.json 2> $OUT/dyn_summary.err; cat $OUT/dyn_summary.json ;;
   esac
 done
 echo "=== done $(date +%T)" | tee -a $OUT/session.log

@@ -14,7 +14,7 @@ def collect(root, counter):
     for f in Path(root).rglob("*counter_collection.csv"):
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                if row.get("Counter_Name") == counter and "quantize_kernel" in row.get("Kernel_Name", ""):
+                if row.get("Counter_Name") == counter and "pq::quantize_kernel<" in row.get("Kernel_Name", ""):
                     vals.append(float(row["Counter_Value"]))
     return vals
 
