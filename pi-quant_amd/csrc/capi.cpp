@@ -113,18 +113,14 @@ struct piquant_context_t {
     bool blocking = true;
     bool assume_device = false;            // skip hipPointerGetAttributes (piquant_hip_assume_device_pointers)
 
-    // Min/max scan state: two slot buffers on the device (see minmax_kernels.hpp).  Calls alternate between them;
-    // the scan that fills one re-arms the other (idle) one, so no separate initialisation launch precedes a scan.
-    // Invariant: d_slots[slot] is armed (all identity) whenever no scan is in flight.
-    int32_t* d_slots[2] = {nullptr, nullptr};
-    int slot = 0;
-    int32_t* d_slots_capture = nullptr;    // slot buffer of scans recorded into a hipGraph (armed by a node of the graph itself)
-    int32_t* h_slots = nullptr;            // pinned mirror of the buffer just scanned (fallback path)
+    // Min/max scan state (minmax_kernels.hpp): slot keys + arrival counters.  Every scan leaves it armed.
+    int32_t* d_state = nullptr;
+    int32_t* h_keys = nullptr;             // pinned int32[2]: D2H landing zone of the folded keys (fallback / sharded path)
     MinmaxMailboxHost* mailbox = nullptr;  // pinned fine-grained host memory the fold kernel publishes into
     void* mailbox_dev = nullptr;           // its device-visible address
     uint32_t mailbox_seq = 0;
     int32_t* d_dist_keys = nullptr;        // {key(min), key(-max)} buffer the RCCL all-reduce of the *_dist call runs on
-    hipStream_t scan_stream = nullptr;     // stream of the previous scan (re-arming relies on stream order)
+    hipStream_t scan_stream = nullptr;     // stream of the previous scan (scans of one context must not overlap)
     void* d_fused = nullptr;               // FusedState of the one-launch params + quantize kernel (fused_kernels.hpp)
     bool fusion = true;                    // piquant_hip_set_fusion
 
@@ -240,15 +236,12 @@ piquant_context_t* piquant_context_create(size_t num_threads) {
     PQ_HIP(hipDeviceGetAttribute(&ctx->num_cu, hipDeviceAttributeMultiprocessorCount, ctx->device));
     PQ_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
-    const size_t slot_bytes = static_cast<size_t>(minmax_slot_ints()) * sizeof(int32_t);
-    for (auto& p : ctx->d_slots) {
-        PQ_HIP(hipMalloc(reinterpret_cast<void**>(&p), slot_bytes));
-        PQ_HIP(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p), float_to_key(std::numeric_limits<float>::max()), minmax_slot_ints()));
-    }
-    PQ_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_slots_capture), slot_bytes));
+    PQ_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_state), static_cast<size_t>(minmax_state_ints()) * sizeof(int32_t)));
+    launch_arm_slots(ctx->d_state, nullptr);
+    PQ_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_dist_keys), 2 * sizeof(int32_t)));
     PQ_HIP(hipMalloc(&ctx->d_fused, fused_state_bytes()));
     init_fused_state(ctx->d_fused, nullptr);
-    PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_slots), slot_bytes, hipHostMallocDefault));
+    PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_keys), 2 * sizeof(int32_t), hipHostMallocDefault));
     if (hipHostMalloc(reinterpret_cast<void**>(&ctx->mailbox), sizeof(MinmaxMailboxHost), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
         hipHostGetDevicePointer(&ctx->mailbox_dev, ctx->mailbox, 0) == hipSuccess) {
         ctx->mailbox->keys[0] = ctx->mailbox->keys[1] = 0;
@@ -275,11 +268,9 @@ void piquant_context_destroy(piquant_context_t* ctx) {
             if (p) (void)hipFree(p);
         for (auto& p : ctx->stage_out)
             if (p) (void)hipFree(p);
-        for (auto& p : ctx->d_slots)
-            if (p) (void)hipFree(p);
-        if (ctx->d_slots_capture) (void)hipFree(ctx->d_slots_capture);
+        if (ctx->d_state) (void)hipFree(ctx->d_state);
         if (ctx->d_fused) (void)hipFree(ctx->d_fused);
-        if (ctx->h_slots) (void)hipHostFree(ctx->h_slots);
+        if (ctx->h_keys) (void)hipHostFree(ctx->h_keys);
         if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
         if (ctx->d_dist_keys) (void)hipFree(ctx->d_dist_keys);
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -502,36 +493,26 @@ void piquant_hip_quantize_dequantize(piquant_context_t* ctx, const void* in, piq
     if (ctx->blocking) wait_stream(ctx->stream);
 }
 
-// Scans x into the context's armed slot buffer (re-arming the idle one for the next call) and returns the buffer
-// that now holds the per-slot {key(min), key(-max)} pairs.  Caller holds ctx->mu and the device guard.
-static int32_t* scan_into_slots(piquant_context_t* ctx, const void* x, piquant_dtype_t dtype, size_t n) {
-    // A scan recorded into a hipGraph is replayed many times with the pointers it was recorded with, so it cannot take part
-    // in the alternating re-arm scheme below (its slot buffer would still hold the previous replay's extremes): a captured
-    // scan uses a buffer of its own and the graph starts with a node that arms it.
-    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(ctx->stream, &capture) != hipSuccess) {
-        (void)hipGetLastError();
-        capture = hipStreamCaptureStatusNone;
-    }
-    if (capture == hipStreamCaptureStatusActive) {
-        const Resolved rc = ctx->resolve_ptr(x);
-        if (rc.pageable) panic("a min/max scan of host memory cannot be captured into a hipGraph (it needs staging copies and synchronisation)");
-        launch_arm_slots(ctx->d_slots_capture, ctx->stream);
-        launch_minmax(rc.dev, dtype, static_cast<int64_t>(n), ctx->d_slots_capture, nullptr, ctx->stream, ctx->num_cu);
-        return ctx->d_slots_capture;
-    }
-    // the previous scan re-armed this call's buffer in ITS stream: keep that ordering if the stream changed
-    if (ctx->scan_stream && ctx->scan_stream != ctx->stream) PQ_HIP(hipStreamSynchronize(ctx->scan_stream));
-    int32_t* cur = ctx->d_slots[ctx->slot];
-    int32_t* idle = ctx->d_slots[ctx->slot ^ 1];
-    ctx->slot ^= 1;
+// Min/max scan of x with `action` as its epilogue (launch.hpp): one launch for device input; staged chunks plus a fold launch
+// for pageable host input; for an empty input the fold of the armed state (the identities, reference
+// kernels_specialized.inl:1422-1423).  Stream-ordered on ctx->stream except for host input, which completes before returning.
+// Caller holds ctx->mu and the device guard.
+static void scan(piquant_context_t* ctx, const void* x, piquant_dtype_t dtype, size_t n, const MinmaxAction& action) {
+    // scans of one context share one state buffer: they must not overlap, which stream order guarantees on one stream
+    if (ctx->scan_stream && ctx->scan_stream != ctx->stream && !stream_is_capturing(ctx->stream)) PQ_HIP(hipStreamSynchronize(ctx->scan_stream));
     ctx->scan_stream = ctx->stream;
+    if (n == 0) {
+        launch_minmax_epilogue(ctx->d_state, action, false, ctx->stream);
+        return;
+    }
     const Resolved r = ctx->resolve_ptr(x);
     if (!r.pageable) {
-        launch_minmax(r.dev, dtype, static_cast<int64_t>(n), cur, idle, ctx->stream, ctx->num_cu);
-        return cur;
+        launch_minmax(r.dev, dtype, static_cast<int64_t>(n), ctx->d_state, action, ctx->stream, ctx->num_cu);
+        return;
     }
-    // host input: stream it through device scratch; all chunks fold into the same slots
+    if (stream_is_capturing(ctx->stream))
+        panic("a min/max scan of host memory cannot be captured into a hipGraph (it needs staging copies and synchronisation)");
+    // host input: stream it through device scratch; all chunks fold into the same slots, one fold launch at the end
     PQ_HIP(hipStreamSynchronize(ctx->stream));
     const size_t chunk = std::min(n, kStageChunkElems);
     ctx->ensure_stage(span_bytes(chunk, dtype), 0);
@@ -540,10 +521,10 @@ static int32_t* scan_into_slots(piquant_context_t* ctx, const void* x, piquant_d
         const size_t m = std::min(chunk, n - off);
         hipStream_t s = ctx->stage_stream[s_i];
         PQ_HIP(hipMemcpyAsync(ctx->stage_in[s_i], static_cast<const char*>(x) + span_bytes(off, dtype), span_bytes(m, dtype), hipMemcpyHostToDevice, s));
-        launch_minmax(ctx->stage_in[s_i], dtype, static_cast<int64_t>(m), cur, off == 0 ? idle : nullptr, s, ctx->num_cu);
+        launch_minmax(ctx->stage_in[s_i], dtype, static_cast<int64_t>(m), ctx->d_state, MinmaxAction {}, s, ctx->num_cu);
     }
     for (auto& s : ctx->stage_stream) PQ_HIP(hipStreamSynchronize(s));
-    return cur;
+    launch_minmax_epilogue(ctx->d_state, action, true, ctx->stream);
 }
 
 void piquant_hip_minmax_keys(piquant_context_t* ctx, const void* x, piquant_dtype_t dtype, size_t n, int32_t* device_keys, int init) {
@@ -553,12 +534,13 @@ void piquant_hip_minmax_keys(piquant_context_t* ctx, const void* x, piquant_dtyp
     if (n != 0 && !x) panic("piquant_hip_minmax_keys: NULL input");
     std::lock_guard<std::mutex> lock(ctx->mu);
     DeviceGuard guard(ctx->device);
-    if (n == 0) {   // nothing to scan: an armed buffer folds to the identity (reference kernels_specialized.inl:1422-1423)
-        if (init) launch_fold_slots(ctx->d_slots[ctx->slot], device_keys, true, ctx->stream);
-        return;
-    }
-    const int32_t* slots = scan_into_slots(ctx, x, dtype, n);
-    launch_fold_slots(slots, device_keys, init != 0, ctx->stream);
+    if (n == 0 && !init) return;   // nothing to scan, nothing to overwrite
+    const Resolved rk = resolve(device_keys);
+    if (rk.pageable) panic("piquant_hip_minmax_keys: the key buffer must live in device (or pinned) memory");
+    MinmaxAction a;
+    a.action = init ? MM_KEYS_SET : MM_KEYS_MIN;
+    a.dst = rk.dev;
+    scan(ctx, x, dtype, n, a);
 }
 
 void piquant_hip_compute_quant_params_device(piquant_context_t* ctx, const void* x, piquant_dtype_t dtype, size_t n, piquant_dtype_t target_quant_dtype,
@@ -572,9 +554,11 @@ void piquant_hip_compute_quant_params_device(piquant_context_t* ctx, const void*
     DeviceGuard guard(ctx->device);
     const Resolved rp = resolve(device_params);
     if (rp.pageable) panic("piquant_hip_compute_quant_params_device: the parameter record must live in device (or pinned) memory");
-    // n == 0: an armed slot buffer folds to the identities, like the synchronous call
-    const int32_t* slots = n == 0 ? ctx->d_slots[ctx->slot] : scan_into_slots(ctx, x, dtype, n);
-    launch_params_from_slots(slots, dtype_of(target_quant_dtype).bits, rp.dev, ctx->stream);
+    MinmaxAction a;
+    a.action = MM_PARAMS;
+    a.bits = dtype_of(target_quant_dtype).bits;
+    a.dst = rp.dev;
+    scan(ctx, x, dtype, n, a);   // n == 0: the identities fold to the degenerate range, like the synchronous call
 }
 
 void piquant_hip_quantize_dynamic(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out, size_t numel,
@@ -592,8 +576,12 @@ void piquant_hip_quantize_dynamic(piquant_context_t* ctx, const void* in, piquan
     DeviceGuard guard(ctx->device);
     const Resolved rp = resolve(device_params);
     if (rp.pageable) panic("piquant_hip_quantize_dynamic: the parameter record must live in device (or pinned) memory");
+    MinmaxAction params_action;
+    params_action.action = MM_PARAMS;
+    params_action.bits = dto.bits;
+    params_action.dst = rp.dev;
     if (numel == 0) {   // parameters of an empty tensor: the identities fold to the degenerate range, as in the synchronous call
-        launch_params_from_slots(ctx->d_slots[ctx->slot], dto.bits, rp.dev, ctx->stream);
+        scan(ctx, nullptr, dtype_in, 0, params_action);
         if (ctx->blocking) wait_stream(ctx->stream);
         return;
     }
@@ -622,8 +610,7 @@ void piquant_hip_quantize_dynamic(piquant_context_t* ctx, const void* in, piquan
         if (fused && record) fused_order_after(ctx->device, ctx->stream);
     }
     if (!fused) {
-        const int32_t* slots = scan_into_slots(ctx, rin.dev, dtype_in, numel);
-        launch_params_from_slots(slots, dto.bits, rp.dev, ctx->stream);
+        scan(ctx, rin.dev, dtype_in, numel, params_action);
         q.dyn_params = rp.dev;
         launch_quantize(q, ctx->stream, ctx->num_cu);
     }
@@ -670,16 +657,16 @@ void piquant_hip_compute_quant_params_dist(piquant_context_t* ctx, const void* l
     {
         std::lock_guard<std::mutex> lock(ctx->mu);
         DeviceGuard guard(ctx->device);
-        if (!ctx->d_dist_keys) PQ_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_dist_keys), 2 * sizeof(int32_t)));
-        // an empty local shard contributes the identities: fold of an armed slot buffer
-        const int32_t* slots = n_local == 0 ? ctx->d_slots[ctx->slot] : scan_into_slots(ctx, local_shard, dtype, n_local);
-        launch_fold_slots(slots, ctx->d_dist_keys, true, ctx->stream);
+        MinmaxAction a;
+        a.action = MM_KEYS_SET;
+        a.dst = ctx->d_dist_keys;
+        scan(ctx, local_shard, dtype, n_local, a);   // an empty local shard contributes the identities
         const int rc = all_reduce(ctx->d_dist_keys, ctx->d_dist_keys, 2, /*ncclInt32*/ 2, /*ncclMin*/ 3, nccl_comm, ctx->stream);
         if (rc != 0) panic("piquant_hip_compute_quant_params_dist: ncclAllReduce failed with code %d", rc);
-        PQ_HIP(hipMemcpyAsync(ctx->h_slots, ctx->d_dist_keys, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        PQ_HIP(hipMemcpyAsync(ctx->h_keys, ctx->d_dist_keys, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
         PQ_HIP(hipStreamSynchronize(ctx->stream));
-        keys[0] = ctx->h_slots[0];
-        keys[1] = ctx->h_slots[1];
+        keys[0] = ctx->h_keys[0];
+        keys[1] = ctx->h_keys[1];
     }
     float lo, hi;
     piquant_hip_decode_minmax_keys(keys, &lo, &hi);
@@ -724,12 +711,15 @@ static void compute_params(piquant_context_t* ctx, const void* x, piquant_dtype_
     } else {
         std::lock_guard<std::mutex> lock(ctx->mu);
         DeviceGuard guard(ctx->device);
-        const int32_t* slots = scan_into_slots(ctx, x, dt, n);
         bool have = false;
         if (ctx->mailbox_dev) {
-            // one-wave fold kernel publishes {keys, seq} straight into pinned host memory; spin on seq
+            // the scan's last block publishes {keys, seq} straight into pinned host memory; spin on seq
             const uint32_t seq = ++ctx->mailbox_seq;
-            launch_fold_publish(slots, ctx->mailbox_dev, seq, ctx->stream);
+            MinmaxAction a;
+            a.action = MM_PUBLISH;
+            a.seq = seq;
+            a.dst = ctx->mailbox_dev;
+            scan(ctx, x, dt, n, a);
             volatile uint32_t* flag = &ctx->mailbox->seq;
             for (uint32_t spins = 0; spins < (1u << 22); ++spins) {
                 if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) {
@@ -748,10 +738,15 @@ static void compute_params(piquant_context_t* ctx, const void* x, piquant_dtype_
                 keys[1] = ctx->mailbox->keys[1];
             }
         }
-        if (!have) {
-            PQ_HIP(hipMemcpyAsync(ctx->h_slots, slots, static_cast<size_t>(minmax_slot_ints()) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        if (!have) {   // no fine-grained host memory (or the flag never showed): keys to device memory, 8-byte copy, synchronise
+            MinmaxAction a;
+            a.action = MM_KEYS_SET;
+            a.dst = ctx->d_dist_keys;
+            scan(ctx, x, dt, n, a);
+            PQ_HIP(hipMemcpyAsync(ctx->h_keys, ctx->d_dist_keys, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
             PQ_HIP(hipStreamSynchronize(ctx->stream));
-            fold_slots_host(ctx->h_slots, keys);
+            keys[0] = ctx->h_keys[0];
+            keys[1] = ctx->h_keys[1];
         }
     }
     float lo, hi;

@@ -45,7 +45,7 @@ struct FusedState {
     uint32_t pad1[31];
     unsigned long long published;   // tag(generation + 1) << 41 | bounded << 40 | zero_point << 32 | bits of scale: what waiting blocks spin on
     uint32_t pad2[30];
-    int32_t slots[2][kMinmaxSlotInts];
+    int32_t slots[2][kMinmaxStateInts];
     uint64_t* stamps;     // TIMING builds (tools/tune_kernels.hip): 8 x 100 MHz wall clock readings per block at the phase boundaries
 };
 
@@ -116,24 +116,6 @@ __device__ __forceinline__ void store_packed(uint8_t* dst, const uint32_t (&w)[O
     else if constexpr (OB == 2) st<POLICY>(reinterpret_cast<uint16_t*>(dst), static_cast<uint16_t>(w[0]));
     else if constexpr (OB == 4) st<POLICY>(reinterpret_cast<uint32_t*>(dst), w[0]);
     else st<POLICY>(reinterpret_cast<u32x2*>(dst), u32x2 {w[0], w[1]});
-}
-
-// src/piquant.cpp:245-258 in IEEE double, as params_from_slots_kernel
-__device__ __forceinline__ void quant_params_epilogue(int32_t k_min, int32_t k_negmax, int bits, float& scale, int64_t& zp) {
-    const double r_min = static_cast<double>(key_to_float(k_min));
-    const double r_max = static_cast<double>(-key_to_float(k_negmax));
-    const uint64_t type_max = (uint64_t {1} << bits) - 1;
-    if (r_max == r_min) {
-        scale = 1.0f;
-        zp = static_cast<int64_t>(type_max >> 1);
-    } else {
-        const double q_max = static_cast<double>(type_max);
-        const double s = (r_max - r_min) / q_max;
-        double z = 0.0 - r_min / s;
-        z = fmax(fmin(static_cast<double>(static_cast<int64_t>(round(z))), q_max), 0.0);
-        scale = static_cast<float>(s);
-        zp = static_cast<int64_t>(z);
-    }
 }
 
 // rounds of BLOCK vectors in one block's share when n_vec vectors are split evenly over G blocks
@@ -254,15 +236,7 @@ fused_params_quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ 
             // arrival count, published word), and a release/acquire fence at agent scope costs an L2 write-back / invalidate
             // per block (measured: 13-17 us of barrier).  What IS needed is that this block's slot atomics are performed
             // before its arrival is counted: they return their old value and the arrival increment is made to depend on it.
-            int32_t* my = slots + (blockIdx.x % kMinmaxSlots) * kMinmaxSlotStride;
-            const int32_t k_lo = float_to_key(lo), k_hi = float_to_key(-hi);
-            int32_t seen0 = k_lo, seen1 = k_hi;
-            if (k_lo < __hip_atomic_load(my + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                seen0 = __hip_atomic_fetch_min(my + 0, k_lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (k_hi < __hip_atomic_load(my + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                seen1 = __hip_atomic_fetch_min(my + 1, k_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint32_t one = 1u;
-            asm volatile("" : "+v"(one) : "v"(seen0), "v"(seen1));
+            const uint32_t one = fold_keys(slots + (blockIdx.x % kMinmaxSlots) * kMinmaxSlotStride, lo, hi);
             before = __hip_atomic_fetch_add(&st->arrived, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         before = __builtin_amdgcn_readfirstlane(before);

@@ -105,17 +105,24 @@ void dequantize_out(const DequantLaunch& d, const DequantParams& p, hipStream_t 
 }
 
 template <int DT_IN>
-void minmax_t(const void* in, int64_t numel, int32_t* slots, int32_t* rearm_slots, hipStream_t stream, int num_cu) {
+void minmax_t(const void* in, int64_t numel, int32_t* state, const MinmaxEpilogue& ep, hipStream_t stream, int num_cu) {
     constexpr int EPV = InVec<DT_IN>::EPV;
     if (!aligned16(in)) {
         const unsigned grid = capped_grid((numel + kMinmaxBlock - 1) / kMinmaxBlock, 8, num_cu);
-        hipLaunchKernelGGL((minmax_scalar_kernel<DT_IN, kMinmaxBlock>), dim3(grid), dim3(kMinmaxBlock), 0, stream, in, numel, slots, rearm_slots);
+        hipLaunchKernelGGL((minmax_scalar_kernel<DT_IN, kMinmaxBlock>), dim3(grid), dim3(kMinmaxBlock), 0, stream, in, numel, state, ep);
         return;
     }
     const int64_t per_block = static_cast<int64_t>(kMinmaxBlock) * kMinmaxU * EPV;
     const unsigned grid = capped_grid((numel + per_block - 1) / per_block, kMinmaxBlocksPerCU, num_cu);
-    hipLaunchKernelGGL((minmax_kernel<DT_IN, kMinmaxU, kMinmaxNT, kMinmaxBlock>), dim3(grid), dim3(kMinmaxBlock), 0, stream, in, numel, slots,
-                       rearm_slots);
+    hipLaunchKernelGGL((minmax_kernel<DT_IN, kMinmaxU, kMinmaxNT, kMinmaxBlock>), dim3(grid), dim3(kMinmaxBlock), 0, stream, in, numel, state, ep);
+}
+
+MinmaxEpilogue to_epilogue(const MinmaxAction& a) {
+    static_assert(MM_NONE == EP_NONE && MM_KEYS_SET == EP_KEYS_SET && MM_KEYS_MIN == EP_KEYS_MIN && MM_PUBLISH == EP_PUBLISH && MM_PARAMS == EP_PARAMS,
+                  "host and device action codes");
+    static_assert(sizeof(MinmaxMailbox) == sizeof(MinmaxMailboxHost), "mailbox layout");
+    if (a.action != MM_NONE && !a.dst) panic("min/max epilogue without a destination");
+    return MinmaxEpilogue {a.action, a.bits, a.seq, a.dst};
 }
 
 }  // namespace
@@ -306,39 +313,19 @@ void launch_arm_slots(int32_t* slots, hipStream_t stream) {
     PQ_HIP(hipGetLastError());
 }
 
-void launch_fold_slots(const int32_t* slots, int32_t* device_keys, bool overwrite, hipStream_t stream) {
-    hipLaunchKernelGGL(fold_slots_kernel, dim3(1), dim3(64), 0, stream, slots, device_keys, overwrite ? 1 : 0);
+void launch_minmax_epilogue(int32_t* state, const MinmaxAction& action, bool rearm, hipStream_t stream) {
+    hipLaunchKernelGGL(minmax_epilogue_kernel, dim3(1), dim3(64), 0, stream, state, to_epilogue(action), rearm ? 1 : 0);
     PQ_HIP(hipGetLastError());
 }
 
-void launch_fold_publish(const int32_t* slots, void* mailbox_device_ptr, uint32_t seq, hipStream_t stream) {
-    static_assert(sizeof(MinmaxMailbox) == sizeof(MinmaxMailboxHost), "mailbox layout");
-    hipLaunchKernelGGL(fold_publish_kernel, dim3(1), dim3(64), 0, stream, slots, static_cast<MinmaxMailbox*>(mailbox_device_ptr), seq);
-    PQ_HIP(hipGetLastError());
-}
+int minmax_state_ints() { return kMinmaxStateInts; }
 
-void launch_params_from_slots(const int32_t* slots, int bits, void* device_param_record, hipStream_t stream) {
-    hipLaunchKernelGGL(params_from_slots_kernel, dim3(1), dim3(64), 0, stream, slots, bits, static_cast<ParamRecord*>(device_param_record));
-    PQ_HIP(hipGetLastError());
-}
-
-void fold_slots_host(const int32_t* slots, int32_t out_keys[2]) {
-    int32_t k0 = slots[0], k1 = slots[1];
-    for (int s = 1; s < kMinmaxSlots; ++s) {
-        k0 = std::min(k0, slots[s * kMinmaxSlotStride + 0]);
-        k1 = std::min(k1, slots[s * kMinmaxSlotStride + 1]);
-    }
-    out_keys[0] = k0;
-    out_keys[1] = k1;
-}
-
-int minmax_slot_ints() { return kMinmaxSlotInts; }
-
-void launch_minmax(const void* in, int dt_in, int64_t numel, int32_t* slots, int32_t* rearm_slots, hipStream_t stream, int num_cu) {
-    if (numel <= 0) return;
+void launch_minmax(const void* in, int dt_in, int64_t numel, int32_t* state, const MinmaxAction& action, hipStream_t stream, int num_cu) {
+    if (numel <= 0) panic("launch_minmax: empty input (an armed state buffer already holds the identities)");
+    const MinmaxEpilogue ep = to_epilogue(action);
     switch (dt_in) {
-        case DT_F32: minmax_t<DT_F32>(in, numel, slots, rearm_slots, stream, num_cu); break;
-        case DT_BF16: minmax_t<DT_BF16>(in, numel, slots, rearm_slots, stream, num_cu); break;
+        case DT_F32: minmax_t<DT_F32>(in, numel, state, ep, stream, num_cu); break;
+        case DT_BF16: minmax_t<DT_BF16>(in, numel, state, ep, stream, num_cu); break;
         default: panic("min/max scan needs a float dtype, got %d", dt_in);
     }
     PQ_HIP(hipGetLastError());

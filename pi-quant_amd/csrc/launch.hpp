@@ -62,21 +62,30 @@ struct RequantLaunch {
 void launch_quantize(const QuantLaunch& q, hipStream_t stream, int num_cu);
 void launch_dequantize(const DequantLaunch& d, hipStream_t stream, int num_cu);
 void launch_requantize(const RequantLaunch& r, hipStream_t stream, int num_cu);
-// Min/max scan into a slot buffer (kMinmaxSlotInts int32, armed with the identity beforehand); rearm_slots
-// (nullable) is a second, idle slot buffer that the scan re-arms for a later call.
-void launch_minmax(const void* in, int dt_in, int64_t numel, int32_t* slots, int32_t* rearm_slots, hipStream_t stream, int num_cu);
-void launch_arm_slots(int32_t* slots, hipStream_t stream);
-// Fold a slot buffer into a {key(min), key(-max)} pair in device memory (overwrite or accumulate with MIN).
-void launch_fold_slots(const int32_t* slots, int32_t* device_keys, bool overwrite, hipStream_t stream);
-// Fold a slot buffer and publish {keys, seq} to a pinned fine-grained host mailbox (device-visible address given).
+// Min/max scan.  `state` is a minmax_state_ints() int32 device buffer armed once with launch_arm_slots: 64 slot key pairs on
+// separate 128-byte lines plus arrival counters.  The block that arrives last folds the slots, re-arms the buffer and runs
+// the epilogue inside the SAME launch, so a scan is one kernel and always leaves `state` armed:
+//   MM_KEYS_SET / MM_KEYS_MIN  dst = int32[2] device {key(min), key(-max)}, overwritten / accumulated with MIN
+//   MM_PUBLISH                 dst = device-visible address of a MinmaxMailboxHost in pinned fine-grained host memory
+//   MM_PARAMS                  dst = 16-byte device ParamRecord (scale, 1/scale, zero point) for `bits`-wide quantization
+//   MM_NONE                    keys stay in the slots (several scans into one buffer); finish with launch_minmax_epilogue
+enum : int { MM_NONE = 0, MM_KEYS_SET = 1, MM_KEYS_MIN = 2, MM_PUBLISH = 3, MM_PARAMS = 4 };
+struct MinmaxAction {
+    int action = MM_NONE;
+    int bits = 0;
+    uint32_t seq = 0;
+    void* dst = nullptr;
+};
 struct MinmaxMailboxHost {
     int32_t keys[2];
     uint32_t seq;
     uint32_t pad;
 };
-void launch_fold_publish(const int32_t* slots, void* mailbox_device_ptr, uint32_t seq, hipStream_t stream);
-// Fold a slot buffer and write the (scale, 1/scale, zero_point) ParamRecord for `bits`-wide quantization to device memory.
-void launch_params_from_slots(const int32_t* slots, int bits, void* device_param_record, hipStream_t stream);
+void launch_minmax(const void* in, int dt_in, int64_t numel, int32_t* state, const MinmaxAction& action, hipStream_t stream, int num_cu);
+// Fold + epilogue as a launch of its own (after MM_NONE scans, or on an armed buffer for an empty input: identities).
+void launch_minmax_epilogue(int32_t* state, const MinmaxAction& action, bool rearm, hipStream_t stream);
+void launch_arm_slots(int32_t* state, hipStream_t stream);
+int minmax_state_ints();
 // compute_quant_params + quantize in one launch with the tensor resident on chip between the two passes (fused_kernels.hpp).
 // q.inv_scale / q.zero_point / q.dyn_params are ignored: the parameters come from the data and are also written to
 // device_param_record.  `state` is a fused_state_bytes() device buffer prepared once with init_fused_state().  Returns false
@@ -86,9 +95,6 @@ bool launch_fused_params_quantize(const QuantLaunch& q, void* state, void* devic
 bool fused_launch_applies(const QuantLaunch& q, int num_cu);   // the test launch_fused_params_quantize makes, without launching
 size_t fused_state_bytes();
 void init_fused_state(void* state, hipStream_t stream);
-// Host-side fold of a slot buffer copied back from the device.
-void fold_slots_host(const int32_t* slots, int32_t out_keys[2]);
-int minmax_slot_ints();
 
 // Aborts with the reference's panic convention (red message on stderr, abort()) on a HIP error.
 void check_hip(hipError_t e, const char* what, const char* file, int line);

@@ -10,9 +10,9 @@
 // Why slots: atomics on ONE address serialise at ~11 ns each on MI355X (measured: with a single key pair the
 // scan time grew linearly with the block count, 2048 blocks = +45 us on an 18 us scan, because all blocks of
 // an evenly split scan finish together).  The blocks therefore fold into kMinmaxSlots key pairs, each on its
-// own 128-byte line (slot = blockIdx % slots), and the slots are folded afterwards: by fold_slots_kernel (one
-// wave) for the asynchronous API, or on the host after the D2H copy for compute_quant_params.
-// Device-scope atomics are coherent across the 8 XCDs' L2s; results are read after the kernel boundary.
+// own 128-byte line (slot = blockIdx % slots), and the block that arrives last folds the slots and runs the call's
+// epilogue (keys, host mailbox or parameter record) inside the same launch.
+// Device-scope atomics are coherent across the 8 XCDs' L2s.
 // NaNs are ignored (v_min/v_max return the non-NaN operand); the reference leaves NaN inputs unspecified.
 #pragma once
 
@@ -33,109 +33,167 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 constexpr int kMinmaxSlots = 64;          // key pairs per slot buffer
-constexpr int kMinmaxSlotStride = 32;     // int32 per slot: one 128-byte line each
+constexpr int kMinmaxSlotStride = 32;     // int32 per slot: one 128-byte line each -- [0] key(min), [1] key(-max), [2] arrivals
 constexpr int kMinmaxSlotInts = kMinmaxSlots * kMinmaxSlotStride;
+constexpr int kMinmaxStateInts = kMinmaxSlotInts + kMinmaxSlotStride;   // + one line: [0] = slots whose blocks have all arrived
 
-// One block's {min,max} into its slot.  The block first looks at the slot with a relaxed device-scope load and
-// only issues the atomic when it would lower the key: keys only ever decrease, so a stale (older, larger)
-// value can cause a redundant atomic but never a missed one.
-__device__ __forceinline__ void fold_keys(int32_t* keys, float lo, float hi) {
-    const int32_t k_lo = float_to_key(lo), k_hi = float_to_key(-hi);
-    if (k_lo < __hip_atomic_load(keys + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(keys + 0, k_lo);
-    if (k_hi < __hip_atomic_load(keys + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(keys + 1, k_hi);
-}
+// What happens to the folded {key(min), key(-max)} pair once the last block of a scan has arrived.  The scan kernel runs
+// this itself (no second launch: a one-wave fold kernel costs 4-5 us, a quarter of the scan at numel 27 264 000).
+enum : int {
+    EP_NONE = 0,        // leave the per-slot keys in the slot buffer (several scans fold into one buffer: staged host input)
+    EP_KEYS_SET = 1,    // dst = int32[2] device keys, overwritten
+    EP_KEYS_MIN = 2,    // dst = int32[2] device keys, accumulated with MIN (sharded / multi-part scans)
+    EP_PUBLISH = 3,     // dst = MinmaxMailbox in pinned fine-grained host memory: keys, then the sequence number, system scope
+    EP_PARAMS = 4,      // dst = ParamRecord: the (min,max) -> (scale, 1/scale, zero point) epilogue for `bits`-wide quantization
+};
 
-// Arms a slot buffer with the identity (+FLT_MAX for min and for -max).
-__global__ void __launch_bounds__(64) arm_slots_kernel(int32_t* slots) {
-    if (threadIdx.x < kMinmaxSlots) {
-        slots[threadIdx.x * kMinmaxSlotStride + 0] = float_to_key(3.402823466e+38f);
-        slots[threadIdx.x * kMinmaxSlotStride + 1] = float_to_key(3.402823466e+38f);
-    }
-}
+struct MinmaxEpilogue {
+    int action;
+    int bits;
+    uint32_t seq;
+    void* dst;
+};
 
-// One wave folds the slots into the caller's key pair: overwrite != 0 stores, otherwise atomicMin (accumulate).
-__global__ void __launch_bounds__(64) fold_slots_kernel(const int32_t* slots, int32_t* keys, int overwrite) {
-    static_assert(kMinmaxSlots == 64, "one lane per slot");
-    int32_t k0 = slots[threadIdx.x * kMinmaxSlotStride + 0];
-    int32_t k1 = slots[threadIdx.x * kMinmaxSlotStride + 1];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        k0 = min(k0, __shfl_xor(k0, off, 64));
-        k1 = min(k1, __shfl_xor(k1, off, 64));
-    }
-    if (threadIdx.x == 0) {
-        if (overwrite) {
-            keys[0] = k0;
-            keys[1] = k1;
-        } else {
-            atomicMin(keys + 0, k0);
-            atomicMin(keys + 1, k1);
-        }
-    }
-}
-
-// Result mailbox in pinned, fine-grained host memory: compute_quant_params' fold kernel stores the folded keys and
-// then the call's sequence number with system scope; the host spins on `seq` instead of paying a D2H copy plus a
-// stream synchronisation (~17 us, as much as the 18 us scan itself at numel 27 264 000).
+// Result mailbox in pinned, fine-grained host memory: the scan's last block stores the folded keys and then the call's
+// sequence number with system scope; the host spins on `seq` instead of paying a D2H copy plus a stream synchronisation
+// (~17 us, as much as the 18 us scan itself at numel 27 264 000).
 struct MinmaxMailbox {
     int32_t keys[2];
     uint32_t seq;
     uint32_t pad;
 };
 
-__global__ void __launch_bounds__(64) fold_publish_kernel(const int32_t* slots, MinmaxMailbox* mailbox, uint32_t seq) {
-    int32_t k0 = slots[threadIdx.x * kMinmaxSlotStride + 0];
-    int32_t k1 = slots[threadIdx.x * kMinmaxSlotStride + 1];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        k0 = min(k0, __shfl_xor(k0, off, 64));
-        k1 = min(k1, __shfl_xor(k1, off, 64));
-    }
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(&mailbox->keys[0], k0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&mailbox->keys[1], k1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&mailbox->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // keys first, then the flag
+// src/piquant.cpp:245-258 in IEEE double (f64 division / round, correctly rounded conversions): bit-identical to the host
+// epilogue on every tested range.  A degenerate range gives (1.0, qmax >> 1) as in the reference (:249-252); a NaN or
+// negative scale cannot abort from the device and is produced as is.
+__device__ __forceinline__ void quant_params_epilogue(int32_t k_min, int32_t k_negmax, int bits, float& scale, int64_t& zp) {
+    const double r_min = static_cast<double>(key_to_float(k_min));
+    const double r_max = static_cast<double>(-key_to_float(k_negmax));
+    const uint64_t type_max = (uint64_t {1} << bits) - 1;
+    if (r_max == r_min) {
+        scale = 1.0f;
+        zp = static_cast<int64_t>(type_max >> 1);
+    } else {
+        const double q_max = static_cast<double>(type_max);
+        const double s = (r_max - r_min) / q_max;
+        double z = 0.0 - r_min / s;
+        z = fmax(fmin(static_cast<double>(static_cast<int64_t>(round(z))), q_max), 0.0);
+        scale = static_cast<float>(s);
+        zp = static_cast<int64_t>(z);
     }
 }
 
-// The (min,max) -> (scale, zero_point) epilogue on the device, for the dynamic path: one wave folds the slots, lane 0
-// runs the reference's double-precision formula (src/piquant.cpp:245-258) -- IEEE f64 division/round and a correctly
-// rounded fp32 reciprocal, so the record is bit-identical to what the host epilogue would produce -- and writes the
-// 16-byte ParamRecord.  A degenerate range gives (1.0, qmax >> 1) as in the reference (:249-252); a NaN or negative
-// scale cannot abort from here and is written as is.
-__global__ void __launch_bounds__(64) params_from_slots_kernel(const int32_t* slots, int bits, ParamRecord* out) {
-    int32_t k0 = slots[threadIdx.x * kMinmaxSlotStride + 0];
-    int32_t k1 = slots[threadIdx.x * kMinmaxSlotStride + 1];
+// One block's {min,max} into its slot: the block first looks at the slot with a relaxed device-scope load and only issues the
+// atomic when it would lower the key (keys only ever decrease, so a stale value can cause a redundant atomic but never a
+// missed one).  Returns a value that depends on the atomics having been PERFORMED (they return the old key): whoever is
+// going to announce this block's arrival makes the announcement depend on it, which orders the two without a fence (an
+// agent-scope release fence writes the L2 back -- measured in the fused kernel's barrier at 13-17 us).
+__device__ __forceinline__ uint32_t fold_keys(int32_t* keys, float lo, float hi) {
+    const int32_t k_lo = float_to_key(lo), k_hi = float_to_key(-hi);
+    int32_t seen0 = k_lo, seen1 = k_hi;
+    if (k_lo < __hip_atomic_load(keys + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        seen0 = __hip_atomic_fetch_min(keys + 0, k_lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k_hi < __hip_atomic_load(keys + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        seen1 = __hip_atomic_fetch_min(keys + 1, k_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t one = 1u;
+    asm volatile("" : "+v"(one) : "v"(seen0), "v"(seen1));
+    return one;
+}
+
+// Arms a scan state buffer: identity keys (+FLT_MAX for min and for -max), all arrival counters zero.
+__global__ void __launch_bounds__(64) arm_slots_kernel(int32_t* state) {
+    if (threadIdx.x < kMinmaxSlots) {
+        state[threadIdx.x * kMinmaxSlotStride + 0] = float_to_key(3.402823466e+38f);
+        state[threadIdx.x * kMinmaxSlotStride + 1] = float_to_key(3.402823466e+38f);
+        state[threadIdx.x * kMinmaxSlotStride + 2] = 0;
+    }
+    if (threadIdx.x == 0) state[kMinmaxSlotInts] = 0;
+}
+
+// One wave (all 64 lanes) folds the slots, re-arms them if asked and performs the epilogue action.
+__device__ __forceinline__ void minmax_finish(int32_t* state, int lane, const MinmaxEpilogue& ep, bool rearm) {
+    static_assert(kMinmaxSlots == 64, "one lane per slot");
+    int32_t k0 = __hip_atomic_load(state + lane * kMinmaxSlotStride + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int32_t k1 = __hip_atomic_load(state + lane * kMinmaxSlotStride + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (rearm) {
+        __hip_atomic_store(state + lane * kMinmaxSlotStride + 0, float_to_key(3.402823466e+38f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(state + lane * kMinmaxSlotStride + 1, float_to_key(3.402823466e+38f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         k0 = min(k0, __shfl_xor(k0, off, 64));
         k1 = min(k1, __shfl_xor(k1, off, 64));
     }
-    if (threadIdx.x == 0) {
-        const double r_min = static_cast<double>(key_to_float(k0));
-        const double r_max = static_cast<double>(-key_to_float(k1));
-        const uint64_t type_max = (uint64_t{1} << bits) - 1;
+    if (lane != 0) return;
+    if (ep.action == EP_KEYS_SET) {
+        int32_t* keys = static_cast<int32_t*>(ep.dst);
+        keys[0] = k0;
+        keys[1] = k1;
+    } else if (ep.action == EP_KEYS_MIN) {
+        int32_t* keys = static_cast<int32_t*>(ep.dst);
+        atomicMin(keys + 0, k0);
+        atomicMin(keys + 1, k1);
+    } else if (ep.action == EP_PUBLISH) {
+        MinmaxMailbox* mailbox = static_cast<MinmaxMailbox*>(ep.dst);
+        __hip_atomic_store(&mailbox->keys[0], k0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&mailbox->keys[1], k1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&mailbox->seq, ep.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // keys first, then the flag
+    } else if (ep.action == EP_PARAMS) {
+        ParamRecord* out = static_cast<ParamRecord*>(ep.dst);
         float scale;
         int64_t zp;
-        if (r_max == r_min) {
-            scale = 1.0f;
-            zp = static_cast<int64_t>(type_max >> 1);
-        } else {
-            const double q_max = static_cast<double>(type_max);
-            const double s = (r_max - r_min) / q_max;
-            double z = 0.0 - r_min / s;
-            z = fmax(fmin(static_cast<double>(static_cast<int64_t>(round(z))), q_max), 0.0);
-            scale = static_cast<float>(s);
-            zp = static_cast<int64_t>(z);
-        }
+        quant_params_epilogue(k0, k1, ep.bits, scale, zp);
         out->scale = scale;
         out->inv_scale = __fdiv_rn(1.0f, scale);
         out->zero_point = zp;
     }
 }
 
+// The same as a kernel of its own, for slot buffers filled by EP_NONE scans (staged host input) and for empty inputs (an armed
+// buffer folds to the identities, reference kernels_specialized.inl:1422-1423).
+__global__ void __launch_bounds__(64) minmax_epilogue_kernel(int32_t* state, MinmaxEpilogue ep, int rearm) {
+    minmax_finish(state, static_cast<int>(threadIdx.x), ep, rearm != 0);
+}
+
+// End of a scan block.  Wave 0: lane 0 folds the block's extremes into its slot and -- unless the scan leaves the keys in
+// the slots (EP_NONE) -- counts the block in: per slot first (blocks b with b % 64 == slot), and the block that completes a
+// slot counts the slot in; so no counter sees more than a handful of atomics at a time (atomics on one address serialise at
+// ~11 ns each, and all blocks of an even split finish together).  The block that completes the last slot folds all slots,
+// re-arms keys and counters for the next scan, and runs the epilogue: a scan is always ONE launch that leaves the state
+// buffer armed, which also makes it replayable inside a hipGraph without any bookkeeping on the host.
+template <int WAVES>
+__device__ __forceinline__ void minmax_block_end(float lo, float hi, const float* s_lo, const float* s_hi, int32_t* state, const MinmaxEpilogue& ep) {
+    const int lane = threadIdx.x & 63;
+    if ((threadIdx.x >> 6) != 0) return;
+    uint32_t last = 0;
+    if (lane == 0) {
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) {
+            lo = __builtin_fminf(lo, s_lo[w]);
+            hi = __builtin_fmaxf(hi, s_hi[w]);
+        }
+        const uint32_t G = gridDim.x, slot = blockIdx.x % kMinmaxSlots;
+        int32_t* my = state + slot * kMinmaxSlotStride;
+        const uint32_t one = fold_keys(my, lo, hi);
+        if (ep.action != EP_NONE) {
+            const uint32_t in_slot = (G - slot + kMinmaxSlots - 1) / kMinmaxSlots;
+            const uint32_t before = __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(my + 2), one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (before == in_slot - 1) {
+                __hip_atomic_store(reinterpret_cast<uint32_t*>(my + 2), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t active = G < static_cast<uint32_t>(kMinmaxSlots) ? G : static_cast<uint32_t>(kMinmaxSlots);
+                uint32_t* done = reinterpret_cast<uint32_t*>(state + kMinmaxSlotInts);
+                if (__hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == active - 1) {
+                    __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    last = 1;
+                }
+            }
+        }
+    }
+    if (__builtin_amdgcn_readfirstlane(last)) minmax_finish(state, lane, ep, true);
+}
+
 template <int DT_IN, int U, bool NT, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) minmax_kernel(const void* __restrict__ in, int64_t numel, int32_t* slots, int32_t* rearm_slots) {
+__global__ void __launch_bounds__(BLOCK) minmax_kernel(const void* __restrict__ in, int64_t numel, int32_t* state, MinmaxEpilogue ep) {
     constexpr int EPV = InVec<DT_IN>::EPV;
     constexpr int WAVES = BLOCK / 64;
     const u32x4* __restrict__ in16 = static_cast<const u32x4*>(in);
@@ -187,23 +245,12 @@ __global__ void __launch_bounds__(BLOCK) minmax_kernel(const void* __restrict__ 
         s_hi[wave] = hi;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int w = 1; w < WAVES; ++w) {
-            lo = __builtin_fminf(lo, s_lo[w]);
-            hi = __builtin_fmaxf(hi, s_hi[w]);
-        }
-        fold_keys(slots + (blockIdx.x % kMinmaxSlots) * kMinmaxSlotStride, lo, hi);
-    }
-    if (rearm_slots != nullptr && blockIdx.x == 0 && threadIdx.x < kMinmaxSlots) {   // re-arm the idle slot buffer for a later call
-        rearm_slots[threadIdx.x * kMinmaxSlotStride + 0] = float_to_key(3.402823466e+38f);
-        rearm_slots[threadIdx.x * kMinmaxSlotStride + 1] = float_to_key(3.402823466e+38f);
-    }
+    minmax_block_end<WAVES>(lo, hi, s_lo, s_hi, state, ep);
 }
 
 // Same scan for buffers that are not 16-byte aligned.
 template <int DT_IN, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) minmax_scalar_kernel(const void* __restrict__ in, int64_t numel, int32_t* slots, int32_t* rearm_slots) {
+__global__ void __launch_bounds__(BLOCK) minmax_scalar_kernel(const void* __restrict__ in, int64_t numel, int32_t* state, MinmaxEpilogue ep) {
     constexpr int WAVES = BLOCK / 64;
     float lo = 3.402823466e+38f, hi = -3.402823466e+38f;
     const int64_t nthreads = static_cast<int64_t>(gridDim.x) * BLOCK;
@@ -221,18 +268,7 @@ __global__ void __launch_bounds__(BLOCK) minmax_scalar_kernel(const void* __rest
         s_hi[wave] = hi;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int w = 1; w < WAVES; ++w) {
-            lo = __builtin_fminf(lo, s_lo[w]);
-            hi = __builtin_fmaxf(hi, s_hi[w]);
-        }
-        fold_keys(slots + (blockIdx.x % kMinmaxSlots) * kMinmaxSlotStride, lo, hi);
-    }
-    if (rearm_slots != nullptr && blockIdx.x == 0 && threadIdx.x < kMinmaxSlots) {   // re-arm the idle slot buffer for a later call
-        rearm_slots[threadIdx.x * kMinmaxSlotStride + 0] = float_to_key(3.402823466e+38f);
-        rearm_slots[threadIdx.x * kMinmaxSlotStride + 1] = float_to_key(3.402823466e+38f);
-    }
+    minmax_block_end<WAVES>(lo, hi, s_lo, s_hi, state, ep);
 }
 
 }  // namespace pq

@@ -268,9 +268,9 @@ static void run_minmax(const Bufs& b, int64_t numel, int num_cu, int32_t* keys) 
     for (int cap : {2, 4, 8, 16, 32}) {
         const unsigned grid = static_cast<unsigned>(cap * num_cu);
         const double us = time_us([&](int i) {
-            // production protocol: cold (armed) slots every launch, the idle buffer re-armed by the scan itself
-            hipLaunchKernelGGL((minmax_kernel<DT_IN, U, NT, BLOCK>), dim3(grid), dim3(BLOCK), 0, g_stream, b.in[i % SETS], numel,
-                               keys + (i & 1) * kMinmaxSlotInts, keys + ((i & 1) ^ 1) * kMinmaxSlotInts);
+            // production protocol: the last block folds the slots into a key pair and re-arms the state inside the launch
+            hipLaunchKernelGGL((minmax_kernel<DT_IN, U, NT, BLOCK>), dim3(grid), dim3(BLOCK), 0, g_stream, b.in[i % SETS], numel, keys,
+                               MinmaxEpilogue {EP_KEYS_SET, 0, 0u, keys + kMinmaxStateInts});
         });
         char name[160];
         std::snprintf(name, sizeof name, "in=%s U=%d nt=%d block=%d cap=%d grid=%u", DT_IN == DT_F32 ? "f32" : "bf16", U, NT ? 1 : 0, BLOCK, cap, grid);
@@ -279,7 +279,7 @@ static void run_minmax(const Bufs& b, int64_t numel, int num_cu, int32_t* keys) 
 }
 
 
-// fused compute_quant_params + quantize (one launch, tensor resident on chip) against the three-launch path
+// fused compute_quant_params + quantize (one launch, tensor resident on chip) against the two-launch path
 struct FusedBufs {
     FusedState* st;
     ParamRecord* rec;
@@ -303,17 +303,14 @@ static void run_fused(const Bufs& b, const FusedBufs& f, int64_t numel, int num_
         hipLaunchKernelGGL((fused_params_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, R_REG, R_LDS, LDS_BATCH, BLOCK, STP>), dim3(num_cu), dim3(BLOCK), 0,
                            g_stream, b.in[i % SETS], static_cast<uint8_t*>(b.out[i % SETS]), numel, p, f.st, f.rec);
     };
-    // correctness first: same bytes and record as scan -> params -> quantize
+    // correctness first: same bytes and record as scan (with parameter epilogue) -> quantize
     CK(hipMemsetAsync(b.out[0], 0x5a, numel, g_stream));
     launch(0);
     CK(hipStreamSynchronize(g_stream));
     CK(hipGetLastError());
     {
-        int32_t* s0 = slots;
-        hipLaunchKernelGGL(arm_slots_kernel, dim3(1), dim3(64), 0, g_stream, s0);
-        hipLaunchKernelGGL((minmax_kernel<DT_F32, 4, true, 256>), dim3(2 * num_cu), dim3(256), 0, g_stream, static_cast<const void*>(b.in[0]), numel, s0,
-                           static_cast<int32_t*>(nullptr));
-        hipLaunchKernelGGL(params_from_slots_kernel, dim3(1), dim3(64), 0, g_stream, static_cast<const int32_t*>(s0), 8, f.rec_ref);
+        hipLaunchKernelGGL((minmax_kernel<DT_F32, 4, true, 256>), dim3(2 * num_cu), dim3(256), 0, g_stream, static_cast<const void*>(b.in[0]), numel, slots,
+                           MinmaxEpilogue {EP_PARAMS, 8, 0u, f.rec_ref});
         QuantParams pd {};
         pd.dyn = f.rec_ref;
         using T = QuantTile<DT_F32, 8, 2, 128>;
@@ -379,8 +376,8 @@ int main(int argc, char** argv) {
         CK(hipMemsetAsync(b.out[s], 0x5a, numel, g_stream));
     }
     int32_t* keys = nullptr;
-    CK(hipMalloc(reinterpret_cast<void**>(&keys), 2 * kMinmaxSlotInts * sizeof(int32_t)));
-    CK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(keys), float_to_key(3.402823466e+38f), 2 * kMinmaxSlotInts, g_stream));
+    CK(hipMalloc(reinterpret_cast<void**>(&keys), (kMinmaxStateInts + 64) * sizeof(int32_t)));   // scan state + a folded key pair behind it
+    hipLaunchKernelGGL(arm_slots_kernel, dim3(1), dim3(64), 0, g_stream, keys);
     CK(hipStreamSynchronize(g_stream));
 
     std::printf("family,variant,us_per_launch_best,algo_GBps,frac_of_8TBps,us_per_launch_worst\n");
@@ -673,24 +670,19 @@ int main(int argc, char** argv) {
         CK(hipMalloc(reinterpret_cast<void**>(&f.stamps), static_cast<size_t>(num_cu) * 64));
         CK(hipMemcpy(reinterpret_cast<char*>(f.st) + offsetof(FusedState, stamps), &f.stamps, sizeof(void*), hipMemcpyHostToDevice));
         CK(hipStreamSynchronize(g_stream));
-        // the three-launch path it replaces, timed the same way
+        // the two-launch path it replaces, timed the same way
         {
             QuantParams pd {};
             pd.dyn = f.rec_ref;
             using T = QuantTile<DT_F32, 8, 2, 128>;
             const int64_t n_tiles = numel / T::BLOCK_ELEMS;
-            int flip = 0;
             const double us = time_us([&](int i) {
-                int32_t* s0 = keys + (flip & 1) * kMinmaxSlotInts;
-                int32_t* s1 = keys + ((flip ^ 1) & 1) * kMinmaxSlotInts;
-                ++flip;
                 hipLaunchKernelGGL((minmax_kernel<DT_F32, 4, true, 256>), dim3(2 * num_cu), dim3(256), 0, g_stream, static_cast<const void*>(b.in[i % SETS]), numel,
-                                   s0, s1);
-                hipLaunchKernelGGL(params_from_slots_kernel, dim3(1), dim3(64), 0, g_stream, static_cast<const int32_t*>(s0), 8, f.rec_ref);
+                                   keys, MinmaxEpilogue {EP_PARAMS, 8, 0u, f.rec_ref});
                 hipLaunchKernelGGL((quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, 2, true, mem_policy(true, ST_WT), 128>), dim3(static_cast<unsigned>(std::max<int64_t>(n_tiles, 1))),
                                    dim3(128), 0, g_stream, static_cast<const void*>(b.in[i % SETS]), static_cast<uint8_t*>(b.out[i % SETS]), numel, n_tiles, pd);
             });
-            report("fused", "f32->u8 three launches (scan, params, quantize)", us, 9.0 * numel);
+            report("fused", "f32->u8 two launches (scan with parameter epilogue, quantize)", us, 9.0 * numel);
         }
         run_fused<18, 9, 9, 1024>(b, f, numel, num_cu, keys);
         run_fused<18, 9, 9, 1024, ST_NT>(b, f, numel, num_cu, keys);
