@@ -327,18 +327,18 @@ def main():
             _, e = time_loop(lambda i: piquant.torch.quantize_dynamic(xs[i % nsets], dtype=torch.uint8, ctx=ctx, out=outs[i % nsets], params=rec),
                              reps, stream)
             ctx.set_fusion(True)
-            extras["quantize_dynamic_f32_u8_three_launches"] = {"GB/s": gbs(9, e, reps), "avg_us_per_call": round(e / reps * 1e6, 3),
-                                                                "note": "same call with fusion off: scan + on-device epilogue + quantize (9 B/elem: x read twice)"}
+            extras["quantize_dynamic_f32_u8_unfused"] = {"GB/s": gbs(9, e, reps), "avg_us_per_call": round(e / reps * 1e6, 3),
+                                                         "note": "same call with fusion off: scan (parameter epilogue in its last block) + quantize, 9 B/elem: x read twice"}
             ctx.set_stream(stream.cuda_stream)
             ctx.set_blocking(False)
             keys = torch.empty(2, dtype=torch.int32, device=dev)
             _, e = time_loop(lambda i: ctx.minmax_keys_ptr(ptr_in[i % nsets], DataType.F32, n, keys.data_ptr(), True), reps, stream)
-            extras["minmax_f32"] = {"GB/s": gbs(4, e, reps), "avg_launch_us": round(e / reps * 1e6, 3), "note": "init kernel + scan per call (piquant_hip_minmax_keys)"}
+            extras["minmax_f32"] = {"GB/s": gbs(4, e, reps), "avg_launch_us": round(e / reps * 1e6, 3), "note": "piquant_hip_minmax_keys: one launch, the last block folds the slots into the key pair"}
             t0 = time.perf_counter()
             for i in range(50):
                 piquant.torch.compute_quant_params(xs[i % nsets], dtype=torch.quint8)
             extras["compute_quant_params_f32_call"] = {"ms_per_call": round((time.perf_counter() - t0) / 50 * 1e3, 5),
-                                                       "note": "full C-ABI call through piquant.torch: scan + fold/publish kernel into a pinned host mailbox + host spin + double epilogue"}
+                                                       "note": "full C-ABI call through piquant.torch: scan whose last block publishes the keys into a pinned host mailbox + host spin + double epilogue"}
             ctx.set_stream(stream.cuda_stream)
             ctx.set_blocking(False)
         # the reference's own calling convention: host buffers in, host buffers out (staged over PCIe, never `value`)
