@@ -49,37 +49,6 @@ struct FusedState {
     uint64_t* stamps;     // TIMING builds (tools/tune_kernels.hip): 8 x 100 MHz wall clock readings per block at the phase boundaries
 };
 
-// one 16-byte input vector -> WORDS packed 32-bit words (OB = EPV*BITS/8 bytes of output)
-template <int DT_IN, int BITS, int MODE>
-__device__ __forceinline__ void quantize_vec(const u32x4& raw, const QuantParams& p, const ElementKeys& keys, uint64_t e0,
-                                             uint32_t (&w)[(InVec<DT_IN>::EPV * BITS / 8) > 4 ? 2 : 1]) {
-    constexpr int EPV = InVec<DT_IN>::EPV, QMAX = (1 << BITS) - 1, WORDS = (EPV * BITS / 8) > 4 ? 2 : 1;
-    float v[EPV];
-    InVec<DT_IN>::unpack(raw, v);
-#pragma unroll
-    for (int j = 0; j < WORDS; ++j) w[j] = 0;
-    if constexpr (MODE == RM_NEAREST_FAST) {
-#pragma unroll
-        for (int e = 0; e < EPV; e += 2) {
-            uint32_t q0, q1;
-            quant_nearest_fast2<QMAX>(v[e], v[e + 1], p, q0, q1);
-            w[(e * BITS) >> 5] |= (q0 | (q1 << BITS)) << ((e * BITS) & 31);
-        }
-    } else if constexpr (MODE == RM_STOCH_ELEM) {
-#pragma unroll
-        for (int e = 0; e < EPV; ++e) {
-            const uint32_t q = quant_stochastic<QMAX>(v[e], p, element_threshold(keys, p.index_base + e0 + e));
-            w[(e * BITS) >> 5] |= q << ((e * BITS) & 31);
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < EPV; ++e) {
-            const uint32_t q = quant_one<MODE, QMAX>(v[e], p, e0 + e);
-            w[(e * BITS) >> 5] |= q << ((e * BITS) & 31);
-        }
-    }
-}
-
 // The nearest step for a call whose data range is known (device_math.hpp, BoundedStep): per element a packed multiply and
 // add, the copysign, one v_med3_f32 and one v_cvt_i32_f32 give the signed offset t = q - zp; the fields are then assembled
 // by Horner steps w = (w << BITS) + t (v_lshl_add_u32, negative t borrow from the field above and the borrow is repaid
@@ -110,13 +79,6 @@ __device__ __forceinline__ void quantize_vec_bounded(const u32x4& raw, float inv
     }
 }
 
-template <int OB, int POLICY>
-__device__ __forceinline__ void store_packed(uint8_t* dst, const uint32_t (&w)[OB > 4 ? 2 : 1]) {
-    if constexpr (OB == 1) st<POLICY>(dst, static_cast<uint8_t>(w[0]));
-    else if constexpr (OB == 2) st<POLICY>(reinterpret_cast<uint16_t*>(dst), static_cast<uint16_t>(w[0]));
-    else if constexpr (OB == 4) st<POLICY>(reinterpret_cast<uint32_t*>(dst), w[0]);
-    else st<POLICY>(reinterpret_cast<u32x2*>(dst), u32x2 {w[0], w[1]});
-}
 
 // rounds of BLOCK vectors in one block's share when n_vec vectors are split evenly over G blocks
 __host__ __device__ inline int fused_rounds(int64_t n_vec, int64_t G, int64_t block) {
@@ -236,7 +198,7 @@ fused_params_quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ 
             // arrival count, published word), and a release/acquire fence at agent scope costs an L2 write-back / invalidate
             // per block (measured: 13-17 us of barrier).  What IS needed is that this block's slot atomics are performed
             // before its arrival is counted: they return their old value and the arrival increment is made to depend on it.
-            const uint32_t one = fold_keys(slots + (blockIdx.x % kMinmaxSlots) * kMinmaxSlotStride, lo, hi);
+            const uint32_t one = fold_keys<false>(slots + (blockIdx.x % kMinmaxSlots) * kMinmaxSlotStride, lo, hi);
             before = __hip_atomic_fetch_add(&st->arrived, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         before = __builtin_amdgcn_readfirstlane(before);

@@ -88,12 +88,15 @@ __device__ __forceinline__ void quant_params_epilogue(int32_t k_min, int32_t k_n
 // missed one).  Returns a value that depends on the atomics having been PERFORMED (they return the old key): whoever is
 // going to announce this block's arrival makes the announcement depend on it, which orders the two without a fence (an
 // agent-scope release fence writes the L2 back -- measured in the fused kernel's barrier at 13-17 us).
+// PRECHECK = false issues both atomics unconditionally: one memory round trip instead of two, right for grids with a few
+// blocks per slot (the fused kernel's 256), wrong for thousands of blocks finishing together.
+template <bool PRECHECK = true>
 __device__ __forceinline__ uint32_t fold_keys(int32_t* keys, float lo, float hi) {
     const int32_t k_lo = float_to_key(lo), k_hi = float_to_key(-hi);
     int32_t seen0 = k_lo, seen1 = k_hi;
-    if (k_lo < __hip_atomic_load(keys + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    if (!PRECHECK || k_lo < __hip_atomic_load(keys + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
         seen0 = __hip_atomic_fetch_min(keys + 0, k_lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (k_hi < __hip_atomic_load(keys + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    if (!PRECHECK || k_hi < __hip_atomic_load(keys + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
         seen1 = __hip_atomic_fetch_min(keys + 1, k_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t one = 1u;
     asm volatile("" : "+v"(one) : "v"(seen0), "v"(seen1));

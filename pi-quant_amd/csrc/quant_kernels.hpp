@@ -115,6 +115,46 @@ __global__ void __launch_bounds__(256) quantize_scalar_kernel(const void* in, ui
                                               static_cast<int64_t>(gridDim.x) * blockDim.x);
 }
 
+// one 16-byte input vector -> WORDS packed 32-bit words (OB = EPV*BITS/8 bytes of output)
+template <int DT_IN, int BITS, int MODE>
+__device__ __forceinline__ void quantize_vec(const u32x4& raw, const QuantParams& p, const ElementKeys& keys, uint64_t e0,
+                                             uint32_t (&w)[(InVec<DT_IN>::EPV * BITS / 8) > 4 ? 2 : 1]) {
+    constexpr int EPV = InVec<DT_IN>::EPV, QMAX = (1 << BITS) - 1, WORDS = (EPV * BITS / 8) > 4 ? 2 : 1;
+    float v[EPV];
+    InVec<DT_IN>::unpack(raw, v);
+#pragma unroll
+    for (int j = 0; j < WORDS; ++j) w[j] = 0;
+    if constexpr (MODE == RM_NEAREST_FAST) {
+#pragma unroll
+        for (int e = 0; e < EPV; e += 2) {
+            uint32_t q0, q1;
+            quant_nearest_fast2<QMAX>(v[e], v[e + 1], p, q0, q1);
+            w[(e * BITS) >> 5] |= (q0 | (q1 << BITS)) << ((e * BITS) & 31);
+        }
+    } else if constexpr (MODE == RM_STOCH_ELEM) {
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+            const uint32_t q = quant_stochastic<QMAX>(v[e], p, element_threshold(keys, p.index_base + e0 + e));
+            w[(e * BITS) >> 5] |= q << ((e * BITS) & 31);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+            const uint32_t q = quant_one<MODE, QMAX>(v[e], p, e0 + e);
+            w[(e * BITS) >> 5] |= q << ((e * BITS) & 31);
+        }
+    }
+}
+
+// OB = 1, 2, 4 or 8 packed bytes of one input vector to `dst`
+template <int OB, int POLICY>
+__device__ __forceinline__ void store_packed(uint8_t* dst, const uint32_t (&w)[OB > 4 ? 2 : 1]) {
+    if constexpr (OB == 1) st<POLICY>(dst, static_cast<uint8_t>(w[0]));
+    else if constexpr (OB == 2) st<POLICY>(reinterpret_cast<uint16_t*>(dst), static_cast<uint16_t>(w[0]));
+    else if constexpr (OB == 4) st<POLICY>(reinterpret_cast<uint32_t*>(dst), w[0]);
+    else st<POLICY>(reinterpret_cast<u32x2*>(dst), u32x2 {w[0], w[1]});
+}
+
 template <int DT_IN, int BITS, int U, int BLOCK>
 struct QuantTile {
     static constexpr int EPV = InVec<DT_IN>::EPV;
@@ -126,12 +166,12 @@ struct QuantTile {
     static constexpr int64_t BLOCK_ELEMS = static_cast<int64_t>(WAVES) * WAVE_VECS * EPV;
 };
 
-template <int DT_IN, int BITS, int MODE, int U, bool STAGE, int NT, int BLOCK, bool PF = false>
+template <int DT_IN, int BITS, int MODE, int U, bool STAGE, int NT, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t numel, int64_t n_tiles, QuantParams p_arg) {
     const QuantParams p = resolved(p_arg);
     using T = QuantTile<DT_IN, BITS, U, BLOCK>;
-    constexpr int EPV = T::EPV, OB = T::OB, QMAX = (1 << BITS) - 1;
+    constexpr int EPV = T::EPV, OB = T::OB;
     constexpr int WORDS = OB > 4 ? 2 : 1;
     constexpr bool NT_LD = (NT & 1) != 0;   // see mem_policy()
     constexpr int NT_ST = NT >> 1;
@@ -142,78 +182,23 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
     const int wave = threadIdx.x >> 6;
     const u32x4* __restrict__ in16 = static_cast<const u32x4*>(in);
 
-    // PF (software prefetch, for persistent grids): the loads of the wave's NEXT tile are issued before the current
-    // tile is converted and stored, so a wave always has U loads in flight instead of idling its memory pipe while
-    // it computes.
-    int64_t tile = blockIdx.x;
-    u32x4 nxt[PF ? U : 1];
-    if constexpr (PF) {
-        if (tile < n_tiles) {
-            const int64_t vn = (tile * T::WAVES + wave) * T::WAVE_VECS;
-#pragma unroll
-            for (int k = 0; k < U; ++k) nxt[k] = ld<NT_LD>(in16 + vn + k * 64 + lane);
-        }
-    }
-    for (; tile < n_tiles; tile += gridDim.x) {
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t v0 = (tile * T::WAVES + wave) * T::WAVE_VECS;   // first input vector of this wave tile
 
         u32x4 raw[U];
-        if constexpr (PF) {
 #pragma unroll
-            for (int k = 0; k < U; ++k) raw[k] = nxt[k];
-            const int64_t tn = tile + gridDim.x;
-            if (tn < n_tiles) {
-                const int64_t vn = (tn * T::WAVES + wave) * T::WAVE_VECS;
-#pragma unroll
-                for (int k = 0; k < U; ++k) nxt[k] = ld<NT_LD>(in16 + vn + k * 64 + lane);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < U; ++k) raw[k] = ld<NT_LD>(in16 + v0 + k * 64 + lane);
-        }
+        for (int k = 0; k < U; ++k) raw[k] = ld<NT_LD>(in16 + v0 + k * 64 + lane);
 
         uint32_t w[U][WORDS];
         [[maybe_unused]] ElementKeys keys {};
         if constexpr (MODE == RM_STOCH_ELEM) keys = element_keys_for(p, p.index_base + static_cast<uint64_t>(v0 + lane) * EPV);
 #pragma unroll
-        for (int k = 0; k < U; ++k) {
-            float v[EPV];
-            InVec<DT_IN>::unpack(raw[k], v);
-#pragma unroll
-            for (int j = 0; j < WORDS; ++j) w[k][j] = 0;
-            const uint64_t e0 = static_cast<uint64_t>(v0 + k * 64 + lane) * EPV;
-            if constexpr (MODE == RM_NEAREST_FAST) {
-#pragma unroll
-                for (int e = 0; e < EPV; e += 2) {
-                    uint32_t q0, q1;
-                    quant_nearest_fast2<QMAX>(v[e], v[e + 1], p, q0, q1);
-                    w[k][(e * BITS) >> 5] |= (q0 | (q1 << BITS)) << ((e * BITS) & 31);
-                }
-            } else if constexpr (MODE == RM_STOCH_ELEM) {
-#pragma unroll
-                for (int e = 0; e < EPV; ++e) {
-                    const uint32_t q = quant_stochastic<QMAX>(v[e], p, element_threshold(keys, p.index_base + e0 + e));
-                    w[k][(e * BITS) >> 5] |= q << ((e * BITS) & 31);
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < EPV; ++e) {
-                    const uint32_t q = quant_one<MODE, QMAX>(v[e], p, e0 + e);
-                    w[k][(e * BITS) >> 5] |= q << ((e * BITS) & 31);
-                }
-            }
-        }
+        for (int k = 0; k < U; ++k) quantize_vec<DT_IN, BITS, MODE>(raw[k], p, keys, static_cast<uint64_t>(v0 + k * 64 + lane) * EPV, w[k]);
 
         uint8_t* o = out + v0 * OB;                                    // output of this wave tile
         if constexpr (!STAGE) {
 #pragma unroll
-            for (int k = 0; k < U; ++k) {
-                uint8_t* dst = o + static_cast<int64_t>(k * 64 + lane) * OB;
-                if constexpr (OB == 1) st<NT_ST>(dst, static_cast<uint8_t>(w[k][0]));
-                else if constexpr (OB == 2) st<NT_ST>(reinterpret_cast<uint16_t*>(dst), static_cast<uint16_t>(w[k][0]));
-                else if constexpr (OB == 4) st<NT_ST>(reinterpret_cast<uint32_t*>(dst), w[k][0]);
-                else st<NT_ST>(reinterpret_cast<u32x2*>(dst), u32x2{w[k][0], w[k][1]});
-            }
+            for (int k = 0; k < U; ++k) store_packed<OB, NT_ST>(o + static_cast<int64_t>(k * 64 + lane) * OB, w[k]);
         } else {
             uint8_t* s = lds + wave * T::WAVE_OUT_BYTES;
 #pragma unroll

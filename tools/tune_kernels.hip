@@ -200,7 +200,7 @@ static QuantParams qparams() {
     return p;
 }
 
-template <int DT_IN, int BITS, int MODE, int U, bool STAGE, int NT, int BLOCK, bool PF = false>
+template <int DT_IN, int BITS, int MODE, int U, bool STAGE, int NT, int BLOCK>
 static void run_quant(const Bufs& b, int64_t numel, int num_cu, double bytes_per_elem) {
     using T = QuantTile<DT_IN, BITS, U, BLOCK>;
     const int64_t n_tiles = numel / T::BLOCK_ELEMS;
@@ -209,12 +209,12 @@ static void run_quant(const Bufs& b, int64_t numel, int num_cu, double bytes_per
         int64_t g = cap == 0 ? n_tiles : std::min<int64_t>(n_tiles, static_cast<int64_t>(cap) * num_cu);
         const unsigned grid = static_cast<unsigned>(std::max<int64_t>(g, 1));
         const double us = time_us([&](int i) {
-            hipLaunchKernelGGL((quantize_kernel<DT_IN, BITS, MODE, U, STAGE, NT, BLOCK, PF>), dim3(grid), dim3(BLOCK), g_dyn_lds, g_stream, b.in[i % SETS],
+            hipLaunchKernelGGL((quantize_kernel<DT_IN, BITS, MODE, U, STAGE, NT, BLOCK>), dim3(grid), dim3(BLOCK), g_dyn_lds, g_stream, b.in[i % SETS],
                                static_cast<uint8_t*>(b.out[i % SETS]), numel, n_tiles, p);
         });
         char name[160];
-        std::snprintf(name, sizeof name, "in=%s bits=%d mode=%d U=%d stage=%d nt=%d block=%d pf=%d lds=%u cap=%d grid=%u", DT_IN == DT_F32 ? "f32" : "bf16", BITS, MODE, U,
-                      STAGE ? 1 : 0, NT, BLOCK, PF ? 1 : 0, g_dyn_lds, cap, grid);
+        std::snprintf(name, sizeof name, "in=%s bits=%d mode=%d U=%d stage=%d nt=%d block=%d lds=%u cap=%d grid=%u", DT_IN == DT_F32 ? "f32" : "bf16", BITS, MODE, U,
+                      STAGE ? 1 : 0, NT, BLOCK, g_dyn_lds, cap, grid);
         report("quantize", name, us, bytes_per_elem * numel);
     }
 }
@@ -540,18 +540,8 @@ int main(int argc, char** argv) {
         g_caps = {0, 2, 4, 8, 16};
         g_rounds = 3;
     }
-    if (only == "pf") {
-        g_caps = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16};
-        run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, 5, 64, false>(b, numel, num_cu, 5);
-        run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, 5, 64, true>(b, numel, num_cu, 5);
-        run_quant<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 64, true>(b, numel, num_cu, 5);
-        run_quant<DT_F32, 8, RM_NEAREST_FAST, 8, true, 5, 64, true>(b, numel, num_cu, 5);
-        run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, 5, 128, true>(b, numel, num_cu, 5);
-        run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, 5, 256, true>(b, numel, num_cu, 5);
-        run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, 5, 256, false>(b, numel, num_cu, 5);
-        run_quant<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 256, true>(b, numel, num_cu, 5);
-        g_caps = {0, 2, 4, 8, 16};
-    }
+    // (a "pf" section once compared persistent grids with software prefetch of the next tile: always slower than one small tile
+    // per block, profiles/r01_tune_experiments.csv; the kernel variant was removed from quant_kernels.hpp)
     if (only == "exp") {
         const QuantParams p = qparams();
         // (1) fixed vs per-byte cost: production headline kernel at several sizes (all within the 109 MB input buffers)
