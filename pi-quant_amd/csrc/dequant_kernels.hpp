@@ -175,7 +175,7 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
                         f[2 * e] = __fadd_rn(f[2 * e], __uint_as_float(old[k][e] << 16));
                         f[2 * e + 1] = __fadd_rn(f[2 * e + 1], __uint_as_float(old[k][e] & 0xffff0000u));
                     }
-                    r[e] = f32_to_bf16_bits(f[2 * e]) | (f32_to_bf16_bits(f[2 * e + 1]) << 16);
+                    r[e] = f32x2_to_bf16x2_bits(f[2 * e], f[2 * e + 1]);
                 }
             }
             st<NT_ST>(out16 + v0 + k * 64 + lane, r);

@@ -81,11 +81,28 @@ __device__ __forceinline__ DequantParams resolved(DequantParams p) {
 // bf16 <-> f32: include/piquant.hpp:86-95
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
 
-__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// fp32 -> bf16 as the reference does it (include/piquant.hpp:86-90): round to nearest even, a NaN stays a NaN with its quiet
+// bit set, (u >> 16) | 0x40.  gfx950 has this as ONE instruction, v_cvt_pk_bf16_f32 (two elements at a time), where the
+// integer formulation costs six per element; tools/probe_bf16_cvt.hip compares the two on all 2^32 inputs (denormals and
+// every NaN payload included): no difference.  f32_to_bf16_bits_int keeps the integer form for that probe.
+__device__ __forceinline__ uint32_t f32_to_bf16_bits_int(float f) {
     const uint32_t u = __float_as_uint(f);
     const uint32_t rne = (u + (0x7fffu + ((u >> 16) & 1u))) >> 16;
     const uint32_t qnan = (u >> 16) | 64u;
     return ((u & 0x7fffffffu) > 0x7f800000u) ? qnan : rne;
+}
+
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+    return static_cast<uint32_t>(__builtin_bit_cast(uint16_t, static_cast<__bf16>(f)));
+}
+
+// {lo, hi} -> packed pair, lo in bits 0-15
+__device__ __forceinline__ uint32_t f32x2_to_bf16x2_bits(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
 
 // x86 cvttps2dq: truncate; NaN and anything outside [-2^31, 2^31) give INT32_MIN.  The float is clamped
@@ -152,8 +169,6 @@ __device__ __forceinline__ uint32_t quant_nearest_fast(float x, const QuantParam
 // Two elements at once: the product and the sum are packed-fp32 instructions (v_pk_mul_f32 / v_pk_add_f32, each
 // element rounded exactly like the scalar op).  Contraction must stay off: a fused multiply-add would skip the
 // rounding of the product that the reference performs.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
 template <int QMAX>
 __device__ __forceinline__ void quant_nearest_fast2(float x0, float x1, const QuantParams& p, uint32_t& q0, uint32_t& q1) {
 #pragma clang fp contract(off)

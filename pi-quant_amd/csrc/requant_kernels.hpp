@@ -49,7 +49,7 @@ __device__ __forceinline__ void requant_vec(const u32x4& raw, const u32x4& old, 
                 r[2 * e] = __fadd_rn(__uint_as_float(old[e] << 16), r[2 * e]);
                 r[2 * e + 1] = __fadd_rn(__uint_as_float(old[e] & 0xffff0000u), r[2 * e + 1]);
             }
-            res[e] = f32_to_bf16_bits(r[2 * e]) | (f32_to_bf16_bits(r[2 * e + 1]) << 16);
+            res[e] = f32x2_to_bf16x2_bits(r[2 * e], r[2 * e + 1]);
         }
     }
 }
