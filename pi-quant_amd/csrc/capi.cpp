@@ -602,7 +602,7 @@ void piquant_hip_quantize_dynamic(piquant_context_t* ctx, const void* in, piquan
             q.ref_head = static_cast<int>(std::min<size_t>(numel, (16u - (reinterpret_cast<uintptr_t>(out) & 15u)) & 15u));
     }
     // One launch with the tensor held on chip between the scan and the quantization when it fits; otherwise (or with fusion
-    // switched off) the same result from three launches: scan, parameter epilogue, quantize reading the record.
+    // switched off) the same result from two launches: the scan, whose last block writes the record, and a quantize that reads it.
     bool fused = false;
     if (ctx->fusion && fused_launch_applies(q, ctx->num_cu)) {
         const bool record = fused_order_before(ctx->device, ctx->stream);

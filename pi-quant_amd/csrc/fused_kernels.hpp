@@ -6,11 +6,12 @@
 // a persistent grid of one block per CU can KEEP its share of x on chip between the two passes:
 //
 //   phase 1  every thread loads its vectors (R_REG of them stay in VGPRs, R_LDS more in the block's LDS) and folds
-//            min/max on the way; block result -> 64 slot pairs in device memory (conditional atomicMin, as minmax_kernel)
-//   barrier  grid-wide: one arrival counter + a generation word (device-scope atomics; all blocks are co-resident because
-//            the grid never exceeds the CU count)
-//   phase 2  every wave folds the 64 slots, every lane runs the reference's double-precision (min,max)->(scale,zp) epilogue
-//            (bit-identical on all lanes), block 0 publishes the 16-byte ParamRecord for the caller / the dequantizing side
+//            min/max on the way; block result -> 64 slot pairs in device memory (atomicMin on keys, as minmax_kernel)
+//   barrier  grid-wide: an arrival counter in device memory; the LAST block to arrive folds the slots, runs the
+//            reference's double-precision (min,max)->(scale,zp) epilogue once, writes the 16-byte ParamRecord for the
+//            caller / the dequantizing side and publishes {launch tag, zero point, scale bits} in one 64-bit word that
+//            the waiting blocks spin on (device-scope atomics only, no fences; all blocks are co-resident because the
+//            grid never exceeds the CU count)
 //   phase 3  the resident vectors are quantized straight from registers / LDS and stored: the only HBM traffic of this
 //            phase is the packed output
 //
@@ -24,8 +25,9 @@
 // layer orders fused launches of different streams behind one another (capi.cpp, FusedOrder); processes that share one GPU
 // must switch the fused path off (PIQUANT_HIP_FUSION=0 / piquant_hip_set_fusion) -- the design rule is one process per GPU.
 //
-// Capacity: (R_REG + R_LDS) x 16 B x BLOCK threads x grid blocks (121.6 MB at 256 CUs).  The host launches this kernel
-// only when the tensor fits and both pointers are 16-byte aligned, and otherwise takes the three-launch path.
+// Capacity: (R_REG + R_LDS) x 16 B x BLOCK threads x grid blocks (113 MB with the production 18 + 9 rounds of 1024 threads
+// on 256 CUs, tuning.hpp).  The host launches this kernel only when the tensor fits and both pointers are 16-byte aligned,
+// and otherwise runs the scan (with the parameter epilogue) and the quantize kernel as two launches.
 //
 // State in device memory (FusedState) is self-maintaining, so that a launch needs no host-side reset and replays
 // unchanged inside a hipGraph: the generation word picks which of two slot buffers this launch folds into and the other

@@ -90,7 +90,7 @@ int minmax_state_ints();
 // q.inv_scale / q.zero_point / q.dyn_params are ignored: the parameters come from the data and are also written to
 // device_param_record.  `state` is a fused_state_bytes() device buffer prepared once with init_fused_state().  Returns false
 // without launching when the call does not qualify (tensor larger than the chip holds, misaligned buffers, reference-layout
-// mode): the caller then runs scan -> params -> quantize as three launches, with identical results.
+// mode): the caller then runs the scan (parameter epilogue in its last block) and the quantize kernel, with identical results.
 bool launch_fused_params_quantize(const QuantLaunch& q, void* state, void* device_param_record, hipStream_t stream, int num_cu);
 bool fused_launch_applies(const QuantLaunch& q, int num_cu);   // the test launch_fused_params_quantize makes, without launching
 size_t fused_state_bytes();

@@ -209,7 +209,7 @@ class Context:
         C.piquant_hip_quantize_dynamic(self._ctx, ptr_in, dtype_in.value, ptr_out, dtype_out.value, numel, params_ptr, round_mode.value)
 
     def set_fusion(self, enabled: bool) -> None:
-        """False: ``quantize_dynamic`` always runs scan, parameter kernel and quantize as three launches (for A/B timing)."""
+        """False: ``quantize_dynamic`` always runs the scan (with its parameter epilogue) and the quantize kernel as two launches (for A/B timing)."""
         C.piquant_hip_set_fusion(self._ctx, 1 if enabled else 0)
 
     def dequantize_dp_ptr(self, ptr_in: int, dtype_in: DataType, ptr_out: int, dtype_out: DataType, numel: int, params_ptr: int,

@@ -246,7 +246,7 @@ def quantize_dynamic(tensor: torch.Tensor, *, dtype: torch.dtype, round_mode: st
                      out: Optional[torch.Tensor] = None, params: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """``compute_quant_params`` + ``quantize`` in one asynchronous call, parameters computed and kept on the device.  Returns
     (quantized, parameter record).  A tensor that fits on the chip (up to ~113 MB on an MI355X) is read from HBM once, by a single
-    kernel that keeps it in registers / LDS between the min/max pass and the quantization; larger ones take three launches."""
+    kernel that keeps it in registers / LDS between the min/max pass and the quantization; larger ones take two launches (scan with the parameter epilogue, then quantize)."""
     assert dtype in _QUANT_TYPES and tensor.is_cuda and tensor.dtype in _DEQUANT_TYPES
     if not tensor.is_contiguous():
         tensor = tensor.contiguous()

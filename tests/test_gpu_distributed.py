@@ -71,7 +71,7 @@ def _ring_gpu_worker(rank, world, port, numel, qname, out_q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     # several processes share ONE GPU here (not the deployment model, which is one process per GPU): the one-launch
     # params + quantize kernel holds a grid barrier and two of them dispatched at the same instant by different processes could
-    # each take part of the CUs, so it is switched off -- the three-launch path produces the same bytes
+    # each take part of the CUs, so it is switched off -- the unfused path produces the same bytes
     os.environ["PIQUANT_HIP_FUSION"] = "0"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:

@@ -848,7 +848,7 @@ def _dynamic_cases(rng, n):
     yield "huge range", (rng.normal(size=n) * 1e30).astype(np.float32)
 
 
-def test_fused_dynamic_quantize_matches_oracle_and_three_launch_path(O):
+def test_fused_dynamic_quantize_matches_oracle_and_unfused_path(O):
     import piquant
 
     rng = np.random.default_rng(2024)
@@ -899,7 +899,7 @@ def test_fused_dynamic_quantize_stochastic_modes(O):
 
 
 def test_fused_dynamic_quantize_capacity_boundary_headline_size_and_misalignment(O):
-    """The largest tensor the chip holds (27 rounds x 1024 threads x 16 B per CU), one vector more (three-launch fallback), the
+    """The largest tensor the chip holds (27 rounds x 1024 threads x 16 B per CU), one vector more (two-launch fallback), the
     BASELINE size, and a misaligned input (fallback): all equal the oracle."""
     import piquant
     import torch
