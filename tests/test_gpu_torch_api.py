@@ -117,3 +117,50 @@ def test_non_contiguous_input_is_made_contiguous():
     q = piquant.torch.quantize(x, scale=0.0078431377, zero_point=127, dtype=torch.uint8)
     q2 = piquant.torch.quantize(x.contiguous(), scale=0.0078431377, zero_point=127, dtype=torch.uint8)
     assert torch.equal(q, q2) and q.shape == x.shape
+
+
+def test_native_front_end_matches_the_ctypes_path():
+    """piquant.torch.quantize / dequantize go through csrc/torch_binding.cpp when it is built; the ctypes path must give the
+    same tensors (dtype, shape, device, bytes), including out=, ADD and non-contiguous input."""
+    import piquant
+    import piquant.torch as pt
+
+    if pt._native is None:
+        pytest.skip("native front end not built")
+    native = pt._native
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.empty(257, 129, device="cuda").uniform_(-2, 3, generator=g)
+    try:
+        for src in (x, x.to(torch.bfloat16), x.t()):
+            for qdt in (torch.quint8, torch.uint8, torch.quint4x2, torch.quint2x4):
+                scale, zp = pt.compute_quant_params(src.contiguous(), dtype=qdt)
+                pt._native = native
+                q_n = pt.quantize(src, scale=scale, zero_point=zp, dtype=qdt)
+                d_n = pt.dequantize(q_n, scale=scale, zero_point=zp, dtype=src.dtype)
+                acc_n = torch.ones_like(d_n)
+                pt.dequantize(q_n, scale=scale, zero_point=zp, dtype=src.dtype, reduce_op="add", out=acc_n)
+                pt._native = None
+                q_c = pt.quantize(src, scale=scale, zero_point=zp, dtype=qdt)
+                d_c = pt.dequantize(q_c, scale=scale, zero_point=zp, dtype=src.dtype)
+                acc_c = torch.ones_like(d_c)
+                pt.dequantize(q_c, scale=scale, zero_point=zp, dtype=src.dtype, reduce_op="add", out=acc_c)
+                assert q_n.dtype == q_c.dtype == qdt and q_n.shape == q_c.shape == src.shape and q_n.device == src.device
+                assert torch.equal(pt.packed_bytes(q_n), pt.packed_bytes(q_c))
+                assert d_n.dtype == src.dtype and torch.equal(d_n.view(torch.int16 if src.dtype == torch.bfloat16 else torch.int32),
+                                                              d_c.view(torch.int16 if src.dtype == torch.bfloat16 else torch.int32))
+                assert torch.equal(acc_n, acc_c)
+        # mixing the two paths on one context: stream / blocking caches must stay coherent
+        pt._native = native
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            a = pt.quantize(x, scale=0.02, zero_point=100, dtype=torch.quint8)
+            pt._native = None
+            b = pt.quantize(x, scale=0.02, zero_point=100, dtype=torch.quint8)
+        pt._native = native
+        c = pt.quantize(x, scale=0.02, zero_point=100, dtype=torch.quint8)
+        torch.cuda.synchronize()
+        assert torch.equal(pt.packed_bytes(a), pt.packed_bytes(b)) and torch.equal(pt.packed_bytes(a), pt.packed_bytes(c))
+        with pytest.raises(ValueError):
+            pt.dequantize(a, scale=0.02, zero_point=100, dtype=torch.float32, reduce_op="add")
+    finally:
+        pt._native = native

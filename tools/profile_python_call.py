@@ -11,6 +11,7 @@ out8 = torch.empty(x.shape, dtype=torch.uint8, device='cuda')
 outq = torch.empty(x.shape, dtype=torch.quint8, device='cuda')
 ctx = piquant.Context.get(0)
 from piquant import DataType, RoundMode
+print("native front end: %s" % (piquant.torch._native is not None))
 print("full quantize(dtype=quint8)       %.2f us" % t(lambda: piquant.torch.quantize(x, scale=scale, zero_point=zp, dtype=torch.quint8)))
 print("full quantize(dtype=uint8)        %.2f us" % t(lambda: piquant.torch.quantize(x, scale=scale, zero_point=zp, dtype=torch.uint8)))
 print("quantize(out=preallocated quint8) %.2f us" % t(lambda: piquant.torch.quantize(x, scale=scale, zero_point=zp, dtype=torch.quint8, out=outq)))
