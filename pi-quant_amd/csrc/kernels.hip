@@ -193,6 +193,8 @@ void init_fused_state(void* state, hipStream_t stream) {
     launch_arm_slots(&st->slots[1][0], stream);
 }
 
+static int64_t n_vec_of(const QuantLaunch& q) { return q.numel / (q.dt_in == DT_F32 ? 4 : 8); }
+
 bool fused_launch_applies(const QuantLaunch& q, int num_cu) {
     if (q.numel <= 0 || q.ref_layout || !aligned16(q.in) || !aligned16(q.out)) return false;
     if (q.dt_in != DT_F32 && q.dt_in != DT_BF16) panic("invalid quantization types: %d -> %d", q.dt_in, q.dt_out);
@@ -209,8 +211,11 @@ bool launch_fused_params_quantize(const QuantLaunch& q, void* state, void* devic
     p.index_base = q.index_base;
     FusedState* st = static_cast<FusedState*>(state);
     ParamRecord* rec = static_cast<ParamRecord*>(device_param_record);
-    // One block per CU: the grid barrier needs every block resident, and a 1024-thread block with 144 KiB of LDS owns its CU.
-    const unsigned grid = static_cast<unsigned>(num_cu);
+    // At most one block per CU: the grid barrier needs every block resident, and a 1024-thread block with 144 KiB of LDS owns
+    // its CU.  Small tensors get a smaller grid (at least kFusedMinRounds vectors per thread before another block is added):
+    // fewer arrivals at the barrier, nothing idle to launch.
+    const int64_t want = (n_vec_of(q) + static_cast<int64_t>(kFusedBlock) * kFusedMinRounds - 1) / (static_cast<int64_t>(kFusedBlock) * kFusedMinRounds);
+    const unsigned grid = static_cast<unsigned>(std::min<int64_t>(num_cu, std::max<int64_t>(want, 1)));
     switch (q.dt_in) {
         case DT_F32: fused_bits<DT_F32>(q, p, st, rec, stream, grid); break;
         default: fused_bits<DT_BF16>(q, p, st, rec, stream, grid); break;

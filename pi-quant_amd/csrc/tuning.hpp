@@ -50,6 +50,7 @@ constexpr int kMinmaxBlocksPerCU = 2;
 constexpr int kFusedBlock = 1024;
 constexpr int kFusedRegRounds = 18;
 constexpr int kFusedLdsRounds = 9;
+constexpr int kFusedMinRounds = 2;   // grid sizing for small tensors: vectors per thread before another block joins
 
 constexpr int kScalarBlock = 256;   // guarded kernels for misaligned buffers
 
