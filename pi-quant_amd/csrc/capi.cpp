@@ -197,7 +197,9 @@ bool fused_order_before(int device, hipStream_t stream) {
     std::lock_guard<std::mutex> lock(o.mu);
     if (o.seen && o.last_stream != stream) {
         if (!o.multi_stream) {
-            PQ_HIP(hipDeviceSynchronize());
+            // once per device and process: whatever the first stream still has in flight finishes before the second stream's
+            // first fused launch (no event exists yet to wait for).  Not fatal if the runtime refuses (another thread capturing).
+            if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
             PQ_HIP(hipEventCreateWithFlags(&o.last, hipEventDisableTiming));
             o.multi_stream = true;
         } else {
