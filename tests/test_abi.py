@@ -112,3 +112,19 @@ def test_no_gpu_is_a_loud_python_error_not_a_fallback():
         piquant.Context()
     with pytest.raises(RuntimeError, match="no CPU path"):
         piquant.torch.quantize(torch.zeros(16), scale=1.0, zero_point=0, dtype=torch.quint8)
+
+
+def test_native_torch_front_end_loads_and_checks_arguments():
+    """piquant/_piquant_torch.so (csrc/torch_binding.cpp, built by __graft_entry__.build()) imports next to libpiquant.so and
+    converts its arguments; without a GPU the call itself must be refused, not attempted."""
+    import torch
+
+    import piquant.torch as pt
+
+    if pt._native is None:
+        pytest.skip("native front end not built (python pi-quant_amd/csrc/build_torch_binding.py)")
+    with pytest.raises(RuntimeError, match="device tensors"):
+        pt._native.quantize(0, torch.zeros(8), 1.0, 0, torch.quint8, 0, None)
+    with pytest.raises(RuntimeError, match="device tensors"):
+        pt._native.dequantize(0, torch.zeros(8, dtype=torch.uint8), 1.0, 0, torch.float32, 0, None)
+    assert set(dir(pt._native)) >= {"quantize", "dequantize"}
