@@ -121,6 +121,16 @@ PIQUANT_EXPORT void piquant_hip_quantize_dynamic(piquant_context_t* ctx, const v
                                                  piquant_round_mode_t mode);
 PIQUANT_EXPORT void piquant_hip_set_fusion(piquant_context_t* ctx, int enabled);
 
+/* out (op)= dequantize(inputs[0]) + dequantize(inputs[1]) + ... : `count` quantized tensors of the same dtype and length, each
+ * with its own 16-byte parameter record in device memory, summed into one float tensor in a single pass -- the reduction
+ * step of a quantized all-reduce in which a rank receives one chunk from every peer (xGMI is a point-to-point mesh: all
+ * peers send at once).  Bit-identical to `count` piquant_hip_dequantize_dp calls in order (the first with `op`, the others
+ * with ADD), but the accumulator is read and written once instead of `count` times.  Device (or pinned) buffers only. */
+PIQUANT_EXPORT void piquant_hip_dequantize_sum(piquant_context_t* ctx, const void* const* inputs,
+                                               const piquant_hip_params_t* const* device_params, size_t count,
+                                               piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out, size_t numel,
+                                               piquant_reduce_op_t op);
+
 /* compute_quant_params of a tensor whose shards live on several GPUs, for C / C++ hosts (one process per GPU): every
  * rank passes its local shard and its RCCL communicator (an ncclComm_t as void*).  Local HIP scan -> {key(min), key(-max)}
  * -> ONE ncclAllReduce(2 x int32, ncclMin) over xGMI on the context's stream -> identical double-precision epilogue on

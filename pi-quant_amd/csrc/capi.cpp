@@ -451,6 +451,41 @@ void piquant_hip_dequantize_dp(piquant_context_t* ctx, const void* in, piquant_d
     dequantize_impl(ctx, in, dtype_in, out, dtype_out, numel, 1.0f, 0, op, device_params);
 }
 
+void piquant_hip_dequantize_sum(piquant_context_t* ctx, const void* const* inputs, const piquant_hip_params_t* const* device_params, size_t count,
+                                piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out, size_t numel, piquant_reduce_op_t op) {
+    if (!ctx) panic("piquant_hip_dequantize_sum: context is NULL");
+    const dtype_row& dti = dtype_of(dtype_in);
+    const dtype_row& dto = dtype_of(dtype_out);
+    if (!dti.quant) panic("dequantize: input dtype (%s) must be a quantized type", dti.name);
+    if (dto.quant) panic("dequantize: output dtype (%s) must be a dequantized type", dto.name);
+    if (op != PIQUANT_REDUCE_OP_SET && op != PIQUANT_REDUCE_OP_ADD) panic("dequantize: invalid reduce op %d", static_cast<int>(op));
+    if (count == 0 || numel == 0) return;
+    if (!inputs || !device_params || !out) panic("dequantize_sum: NULL argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    const Resolved rout = ctx->resolve_ptr(out);
+    if (rout.pageable) panic("piquant_hip_dequantize_sum needs device (or pinned) buffers");
+    // more inputs than one launch takes: the first launch carries the caller's op, the following ones accumulate
+    for (size_t first = 0; first < count; first += kDequantSumMaxInputs) {
+        DequantSumLaunch d {};
+        d.count = static_cast<int>(std::min<size_t>(kDequantSumMaxInputs, count - first));
+        for (int i = 0; i < d.count; ++i) {
+            if (!inputs[first + i] || !device_params[first + i]) panic("dequantize_sum: NULL input %zu", first + i);
+            const Resolved ri = ctx->resolve_ptr(inputs[first + i]), rp = resolve(device_params[first + i]);
+            if (ri.pageable || rp.pageable) panic("piquant_hip_dequantize_sum needs device (or pinned) buffers");
+            d.in[i] = ri.dev;
+            d.params[i] = rp.dev;
+        }
+        d.out = rout.dev;
+        d.numel = static_cast<int64_t>(numel);
+        d.dt_in = dtype_in;
+        d.dt_out = dtype_out;
+        d.op = (first == 0 && op == PIQUANT_REDUCE_OP_SET) ? OP_SET : OP_ADD;
+        launch_dequantize_sum(d, ctx->stream, ctx->num_cu);
+    }
+    if (ctx->blocking) wait_stream(ctx->stream);
+}
+
 void piquant_hip_quantize_dequantize(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in_out, void* out, piquant_dtype_t quant_dtype,
                                      size_t numel, float scale, int64_t zero_point, piquant_round_mode_t mode, piquant_reduce_op_t op) {
     if (!ctx) panic("piquant_hip_quantize_dequantize: context is NULL");

@@ -188,4 +188,114 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// out (op)= sum over K quantized inputs, each with its own device-resident (scale, zero point): the reduction step of a
+// quantized all-reduce on a point-to-point mesh, where a rank receives one quantized chunk from every peer at once.
+// K sequential dequantize(ADD) calls re-read and re-write the accumulator K times (9 B/elem each); here it is read and written
+// once: K x packed bytes + 2 x float bytes per element.  The arithmetic is that of the K calls in order -- acc = old (ADD) or
+// the first term (SET), then acc = acc + f_k with the accumulator rounded to the output type after every term, as it would be
+// when stored between calls -- so the result is bit-identical to them (tests compare both ways).
+// Layout: lane l of a wave owns output vector v0 + k*64 + l and reads the OB packed bytes that produce it from every input
+// (4 / 2 / 1 bytes for fp32 output, 8 / 4 / 2 for bf16): narrow but contiguous across the wave.
+constexpr int kDequantSumMax = 16;
+
+struct DequantSumArgs {
+    const uint8_t* in[kDequantSumMax];
+    const ParamRecord* params[kDequantSumMax];
+    int count;
+};
+
+template <int BITS, int DT_OUT>
+__device__ __forceinline__ void dequant_sum_term(const uint8_t* src, const DequantParams& p, float (&acc)[DT_OUT == DT_F32 ? 4 : 8], bool first) {
+    constexpr int EPV = DT_OUT == DT_F32 ? 4 : 8, IB = EPV * BITS / 8, WORDS = IB > 4 ? 2 : 1;
+    constexpr int FORM = DequantForm<BITS, DT_OUT>::value;
+    uint32_t w[WORDS];
+    if constexpr (IB == 1) w[0] = ld<true>(src);
+    else if constexpr (IB == 2) w[0] = ld<true>(reinterpret_cast<const uint16_t*>(src));
+    else if constexpr (IB == 4) w[0] = ld<true>(reinterpret_cast<const uint32_t*>(src));
+    else {
+        const u32x2 t = ld<true>(reinterpret_cast<const u32x2*>(src));
+        w[0] = t[0];
+        w[WORDS - 1] = t[1];
+    }
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+        const uint32_t q = (w[(e * BITS) >> 5] >> ((e * BITS) & 31)) & ((1u << BITS) - 1u);
+        const float f = dequant_one<FORM>(q, p);
+        float a = first ? f : __fadd_rn(f, acc[e]);
+        if constexpr (DT_OUT == DT_BF16) a = bf16_bits_to_f32(f32_to_bf16_bits(a));   // what a store to bf16 memory between two calls does
+        acc[e] = a;
+    }
+}
+
+template <int BITS, int DT_OUT, int OP, int U, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) dequantize_sum_kernel(DequantSumArgs a, void* out, int64_t numel, int64_t n_tiles) {
+    constexpr int EPV = DT_OUT == DT_F32 ? 4 : 8, IB = EPV * BITS / 8;
+    constexpr int64_t TILE_VECS = static_cast<int64_t>(BLOCK) * U;
+    u32x4* out16 = static_cast<u32x4*>(out);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t v0 = tile * TILE_VECS + static_cast<int64_t>(wave) * U * 64;
+        float acc[U][EPV];
+        if constexpr (OP == OP_ADD) {
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const u32x4 old = ld<true>(out16 + v0 + k * 64 + lane);
+                if constexpr (DT_OUT == DT_F32) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[k][e] = __uint_as_float(old[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[k][2 * e] = __uint_as_float(old[e] << 16);
+                        acc[k][2 * e + 1] = __uint_as_float(old[e] & 0xffff0000u);
+                    }
+                }
+            }
+        }
+        for (int i = 0; i < a.count; ++i) {
+            DequantParams p {};
+            p.dyn = a.params[i];
+            p = resolved(p);
+#pragma unroll
+            for (int k = 0; k < U; ++k)
+                dequant_sum_term<BITS, DT_OUT>(a.in[i] + (v0 + k * 64 + lane) * IB, p, acc[k], OP == OP_SET && i == 0);
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            u32x4 r;
+            if constexpr (DT_OUT == DT_F32) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = __float_as_uint(acc[k][e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = f32x2_to_bf16x2_bits(acc[k][2 * e], acc[k][2 * e + 1]);
+            }
+            st<ST_WT>(out16 + v0 + k * 64 + lane, r);
+        }
+    }
+
+    // ragged tail -- and everything, when a buffer is not 16-byte aligned (n_tiles == 0): element by element, same order of terms
+    const int64_t done = n_tiles * TILE_VECS * EPV;
+    {
+        for (int64_t i = done + static_cast<int64_t>(blockIdx.x) * BLOCK + threadIdx.x; i < numel; i += static_cast<int64_t>(gridDim.x) * BLOCK) {
+            float acc = 0.0f;
+            if constexpr (OP == OP_ADD) acc = DT_OUT == DT_F32 ? static_cast<const float*>(out)[i] : bf16_bits_to_f32(static_cast<const uint16_t*>(out)[i]);
+            for (int t = 0; t < a.count; ++t) {
+                DequantParams p {};
+                p.dyn = a.params[t];
+                p = resolved(p);
+                constexpr int PACK = 8 / BITS;
+                const uint32_t q = (a.in[t][i / PACK] >> ((i % PACK) * BITS)) & ((1u << BITS) - 1u);
+                const float f = dequant_one<DequantForm<BITS, DT_OUT>::value>(q, p);
+                acc = (OP == OP_SET && t == 0) ? f : __fadd_rn(f, acc);
+                if constexpr (DT_OUT == DT_BF16) acc = bf16_bits_to_f32(f32_to_bf16_bits(acc));
+            }
+            if constexpr (DT_OUT == DT_F32) static_cast<float*>(out)[i] = acc;
+            else static_cast<uint16_t*>(out)[i] = static_cast<uint16_t>(f32_to_bf16_bits(acc));
+        }
+    }
+}
+
 }  // namespace pq

@@ -246,6 +246,60 @@ void launch_dequantize(const DequantLaunch& d, hipStream_t stream, int num_cu) {
 
 namespace {
 
+template <int BITS, int DT_OUT, int OP>
+void dequantize_sum_t(const DequantSumLaunch& d, const DequantSumArgs& a, hipStream_t stream, int num_cu) {
+    constexpr int U = 2, BLOCK = 128;
+    constexpr int EPV = DT_OUT == DT_F32 ? 4 : 8;
+    bool aligned = aligned16(d.out);
+    for (int i = 0; i < d.count; ++i) aligned = aligned && aligned16(d.in[i]);
+    const int64_t tile_elems = static_cast<int64_t>(BLOCK) * U * EPV;
+    const int64_t n_tiles = aligned ? d.numel / tile_elems : 0;
+    const unsigned grid = n_tiles > 0 ? static_cast<unsigned>(std::min<int64_t>(n_tiles, int64_t {1} << 30))
+                                      : capped_grid((d.numel + BLOCK - 1) / BLOCK, 16, num_cu);
+    hipLaunchKernelGGL((dequantize_sum_kernel<BITS, DT_OUT, OP, U, BLOCK>), dim3(grid), dim3(BLOCK), 0, stream, a, d.out, d.numel, n_tiles);
+}
+
+template <int BITS, int DT_OUT>
+void dequantize_sum_op(const DequantSumLaunch& d, const DequantSumArgs& a, hipStream_t stream, int num_cu) {
+    switch (d.op) {
+        case OP_SET: dequantize_sum_t<BITS, DT_OUT, OP_SET>(d, a, stream, num_cu); return;
+        case OP_ADD: dequantize_sum_t<BITS, DT_OUT, OP_ADD>(d, a, stream, num_cu); return;
+        default: panic("invalid reduce op %d", d.op);
+    }
+}
+
+template <int BITS>
+void dequantize_sum_out(const DequantSumLaunch& d, const DequantSumArgs& a, hipStream_t stream, int num_cu) {
+    switch (d.dt_out) {
+        case DT_F32: dequantize_sum_op<BITS, DT_F32>(d, a, stream, num_cu); return;
+        case DT_BF16: dequantize_sum_op<BITS, DT_BF16>(d, a, stream, num_cu); return;
+        default: panic("invalid dequantization types: %d -> %d", d.dt_in, d.dt_out);
+    }
+}
+
+}  // namespace
+
+void launch_dequantize_sum(const DequantSumLaunch& d, hipStream_t stream, int num_cu) {
+    static_assert(kDequantSumMaxInputs == kDequantSumMax, "host and device input limits");
+    if (d.numel <= 0 || d.count <= 0) return;
+    if (d.count > kDequantSumMax) panic("dequantize_sum: %d inputs, at most %d per call", d.count, kDequantSumMax);
+    DequantSumArgs a {};
+    a.count = d.count;
+    for (int i = 0; i < d.count; ++i) {
+        a.in[i] = static_cast<const uint8_t*>(d.in[i]);
+        a.params[i] = static_cast<const ParamRecord*>(d.params[i]);
+    }
+    switch (d.dt_in) {
+        case DT_UINT8: dequantize_sum_out<8>(d, a, stream, num_cu); break;
+        case DT_UINT4: dequantize_sum_out<4>(d, a, stream, num_cu); break;
+        case DT_UINT2: dequantize_sum_out<2>(d, a, stream, num_cu); break;
+        default: panic("invalid dequantization types: %d -> %d", d.dt_in, d.dt_out);
+    }
+    PQ_HIP(hipGetLastError());
+}
+
+namespace {
+
 template <int DT, int BITS, int MODE, int OP>
 void requantize_t(const RequantLaunch& r, const QuantParams& qp, const DequantParams& dp, float scale_bf16, hipStream_t stream, int num_cu) {
     constexpr KernelTune t = kRequantTune;

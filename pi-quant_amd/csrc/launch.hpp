@@ -58,6 +58,20 @@ struct RequantLaunch {
     uint64_t index_base;
 };
 
+// out (op)= sum of `count` quantized inputs of type dt_in, input i with its own 16-byte device ParamRecord (dequant_kernels.hpp)
+constexpr int kDequantSumMaxInputs = 16;
+struct DequantSumLaunch {
+    const void* in[kDequantSumMaxInputs];
+    const void* params[kDequantSumMaxInputs];
+    int count;
+    void* out;
+    int64_t numel;
+    int dt_in;
+    int dt_out;
+    int op;
+};
+void launch_dequantize_sum(const DequantSumLaunch& d, hipStream_t stream, int num_cu);
+
 // All launches are asynchronous on `stream`; num_cu sizes capped grids.
 void launch_quantize(const QuantLaunch& q, hipStream_t stream, int num_cu);
 void launch_dequantize(const DequantLaunch& d, hipStream_t stream, int num_cu);

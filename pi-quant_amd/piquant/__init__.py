@@ -208,6 +208,19 @@ class Context:
         self.assume_device_pointers(_device_ptrs)
         C.piquant_hip_quantize_dynamic(self._ctx, ptr_in, dtype_in.value, ptr_out, dtype_out.value, numel, params_ptr, round_mode.value)
 
+    def dequantize_sum_ptr(self, ptrs_in, params_ptrs, dtype_in: DataType, ptr_out: int, dtype_out: DataType, numel: int, reduce_op: ReduceOp,
+                           _device_ptrs: bool = False) -> None:
+        """out (op)= sum of dequantize(input i) over several quantized buffers, each with its own device parameter record, in one
+        pass (include/piquant_hip.h, piquant_hip_dequantize_sum); bit-identical to the calls made one after the other."""
+        assert dtype_in.is_quantized and dtype_out.is_dequantized and len(ptrs_in) == len(params_ptrs)
+        n = len(ptrs_in)
+        if n == 0:
+            return
+        self.assume_device_pointers(_device_ptrs)
+        arr_in = (_C.c_void_p * n)(*ptrs_in)
+        arr_p = (_C.c_void_p * n)(*params_ptrs)
+        C.piquant_hip_dequantize_sum(self._ctx, arr_in, arr_p, n, dtype_in.value, ptr_out, dtype_out.value, numel, reduce_op.value)
+
     def set_fusion(self, enabled: bool) -> None:
         """False: ``quantize_dynamic`` always runs the scan (with its parameter epilogue) and the quantize kernel as two launches (for A/B timing)."""
         C.piquant_hip_set_fusion(self._ctx, 1 if enabled else 0)

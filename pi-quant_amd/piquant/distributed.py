@@ -89,6 +89,13 @@ class _DeviceOps:
         dequantize_dynamic(buf[_HEADER_BYTES:], buf[:_HEADER_BYTES], dtype=out.dtype, reduce_op=reduce_op, ctx=self.ctx, out=out,
                            quant_dtype=qdtype, shape=out.shape)
 
+    def decode_sum(self, bufs, out: torch.Tensor, qdtype: torch.dtype) -> None:
+        """out += sum of the wire buffers, one pass over ``out`` (same result as decode(..., 'add') buffer by buffer)."""
+        from .torch import dequantize_sum
+
+        dequantize_sum([b[_HEADER_BYTES:] for b in bufs], [b[:_HEADER_BYTES] for b in bufs], dtype=out.dtype, reduce_op='add', ctx=self.ctx,
+                       out=out, quant_dtype=qdtype, shape=out.shape)
+
 
 def _exchange(send: torch.Tensor, recv: torch.Tensor, nxt: int, prv: int, group) -> None:
     """Send `send` to the next rank of the ring while receiving `recv` from the previous one.  RCCL (backend nccl)
@@ -105,6 +112,29 @@ def _exchange(send: torch.Tensor, recv: torch.Tensor, nxt: int, prv: int, group)
     req_s.wait()
     req_r.wait()
     recv.copy_(r_host)
+
+
+def _all_to_all(send: torch.Tensor, recv: torch.Tensor, group) -> None:
+    """Equal-split all-to-all of byte buffers (slot j of `send` goes to rank j).  RCCL moves device buffers peer to peer -- on
+    MI355X every pair of GPUs has its own xGMI link, so all G-1 transfers of a rank run at once; other backends (gloo, tests)
+    are staged through host memory."""
+    if dist.get_backend(group) == 'nccl':
+        dist.all_to_all_single(recv, send, group=group)
+        return
+    r_host = torch.empty(recv.shape, dtype=recv.dtype)
+    dist.all_to_all_single(r_host, send.cpu(), group=group)
+    recv.copy_(r_host)
+
+
+def _all_gather(mine: torch.Tensor, everyone: torch.Tensor, group) -> None:
+    """`everyone` = concatenation over ranks of equally sized `mine` buffers."""
+    world = dist.get_world_size(group)
+    if dist.get_backend(group) == 'nccl':
+        dist.all_gather_into_tensor(everyone, mine, group=group)
+        return
+    parts = [torch.empty(mine.shape, dtype=mine.dtype) for _ in range(world)]
+    dist.all_gather(parts, mine.cpu(), group=group)
+    everyone.copy_(torch.cat(parts))
 
 
 def ring_chunks(numel: int, world_size: int, packed_bits: int = 8, align: int = 4096):
@@ -124,9 +154,13 @@ def quantized_all_reduce(
     round_mode: str = 'nearest',
     group: Optional[dist.ProcessGroup] = None,
     ctx: Optional[Context] = None,
+    algorithm: str = 'ring',
     _ops=None,
 ) -> torch.Tensor:
     """In-place SUM all-reduce of a contiguous float32/bfloat16 tensor whose wire format is quantized.
+
+    ``algorithm='direct'`` selects the mesh schedule of ``quantized_all_reduce_direct`` (one all-to-all + one all-gather, every
+    value quantized exactly twice); the default is the ring described here.
 
     Ring reduce-scatter: at every hop a rank quantizes the chunk it forwards with parameters taken from that chunk's
     current partial sum (``compute_quant_params``), sends ``header + packed bytes`` to its successor, and accumulates what it
@@ -139,6 +173,9 @@ def quantized_all_reduce(
     point-to-point stream, which is what the per-link (not NVSwitch-style) bandwidth of MI355X wants.
     """
     assert tensor.is_contiguous() and tensor.dtype in (torch.float32, torch.bfloat16)
+    assert algorithm in ('ring', 'direct')
+    if algorithm == 'direct':
+        return quantized_all_reduce_direct(tensor, quant_dtype=quant_dtype, round_mode=round_mode, group=group, ctx=ctx, _ops=_ops)
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if world == 1:
@@ -180,4 +217,68 @@ def quantized_all_reduce(
             ops.decode(recv[:n_recv], x_recv, quant_dtype, 'set')
         send, recv = recv, send          # forward the received bytes as they are
         n_cur = n_recv
+    return tensor
+
+
+def quantized_all_reduce_direct(
+    tensor: torch.Tensor,
+    *,
+    quant_dtype: torch.dtype = torch.uint8,
+    round_mode: str = 'nearest',
+    group: Optional[dist.ProcessGroup] = None,
+    ctx: Optional[Context] = None,
+    _ops=None,
+) -> torch.Tensor:
+    """In-place quantized SUM all-reduce for a point-to-point mesh (MI355X: every GPU has its own xGMI link to each of its 7 peers).
+
+    A ring keeps one link per direction busy and re-quantizes a partial sum at each of its G-1 hops.  Here rank r owns chunk r:
+
+    1. every rank quantizes chunk j of its tensor for every peer j (parameters from that chunk, 16-byte header + packed bytes),
+    2. ONE all-to-all delivers them -- G-1 transfers per rank, each on its own link, all at once,
+    3. the owner adds the G-1 received chunks to its own (unquantized) values in a single pass (``dequantize_sum``),
+    4. quantizes the finished chunk once, ONE all-gather distributes it, and every rank (the owner included) stores
+       ``dequantize(..., 'set')`` of the same bytes, so all ranks end bit-identical.
+
+    Every value is quantized exactly twice whatever the world size (a ring: up to G times), the wire carries the same
+    2(G-1)/G x packed bytes per element, and the two collectives are what RCCL implements natively over the mesh.
+    """
+    assert tensor.is_contiguous() and tensor.dtype in (torch.float32, torch.bfloat16)
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        return tensor
+    ops = _ops or _DeviceOps(ctx)
+    qdt = torch_to_piquant_dtype(quant_dtype)
+    flat = tensor.view(-1)
+    chunks = ring_chunks(flat.numel(), world, qdt.bit_size)
+    slot = _HEADER_BYTES + max(qdt.packed_nbytes(e - b) for b, e in chunks)
+    slot = -(-slot // 16) * 16                       # every slot starts on a 16-byte boundary (vector kernels on both sides)
+    send = torch.zeros(world * slot, dtype=torch.uint8, device=tensor.device)
+    recv = torch.empty(world * slot, dtype=torch.uint8, device=tensor.device)
+
+    def wire_len(idx):
+        b, e = chunks[idx]
+        return _HEADER_BYTES + qdt.packed_nbytes(e - b)
+
+    # ---- reduce-scatter over the mesh ----
+    for j in range(world):
+        b, e = chunks[j]
+        if j != rank and e > b:
+            ops.encode(flat[b:e], send[j * slot: j * slot + wire_len(j)], quant_dtype, round_mode)
+    _all_to_all(send, recv, group)
+    b_own, e_own = chunks[rank]
+    x_own = flat[b_own:e_own]
+    n_own = wire_len(rank)
+    if x_own.numel():
+        ops.decode_sum([recv[i * slot: i * slot + n_own] for i in range(world) if i != rank], x_own, quant_dtype)
+
+    # ---- all-gather of the finished chunks ----
+    mine = torch.zeros(slot, dtype=torch.uint8, device=tensor.device)
+    if x_own.numel():
+        ops.encode(x_own, mine[:n_own], quant_dtype, round_mode)
+    _all_gather(mine, recv, group)
+    for j in range(world):
+        b, e = chunks[j]
+        if e > b:
+            ops.decode(recv[j * slot: j * slot + wire_len(j)], flat[b:e], quant_dtype, 'set')
     return tensor

@@ -308,3 +308,27 @@ def dequantize_dynamic(tensor: torch.Tensor, params: torch.Tensor, *, dtype: tor
     ctx.dequantize_dp_ptr(tensor.data_ptr(), dtype_in, out.data_ptr(), torch_to_piquant_dtype(out.dtype), numel, params.data_ptr(),
                           _REDUCE_OPS[reduce_op], _device_ptrs=True)
     return out
+
+
+def dequantize_sum(tensors, params, *, dtype: torch.dtype, reduce_op: str = 'set', ctx: Optional[Context] = None,
+                   out: Optional[torch.Tensor] = None, quant_dtype: Optional[torch.dtype] = None, shape=None) -> torch.Tensor:
+    """out (op)= sum_i dequantize(tensors[i]) with (scale, zero_point) of input i read from the device record ``params[i]``: one pass
+    over the accumulator instead of ``len(tensors)``; the result equals ``dequantize_dynamic`` applied in order (first with
+    ``reduce_op``, the rest with 'add') bit for bit.  The reduction step of ``piquant.distributed.quantized_all_reduce``."""
+    assert dtype in _DEQUANT_TYPES and len(tensors) == len(params) and len(tensors) > 0
+    first = tensors[0]
+    assert all(t.is_cuda and t.is_contiguous() for t in tensors) and all(p.is_cuda for p in params)
+    dtype_in, logical_shape = _quant_meta(first, quant_dtype, shape)
+    numel = 1
+    for s_ in logical_shape:
+        numel *= int(s_)
+    if out is None:
+        if reduce_op == 'add':
+            raise ValueError("reduce_op='add' accumulates into out=; pass the accumulator tensor")
+        out = torch.empty(logical_shape, dtype=dtype, device=first.device)
+    else:
+        assert out.dtype == dtype and out.is_contiguous() and out.device == first.device and out.numel() == numel
+    ctx = _ctx_for(first, ctx)
+    ctx.dequantize_sum_ptr([t.data_ptr() for t in tensors], [p.data_ptr() for p in params], dtype_in, out.data_ptr(), torch_to_piquant_dtype(out.dtype),
+                           numel, _REDUCE_OPS[reduce_op], _device_ptrs=True)
+    return out

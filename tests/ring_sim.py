@@ -48,6 +48,36 @@ def simulate(O, xs, qd, chunks, round_mode=0):
     return xs
 
 
+def simulate_direct(O, xs, qd, chunks, round_mode=0):
+    """piquant.distributed.quantized_all_reduce_direct for G ranks: all-to-all of quantized chunks, the owner adds them to its own
+    values in increasing rank order, one more quantization, all-gather."""
+    G = len(xs)
+    xs = [x.copy() for x in xs]
+    final = []
+    for owner in range(G):
+        b, e = chunks[owner]
+        if e == b:
+            final.append(None)
+            continue
+        acc = xs[owner][b:e].copy()
+        for src in range(G):
+            if src == owner:
+                continue
+            s = xs[src][b:e]
+            scale, zp = O.compute_quant_params(s, O.F32, qd)
+            q = O.quantize(s, O.F32, qd, scale, zp, round_mode)
+            acc = O.dequantize(q, qd, O.F32, acc.size, scale, zp, O.ADD, out=acc)
+        scale, zp = O.compute_quant_params(acc, O.F32, qd)
+        q = O.quantize(acc, O.F32, qd, scale, zp, round_mode)
+        final.append(O.dequantize(q, qd, O.F32, acc.size, scale, zp))
+    for r in range(G):
+        for owner in range(G):
+            b, e = chunks[owner]
+            if e > b:
+                xs[r][b:e] = final[owner]
+    return xs
+
+
 class OracleOps:
     """Wire encode / decode on CPU torch tensors through the oracle: stands in for the HIP ops where there is no GPU.
     Same wire format: 16-byte header {float scale, float 1/scale, int64 zero_point} + packed bytes."""
@@ -79,3 +109,7 @@ class OracleOps:
         res = self.O.dequantize(buf[16:].numpy(), self._qd(qdtype), self.O.F32, out.numel(), scale, zp, 1 if reduce_op == "add" else 0,
                                 out=out.numpy().copy())
         out.copy_(torch.from_numpy(res))
+
+    def decode_sum(self, bufs, out, qdtype):
+        for buf in bufs:
+            self.decode(buf, out, qdtype, "add")

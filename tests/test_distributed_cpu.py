@@ -97,7 +97,7 @@ def test_shard_range_is_the_reference_split(oracle_mod):
 # quantized ring all-reduce: ring schedule, wire format and chunking over gloo; the three ops come from the oracle
 # (the HIP ops need a GPU -- tests/test_gpu_distributed.py runs the same schedule with them)
 # ---------------------------------------------------------------------------------------------------------------
-def _ring_worker(rank, world, port, numel, qname, out_q):
+def _ring_worker(rank, world, port, numel, qname, out_q, algorithm="ring"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -106,25 +106,26 @@ def _ring_worker(rank, world, port, numel, qname, out_q):
         from ring_sim import OracleOps
 
         x = torch.from_numpy(np.random.default_rng(100 + rank).uniform(-1, 1, numel).astype(np.float32))
-        D.quantized_all_reduce(x, quant_dtype=getattr(torch, qname), _ops=OracleOps(O))
+        D.quantized_all_reduce(x, quant_dtype=getattr(torch, qname), algorithm=algorithm, _ops=OracleOps(O))
         out_q.put((rank, x.numpy().copy()))
     finally:
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("algorithm", ["ring", "direct"])
 @pytest.mark.parametrize("world,numel,qname", [(2, 50_001, "uint8"), (3, 20_000, "quint4x2"), (4, 9_000, "uint8"), (3, 5, "uint8")])
-def test_quantized_ring_all_reduce_schedule(oracle_mod, world, numel, qname):
+def test_quantized_all_reduce_schedule(oracle_mod, world, numel, qname, algorithm):
     import sys
 
     sys.path.insert(0, os.path.dirname(__file__))
     import piquant.distributed as D
-    from ring_sim import simulate
+    from ring_sim import simulate, simulate_direct
 
     O = oracle_mod
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_ring_worker, args=(r, world, port, numel, qname, q)) for r in range(world)]
+    procs = [ctx.Process(target=_ring_worker, args=(r, world, port, numel, qname, q, algorithm)) for r in range(world)]
     for p in procs:
         p.start()
     results = dict(q.get(timeout=180) for _ in range(world))
@@ -134,7 +135,7 @@ def test_quantized_ring_all_reduce_schedule(oracle_mod, world, numel, qname):
     xs = [np.random.default_rng(100 + r).uniform(-1, 1, numel).astype(np.float32) for r in range(world)]
     qd = {"uint8": O.UINT8, "quint4x2": O.UINT4}[qname]
     bits = {O.UINT8: 8, O.UINT4: 4}[qd]
-    want = simulate(O, xs, qd, D.ring_chunks(numel, world, bits))
+    want = (simulate if algorithm == "ring" else simulate_direct)(O, xs, qd, D.ring_chunks(numel, world, bits))
     exact = np.sum(xs, axis=0)
     for r in range(world):
         assert np.array_equal(results[r], want[r]), r                 # the distributed run IS the simulated schedule

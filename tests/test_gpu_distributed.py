@@ -60,7 +60,7 @@ def test_keys_fold_like_an_all_reduce(pg, oracle_mod):
 # gloo staged through host memory (RCCL refuses two ranks on one device); the schedule and every kernel are the real
 # ones, so each rank must reproduce the oracle simulation bit for bit.
 # ---------------------------------------------------------------------------------------------------------------
-def _ring_gpu_worker(rank, world, port, numel, qname, out_q):
+def _ring_gpu_worker(rank, world, port, numel, qname, out_q, algorithm="ring"):
     import sys
     from pathlib import Path
 
@@ -79,22 +79,23 @@ def _ring_gpu_worker(rank, world, port, numel, qname, out_q):
 
         torch.cuda.set_device(0)
         x = torch.from_numpy(np.random.default_rng(100 + rank).uniform(-1, 1, numel).astype(np.float32)).cuda()
-        D.quantized_all_reduce(x, quant_dtype=getattr(torch, qname))
+        D.quantized_all_reduce(x, quant_dtype=getattr(torch, qname), algorithm=algorithm)
         torch.cuda.synchronize()
         out_q.put((rank, x.cpu().numpy()))
     finally:
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("algorithm", ["ring", "direct"])
 @pytest.mark.parametrize("world,numel,qname", [(2, 1_000_003, "uint8"), (3, 300_000, "quint4x2")])
-def test_quantized_ring_all_reduce_with_hip_kernels(oracle_mod, world, numel, qname):
+def test_quantized_all_reduce_with_hip_kernels(oracle_mod, world, numel, qname, algorithm):
     import sys
 
     import torch.multiprocessing as mp
 
     sys.path.insert(0, os.path.dirname(__file__))
     import piquant.distributed as D
-    from ring_sim import simulate
+    from ring_sim import simulate, simulate_direct
 
     O = oracle_mod
     with socket.socket() as s:
@@ -102,7 +103,7 @@ def test_quantized_ring_all_reduce_with_hip_kernels(oracle_mod, world, numel, qn
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_ring_gpu_worker, args=(r, world, port, numel, qname, q)) for r in range(world)]
+    procs = [ctx.Process(target=_ring_gpu_worker, args=(r, world, port, numel, qname, q, algorithm)) for r in range(world)]
     for p in procs:
         p.start()
     results = dict(q.get(timeout=600) for _ in range(world))
@@ -111,7 +112,7 @@ def test_quantized_ring_all_reduce_with_hip_kernels(oracle_mod, world, numel, qn
         assert p.exitcode == 0
     xs = [np.random.default_rng(100 + r).uniform(-1, 1, numel).astype(np.float32) for r in range(world)]
     qd, bits = {"uint8": (O.UINT8, 8), "quint4x2": (O.UINT4, 4)}[qname]
-    want = simulate(O, xs, qd, D.ring_chunks(numel, world, bits))
+    want = (simulate if algorithm == "ring" else simulate_direct)(O, xs, qd, D.ring_chunks(numel, world, bits))
     for r in range(world):
         assert np.array_equal(results[r], want[r]), r
     exact = np.sum(xs, axis=0)

@@ -942,3 +942,42 @@ def test_fused_dynamic_quantize_from_two_streams_and_contexts(O):
         scale, zp = O.compute_quant_params(x, 0, 4)
         assert piquant.torch.params_to_host(recs[i]) == (scale, zp)
         assert np.array_equal(outs[i].cpu().numpy(), O.quantize(x, 0, 4, scale, zp))
+
+
+def test_dequantize_sum_equals_sequential_adds(O):
+    """piquant_hip_dequantize_sum: K quantized inputs with their own device parameter records summed in one pass == the K
+    dequantize calls in order (and == the oracle), for every dtype pair, SET and ADD, ragged sizes, 1..17 inputs (one launch takes
+    16) and a misaligned accumulator."""
+    import piquant
+    import piquant.torch as pt
+    import torch
+
+    rng = np.random.default_rng(404)
+    tq = {4: torch.quint8, 3: torch.quint4x2, 2: torch.quint2x4}
+    for n in (1, 7, 1000, 4099, 300_001):
+        for dt_q in (4, 3, 2):
+            for f_name, fdt, dt_f in (("f32", torch.float32, 0), ("bf16", torch.bfloat16, 1)):
+                for K in (1, 3, 17) if n == 4099 else (1, 3):
+                    xs = [rng.uniform(-1 - i, 2 + 0.5 * i, n).astype(np.float32) for i in range(K)]
+                    qs, recs, hp = [], [], []
+                    for x in xs:
+                        q, rec = pt.quantize_dynamic(torch.from_numpy(x).cuda(), dtype=tq[dt_q])
+                        qs.append(pt.packed_bytes(q))
+                        recs.append(rec)
+                        hp.append(pt.params_to_host(rec))
+                    prev = rng.uniform(-3, 3, n).astype(np.float32)
+                    prev_in = prev if dt_f == 0 else O.f32_to_bf16(prev)
+                    for op in ("set", "add"):
+                        # oracle: the calls one after the other
+                        want = prev_in.copy()
+                        for i in range(K):
+                            want = O.dequantize(qs[i].cpu().numpy(), dt_q, dt_f, n, hp[i][0], hp[i][1], 1 if (op == "add" or i > 0) else 0, out=want)
+                        for off in (0, 1) if n == 1000 else (0,):
+                            buf = torch.zeros(n + 8 if dt_f == 0 else n + 16, dtype=fdt, device="cuda")
+                            acc = buf[off: off + n]
+                            src = torch.from_numpy(prev_in).cuda() if dt_f == 0 else torch.from_numpy(prev_in.view(np.int16)).cuda().view(torch.bfloat16)
+                            acc.copy_(src)
+                            pt.dequantize_sum(qs, recs, dtype=fdt, reduce_op=op, out=acc, quant_dtype=tq[dt_q], shape=(n,))
+                            got = acc.cpu().numpy() if dt_f == 0 else acc.view(torch.int16).cpu().numpy().view(np.uint16)
+                            assert same_floats(got, want), (n, dt_q, f_name, K, op, off)
+                            assert bool((buf[:off] == 0).all()) and bool((buf[off + n:] == 0).all())
