@@ -329,6 +329,19 @@ def main():
             ctx.set_fusion(True)
             extras["quantize_dynamic_f32_u8_unfused"] = {"GB/s": gbs(9, e, reps), "avg_us_per_call": round(e / reps * 1e6, 3),
                                                          "note": "same call with fusion off: scan (parameter epilogue in its last block) + quantize, 9 B/elem: x read twice"}
+            # reduction step of the mesh all-reduce: 7 quantized chunks from 7 peers summed into the accumulator in one pass
+            recs7 = [torch.empty(16, dtype=torch.uint8, device=dev) for _ in range(7)]
+            q7 = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(7)]
+            for i in range(7):
+                piquant.torch.quantize_dynamic(xs[i % nsets], dtype=torch.uint8, ctx=ctx, out=q7[i], params=recs7[i])
+            accs = [torch.zeros(n, device=dev) for _ in range(3)]
+            ptr_q7, ptr_r7 = [t.data_ptr() for t in q7], [t.data_ptr() for t in recs7]
+            _, e = time_loop(lambda i: ctx.dequantize_sum_ptr(ptr_q7, ptr_r7, DataType.UINT8, accs[i % 3].data_ptr(), DataType.F32, n, piquant.ReduceOp.ADD,
+                                                              _device_ptrs=True), 100, stream)
+            extras["dequantize_sum_7x_u8_f32_add"] = {"GB/s": gbs(15, e, 100), "avg_launch_us": round(e / 100 * 1e6, 3),
+                                                      "note": "acc += sum of 7 quantized inputs with device-resident parameters, one pass (15 B/elem); "
+                                                              "7 dequantize(ADD) calls move 63 B/elem"}
+            del q7, accs
             ctx.set_stream(stream.cuda_stream)
             ctx.set_blocking(False)
             keys = torch.empty(2, dtype=torch.int32, device=dev)

@@ -248,7 +248,7 @@ namespace {
 
 template <int BITS, int DT_OUT, int OP>
 void dequantize_sum_t(const DequantSumLaunch& d, const DequantSumArgs& a, hipStream_t stream, int num_cu) {
-    constexpr int U = 2, BLOCK = 128;
+    constexpr int U = 2, BLOCK = 128;   // U = 4 / 256 threads measured the same (70.8 vs 71.2 us for 7 x uint8 -> fp32 at numel 27 264 000)
     constexpr int EPV = DT_OUT == DT_F32 ? 4 : 8;
     bool aligned = aligned16(d.out);
     for (int i = 0; i < d.count; ++i) aligned = aligned && aligned16(d.in[i]);
