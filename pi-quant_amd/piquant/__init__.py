@@ -144,6 +144,15 @@ class Context:
             C.piquant_hip_set_stream(self._ctx, hip_stream or None)
             self._stream = hip_stream
 
+    def _native_call(self) -> int:
+        """For the C++ front end (csrc/torch_binding.cpp), which pushes stream / non-blocking / device-pointer mode to the native
+        context itself: returns the native handle and brings the cache of pushed settings in line (the stream as unknown, so a
+        later ctypes call pushes it again)."""
+        self._stream = None
+        self._blocking = False
+        self._assume_device = True
+        return self._ctx
+
     def reset_stream(self) -> None:
         """Back to the context's private non-blocking stream (the state of a new context)."""
         if self._stream != 'own':

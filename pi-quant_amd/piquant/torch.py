@@ -94,16 +94,12 @@ def _ctx_for(tensor: torch.Tensor, ctx: Optional[Context]) -> Context:
     return ctx
 
 
-def _native_ctx(tensor: torch.Tensor, ctx: Optional[Context]) -> Context:
-    """Context for a call through the native front end, which sets stream / non-blocking / device-pointer mode itself; the
-    Python-side cache of those settings is marked accordingly (the stream as unknown, so a later ctypes call pushes it again)."""
+def _native_handle(tensor: torch.Tensor, ctx: Optional[Context]) -> int:
+    """Native context handle for a call through the C++ front end (default context of the tensor's device unless one is given)."""
     if ctx is None:
         index = tensor.device.index
         ctx = Context._defaults.get(index) or Context.get(index)
-    ctx._stream = None
-    ctx._blocking = False
-    ctx._assume_device = True
-    return ctx
+    return ctx._native_call()
 
 
 def _quant_meta(tensor: torch.Tensor, quant_dtype: Optional[torch.dtype], shape) -> Tuple[DataType, torch.Size]:
@@ -141,7 +137,7 @@ def quantize(
     """Reference ``torch.py:70-99``; the result lives on ``tensor.device``."""
     assert dtype in _QUANT_TYPES, f'Unsupported quantized dtype: {dtype}. Must be one of {list(_QUANT_TYPES)}'
     if _native is not None and tensor.is_cuda and tensor.dtype in _DEQUANT_TYPES:
-        return _native.quantize(_native_ctx(tensor, ctx)._ctx, tensor, scale, zero_point, dtype, _ROUND_MODE_CODES[round_mode], out)
+        return _native.quantize(_native_handle(tensor, ctx), tensor, scale, zero_point, dtype, _ROUND_MODE_CODES[round_mode], out)
     if not tensor.is_contiguous():
         tensor = tensor.contiguous()
     dtype_in = torch_to_piquant_dtype(tensor.dtype)
@@ -184,7 +180,7 @@ def dequantize(
     if _native is not None and tensor.is_cuda and quant_dtype is None and shape is None and tensor.dtype in _QUANT_TYPES:
         if out is None and reduce_op == 'add':
             raise ValueError("reduce_op='add' accumulates into out=; pass the accumulator tensor")
-        return _native.dequantize(_native_ctx(tensor, ctx)._ctx, tensor, scale, zero_point, dtype, _REDUCE_OP_CODES[reduce_op], out)
+        return _native.dequantize(_native_handle(tensor, ctx), tensor, scale, zero_point, dtype, _REDUCE_OP_CODES[reduce_op], out)
     if not tensor.is_contiguous():
         tensor = tensor.contiguous()
     dtype_in, logical_shape = _quant_meta(tensor, quant_dtype, shape)
