@@ -52,6 +52,15 @@ def main():
                       f"reported; raw summaries in profiles/{rnd}_pmc_summary.json"}}
         (PROF / "hbm_traffic.json").write_text(json.dumps(traffic, indent=1))
         done.append("hbm_traffic.json")
+    statsx = next(iter(sorted(OUT.glob("profx/**/*kernel_stats.csv"))), None)
+    if statsx:
+        rows = [r for r in csv.DictReader(statsx.open()) if r["Name"].startswith(("void pq::", "pq::"))]
+        with (PROF / f"{rnd}_all_kernels_stats.csv").open("w", newline="") as f:
+            w = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC)
+            w.writerow(["Name", "Calls", "AverageNs", "MinNs", "MaxNs", "Percentage"])
+            for r in rows:
+                w.writerow([r["Name"][:160], int(r["Calls"]), float(r["AverageNs"]), int(r["MinNs"]), int(r["MaxNs"]), float(r["Percentage"])])
+        done.append(f"{rnd}_all_kernels_stats.csv")
     dyn = OUT / "dyn_summary.json"
     if dyn.exists() and dyn.stat().st_size:
         doc = {"command": "rocprofv3 --kernel-trace {--stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE} -- python tools/dynamic_quantize_workload.py "

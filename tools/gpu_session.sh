@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session: smoke, GPU tests, kernel sweep, bench, rocprof.  Usage (from the repo root, via gpurun):
-#   gpurun --timeout 1800 -- 'bash tools/gpu_session.sh [phases...]'      phases: smoke tests tune bench prof pmc dyn
+#   gpurun --timeout 1800 -- 'bash tools/gpu_session.sh [phases...]'      phases: smoke tests tune bench prof profx pmc dyn
 # Everything is written under gpurun_out/ (merged back by gpurun).
 set -u
 cd "$(dirname "$0")/.."
@@ -25,6 +25,7 @@ for ph in $PHASES; do
            (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d "$OLDPWD/$OUT/pmc_fetch" -o pmc -- python "$OLDPWD/bench.py" --steps 60 --warmup 10 --no-cpu-baseline --no-extras > /dev/null 2> "$OLDPWD/$OUT/pmc_fetch.err"); echo "pmc fetch rc=$?" | tee -a $OUT/session.log
            (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d "$OLDPWD/$OUT/pmc_write" -o pmc -- python "$OLDPWD/bench.py" --steps 60 --warmup 10 --no-cpu-baseline --no-extras > /dev/null 2> "$OLDPWD/$OUT/pmc_write.err"); echo "pmc write rc=$?" | tee -a $OUT/session.log
            python tools/summarize_pmc.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_summary.json 2> $OUT/pmc_summary.err; cat $OUT/pmc_summary.json ;;
+    profx) rm -rf $OUT/profx; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -f csv -d "$OLDPWD/$OUT/profx" -o benchx -- python "$OLDPWD/bench.py" --steps 300 --warmup 30 --no-cpu-baseline > "$OLDPWD/$OUT/profx_bench.json" 2> "$OLDPWD/$OUT/profx.err"); echo "profx rc=$?" | tee -a $OUT/session.log ;;
     dyn)   rm -rf $OUT/dyn_stats $OUT/dyn_fetch $OUT/dyn_write
            (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d "$OLDPWD/$OUT/dyn_stats" -o dyn -- python "$OLDPWD/tools/dynamic_quantize_workload.py" > /dev/null 2> "$OLDPWD/$OUT/dyn_stats.err"); echo "dyn stats rc=$?" | tee -a $OUT/session.log
            (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d "$OLDPWD/$OUT/dyn_fetch" -o dyn -- python "$OLDPWD/tools/dynamic_quantize_workload.py" > /dev/null 2> "$OLDPWD/$OUT/dyn_fetch.err"); echo "dyn fetch rc=$?" | tee -a $OUT/session.log
