@@ -83,9 +83,9 @@ __device__ __forceinline__ void quantize_vec_bounded(const u32x4& raw, float inv
 
 
 // rounds of BLOCK vectors in one block's share when n_vec vectors are split evenly over G blocks
-__host__ __device__ inline int fused_rounds(int64_t n_vec, int64_t G, int64_t block) {
+__host__ __device__ inline int64_t fused_rounds(int64_t n_vec, int64_t G, int64_t block) {
     const int64_t per_block = (n_vec + G - 1) / G;
-    return static_cast<int>((per_block + block - 1) / block);
+    return (per_block + block - 1) / block;
 }
 
 template <int DT_IN>
@@ -119,7 +119,7 @@ fused_params_quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ 
     const int64_t G = gridDim.x;
     const int64_t n_vec = numel / EPV;
     constexpr int64_t round_vecs = BLOCK;
-    const int rounds = fused_rounds(n_vec, G, BLOCK);                             // <= R_REG + R_LDS (host guarantees)
+    const int rounds = static_cast<int>(fused_rounds(n_vec, G, BLOCK));           // <= R_REG + R_LDS (host guarantees)
     const int64_t v_first = static_cast<int64_t>(blockIdx.x) * rounds * BLOCK + tid;
     const int64_t v_last = n_vec > 0 ? n_vec - 1 : 0;
     const u32x4* __restrict__ in16 = static_cast<const u32x4*>(in);

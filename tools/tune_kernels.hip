@@ -295,7 +295,7 @@ static void run_fused(const Bufs& b, const FusedBufs& f, int64_t numel, int num_
     std::snprintf(name, sizeof name, "f32->u8 fused R_REG=%d R_LDS=%d batch=%d block=%d st=%s", R_REG, R_LDS, LDS_BATCH, BLOCK,
                   STP == ST_WT ? "wt" : (STP == ST_NT ? "nt" : "plain"));
     if (fused_rounds(n_vec, num_cu, BLOCK) > R_REG + R_LDS) {
-        std::fprintf(stderr, "%s: tensor does not fit (%d rounds)\n", name, fused_rounds(n_vec, num_cu, BLOCK));
+        std::fprintf(stderr, "%s: tensor does not fit (%lld rounds)\n", name, static_cast<long long>(fused_rounds(n_vec, num_cu, BLOCK)));
         return;
     }
     QuantParams p {};
