@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Long randomized parity run on the GPU: HIP kernels vs the oracle, bit for bit, for a wall-clock budget.
+
+Every iteration draws a configuration (dtype pair, rounding mode, store op, ragged size up to 2 M elements, scale over 60
+decades, zero point from the int64 range or a sane one, any fp32 bit pattern as data incl. NaN/inf/denormals, or ordinary
+data) and checks quantize, dequantize, the fused quantize->dequantize, dynamic (params + quantize, fused and unfused) and
+dequantize_sum.  Prints one JSON line: iterations, elements compared, mismatches (must be 0).
+
+  python tools/parity_soak.py --seconds 600 [--seed 1]        (tests/ holds the short, deterministic versions)
+"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+for p in (str(ROOT), str(ROOT / "pi-quant_amd"), str(ROOT / "tests")):
+    sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import oracle as O  # noqa: E402
+import piquant  # noqa: E402
+import piquant.torch as pt  # noqa: E402
+from helpers import gpu_dequantize, gpu_quantize, same_floats  # noqa: E402
+from test_gpu_parity import _fuzz_values, gpu_quantize_dynamic, gpu_requantize  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=600.0)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    ctx, plain = piquant.Context(), piquant.Context()
+    plain.set_fusion(False)
+    t_end = time.time() + args.seconds
+    it = elems = bad = 0
+    kinds = {"quantize": 0, "dequantize": 0, "requantize": 0, "dynamic": 0, "dequantize_sum": 0}
+    tq = {4: torch.quint8, 3: torch.quint4x2, 2: torch.quint2x4}
+    while time.time() < t_end:
+        it += 1
+        n = int(rng.integers(1, 2_000_000)) if it % 4 == 0 else int(rng.integers(1, 50_000))
+        wild = it % 2 == 0
+        x = _fuzz_values(rng, n) if wild else rng.uniform(-3, 3, n).astype(np.float32)
+        scale = float(np.float32(10.0 ** rng.uniform(-30, 30))) if wild else float(np.float32(rng.uniform(0.001, 0.1)))
+        zp = int(rng.integers(-2**63, 2**63 - 1)) if it % 5 == 0 else int(rng.integers(-300, 300))
+        dt_f, dt_q = int(rng.integers(0, 2)), int(rng.integers(2, 5))
+        xin = x if dt_f == 0 else O.f32_to_bf16(x)
+        rm = int(rng.integers(0, 2))
+        tau = float(rng.uniform(0, 1)) if rm else 0.0
+        ctx.set_stochastic_threshold(tau if rm else None)
+        op = int(rng.integers(0, 2))
+
+        got = gpu_quantize(ctx, xin, dt_f, dt_q, scale, zp, rm)
+        bad += int(not np.array_equal(got, O.quantize(xin, dt_f, dt_q, scale, zp, rm, tau)))
+        kinds["quantize"] += 1
+
+        q = rng.integers(0, 256, O.packed_numel(n, dt_q)).astype(np.uint8)
+        prev = (_fuzz_values(rng, n) if wild else rng.uniform(-5, 5, n).astype(np.float32))
+        prev = prev if dt_f == 0 else O.f32_to_bf16(prev)
+        got = gpu_dequantize(ctx, q, dt_q, dt_f, n, scale, zp, op, prev=prev)
+        bad += int(not same_floats(got, O.dequantize(q, dt_q, dt_f, n, scale, zp, op, out=prev.copy())))
+        kinds["dequantize"] += 1
+
+        got = gpu_requantize(ctx, xin, dt_f, dt_q, scale, zp, rm, op, prev)
+        bad += int(not same_floats(got, O.requantize(xin, dt_f, dt_q, scale, zp, rm, tau, op, out=prev.copy())))
+        kinds["requantize"] += 1
+        elems += 3 * n
+
+        if not wild:   # data-derived parameters need a positive finite scale
+            want_p = O.compute_quant_params(xin, dt_f, dt_q)
+            want = O.quantize(xin, dt_f, dt_q, want_p[0], want_p[1], rm, tau)
+            for c in (ctx, plain):
+                c.set_stochastic_threshold(tau if rm else None)
+                got, got_p = gpu_quantize_dynamic(c, xin, dt_f, dt_q, rm)
+                bad += int(got_p != want_p or not np.array_equal(got, want))
+            kinds["dynamic"] += 2
+            elems += 2 * n
+            K = int(rng.integers(1, 5))
+            if K:
+                xs = [rng.uniform(-2 - i, 2 + i, n).astype(np.float32) for i in range(K)]
+                qs, recs = [], []
+                want_acc = prev.copy()
+                for xk in xs:
+                    qq, rec = pt.quantize_dynamic(torch.from_numpy(xk).cuda(), dtype=tq[dt_q])
+                    qs.append(pt.packed_bytes(qq))
+                    recs.append(rec)
+                    s_k, z_k = pt.params_to_host(rec)
+                    want_acc = O.dequantize(qs[-1].cpu().numpy(), dt_q, dt_f, n, s_k, z_k, 1, out=want_acc)
+                fdt = torch.float32 if dt_f == 0 else torch.bfloat16
+                acc = torch.from_numpy(prev).cuda() if dt_f == 0 else torch.from_numpy(prev.view(np.int16)).cuda().view(torch.bfloat16)
+                pt.dequantize_sum(qs, recs, dtype=fdt, reduce_op="add", out=acc, quant_dtype=tq[dt_q], shape=(n,))
+                got_acc = acc.cpu().numpy() if dt_f == 0 else acc.view(torch.int16).cpu().numpy().view(np.uint16)
+                bad += int(not same_floats(got_acc, want_acc))
+                kinds["dequantize_sum"] += 1
+                elems += K * n
+    print(json.dumps({"seconds": args.seconds, "seed": args.seed, "iterations": it, "checks": kinds, "elements_compared": elems, "mismatching_checks": bad,
+                      "device": torch.cuda.get_device_name(0)}))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
