@@ -46,7 +46,8 @@ constexpr int kMinmaxBlocksPerCU = 2;
 // 16-byte vectors stay in registers and 9 more in LDS (144 KiB per block), all 27 loads issued before the first use.
 // Measured at numel 27 264 000 fp32 -> uint8 (profiles/r01_tune_fused.csv): 28.7 us against 42.5 us for scan + params +
 // quantize; 512-thread blocks (40 + 18) 31-33 us, 256-thread blocks (80 + 36) 41 us -- fewer waves leave the quantize phase
-// latency-bound; store policy is neutral here (pure write phase).  Capacity 27 rounds x 1024 x 16 B per CU = 113 MB at 256 CUs.
+// latency-bound; store policy is neutral here (pure write phase), and so is gathering four lanes' dwords by DPP into
+// 16-byte stores (29.6 vs 28.8 us).  Capacity 27 rounds x 1024 x 16 B per CU = 113 MB at 256 CUs.
 constexpr int kFusedBlock = 1024;
 constexpr int kFusedRegRounds = 18;
 constexpr int kFusedLdsRounds = 9;
