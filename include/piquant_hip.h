@@ -111,7 +111,7 @@ PIQUANT_EXPORT void piquant_hip_dequantize_dp(piquant_context_t* ctx, const void
  * round trip, hipGraph-capturable.  When the tensor fits on the chip (<= ~113 MB of fp32 / bf16 input on a 256-CU MI355X,
  * 16-byte aligned buffers) this is a single kernel launch that reads the tensor ONCE: every CU keeps its share in vector
  * registers and LDS between the min/max pass and the quantization pass (5 B/elem of HBM traffic for fp32 -> uint8 instead
- * of 9).  Larger or misaligned tensors take a scan (its last block writes the parameters) + quantize (two launches); the output bytes and the
+ * of 9).  Up to ~268 MB the same launch keeps 113 MB on chip and streams the remainder twice.  Larger or misaligned tensors take a scan (its last block writes the parameters) + quantize (two launches); the output bytes and the
  * record are identical either way.  piquant_hip_set_fusion(ctx, 0), or PIQUANT_HIP_FUSION=0 in the environment when the
  * context is created, forces the two-launch form.  The one-launch kernel synchronises its blocks with a grid barrier (one
  * block per CU); the library orders such launches from different streams of one process behind one another, but processes

@@ -26,8 +26,10 @@
 // must switch the fused path off (PIQUANT_HIP_FUSION=0 / piquant_hip_set_fusion) -- the design rule is one process per GPU.
 //
 // Capacity: (R_REG + R_LDS) x 16 B x BLOCK threads x grid blocks (113 MB with the production 18 + 9 rounds of 1024 threads
-// on 256 CUs, tuning.hpp).  The host launches this kernel only when the tensor fits and both pointers are 16-byte aligned,
-// and otherwise runs the scan (with the parameter epilogue) and the quantize kernel as two launches.
+// on 256 CUs, tuning.hpp).  A somewhat larger tensor keeps that much on chip and streams the rest of every block's share
+// twice (min/max in phase 1, a second read in phase 3): still fewer bytes than two full passes.  The host launches this kernel
+// when both pointers are 16-byte aligned and the tensor is at most kFusedMaxRounds rounds per thread, and otherwise runs the
+// scan (with the parameter epilogue) and the quantize kernel as two launches.
 //
 // State in device memory (FusedState) is self-maintaining, so that a launch needs no host-side reset and replays
 // unchanged inside a hipGraph: the generation word picks which of two slot buffers this launch folds into and the other
@@ -119,8 +121,11 @@ fused_params_quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ 
     const int64_t G = gridDim.x;
     const int64_t n_vec = numel / EPV;
     constexpr int64_t round_vecs = BLOCK;
-    const int rounds = static_cast<int>(fused_rounds(n_vec, G, BLOCK));           // <= R_REG + R_LDS (host guarantees)
-    const int64_t v_first = static_cast<int64_t>(blockIdx.x) * rounds * BLOCK + tid;
+    // A share is rounds_total rounds long; the first R_REG + R_LDS of them stay on chip, the rest (tensors larger than the chip
+    // holds) are streamed: scanned in phase 1, read a second time in phase 3.
+    const int64_t rounds_total = fused_rounds(n_vec, G, BLOCK);
+    const int rounds = static_cast<int>(rounds_total < R_REG + R_LDS ? rounds_total : R_REG + R_LDS);
+    const int64_t v_first = static_cast<int64_t>(blockIdx.x) * rounds_total * BLOCK + tid;
     const int64_t v_last = n_vec > 0 ? n_vec - 1 : 0;
     const u32x4* __restrict__ in16 = static_cast<const u32x4*>(in);
 
@@ -162,6 +167,21 @@ fused_params_quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ 
                 const int64_t v = v_first + (R_REG + j0 + j) * round_vecs;
                 minmax_vec<DT_IN>(t[j], v < n_vec, lo, hi);
                 resident[(j0 + j) * BLOCK + tid] = t[j];
+            }
+        }
+        // rounds that do not fit on chip: min/max only, LDS_BATCH loads in flight per lane
+#pragma unroll 1
+        for (int64_t k0 = R_REG + R_LDS; k0 < rounds_total; k0 += LDS_BATCH) {
+            u32x4 t[LDS_BATCH];
+#pragma unroll
+            for (int j = 0; j < LDS_BATCH; ++j) {
+                const int64_t v = v_first + (k0 + j) * round_vecs;
+                t[j] = ld<true>(in16 + (v < n_vec ? v : v_last));
+            }
+#pragma unroll
+            for (int j = 0; j < LDS_BATCH; ++j) {
+                const int64_t v = v_first + (k0 + j) * round_vecs;
+                minmax_vec<DT_IN>(t[j], k0 + j < rounds_total && v < n_vec, lo, hi);
             }
         }
 #pragma unroll
@@ -270,7 +290,7 @@ fused_params_quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ 
     for (int i = 0; i < FIELDS; ++i) zp_word |= static_cast<uint32_t>(p.zp32) << (i * BITS);
     const BoundedStep bstep {-static_cast<float>(p.zp32), static_cast<float>(((1 << BITS) - 1) - p.zp32), zp_word};
     // A block whose whole share lies inside the tensor (all but the last one or two) needs no per-vector bounds check.
-    const bool full_share = (static_cast<int64_t>(blockIdx.x) + 1) * rounds * BLOCK <= n_vec;
+    const bool full_share = (static_cast<int64_t>(blockIdx.x) + 1) * rounds_total * BLOCK <= n_vec;
     auto emit = [&](auto bounded_tag, auto full_tag) {
         constexpr bool BOUNDED = decltype(bounded_tag)::value, FULL = decltype(full_tag)::value;
         auto one = [&](const u32x4& raw, int64_t v) {
@@ -289,6 +309,26 @@ fused_params_quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ 
         for (int j = 0; j < R_LDS; ++j) {
             if (R_REG + j >= rounds) break;
             one(resident[j * BLOCK + tid], v_first + (R_REG + j) * round_vecs);
+        }
+        // streamed rounds: second read
+#pragma unroll 1
+        for (int64_t k0 = R_REG + R_LDS; k0 < rounds_total; k0 += LDS_BATCH) {
+            u32x4 t[LDS_BATCH];
+#pragma unroll
+            for (int j = 0; j < LDS_BATCH; ++j) {
+                const int64_t v = v_first + (k0 + j) * round_vecs;
+                t[j] = ld<true>(in16 + (v < n_vec ? v : v_last));
+            }
+#pragma unroll
+            for (int j = 0; j < LDS_BATCH; ++j) {
+                const int64_t v = v_first + (k0 + j) * round_vecs;
+                if (k0 + j < rounds_total && v < n_vec) {
+                    uint32_t w[WORDS];
+                    if constexpr (BOUNDED) quantize_vec_bounded<DT_IN, BITS>(t[j], p.inv_scale, bstep, w);
+                    else quantize_vec<DT_IN, BITS, MODE>(t[j], p, keys, static_cast<uint64_t>(v) * EPV, w);
+                    store_packed<OB, ST_POLICY>(out + v * OB, w);
+                }
+            }
         }
     };
     // grid-uniform: the data range decides whether the short step is exact for every element of this call

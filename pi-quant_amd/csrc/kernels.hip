@@ -199,7 +199,7 @@ bool fused_launch_applies(const QuantLaunch& q, int num_cu) {
     if (q.numel <= 0 || q.ref_layout || !aligned16(q.in) || !aligned16(q.out)) return false;
     if (q.dt_in != DT_F32 && q.dt_in != DT_BF16) panic("invalid quantization types: %d -> %d", q.dt_in, q.dt_out);
     const int64_t n_vec = q.numel / (q.dt_in == DT_F32 ? 4 : 8);
-    return fused_rounds(n_vec, num_cu, kFusedBlock) <= kFusedRegRounds + kFusedLdsRounds;   // does the tensor fit on the chip?
+    return fused_rounds(n_vec, num_cu, kFusedBlock) <= kFusedMaxRounds;   // on chip entirely, or mostly with a streamed remainder
 }
 
 bool launch_fused_params_quantize(const QuantLaunch& q, void* state, void* device_param_record, hipStream_t stream, int num_cu) {

@@ -899,8 +899,10 @@ def test_fused_dynamic_quantize_stochastic_modes(O):
 
 
 def test_fused_dynamic_quantize_capacity_boundary_headline_size_and_misalignment(O):
-    """The largest tensor the chip holds (27 rounds x 1024 threads x 16 B per CU), one vector more (two-launch fallback), the
-    BASELINE size, and a misaligned input (fallback): all equal the oracle."""
+    """The largest tensor the chip holds (27 rounds x 1024 threads x 16 B per CU), one vector more and 1.5x that (part of every
+    block's share streamed twice), the largest size the fused kernel takes (64 rounds) and one vector more (two launches), the
+    BASELINE size, a misaligned input (fallback), and the stochastic / per-element modes over a streamed remainder: all equal
+    the oracle."""
     import piquant
     import torch
 
@@ -908,14 +910,32 @@ def test_fused_dynamic_quantize_capacity_boundary_headline_size_and_misalignment
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     fits = 27 * 1024 * cus * 4
     rng = np.random.default_rng(5)
-    for n, off in ((fits, 0), (fits + 4, 0), (fits + 3, 0), (N1, 0), (100_003, 4)):
+    limit = 64 * 1024 * cus * 4
+    for n, off in ((fits, 0), (fits + 4, 0), (fits + 3, 0), (fits * 3 // 2 + 7, 0), (limit, 0), (limit + 4, 0), (N1, 0), (100_003, 4)):
         x = rng.uniform(-1, 1, n).astype(np.float32)
         x[n // 3] = 1.5
-        x[n // 2] = -1.25
+        x[n - 5] = -1.25                      # the minimum sits in the streamed part of the last block's share
         scale, zp = O.compute_quant_params(x, 0, 4)
         got, p = gpu_quantize_dynamic(c, x, 0, 4, offset_in=off)
         assert p == (scale, zp), (n, off)
         assert np.array_equal(got, O.quantize(x, 0, 4, scale, zp)), (n, off)
+    # other modes and dtypes over a streamed remainder
+    n = fits + fits // 3 + 11
+    x = rng.uniform(-2, 3, n).astype(np.float32)
+    xb = O.f32_to_bf16(rng.uniform(-2, 3, 2 * n).astype(np.float32))
+    c.set_stochastic_threshold(0.4375)
+    scale, zp = O.compute_quant_params(x, 0, 3)
+    got, p = gpu_quantize_dynamic(c, x, 0, 3, 1)
+    assert p == (scale, zp) and np.array_equal(got, O.quantize(x, 0, 3, scale, zp, 1, 0.4375))
+    c.set_stochastic_threshold(None)
+    c.set_stochastic_per_element(True, seed=5, index_base=123)
+    got, p = gpu_quantize_dynamic(c, x, 0, 4, 1)
+    scale, zp = O.compute_quant_params(x, 0, 4)
+    assert p == (scale, zp) and np.array_equal(got, O.quantize_per_element(x, 0, 4, scale, zp, 5, 123))
+    c.set_stochastic_per_element(False)
+    scale, zp = O.compute_quant_params(xb, 1, 3)
+    got, p = gpu_quantize_dynamic(c, xb, 1, 3)
+    assert p == (scale, zp) and np.array_equal(got, O.quantize(xb, 1, 3, scale, zp))
 
 
 def test_fused_dynamic_quantize_from_two_streams_and_contexts(O):

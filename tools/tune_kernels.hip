@@ -294,10 +294,8 @@ static void run_fused(const Bufs& b, const FusedBufs& f, int64_t numel, int num_
     char name[128];
     std::snprintf(name, sizeof name, "f32->u8 fused R_REG=%d R_LDS=%d batch=%d block=%d st=%s", R_REG, R_LDS, LDS_BATCH, BLOCK,
                   STP == ST_WT ? "wt" : (STP == ST_NT ? "nt" : "plain"));
-    if (fused_rounds(n_vec, num_cu, BLOCK) > R_REG + R_LDS) {
-        std::fprintf(stderr, "%s: tensor does not fit (%lld rounds)\n", name, static_cast<long long>(fused_rounds(n_vec, num_cu, BLOCK)));
-        return;
-    }
+    if (fused_rounds(n_vec, num_cu, BLOCK) > R_REG + R_LDS)
+        std::fprintf(stderr, "%s: %lld rounds, %d of them resident\n", name, static_cast<long long>(fused_rounds(n_vec, num_cu, BLOCK)), R_REG + R_LDS);
     QuantParams p {};
     auto launch = [&](int i) {
         hipLaunchKernelGGL((fused_params_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, R_REG, R_LDS, LDS_BATCH, BLOCK, STP>), dim3(num_cu), dim3(BLOCK), 0,
@@ -675,14 +673,16 @@ int main(int argc, char** argv) {
             report("fused", "f32->u8 two launches (scan with parameter epilogue, quantize)", us, 9.0 * numel);
         }
         run_fused<18, 9, 9, 1024>(b, f, numel, num_cu, keys);
-        run_fused<18, 9, 9, 1024, ST_NT>(b, f, numel, num_cu, keys);
-        run_fused<18, 9, 9, 1024, ST_PLAIN>(b, f, numel, num_cu, keys);
-        run_fused<18, 9, 3, 1024>(b, f, numel, num_cu, keys);
-        run_fused<20, 8, 8, 1024>(b, f, numel, num_cu, keys);
-        run_fused<40, 18, 18, 512>(b, f, numel, num_cu, keys);
-        run_fused<40, 18, 6, 512>(b, f, numel, num_cu, keys);
-        run_fused<48, 10, 10, 512>(b, f, numel, num_cu, keys);
-        run_fused<80, 36, 12, 256>(b, f, numel, num_cu, keys);
+        if (numel <= 27264000) {
+            run_fused<18, 9, 9, 1024, ST_NT>(b, f, numel, num_cu, keys);
+            run_fused<18, 9, 9, 1024, ST_PLAIN>(b, f, numel, num_cu, keys);
+            run_fused<18, 9, 3, 1024>(b, f, numel, num_cu, keys);
+            run_fused<20, 8, 8, 1024>(b, f, numel, num_cu, keys);
+            run_fused<40, 18, 18, 512>(b, f, numel, num_cu, keys);
+            run_fused<40, 18, 6, 512>(b, f, numel, num_cu, keys);
+            run_fused<48, 10, 10, 512>(b, f, numel, num_cu, keys);
+            run_fused<80, 36, 12, 256>(b, f, numel, num_cu, keys);
+        }
     }
     return 0;
 }
