@@ -114,6 +114,7 @@ fused_params_quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ 
     static_assert(R_LDS % LDS_BATCH == 0, "the LDS-resident rounds are loaded in whole batches");
     constexpr int EPV = InVec<DT_IN>::EPV, OB = EPV * BITS / 8, WAVES = BLOCK / 64;
     constexpr int WORDS = OB > 4 ? 2 : 1;
+    constexpr int STREAM_BATCH = 4;   // loads in flight per lane in the streamed rounds (the resident registers stay live next to them)
     __shared__ u32x4 resident[R_LDS * BLOCK];
     __shared__ float s_lo[WAVES], s_hi[WAVES];
 
@@ -171,15 +172,15 @@ fused_params_quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ 
         }
         // rounds that do not fit on chip: min/max only, LDS_BATCH loads in flight per lane
 #pragma unroll 1
-        for (int64_t k0 = R_REG + R_LDS; k0 < rounds_total; k0 += LDS_BATCH) {
-            u32x4 t[LDS_BATCH];
+        for (int64_t k0 = R_REG + R_LDS; k0 < rounds_total; k0 += STREAM_BATCH) {
+            u32x4 t[STREAM_BATCH];
 #pragma unroll
-            for (int j = 0; j < LDS_BATCH; ++j) {
+            for (int j = 0; j < STREAM_BATCH; ++j) {
                 const int64_t v = v_first + (k0 + j) * round_vecs;
                 t[j] = ld<true>(in16 + (v < n_vec ? v : v_last));
             }
 #pragma unroll
-            for (int j = 0; j < LDS_BATCH; ++j) {
+            for (int j = 0; j < STREAM_BATCH; ++j) {
                 const int64_t v = v_first + (k0 + j) * round_vecs;
                 minmax_vec<DT_IN>(t[j], k0 + j < rounds_total && v < n_vec, lo, hi);
             }
@@ -312,15 +313,15 @@ fused_params_quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ 
         }
         // streamed rounds: second read
 #pragma unroll 1
-        for (int64_t k0 = R_REG + R_LDS; k0 < rounds_total; k0 += LDS_BATCH) {
-            u32x4 t[LDS_BATCH];
+        for (int64_t k0 = R_REG + R_LDS; k0 < rounds_total; k0 += STREAM_BATCH) {
+            u32x4 t[STREAM_BATCH];
 #pragma unroll
-            for (int j = 0; j < LDS_BATCH; ++j) {
+            for (int j = 0; j < STREAM_BATCH; ++j) {
                 const int64_t v = v_first + (k0 + j) * round_vecs;
                 t[j] = ld<true>(in16 + (v < n_vec ? v : v_last));
             }
 #pragma unroll
-            for (int j = 0; j < LDS_BATCH; ++j) {
+            for (int j = 0; j < STREAM_BATCH; ++j) {
                 const int64_t v = v_first + (k0 + j) * round_vecs;
                 if (k0 + j < rounds_total && v < n_vec) {
                     uint32_t w[WORDS];
