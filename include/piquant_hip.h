@@ -121,6 +121,23 @@ PIQUANT_EXPORT void piquant_hip_quantize_dynamic(piquant_context_t* ctx, const v
                                                  piquant_round_mode_t mode);
 PIQUANT_EXPORT void piquant_hip_set_fusion(piquant_context_t* ctx, int enabled);
 
+/* piquant_hip_quantize_dynamic for `count` independent tensors of the same dtype pair, each with its own parameters and its own
+ * 16-byte record: outputs[i] = quantize(inputs[i]) with (scale, zero_point) from inputs[i].  Up to 16 tensors share ONE kernel
+ * launch (the grid is cut into one sub-grid per tensor, each with its own barrier), which is what a rank of a mesh all-reduce
+ * needs when it quantizes one chunk per peer, or a trainer with many small gradient tensors.  PIQUANT_STOCHASTIC draws one
+ * threshold for the whole batch.  Results are identical to `count` single calls. */
+PIQUANT_EXPORT void piquant_hip_quantize_dynamic_batch(piquant_context_t* ctx, const void* const* inputs, piquant_dtype_t dtype_in,
+                                                       void* const* outputs, piquant_dtype_t dtype_out, const size_t* numels,
+                                                       piquant_hip_params_t* const* device_params, size_t count,
+                                                       piquant_round_mode_t mode);
+
+/* piquant_hip_dequantize_dp for `count` independent tensors of the same dtype pair in one launch per 16 tensors:
+ * outputs[i] (op)= dequantize(inputs[i]) with the parameters of tensor i read from its device record. */
+PIQUANT_EXPORT void piquant_hip_dequantize_dp_batch(piquant_context_t* ctx, const void* const* inputs, piquant_dtype_t dtype_in,
+                                                    void* const* outputs, piquant_dtype_t dtype_out, const size_t* numels,
+                                                    const piquant_hip_params_t* const* device_params, size_t count,
+                                                    piquant_reduce_op_t op);
+
 /* out (op)= dequantize(inputs[0]) + dequantize(inputs[1]) + ... : `count` quantized tensors of the same dtype and length, each
  * with its own 16-byte parameter record in device memory, summed into one float tensor in a single pass -- the reduction
  * step of a quantized all-reduce in which a rank receives one chunk from every peer (xGMI is a point-to-point mesh: all

@@ -23,6 +23,7 @@
 #include <limits>
 #include <mutex>
 #include <random>
+#include <vector>
 
 namespace pq {
 
@@ -486,6 +487,43 @@ void piquant_hip_dequantize_sum(piquant_context_t* ctx, const void* const* input
     if (ctx->blocking) wait_stream(ctx->stream);
 }
 
+void piquant_hip_dequantize_dp_batch(piquant_context_t* ctx, const void* const* inputs, piquant_dtype_t dtype_in, void* const* outputs,
+                                     piquant_dtype_t dtype_out, const size_t* numels, const piquant_hip_params_t* const* device_params, size_t count,
+                                     piquant_reduce_op_t op) {
+    if (!ctx) panic("piquant_hip_dequantize_dp_batch: context is NULL");
+    const dtype_row& dti = dtype_of(dtype_in);
+    const dtype_row& dto = dtype_of(dtype_out);
+    if (!dti.quant) panic("dequantize: input dtype (%s) must be a quantized type", dti.name);
+    if (dto.quant) panic("dequantize: output dtype (%s) must be a dequantized type", dto.name);
+    if (op != PIQUANT_REDUCE_OP_SET && op != PIQUANT_REDUCE_OP_ADD) panic("dequantize: invalid reduce op %d", static_cast<int>(op));
+    if (count == 0) return;
+    if (!inputs || !outputs || !numels || !device_params) panic("piquant_hip_dequantize_dp_batch: NULL argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    size_t i = 0;
+    while (i < count) {
+        DequantBatchLaunch d {};
+        d.dt_in = dtype_in;
+        d.dt_out = dtype_out;
+        d.op = op == PIQUANT_REDUCE_OP_ADD ? OP_ADD : OP_SET;
+        while (i < count && d.count < kDequantBatchMaxInputs) {
+            if (numels[i] != 0) {
+                if (!inputs[i] || !outputs[i] || !device_params[i]) panic("dequantize: NULL buffer %zu", i);
+                const Resolved ri = ctx->resolve_ptr(inputs[i]), ro = ctx->resolve_ptr(outputs[i]), rp = resolve(device_params[i]);
+                if (ri.pageable || ro.pageable || rp.pageable) panic("piquant_hip_dequantize_dp_batch needs device (or pinned) buffers");
+                d.in[d.count] = ri.dev;
+                d.out[d.count] = ro.dev;
+                d.params[d.count] = rp.dev;
+                d.numel[d.count] = static_cast<int64_t>(numels[i]);
+                ++d.count;
+            }
+            ++i;
+        }
+        launch_dequantize_batch(d, ctx->stream);
+    }
+    if (ctx->blocking) wait_stream(ctx->stream);
+}
+
 void piquant_hip_quantize_dequantize(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in_out, void* out, piquant_dtype_t quant_dtype,
                                      size_t numel, float scale, int64_t zero_point, piquant_round_mode_t mode, piquant_reduce_op_t op) {
     if (!ctx) panic("piquant_hip_quantize_dequantize: context is NULL");
@@ -598,14 +636,54 @@ void piquant_hip_compute_quant_params_device(piquant_context_t* ctx, const void*
     scan(ctx, x, dtype, n, a);   // n == 0: the identities fold to the degenerate range, like the synchronous call
 }
 
-void piquant_hip_quantize_dynamic(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out, size_t numel,
-                                  piquant_hip_params_t* device_params, piquant_round_mode_t mode) {
-    if (!ctx) panic("piquant_hip_quantize_dynamic: context is NULL");
+// compute_quant_params + quantize of ONE tensor on resolved device pointers; `q` carries dtypes and the round-mode fields.
+// Caller holds ctx->mu and the device guard.
+static void quantize_dynamic_one(piquant_context_t* ctx, QuantLaunch q, const void* in_dev, void* out_dev, const void* out_as_passed, size_t numel,
+                                 void* params_dev) {
+    MinmaxAction params_action;
+    params_action.action = MM_PARAMS;
+    params_action.bits = dtype_of(static_cast<piquant_dtype_t>(q.dt_out)).bits;
+    params_action.dst = params_dev;
+    if (numel == 0) {   // parameters of an empty tensor: the identities fold to the degenerate range, as in the synchronous call
+        scan(ctx, nullptr, static_cast<piquant_dtype_t>(q.dt_in), 0, params_action);
+        return;
+    }
+    q.in = in_dev;
+    q.out = out_dev;
+    q.numel = static_cast<int64_t>(numel);
+    if (ctx->reference_layout) {
+        q.ref_layout = true;
+        q.ref_total = q.numel;
+        if (q.dt_in == PIQUANT_DTYPE_F32 && q.dt_out == PIQUANT_DTYPE_UINT8 && q.round_mode == RM_NEAREST_FAST)
+            q.ref_head = static_cast<int>(std::min<size_t>(numel, (16u - (reinterpret_cast<uintptr_t>(out_as_passed) & 15u)) & 15u));
+    }
+    // One launch with the tensor held on chip between the scan and the quantization when it fits; otherwise (or with fusion
+    // switched off) the same result from two launches: the scan, whose last block writes the record, and a quantize that reads it.
+    bool fused = false;
+    if (ctx->fusion && fused_launch_applies(q, ctx->num_cu)) {
+        const bool record = fused_order_before(ctx->device, ctx->stream);
+        fused = launch_fused_params_quantize(q, ctx->d_fused, params_dev, ctx->stream, ctx->num_cu);
+        if (fused && record) fused_order_after(ctx->device, ctx->stream);
+    }
+    if (!fused) {
+        scan(ctx, in_dev, static_cast<piquant_dtype_t>(q.dt_in), numel, params_action);
+        q.dyn_params = params_dev;
+        launch_quantize(q, ctx->stream, ctx->num_cu);
+    }
+}
+
+static void check_dynamic_types(piquant_dtype_t dtype_in, piquant_dtype_t dtype_out, piquant_round_mode_t mode) {
     const dtype_row& dti = dtype_of(dtype_in);
     const dtype_row& dto = dtype_of(dtype_out);
     if (dti.quant) panic("quantize: input dtype (%s) must be a dequantized type", dti.name);
     if (!dto.quant) panic("quantize: output dtype (%s) must be a quantized type", dto.name);
     if (mode != PIQUANT_NEAREST && mode != PIQUANT_STOCHASTIC) panic("quantize: invalid round mode %d", static_cast<int>(mode));
+}
+
+void piquant_hip_quantize_dynamic(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out, size_t numel,
+                                  piquant_hip_params_t* device_params, piquant_round_mode_t mode) {
+    if (!ctx) panic("piquant_hip_quantize_dynamic: context is NULL");
+    check_dynamic_types(dtype_in, dtype_out, mode);
     if (!device_params) panic("piquant_hip_quantize_dynamic: NULL parameter record");
     if (numel != 0 && (!in || !out)) panic("quantize: NULL buffer");
 
@@ -613,43 +691,81 @@ void piquant_hip_quantize_dynamic(piquant_context_t* ctx, const void* in, piquan
     DeviceGuard guard(ctx->device);
     const Resolved rp = resolve(device_params);
     if (rp.pageable) panic("piquant_hip_quantize_dynamic: the parameter record must live in device (or pinned) memory");
-    MinmaxAction params_action;
-    params_action.action = MM_PARAMS;
-    params_action.bits = dto.bits;
-    params_action.dst = rp.dev;
-    if (numel == 0) {   // parameters of an empty tensor: the identities fold to the degenerate range, as in the synchronous call
-        scan(ctx, nullptr, dtype_in, 0, params_action);
-        if (ctx->blocking) wait_stream(ctx->stream);
-        return;
-    }
-    const Resolved rin = ctx->resolve_ptr(in), rout = ctx->resolve_ptr(out);
-    if (rin.pageable || rout.pageable) panic("piquant_hip_quantize_dynamic needs device (or pinned) buffers");
-
     QuantLaunch q {};
-    q.in = rin.dev;
-    q.out = rout.dev;
-    q.numel = static_cast<int64_t>(numel);
     q.dt_in = dtype_in;
     q.dt_out = dtype_out;
     fill_round_mode(ctx, q, mode);
-    if (ctx->reference_layout) {
-        q.ref_layout = true;
-        q.ref_total = q.numel;
-        if (dtype_in == PIQUANT_DTYPE_F32 && dtype_out == PIQUANT_DTYPE_UINT8 && mode == PIQUANT_NEAREST)
-            q.ref_head = static_cast<int>(std::min<size_t>(numel, (16u - (reinterpret_cast<uintptr_t>(out) & 15u)) & 15u));
+    if (numel == 0) {
+        quantize_dynamic_one(ctx, q, nullptr, nullptr, nullptr, 0, rp.dev);
+    } else {
+        const Resolved rin = ctx->resolve_ptr(in), rout = ctx->resolve_ptr(out);
+        if (rin.pageable || rout.pageable) panic("piquant_hip_quantize_dynamic needs device (or pinned) buffers");
+        quantize_dynamic_one(ctx, q, rin.dev, rout.dev, out, numel, rp.dev);
     }
-    // One launch with the tensor held on chip between the scan and the quantization when it fits; otherwise (or with fusion
-    // switched off) the same result from two launches: the scan, whose last block writes the record, and a quantize that reads it.
-    bool fused = false;
-    if (ctx->fusion && fused_launch_applies(q, ctx->num_cu)) {
-        const bool record = fused_order_before(ctx->device, ctx->stream);
-        fused = launch_fused_params_quantize(q, ctx->d_fused, rp.dev, ctx->stream, ctx->num_cu);
-        if (fused && record) fused_order_after(ctx->device, ctx->stream);
+    if (ctx->blocking) wait_stream(ctx->stream);
+}
+
+void piquant_hip_quantize_dynamic_batch(piquant_context_t* ctx, const void* const* inputs, piquant_dtype_t dtype_in, void* const* outputs,
+                                        piquant_dtype_t dtype_out, const size_t* numels, piquant_hip_params_t* const* device_params, size_t count,
+                                        piquant_round_mode_t mode) {
+    if (!ctx) panic("piquant_hip_quantize_dynamic_batch: context is NULL");
+    check_dynamic_types(dtype_in, dtype_out, mode);
+    if (count == 0) return;
+    if (!inputs || !outputs || !numels || !device_params) panic("piquant_hip_quantize_dynamic_batch: NULL argument");
+
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    QuantLaunch q {};
+    q.dt_in = dtype_in;
+    q.dt_out = dtype_out;
+    fill_round_mode(ctx, q, mode);   // stochastic: ONE threshold for the whole batch, as one call of the reference has one
+    struct Item {
+        const void* in;
+        void* out;
+        const void* out_as_passed;
+        size_t numel;
+        void* params;
+    };
+    std::vector<Item> items(count);
+    for (size_t i = 0; i < count; ++i) {
+        if (!device_params[i]) panic("piquant_hip_quantize_dynamic_batch: NULL parameter record %zu", i);
+        const Resolved rp = resolve(device_params[i]);
+        if (rp.pageable) panic("piquant_hip_quantize_dynamic_batch: parameter records must live in device (or pinned) memory");
+        items[i] = {nullptr, nullptr, outputs[i], numels[i], rp.dev};
+        if (numels[i] == 0) continue;
+        if (!inputs[i] || !outputs[i]) panic("quantize: NULL buffer %zu", i);
+        const Resolved rin = ctx->resolve_ptr(inputs[i]), rout = ctx->resolve_ptr(outputs[i]);
+        if (rin.pageable || rout.pageable) panic("piquant_hip_quantize_dynamic_batch needs device (or pinned) buffers");
+        items[i].in = rin.dev;
+        items[i].out = rout.dev;
     }
-    if (!fused) {
-        scan(ctx, rin.dev, dtype_in, numel, params_action);
-        q.dyn_params = rp.dev;
-        launch_quantize(q, ctx->stream, ctx->num_cu);
+    // Up to kFusedBatchMax non-empty tensors per launch: one sub-grid, one barrier, one parameter record each.  Whatever does not
+    // qualify (fusion off, reference-layout mode, a misaligned or oversized tensor in the group) goes one tensor at a time.
+    size_t i = 0;
+    while (i < count) {
+        FusedBatch b {};
+        size_t j = i;
+        while (j < count && b.count < kFusedBatchMax) {
+            if (items[j].numel != 0) {
+                b.in[b.count] = items[j].in;
+                b.out[b.count] = items[j].out;
+                b.numel[b.count] = static_cast<int64_t>(items[j].numel);
+                b.params[b.count] = items[j].params;
+                ++b.count;
+            }
+            ++j;
+        }
+        bool fused = false;
+        if (ctx->fusion && !ctx->reference_layout && b.count > 1) {
+            const bool record = fused_order_before(ctx->device, ctx->stream);
+            fused = launch_fused_params_quantize_batch(q, b, ctx->d_fused, ctx->stream, ctx->num_cu);
+            if (fused && record) fused_order_after(ctx->device, ctx->stream);
+        }
+        for (size_t k = i; k < j; ++k) {
+            if (fused && items[k].numel != 0) continue;
+            quantize_dynamic_one(ctx, q, items[k].in, items[k].out, items[k].out_as_passed, items[k].numel, items[k].params);
+        }
+        i = j;
     }
     if (ctx->blocking) wait_stream(ctx->stream);
 }

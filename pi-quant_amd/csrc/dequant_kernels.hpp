@@ -298,4 +298,78 @@ __global__ void __launch_bounds__(BLOCK) dequantize_sum_kernel(DequantSumArgs a,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Several independent tensors dequantized by ONE launch, each with its own device-resident parameters: out_g (op)=
+// dequantize(in_g).  The last step of a quantized all-reduce decodes one chunk per rank; G launches of a few microseconds each
+// are mostly fixed cost.  A block owns one tile of one tensor (tile_begin[] is the running tile count); the arithmetic and the
+// access pattern are those of dequantize_sum_kernel with a single term, so results equal the single-tensor kernels.
+constexpr int kDequantBatchMax = 16;
+
+struct DequantBatchArgs {
+    const uint8_t* in[kDequantBatchMax];
+    void* out[kDequantBatchMax];
+    const ParamRecord* params[kDequantBatchMax];
+    int64_t numel[kDequantBatchMax];
+    int64_t tile_begin[kDequantBatchMax + 1];   // tiles of tensor g are [tile_begin[g], tile_begin[g + 1])
+    int vector_ok[kDequantBatchMax];            // both buffers of tensor g are 16-byte aligned
+    int count;
+};
+
+template <int BITS, int DT_OUT, int OP, int U, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) dequantize_batch_kernel(DequantBatchArgs a) {
+    constexpr int EPV = DT_OUT == DT_F32 ? 4 : 8, IB = EPV * BITS / 8;
+    constexpr int64_t TILE_VECS = static_cast<int64_t>(BLOCK) * U, TILE_ELEMS = TILE_VECS * EPV;
+    int g = 0;
+    while (g + 1 < a.count && static_cast<int64_t>(blockIdx.x) >= a.tile_begin[g + 1]) ++g;   // wave-uniform, <= 15 steps
+    const int64_t tile = static_cast<int64_t>(blockIdx.x) - a.tile_begin[g];
+    const int64_t numel = a.numel[g];
+    const uint8_t* in = a.in[g];
+    void* out = a.out[g];
+    DequantParams p {};
+    p.dyn = a.params[g];
+    p = resolved(p);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t e_begin = tile * TILE_ELEMS;
+
+    if (a.vector_ok[g] && e_begin + TILE_ELEMS <= numel) {
+        u32x4* out16 = static_cast<u32x4*>(out);
+        const int64_t v0 = tile * TILE_VECS + static_cast<int64_t>(wave) * U * 64;
+        float acc[U][EPV];
+        if constexpr (OP == OP_ADD) {
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const u32x4 old = ld<true>(out16 + v0 + k * 64 + lane);
+                if constexpr (DT_OUT == DT_F32) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[k][e] = __uint_as_float(old[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[k][2 * e] = __uint_as_float(old[e] << 16);
+                        acc[k][2 * e + 1] = __uint_as_float(old[e] & 0xffff0000u);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) dequant_sum_term<BITS, DT_OUT>(in + (v0 + k * 64 + lane) * IB, p, acc[k], OP == OP_SET);
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            u32x4 r;
+            if constexpr (DT_OUT == DT_F32) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = __float_as_uint(acc[k][e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = f32x2_to_bf16x2_bits(acc[k][2 * e], acc[k][2 * e + 1]);
+            }
+            st<ST_WT>(out16 + v0 + k * 64 + lane, r);
+        }
+        return;
+    }
+    // ragged last tile of a tensor, or a tensor with a misaligned buffer: element by element
+    const int64_t e_end = e_begin + TILE_ELEMS < numel ? e_begin + TILE_ELEMS : numel;
+    for (int64_t i = e_begin + threadIdx.x; i < e_end; i += BLOCK) dequant_store_scalar<BITS, DT_OUT, OP>(in, out, i, p);
+}
+
 }  // namespace pq

@@ -53,6 +53,20 @@ struct FusedState {
     uint64_t* stamps;     // TIMING builds (tools/tune_kernels.hip): 8 x 100 MHz wall clock readings per block at the phase boundaries
 };
 
+// A launch handles up to kFusedMaxGroups independent tensors (the chunks a rank quantizes for its peers in a mesh all-reduce,
+// or simply several tensors at once): the grid is cut into `count` sub-grids of blocks_per_group blocks, each with its own
+// barrier state, parameters and record.  Nothing is shared between groups.
+constexpr int kFusedMaxGroups = 16;
+
+struct FusedGroups {
+    const void* in[kFusedMaxGroups];
+    uint8_t* out[kFusedMaxGroups];
+    int64_t numel[kFusedMaxGroups];
+    ParamRecord* params[kFusedMaxGroups];
+    int count;
+    int blocks_per_group;
+};
+
 // The nearest step for a call whose data range is known (device_math.hpp, BoundedStep): per element a packed multiply and
 // add, the copysign, one v_med3_f32 and one v_cvt_i32_f32 give the signed offset t = q - zp; the fields are then assembled
 // by Horner steps w = (w << BITS) + t (v_lshl_add_u32, negative t borrow from the field above and the borrow is repaid
@@ -109,8 +123,15 @@ __device__ __forceinline__ void minmax_vec(const u32x4& raw, bool valid, float& 
 // spread between the fastest and the slowest block: tens of thousands of concurrent 1 KiB streams leave no DRAM locality.)
 template <int DT_IN, int BITS, int MODE, int R_REG, int R_LDS, int LDS_BATCH, int BLOCK, int ST_POLICY = ST_WT, bool TIMING = false>
 __global__ void __launch_bounds__(BLOCK)
-fused_params_quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t numel, QuantParams p_arg, FusedState* st,
-                             ParamRecord* params_out) {
+fused_params_quantize_kernel(FusedGroups groups, QuantParams p_arg, FusedState* states) {
+    // Block -> (tensor, block within the tensor's sub-grid).  With one tensor this is the identity.
+    const int group = static_cast<int>(blockIdx.x) / groups.blocks_per_group;
+    const uint32_t block = blockIdx.x - static_cast<uint32_t>(group) * groups.blocks_per_group;
+    const void* __restrict__ in = groups.in[group];
+    uint8_t* __restrict__ out = groups.out[group];
+    const int64_t numel = groups.numel[group];
+    ParamRecord* params_out = groups.params[group];
+    FusedState* st = states + group;
     static_assert(R_LDS % LDS_BATCH == 0, "the LDS-resident rounds are loaded in whole batches");
     constexpr int EPV = InVec<DT_IN>::EPV, OB = EPV * BITS / 8, WAVES = BLOCK / 64;
     constexpr int WORDS = OB > 4 ? 2 : 1;
@@ -119,26 +140,26 @@ fused_params_quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ 
     __shared__ float s_lo[WAVES], s_hi[WAVES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t G = gridDim.x;
+    const int64_t G = groups.blocks_per_group;
     const int64_t n_vec = numel / EPV;
     constexpr int64_t round_vecs = BLOCK;
     // A share is rounds_total rounds long; the first R_REG + R_LDS of them stay on chip, the rest (tensors larger than the chip
     // holds) are streamed: scanned in phase 1, read a second time in phase 3.
     const int64_t rounds_total = fused_rounds(n_vec, G, BLOCK);
     const int rounds = static_cast<int>(rounds_total < R_REG + R_LDS ? rounds_total : R_REG + R_LDS);
-    const int64_t v_first = static_cast<int64_t>(blockIdx.x) * rounds_total * BLOCK + tid;
+    const int64_t v_first = static_cast<int64_t>(block) * rounds_total * BLOCK + tid;
     const int64_t v_last = n_vec > 0 ? n_vec - 1 : 0;
     const u32x4* __restrict__ in16 = static_cast<const u32x4*>(in);
 
     auto stamp = [&](int i) {
         if constexpr (TIMING) {
-            if (tid == 0) st->stamps[blockIdx.x * 8 + i] = wall_clock64();
+            if (tid == 0) st->stamps[block * 8 + i] = wall_clock64();
         }
     };
     stamp(0);
     const uint32_t gen = __hip_atomic_load(&st->generation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int32_t* slots = st->slots[gen & 1];
-    if (blockIdx.x == 0 && tid < kMinmaxSlots) {   // the other buffer was read by the previous launch, which has completed
+    if (block == 0 && tid < kMinmaxSlots) {   // the other buffer was read by the previous launch, which has completed
         int32_t* idle = st->slots[(gen & 1) ^ 1];
         idle[tid * kMinmaxSlotStride + 0] = float_to_key(3.402823466e+38f);
         idle[tid * kMinmaxSlotStride + 1] = float_to_key(3.402823466e+38f);
@@ -190,7 +211,7 @@ fused_params_quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ 
             if (k < rounds) minmax_vec<DT_IN>(r[k], v_first + k * round_vecs < n_vec, lo, hi);
         }
     }
-    if (blockIdx.x == 0 && tid < numel - n_vec * EPV) {   // the numel % EPV scalar elements
+    if (block == 0 && tid < numel - n_vec * EPV) {   // the numel % EPV scalar elements
         const float x = InVec<DT_IN>::load_scalar(in, n_vec * EPV + tid);
         lo = __builtin_fminf(lo, x);
         hi = __builtin_fmaxf(hi, x);
@@ -221,7 +242,7 @@ fused_params_quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ 
             // arrival count, published word), and a release/acquire fence at agent scope costs an L2 write-back / invalidate
             // per block (measured: 13-17 us of barrier).  What IS needed is that this block's slot atomics are performed
             // before its arrival is counted: they return their old value and the arrival increment is made to depend on it.
-            const uint32_t one = fold_keys<false>(slots + (blockIdx.x % kMinmaxSlots) * kMinmaxSlotStride, lo, hi);
+            const uint32_t one = fold_keys<false>(slots + (block % kMinmaxSlots) * kMinmaxSlotStride, lo, hi);
             before = __hip_atomic_fetch_add(&st->arrived, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         before = __builtin_amdgcn_readfirstlane(before);
@@ -291,7 +312,7 @@ fused_params_quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ 
     for (int i = 0; i < FIELDS; ++i) zp_word |= static_cast<uint32_t>(p.zp32) << (i * BITS);
     const BoundedStep bstep {-static_cast<float>(p.zp32), static_cast<float>(((1 << BITS) - 1) - p.zp32), zp_word};
     // A block whose whole share lies inside the tensor (all but the last one or two) needs no per-vector bounds check.
-    const bool full_share = (static_cast<int64_t>(blockIdx.x) + 1) * rounds_total * BLOCK <= n_vec;
+    const bool full_share = (static_cast<int64_t>(block) + 1) * rounds_total * BLOCK <= n_vec;
     auto emit = [&](auto bounded_tag, auto full_tag) {
         constexpr bool BOUNDED = decltype(bounded_tag)::value, FULL = decltype(full_tag)::value;
         auto one = [&](const u32x4& raw, int64_t v) {
@@ -339,7 +360,7 @@ fused_params_quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ 
     } else {
         emit(std::false_type {}, std::false_type {});
     }
-    if (blockIdx.x == gridDim.x - 1 && n_vec * EPV < numel) {
+    if (block == G - 1 && n_vec * EPV < numel) {
         constexpr int PACK = 8 / BITS;
         quantize_bytes_guarded<DT_IN, BITS, MODE>(in, out, numel, n_vec * EPV / PACK, (numel + PACK - 1) / PACK, p, tid, BLOCK);
     }

@@ -153,75 +153,109 @@ void launch_quantize(const QuantLaunch& q, hipStream_t stream, int num_cu) {
 namespace {
 
 template <int DT_IN, int BITS, int MODE>
-void fused_launch(const QuantLaunch& q, const QuantParams& p, FusedState* st, ParamRecord* rec, hipStream_t stream, unsigned grid) {
-    hipLaunchKernelGGL((fused_params_quantize_kernel<DT_IN, BITS, MODE, kFusedRegRounds, kFusedLdsRounds, kFusedLdsRounds, kFusedBlock>), dim3(grid),
-                       dim3(kFusedBlock), 0, stream, q.in, static_cast<uint8_t*>(q.out), q.numel, p, st, rec);
+void fused_launch(const FusedGroups& g, const QuantParams& p, FusedState* states, hipStream_t stream) {
+    hipLaunchKernelGGL((fused_params_quantize_kernel<DT_IN, BITS, MODE, kFusedRegRounds, kFusedLdsRounds, kFusedLdsRounds, kFusedBlock>),
+                       dim3(static_cast<unsigned>(g.count * g.blocks_per_group)), dim3(kFusedBlock), 0, stream, g, p, states);
 }
 
 template <int DT_IN, int BITS>
-void fused_mode(const QuantLaunch& q, const QuantParams& p, FusedState* st, ParamRecord* rec, hipStream_t stream, unsigned grid) {
-    switch (q.round_mode) {
+void fused_mode(int round_mode, const FusedGroups& g, const QuantParams& p, FusedState* states, hipStream_t stream) {
+    switch (round_mode) {
         case RM_NEAREST_FAST:
             // fp32 -> uint2 has no SIMD fast path in the reference: generic int64 step everywhere, as in launch_quantize
-            if constexpr (DT_IN == DT_F32 && BITS == 2) fused_launch<DT_IN, BITS, RM_NEAREST_I64>(q, p, st, rec, stream, grid);
-            else fused_launch<DT_IN, BITS, RM_NEAREST_FAST>(q, p, st, rec, stream, grid);
+            if constexpr (DT_IN == DT_F32 && BITS == 2) fused_launch<DT_IN, BITS, RM_NEAREST_I64>(g, p, states, stream);
+            else fused_launch<DT_IN, BITS, RM_NEAREST_FAST>(g, p, states, stream);
             return;
-        case RM_STOCH_CALL: fused_launch<DT_IN, BITS, RM_STOCH_CALL>(q, p, st, rec, stream, grid); return;
-        case RM_STOCH_ELEM: fused_launch<DT_IN, BITS, RM_STOCH_ELEM>(q, p, st, rec, stream, grid); return;
-        default: panic("invalid round mode %d", q.round_mode);
+        case RM_STOCH_CALL: fused_launch<DT_IN, BITS, RM_STOCH_CALL>(g, p, states, stream); return;
+        case RM_STOCH_ELEM: fused_launch<DT_IN, BITS, RM_STOCH_ELEM>(g, p, states, stream); return;
+        default: panic("invalid round mode %d", round_mode);
     }
 }
 
 template <int DT_IN>
-void fused_bits(const QuantLaunch& q, const QuantParams& p, FusedState* st, ParamRecord* rec, hipStream_t stream, unsigned grid) {
-    switch (q.dt_out) {
-        case DT_UINT8: fused_mode<DT_IN, 8>(q, p, st, rec, stream, grid); return;
-        case DT_UINT4: fused_mode<DT_IN, 4>(q, p, st, rec, stream, grid); return;
-        case DT_UINT2: fused_mode<DT_IN, 2>(q, p, st, rec, stream, grid); return;
-        default: panic("invalid quantization types: %d -> %d", q.dt_in, q.dt_out);
+void fused_bits(int dt_out, int round_mode, const FusedGroups& g, const QuantParams& p, FusedState* states, hipStream_t stream) {
+    switch (dt_out) {
+        case DT_UINT8: fused_mode<DT_IN, 8>(round_mode, g, p, states, stream); return;
+        case DT_UINT4: fused_mode<DT_IN, 4>(round_mode, g, p, states, stream); return;
+        case DT_UINT2: fused_mode<DT_IN, 2>(round_mode, g, p, states, stream); return;
+        default: panic("invalid quantization types: %d -> %d", DT_IN, dt_out);
     }
 }
 
+int64_t n_vec_of(int64_t numel, int dt_in) { return numel / (dt_in == DT_F32 ? 4 : 8); }
+
 }  // namespace
 
-size_t fused_state_bytes() { return sizeof(FusedState); }
+size_t fused_state_bytes() { return sizeof(FusedState) * kFusedMaxGroups; }
 
 void init_fused_state(void* state, hipStream_t stream) {
-    PQ_HIP(hipMemsetAsync(state, 0, sizeof(FusedState), stream));
+    PQ_HIP(hipMemsetAsync(state, 0, fused_state_bytes(), stream));
     FusedState* st = static_cast<FusedState*>(state);
-    launch_arm_slots(&st->slots[0][0], stream);
-    launch_arm_slots(&st->slots[1][0], stream);
+    for (int g = 0; g < kFusedMaxGroups; ++g) {
+        launch_arm_slots(&st[g].slots[0][0], stream);
+        launch_arm_slots(&st[g].slots[1][0], stream);
+    }
 }
 
-static int64_t n_vec_of(const QuantLaunch& q) { return q.numel / (q.dt_in == DT_F32 ? 4 : 8); }
+// Sub-grid size for `count` tensors of which the largest has `max_numel` elements, or 0 when the batch cannot take the fused
+// kernel.  At most one block per CU overall (the grid barriers need every block resident; a 1024-thread block with 144 KiB of
+// LDS owns its CU); small tensors get fewer blocks (at least kFusedMinRounds vectors per thread before another block is
+// added): fewer arrivals at the barrier, nothing idle to launch.
+static int fused_blocks_per_group(int64_t max_numel, int dt_in, int count, int num_cu) {
+    if (count < 1 || count > kFusedMaxGroups || num_cu < count) return 0;
+    const int64_t n_vec = n_vec_of(max_numel, dt_in);
+    const int cap = num_cu / count;
+    if (fused_rounds(n_vec, cap, kFusedBlock) > kFusedMaxRounds) return 0;   // on chip entirely, or mostly with a streamed remainder
+    const int64_t per = static_cast<int64_t>(kFusedBlock) * kFusedMinRounds;
+    return static_cast<int>(std::min<int64_t>(cap, std::max<int64_t>((n_vec + per - 1) / per, 1)));
+}
 
 bool fused_launch_applies(const QuantLaunch& q, int num_cu) {
     if (q.numel <= 0 || q.ref_layout || !aligned16(q.in) || !aligned16(q.out)) return false;
     if (q.dt_in != DT_F32 && q.dt_in != DT_BF16) panic("invalid quantization types: %d -> %d", q.dt_in, q.dt_out);
-    const int64_t n_vec = q.numel / (q.dt_in == DT_F32 ? 4 : 8);
-    return fused_rounds(n_vec, num_cu, kFusedBlock) <= kFusedMaxRounds;   // on chip entirely, or mostly with a streamed remainder
+    return fused_blocks_per_group(q.numel, q.dt_in, 1, num_cu) > 0;
 }
 
-bool launch_fused_params_quantize(const QuantLaunch& q, void* state, void* device_param_record, hipStream_t stream, int num_cu) {
-    if (!fused_launch_applies(q, num_cu)) return false;
+bool launch_fused_params_quantize_batch(const QuantLaunch& q, const FusedBatch& b, void* state, hipStream_t stream, int num_cu) {
+    static_assert(kFusedBatchMax == kFusedMaxGroups, "host and device batch limits");
+    if (b.count < 1 || b.count > kFusedMaxGroups || q.ref_layout) return false;
+    if (q.dt_in != DT_F32 && q.dt_in != DT_BF16) panic("invalid quantization types: %d -> %d", q.dt_in, q.dt_out);
+    FusedGroups g {};
+    int64_t max_numel = 0;
+    for (int i = 0; i < b.count; ++i) {
+        if (b.numel[i] <= 0 || !aligned16(b.in[i]) || !aligned16(b.out[i])) return false;
+        g.in[i] = b.in[i];
+        g.out[i] = static_cast<uint8_t*>(b.out[i]);
+        g.numel[i] = b.numel[i];
+        g.params[i] = static_cast<ParamRecord*>(b.params[i]);
+        max_numel = std::max(max_numel, b.numel[i]);
+    }
+    g.count = b.count;
+    g.blocks_per_group = fused_blocks_per_group(max_numel, q.dt_in, b.count, num_cu);
+    if (g.blocks_per_group == 0) return false;
     QuantParams p {};
     p.threshold = q.threshold;
     p.seed_lo = static_cast<uint32_t>(q.seed);
     p.seed_hi = static_cast<uint32_t>(q.seed >> 32);
     p.index_base = q.index_base;
-    FusedState* st = static_cast<FusedState*>(state);
-    ParamRecord* rec = static_cast<ParamRecord*>(device_param_record);
-    // At most one block per CU: the grid barrier needs every block resident, and a 1024-thread block with 144 KiB of LDS owns
-    // its CU.  Small tensors get a smaller grid (at least kFusedMinRounds vectors per thread before another block is added):
-    // fewer arrivals at the barrier, nothing idle to launch.
-    const int64_t want = (n_vec_of(q) + static_cast<int64_t>(kFusedBlock) * kFusedMinRounds - 1) / (static_cast<int64_t>(kFusedBlock) * kFusedMinRounds);
-    const unsigned grid = static_cast<unsigned>(std::min<int64_t>(num_cu, std::max<int64_t>(want, 1)));
+    FusedState* states = static_cast<FusedState*>(state);
     switch (q.dt_in) {
-        case DT_F32: fused_bits<DT_F32>(q, p, st, rec, stream, grid); break;
-        default: fused_bits<DT_BF16>(q, p, st, rec, stream, grid); break;
+        case DT_F32: fused_bits<DT_F32>(q.dt_out, q.round_mode, g, p, states, stream); break;
+        default: fused_bits<DT_BF16>(q.dt_out, q.round_mode, g, p, states, stream); break;
     }
     PQ_HIP(hipGetLastError());
     return true;
+}
+
+bool launch_fused_params_quantize(const QuantLaunch& q, void* state, void* device_param_record, hipStream_t stream, int num_cu) {
+    if (!fused_launch_applies(q, num_cu)) return false;
+    FusedBatch b {};
+    b.count = 1;
+    b.in[0] = q.in;
+    b.out[0] = q.out;
+    b.numel[0] = q.numel;
+    b.params[0] = device_param_record;
+    return launch_fused_params_quantize_batch(q, b, state, stream, num_cu);
 }
 
 void launch_dequantize(const DequantLaunch& d, hipStream_t stream, int num_cu) {
@@ -278,6 +312,64 @@ void dequantize_sum_out(const DequantSumLaunch& d, const DequantSumArgs& a, hipS
 }
 
 }  // namespace
+
+namespace {
+
+template <int BITS, int DT_OUT, int OP>
+void dequantize_batch_t(const DequantBatchLaunch& d, hipStream_t stream) {
+    constexpr int U = 2, BLOCK = 128;
+    constexpr int EPV = DT_OUT == DT_F32 ? 4 : 8;
+    constexpr int64_t TILE_ELEMS = static_cast<int64_t>(BLOCK) * U * EPV;
+    DequantBatchArgs a {};
+    int64_t tiles = 0;
+    for (int i = 0; i < d.count; ++i) {
+        a.in[i] = static_cast<const uint8_t*>(d.in[i]);
+        a.out[i] = d.out[i];
+        a.params[i] = static_cast<const ParamRecord*>(d.params[i]);
+        a.numel[i] = d.numel[i];
+        a.vector_ok[i] = aligned16(d.in[i]) && aligned16(d.out[i]) ? 1 : 0;
+        a.tile_begin[i] = tiles;
+        tiles += (d.numel[i] + TILE_ELEMS - 1) / TILE_ELEMS;
+    }
+    a.tile_begin[d.count] = tiles;
+    a.count = d.count;
+    if (tiles == 0) return;
+    if (tiles > (int64_t {1} << 31) - 1) panic("dequantize_batch: %lld tiles in one launch", static_cast<long long>(tiles));
+    hipLaunchKernelGGL((dequantize_batch_kernel<BITS, DT_OUT, OP, U, BLOCK>), dim3(static_cast<unsigned>(tiles)), dim3(BLOCK), 0, stream, a);
+}
+
+template <int BITS, int DT_OUT>
+void dequantize_batch_op(const DequantBatchLaunch& d, hipStream_t stream) {
+    switch (d.op) {
+        case OP_SET: dequantize_batch_t<BITS, DT_OUT, OP_SET>(d, stream); return;
+        case OP_ADD: dequantize_batch_t<BITS, DT_OUT, OP_ADD>(d, stream); return;
+        default: panic("invalid reduce op %d", d.op);
+    }
+}
+
+template <int BITS>
+void dequantize_batch_out(const DequantBatchLaunch& d, hipStream_t stream) {
+    switch (d.dt_out) {
+        case DT_F32: dequantize_batch_op<BITS, DT_F32>(d, stream); return;
+        case DT_BF16: dequantize_batch_op<BITS, DT_BF16>(d, stream); return;
+        default: panic("invalid dequantization types: %d -> %d", d.dt_in, d.dt_out);
+    }
+}
+
+}  // namespace
+
+void launch_dequantize_batch(const DequantBatchLaunch& d, hipStream_t stream) {
+    static_assert(kDequantBatchMaxInputs == kDequantBatchMax, "host and device batch limits");
+    if (d.count <= 0) return;
+    if (d.count > kDequantBatchMax) panic("dequantize_batch: %d tensors, at most %d per launch", d.count, kDequantBatchMax);
+    switch (d.dt_in) {
+        case DT_UINT8: dequantize_batch_out<8>(d, stream); break;
+        case DT_UINT4: dequantize_batch_out<4>(d, stream); break;
+        case DT_UINT2: dequantize_batch_out<2>(d, stream); break;
+        default: panic("invalid dequantization types: %d -> %d", d.dt_in, d.dt_out);
+    }
+    PQ_HIP(hipGetLastError());
+}
 
 void launch_dequantize_sum(const DequantSumLaunch& d, hipStream_t stream, int num_cu) {
     static_assert(kDequantSumMaxInputs == kDequantSumMax, "host and device input limits");

@@ -72,6 +72,21 @@ struct DequantSumLaunch {
 };
 void launch_dequantize_sum(const DequantSumLaunch& d, hipStream_t stream, int num_cu);
 
+// out[g] (op)= dequantize(in[g]) for up to kDequantBatchMaxInputs independent tensors in one launch, parameters of tensor g from
+// its 16-byte device ParamRecord (dequant_kernels.hpp)
+constexpr int kDequantBatchMaxInputs = 16;
+struct DequantBatchLaunch {
+    const void* in[kDequantBatchMaxInputs];
+    void* out[kDequantBatchMaxInputs];
+    const void* params[kDequantBatchMaxInputs];
+    int64_t numel[kDequantBatchMaxInputs];
+    int count;
+    int dt_in;
+    int dt_out;
+    int op;
+};
+void launch_dequantize_batch(const DequantBatchLaunch& d, hipStream_t stream);
+
 // All launches are asynchronous on `stream`; num_cu sizes capped grids.
 void launch_quantize(const QuantLaunch& q, hipStream_t stream, int num_cu);
 void launch_dequantize(const DequantLaunch& d, hipStream_t stream, int num_cu);
@@ -106,6 +121,18 @@ int minmax_state_ints();
 // without launching when the call does not qualify (tensor larger than the chip holds, misaligned buffers, reference-layout
 // mode): the caller then runs the scan (parameter epilogue in its last block) and the quantize kernel, with identical results.
 bool launch_fused_params_quantize(const QuantLaunch& q, void* state, void* device_param_record, hipStream_t stream, int num_cu);
+// The same for up to kFusedBatchMax independent tensors in ONE launch (dtype pair and rounding mode from `q`, whose buffers are
+// ignored): the grid is cut into one sub-grid per tensor, each with its own barrier and parameters.  false when the batch does
+// not qualify (a misaligned buffer, an empty tensor, a tensor too large for its sub-grid): launch them one by one instead.
+constexpr int kFusedBatchMax = 16;
+struct FusedBatch {
+    const void* in[kFusedBatchMax];
+    void* out[kFusedBatchMax];
+    int64_t numel[kFusedBatchMax];
+    void* params[kFusedBatchMax];   // 16-byte device ParamRecord per tensor
+    int count;
+};
+bool launch_fused_params_quantize_batch(const QuantLaunch& q, const FusedBatch& b, void* state, hipStream_t stream, int num_cu);
 bool fused_launch_applies(const QuantLaunch& q, int num_cu);   // the test launch_fused_params_quantize makes, without launching
 size_t fused_state_bytes();
 void init_fused_state(void* state, hipStream_t stream);

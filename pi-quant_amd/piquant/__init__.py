@@ -217,6 +217,29 @@ class Context:
         self.assume_device_pointers(_device_ptrs)
         C.piquant_hip_quantize_dynamic(self._ctx, ptr_in, dtype_in.value, ptr_out, dtype_out.value, numel, params_ptr, round_mode.value)
 
+    def quantize_dynamic_batch_ptr(self, ptrs_in, dtype_in: DataType, ptrs_out, dtype_out: DataType, numels, params_ptrs, round_mode: RoundMode,
+                                   _device_ptrs: bool = False) -> None:
+        """``quantize_dynamic_ptr`` for several independent tensors (own parameters and record each); up to 16 of them share one
+        kernel launch (include/piquant_hip.h, piquant_hip_quantize_dynamic_batch)."""
+        n = len(ptrs_in)
+        assert dtype_in.is_dequantized and dtype_out.is_quantized and n == len(ptrs_out) == len(numels) == len(params_ptrs)
+        if n == 0:
+            return
+        self.assume_device_pointers(_device_ptrs)
+        C.piquant_hip_quantize_dynamic_batch(self._ctx, (_C.c_void_p * n)(*ptrs_in), dtype_in.value, (_C.c_void_p * n)(*ptrs_out), dtype_out.value,
+                                             (_C.c_size_t * n)(*numels), (_C.c_void_p * n)(*params_ptrs), n, round_mode.value)
+
+    def dequantize_dp_batch_ptr(self, ptrs_in, dtype_in: DataType, ptrs_out, dtype_out: DataType, numels, params_ptrs, reduce_op: ReduceOp,
+                                _device_ptrs: bool = False) -> None:
+        """``dequantize_dp_ptr`` for several independent tensors in one launch per 16 (piquant_hip_dequantize_dp_batch)."""
+        n = len(ptrs_in)
+        assert dtype_in.is_quantized and dtype_out.is_dequantized and n == len(ptrs_out) == len(numels) == len(params_ptrs)
+        if n == 0:
+            return
+        self.assume_device_pointers(_device_ptrs)
+        C.piquant_hip_dequantize_dp_batch(self._ctx, (_C.c_void_p * n)(*ptrs_in), dtype_in.value, (_C.c_void_p * n)(*ptrs_out), dtype_out.value,
+                                          (_C.c_size_t * n)(*numels), (_C.c_void_p * n)(*params_ptrs), n, reduce_op.value)
+
     def dequantize_sum_ptr(self, ptrs_in, params_ptrs, dtype_in: DataType, ptr_out: int, dtype_out: DataType, numel: int, reduce_op: ReduceOp,
                            _device_ptrs: bool = False) -> None:
         """out (op)= sum of dequantize(input i) over several quantized buffers, each with its own device parameter record, in one

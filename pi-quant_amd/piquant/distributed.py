@@ -89,6 +89,22 @@ class _DeviceOps:
         dequantize_dynamic(buf[_HEADER_BYTES:], buf[:_HEADER_BYTES], dtype=out.dtype, reduce_op=reduce_op, ctx=self.ctx, out=out,
                            quant_dtype=qdtype, shape=out.shape)
 
+    def encode_batch(self, xs, bufs, qdtype: torch.dtype, round_mode: str) -> None:
+        """encode(xs[i], bufs[i]) for all i with one kernel launch per 16 chunks (each chunk its own parameters)."""
+        from .torch import quantize_dynamic_batch
+
+        if xs:
+            quantize_dynamic_batch(list(xs), dtype=qdtype, round_mode=round_mode, ctx=self.ctx, outs=[b[_HEADER_BYTES:] for b in bufs],
+                                   params=[b[:_HEADER_BYTES] for b in bufs])
+
+    def decode_batch(self, bufs, outs, qdtype: torch.dtype, reduce_op: str) -> None:
+        """decode(bufs[i], outs[i]) for all i with one kernel launch per 16 chunks."""
+        from .torch import dequantize_dynamic_batch
+
+        if bufs:
+            dequantize_dynamic_batch([b[_HEADER_BYTES:] for b in bufs], [b[:_HEADER_BYTES] for b in bufs], dtype=outs[0].dtype, reduce_op=reduce_op,
+                                     ctx=self.ctx, outs=list(outs), quant_dtype=qdtype, shapes=[o.shape for o in outs])
+
     def decode_sum(self, bufs, out: torch.Tensor, qdtype: torch.dtype) -> None:
         """out += sum of the wire buffers, one pass over ``out`` (same result as decode(..., 'add') buffer by buffer)."""
         from .torch import dequantize_sum
@@ -233,11 +249,12 @@ def quantized_all_reduce_direct(
 
     A ring keeps one link per direction busy and re-quantizes a partial sum at each of its G-1 hops.  Here rank r owns chunk r:
 
-    1. every rank quantizes chunk j of its tensor for every peer j (parameters from that chunk, 16-byte header + packed bytes),
+    1. every rank quantizes chunk j of its tensor for every peer j (parameters from that chunk, 16-byte header + packed bytes;
+       all G-1 chunks in ONE kernel launch, ``quantize_dynamic_batch``),
     2. ONE all-to-all delivers them -- G-1 transfers per rank, each on its own link, all at once,
     3. the owner adds the G-1 received chunks to its own (unquantized) values in a single pass (``dequantize_sum``),
     4. quantizes the finished chunk once, ONE all-gather distributes it, and every rank (the owner included) stores
-       ``dequantize(..., 'set')`` of the same bytes, so all ranks end bit-identical.
+       ``dequantize(..., 'set')`` of the same bytes (all G chunks in one launch), so all ranks end bit-identical.
 
     Every value is quantized exactly twice whatever the world size (a ring: up to G times), the wire carries the same
     2(G-1)/G x packed bytes per element, and the two collectives are what RCCL implements natively over the mesh.
@@ -261,10 +278,8 @@ def quantized_all_reduce_direct(
         return _HEADER_BYTES + qdt.packed_nbytes(e - b)
 
     # ---- reduce-scatter over the mesh ----
-    for j in range(world):
-        b, e = chunks[j]
-        if j != rank and e > b:
-            ops.encode(flat[b:e], send[j * slot: j * slot + wire_len(j)], quant_dtype, round_mode)
+    peers = [j for j in range(world) if j != rank and chunks[j][1] > chunks[j][0]]
+    ops.encode_batch([flat[chunks[j][0]:chunks[j][1]] for j in peers], [send[j * slot: j * slot + wire_len(j)] for j in peers], quant_dtype, round_mode)
     _all_to_all(send, recv, group)
     b_own, e_own = chunks[rank]
     x_own = flat[b_own:e_own]
@@ -277,8 +292,6 @@ def quantized_all_reduce_direct(
     if x_own.numel():
         ops.encode(x_own, mine[:n_own], quant_dtype, round_mode)
     _all_gather(mine, recv, group)
-    for j in range(world):
-        b, e = chunks[j]
-        if e > b:
-            ops.decode(recv[j * slot: j * slot + wire_len(j)], flat[b:e], quant_dtype, 'set')
+    full = [j for j in range(world) if chunks[j][1] > chunks[j][0]]
+    ops.decode_batch([recv[j * slot: j * slot + wire_len(j)] for j in full], [flat[chunks[j][0]:chunks[j][1]] for j in full], quant_dtype, 'set')
     return tensor

@@ -328,3 +328,47 @@ def dequantize_sum(tensors, params, *, dtype: torch.dtype, reduce_op: str = 'set
     ctx.dequantize_sum_ptr([t.data_ptr() for t in tensors], [p.data_ptr() for p in params], dtype_in, out.data_ptr(), torch_to_piquant_dtype(out.dtype),
                            numel, _REDUCE_OPS[reduce_op], _device_ptrs=True)
     return out
+
+
+def quantize_dynamic_batch(tensors, *, dtype: torch.dtype, round_mode: str = 'nearest', ctx: Optional[Context] = None, outs=None, params=None):
+    """``quantize_dynamic`` for a list of independent tensors of one float dtype: each gets its own (scale, zero_point) and record,
+    up to 16 of them are processed by ONE kernel launch.  Returns (list of quantized tensors, list of parameter records)."""
+    assert dtype in _QUANT_TYPES and len(tensors) > 0
+    fdt = tensors[0].dtype
+    assert fdt in _DEQUANT_TYPES and all(t.is_cuda and t.dtype == fdt for t in tensors)
+    tensors = [t if t.is_contiguous() else t.contiguous() for t in tensors]
+    if outs is None:
+        outs = [torch.empty(t.shape, dtype=dtype, device=t.device) for t in tensors]
+    if params is None:
+        block = torch.empty(len(tensors) * PARAMS_NBYTES, dtype=torch.uint8, device=tensors[0].device)
+        params = [block[i * PARAMS_NBYTES: (i + 1) * PARAMS_NBYTES] for i in range(len(tensors))]
+    assert len(outs) == len(params) == len(tensors)
+    ctx = _ctx_for(tensors[0], ctx)
+    ctx.quantize_dynamic_batch_ptr([t.data_ptr() for t in tensors], torch_to_piquant_dtype(fdt), [o.data_ptr() for o in outs], torch_to_piquant_dtype(dtype),
+                                   [t.numel() for t in tensors], [p.data_ptr() for p in params], _ROUND_MODES[round_mode], _device_ptrs=True)
+    return outs, params
+
+
+def dequantize_dynamic_batch(tensors, params, *, dtype: torch.dtype, reduce_op: str = 'set', ctx: Optional[Context] = None, outs=None,
+                             quant_dtype: Optional[torch.dtype] = None, shapes=None):
+    """``dequantize_dynamic`` for a list of independent quantized tensors (raw uint8 buffers with ``quant_dtype=`` and ``shapes=``, or
+    quantized torch tensors) in one launch per 16; ``outs`` are required for ``reduce_op='add'``."""
+    assert dtype in _DEQUANT_TYPES and len(tensors) == len(params) and len(tensors) > 0
+    metas = [_quant_meta(t, quant_dtype, None if shapes is None else shapes[i]) for i, t in enumerate(tensors)]
+    dtype_in = metas[0][0]
+    assert all(m[0] == dtype_in for m in metas) and all(t.is_cuda and t.is_contiguous() for t in tensors)
+    numels = []
+    for _dt, shp in metas:
+        n = 1
+        for s_ in shp:
+            n *= int(s_)
+        numels.append(n)
+    if outs is None:
+        if reduce_op == 'add':
+            raise ValueError("reduce_op='add' accumulates into outs=; pass the accumulator tensors")
+        outs = [torch.empty(m[1], dtype=dtype, device=t.device) for m, t in zip(metas, tensors)]
+    assert all(o.dtype == dtype and o.is_contiguous() and o.numel() == n for o, n in zip(outs, numels))
+    ctx = _ctx_for(tensors[0], ctx)
+    ctx.dequantize_dp_batch_ptr([t.data_ptr() for t in tensors], dtype_in, [o.data_ptr() for o in outs], torch_to_piquant_dtype(dtype), numels,
+                                [p.data_ptr() for p in params], _REDUCE_OPS[reduce_op], _device_ptrs=True)
+    return outs

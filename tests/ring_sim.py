@@ -113,3 +113,11 @@ class OracleOps:
     def decode_sum(self, bufs, out, qdtype):
         for buf in bufs:
             self.decode(buf, out, qdtype, "add")
+
+    def encode_batch(self, xs, bufs, qdtype, round_mode):
+        for x, buf in zip(xs, bufs):
+            self.encode(x, buf, qdtype, round_mode)
+
+    def decode_batch(self, bufs, outs, qdtype, reduce_op):
+        for buf, out in zip(bufs, outs):
+            self.decode(buf, out, qdtype, reduce_op)

@@ -1001,3 +1001,63 @@ def test_dequantize_sum_equals_sequential_adds(O):
                             got = acc.cpu().numpy() if dt_f == 0 else acc.view(torch.int16).cpu().numpy().view(np.uint16)
                             assert same_floats(got, want), (n, dt_q, f_name, K, op, off)
                             assert bool((buf[:off] == 0).all()) and bool((buf[off + n:] == 0).all())
+
+
+def test_batched_dynamic_quantize_and_dequantize_equal_single_calls(O):
+    """quantize_dynamic_batch / dequantize_dynamic_batch: up to 16 independent tensors per launch, each with its own parameters --
+    every output and record must equal the single-tensor calls (and the oracle); ragged and empty tensors, a misaligned one (drops the
+    whole group to single calls), more than 16 tensors, a tensor too large for its sub-grid, stochastic mode."""
+    import piquant
+    import piquant.torch as pt
+    import torch
+
+    rng = np.random.default_rng(909)
+    ctx = piquant.Context()
+    tq = {4: torch.quint8, 3: torch.quint4x2, 2: torch.quint2x4}
+    size_sets = [
+        [3_407_872] * 7,                                  # the chunks of an 8-way all-reduce of the BASELINE tensor
+        [1, 7, 1000, 4099, 65_536, 300_001, 5],
+        [2000 + 17 * i for i in range(19)],               # more than one launch's worth
+        [5_000_000, 100, 5_000_000],                      # too large for a third of the chip each -> single calls
+    ]
+    for sizes in size_sets:
+        for dt_f, fdt in ((0, torch.float32), (1, torch.bfloat16)):
+            for dt_q in (4, 3) if sizes[0] > 1_000_000 else (4, 3, 2):
+                for rm, tau in ((0, 0.0), (1, 0.625)):
+                    if rm and dt_q == 2:
+                        continue
+                    xs = [rng.uniform(-1 - 0.1 * i, 2 + 0.2 * i, n).astype(np.float32) for i, n in enumerate(sizes)]
+                    xin = [x if dt_f == 0 else O.f32_to_bf16(x) for x in xs]
+                    xd = [torch.from_numpy(x).cuda() if dt_f == 0 else torch.from_numpy(x.view(np.int16)).cuda().view(torch.bfloat16) for x in xin]
+                    ctx.set_stochastic_threshold(tau if rm else None)
+                    qs, recs = pt.quantize_dynamic_batch(xd, dtype=tq[dt_q], round_mode="stochastic" if rm else "nearest", ctx=ctx)
+                    torch.cuda.synchronize()
+                    for i, x in enumerate(xin):
+                        scale, zp = O.compute_quant_params(x, dt_f, dt_q)
+                        assert pt.params_to_host(recs[i]) == (scale, zp), (sizes, i)
+                        assert np.array_equal(pt.packed_bytes(qs[i]).cpu().numpy(), O.quantize(x, dt_f, dt_q, scale, zp, rm, tau)), (sizes, dt_f, dt_q, rm, i)
+                    # and back, SET then ADD, in one launch per 16
+                    back = pt.dequantize_dynamic_batch(qs, recs, dtype=fdt, ctx=ctx)
+                    accs = [torch.ones_like(b) for b in back]
+                    pt.dequantize_dynamic_batch(qs, recs, dtype=fdt, reduce_op="add", outs=accs, ctx=ctx)
+                    for i, x in enumerate(xin):
+                        scale, zp = pt.params_to_host(recs[i])
+                        qb = pt.packed_bytes(qs[i]).cpu().numpy()
+                        want = O.dequantize(qb, dt_q, dt_f, x.size, scale, zp)
+                        ones = np.ones(x.size, np.float32) if dt_f == 0 else O.f32_to_bf16(np.ones(x.size, np.float32))
+                        want_acc = O.dequantize(qb, dt_q, dt_f, x.size, scale, zp, 1, out=ones)
+                        got = back[i].cpu().numpy() if dt_f == 0 else back[i].view(torch.int16).cpu().numpy().view(np.uint16)
+                        got_acc = accs[i].cpu().numpy() if dt_f == 0 else accs[i].view(torch.int16).cpu().numpy().view(np.uint16)
+                        assert same_floats(got, want) and same_floats(got_acc, want_acc), (sizes, dt_f, dt_q, i)
+    ctx.set_stochastic_threshold(None)
+    # an empty tensor and a misaligned one inside a batch
+    xs = [rng.uniform(-1, 1, n).astype(np.float32) for n in (1000, 0, 3000)]
+    big = torch.zeros(3004, device="cuda")
+    xd = [torch.from_numpy(xs[0]).cuda(), torch.empty(0, device="cuda"), big[1:3001]]
+    xd[2].copy_(torch.from_numpy(xs[2]))
+    qs, recs = pt.quantize_dynamic_batch(xd, dtype=torch.quint8, ctx=ctx)
+    for i in (0, 2):
+        scale, zp = O.compute_quant_params(xs[i], 0, 4)
+        assert pt.params_to_host(recs[i]) == (scale, zp)
+        assert np.array_equal(pt.packed_bytes(qs[i]).cpu().numpy(), O.quantize(xs[i], 0, 4, scale, zp))
+    assert pt.params_to_host(recs[1]) == O.compute_quant_params(xs[1], 0, 4)

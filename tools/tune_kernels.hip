@@ -288,6 +288,17 @@ struct FusedBufs {
     uint64_t* stamps;
 };
 
+static FusedGroups one_group(const void* in, void* out, int64_t numel, ParamRecord* rec, int blocks) {
+    FusedGroups g {};
+    g.in[0] = in;
+    g.out[0] = static_cast<uint8_t*>(out);
+    g.numel[0] = numel;
+    g.params[0] = rec;
+    g.count = 1;
+    g.blocks_per_group = blocks;
+    return g;
+}
+
 template <int R_REG, int R_LDS, int LDS_BATCH, int BLOCK, int STP = ST_WT>
 static void run_fused(const Bufs& b, const FusedBufs& f, int64_t numel, int num_cu, int32_t* slots) {
     const int64_t n_vec = numel / 4;
@@ -299,7 +310,7 @@ static void run_fused(const Bufs& b, const FusedBufs& f, int64_t numel, int num_
     QuantParams p {};
     auto launch = [&](int i) {
         hipLaunchKernelGGL((fused_params_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, R_REG, R_LDS, LDS_BATCH, BLOCK, STP>), dim3(num_cu), dim3(BLOCK), 0,
-                           g_stream, b.in[i % SETS], static_cast<uint8_t*>(b.out[i % SETS]), numel, p, f.st, f.rec);
+                           g_stream, one_group(b.in[i % SETS], b.out[i % SETS], numel, f.rec, num_cu), p, f.st);
     };
     // correctness first: same bytes and record as scan (with parameter epilogue) -> quantize
     CK(hipMemsetAsync(b.out[0], 0x5a, numel, g_stream));
@@ -332,7 +343,7 @@ static void run_fused(const Bufs& b, const FusedBufs& f, int64_t numel, int num_
     // where block 0 spends its time (100 MHz wall clock): one launch on a quiet device
     CK(hipStreamSynchronize(g_stream));
     hipLaunchKernelGGL((fused_params_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, R_REG, R_LDS, LDS_BATCH, BLOCK, STP, true>), dim3(num_cu), dim3(BLOCK), 0, g_stream,
-                       b.in[3], static_cast<uint8_t*>(b.out[3]), numel, p, f.st, f.rec);
+                       one_group(b.in[3], b.out[3], numel, f.rec, num_cu), p, f.st);
     CK(hipStreamSynchronize(g_stream));
     std::vector<uint64_t> t(static_cast<size_t>(num_cu) * 8);
     CK(hipMemcpy(t.data(), f.stamps, t.size() * 8, hipMemcpyDeviceToHost));
