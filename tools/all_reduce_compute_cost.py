@@ -51,12 +51,11 @@ def main():
                 ops.decode(bufs[j * slot: j * slot + nbytes[j]], x[chunks[j][0]:chunks[j][1]], qdt, "set")
 
         def direct():
-            for j in range(1, W):                    # one encode per peer
-                ops.encode(x[chunks[j][0]:chunks[j][1]], bufs[j * slot: j * slot + nbytes[j]], qdt, "nearest")
+            peers = list(range(1, W))                # one launch quantizes the chunk of every peer
+            ops.encode_batch([x[chunks[j][0]:chunks[j][1]] for j in peers], [bufs[j * slot: j * slot + nbytes[j]] for j in peers], qdt, "nearest")
             ops.decode_sum([bufs[i * slot: i * slot + nbytes[0]] for i in range(1, W)], x[chunks[0][0]:chunks[0][1]], qdt)
             ops.encode(x[chunks[0][0]:chunks[0][1]], bufs[0: nbytes[0]], qdt, "nearest")
-            for j in range(W):
-                ops.decode(bufs[j * slot: j * slot + nbytes[j]], x[chunks[j][0]:chunks[j][1]], qdt, "set")
+            ops.decode_batch([bufs[j * slot: j * slot + nbytes[j]] for j in range(W)], [x[chunks[j][0]:chunks[j][1]] for j in range(W)], qdt, "set")
 
         row = {}
         for name, fn in (("ring", ring), ("direct", direct)):
