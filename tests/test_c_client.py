@@ -69,3 +69,49 @@ def test_c_client_results_match_oracle(tmp_path, oracle_mod, client):
     assert int(out[4], 16) == _fnv1a(q8.tobytes())
     assert int(out[5], 16) == _fnv1a(q4.tobytes())
     assert int(out[6], 16) == _fnv1a(back.tobytes())
+
+
+def _build_hip_client(tmp_path):
+    exe = tmp_path / "hip_client"
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-O2", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", f"-I{ROOT / 'include'}",
+                    str(ROOT / "tests" / "hip_client.cpp"), f"-L{LIBDIR}", "-lpiquant", "-L/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{LIBDIR}",
+                    "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
+    return exe
+
+
+def test_hip_client_compiles_and_links(tmp_path):
+    """A C++ program with its own HIP runtime (no Python, no PyTorch) against the GPU-side extras of the library."""
+    assert _build_hip_client(tmp_path).exists()
+
+
+@pytest.mark.gpu
+def test_hip_client_device_buffers_match_oracle(tmp_path, oracle_mod):
+    """Device buffers on the caller's stream from a torch-free process: fused params + quantize, the batched form, dequantize from
+    the device record and dequantize_sum, all checked against the oracle."""
+    O = oracle_mod
+    n = 1_000_003
+    exe = _build_hip_client(tmp_path)
+    out = subprocess.run([str(exe), str(n)], check=True, capture_output=True, text=True, timeout=300).stdout.split()
+    s = np.uint32(12345)
+    x = np.empty(n, dtype=np.float32)
+    with np.errstate(over="ignore"):
+        for i in range(n):
+            s ^= np.uint32(s << np.uint32(13))
+            s ^= np.uint32(s >> np.uint32(17))
+            s ^= np.uint32(s << np.uint32(5))
+            x[i] = np.float32(int(s) >> 8) * np.float32(2.0 / 16777216.0) - np.float32(1.0)
+    half = int(out[10])
+    assert half == (n // 2) & ~3
+    parts = [x, x[:half], x[half:2 * half]]
+    params = [O.compute_quant_params(p, O.F32, O.UINT8) for p in parts]
+    for i, (sc, zp) in enumerate(params):
+        assert (np.float32(float(out[2 * i])), int(out[2 * i + 1])) == (np.float32(sc), zp), i
+    qs = [O.quantize(p, O.F32, O.UINT8, sc, zp) for p, (sc, zp) in zip(parts, params)]
+    for i in range(3):
+        assert int(out[6 + i], 16) == _fnv1a(qs[i].tobytes()), i
+    back = O.dequantize(qs[0], O.UINT8, O.F32, n, *params[0])
+    acc = back[:half].copy()
+    acc = O.dequantize(qs[1], O.UINT8, O.F32, half, params[1][0], params[1][1], O.ADD, out=acc)
+    acc = O.dequantize(qs[2], O.UINT8, O.F32, half, params[2][0], params[2][1], O.ADD, out=acc)
+    back[:half] = acc
+    assert int(out[9], 16) == _fnv1a(back.tobytes())
