@@ -121,6 +121,29 @@ public:
                                   zero_point, mode, op);
     }
 
+    // ---- additive, GPU only (piquant_hip.h): spans over DEVICE memory, work enqueued on the stream given to set_stream ----------
+    void set_stream(void* hip_stream) const { piquant_hip_set_stream(handle_, hip_stream); }
+    void set_blocking(bool blocking) const { piquant_hip_set_blocking(handle_, blocking ? 1 : 0); }
+
+    // compute_quant_config_from_data + quantize as one call; (scale, zero_point) stay in *device_params (a 16-byte record in device
+    // memory) for dequantize_with / the receiving side.  One kernel launch that reads the tensor once when it fits on the chip.
+    void quantize_dynamic(std::span<const std::byte> in, dtype dtype_in, std::span<std::byte> out, dtype dtype_out, piquant_hip_params_t* device_params,
+                          round_mode mode) const {
+        const std::size_t n = elements_of(in.size(), dtype_in, "quantize_dynamic");
+        expect(out.size() == storage_bytes(n, dtype_out), "quantize_dynamic: output span has %zu byte(s), %zu needed for %zu element(s)", out.size(),
+               storage_bytes(n, dtype_out), n);
+        piquant_hip_quantize_dynamic(handle_, in.data(), c(dtype_in), out.data(), c(dtype_out), n, device_params, static_cast<piquant_round_mode_t>(mode));
+    }
+
+    // dequantize with the parameters read from a device record
+    void dequantize_with(std::span<const std::byte> in, dtype dtype_in, std::span<std::byte> out, dtype dtype_out, const piquant_hip_params_t* device_params,
+                         reduce_op op) const {
+        const std::size_t n = elements_of(out.size(), dtype_out, "dequantize_with");
+        expect(in.size() == storage_bytes(n, dtype_in), "dequantize_with: input span has %zu byte(s), %zu needed for %zu element(s)", in.size(),
+               storage_bytes(n, dtype_in), n);
+        piquant_hip_dequantize_dp(handle_, in.data(), c(dtype_in), out.data(), c(dtype_out), n, device_params, static_cast<piquant_reduce_op_t>(op));
+    }
+
     [[nodiscard]] std::pair<fp32_t, std::int64_t> compute_quant_config_from_data(std::span<const fp32_t> x, dtype quant_dst_dtype) const {
         fp32_t scale {};
         std::int64_t zp {};

@@ -1,7 +1,7 @@
 // A C++ process with its own HIP runtime (no Python, no PyTorch) driving the GPU-side extras of libpiquant.so on device buffers
 // and its own stream: parameters + quantize in one call (piquant_hip_quantize_dynamic), the batched form, dequantize from the
 // device-resident record, dequantize_sum.  Prints checksums that tests/test_c_client.py compares with the oracle.
-//   g++ -std=c++17 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude tests/hip_client.cpp -L<libdir> -lpiquant -L/opt/rocm/lib -lamdhip64
+//   g++ -std=c++20 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude tests/hip_client.cpp -L<libdir> -lpiquant -L/opt/rocm/lib -lamdhip64
 #include <hip/hip_runtime_api.h>
 
 #include <cstdint>
@@ -9,8 +9,7 @@
 #include <cstdlib>
 #include <vector>
 
-#include "piquant.h"
-#include "piquant_hip.h"
+#include "piquant.hpp"   // the C++ layer (spans) over piquant.h / piquant_hip.h
 
 #define CK(x)                                                                            \
     do {                                                                                 \
@@ -49,12 +48,16 @@ int main(int argc, char** argv) {
     CK(hipMalloc(reinterpret_cast<void**>(&d_rec), 3 * sizeof(piquant_hip_params_t)));
     CK(hipMemcpyAsync(d_x, x.data(), n * 4, hipMemcpyHostToDevice, stream));
 
-    piquant_context_t* ctx = piquant_context_create(0);
-    piquant_hip_set_stream(ctx, stream);
-    piquant_hip_set_blocking(ctx, 0);
-    // whole tensor: parameters + quantize in one launch, then back through the device record
-    piquant_hip_quantize_dynamic(ctx, d_x, PIQUANT_DTYPE_F32, d_q, PIQUANT_DTYPE_UINT8, n, d_rec, PIQUANT_NEAREST);
-    piquant_hip_dequantize_dp(ctx, d_q, PIQUANT_DTYPE_UINT8, d_back, PIQUANT_DTYPE_F32, n, d_rec, PIQUANT_REDUCE_OP_SET);
+    piquant::context cx;
+    piquant_context_t* ctx = cx.native();
+    cx.set_stream(stream);
+    cx.set_blocking(false);
+    // whole tensor through the C++ layer (spans over device memory): parameters + quantize in one launch, then back through the
+    // device record
+    cx.quantize_dynamic(std::span<const std::byte>(reinterpret_cast<const std::byte*>(d_x), n * 4), piquant::dtype::f32,
+                        std::span<std::byte>(reinterpret_cast<std::byte*>(d_q), n), piquant::dtype::uint8, d_rec, piquant::round_mode::nearest);
+    cx.dequantize_with(std::span<const std::byte>(reinterpret_cast<const std::byte*>(d_q), n), piquant::dtype::uint8,
+                       std::span<std::byte>(reinterpret_cast<std::byte*>(d_back), n * 4), piquant::dtype::f32, d_rec, piquant::reduce_op::set);
     // two halves as a batch (own parameters each), then both halves summed onto the first half of `back`
     const size_t half = (n / 2) & ~static_cast<size_t>(3);
     const void* ins[2] = {d_x, d_x + half};
@@ -79,6 +82,5 @@ int main(int argc, char** argv) {
                 static_cast<double>(rec[2].scale), static_cast<long long>(rec[2].zero_point), static_cast<unsigned long long>(fnv1a(q.data(), n)),
                 static_cast<unsigned long long>(fnv1a(qa.data(), half)), static_cast<unsigned long long>(fnv1a(qb.data(), half)),
                 static_cast<unsigned long long>(fnv1a(back.data(), n * 4)), half);
-    piquant_context_destroy(ctx);
     return 0;
 }

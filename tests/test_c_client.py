@@ -73,7 +73,7 @@ def test_c_client_results_match_oracle(tmp_path, oracle_mod, client):
 
 def _build_hip_client(tmp_path):
     exe = tmp_path / "hip_client"
-    subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-O2", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", f"-I{ROOT / 'include'}",
+    subprocess.run(["g++", "-std=c++20", "-Wall", "-Wextra", "-O2", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", f"-I{ROOT / 'include'}",
                     str(ROOT / "tests" / "hip_client.cpp"), f"-L{LIBDIR}", "-lpiquant", "-L/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{LIBDIR}",
                     "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
     return exe
