@@ -60,8 +60,8 @@ def time_loop(fn, steps, stream):
     e1.record(stream)
     while not e1.query():      # busy-wait for the last step: a sleeping hipDeviceSynchronize wakes up tens of microseconds late,
         pass                   # which is visible when K is small (20 steps are 440 us of work)
+    t1 = time.perf_counter()   # every timed step ran on `stream` before e1: the work is complete here
     torch.cuda.synchronize()
-    t1 = time.perf_counter()
     return t1 - t0, e0.elapsed_time(e1) * 1e-3
 
 
