@@ -38,7 +38,7 @@ def main():
     plain.set_fusion(False)
     t_end = time.time() + args.seconds
     it = elems = bad = 0
-    kinds = {"quantize": 0, "dequantize": 0, "requantize": 0, "dynamic": 0, "dequantize_sum": 0}
+    kinds = {"quantize": 0, "dequantize": 0, "requantize": 0, "dynamic": 0, "dequantize_sum": 0, "batch": 0}
     tq = {4: torch.quint8, 3: torch.quint4x2, 2: torch.quint2x4}
     while time.time() < t_end:
         it += 1
@@ -97,6 +97,22 @@ def main():
                 bad += int(not same_floats(got_acc, want_acc))
                 kinds["dequantize_sum"] += 1
                 elems += K * n
+        if not wild and it % 7 == 0:   # several tensors per launch, then back
+            sizes = [int(rng.integers(1, 400_000)) for _ in range(int(rng.integers(2, 20)))]
+            parts = [rng.uniform(-1 - i, 1.5 + i, m).astype(np.float32) for i, m in enumerate(sizes)]
+            pin = [a if dt_f == 0 else O.f32_to_bf16(a) for a in parts]
+            fdt = torch.float32 if dt_f == 0 else torch.bfloat16
+            pd = [torch.from_numpy(a).cuda() if dt_f == 0 else torch.from_numpy(a.view(np.int16)).cuda().view(torch.bfloat16) for a in pin]
+            qs_b, recs_b = pt.quantize_dynamic_batch(pd, dtype=tq[dt_q], ctx=ctx)
+            outs_b = pt.dequantize_dynamic_batch(qs_b, recs_b, dtype=fdt, ctx=ctx)
+            for a, qq, rr, oo in zip(pin, qs_b, recs_b, outs_b):
+                wp = O.compute_quant_params(a, dt_f, dt_q)
+                wq = O.quantize(a, dt_f, dt_q, wp[0], wp[1])
+                go = oo.cpu().numpy() if dt_f == 0 else oo.view(torch.int16).cpu().numpy().view(np.uint16)
+                bad += int(pt.params_to_host(rr) != wp or not np.array_equal(pt.packed_bytes(qq).cpu().numpy(), wq)
+                           or not same_floats(go, O.dequantize(wq, dt_q, dt_f, a.size, wp[0], wp[1])))
+                elems += 2 * a.size
+            kinds["batch"] += len(sizes)
     print(json.dumps({"seconds": args.seconds, "seed": args.seed, "iterations": it, "checks": kinds, "elements_compared": elems, "mismatching_checks": bad,
                       "device": torch.cuda.get_device_name(0)}))
     sys.exit(1 if bad else 0)
