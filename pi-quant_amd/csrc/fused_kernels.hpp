@@ -71,7 +71,10 @@ struct FusedGroups {
 // add, the copysign, one v_med3_f32 and one v_cvt_i32_f32 give the signed offset t = q - zp; the fields are then assembled
 // by Horner steps w = (w << BITS) + t (v_lshl_add_u32, negative t borrow from the field above and the borrow is repaid
 // exactly when zp is added to every field at once): 4 integer instructions per four elements instead of 4 adds + 3 packs.
-template <int DT_IN, int BITS>
+// GENERIC selects the rounding of the reference's generic nearest step (std::round, quantize.inl:21-26 -- the only form fp32 ->
+// uint2 has) instead of the SIMD bodies' trunc(p + copysign(0.5, p)); under the same range condition its int64 arithmetic
+// gives the same integers as the clamp in the float domain, and a NaN again ends at the lower bound, i.e. 0.
+template <int DT_IN, int BITS, bool GENERIC = false>
 __device__ __forceinline__ void quantize_vec_bounded(const u32x4& raw, float inv_scale, const BoundedStep& b,
                                                      uint32_t (&w)[(InVec<DT_IN>::EPV * BITS / 8) > 4 ? 2 : 1]) {
 #pragma clang fp contract(off)
@@ -83,8 +86,13 @@ __device__ __forceinline__ void quantize_vec_bounded(const u32x4& raw, float inv
     for (int e = 0; e < EPV; e += 2) {
         const f32x2 x = {v[e], v[e + 1]};
         const f32x2 prod = x * inv_scale;
-        const f32x2 half = {__builtin_copysignf(0.5f, prod[0]), __builtin_copysignf(0.5f, prod[1])};
-        const f32x2 adj = prod + half;
+        f32x2 adj;
+        if constexpr (GENERIC) {
+            adj = f32x2 {roundf(prod[0]), roundf(prod[1])};
+        } else {
+            const f32x2 half = {__builtin_copysignf(0.5f, prod[0]), __builtin_copysignf(0.5f, prod[1])};
+            adj = prod + half;
+        }
         t[e] = quant_nearest_bounded_offset(adj[0], b);
         t[e + 1] = quant_nearest_bounded_offset(adj[1], b);
     }
@@ -318,7 +326,7 @@ fused_params_quantize_kernel(FusedGroups groups, QuantParams p_arg, FusedState* 
         auto one = [&](const u32x4& raw, int64_t v) {
             if (FULL || v < n_vec) {
                 uint32_t w[WORDS];
-                if constexpr (BOUNDED) quantize_vec_bounded<DT_IN, BITS>(raw, p.inv_scale, bstep, w);
+                if constexpr (BOUNDED) quantize_vec_bounded<DT_IN, BITS, MODE == RM_NEAREST_I64>(raw, p.inv_scale, bstep, w);
                 else quantize_vec<DT_IN, BITS, MODE>(raw, p, keys, static_cast<uint64_t>(v) * EPV, w);
                 store_packed<OB, ST_POLICY>(out + v * OB, w);
             }
@@ -346,7 +354,7 @@ fused_params_quantize_kernel(FusedGroups groups, QuantParams p_arg, FusedState* 
                 const int64_t v = v_first + (k0 + j) * round_vecs;
                 if (k0 + j < rounds_total && v < n_vec) {
                     uint32_t w[WORDS];
-                    if constexpr (BOUNDED) quantize_vec_bounded<DT_IN, BITS>(t[j], p.inv_scale, bstep, w);
+                    if constexpr (BOUNDED) quantize_vec_bounded<DT_IN, BITS, MODE == RM_NEAREST_I64>(t[j], p.inv_scale, bstep, w);
                     else quantize_vec<DT_IN, BITS, MODE>(t[j], p, keys, static_cast<uint64_t>(v) * EPV, w);
                     store_packed<OB, ST_POLICY>(out + v * OB, w);
                 }
@@ -354,7 +362,7 @@ fused_params_quantize_kernel(FusedGroups groups, QuantParams p_arg, FusedState* 
         }
     };
     // grid-uniform: the data range decides whether the short step is exact for every element of this call
-    if (MODE == RM_NEAREST_FAST && bounded_ok) {
+    if ((MODE == RM_NEAREST_FAST || MODE == RM_NEAREST_I64) && bounded_ok) {
         if (full_share) emit(std::true_type {}, std::true_type {});
         else emit(std::true_type {}, std::false_type {});
     } else {
