@@ -129,7 +129,7 @@ __device__ __forceinline__ void minmax_vec(const u32x4& raw, bool valid, float& 
 // per wave instruction.  (Interleaving the blocks' rounds across the whole tensor instead -- every block touching a new
 // 2 MiB-strided 8 KiB piece per round, ~46 of them in flight per wave -- measured 2.9 TB/s in the load phase and a 2x
 // spread between the fastest and the slowest block: tens of thousands of concurrent 1 KiB streams leave no DRAM locality.)
-template <int DT_IN, int BITS, int MODE, int R_REG, int R_LDS, int LDS_BATCH, int BLOCK, int ST_POLICY = ST_WT, bool TIMING = false>
+template <int DT_IN, int BITS, int MODE, int R_REG, int R_LDS, int LDS_BATCH, int BLOCK, int ST_POLICY = ST_WT, bool TIMING = false, int STREAM_BATCH = 4>
 __global__ void __launch_bounds__(BLOCK)
 fused_params_quantize_kernel(FusedGroups groups, QuantParams p_arg, FusedState* states) {
     // Block -> (tensor, block within the tensor's sub-grid).  With one tensor this is the identity.
@@ -143,7 +143,7 @@ fused_params_quantize_kernel(FusedGroups groups, QuantParams p_arg, FusedState* 
     static_assert(R_LDS % LDS_BATCH == 0, "the LDS-resident rounds are loaded in whole batches");
     constexpr int EPV = InVec<DT_IN>::EPV, OB = EPV * BITS / 8, WAVES = BLOCK / 64;
     constexpr int WORDS = OB > 4 ? 2 : 1;
-    constexpr int STREAM_BATCH = 4;   // loads in flight per lane in the streamed rounds (the resident registers stay live next to them)
+    // STREAM_BATCH: loads in flight per lane in the streamed rounds (the resident registers stay live next to them)
     __shared__ u32x4 resident[R_LDS * BLOCK];
     __shared__ float s_lo[WAVES], s_hi[WAVES];
 

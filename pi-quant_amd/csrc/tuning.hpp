@@ -52,8 +52,8 @@ constexpr int kFusedBlock = 1024;
 constexpr int kFusedRegRounds = 18;
 constexpr int kFusedLdsRounds = 9;
 // Tensors up to kFusedMaxRounds rounds per thread (2.4x what the chip holds, 268 MB at 256 CUs) still take the fused kernel:
-// the part that does not fit is streamed twice (4 loads in flight per lane there: more would spill next to the 18 resident
-// vectors).  Measured fp32 -> uint8 against scan + quantize: 43.6 vs 48.8 us at 128 MB, 54.4 vs 60.3 at 164 MB, 73.3 vs 78.4 at
+// the part that does not fit is streamed twice (4 loads in flight per lane there: 2, 6 and 8 measured no better -- 55.8 / 55.9 /
+// 53.8 vs 54.7 us at 164 MB, 78.0 / 74.5 / 77.1 vs 73.6 us at 218 MB -- and 8 spills for bf16 next to the 18 resident vectors).  Measured fp32 -> uint8 against scan + quantize: 43.6 vs 48.8 us at 128 MB, 54.4 vs 60.3 at 164 MB, 73.3 vs 78.4 at
 // 218 MB (-6..-11 %); at 436 MB it is a tie (154 vs 152) and at 872 MB the persistent grid's streaming (5.5 TB/s) loses to the
 // tuned kernels (326 vs 298 us), so larger tensors take the two launches.
 constexpr int kFusedMaxRounds = 64;

@@ -299,17 +299,17 @@ static FusedGroups one_group(const void* in, void* out, int64_t numel, ParamReco
     return g;
 }
 
-template <int R_REG, int R_LDS, int LDS_BATCH, int BLOCK, int STP = ST_WT>
+template <int R_REG, int R_LDS, int LDS_BATCH, int BLOCK, int STP = ST_WT, int SB = 4>
 static void run_fused(const Bufs& b, const FusedBufs& f, int64_t numel, int num_cu, int32_t* slots) {
     const int64_t n_vec = numel / 4;
     char name[128];
-    std::snprintf(name, sizeof name, "f32->u8 fused R_REG=%d R_LDS=%d batch=%d block=%d st=%s", R_REG, R_LDS, LDS_BATCH, BLOCK,
+    std::snprintf(name, sizeof name, "f32->u8 fused R_REG=%d R_LDS=%d batch=%d block=%d stream_batch=%d st=%s", R_REG, R_LDS, LDS_BATCH, BLOCK, SB,
                   STP == ST_WT ? "wt" : (STP == ST_NT ? "nt" : "plain"));
     if (fused_rounds(n_vec, num_cu, BLOCK) > R_REG + R_LDS)
         std::fprintf(stderr, "%s: %lld rounds, %d of them resident\n", name, static_cast<long long>(fused_rounds(n_vec, num_cu, BLOCK)), R_REG + R_LDS);
     QuantParams p {};
     auto launch = [&](int i) {
-        hipLaunchKernelGGL((fused_params_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, R_REG, R_LDS, LDS_BATCH, BLOCK, STP>), dim3(num_cu), dim3(BLOCK), 0,
+        hipLaunchKernelGGL((fused_params_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, R_REG, R_LDS, LDS_BATCH, BLOCK, STP, false, SB>), dim3(num_cu), dim3(BLOCK), 0,
                            g_stream, one_group(b.in[i % SETS], b.out[i % SETS], numel, f.rec, num_cu), p, f.st);
     };
     // correctness first: same bytes and record as scan (with parameter epilogue) -> quantize
@@ -342,7 +342,7 @@ static void run_fused(const Bufs& b, const FusedBufs& f, int64_t numel, int num_
     report("fused", name, us, 5.0 * numel);
     // where block 0 spends its time (100 MHz wall clock): one launch on a quiet device
     CK(hipStreamSynchronize(g_stream));
-    hipLaunchKernelGGL((fused_params_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, R_REG, R_LDS, LDS_BATCH, BLOCK, STP, true>), dim3(num_cu), dim3(BLOCK), 0, g_stream,
+    hipLaunchKernelGGL((fused_params_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, R_REG, R_LDS, LDS_BATCH, BLOCK, STP, true, SB>), dim3(num_cu), dim3(BLOCK), 0, g_stream,
                        one_group(b.in[3], b.out[3], numel, f.rec, num_cu), p, f.st);
     CK(hipStreamSynchronize(g_stream));
     std::vector<uint64_t> t(static_cast<size_t>(num_cu) * 8);
@@ -684,6 +684,13 @@ int main(int argc, char** argv) {
             report("fused", "f32->u8 two launches (scan with parameter epilogue, quantize)", us, 9.0 * numel);
         }
         run_fused<18, 9, 9, 1024>(b, f, numel, num_cu, keys);
+        if (numel > 27264000) {
+            run_fused<18, 9, 9, 1024, ST_WT, 2>(b, f, numel, num_cu, keys);
+            run_fused<18, 9, 9, 1024, ST_WT, 6>(b, f, numel, num_cu, keys);
+            run_fused<18, 9, 9, 1024, ST_WT, 8>(b, f, numel, num_cu, keys);
+            run_fused<14, 9, 9, 1024, ST_WT, 8>(b, f, numel, num_cu, keys);
+            run_fused<12, 9, 9, 1024, ST_WT, 12>(b, f, numel, num_cu, keys);
+        }
         if (numel <= 27264000) {
             run_fused<18, 9, 9, 1024, ST_NT>(b, f, numel, num_cu, keys);
             run_fused<18, 9, 9, 1024, ST_PLAIN>(b, f, numel, num_cu, keys);
