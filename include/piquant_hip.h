@@ -138,6 +138,19 @@ PIQUANT_EXPORT void piquant_hip_dequantize_dp_batch(piquant_context_t* ctx, cons
                                                     const piquant_hip_params_t* const* device_params, size_t count,
                                                     piquant_reduce_op_t op);
 
+/* The owner's step of a mesh all-reduce in one call: out = quantize(acc + dequantize(inputs[0]) + dequantize(inputs[1]) + ...)
+ * with the parameters computed from that sum and left in *device_params.  `inputs` are `count` quantized tensors of type
+ * dtype_out (the type being produced), each with its device record; terms are added in order, the running sum rounded to
+ * dtype_acc after each.  When everything stays on chip (a chunk of an all-reduce always does) this is ONE launch that never
+ * writes the sum to memory; otherwise it is piquant_hip_dequantize_sum into `acc` followed by piquant_hip_quantize_dynamic.
+ * The output bytes and the record are identical either way; the contents of `acc` afterwards are unspecified (unchanged by
+ * the one-launch form, the sum after the two-step form). */
+PIQUANT_EXPORT void piquant_hip_reduce_quantize_dynamic(piquant_context_t* ctx, void* acc, piquant_dtype_t dtype_acc,
+                                                        const void* const* inputs,
+                                                        const piquant_hip_params_t* const* input_params, size_t count, void* out,
+                                                        piquant_dtype_t dtype_out, size_t numel,
+                                                        piquant_hip_params_t* device_params, piquant_round_mode_t mode);
+
 /* out (op)= dequantize(inputs[0]) + dequantize(inputs[1]) + ... : `count` quantized tensors of the same dtype and length, each
  * with its own 16-byte parameter record in device memory, summed into one float tensor in a single pass -- the reduction
  * step of a quantized all-reduce in which a rank receives one chunk from every peer (xGMI is a point-to-point mesh: all

@@ -771,6 +771,53 @@ void piquant_hip_quantize_dynamic_batch(piquant_context_t* ctx, const void* cons
     if (ctx->blocking) wait_stream(ctx->stream);
 }
 
+void piquant_hip_reduce_quantize_dynamic(piquant_context_t* ctx, void* acc, piquant_dtype_t dtype_acc, const void* const* inputs,
+                                         const piquant_hip_params_t* const* input_params, size_t count, void* out, piquant_dtype_t dtype_out, size_t numel,
+                                         piquant_hip_params_t* device_params, piquant_round_mode_t mode) {
+    if (!ctx) panic("piquant_hip_reduce_quantize_dynamic: context is NULL");
+    check_dynamic_types(dtype_acc, dtype_out, mode);
+    if (!device_params) panic("piquant_hip_reduce_quantize_dynamic: NULL parameter record");
+    if (numel == 0 || count == 0) {   // nothing to add (or nothing at all): the plain call
+        piquant_hip_quantize_dynamic(ctx, acc, dtype_acc, out, dtype_out, numel, device_params, mode);
+        return;
+    }
+    if (!acc || !out || !inputs || !input_params) panic("piquant_hip_reduce_quantize_dynamic: NULL argument");
+    bool fused = false;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        DeviceGuard guard(ctx->device);
+        const Resolved rp = resolve(device_params), racc = ctx->resolve_ptr(acc), rout = ctx->resolve_ptr(out);
+        if (rp.pageable || racc.pageable || rout.pageable) panic("piquant_hip_reduce_quantize_dynamic needs device (or pinned) buffers");
+        if (ctx->fusion && !ctx->reference_layout && count <= static_cast<size_t>(kDequantSumMaxInputs)) {
+            QuantLaunch q {};
+            q.in = racc.dev;
+            q.out = rout.dev;
+            q.numel = static_cast<int64_t>(numel);
+            q.dt_in = dtype_acc;
+            q.dt_out = dtype_out;
+            fill_round_mode(ctx, q, mode);
+            DequantSumLaunch terms {};
+            terms.count = static_cast<int>(count);
+            terms.dt_in = dtype_out;
+            for (size_t i = 0; i < count; ++i) {
+                if (!inputs[i] || !input_params[i]) panic("piquant_hip_reduce_quantize_dynamic: NULL input %zu", i);
+                const Resolved ri = ctx->resolve_ptr(inputs[i]), rq = resolve(input_params[i]);
+                if (ri.pageable || rq.pageable) panic("piquant_hip_reduce_quantize_dynamic needs device (or pinned) buffers");
+                terms.in[i] = ri.dev;
+                terms.params[i] = rq.dev;
+            }
+            const bool record = fused_order_before(ctx->device, ctx->stream);
+            fused = launch_fused_reduce_quantize(q, terms, ctx->d_fused, rp.dev, ctx->stream, ctx->num_cu);
+            if (fused && record) fused_order_after(ctx->device, ctx->stream);
+            if (fused && ctx->blocking) wait_stream(ctx->stream);
+        }
+    }
+    if (fused) return;
+    // the same result in two steps (and with `acc` updated on the way): one-pass sum into acc, then parameters + quantize
+    piquant_hip_dequantize_sum(ctx, inputs, input_params, count, dtype_out, acc, dtype_acc, numel, PIQUANT_REDUCE_OP_ADD);
+    piquant_hip_quantize_dynamic(ctx, acc, dtype_acc, out, dtype_out, numel, device_params, mode);
+}
+
 void piquant_hip_set_fusion(piquant_context_t* ctx, int enabled) {
     if (!ctx) panic("piquant_hip_set_fusion: context is NULL");
     std::lock_guard<std::mutex> lock(ctx->mu);

@@ -36,6 +36,7 @@
 // one is re-armed for the next launch; the last block to arrive resets the counter before it bumps the generation.
 #pragma once
 
+#include "dequant_kernels.hpp"
 #include "minmax_kernels.hpp"
 
 #include <type_traits>
@@ -66,6 +67,39 @@ struct FusedGroups {
     int count;
     int blocks_per_group;
 };
+
+// REDUCE variant (one tensor per launch): the values that are scanned and quantized are not `in` itself but
+//     in + dequantize(red.in[0]) + dequantize(red.in[1]) + ...     (terms added in this order, each with its own device record,
+//                                                                    the running sum rounded to in's type after every term)
+// -- the owner's step of a mesh all-reduce: add the chunks received from the peers to the own values and quantize the sum for
+// the all-gather, without writing the sum to memory and reading it back.  Identical to dequantize_sum_kernel (ADD) followed by
+// this kernel without the terms.  The host uses it only when the whole tensor stays on chip and numel is a whole number of
+// 16-byte vectors.
+struct FusedReduce {
+    const uint8_t* in[kDequantSumMax];
+    const ParamRecord* params[kDequantSumMax];
+    int count;
+};
+
+template <int DT_IN, int RED_BITS>
+__device__ __forceinline__ void add_reduce_terms(u32x4& raw, int64_t v, const FusedReduce& red) {
+    constexpr int EPV = InVec<DT_IN>::EPV, IB = EPV * RED_BITS / 8;
+    float acc[EPV];
+    InVec<DT_IN>::unpack(raw, acc);
+    for (int i = 0; i < red.count; ++i) {
+        DequantParams p {};
+        p.dyn = red.params[i];
+        p = resolved(p);
+        dequant_sum_term<RED_BITS, DT_IN>(red.in[i] + v * IB, p, acc, false);
+    }
+    if constexpr (DT_IN == DT_F32) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) raw[e] = __float_as_uint(acc[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) raw[e] = f32x2_to_bf16x2_bits(acc[2 * e], acc[2 * e + 1]);   // already bf16 values: exact
+    }
+}
 
 // The nearest step for a call whose data range is known (device_math.hpp, BoundedStep): per element a packed multiply and
 // add, the copysign, one v_med3_f32 and one v_cvt_i32_f32 give the signed offset t = q - zp; the fields are then assembled
@@ -129,9 +163,10 @@ __device__ __forceinline__ void minmax_vec(const u32x4& raw, bool valid, float& 
 // per wave instruction.  (Interleaving the blocks' rounds across the whole tensor instead -- every block touching a new
 // 2 MiB-strided 8 KiB piece per round, ~46 of them in flight per wave -- measured 2.9 TB/s in the load phase and a 2x
 // spread between the fastest and the slowest block: tens of thousands of concurrent 1 KiB streams leave no DRAM locality.)
-template <int DT_IN, int BITS, int MODE, int R_REG, int R_LDS, int LDS_BATCH, int BLOCK, int ST_POLICY = ST_WT, bool TIMING = false, int STREAM_BATCH = 4>
+template <int DT_IN, int BITS, int MODE, int R_REG, int R_LDS, int LDS_BATCH, int BLOCK, int ST_POLICY = ST_WT, bool TIMING = false, int STREAM_BATCH = 4,
+          int RED_BITS = 0>
 __global__ void __launch_bounds__(BLOCK)
-fused_params_quantize_kernel(FusedGroups groups, QuantParams p_arg, FusedState* states) {
+fused_params_quantize_kernel(FusedGroups groups, QuantParams p_arg, FusedState* states, FusedReduce red) {
     // Block -> (tensor, block within the tensor's sub-grid).  With one tensor this is the identity.
     const int group = static_cast<int>(blockIdx.x) / groups.blocks_per_group;
     const uint32_t block = blockIdx.x - static_cast<uint32_t>(group) * groups.blocks_per_group;
@@ -195,13 +230,15 @@ fused_params_quantize_kernel(FusedGroups groups, QuantParams p_arg, FusedState* 
 #pragma unroll
             for (int j = 0; j < LDS_BATCH; ++j) {
                 const int64_t v = v_first + (R_REG + j0 + j) * round_vecs;
+                if constexpr (RED_BITS != 0) add_reduce_terms<DT_IN, RED_BITS>(t[j], v < n_vec ? v : v_last, red);
                 minmax_vec<DT_IN>(t[j], v < n_vec, lo, hi);
                 resident[(j0 + j) * BLOCK + tid] = t[j];
             }
         }
-        // rounds that do not fit on chip: min/max only, LDS_BATCH loads in flight per lane
+        // rounds that do not fit on chip: min/max only, STREAM_BATCH loads in flight per lane (never with reduce terms: the host
+        // sends only fully resident tensors to that variant)
 #pragma unroll 1
-        for (int64_t k0 = R_REG + R_LDS; k0 < rounds_total; k0 += STREAM_BATCH) {
+        for (int64_t k0 = R_REG + R_LDS; RED_BITS == 0 && k0 < rounds_total; k0 += STREAM_BATCH) {
             u32x4 t[STREAM_BATCH];
 #pragma unroll
             for (int j = 0; j < STREAM_BATCH; ++j) {
@@ -216,7 +253,11 @@ fused_params_quantize_kernel(FusedGroups groups, QuantParams p_arg, FusedState* 
         }
 #pragma unroll
         for (int k = 0; k < R_REG; ++k) {
-            if (k < rounds) minmax_vec<DT_IN>(r[k], v_first + k * round_vecs < n_vec, lo, hi);
+            if (k < rounds) {
+                const int64_t v = v_first + k * round_vecs;
+                if constexpr (RED_BITS != 0) add_reduce_terms<DT_IN, RED_BITS>(r[k], v < n_vec ? v : v_last, red);
+                minmax_vec<DT_IN>(r[k], v < n_vec, lo, hi);
+            }
         }
     }
     if (block == 0 && tid < numel - n_vec * EPV) {   // the numel % EPV scalar elements
@@ -342,7 +383,7 @@ fused_params_quantize_kernel(FusedGroups groups, QuantParams p_arg, FusedState* 
         }
         // streamed rounds: second read
 #pragma unroll 1
-        for (int64_t k0 = R_REG + R_LDS; k0 < rounds_total; k0 += STREAM_BATCH) {
+        for (int64_t k0 = R_REG + R_LDS; RED_BITS == 0 && k0 < rounds_total; k0 += STREAM_BATCH) {
             u32x4 t[STREAM_BATCH];
 #pragma unroll
             for (int j = 0; j < STREAM_BATCH; ++j) {

@@ -153,31 +153,36 @@ void launch_quantize(const QuantLaunch& q, hipStream_t stream, int num_cu) {
 namespace {
 
 template <int DT_IN, int BITS, int MODE>
-void fused_launch(const FusedGroups& g, const QuantParams& p, FusedState* states, hipStream_t stream) {
-    hipLaunchKernelGGL((fused_params_quantize_kernel<DT_IN, BITS, MODE, kFusedRegRounds, kFusedLdsRounds, kFusedLdsRounds, kFusedBlock>),
-                       dim3(static_cast<unsigned>(g.count * g.blocks_per_group)), dim3(kFusedBlock), 0, stream, g, p, states);
+void fused_launch(const FusedGroups& g, const QuantParams& p, FusedState* states, const FusedReduce* red, hipStream_t stream) {
+    const dim3 grid(static_cast<unsigned>(g.count * g.blocks_per_group));
+    if (red == nullptr)
+        hipLaunchKernelGGL((fused_params_quantize_kernel<DT_IN, BITS, MODE, kFusedRegRounds, kFusedLdsRounds, kFusedLdsRounds, kFusedBlock>), grid,
+                           dim3(kFusedBlock), 0, stream, g, p, states, FusedReduce {});
+    else   // the terms to add have the quantized type this call produces (chunks of one all-reduce)
+        hipLaunchKernelGGL((fused_params_quantize_kernel<DT_IN, BITS, MODE, kFusedReduceRegRounds, kFusedLdsRounds, kFusedLdsRounds, kFusedBlock, ST_WT, false, 4, BITS>),
+                           grid, dim3(kFusedBlock), 0, stream, g, p, states, *red);
 }
 
 template <int DT_IN, int BITS>
-void fused_mode(int round_mode, const FusedGroups& g, const QuantParams& p, FusedState* states, hipStream_t stream) {
+void fused_mode(int round_mode, const FusedGroups& g, const QuantParams& p, FusedState* states, const FusedReduce* red, hipStream_t stream) {
     switch (round_mode) {
         case RM_NEAREST_FAST:
             // fp32 -> uint2 has no SIMD fast path in the reference: generic int64 step everywhere, as in launch_quantize
-            if constexpr (DT_IN == DT_F32 && BITS == 2) fused_launch<DT_IN, BITS, RM_NEAREST_I64>(g, p, states, stream);
-            else fused_launch<DT_IN, BITS, RM_NEAREST_FAST>(g, p, states, stream);
+            if constexpr (DT_IN == DT_F32 && BITS == 2) fused_launch<DT_IN, BITS, RM_NEAREST_I64>(g, p, states, red, stream);
+            else fused_launch<DT_IN, BITS, RM_NEAREST_FAST>(g, p, states, red, stream);
             return;
-        case RM_STOCH_CALL: fused_launch<DT_IN, BITS, RM_STOCH_CALL>(g, p, states, stream); return;
-        case RM_STOCH_ELEM: fused_launch<DT_IN, BITS, RM_STOCH_ELEM>(g, p, states, stream); return;
+        case RM_STOCH_CALL: fused_launch<DT_IN, BITS, RM_STOCH_CALL>(g, p, states, red, stream); return;
+        case RM_STOCH_ELEM: fused_launch<DT_IN, BITS, RM_STOCH_ELEM>(g, p, states, red, stream); return;
         default: panic("invalid round mode %d", round_mode);
     }
 }
 
 template <int DT_IN>
-void fused_bits(int dt_out, int round_mode, const FusedGroups& g, const QuantParams& p, FusedState* states, hipStream_t stream) {
+void fused_bits(int dt_out, int round_mode, const FusedGroups& g, const QuantParams& p, FusedState* states, const FusedReduce* red, hipStream_t stream) {
     switch (dt_out) {
-        case DT_UINT8: fused_mode<DT_IN, 8>(round_mode, g, p, states, stream); return;
-        case DT_UINT4: fused_mode<DT_IN, 4>(round_mode, g, p, states, stream); return;
-        case DT_UINT2: fused_mode<DT_IN, 2>(round_mode, g, p, states, stream); return;
+        case DT_UINT8: fused_mode<DT_IN, 8>(round_mode, g, p, states, red, stream); return;
+        case DT_UINT4: fused_mode<DT_IN, 4>(round_mode, g, p, states, red, stream); return;
+        case DT_UINT2: fused_mode<DT_IN, 2>(round_mode, g, p, states, red, stream); return;
         default: panic("invalid quantization types: %d -> %d", DT_IN, dt_out);
     }
 }
@@ -240,8 +245,46 @@ bool launch_fused_params_quantize_batch(const QuantLaunch& q, const FusedBatch& 
     p.index_base = q.index_base;
     FusedState* states = static_cast<FusedState*>(state);
     switch (q.dt_in) {
-        case DT_F32: fused_bits<DT_F32>(q.dt_out, q.round_mode, g, p, states, stream); break;
-        default: fused_bits<DT_BF16>(q.dt_out, q.round_mode, g, p, states, stream); break;
+        case DT_F32: fused_bits<DT_F32>(q.dt_out, q.round_mode, g, p, states, nullptr, stream); break;
+        default: fused_bits<DT_BF16>(q.dt_out, q.round_mode, g, p, states, nullptr, stream); break;
+    }
+    PQ_HIP(hipGetLastError());
+    return true;
+}
+
+bool launch_fused_reduce_quantize(const QuantLaunch& q, const DequantSumLaunch& terms, void* state, void* device_param_record, hipStream_t stream,
+                                  int num_cu) {
+    // only what stays on chip entirely, in whole vectors, with terms of the type being produced; everything else: two calls
+    if (q.numel <= 0 || q.ref_layout || !aligned16(q.in) || !aligned16(q.out) || terms.count < 1 || terms.count > kDequantSumMax) return false;
+    if (q.dt_in != DT_F32 && q.dt_in != DT_BF16) panic("invalid quantization types: %d -> %d", q.dt_in, q.dt_out);
+    if (terms.dt_in != q.dt_out) return false;
+    const int epv = q.dt_in == DT_F32 ? 4 : 8;
+    if (q.numel % epv != 0) return false;
+    const int bpg = fused_blocks_per_group(q.numel, q.dt_in, 1, num_cu);
+    if (bpg == 0 || fused_rounds(q.numel / epv, bpg, kFusedBlock) > kFusedReduceRegRounds + kFusedLdsRounds) return false;
+    FusedReduce red {};
+    red.count = terms.count;
+    for (int i = 0; i < terms.count; ++i) {
+        if (!aligned16(terms.in[i])) return false;
+        red.in[i] = static_cast<const uint8_t*>(terms.in[i]);
+        red.params[i] = static_cast<const ParamRecord*>(terms.params[i]);
+    }
+    FusedGroups g {};
+    g.in[0] = q.in;
+    g.out[0] = static_cast<uint8_t*>(q.out);
+    g.numel[0] = q.numel;
+    g.params[0] = static_cast<ParamRecord*>(device_param_record);
+    g.count = 1;
+    g.blocks_per_group = bpg;
+    QuantParams p {};
+    p.threshold = q.threshold;
+    p.seed_lo = static_cast<uint32_t>(q.seed);
+    p.seed_hi = static_cast<uint32_t>(q.seed >> 32);
+    p.index_base = q.index_base;
+    FusedState* states = static_cast<FusedState*>(state);
+    switch (q.dt_in) {
+        case DT_F32: fused_bits<DT_F32>(q.dt_out, q.round_mode, g, p, states, &red, stream); break;
+        default: fused_bits<DT_BF16>(q.dt_out, q.round_mode, g, p, states, &red, stream); break;
     }
     PQ_HIP(hipGetLastError());
     return true;

@@ -134,6 +134,11 @@ struct FusedBatch {
 };
 bool launch_fused_params_quantize_batch(const QuantLaunch& q, const FusedBatch& b, void* state, hipStream_t stream, int num_cu);
 bool fused_launch_applies(const QuantLaunch& q, int num_cu);   // the test launch_fused_params_quantize makes, without launching
+// The same kernel fed with in + sum of dequantized `terms` (dt_in of the terms == q.dt_out; terms.out / terms.op unused): the
+// owner's step of a mesh all-reduce.  false when it does not qualify -- then dequantize_sum into `in` followed by the plain
+// fused call gives the same bytes.  Declared after DequantSumLaunch.
+bool launch_fused_reduce_quantize(const QuantLaunch& q, const DequantSumLaunch& terms, void* state, void* device_param_record, hipStream_t stream,
+                                  int num_cu);
 size_t fused_state_bytes();
 void init_fused_state(void* state, hipStream_t stream);
 

@@ -240,6 +240,16 @@ class Context:
         C.piquant_hip_dequantize_dp_batch(self._ctx, (_C.c_void_p * n)(*ptrs_in), dtype_in.value, (_C.c_void_p * n)(*ptrs_out), dtype_out.value,
                                           (_C.c_size_t * n)(*numels), (_C.c_void_p * n)(*params_ptrs), n, reduce_op.value)
 
+    def reduce_quantize_dynamic_ptr(self, ptr_acc: int, dtype_acc: DataType, ptrs_in, params_in, ptr_out: int, dtype_out: DataType, numel: int,
+                                    params_ptr: int, round_mode: RoundMode, _device_ptrs: bool = False) -> None:
+        """out = quantize(acc + sum_i dequantize(input i)) with parameters from that sum, left in ``params_ptr`` (include/piquant_hip.h,
+        piquant_hip_reduce_quantize_dynamic); the inputs have type ``dtype_out``.  ``acc`` is unspecified afterwards."""
+        assert dtype_acc.is_dequantized and dtype_out.is_quantized and len(ptrs_in) == len(params_in) and params_ptr != 0
+        n = len(ptrs_in)
+        self.assume_device_pointers(_device_ptrs)
+        C.piquant_hip_reduce_quantize_dynamic(self._ctx, ptr_acc, dtype_acc.value, (_C.c_void_p * max(n, 1))(*ptrs_in), (_C.c_void_p * max(n, 1))(*params_in), n,
+                                              ptr_out, dtype_out.value, numel, params_ptr, round_mode.value)
+
     def dequantize_sum_ptr(self, ptrs_in, params_ptrs, dtype_in: DataType, ptr_out: int, dtype_out: DataType, numel: int, reduce_op: ReduceOp,
                            _device_ptrs: bool = False) -> None:
         """out (op)= sum of dequantize(input i) over several quantized buffers, each with its own device parameter record, in one

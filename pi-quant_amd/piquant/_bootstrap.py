@@ -40,6 +40,7 @@ _DECLS = [
     ('piquant_hip_set_fusion', None, [_vp, _int]),
     ('piquant_hip_quantize_dynamic_batch', None, [_vp, C.POINTER(C.c_void_p), _int, C.POINTER(C.c_void_p), _int, C.POINTER(_sz), C.POINTER(C.c_void_p), _sz, _int]),
     ('piquant_hip_dequantize_dp_batch', None, [_vp, C.POINTER(C.c_void_p), _int, C.POINTER(C.c_void_p), _int, C.POINTER(_sz), C.POINTER(C.c_void_p), _sz, _int]),
+    ('piquant_hip_reduce_quantize_dynamic', None, [_vp, _vp, _int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _sz, _vp, _int, _sz, _vp, _int]),
     ('piquant_hip_dequantize_sum', None, [_vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _sz, _int, _vp, _int, _sz, _int]),
     ('piquant_hip_dequantize_dp', None, [_vp, _vp, _int, _vp, _int, _sz, _vp, _int]),
     ('piquant_hip_compute_quant_params_dist', None, [_vp, _vp, _int, _sz, _int, _vp, C.POINTER(_f32), C.POINTER(_i64)]),

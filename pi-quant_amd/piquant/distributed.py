@@ -105,6 +105,13 @@ class _DeviceOps:
             dequantize_dynamic_batch([b[_HEADER_BYTES:] for b in bufs], [b[:_HEADER_BYTES] for b in bufs], dtype=outs[0].dtype, reduce_op=reduce_op,
                                      ctx=self.ctx, outs=list(outs), quant_dtype=qdtype, shapes=[o.shape for o in outs])
 
+    def reduce_encode(self, bufs, acc: torch.Tensor, buf: torch.Tensor, qdtype: torch.dtype, round_mode: str) -> None:
+        """encode(acc + sum of the wire buffers) into ``buf`` as one call (``acc`` is scratch afterwards)."""
+        from .torch import reduce_quantize_dynamic
+
+        reduce_quantize_dynamic(acc, [b[_HEADER_BYTES:] for b in bufs], [b[:_HEADER_BYTES] for b in bufs], dtype=qdtype, round_mode=round_mode,
+                                ctx=self.ctx, out=buf[_HEADER_BYTES:], out_params=buf[:_HEADER_BYTES])
+
     def decode_sum(self, bufs, out: torch.Tensor, qdtype: torch.dtype) -> None:
         """out += sum of the wire buffers, one pass over ``out`` (same result as decode(..., 'add') buffer by buffer)."""
         from .torch import dequantize_sum
@@ -254,8 +261,9 @@ def quantized_all_reduce_direct(
     1. every rank quantizes chunk j of its tensor for every peer j (parameters from that chunk, 16-byte header + packed bytes;
        all G-1 chunks in ONE kernel launch, ``quantize_dynamic_batch``),
     2. ONE all-to-all delivers them -- G-1 transfers per rank, each on its own link, all at once,
-    3. the owner adds the G-1 received chunks to its own (unquantized) values in a single pass (``dequantize_sum``),
-    4. quantizes the finished chunk once, ONE all-gather distributes it, and every rank (the owner included) stores
+    3. the owner adds the G-1 received chunks to its own (unquantized) values and
+    4. quantizes the finished chunk -- both in ONE launch that keeps the sum on chip (``reduce_quantize_dynamic``); ONE all-gather
+       distributes it, and every rank (the owner included) stores
        ``dequantize(..., 'set')`` of the same bytes (all G chunks in one launch), so all ranks end bit-identical.
 
     Every value is quantized exactly twice whatever the world size (a ring: up to G times), the wire carries the same
@@ -286,14 +294,14 @@ def quantized_all_reduce_direct(
     b_own, e_own = chunks[rank]
     x_own = flat[b_own:e_own]
     n_own = wire_len(rank)
-    if x_own.numel():
-        ops.decode_sum([recv[i * slot: i * slot + n_own] for i in range(world) if i != rank], x_own, quant_dtype)
-
-    # ---- all-gather of the finished chunks ----
+    # ---- the owner's sum, quantized for the all-gather in the same launch (the sum itself is never stored: the final value of the
+    # own chunk, too, comes from decoding the gathered bytes) ----
     mine = torch.zeros(slot, dtype=torch.uint8, device=tensor.device)
     if x_own.numel():
-        ops.encode(x_own, mine[:n_own], quant_dtype, round_mode)
-    _all_gather(mine, recv, group)
+        ops.reduce_encode([recv[i * slot: i * slot + n_own] for i in range(world) if i != rank], x_own, mine[:n_own], quant_dtype, round_mode)
+    gathered = torch.empty(world * slot, dtype=torch.uint8, device=tensor.device)   # not `recv`: the launch above is still reading it
+    _all_gather(mine, gathered, group)
+    recv = gathered
     full = [j for j in range(world) if chunks[j][1] > chunks[j][0]]
     ops.decode_batch([recv[j * slot: j * slot + wire_len(j)] for j in full], [flat[chunks[j][0]:chunks[j][1]] for j in full], quant_dtype, 'set')
     return tensor

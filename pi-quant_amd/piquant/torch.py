@@ -372,3 +372,21 @@ def dequantize_dynamic_batch(tensors, params, *, dtype: torch.dtype, reduce_op: 
     ctx.dequantize_dp_batch_ptr([t.data_ptr() for t in tensors], dtype_in, [o.data_ptr() for o in outs], torch_to_piquant_dtype(dtype), numels,
                                 [p.data_ptr() for p in params], _REDUCE_OPS[reduce_op], _device_ptrs=True)
     return outs
+
+
+def reduce_quantize_dynamic(acc: torch.Tensor, tensors, params, *, dtype: torch.dtype, round_mode: str = 'nearest', ctx: Optional[Context] = None,
+                            out: Optional[torch.Tensor] = None, out_params: Optional[torch.Tensor] = None):
+    """(quantize(acc + sum_i dequantize(tensors[i])), record): the owner's step of a mesh all-reduce as one call -- one kernel launch
+    that never writes the sum to memory when it stays on chip.  ``tensors`` are raw uint8 buffers of packed ``dtype`` values with
+    ``acc.numel()`` elements each, ``params`` their device records.  The contents of ``acc`` afterwards are unspecified."""
+    assert dtype in _QUANT_TYPES and acc.is_cuda and acc.is_contiguous() and acc.dtype in _DEQUANT_TYPES and len(tensors) == len(params)
+    assert all(t.is_cuda and t.is_contiguous() for t in tensors)
+    if out is None:
+        out = torch.empty(acc.shape, dtype=dtype, device=acc.device)
+    if out_params is None:
+        out_params = torch.empty(PARAMS_NBYTES, dtype=torch.uint8, device=acc.device)
+    ctx = _ctx_for(acc, ctx)
+    ctx.reduce_quantize_dynamic_ptr(acc.data_ptr(), torch_to_piquant_dtype(acc.dtype), [t.data_ptr() for t in tensors], [p.data_ptr() for p in params],
+                                    out.data_ptr(), torch_to_piquant_dtype(dtype), acc.numel(), out_params.data_ptr(), _ROUND_MODES[round_mode],
+                                    _device_ptrs=True)
+    return out, out_params

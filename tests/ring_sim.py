@@ -121,3 +121,7 @@ class OracleOps:
     def decode_batch(self, bufs, outs, qdtype, reduce_op):
         for buf, out in zip(bufs, outs):
             self.decode(buf, out, qdtype, reduce_op)
+
+    def reduce_encode(self, bufs, acc, buf, qdtype, round_mode):
+        self.decode_sum(bufs, acc, qdtype)
+        self.encode(acc, buf, qdtype, round_mode)

@@ -1061,3 +1061,46 @@ def test_batched_dynamic_quantize_and_dequantize_equal_single_calls(O):
         assert pt.params_to_host(recs[i]) == (scale, zp)
         assert np.array_equal(pt.packed_bytes(qs[i]).cpu().numpy(), O.quantize(xs[i], 0, 4, scale, zp))
     assert pt.params_to_host(recs[1]) == O.compute_quant_params(xs[1], 0, 4)
+
+
+def test_reduce_quantize_dynamic_equals_sum_then_quantize(O):
+    """piquant_hip_reduce_quantize_dynamic: quantize(acc + sum of dequantized inputs) with parameters from the sum, in one launch that
+    keeps the sum on chip.  Bytes and record must equal dequantize_sum followed by quantize_dynamic (and the oracle) for every dtype
+    pair, rounding mode, 1..7 terms; ragged / oversized tensors take the two-step form and must agree as well."""
+    import piquant
+    import piquant.torch as pt
+    import torch
+
+    rng = np.random.default_rng(1312)
+    ctx = piquant.Context()
+    tq = {4: torch.quint8, 3: torch.quint4x2, 2: torch.quint2x4}
+    checked = 0
+    for n in (8, 4096, 70_000, 3_407_872, 3_407_875, 24_000_000):
+        for dt_f, fdt in ((0, torch.float32), (1, torch.bfloat16)):
+            for dt_q in (4, 3, 2):
+                if n > 5_000_000 and (dt_q != 4 or dt_f != 0):
+                    continue
+                for K in (1, 7) if n >= 3_000_000 else (1, 3):
+                    for rm, tau in ((0, 0.0), (1, 0.28125)):
+                        if rm and (dt_q == 2 or n > 5_000_000):
+                            continue
+                        own = rng.uniform(-2, 2, n).astype(np.float32)
+                        own_in = own if dt_f == 0 else O.f32_to_bf16(own)
+                        terms = [rng.uniform(-1 - i, 1 + 0.5 * i, n).astype(np.float32) for i in range(K)]
+                        qs, recs, want_acc = [], [], own_in.copy()
+                        for t in terms:
+                            q, rec = pt.quantize_dynamic(torch.from_numpy(t).cuda(), dtype=tq[dt_q], ctx=ctx)
+                            qs.append(pt.packed_bytes(q))
+                            recs.append(rec)
+                            s_k, z_k = pt.params_to_host(rec)
+                            want_acc = O.dequantize(qs[-1].cpu().numpy(), dt_q, dt_f, n, s_k, z_k, 1, out=want_acc)
+                        want_p = O.compute_quant_params(want_acc, dt_f, dt_q)
+                        want_q = O.quantize(want_acc, dt_f, dt_q, want_p[0], want_p[1], rm, tau)
+                        acc = torch.from_numpy(own_in).cuda() if dt_f == 0 else torch.from_numpy(own_in.view(np.int16)).cuda().view(torch.bfloat16)
+                        ctx.set_stochastic_threshold(tau if rm else None)
+                        out, rec = pt.reduce_quantize_dynamic(acc, qs, recs, dtype=tq[dt_q], round_mode="stochastic" if rm else "nearest", ctx=ctx)
+                        assert pt.params_to_host(rec) == want_p, (n, dt_f, dt_q, K, rm)
+                        assert np.array_equal(pt.packed_bytes(out).cpu().numpy(), want_q), (n, dt_f, dt_q, K, rm)
+                        checked += 1
+    ctx.set_stochastic_threshold(None)
+    assert checked > 60

@@ -310,7 +310,7 @@ static void run_fused(const Bufs& b, const FusedBufs& f, int64_t numel, int num_
     QuantParams p {};
     auto launch = [&](int i) {
         hipLaunchKernelGGL((fused_params_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, R_REG, R_LDS, LDS_BATCH, BLOCK, STP, false, SB>), dim3(num_cu), dim3(BLOCK), 0,
-                           g_stream, one_group(b.in[i % SETS], b.out[i % SETS], numel, f.rec, num_cu), p, f.st);
+                           g_stream, one_group(b.in[i % SETS], b.out[i % SETS], numel, f.rec, num_cu), p, f.st, FusedReduce {});
     };
     // correctness first: same bytes and record as scan (with parameter epilogue) -> quantize
     CK(hipMemsetAsync(b.out[0], 0x5a, numel, g_stream));
@@ -343,7 +343,7 @@ static void run_fused(const Bufs& b, const FusedBufs& f, int64_t numel, int num_
     // where block 0 spends its time (100 MHz wall clock): one launch on a quiet device
     CK(hipStreamSynchronize(g_stream));
     hipLaunchKernelGGL((fused_params_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, R_REG, R_LDS, LDS_BATCH, BLOCK, STP, true, SB>), dim3(num_cu), dim3(BLOCK), 0, g_stream,
-                       one_group(b.in[3], b.out[3], numel, f.rec, num_cu), p, f.st);
+                       one_group(b.in[3], b.out[3], numel, f.rec, num_cu), p, f.st, FusedReduce {});
     CK(hipStreamSynchronize(g_stream));
     std::vector<uint64_t> t(static_cast<size_t>(num_cu) * 8);
     CK(hipMemcpy(t.data(), f.stamps, t.size() * 8, hipMemcpyDeviceToHost));
