@@ -205,19 +205,25 @@ struct DequantSumArgs {
     int count;
 };
 
-template <int BITS, int DT_OUT>
-__device__ __forceinline__ void dequant_sum_term(const uint8_t* src, const DequantParams& p, float (&acc)[DT_OUT == DT_F32 ? 4 : 8], bool first) {
-    constexpr int EPV = DT_OUT == DT_F32 ? 4 : 8, IB = EPV * BITS / 8, WORDS = IB > 4 ? 2 : 1;
-    constexpr int FORM = DequantForm<BITS, DT_OUT>::value;
-    uint32_t w[WORDS];
+// the packed bytes of one output vector (IB = 1, 2, 4 or 8 of them) as one or two 32-bit words
+template <int IB>
+__device__ __forceinline__ void load_packed(const uint8_t* src, uint32_t (&w)[IB > 4 ? 2 : 1]) {
     if constexpr (IB == 1) w[0] = ld<true>(src);
     else if constexpr (IB == 2) w[0] = ld<true>(reinterpret_cast<const uint16_t*>(src));
     else if constexpr (IB == 4) w[0] = ld<true>(reinterpret_cast<const uint32_t*>(src));
     else {
         const u32x2 t = ld<true>(reinterpret_cast<const u32x2*>(src));
         w[0] = t[0];
-        w[WORDS - 1] = t[1];
+        w[1] = t[1];
     }
+}
+
+// acc = dequantize(w) (first) or acc + dequantize(w), element by element, rounded to the output type
+template <int BITS, int DT_OUT>
+__device__ __forceinline__ void dequant_sum_accumulate(const uint32_t (&w)[((DT_OUT == DT_F32 ? 4 : 8) * BITS / 8) > 4 ? 2 : 1], const DequantParams& p,
+                                                       float (&acc)[DT_OUT == DT_F32 ? 4 : 8], bool first) {
+    constexpr int EPV = DT_OUT == DT_F32 ? 4 : 8;
+    constexpr int FORM = DequantForm<BITS, DT_OUT>::value;
 #pragma unroll
     for (int e = 0; e < EPV; ++e) {
         const uint32_t q = (w[(e * BITS) >> 5] >> ((e * BITS) & 31)) & ((1u << BITS) - 1u);
@@ -226,6 +232,14 @@ __device__ __forceinline__ void dequant_sum_term(const uint8_t* src, const Dequa
         if constexpr (DT_OUT == DT_BF16) a = bf16_bits_to_f32(f32_to_bf16_bits(a));   // what a store to bf16 memory between two calls does
         acc[e] = a;
     }
+}
+
+template <int BITS, int DT_OUT>
+__device__ __forceinline__ void dequant_sum_term(const uint8_t* src, const DequantParams& p, float (&acc)[DT_OUT == DT_F32 ? 4 : 8], bool first) {
+    constexpr int IB = (DT_OUT == DT_F32 ? 4 : 8) * BITS / 8;
+    uint32_t w[IB > 4 ? 2 : 1];
+    load_packed<IB>(src, w);
+    dequant_sum_accumulate<BITS, DT_OUT>(w, p, acc, first);
 }
 
 template <int BITS, int DT_OUT, int OP, int U, int BLOCK>

@@ -84,13 +84,25 @@ struct FusedReduce {
 template <int DT_IN, int RED_BITS>
 __device__ __forceinline__ void add_reduce_terms(u32x4& raw, int64_t v, const FusedReduce& red) {
     constexpr int EPV = InVec<DT_IN>::EPV, IB = EPV * RED_BITS / 8;
+    constexpr int GROUP = 8;   // terms whose loads are in flight together (a thread owns only a few vectors: one load at a time
+                               // would be a chain of memory round trips)
     float acc[EPV];
     InVec<DT_IN>::unpack(raw, acc);
-    for (int i = 0; i < red.count; ++i) {
-        DequantParams p {};
-        p.dyn = red.params[i];
-        p = resolved(p);
-        dequant_sum_term<RED_BITS, DT_IN>(red.in[i] + v * IB, p, acc, false);
+    for (int i0 = 0; i0 < red.count; i0 += GROUP) {
+        uint32_t w[GROUP][IB > 4 ? 2 : 1];
+#pragma unroll
+        for (int j = 0; j < GROUP; ++j) {
+            if (i0 + j < red.count) load_packed<IB>(red.in[i0 + j] + v * IB, w[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < GROUP; ++j) {
+            if (i0 + j < red.count) {
+                DequantParams p {};
+                p.dyn = red.params[i0 + j];
+                p = resolved(p);
+                dequant_sum_accumulate<RED_BITS, DT_IN>(w[j], p, acc, false);
+            }
+        }
     }
     if constexpr (DT_IN == DT_F32) {
 #pragma unroll

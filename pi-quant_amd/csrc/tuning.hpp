@@ -57,7 +57,7 @@ constexpr int kFusedLdsRounds = 9;
 // 218 MB (-6..-11 %); at 436 MB it is a tie (154 vs 152) and at 872 MB the persistent grid's streaming (5.5 TB/s) loses to the
 // tuned kernels (326 vs 298 us), so larger tensors take the two launches.
 constexpr int kFusedMaxRounds = 64;
-constexpr int kFusedReduceRegRounds = 12;   // the reduce variant needs registers for its terms: fewer resident vectors, no spills (81 MB)
+constexpr int kFusedReduceRegRounds = 10;   // the reduce variant needs registers for its terms (8 loads in flight): fewer resident vectors, no spills (80 MB)
 constexpr int kFusedMinRounds = 2;   // grid sizing for small tensors: vectors per thread before another block joins
 
 constexpr int kScalarBlock = 256;   // guarded kernels for misaligned buffers

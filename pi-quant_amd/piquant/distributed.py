@@ -183,8 +183,8 @@ def quantized_all_reduce(
     """In-place SUM all-reduce of a contiguous float32/bfloat16 tensor whose wire format is quantized.
 
     ``algorithm='direct'`` (the default: MI355X's xGMI is a point-to-point mesh) is the schedule of
-    ``quantized_all_reduce_direct`` -- one all-to-all + one all-gather, every value quantized exactly twice, 84 us of kernel
-    time per rank for an 8-way all-reduce of 109 MB against 187 us for the ring.  ``algorithm='ring'`` is the schedule described
+    ``quantized_all_reduce_direct`` -- one all-to-all + one all-gather, every value quantized exactly twice, 79 us of kernel
+    time per rank for an 8-way all-reduce of 109 MB against 188 us for the ring.  ``algorithm='ring'`` is the schedule described
     here, for topologies where one neighbour link is all there is.
 
     Ring reduce-scatter: at every hop a rank quantizes the chunk it forwards with parameters taken from that chunk's

@@ -37,6 +37,7 @@ def main():
         nbytes = [HEADER + piquant.DataType.UINT8.packed_nbytes(e - b) if bits == 8 else HEADER + piquant.DataType.UINT4.packed_nbytes(e - b) for b, e in chunks]
         slot = -(-max(nbytes) // 16) * 16
         bufs = torch.zeros(W * slot, dtype=torch.uint8, device=dev)
+        mine = torch.zeros(slot, dtype=torch.uint8, device=dev)
         for j, (b, e) in enumerate(chunks):          # valid wire content in every slot
             ops.encode(x[b:e], bufs[j * slot: j * slot + nbytes[j]], qdt, "nearest")
 
@@ -53,8 +54,7 @@ def main():
         def direct():
             peers = list(range(1, W))                # one launch quantizes the chunk of every peer
             ops.encode_batch([x[chunks[j][0]:chunks[j][1]] for j in peers], [bufs[j * slot: j * slot + nbytes[j]] for j in peers], qdt, "nearest")
-            ops.decode_sum([bufs[i * slot: i * slot + nbytes[0]] for i in range(1, W)], x[chunks[0][0]:chunks[0][1]], qdt)
-            ops.encode(x[chunks[0][0]:chunks[0][1]], bufs[0: nbytes[0]], qdt, "nearest")
+            ops.reduce_encode([bufs[i * slot: i * slot + nbytes[0]] for i in range(1, W)], x[chunks[0][0]:chunks[0][1]], mine[: nbytes[0]], qdt, "nearest")
             ops.decode_batch([bufs[j * slot: j * slot + nbytes[j]] for j in range(W)], [x[chunks[j][0]:chunks[j][1]] for j in range(W)], qdt, "set")
 
         row = {}
