@@ -42,12 +42,10 @@ def main():
             ops.encode(x[b:e], bufs[j * slot: j * slot + nbytes[j]], qdt, "nearest")
 
         def ring():
-            for step in range(W - 1):                # reduce-scatter hops: encode what is forwarded, add what arrives
-                s, r = (0 - step) % W, (0 - step - 1) % W
-                ops.encode(x[chunks[s][0]:chunks[s][1]], bufs[s * slot: s * slot + nbytes[s]], qdt, "nearest")
-                ops.decode(bufs[r * slot: r * slot + nbytes[r]], x[chunks[r][0]:chunks[r][1]], qdt, "add")
-            o = 1 % W
-            ops.encode(x[chunks[o][0]:chunks[o][1]], bufs[o * slot: o * slot + nbytes[o]], qdt, "nearest")
+            ops.encode(x[chunks[0][0]:chunks[0][1]], bufs[0: nbytes[0]], qdt, "nearest")
+            for step in range(W - 1):                # reduce-scatter hops: add what arrives, forward the re-quantized sum (one launch)
+                r = (0 - step - 1) % W
+                ops.reduce_encode([bufs[r * slot: r * slot + nbytes[r]]], x[chunks[r][0]:chunks[r][1]], mine[: nbytes[r]], qdt, "nearest")
             for j in range(W):                       # all-gather: every chunk decoded once
                 ops.decode(bufs[j * slot: j * slot + nbytes[j]], x[chunks[j][0]:chunks[j][1]], qdt, "set")
 
