@@ -187,10 +187,9 @@ def quantized_all_reduce(
     time per rank for an 8-way all-reduce of 109 MB against 152 us for the ring.  ``algorithm='ring'`` is the schedule described
     here, for topologies where one neighbour link is all there is.
 
-    Ring reduce-scatter: at every hop a rank quantizes the chunk it forwards with parameters taken from that chunk's
-    current partial sum (``compute_quant_params``), sends ``header + packed bytes`` to its successor, and accumulates what it
-    receives with ``dequantize(reduce_op='add')`` -- the ADD store operator's purpose.  The parameters are computed on the
-    device into the 16-byte wire header and consumed from it on the other side, so a hop costs no host round trip.
+    Ring reduce-scatter: at every hop a rank receives ``header + packed bytes`` of a chunk's partial sum from its predecessor, adds
+    them to its own values of that chunk and quantizes the new partial sum -- parameters from the sum itself, computed on the device
+    into the 16-byte wire header -- for its successor: ONE kernel launch per hop (``reduce_quantize_dynamic``) and no host round trip.
     Ring all-gather: the owner of a
     finished chunk quantizes it once; the bytes travel round the ring unchanged and every rank (the owner included)
     stores ``dequantize(..., 'set')`` of the same bytes, so all ranks end bit-identical.  Wire traffic per element is
