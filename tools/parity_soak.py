@@ -38,7 +38,7 @@ def main():
     plain.set_fusion(False)
     t_end = time.time() + args.seconds
     it = elems = bad = 0
-    kinds = {"quantize": 0, "dequantize": 0, "requantize": 0, "dynamic": 0, "dequantize_sum": 0, "batch": 0}
+    kinds = {"quantize": 0, "dequantize": 0, "requantize": 0, "dynamic": 0, "dequantize_sum": 0, "reduce_quantize": 0, "batch": 0}
     tq = {4: torch.quint8, 3: torch.quint4x2, 2: torch.quint2x4}
     while time.time() < t_end:
         it += 1
@@ -97,6 +97,16 @@ def main():
                 bad += int(not same_floats(got_acc, want_acc))
                 kinds["dequantize_sum"] += 1
                 elems += K * n
+                # the same sum re-quantized in one call (parameters from the sum)
+                acc2 = torch.from_numpy(prev).cuda() if dt_f == 0 else torch.from_numpy(prev.view(np.int16)).cuda().view(torch.bfloat16)
+                ctx.set_stochastic_threshold(tau if rm else None)
+                rq, rrec = pt.reduce_quantize_dynamic(acc2, qs, recs, dtype=tq[dt_q], round_mode="stochastic" if rm else "nearest", ctx=ctx)
+                wp = O.compute_quant_params(want_acc, dt_f, dt_q)
+                if wp[0] > 0 and np.isfinite(wp[0]):
+                    bad += int(pt.params_to_host(rrec) != wp or not np.array_equal(pt.packed_bytes(rq).cpu().numpy(),
+                                                                                  O.quantize(want_acc, dt_f, dt_q, wp[0], wp[1], rm, tau)))
+                    kinds["reduce_quantize"] += 1
+                    elems += n
         if not wild and it % 7 == 0:   # several tensors per launch, then back
             sizes = [int(rng.integers(1, 400_000)) for _ in range(int(rng.integers(2, 20)))]
             parts = [rng.uniform(-1 - i, 1.5 + i, m).astype(np.float32) for i, m in enumerate(sizes)]
