@@ -46,6 +46,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline time budget")
+    # test plumbing: exercise the N > 1 control flow on a box with ONE GPU (all ranks on cuda:0, gloo instead of RCCL, which
+    # refuses two ranks on one device); the numbers of such a run mean nothing
+    ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)
+    ap.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -140,9 +144,14 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU: the product has no CPU path"
     use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ      # launched by torch.distributed.run (any N, also N=1)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: for N > 1 launch through torch.distributed.run"
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank if use_dist else 0)
     if use_dist:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     dev = torch.device("cuda", torch.cuda.current_device())
 
     import piquant

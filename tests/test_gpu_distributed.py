@@ -151,3 +151,30 @@ def test_native_rccl_all_reduce_entry_point(oracle_mod):
                 assert got == O.compute_quant_params(x, O.F32, odt), (n, dt)
     finally:
         rccl.ncclCommDestroy(comm)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bench.py's multi-rank control flow (barriers, max over ranks, the sharded config-5 measurement with its collective)
+# on ONE GPU: two ranks share cuda:0 and talk gloo, because RCCL refuses two ranks on one device.  The numbers mean
+# nothing; the run must finish, print exactly one JSON line and get the sharded parameters right.
+# ---------------------------------------------------------------------------------------------------------------
+def test_bench_two_ranks_sharing_the_gpu():
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(root / "bench.py"), "--gpus", "2", "--steps", "50", "--warmup", "5", "--backend", "gloo",
+                        "--share-gpu"], capture_output=True, text=True, timeout=600, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 50 and d["scaling"] == "weak" and d["value"] > 0
+    c5 = d["extras"]["config5_sharded_compute_quant_params"]
+    assert c5["result_correct"] and c5["numel_per_gpu"] == (1 << 30) // 2
