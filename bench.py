@@ -1,14 +1,18 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X-native pi-quant hot path.
 
-Metric (BASELINE.json): GiB/s of fp32 input quantized to uint8 (nearest rounding) at numel = 27 264 000 per
-GPU, plus the fraction of the HBM roofline, on 1/2/4/8 GPUs.
+Metric (BASELINE.json): GiB/s of fp32 input quantized to uint8 (nearest rounding) on ONE 27 264 000-element
+tensor, plus the fraction of the HBM roofline, on 1/2/4/8 GPUs.
 
-A "step" is ONE piquant_quantize call through the C ABI of libpiquant.so (fp32 -> uint8, NEAREST) over one
-27 264 000-element tensor that is already resident in HBM.  Steps rotate over several distinct input/output
-buffer sets (> 256 MiB in total) so that the 256 MiB Infinity Cache cannot serve the reads: the number is an
-HBM number.  Multi-GPU: one process per GPU, every rank quantizes its own tensor (data-parallel gradients;
-quantize needs no collective), so per-GPU work is fixed -> weak scaling; value = all ranks' bytes / max time.
+A "step" is one quantization of that tensor: every rank makes ONE piquant_quantize call through the C ABI of
+libpiquant.so (fp32 -> uint8, NEAREST) over ITS shard of the tensor -- elements shard_range(numel, rank, N), the
+reference's pool split (src/piquant.cpp:145-157) with GPUs in place of threads -- already resident in its HBM.
+quantize needs no collective; (scale, zero_point) are the tensor's global parameters (sharded min/max scan + one 8-byte
+MIN all-reduce, done once before the timed region).  Total work is fixed as N grows -> STRONG scaling;
+value = the tensor's fp32 bytes x K / max-over-ranks time.  At N = 1 the shard is the whole tensor.  Steps rotate over
+several distinct buffer sets (>= 818 MB per GPU at every N) so that the 256 MiB Infinity Cache cannot serve the reads:
+the number is an HBM number.  The weak-scaling variant (every rank its own 27 264 000-element tensor, the data-parallel
+gradient case) is timed separately into extras.weak_scaling_own_tensor_per_gpu for N > 1.
 
 Launch: python bench.py [--gpus 1]            or, for N > 1,
         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -42,7 +46,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--numel", type=int, default=NUMEL)
-    ap.add_argument("--sets", type=int, default=6, help="distinct buffer sets rotated through (6 x 136 MB = 818 MB)")
+    ap.add_argument("--sets", type=int, default=6, help="distinct buffer sets rotated through at N=1 (6 x 136 MB = 818 MB); N>1 keeps the same bytes per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline time budget")
@@ -157,21 +161,33 @@ def main():
     import piquant
     from piquant import DataType, RoundMode
 
-    n = args.numel
+    import piquant.distributed as pqd
+
+    n_total = args.numel
+    # This rank's shard of the ONE logical tensor (the reference's split rule, src/piquant.cpp:145-157, ranks for threads).
+    b0, e0 = pqd.shard_range(n_total, rank, world, 8)
+    n = e0 - b0
     ctx = piquant.Context()
     stream = torch.cuda.Stream()
     ctx.set_stream(stream.cuda_stream)
     ctx.set_blocking(False)
 
-    # synthetic data: x ~ U(-1,1) fp32, seeded per rank and per set
+    # Rotating buffer sets: the same bytes per GPU at every N (818 MB with the default 6 sets at N = 1), so that the 256 MiB
+    # Infinity Cache never holds the working set -- shards shrink with N, the number of sets grows.
+    nsets = args.sets if world == 1 else max(args.sets, -(-args.sets * n_total // max(n, 1)))
+    # synthetic data: logical tensor s is x_s ~ U(-1,1) fp32; a rank generates only its shard of it (seeded per rank and set)
     xs, outs = [], []
-    for s in range(args.sets):
+    for s in range(nsets):
         g = torch.Generator(device=dev)
         g.manual_seed(1000 * rank + s)
         xs.append(torch.empty(n, dtype=torch.float32, device=dev).uniform_(-1.0, 1.0, generator=g))
         outs.append(torch.empty(n, dtype=torch.uint8, device=dev))
     torch.cuda.synchronize()
-    scale, zp = piquant.torch.compute_quant_params(xs[0], dtype=torch.quint8)
+    # global parameters of tensor 0: local scan + ONE 8-byte all_reduce(MIN) + epilogue (identical on every rank); world 1: the plain call
+    if world == 1:
+        scale, zp = piquant.torch.compute_quant_params(xs[0], dtype=torch.quint8)
+    else:
+        scale, zp = pqd.compute_quant_params(xs[0], dtype=torch.quint8)
     torch.cuda.synchronize()
     ctx.set_stream(stream.cuda_stream)
     ctx.set_blocking(False)
@@ -179,15 +195,15 @@ def main():
     xs0_host = xs[0].cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     ptr_in = [t.data_ptr() for t in xs]
     ptr_out = [t.data_ptr() for t in outs]
-    nsets = args.sets
 
     def step(i):
         k = i % nsets
-        ctx.quantize_ptr(ptr_in[k], DataType.F32, ptr_out[k], DataType.UINT8, n, scale, zp, RoundMode.NEAREST)
+        ctx.quantize_ptr(ptr_in[k], DataType.F32, ptr_out[k], DataType.UINT8, n, scale, zp, RoundMode.NEAREST, _device_ptrs=True)
 
+    PREWARM = 2000
     with torch.cuda.stream(stream):
-        for i in range(2000):            # untimed pre-warm (~45 ms) so short K/W runs are not measured on ramping clocks
-            step(i)
+        for i in range(PREWARM):         # untimed pre-warm (~45 ms at N=1) so short K/W runs are not measured on ramping clocks;
+            step(i)                      # reported as config.prewarm_launches
         for i in range(args.warmup):
             step(i)
         torch.cuda.synchronize()
@@ -202,13 +218,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max, ev_max = float(t[0]), float(t[1])
 
-    gib_per_step = n * 4 / 2**30
-    value = world * gib_per_step * args.steps / wall_max
-    kernel_s = ev_max / args.steps                                   # average launch duration from HIP events on the launch stream
-    achieved = ALGO_BYTES_PER_ELEM * n / kernel_s / 1e9
+    gib_per_step = n_total * 4 / 2**30                              # one step quantizes the whole logical tensor (all shards)
+    value = gib_per_step * args.steps / wall_max
+    kernel_s = ev_max / args.steps                                   # average launch duration from HIP events on the launch stream (slowest rank)
+    n_max = -(-n_total // world)                                     # the largest shard
+    achieved = ALGO_BYTES_PER_ELEM * n_max / kernel_s / 1e9          # per-GPU HBM rate of the dominant kernel
 
     result = {
-        "metric": "GiB/s quantize fp32->uint8 (numel=27.26M per GPU, nearest)",
+        "metric": "GiB/s quantize fp32->uint8 (numel=27.26M, nearest)",
         "value": round(value, 2),
         "unit": "GiB/s",
         "n_gpus": world,
@@ -216,26 +233,35 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(wall_max / args.steps * 1e3, 6),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "BASELINE configs[1]: fp32->uint8 nearest-round on MI355X, numel=27264000 per GPU, inputs resident in HBM, "
-                        f"{nsets} rotating buffer sets ({nsets * ALGO_BYTES_PER_ELEM * n / 1e6:.0f} MB) to defeat the 256 MiB Infinity Cache",
-            "numel_per_gpu": n, "round_mode": "nearest", "scale": scale, "zero_point": zp,
-            "api": "piquant_quantize (C ABI, libpiquant.so), stream-ordered", "parallelism": f"dp{world} (independent shards, no collective)",
+            "workload": f"BASELINE configs[1]: fp32->uint8 nearest-round on MI355X, ONE tensor of numel={n_total}" +
+                        (" on one GPU" if world == 1 else f" sharded over {world} GPUs by the reference's range split (src/piquant.cpp:145-157), "
+                                                          f"{n_max} elements per GPU, no collective in the timed region") +
+                        f", inputs resident in HBM, {nsets} rotating buffer sets ({nsets * ALGO_BYTES_PER_ELEM * n / 1e6:.0f} MB per GPU) to defeat the "
+                        "256 MiB Infinity Cache",
+            "numel_total": n_total, "numel_per_gpu": n_max, "round_mode": "nearest", "scale": scale, "zero_point": zp,
+            "api": "piquant_quantize (C ABI, libpiquant.so), stream-ordered, one call per GPU per step",
+            "parallelism": f"dp{world} (one shard of the tensor per GPU, no collective)",
+            "prewarm_launches": PREWARM, "buffer_sets": nsets,
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": None,
-            "kernel": "pq::quantize_kernel<f32,u8,nearest>", "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ELEM * n,
+            "kernel": "pq::quantize_kernel<f32,u8,nearest>", "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ELEM * n_max,
             "avg_launch_us": round(kernel_s * 1e6, 3), "timing": "HIP events on the launch stream around the K timed launches / K",
         },
     }
+    if world > 1:
+        result["roofline"]["scope"] = (f"per GPU: each launch moves {ALGO_BYTES_PER_ELEM * n_max} algorithmic bytes; at {n_max} elements per GPU a launch is "
+                                       "dominated by its fixed ~2.4 us dispatch ramp/drain (DESIGN.md section 4), so the per-GPU fraction falls with N")
+        result["roofline"]["aggregate_GB/s"] = round(ALGO_BYTES_PER_ELEM * n_total / kernel_s / 1e9, 1)
 
     tr = ROOT / "profiles" / "hbm_traffic.json"
-    if tr.exists():
+    if tr.exists() and world == 1 and n_total == NUMEL:      # the PMC passes were taken on the full-size launch
         try:
             rec = json.loads(tr.read_text()).get("quantize_f32_u8")
             if rec:
@@ -250,8 +276,6 @@ def main():
     config5 = None
     if not args.no_extras:
         try:
-            import piquant.distributed as pqd
-
             total5 = 1 << 30
             b5, e5 = pqd.shard_range(total5, rank, world, 8)
             g5 = torch.Generator(device=dev)
@@ -278,7 +302,9 @@ def main():
             want5 = piquant.quant_params_from_minmax(-7.5, 9.25, DataType.UINT8)
             config5 = {"numel_total": total5, "numel_per_gpu": e5 - b5, "ms_per_call": round(float(t5t[0]) * 1e3, 5),
                        "aggregate_GB/s": round(4.0 * total5 / float(t5t[0]) / 1e9, 1), "result": list(got5), "result_correct": tuple(got5) == want5,
-                       "note": "HIP scan of the local shard + one 8-byte all_reduce(MIN) (RCCL) + host epilogue, synchronous per call"}
+                       "note": "HIP scan of the local shard + " + (f"one 8-byte all_reduce(MIN) over {'RCCL' if args.backend == 'nccl' else args.backend} ({world} ranks)"
+                                                                  if world > 1 else "no collective (one rank: the all-reduce is skipped)") +
+                               " + host epilogue, synchronous per call"}
             del shard
             ctx.set_stream(stream.cuda_stream)
             ctx.set_blocking(False)
@@ -287,8 +313,42 @@ def main():
             ctx.set_stream(stream.cuda_stream)
             ctx.set_blocking(False)
 
+    # N > 1: the weak-scaling variant next to the strong-scaling headline -- every rank quantizes its OWN full-size tensor (the
+    # data-parallel gradient case), same protocol; runs on every rank, reported under extras.
+    weak = None
+    if not args.no_extras and world > 1:
+        try:
+            wsets = args.sets
+            wx, wo = [], []
+            for s_ in range(wsets):
+                g = torch.Generator(device=dev)
+                g.manual_seed(500_000 + 1000 * rank + s_)
+                wx.append(torch.empty(n_total, dtype=torch.float32, device=dev).uniform_(-1.0, 1.0, generator=g))
+                wo.append(torch.empty(n_total, dtype=torch.uint8, device=dev))
+            pwi, pwo = [t_.data_ptr() for t_ in wx], [t_.data_ptr() for t_ in wo]
+
+            def wstep(i):
+                ctx.quantize_ptr(pwi[i % wsets], DataType.F32, pwo[i % wsets], DataType.UINT8, n_total, scale, zp, RoundMode.NEAREST, _device_ptrs=True)
+
+            with torch.cuda.stream(stream):
+                for i in range(max(args.warmup, 20)):
+                    wstep(i)
+                torch.cuda.synchronize()
+                dist.barrier()
+                ww, we = time_loop(wstep, args.steps, stream)
+                dist.barrier()
+            wt = torch.tensor([ww, we], dtype=torch.float64, device=dev)
+            dist.all_reduce(wt, op=dist.ReduceOp.MAX)
+            weak = {"scaling": "weak", "numel_per_gpu": n_total, "GiB/s": round(world * gib_per_step * args.steps / float(wt[0]), 2),
+                    "ms_per_step": round(float(wt[0]) / args.steps * 1e3, 6), "avg_launch_us": round(float(wt[1]) / args.steps * 1e6, 3),
+                    "per_gpu_roofline_frac": round(ALGO_BYTES_PER_ELEM * n_total / (float(wt[1]) / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                    "note": "every rank quantizes its own 27 264 000-element tensor (round 1's headline for N > 1); value = all ranks' bytes / max time"}
+            del wx, wo
+        except Exception as exc:
+            weak = {"error": repr(exc)}
+
     if rank == 0 and not args.no_extras and world > 1:
-        result["extras"] = {"config5_sharded_compute_quant_params": config5}
+        result["extras"] = {"config5_sharded_compute_quant_params": config5, "weak_scaling_own_tensor_per_gpu": weak}
     if rank == 0 and not args.no_extras and world == 1:     # the single-GPU side measurements stay out of the multi-rank runs
         extras = {"config5_sharded_compute_quant_params": config5}
         with torch.cuda.stream(stream):

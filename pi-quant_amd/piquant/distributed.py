@@ -19,18 +19,123 @@ from . import Context, DataType, decode_minmax_keys, quant_params_from_minmax
 from .torch import _QUANT_TYPES, _ctx_for, torch_to_piquant_dtype
 
 
-def shard_range(numel: int, rank: int, world_size: int, packed_bits: int = 8) -> Tuple[int, int]:
+def shard_range(numel: int, rank: int, world_size: int, packed_bits: int = 8, align: int = 1) -> Tuple[int, int]:
     """[begin, end) of ``rank``'s shard: the reference's range split (``src/piquant.cpp:145-157``) -- boundaries are
-    aligned down to a whole packed byte (2 elements for uint4, 4 for uint2); the last rank keeps the ragged end."""
+    aligned down to a whole packed byte (2 elements for uint4, 4 for uint2); the last rank keeps the ragged end.
+    ``align`` (1 = the reference rule only; otherwise a multiple of the pack factor, e.g. 4096) aligns interior boundaries down further, so that every shard of ONE
+    shared allocation also starts on a 16-byte vector of both the float and the packed side."""
     world_size = max(1, world_size)
     pack = 8 // packed_bits if packed_bits < 8 else 1
+    if align < 1 or (align != 1 and align % pack != 0):
+        raise ValueError(f'align={align} must be 1 (whole packed bytes only) or a multiple of the pack factor {pack}')
+    unit = max(pack, align)
     begin = numel * rank // world_size
     end = numel * (rank + 1) // world_size
-    if pack > 1:
-        begin -= begin % pack
+    if unit > 1:
+        begin -= begin % unit
         if rank + 1 != world_size:
-            end -= end % pack
+            end -= end % unit
     return begin, max(begin, end)
+
+
+def _rank_world(rank: Optional[int], world_size: Optional[int], group) -> Tuple[int, int]:
+    if rank is None or world_size is None:
+        if not (dist.is_available() and dist.is_initialized()):
+            raise ValueError('rank= and world_size= are required when torch.distributed is not initialised')
+        rank = dist.get_rank(group) if rank is None else rank
+        world_size = dist.get_world_size(group) if world_size is None else world_size
+    if not 0 <= rank < world_size:
+        raise ValueError(f'rank {rank} is outside [0, {world_size})')
+    return rank, world_size
+
+
+def quantize_shard(
+    tensor: torch.Tensor,
+    *,
+    scale: float,
+    zero_point: int,
+    dtype: torch.dtype,
+    round_mode: str = 'nearest',
+    out: Optional[torch.Tensor] = None,
+    rank: Optional[int] = None,
+    world_size: Optional[int] = None,
+    group: Optional[dist.ProcessGroup] = None,
+    align: int = 1,
+    ctx: Optional[Context] = None,
+    _quantize=None,
+) -> Tuple[torch.Tensor, Tuple[int, int]]:
+    """This rank's share of ``quantize(tensor)`` for ONE logical tensor that every rank holds (or addresses): elements
+    ``shard_range(numel, rank, world)`` -- the reference's pool split (``src/piquant.cpp:145-157``) with ranks in place of
+    threads -- are quantized with the caller's (global) ``scale`` / ``zero_point``; no collective.
+
+    Returns ``(packed bytes of the shard, (begin, end))``.  With ``out=`` (a contiguous quantized tensor or raw uint8 buffer
+    for the WHOLE tensor) the bytes are written in place at ``begin * bits / 8`` and the returned tensor is that slice, so
+    the concatenation over ranks is byte for byte what a single ``quantize`` call produces (the kernels are
+    position-independent; tested)."""
+    from .torch import packed_bytes, quantize
+
+    if dtype not in _QUANT_TYPES:
+        raise ValueError(f'Unsupported quantized dtype: {dtype}')
+    if not tensor.is_contiguous():
+        raise ValueError('quantize_shard needs a contiguous tensor: a shard is a range of the flat element order')
+    qdt = torch_to_piquant_dtype(dtype)
+    rank, world_size = _rank_world(rank, world_size, group)
+    flat = tensor.view(-1)
+    begin, end = shard_range(flat.numel(), rank, world_size, qdt.bit_size, align)
+    n_bytes = qdt.packed_nbytes(end - begin)
+    first = begin * qdt.bit_size // 8
+    if out is None:
+        dst = torch.empty(n_bytes, dtype=torch.uint8, device=tensor.device)
+    else:
+        whole = out if out.dtype == torch.uint8 else packed_bytes(out)
+        if whole.device != tensor.device or not whole.is_contiguous() or whole.numel() < qdt.packed_nbytes(flat.numel()):
+            raise ValueError(f'out= must be a contiguous buffer on {tensor.device} holding the whole quantized tensor '
+                             f'({qdt.packed_nbytes(flat.numel())} bytes)')
+        dst = whole.view(-1)[first: first + n_bytes]
+    if end > begin:
+        (_quantize or quantize)(flat[begin:end], scale=scale, zero_point=zero_point, dtype=dtype,
+                                round_mode=round_mode, ctx=ctx, out=dst)
+    return dst, (begin, end)
+
+
+def dequantize_shard(
+    packed: torch.Tensor,
+    *,
+    numel: int,
+    scale: float,
+    zero_point: int,
+    quant_dtype: torch.dtype,
+    out: torch.Tensor,
+    reduce_op: str = 'set',
+    rank: Optional[int] = None,
+    world_size: Optional[int] = None,
+    group: Optional[dist.ProcessGroup] = None,
+    align: int = 1,
+    ctx: Optional[Context] = None,
+    _dequantize=None,
+) -> Tuple[torch.Tensor, Tuple[int, int]]:
+    """This rank's share of ``dequantize``: ``packed`` holds the WHOLE quantized tensor of ``numel`` elements (a quantized
+    torch tensor or its raw uint8 bytes), ``out`` the whole float tensor; elements ``shard_range(numel, rank, world)`` of
+    ``out`` are set (or accumulated into, ``reduce_op='add'``).  Returns ``(out[begin:end] view, (begin, end))``."""
+    from .torch import dequantize, packed_bytes
+
+    if quant_dtype not in _QUANT_TYPES:
+        raise ValueError(f'Unsupported quantized dtype: {quant_dtype}')
+    qdt = torch_to_piquant_dtype(quant_dtype)
+    raw = packed if packed.dtype == torch.uint8 else packed_bytes(packed)
+    if not raw.is_contiguous() or raw.numel() < qdt.packed_nbytes(numel):
+        raise ValueError(f'packed must be contiguous and hold {qdt.packed_nbytes(numel)} bytes for {numel} elements')
+    if not out.is_contiguous() or out.numel() != numel or out.device != raw.device:
+        raise ValueError('out= must be the contiguous float tensor of the whole logical tensor, on the same device')
+    rank, world_size = _rank_world(rank, world_size, group)
+    begin, end = shard_range(numel, rank, world_size, qdt.bit_size, align)
+    dst = out.view(-1)[begin:end]
+    if end > begin:
+        first = begin * qdt.bit_size // 8
+        src = raw.view(-1)[first: first + qdt.packed_nbytes(end - begin)]
+        (_dequantize or dequantize)(src, scale=scale, zero_point=zero_point, dtype=out.dtype, reduce_op=reduce_op, ctx=ctx, out=dst,
+                                    quant_dtype=quant_dtype, shape=(end - begin,))
+    return dst, (begin, end)
 
 
 def local_minmax_keys(tensor: torch.Tensor, ctx: Optional[Context] = None) -> torch.Tensor:

@@ -93,6 +93,72 @@ def test_shard_range_is_the_reference_split(oracle_mod):
                 assert end_prev == n or n == 0
 
 
+def test_shard_range_alignment_option():
+    import piquant.distributed as D
+
+    n = 27_264_000
+    assert [D.shard_range(n, r, 2, 8) for r in range(2)] == [(0, 13_632_000), (13_632_000, n)]   # the reference rule: no rounding for uint8
+    for world in (2, 3, 8):
+        prev = 0
+        for r in range(world):
+            b, e = D.shard_range(n, r, world, 4, align=4096)
+            assert b == prev and (b % 4096 == 0) and (e % 4096 == 0 or r == world - 1)
+            prev = e
+        assert prev == n
+    with pytest.raises(ValueError):
+        D.shard_range(n, 0, 2, 2, align=6)   # not a multiple of the pack factor 4
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("qname,bits", [("uint8", 8), ("quint4x2", 4), ("quint2x4", 2)])
+def test_quantize_and_dequantize_shard_cover_the_tensor(oracle_mod, world, qname, bits):
+    """quantize_shard / dequantize_shard over all ranks == one call on the whole tensor (reference split, src/piquant.cpp:145-157).
+    The element-wise op is injected from the oracle here (the HIP op needs a GPU; tests/test_gpu_distributed.py runs the real one)."""
+    import piquant.distributed as D
+
+    O = oracle_mod
+    odt = {8: O.UINT8, 4: O.UINT4, 2: O.UINT2}[bits]
+    qdtype = getattr(torch, qname)
+    n = 10_007
+    x = np.random.default_rng(3).uniform(-2, 2, n).astype(np.float32)
+    scale, zp = O.compute_quant_params(x, O.F32, odt)
+    want_q = O.quantize(x, O.F32, odt, scale, zp)
+
+    def q_op(t, *, scale, zero_point, dtype, round_mode, ctx, out):
+        out.copy_(torch.from_numpy(O.quantize(t.numpy(), O.F32, odt, scale, zero_point)))
+        return out
+
+    def dq_op(src, *, scale, zero_point, dtype, reduce_op, ctx, out, quant_dtype, shape):
+        m = int(shape[0])
+        prev = out.numpy().copy()
+        got = O.dequantize(src.numpy(), odt, O.F32, m, scale, zero_point, O.ADD if reduce_op == 'add' else O.SET, out=prev)
+        out.copy_(torch.from_numpy(got))
+        return out
+
+    xt = torch.from_numpy(x)
+    whole = torch.full((want_q.size,), 0xAA, dtype=torch.uint8)
+    pieces = []
+    for r in range(world):
+        dst, (b, e) = D.quantize_shard(xt, scale=scale, zero_point=zp, dtype=qdtype, out=whole, rank=r, world_size=world, _quantize=q_op)
+        assert (b, e) == D.shard_range(n, r, world, bits)
+        piece, _ = D.quantize_shard(xt, scale=scale, zero_point=zp, dtype=qdtype, rank=r, world_size=world, _quantize=q_op)
+        assert torch.equal(piece, dst)
+        pieces.append(piece)
+    assert np.array_equal(whole.numpy(), want_q)
+    assert np.array_equal(torch.cat(pieces).numpy(), want_q)
+
+    acc = torch.ones(n)
+    for r in range(world):
+        D.dequantize_shard(whole, numel=n, scale=scale, zero_point=zp, quant_dtype=qdtype, out=acc, reduce_op='add', rank=r, world_size=world,
+                           _dequantize=dq_op)
+    want = O.dequantize(want_q, odt, O.F32, n, scale, zp, O.ADD, out=np.ones(n, dtype=np.float32))
+    assert np.array_equal(acc.numpy().view(np.uint32), want.view(np.uint32))
+    with pytest.raises(ValueError):
+        D.quantize_shard(xt, scale=scale, zero_point=zp, dtype=qdtype, out=whole[:-1], rank=0, world_size=world, _quantize=q_op)
+    with pytest.raises(ValueError):
+        D.quantize_shard(xt, scale=scale, zero_point=zp, dtype=qdtype, rank=world, world_size=world, _quantize=q_op)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # quantized ring all-reduce: ring schedule, wire format and chunking over gloo; the three ops come from the oracle
 # (the HIP ops need a GPU -- tests/test_gpu_distributed.py runs the same schedule with them)

@@ -153,10 +153,50 @@ def test_native_rccl_all_reduce_entry_point(oracle_mod):
         rccl.ncclCommDestroy(comm)
 
 
+@pytest.mark.parametrize("world", [2, 8])
+@pytest.mark.parametrize("qname,fdtype", [("uint8", torch.float32), ("quint4x2", torch.bfloat16), ("quint2x4", torch.float32)])
+def test_quantize_shard_concatenation_is_the_whole_call(oracle_mod, world, qname, fdtype):
+    """Strong scaling of the headline tensor: the shards of ONE 27 264 000-element tensor (reference split, src/piquant.cpp:145-157),
+    quantized rank by rank with the HIP kernels, are byte for byte the single-call result; dequantize_shard (SET and ADD) likewise."""
+    import piquant
+    import piquant.distributed as D
+
+    n = 27_264_000 + (3 if qname != "uint8" else 0)     # ragged for the packed types
+    qdtype = getattr(torch, qname)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(17)
+    x = torch.empty(n, device="cuda").uniform_(-1, 1, generator=g).to(fdtype)
+    scale, zp = piquant.torch.compute_quant_params(x, dtype=qdtype)
+    whole = piquant.torch.packed_bytes(piquant.torch.quantize(x, scale=scale, zero_point=zp, dtype=qdtype))
+    buf = torch.full_like(whole, 0xAA)
+    for r in range(world):
+        dst, (b, e) = D.quantize_shard(x, scale=scale, zero_point=zp, dtype=qdtype, out=buf, rank=r, world_size=world)
+        assert e > b and dst.numel() == piquant.torch.torch_to_piquant_dtype(qdtype).packed_nbytes(e - b)
+    assert torch.equal(buf, whole)
+    full = piquant.torch.dequantize(whole, scale=scale, zero_point=zp, dtype=fdtype, quant_dtype=qdtype, shape=(n,))
+    out = torch.full((n,), 7.0, device="cuda", dtype=fdtype)
+    for r in range(world):
+        D.dequantize_shard(buf, numel=n, scale=scale, zero_point=zp, quant_dtype=qdtype, out=out, rank=r, world_size=world)
+    assert torch.equal(out.view(torch.int16 if fdtype == torch.bfloat16 else torch.int32), full.view(torch.int16 if fdtype == torch.bfloat16 else torch.int32))
+    acc = torch.ones(n, device="cuda", dtype=fdtype)
+    want = piquant.torch.dequantize(whole, scale=scale, zero_point=zp, dtype=fdtype, quant_dtype=qdtype, shape=(n,), reduce_op="add",
+                                    out=torch.ones(n, device="cuda", dtype=fdtype))
+    for r in range(world):
+        D.dequantize_shard(buf, numel=n, scale=scale, zero_point=zp, quant_dtype=qdtype, out=acc, reduce_op="add", rank=r, world_size=world)
+    assert torch.equal(acc, want)
+    # and the whole thing equals the oracle on a window (the full-size oracle comparison lives in test_gpu_parity.py::test_config2)
+    O = oracle_mod
+    if fdtype == torch.float32 and qname == "uint8":
+        lo = D.shard_range(n, world - 1, world, 8)[0] - 1000
+        xs = x[lo: lo + 5000].cpu().numpy()
+        assert np.array_equal(buf[lo: lo + 5000].cpu().numpy(), O.quantize(xs, O.F32, O.UINT8, scale, zp))
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # bench.py's multi-rank control flow (barriers, max over ranks, the sharded config-5 measurement with its collective)
 # on ONE GPU: two ranks share cuda:0 and talk gloo, because RCCL refuses two ranks on one device.  The numbers mean
-# nothing; the run must finish, print exactly one JSON line and get the sharded parameters right.
+# nothing; the run must finish, print exactly one JSON line, shard the headline tensor (strong scaling) and get the sharded
+# parameters right.
 # ---------------------------------------------------------------------------------------------------------------
 def test_bench_two_ranks_sharing_the_gpu():
     import json
@@ -175,6 +215,13 @@ def test_bench_two_ranks_sharing_the_gpu():
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 50 and d["scaling"] == "weak" and d["value"] > 0
+    # the headline is the north-star workload: ONE 27 264 000-element tensor split over the ranks (reference src/piquant.cpp:145-157)
+    assert d["n_gpus"] == 2 and d["steps"] == 50 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["numel_total"] == 27_264_000 and d["config"]["numel_per_gpu"] == 13_632_000
+    assert d["roofline"]["algorithmic_bytes_per_launch"] == 5 * 13_632_000
+    # value counts the whole tensor once per step, not once per rank
+    assert abs(d["value"] - 27_264_000 * 4 / 2**30 * 50 / (d["ms_per_step"] * 50e-3)) / d["value"] < 1e-3
     c5 = d["extras"]["config5_sharded_compute_quant_params"]
-    assert c5["result_correct"] and c5["numel_per_gpu"] == (1 << 30) // 2
+    assert c5["result_correct"] and c5["numel_per_gpu"] == (1 << 30) // 2 and "gloo" in c5["note"]
+    weak = d["extras"]["weak_scaling_own_tensor_per_gpu"]
+    assert weak["scaling"] == "weak" and weak["numel_per_gpu"] == 27_264_000 and weak["GiB/s"] > 0
