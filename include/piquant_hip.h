@@ -28,6 +28,12 @@ PIQUANT_EXPORT void piquant_hip_reset_stream(piquant_context_t* ctx);
  * stream order.  Host-pointer calls and compute_quant_params always complete before returning. */
 PIQUANT_EXPORT void piquant_hip_set_blocking(piquant_context_t* ctx, int blocking);
 
+/* How a blocking call waits for the GPU: 0 = hipStreamSynchronize; 1 = the command processor writes the call's sequence number
+ * into a pinned host word behind the kernel (hipStreamWriteValue32) and the host spins on it; 2 = the same word written by a
+ * one-thread kernel.  All three return after the work has completed; they differ in latency only.  The
+ * environment variable PIQUANT_HIP_BLOCKING_WAIT = sync | write32 | kernel sets it at context creation. */
+PIQUANT_EXPORT void piquant_hip_set_blocking_wait(piquant_context_t* ctx, int mode);
+
 /* Pointer classification.  By default every buffer is classified with hipPointerGetAttributes (device / pinned: used in
  * place; pageable host: staged over PCIe).  A binding that already knows its buffers are device memory (PyTorch device
  * tensors) sets assume != 0 to skip the two runtime queries per call -- they are a visible share of the ~10 us a small
@@ -88,7 +94,8 @@ PIQUANT_EXPORT void piquant_hip_minmax_keys(piquant_context_t* ctx, const void* 
  * stream of launches (capturable in a hipGraph).  The record is 16 bytes of device memory, e.g. the header of a wire
  * buffer.  piquant_hip_compute_quant_params_device = min/max scan + a one-wave kernel running the reference's
  * double-precision epilogue (src/piquant.cpp:245-258; results are bit-identical to piquant_compute_quant_params_*,
- * except that a NaN / negative scale cannot abort from the device).  The *_dp calls are piquant_quantize /
+ * except that the device cannot abort: where the synchronous call would -- nothing scanned, i.e. an empty tensor or one made
+ * of NaNs only, max < min -- the record is the degenerate one, scale 1.0 and zero point qmax >> 1).  The *_dp calls are piquant_quantize /
  * piquant_dequantize with scale and zero_point read from the record.  Device (or pinned) buffers only. */
 typedef struct piquant_hip_params_t {
     float scale;
@@ -114,12 +121,22 @@ PIQUANT_EXPORT void piquant_hip_dequantize_dp(piquant_context_t* ctx, const void
  * of 9).  Up to ~268 MB the same launch keeps 113 MB on chip and streams the remainder twice.  Larger or misaligned tensors take a scan (its last block writes the parameters) + quantize (two launches); the output bytes and the
  * record are identical either way.  piquant_hip_set_fusion(ctx, 0), or PIQUANT_HIP_FUSION=0 in the environment when the
  * context is created, forces the two-launch form.  The one-launch kernel synchronises its blocks with a grid barrier (one
- * block per CU); the library orders such launches from different streams of one process behind one another, but processes
- * that SHARE a GPU must switch it off (two barrier kernels dispatched at the same instant could each hold part of the CUs). */
+ * block per CU) whose waits are bounded (piquant_hip_set_barrier_timeout_us below): it cannot deadlock or abort whatever else
+ * runs on the GPU; the library additionally orders such launches from different streams of one process behind one another. */
 PIQUANT_EXPORT void piquant_hip_quantize_dynamic(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in, void* out,
                                                  piquant_dtype_t dtype_out, size_t numel, piquant_hip_params_t* device_params,
                                                  piquant_round_mode_t mode);
 PIQUANT_EXPORT void piquant_hip_set_fusion(piquant_context_t* ctx, int enabled);
+
+/* The one-launch kernel's grid barrier never waits without bound: a block that has waited `microseconds` (default 1000) for the
+ * rest of its grid -- which on an idle GPU arrives within a few microseconds -- assumes that the missing blocks cannot start
+ * because something else holds their CUs (a kernel of another stream or process, an RCCL kernel waiting for a peer), hands its
+ * share over and exits, freeing its CU.  The barrier still opens when the last block has arrived; the blocks resident then also
+ * quantize the shares that were handed over, from HBM.  Results are identical; only the time differs.  0 restores the default.
+ * piquant_hip_barrier_bailouts returns how many blocks ever left a barrier of this context early (0 in normal operation;
+ * synchronises the context's stream). */
+PIQUANT_EXPORT void piquant_hip_set_barrier_timeout_us(piquant_context_t* ctx, uint32_t microseconds);
+PIQUANT_EXPORT uint64_t piquant_hip_barrier_bailouts(piquant_context_t* ctx);
 
 /* piquant_hip_quantize_dynamic for `count` independent tensors of the same dtype pair, each with its own parameters and its own
  * 16-byte record: outputs[i] = quantize(inputs[i]) with (scale, zero_point) from inputs[i].  Up to 16 tensors share ONE kernel

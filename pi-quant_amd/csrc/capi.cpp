@@ -23,6 +23,7 @@
 #include <limits>
 #include <mutex>
 #include <random>
+#include <string>
 #include <vector>
 
 namespace pq {
@@ -124,6 +125,11 @@ struct piquant_context_t {
     hipStream_t scan_stream = nullptr;     // stream of the previous scan (scans of one context must not overlap)
     void* d_fused = nullptr;               // FusedState of the one-launch params + quantize kernel (fused_kernels.hpp)
     bool fusion = true;                    // piquant_hip_set_fusion
+    uint32_t barrier_timeout_us = 0;       // piquant_hip_set_barrier_timeout_us (0 = the kernel's default, 1 ms)
+    int wait_mode = 0;                     // how a blocking call waits (WAIT_*, piquant_hip_set_blocking_wait)
+    uint32_t* done = nullptr;              // pinned, host-coherent completion word of blocking calls ...
+    void* done_dev = nullptr;              // ... and its device-visible address
+    uint32_t done_seq = 0;
 
     // device scratch for host-pointer calls, grown on demand
     void* stage_in[2] = {nullptr, nullptr};
@@ -165,15 +171,55 @@ namespace {
 // factor, so chunk boundaries never split a packed byte or a 16-byte vector.
 constexpr size_t kStageChunkElems = size_t{1} << 24;
 
-// Completion wait of a blocking call.  (Polling hipStreamQuery instead was measured slower -- 36.7 vs 34.4 us per blocking
-// fp32->uint8 call at numel 27 264 000 -- and busy-polling an event recorded after the kernel the same, 34.9 vs 34.6: the
-// ~13 us a blocking call costs over the kernel's 21.8 are launch-from-idle and completion-signal latency, not the wait.)
-void wait_stream(hipStream_t stream) { PQ_HIP(hipStreamSynchronize(stream)); }
+constexpr int kDefaultBlockingWait = 0;   // WAIT_SYNC until the A/B says otherwise (profiles/r02_blocking_wait_ab.json)
 
-// Two grid-barrier kernels dispatched at the same moment from different streams could each take part of the CUs and wait
-// forever for the rest (fused_kernels.hpp).  Launches on ONE stream are ordered by the stream.  The first time a second
-// stream issues a fused launch on a device, the device is synchronised once and from then on every fused launch records an
-// event that the next fused launch on a different stream waits for.  A process that keeps to one stream pays nothing.
+// Completion wait of a blocking call (the reference's calls return after the pool has joined, src/piquant.cpp:203-210).
+//   WAIT_SYNC     hipStreamSynchronize: the runtime waits on the queue's completion signal (interrupt or its own polling).
+//   WAIT_WRITE32  hipStreamWriteValue32 behind the kernel: the command processor stores the call's sequence number into a pinned,
+//                 host-coherent word once everything earlier on the stream has completed; the host spins on that word.
+//   WAIT_KERNEL   the same word written by a one-thread kernel launched behind the work (system-scope store).
+// Measured A/B at numel 27 264 000 (fp32 -> uint8, 21.9 us kernel): profiles/r02_blocking_wait_ab.json.  (Polling hipStreamQuery or
+// busy-polling an event recorded after the kernel were measured in round 1: 36.7 / 34.9 vs 34.4 us for hipStreamSynchronize.)
+enum : int { WAIT_SYNC = 0, WAIT_WRITE32 = 1, WAIT_KERNEL = 2 };
+
+void wait_stream(piquant_context_t* ctx) {
+    hipStream_t stream = ctx->stream;
+    if (ctx->wait_mode == WAIT_SYNC || !ctx->done_dev) {
+        PQ_HIP(hipStreamSynchronize(stream));
+        return;
+    }
+    const uint32_t seq = ++ctx->done_seq;
+    if (ctx->wait_mode == WAIT_WRITE32) {
+        if (hipStreamWriteValue32(stream, ctx->done_dev, seq, 0) != hipSuccess) {   // not supported for this memory / runtime: stay with the runtime's wait
+            (void)hipGetLastError();
+            ctx->wait_mode = WAIT_SYNC;
+            PQ_HIP(hipStreamSynchronize(stream));
+            return;
+        }
+    } else {
+        launch_publish_seq(static_cast<uint32_t*>(ctx->done_dev), seq, stream);
+    }
+    volatile uint32_t* flag = ctx->done;
+    for (uint32_t spins = 0;; ++spins) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return;
+        if ((spins & 0x3fff) == 0x3fff) {   // every ~50 us: has the stream drained (or failed) without the word becoming visible?
+            const hipError_t q = hipStreamQuery(stream);
+            if (q == hipSuccess) {
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return;
+                PQ_HIP(hipStreamSynchronize(stream));
+                return;
+            }
+            if (q != hipErrorNotReady) PQ_HIP(q);
+        }
+        __builtin_ia32_pause();
+    }
+}
+
+// Two grid-barrier kernels dispatched at the same moment from different streams could each take part of the CUs and make each
+// other's blocks wait for their barrier timeout (fused_kernels.hpp: never a deadlock, but the orphan pick-up that follows is slow).
+// Launches on ONE stream are ordered by the stream.  The first time a second stream issues a fused launch on a device, the
+// device is synchronised once and from then on every fused launch records an event that the next fused launch on a different
+// stream waits for.  A process that keeps to one stream pays nothing.
 struct FusedOrder {
     std::mutex mu;
     hipStream_t last_stream = nullptr;
@@ -192,32 +238,39 @@ bool stream_is_capturing(hipStream_t s) {
     return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
 }
 
-// call before a fused launch on `stream`; returns true if an event must be recorded after it (fused_order_after)
-bool fused_order_before(int device, hipStream_t stream) {
-    if (stream_is_capturing(stream)) return false;   // a graph is replayed as a unit; its launches are ordered inside it
-    FusedOrder& o = fused_order(device);
-    std::lock_guard<std::mutex> lock(o.mu);
-    if (o.seen && o.last_stream != stream) {
-        if (!o.multi_stream) {
-            // once per device and process: whatever the first stream still has in flight finishes before the second stream's
-            // first fused launch (no event exists yet to wait for).  Not fatal if the runtime refuses (another thread capturing).
-            if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
-            PQ_HIP(hipEventCreateWithFlags(&o.last, hipEventDisableTiming));
-            o.multi_stream = true;
-        } else {
-            PQ_HIP(hipStreamWaitEvent(stream, o.last, 0));
+// Wait for the previous fused launch of the device, launch, record: ONE critical section (the per-device mutex is held from the
+// constructor to the destructor), so two threads with two contexts cannot slip a launch between each other's wait and record.
+// A capturing stream takes no part: a graph is replayed as a unit, and fused nodes that end up on parallel branches of one graph
+// are covered by the kernel's own bounded barrier wait.
+class FusedLaunchOrder {
+  public:
+    FusedLaunchOrder(int device, hipStream_t stream) : o_(fused_order(device)), stream_(stream), lock_(o_.mu, std::defer_lock) {
+        if (stream_is_capturing(stream)) return;
+        lock_.lock();
+        if (o_.seen && o_.last_stream != stream) {
+            if (!o_.multi_stream) {
+                // once per device and process: whatever the first stream still has in flight finishes before the second stream's
+                // first fused launch (no event exists yet to wait for).  Not fatal if the runtime refuses (another thread capturing).
+                if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+                PQ_HIP(hipEventCreateWithFlags(&o_.last, hipEventDisableTiming));
+                o_.multi_stream = true;
+            } else {
+                PQ_HIP(hipStreamWaitEvent(stream, o_.last, 0));
+            }
         }
+        o_.seen = true;
+        o_.last_stream = stream;
     }
-    o.seen = true;
-    o.last_stream = stream;
-    return o.multi_stream;
-}
+    // call after a fused kernel was actually enqueued
+    void launched() {
+        if (lock_.owns_lock() && o_.multi_stream) PQ_HIP(hipEventRecord(o_.last, stream_));
+    }
 
-void fused_order_after(int device, hipStream_t stream) {
-    FusedOrder& o = fused_order(device);
-    std::lock_guard<std::mutex> lock(o.mu);
-    PQ_HIP(hipEventRecord(o.last, stream));
-}
+  private:
+    FusedOrder& o_;
+    hipStream_t stream_;
+    std::unique_lock<std::mutex> lock_;
+};
 
 float draw_threshold(piquant_context_t* ctx) {
     if (ctx->fixed_threshold >= 0.0f) return ctx->fixed_threshold;
@@ -254,8 +307,21 @@ piquant_context_t* piquant_context_create(size_t num_threads) {
         (void)hipGetLastError();
         ctx->mailbox_dev = nullptr;   // no fine-grained host memory: compute_quant_params falls back to D2H + sync
     }
+    if (hipHostMalloc(reinterpret_cast<void**>(&ctx->done), 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+        hipHostGetDevicePointer(&ctx->done_dev, ctx->done, 0) == hipSuccess) {
+        *ctx->done = 0;
+    } else {
+        (void)hipGetLastError();
+        ctx->done_dev = nullptr;
+    }
+    ctx->wait_mode = kDefaultBlockingWait;
+    if (const char* env = std::getenv("PIQUANT_HIP_BLOCKING_WAIT")) {
+        const std::string m(env);
+        ctx->wait_mode = m == "write32" ? WAIT_WRITE32 : (m == "kernel" ? WAIT_KERNEL : WAIT_SYNC);
+    }
     PQ_HIP(hipDeviceSynchronize());   // the arming memsets ran on the null stream; scans may run on any stream
     if (const char* env = std::getenv("PIQUANT_HIP_FUSION")) ctx->fusion = !(env[0] == '0' && env[1] == '\0');
+    if (const char* env = std::getenv("PIQUANT_HIP_BARRIER_TIMEOUT_US")) ctx->barrier_timeout_us = static_cast<uint32_t>(std::strtoul(env, nullptr, 10));
     std::random_device rd;
     ctx->rng.seed((static_cast<uint64_t>(rd()) << 32) ^ rd());
     return ctx;
@@ -276,6 +342,7 @@ void piquant_context_destroy(piquant_context_t* ctx) {
         if (ctx->d_fused) (void)hipFree(ctx->d_fused);
         if (ctx->h_keys) (void)hipHostFree(ctx->h_keys);
         if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
+        if (ctx->done) (void)hipHostFree(ctx->done);
         if (ctx->d_dist_keys) (void)hipFree(ctx->d_dist_keys);
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     }
@@ -335,7 +402,7 @@ static void quantize_impl(piquant_context_t* ctx, const void* in, piquant_dtype_
         q.out = rout.dev;
         q.numel = static_cast<int64_t>(numel);
         launch_quantize(q, ctx->stream, ctx->num_cu);
-        if (ctx->blocking) wait_stream(ctx->stream);
+        if (ctx->blocking) wait_stream(ctx);
         return;
     }
 
@@ -412,7 +479,7 @@ static void dequantize_impl(piquant_context_t* ctx, const void* in, piquant_dtyp
         d.out = rout.dev;
         d.numel = static_cast<int64_t>(numel);
         launch_dequantize(d, ctx->stream, ctx->num_cu);
-        if (ctx->blocking) wait_stream(ctx->stream);
+        if (ctx->blocking) wait_stream(ctx);
         return;
     }
 
@@ -485,7 +552,7 @@ void piquant_hip_dequantize_sum(piquant_context_t* ctx, const void* const* input
         d.op = (first == 0 && op == PIQUANT_REDUCE_OP_SET) ? OP_SET : OP_ADD;
         launch_dequantize_sum(d, ctx->stream, ctx->num_cu);
     }
-    if (ctx->blocking) wait_stream(ctx->stream);
+    if (ctx->blocking) wait_stream(ctx);
 }
 
 void piquant_hip_dequantize_dp_batch(piquant_context_t* ctx, const void* const* inputs, piquant_dtype_t dtype_in, void* const* outputs,
@@ -522,7 +589,7 @@ void piquant_hip_dequantize_dp_batch(piquant_context_t* ctx, const void* const* 
         }
         launch_dequantize_batch(d, ctx->stream);
     }
-    if (ctx->blocking) wait_stream(ctx->stream);
+    if (ctx->blocking) wait_stream(ctx);
 }
 
 void piquant_hip_quantize_dequantize(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in_out, void* out, piquant_dtype_t quant_dtype,
@@ -566,7 +633,7 @@ void piquant_hip_quantize_dequantize(piquant_context_t* ctx, const void* in, piq
         r.threshold = draw_threshold(ctx);
     }
     launch_requantize(r, ctx->stream, ctx->num_cu);
-    if (ctx->blocking) wait_stream(ctx->stream);
+    if (ctx->blocking) wait_stream(ctx);
 }
 
 // Min/max scan of x with `action` as its epilogue (launch.hpp): one launch for device input; staged chunks plus a fold launch
@@ -634,7 +701,7 @@ void piquant_hip_compute_quant_params_device(piquant_context_t* ctx, const void*
     a.action = MM_PARAMS;
     a.bits = dtype_of(target_quant_dtype).bits;
     a.dst = rp.dev;
-    scan(ctx, x, dtype, n, a);   // n == 0: the identities fold to the degenerate range, like the synchronous call
+    scan(ctx, x, dtype, n, a);   // n == 0: the armed identities (max < min) get the degenerate record (1.0, qmax >> 1); the synchronous call aborts instead
 }
 
 // compute_quant_params + quantize of ONE tensor on resolved device pointers; `q` carries dtypes and the round-mode fields.
@@ -645,7 +712,7 @@ static void quantize_dynamic_one(piquant_context_t* ctx, QuantLaunch q, const vo
     params_action.action = MM_PARAMS;
     params_action.bits = dtype_of(static_cast<piquant_dtype_t>(q.dt_out)).bits;
     params_action.dst = params_dev;
-    if (numel == 0) {   // parameters of an empty tensor: the identities fold to the degenerate range, as in the synchronous call
+    if (numel == 0) {   // parameters of an empty tensor: the device epilogue writes the degenerate record (1.0, qmax >> 1) for the armed identities
         scan(ctx, nullptr, static_cast<piquant_dtype_t>(q.dt_in), 0, params_action);
         return;
     }
@@ -662,9 +729,10 @@ static void quantize_dynamic_one(piquant_context_t* ctx, QuantLaunch q, const vo
     // switched off) the same result from two launches: the scan, whose last block writes the record, and a quantize that reads it.
     bool fused = false;
     if (ctx->fusion && fused_launch_applies(q, ctx->num_cu)) {
-        const bool record = fused_order_before(ctx->device, ctx->stream);
+        FusedLaunchOrder order(ctx->device, ctx->stream);
+        q.barrier_timeout_us = ctx->barrier_timeout_us;
         fused = launch_fused_params_quantize(q, ctx->d_fused, params_dev, ctx->stream, ctx->num_cu);
-        if (fused && record) fused_order_after(ctx->device, ctx->stream);
+        if (fused) order.launched();
     }
     if (!fused) {
         scan(ctx, in_dev, static_cast<piquant_dtype_t>(q.dt_in), numel, params_action);
@@ -703,7 +771,7 @@ void piquant_hip_quantize_dynamic(piquant_context_t* ctx, const void* in, piquan
         if (rin.pageable || rout.pageable) panic("piquant_hip_quantize_dynamic needs device (or pinned) buffers");
         quantize_dynamic_one(ctx, q, rin.dev, rout.dev, out, numel, rp.dev);
     }
-    if (ctx->blocking) wait_stream(ctx->stream);
+    if (ctx->blocking) wait_stream(ctx);
 }
 
 void piquant_hip_quantize_dynamic_batch(piquant_context_t* ctx, const void* const* inputs, piquant_dtype_t dtype_in, void* const* outputs,
@@ -758,9 +826,10 @@ void piquant_hip_quantize_dynamic_batch(piquant_context_t* ctx, const void* cons
         }
         bool fused = false;
         if (ctx->fusion && !ctx->reference_layout && b.count > 1) {
-            const bool record = fused_order_before(ctx->device, ctx->stream);
+            FusedLaunchOrder order(ctx->device, ctx->stream);
+            q.barrier_timeout_us = ctx->barrier_timeout_us;
             fused = launch_fused_params_quantize_batch(q, b, ctx->d_fused, ctx->stream, ctx->num_cu);
-            if (fused && record) fused_order_after(ctx->device, ctx->stream);
+            if (fused) order.launched();
         }
         for (size_t k = i; k < j; ++k) {
             if (fused && items[k].numel != 0) continue;
@@ -768,7 +837,7 @@ void piquant_hip_quantize_dynamic_batch(piquant_context_t* ctx, const void* cons
         }
         i = j;
     }
-    if (ctx->blocking) wait_stream(ctx->stream);
+    if (ctx->blocking) wait_stream(ctx);
 }
 
 void piquant_hip_reduce_quantize_dynamic(piquant_context_t* ctx, void* acc, piquant_dtype_t dtype_acc, const void* const* inputs,
@@ -806,10 +875,13 @@ void piquant_hip_reduce_quantize_dynamic(piquant_context_t* ctx, void* acc, piqu
                 terms.in[i] = ri.dev;
                 terms.params[i] = rq.dev;
             }
-            const bool record = fused_order_before(ctx->device, ctx->stream);
-            fused = launch_fused_reduce_quantize(q, terms, ctx->d_fused, rp.dev, ctx->stream, ctx->num_cu);
-            if (fused && record) fused_order_after(ctx->device, ctx->stream);
-            if (fused && ctx->blocking) wait_stream(ctx->stream);
+            {
+                FusedLaunchOrder order(ctx->device, ctx->stream);
+                q.barrier_timeout_us = ctx->barrier_timeout_us;
+                fused = launch_fused_reduce_quantize(q, terms, ctx->d_fused, rp.dev, ctx->stream, ctx->num_cu);
+                if (fused) order.launched();
+            }
+            if (fused && ctx->blocking) wait_stream(ctx);
         }
     }
     if (fused) return;
@@ -822,6 +894,20 @@ void piquant_hip_set_fusion(piquant_context_t* ctx, int enabled) {
     if (!ctx) panic("piquant_hip_set_fusion: context is NULL");
     std::lock_guard<std::mutex> lock(ctx->mu);
     ctx->fusion = enabled != 0;
+}
+
+void piquant_hip_set_barrier_timeout_us(piquant_context_t* ctx, uint32_t microseconds) {
+    if (!ctx) panic("piquant_hip_set_barrier_timeout_us: context is NULL");
+    if (microseconds > 40000000u) panic("piquant_hip_set_barrier_timeout_us: %u us is beyond the 40 s the tick counter holds", microseconds);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->barrier_timeout_us = microseconds;
+}
+
+uint64_t piquant_hip_barrier_bailouts(piquant_context_t* ctx) {
+    if (!ctx) panic("piquant_hip_barrier_bailouts: context is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    return fused_state_bailouts(ctx->d_fused, ctx->stream);
 }
 
 // RCCL's ncclAllReduce, looked up once in whatever RCCL the process has loaded (PyTorch's bundled one, /opt/rocm's, ...).
@@ -989,6 +1075,13 @@ void piquant_hip_set_blocking(piquant_context_t* ctx, int blocking) {
     if (!ctx) panic("piquant_hip_set_blocking: context is NULL");
     std::lock_guard<std::mutex> lock(ctx->mu);
     ctx->blocking = blocking != 0;
+}
+
+void piquant_hip_set_blocking_wait(piquant_context_t* ctx, int mode) {
+    if (!ctx) panic("piquant_hip_set_blocking_wait: context is NULL");
+    if (mode < WAIT_SYNC || mode > WAIT_KERNEL) panic("piquant_hip_set_blocking_wait: invalid mode %d", mode);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->wait_mode = mode;
 }
 
 void piquant_hip_set_stochastic_threshold(piquant_context_t* ctx, float threshold) {

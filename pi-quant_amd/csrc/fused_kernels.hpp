@@ -19,11 +19,23 @@
 // The arithmetic is the same code as the two-pass path (minmax keys, params epilogue, quant_nearest_fast2 / quant_one), so
 // the output bytes and the record are identical to compute_quant_params_device + quantize_dp -- tests compare them.
 //
-// Co-residency: the barrier needs all blocks on the chip at once.  A block takes a whole CU (144 KiB of LDS), the grid never
-// exceeds the CU count, and kernels that do not wait on this one only delay it.  What must not happen is TWO barrier kernels
-// being dispatched at the same instant, each getting part of the CUs and waiting for the rest: within a process the host
-// layer orders fused launches of different streams behind one another (capi.cpp, FusedOrder); processes that share one GPU
-// must switch the fused path off (PIQUANT_HIP_FUSION=0 / piquant_hip_set_fusion) -- the design rule is one process per GPU.
+// Co-residency is NOT assumed.  A block takes a whole CU (144 KiB of LDS) and the grid never exceeds the CU count, so on an idle
+// GPU every block is resident and the barrier opens a few microseconds after the last load.  But a plain launch guarantees
+// nothing (and hipLaunchCooperativeKernel only CHECKS the grid against the occupancy query, for ~17 us per launch -- it does
+// not reserve CUs against kernels of other streams or processes): an RCCL kernel waiting for a peer, another stream's compute
+// or a second process can hold CUs, and then part of the grid waits at the barrier for blocks that cannot start.  So every
+// wait is BOUNDED (wall clock, FusedGroups::bail_ticks, 1 ms by default), and a block whose wait runs out LEAVES: it marks its
+// share as orphaned and exits, which frees its CU for a block that has not started.  Its min/max is already counted, the barrier
+// still opens when the last block has arrived, and whoever is resident then quantizes the orphaned shares too, streaming them
+// from HBM a second time (identical bytes: same step, same parameters).  Slow in that case, never stuck, never fatal:
+//   bail    mark (fetch_or on the group's orphan bitmap, returned value awaited) -> look at the barrier once more
+//           -> still closed: exit.   Open after all: take the mark back (fetch_and); whoever gets the bit owns the share.
+//   pick-up after its own stores every block reads the bitmap (one load, overlapping the store drain); set bits are claimed
+//           with fetch_and, so every orphaned share is quantized exactly once.  A mark made by a block that really left is
+//           performed before that block's last look at the barrier, hence before the barrier opens, hence before any
+//           survivor reads the bitmap: no share is missed.
+// Two barrier kernels launched at the same instant from different streams therefore only delay each other; the host layer still
+// orders them within a process (capi.cpp, FusedOrder) because the slow path is slow.
 //
 // Capacity: (R_REG + R_LDS) x 16 B x BLOCK threads x grid blocks (113 MB with the production 18 + 9 rounds of 1024 threads
 // on 256 CUs, tuning.hpp).  A somewhat larger tensor keeps that much on chip and streams the rest of every block's share
@@ -43,14 +55,21 @@
 
 namespace pq {
 
+constexpr int kFusedMaxBlocks = 256;                                   // blocks of one sub-grid (one per CU)
+constexpr unsigned long long kFusedNotArrived = 0x7fffffff7fffffffull;   // both halves are keys of NaN patterns: never a block's {key(min), key(-max)}
+
 struct FusedState {
-    uint32_t arrived;
+    uint32_t arrived;                 // counter barrier: blocks that have folded their keys into `slots`
     uint32_t pad0[31];
-    uint32_t generation;
+    uint32_t generation;              // launches served so far; its parity selects the slot buffer of this launch
     uint32_t pad1[31];
-    unsigned long long published;   // tag(generation + 1) << 41 | bounded << 40 | zero_point << 32 | bits of scale: what waiting blocks spin on
+    unsigned long long published;     // counter barrier: tag(generation + 1) << 41 | bounded << 40 | zero_point << 32 | bits of scale
     uint32_t pad2[30];
-    int32_t slots[2][kMinmaxStateInts];
+    uint32_t orphans[kFusedMaxBlocks / 32];   // bit b: block b of the sub-grid left the barrier early, its share is up for adoption
+    uint32_t bailouts;                // blocks that ever left early (diagnostic, piquant_hip_barrier_bailouts)
+    uint32_t pad3[32 - kFusedMaxBlocks / 32 - 1];
+    int32_t slots[2][kMinmaxStateInts];                       // counter barrier: 64 slot key pairs per buffer
+    unsigned long long gathered[2][kFusedMaxBlocks];          // all-gather barrier: one {key(min), key(-max)} word per block
     uint64_t* stamps;     // TIMING builds (tools/tune_kernels.hip): 8 x 100 MHz wall clock readings per block at the phase boundaries
 };
 
@@ -66,6 +85,7 @@ struct FusedGroups {
     ParamRecord* params[kFusedMaxGroups];
     int count;
     int blocks_per_group;
+    uint32_t bail_ticks;   // longest wait at the grid barrier in 100 MHz wall-clock ticks before a block gives up its share (0: 1 ms)
 };
 
 // REDUCE variant (one tensor per launch): the values that are scanned and quantized are not `in` itself but
@@ -170,13 +190,29 @@ __device__ __forceinline__ void minmax_vec(const u32x4& raw, bool valid, float& 
     }
 }
 
+// What a block knows once the barrier is open: everything phase 3 needs, in one word (the counter barrier publishes exactly
+// this word; the all-gather barrier lets every block derive it from the gathered keys).
+__device__ __forceinline__ unsigned long long fused_params_word(int32_t k0, int32_t k1, int bits, uint32_t tag23, float& scale, int64_t& zp) {
+    quant_params_epilogue(k0, k1, bits, scale, zp);       // 0 <= zp <= 2^bits - 1
+    // can every element take the bounded step?  abs(x) <= max(abs(min), abs(max)), products are monotone
+    const float reach = __fmul_rn(__builtin_fmaxf(__builtin_fabsf(key_to_float(k0)), __builtin_fabsf(key_to_float(k1))), __fdiv_rn(1.0f, scale));
+    const unsigned long long bounded = reach < 1.0e9f ? 1ull : 0ull;
+    return (static_cast<unsigned long long>(tag23 & 0x7fffffu) << 41) | (bounded << 40) | (static_cast<unsigned long long>(zp) << 32) | __float_as_uint(scale);
+}
+
 // A block owns ONE contiguous share of the tensor (rounds * BLOCK vectors; 426 KiB at the headline size) and walks it in
 // rounds of BLOCK consecutive vectors: vector of thread `tid` in round k = share_begin + k * BLOCK + tid, a coalesced 1 KiB
 // per wave instruction.  (Interleaving the blocks' rounds across the whole tensor instead -- every block touching a new
 // 2 MiB-strided 8 KiB piece per round, ~46 of them in flight per wave -- measured 2.9 TB/s in the load phase and a 2x
 // spread between the fastest and the slowest block: tens of thousands of concurrent 1 KiB streams leave no DRAM locality.)
+//
+// AG selects the grid barrier.  false: blocks fold into 64 slot key pairs (atomicMin), count themselves in, the LAST one folds
+// the slots, runs the epilogue and publishes one 64-bit word the others spin on (four dependent round trips on the critical
+// path).  true ("all-gather"): every block stores its own {key(min), key(-max)} word into its own slot with ONE store and then
+// sweeps all G slots (wave 0, up to four 8-byte loads per lane) until none is empty; everybody derives the parameters itself
+// (a double-precision division per block is nothing) -- one store propagation plus one sweep on the critical path.
 template <int DT_IN, int BITS, int MODE, int R_REG, int R_LDS, int LDS_BATCH, int BLOCK, int ST_POLICY = ST_WT, bool TIMING = false, int STREAM_BATCH = 4,
-          int RED_BITS = 0>
+          int RED_BITS = 0, bool AG = true>
 __global__ void __launch_bounds__(BLOCK)
 fused_params_quantize_kernel(FusedGroups groups, QuantParams p_arg, FusedState* states, FusedReduce red) {
     // Block -> (tensor, block within the tensor's sub-grid).  With one tensor this is the identity.
@@ -213,11 +249,16 @@ fused_params_quantize_kernel(FusedGroups groups, QuantParams p_arg, FusedState* 
     };
     stamp(0);
     const uint32_t gen = __hip_atomic_load(&st->generation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int32_t* slots = st->slots[gen & 1];
-    if (block == 0 && tid < kMinmaxSlots) {   // the other buffer was read by the previous launch, which has completed
-        int32_t* idle = st->slots[(gen & 1) ^ 1];
-        idle[tid * kMinmaxSlotStride + 0] = float_to_key(3.402823466e+38f);
-        idle[tid * kMinmaxSlotStride + 1] = float_to_key(3.402823466e+38f);
+    if (block == 0) {   // re-arm the buffer the NEXT launch will use: the previous launch read it, and that launch has completed
+        if constexpr (AG) {
+            if (tid < kFusedMaxBlocks) st->gathered[(gen & 1) ^ 1][tid] = kFusedNotArrived;
+        } else {
+            if (tid < kMinmaxSlots) {
+                int32_t* idle = st->slots[(gen & 1) ^ 1];
+                idle[tid * kMinmaxSlotStride + 0] = float_to_key(3.402823466e+38f);
+                idle[tid * kMinmaxSlotStride + 1] = float_to_key(3.402823466e+38f);
+            }
+        }
     }
 
     // ---- phase 1: load everything once; rounds [0, R_REG) stay in registers, [R_REG, R_REG + R_LDS) in LDS -------------
@@ -287,65 +328,161 @@ fused_params_quantize_kernel(FusedGroups groups, QuantParams p_arg, FusedState* 
     __syncthreads();
     stamp(1);
     // ---- grid barrier + phase 2, by wave 0 of every block ------------------------------------------------------------------
-    // The LAST block to arrive folds the 64 slots (one lane each), runs the (min,max) -> (scale, zero point) epilogue once
-    // and publishes {generation tag, zero point (< 256), scale bits} in ONE 64-bit word; everybody else spins on that word,
-    // so a waiting block has its parameters the moment it sees the barrier open -- no second round trip for a record.
+    // No fences anywhere in this barrier: the only data that crosses blocks travels in device-scope atomics (key words, arrival
+    // count, published word, orphan bitmap), and a release/acquire fence at agent scope costs an L2 write-back / invalidate per
+    // block (measured: 13-17 us of barrier).  Where one atomic must be PERFORMED before the next is issued, the second is made
+    // to depend on the first one's returned value.
     __shared__ unsigned long long s_pub;
+    __shared__ int s_leave;      // this block gives up its share (wait ran out): every thread exits
+    __shared__ int s_orphans;    // after phase 3: somebody's share is waiting for adoption
+    __shared__ int s_claim;
+    if (tid == 0) {
+        s_leave = 0;
+        s_orphans = 0;
+    }
     if (wave == 0) {
-        uint32_t before = 0;
-        if (lane == 0) {
 #pragma unroll
-            for (int w = 1; w < WAVES; ++w) {
-                lo = __builtin_fminf(lo, s_lo[w]);
-                hi = __builtin_fmaxf(hi, s_hi[w]);
-            }
-            // No fences anywhere in this barrier: the only data that crosses blocks travels in device-scope atomics (slot keys,
-            // arrival count, published word), and a release/acquire fence at agent scope costs an L2 write-back / invalidate
-            // per block (measured: 13-17 us of barrier).  What IS needed is that this block's slot atomics are performed
-            // before its arrival is counted: they return their old value and the arrival increment is made to depend on it.
-            const uint32_t one = fold_keys<false>(slots + (block % kMinmaxSlots) * kMinmaxSlotStride, lo, hi);
-            before = __hip_atomic_fetch_add(&st->arrived, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int w = 1; w < WAVES; ++w) {
+            lo = __builtin_fminf(lo, s_lo[w]);   // every lane of wave 0 holds the wave result; fold the other waves in all lanes
+            hi = __builtin_fmaxf(hi, s_hi[w]);
         }
-        before = __builtin_amdgcn_readfirstlane(before);
-        const unsigned long long tag = static_cast<unsigned long long>((gen + 1u) & 0x7fffffu) << 41;
-        unsigned long long pub;
-        if (before == static_cast<uint32_t>(G) - 1u) {
-            static_assert(kMinmaxSlots == 64, "one lane per slot");
-            int32_t k0 = __hip_atomic_load(slots + lane * kMinmaxSlotStride + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int32_t k1 = __hip_atomic_load(slots + lane * kMinmaxSlotStride + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                k0 = min(k0, __shfl_xor(k0, off, 64));
-                k1 = min(k1, __shfl_xor(k1, off, 64));
+        const uint32_t bail_ticks = groups.bail_ticks != 0 ? groups.bail_ticks : 100000u;   // 100 MHz ticks: 1 ms
+        const uint64_t t_arrive = wall_clock64();
+        const uint32_t my_word = block >> 5, my_bit = 1u << (block & 31);
+        bool leave = false;
+        unsigned long long pub = 0;
+        // Wait ran out: mark the share, look once more (`closed()`), leave only if the barrier is still closed.  Returns true when
+        // this block must exit.  Wave-uniform; lane 0 does the atomics.
+        auto give_up = [&](auto&& closed) -> bool {
+            uint32_t old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_or(&st->orphans[my_word], my_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            old = __builtin_amdgcn_readfirstlane(old);          // the mark is performed before the look that follows is issued
+            asm volatile("" : "+s"(old) : : "memory");
+            if (closed()) {
+                if (lane == 0) __hip_atomic_fetch_add(&st->bailouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return true;
             }
-            float scale;
-            int64_t zp;
-            quant_params_epilogue(k0, k1, BITS, scale, zp);       // 0 <= zp <= 2^BITS - 1
-            // can every element take the bounded step?  abs(x) <= max(abs(min), abs(max)), products are monotone
-            const float reach = __fmul_rn(__builtin_fmaxf(__builtin_fabsf(key_to_float(k0)), __builtin_fabsf(key_to_float(k1))), __fdiv_rn(1.0f, scale));
-            const unsigned long long bounded = reach < 1.0e9f ? 1ull : 0ull;
-            pub = tag | (bounded << 40) | (static_cast<unsigned long long>(zp) << 32) | __float_as_uint(scale);
-            if (lane == 0) {
-                params_out->scale = scale;
-                params_out->inv_scale = __fdiv_rn(1.0f, scale);
-                params_out->zero_point = zp;
-                __hip_atomic_store(&st->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&st->generation, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&st->published, pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the barrier opened while we were marking: whoever clears the bit owns the share
+            uint32_t was = 0;
+            if (lane == 0) was = __hip_atomic_fetch_and(&st->orphans[my_word], ~my_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            was = __builtin_amdgcn_readfirstlane(was);
+            return (was & my_bit) == 0;   // already adopted by a block that passed the barrier: nothing left to do here
+        };
+        if constexpr (AG) {
+            static_assert(kFusedMaxBlocks % 64 == 0, "whole wave loads");
+            constexpr int LPL = kFusedMaxBlocks / 64;   // slots per lane
+            unsigned long long* slots64 = st->gathered[gen & 1];
+            const unsigned long long mine = static_cast<unsigned long long>(static_cast<uint32_t>(float_to_key(lo))) |
+                                            (static_cast<unsigned long long>(static_cast<uint32_t>(float_to_key(-hi))) << 32);
+            if (lane == 0) __hip_atomic_store(slots64 + block, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long ident = static_cast<unsigned long long>(static_cast<uint32_t>(float_to_key(3.402823466e+38f))) * 0x100000001ull;
+            unsigned long long seen[LPL];
+#pragma unroll
+            for (int j = 0; j < LPL; ++j) {
+                const uint32_t slot = j * 64 + lane;
+                seen[j] = slot == block ? mine : (slot < static_cast<uint32_t>(G) ? kFusedNotArrived : ident);
+            }
+            auto sweep = [&]() -> bool {   // true while some block has not arrived
+                bool missing = false;
+#pragma unroll
+                for (int j = 0; j < LPL; ++j) {
+                    if (seen[j] == kFusedNotArrived) {
+                        seen[j] = __hip_atomic_load(slots64 + j * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        missing |= seen[j] == kFusedNotArrived;
+                    }
+                }
+                return __any(missing ? 1 : 0) != 0;
+            };
+            while (sweep()) {
+                __builtin_amdgcn_s_sleep(4);
+                if (wall_clock64() - t_arrive > bail_ticks) {
+                    if (give_up(sweep)) {
+                        leave = true;
+                        break;
+                    }
+                    break;   // open after all (sweep() inside give_up saw every slot)
+                }
+            }
+            if (!leave) {
+                int32_t k0 = 0x7fffffff, k1 = 0x7fffffff;
+#pragma unroll
+                for (int j = 0; j < LPL; ++j) {
+                    k0 = min(k0, static_cast<int32_t>(static_cast<uint32_t>(seen[j])));
+                    k1 = min(k1, static_cast<int32_t>(static_cast<uint32_t>(seen[j] >> 32)));
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    k0 = min(k0, __shfl_xor(k0, off, 64));
+                    k1 = min(k1, __shfl_xor(k1, off, 64));
+                }
+                float scale;
+                int64_t zp;
+                pub = fused_params_word(k0, k1, BITS, 0u, scale, zp);
+                if (block == 0 && lane == 0) {   // block 0's duties (also carried out by whoever adopts block 0's share)
+                    params_out->scale = scale;
+                    params_out->inv_scale = __fdiv_rn(1.0f, scale);
+                    params_out->zero_point = zp;
+                    __hip_atomic_store(&st->generation, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every block has read it: all have arrived
+                }
             }
         } else {
-            pub = 0;
+            uint32_t before = 0;
+            int32_t* slots = st->slots[gen & 1];
             if (lane == 0) {
-                uint32_t spins = 0;
-                while (((pub = __hip_atomic_load(&st->published, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 41) != (tag >> 41)) {
+                // this block's slot atomics are performed before its arrival is counted: they return their old value and the
+                // arrival increment is made to depend on it
+                const uint32_t one = fold_keys<false>(slots + (block % kMinmaxSlots) * kMinmaxSlotStride, lo, hi);
+                before = __hip_atomic_fetch_add(&st->arrived, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            before = __builtin_amdgcn_readfirstlane(before);
+            const uint32_t tag = (gen + 1u) & 0x7fffffu;
+            if (before == static_cast<uint32_t>(G) - 1u) {
+                // The LAST block to arrive folds the 64 slots (one lane each), runs the (min,max) -> (scale, zero point) epilogue once
+                // and publishes {generation tag, zero point (< 256), scale bits} in ONE 64-bit word; everybody else spins on that
+                // word, so a waiting block has its parameters the moment it sees the barrier open.
+                static_assert(kMinmaxSlots == 64, "one lane per slot");
+                int32_t k0 = __hip_atomic_load(slots + lane * kMinmaxSlotStride + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int32_t k1 = __hip_atomic_load(slots + lane * kMinmaxSlotStride + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    k0 = min(k0, __shfl_xor(k0, off, 64));
+                    k1 = min(k1, __shfl_xor(k1, off, 64));
+                }
+                float scale;
+                int64_t zp;
+                pub = fused_params_word(k0, k1, BITS, tag, scale, zp);
+                if (lane == 0) {
+                    params_out->scale = scale;
+                    params_out->inv_scale = __fdiv_rn(1.0f, scale);
+                    params_out->zero_point = zp;
+                    __hip_atomic_store(&st->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&st->generation, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&st->published, pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                auto closed = [&]() -> bool {
+                    unsigned long long v = 0;
+                    if (lane == 0) v = __hip_atomic_load(&st->published, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    pub = (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32))) << 32) |
+                          __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
+                    return static_cast<uint32_t>(pub >> 41) != tag;
+                };
+                while (closed()) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 23)) __builtin_trap();   // several seconds: a block that never arrives must fail the launch, not hang the device
+                    if (wall_clock64() - t_arrive > bail_ticks) {
+                        leave = give_up(closed);
+                        break;
+                    }
                 }
             }
         }
-        if (lane == 0) s_pub = pub;
+        if (lane == 0) {
+            s_pub = pub;
+            s_leave = leave ? 1 : 0;
+        }
     }
     __syncthreads();
+    if (s_leave) return;   // the share is orphaned: a block that is resident when the barrier opens quantizes it from HBM
     stamp(2);
     // Every load of phase 1 has long been consumed, but the compiler's wait-count bookkeeping loses that across the guarded,
     // unrolled rounds and would put `s_waitcnt vmcnt(0)` in front of each resident vector of phase 3 -- which on gfx9 also
@@ -374,6 +511,7 @@ fused_params_quantize_kernel(FusedGroups groups, QuantParams p_arg, FusedState* 
     const BoundedStep bstep {-static_cast<float>(p.zp32), static_cast<float>(((1 << BITS) - 1) - p.zp32), zp_word};
     // A block whose whole share lies inside the tensor (all but the last one or two) needs no per-vector bounds check.
     const bool full_share = (static_cast<int64_t>(block) + 1) * rounds_total * BLOCK <= n_vec;
+    const bool short_step = (MODE == RM_NEAREST_FAST || MODE == RM_NEAREST_I64) && bounded_ok;   // grid-uniform: the data range decides
     auto emit = [&](auto bounded_tag, auto full_tag) {
         constexpr bool BOUNDED = decltype(bounded_tag)::value, FULL = decltype(full_tag)::value;
         auto one = [&](const u32x4& raw, int64_t v) {
@@ -414,21 +552,69 @@ fused_params_quantize_kernel(FusedGroups groups, QuantParams p_arg, FusedState* 
             }
         }
     };
-    // grid-uniform: the data range decides whether the short step is exact for every element of this call
-    if ((MODE == RM_NEAREST_FAST || MODE == RM_NEAREST_I64) && bounded_ok) {
+    if (short_step) {
         if (full_share) emit(std::true_type {}, std::true_type {});
         else emit(std::true_type {}, std::false_type {});
     } else {
         emit(std::false_type {}, std::false_type {});
     }
-    if (block == G - 1 && n_vec * EPV < numel) {
-        constexpr int PACK = 8 / BITS;
-        quantize_bytes_guarded<DT_IN, BITS, MODE>(in, out, numel, n_vec * EPV / PACK, (numel + PACK - 1) / PACK, p, tid, BLOCK);
-    }
+    auto ragged_tail = [&]() {   // the numel % EPV elements behind the last whole vector: part of the LAST block's share
+        if (n_vec * EPV < numel) {
+            constexpr int PACK = 8 / BITS;
+            quantize_bytes_guarded<DT_IN, BITS, MODE>(in, out, numel, n_vec * EPV / PACK, (numel + PACK - 1) / PACK, p, tid, BLOCK);
+        }
+    };
+    if (block == G - 1) ragged_tail();
     if constexpr (TIMING) {
         __builtin_amdgcn_s_waitcnt(0);   // stores issued (not necessarily landed)
         __syncthreads();
         stamp(4);
+    }
+
+    // ---- adoption of orphaned shares (see the header): one load per block, issued behind the stores and overlapping their drain
+    if (wave == 0 && lane < kFusedMaxBlocks / 32) {
+        if (__hip_atomic_load(&st->orphans[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) s_orphans = 1;
+    }
+    __syncthreads();
+    if (!s_orphans) return;
+    for (;;) {   // cold path
+        if (tid == 0) {
+            int got = -1;
+            for (uint32_t i = 0; i < static_cast<uint32_t>(G) && got < 0; ++i) {
+                const uint32_t ob = (block + 1 + i) % static_cast<uint32_t>(G);   // start behind the own index: survivors spread over the orphans
+                const uint32_t bit = 1u << (ob & 31);
+                if ((__hip_atomic_load(&st->orphans[ob >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) != 0 &&
+                    (__hip_atomic_fetch_and(&st->orphans[ob >> 5], ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) != 0)
+                    got = static_cast<int>(ob);
+            }
+            s_claim = got;
+        }
+        __syncthreads();
+        const int ob = s_claim;
+        if (ob < 0) return;
+        const int64_t o_first = static_cast<int64_t>(ob) * rounds_total * BLOCK + tid;
+        [[maybe_unused]] ElementKeys okeys {};
+        if constexpr (MODE == RM_STOCH_ELEM) okeys = element_keys_for(p, p.index_base + static_cast<uint64_t>(o_first) * EPV);
+#pragma unroll 1
+        for (int64_t k = 0; k < rounds_total; ++k) {
+            const int64_t v = o_first + k * round_vecs;
+            if (v < n_vec) {
+                u32x4 t = ld<true>(in16 + v);
+                if constexpr (RED_BITS != 0) add_reduce_terms<DT_IN, RED_BITS>(t, v, red);
+                uint32_t w[WORDS];
+                if (short_step) quantize_vec_bounded<DT_IN, BITS, MODE == RM_NEAREST_I64>(t, p.inv_scale, bstep, w);
+                else quantize_vec<DT_IN, BITS, MODE>(t, p, okeys, static_cast<uint64_t>(v) * EPV, w);
+                store_packed<OB, ST_POLICY>(out + v * OB, w);
+            }
+        }
+        if (ob == G - 1) ragged_tail();
+        if (AG && ob == 0 && tid == 0) {   // block 0's duties: the record and the generation
+            params_out->scale = scale;
+            params_out->inv_scale = __fdiv_rn(1.0f, scale);
+            params_out->zero_point = zp;
+            __hip_atomic_store(&st->generation, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();   // s_claim is rewritten in the next round
     }
 }
 

@@ -107,14 +107,22 @@ void dequantize_out(const DequantLaunch& d, const DequantParams& p, hipStream_t 
 template <int DT_IN>
 void minmax_t(const void* in, int64_t numel, int32_t* state, const MinmaxEpilogue& ep, hipStream_t stream, int num_cu) {
     constexpr int EPV = InVec<DT_IN>::EPV;
+    // scans that deliver a result end with the gather protocol; scans that leave their keys in the slots (EP_NONE: several staged
+    // chunks of a host buffer folding into one state) keep the slot atomics
     if (!aligned16(in)) {
         const unsigned grid = capped_grid((numel + kMinmaxBlock - 1) / kMinmaxBlock, 8, num_cu);
-        hipLaunchKernelGGL((minmax_scalar_kernel<DT_IN, kMinmaxBlock>), dim3(grid), dim3(kMinmaxBlock), 0, stream, in, numel, state, ep);
+        if (kMinmaxGatherEnd && ep.action != EP_NONE && grid <= static_cast<unsigned>(kMinmaxGatherMax))
+            hipLaunchKernelGGL((minmax_scalar_kernel<DT_IN, kMinmaxBlock, true>), dim3(grid), dim3(kMinmaxBlock), 0, stream, in, numel, state, ep);
+        else
+            hipLaunchKernelGGL((minmax_scalar_kernel<DT_IN, kMinmaxBlock, false>), dim3(grid), dim3(kMinmaxBlock), 0, stream, in, numel, state, ep);
         return;
     }
     const int64_t per_block = static_cast<int64_t>(kMinmaxBlock) * kMinmaxU * EPV;
     const unsigned grid = capped_grid((numel + per_block - 1) / per_block, kMinmaxBlocksPerCU, num_cu);
-    hipLaunchKernelGGL((minmax_kernel<DT_IN, kMinmaxU, kMinmaxNT, kMinmaxBlock>), dim3(grid), dim3(kMinmaxBlock), 0, stream, in, numel, state, ep);
+    if (kMinmaxGatherEnd && ep.action != EP_NONE && grid <= static_cast<unsigned>(kMinmaxGatherMax))
+        hipLaunchKernelGGL((minmax_kernel<DT_IN, kMinmaxU, kMinmaxNT, kMinmaxBlock, true>), dim3(grid), dim3(kMinmaxBlock), 0, stream, in, numel, state, ep);
+    else
+        hipLaunchKernelGGL((minmax_kernel<DT_IN, kMinmaxU, kMinmaxNT, kMinmaxBlock, false>), dim3(grid), dim3(kMinmaxBlock), 0, stream, in, numel, state, ep);
 }
 
 MinmaxEpilogue to_epilogue(const MinmaxAction& a) {
@@ -152,37 +160,54 @@ void launch_quantize(const QuantLaunch& q, hipStream_t stream, int num_cu) {
 
 namespace {
 
+// One block per CU is all the fused kernel asks for; if an instantiation could not even get that (register / LDS budget of a
+// future compiler or device), the launch is refused and the caller takes the two-launch path.  Asked once per instantiation.
+template <typename K>
+bool fused_kernel_fits(K kernel) {
+    int blocks = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, kFusedBlock, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return blocks >= 1;
+}
+
 template <int DT_IN, int BITS, int MODE>
-void fused_launch(const FusedGroups& g, const QuantParams& p, FusedState* states, const FusedReduce* red, hipStream_t stream) {
+bool fused_launch(const FusedGroups& g, const QuantParams& p, FusedState* states, const FusedReduce* red, hipStream_t stream) {
     const dim3 grid(static_cast<unsigned>(g.count * g.blocks_per_group));
-    if (red == nullptr)
-        hipLaunchKernelGGL((fused_params_quantize_kernel<DT_IN, BITS, MODE, kFusedRegRounds, kFusedLdsRounds, kFusedLdsRounds, kFusedBlock>), grid,
-                           dim3(kFusedBlock), 0, stream, g, p, states, FusedReduce {});
-    else   // the terms to add have the quantized type this call produces (chunks of one all-reduce)
-        hipLaunchKernelGGL((fused_params_quantize_kernel<DT_IN, BITS, MODE, kFusedReduceRegRounds, kFusedLdsRounds, kFusedLdsRounds, kFusedBlock, ST_WT, false, 4, BITS>),
-                           grid, dim3(kFusedBlock), 0, stream, g, p, states, *red);
+    if (red == nullptr) {
+        auto kernel = fused_params_quantize_kernel<DT_IN, BITS, MODE, kFusedRegRounds, kFusedLdsRounds, kFusedLdsRounds, kFusedBlock, ST_WT, false, 4, 0, kFusedAllGather>;
+        static const bool fits = fused_kernel_fits(kernel);
+        if (!fits) return false;
+        hipLaunchKernelGGL(kernel, grid, dim3(kFusedBlock), 0, stream, g, p, states, FusedReduce {});
+    } else {   // the terms to add have the quantized type this call produces (chunks of one all-reduce)
+        auto kernel = fused_params_quantize_kernel<DT_IN, BITS, MODE, kFusedReduceRegRounds, kFusedLdsRounds, kFusedLdsRounds, kFusedBlock, ST_WT, false, 4, BITS, kFusedAllGather>;
+        static const bool fits = fused_kernel_fits(kernel);
+        if (!fits) return false;
+        hipLaunchKernelGGL(kernel, grid, dim3(kFusedBlock), 0, stream, g, p, states, *red);
+    }
+    return true;
 }
 
 template <int DT_IN, int BITS>
-void fused_mode(int round_mode, const FusedGroups& g, const QuantParams& p, FusedState* states, const FusedReduce* red, hipStream_t stream) {
+bool fused_mode(int round_mode, const FusedGroups& g, const QuantParams& p, FusedState* states, const FusedReduce* red, hipStream_t stream) {
     switch (round_mode) {
         case RM_NEAREST_FAST:
             // fp32 -> uint2 has no SIMD fast path in the reference: generic int64 step everywhere, as in launch_quantize
-            if constexpr (DT_IN == DT_F32 && BITS == 2) fused_launch<DT_IN, BITS, RM_NEAREST_I64>(g, p, states, red, stream);
-            else fused_launch<DT_IN, BITS, RM_NEAREST_FAST>(g, p, states, red, stream);
-            return;
-        case RM_STOCH_CALL: fused_launch<DT_IN, BITS, RM_STOCH_CALL>(g, p, states, red, stream); return;
-        case RM_STOCH_ELEM: fused_launch<DT_IN, BITS, RM_STOCH_ELEM>(g, p, states, red, stream); return;
+            if constexpr (DT_IN == DT_F32 && BITS == 2) return fused_launch<DT_IN, BITS, RM_NEAREST_I64>(g, p, states, red, stream);
+            else return fused_launch<DT_IN, BITS, RM_NEAREST_FAST>(g, p, states, red, stream);
+        case RM_STOCH_CALL: return fused_launch<DT_IN, BITS, RM_STOCH_CALL>(g, p, states, red, stream);
+        case RM_STOCH_ELEM: return fused_launch<DT_IN, BITS, RM_STOCH_ELEM>(g, p, states, red, stream);
         default: panic("invalid round mode %d", round_mode);
     }
 }
 
 template <int DT_IN>
-void fused_bits(int dt_out, int round_mode, const FusedGroups& g, const QuantParams& p, FusedState* states, const FusedReduce* red, hipStream_t stream) {
+bool fused_bits(int dt_out, int round_mode, const FusedGroups& g, const QuantParams& p, FusedState* states, const FusedReduce* red, hipStream_t stream) {
     switch (dt_out) {
-        case DT_UINT8: fused_mode<DT_IN, 8>(round_mode, g, p, states, red, stream); return;
-        case DT_UINT4: fused_mode<DT_IN, 4>(round_mode, g, p, states, red, stream); return;
-        case DT_UINT2: fused_mode<DT_IN, 2>(round_mode, g, p, states, red, stream); return;
+        case DT_UINT8: return fused_mode<DT_IN, 8>(round_mode, g, p, states, red, stream);
+        case DT_UINT4: return fused_mode<DT_IN, 4>(round_mode, g, p, states, red, stream);
+        case DT_UINT2: return fused_mode<DT_IN, 2>(round_mode, g, p, states, red, stream);
         default: panic("invalid quantization types: %d -> %d", DT_IN, dt_out);
     }
 }
@@ -196,10 +221,25 @@ size_t fused_state_bytes() { return sizeof(FusedState) * kFusedMaxGroups; }
 void init_fused_state(void* state, hipStream_t stream) {
     PQ_HIP(hipMemsetAsync(state, 0, fused_state_bytes(), stream));
     FusedState* st = static_cast<FusedState*>(state);
+    static_assert(static_cast<uint32_t>(kFusedNotArrived) == static_cast<uint32_t>(kFusedNotArrived >> 32), "the empty-slot word is one repeated dword");
     for (int g = 0; g < kFusedMaxGroups; ++g) {
-        launch_arm_slots(&st[g].slots[0][0], stream);
-        launch_arm_slots(&st[g].slots[1][0], stream);
+        launch_arm_slots(&st[g].slots[0][0], stream, false);
+        launch_arm_slots(&st[g].slots[1][0], stream, false);
+        PQ_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&st[g].gathered[0][0]), static_cast<int>(static_cast<uint32_t>(kFusedNotArrived)),
+                                 sizeof(st[g].gathered) / sizeof(uint32_t), stream));
     }
+}
+
+uint64_t fused_state_bailouts(const void* state, hipStream_t stream) {
+    const FusedState* st = static_cast<const FusedState*>(state);
+    uint64_t total = 0;
+    for (int g = 0; g < kFusedMaxGroups; ++g) {
+        uint32_t n = 0;
+        PQ_HIP(hipMemcpyAsync(&n, &st[g].bailouts, sizeof n, hipMemcpyDeviceToHost, stream));
+        PQ_HIP(hipStreamSynchronize(stream));
+        total += n;
+    }
+    return total;
 }
 
 // Sub-grid size for `count` tensors of which the largest has `max_numel` elements, or 0 when the batch cannot take the fused
@@ -209,7 +249,7 @@ void init_fused_state(void* state, hipStream_t stream) {
 static int fused_blocks_per_group(int64_t max_numel, int dt_in, int count, int num_cu) {
     if (count < 1 || count > kFusedMaxGroups || num_cu < count) return 0;
     const int64_t n_vec = n_vec_of(max_numel, dt_in);
-    const int cap = num_cu / count;
+    const int cap = std::min(num_cu / count, kFusedMaxBlocks);
     if (fused_rounds(n_vec, cap, kFusedBlock) > kFusedMaxRounds) return 0;   // on chip entirely, or mostly with a streamed remainder
     const int64_t per = static_cast<int64_t>(kFusedBlock) * kFusedMinRounds;
     return static_cast<int>(std::min<int64_t>(cap, std::max<int64_t>((n_vec + per - 1) / per, 1)));
@@ -238,18 +278,17 @@ bool launch_fused_params_quantize_batch(const QuantLaunch& q, const FusedBatch& 
     g.count = b.count;
     g.blocks_per_group = fused_blocks_per_group(max_numel, q.dt_in, b.count, num_cu);
     if (g.blocks_per_group == 0) return false;
+    g.bail_ticks = q.barrier_timeout_us * 100u;   // 100 MHz wall clock; 0 = the kernel's default (1 ms)
     QuantParams p {};
     p.threshold = q.threshold;
     p.seed_lo = static_cast<uint32_t>(q.seed);
     p.seed_hi = static_cast<uint32_t>(q.seed >> 32);
     p.index_base = q.index_base;
     FusedState* states = static_cast<FusedState*>(state);
-    switch (q.dt_in) {
-        case DT_F32: fused_bits<DT_F32>(q.dt_out, q.round_mode, g, p, states, nullptr, stream); break;
-        default: fused_bits<DT_BF16>(q.dt_out, q.round_mode, g, p, states, nullptr, stream); break;
-    }
+    const bool launched = q.dt_in == DT_F32 ? fused_bits<DT_F32>(q.dt_out, q.round_mode, g, p, states, nullptr, stream)
+                                            : fused_bits<DT_BF16>(q.dt_out, q.round_mode, g, p, states, nullptr, stream);
     PQ_HIP(hipGetLastError());
-    return true;
+    return launched;
 }
 
 bool launch_fused_reduce_quantize(const QuantLaunch& q, const DequantSumLaunch& terms, void* state, void* device_param_record, hipStream_t stream,
@@ -276,18 +315,17 @@ bool launch_fused_reduce_quantize(const QuantLaunch& q, const DequantSumLaunch& 
     g.params[0] = static_cast<ParamRecord*>(device_param_record);
     g.count = 1;
     g.blocks_per_group = bpg;
+    g.bail_ticks = q.barrier_timeout_us * 100u;
     QuantParams p {};
     p.threshold = q.threshold;
     p.seed_lo = static_cast<uint32_t>(q.seed);
     p.seed_hi = static_cast<uint32_t>(q.seed >> 32);
     p.index_base = q.index_base;
     FusedState* states = static_cast<FusedState*>(state);
-    switch (q.dt_in) {
-        case DT_F32: fused_bits<DT_F32>(q.dt_out, q.round_mode, g, p, states, &red, stream); break;
-        default: fused_bits<DT_BF16>(q.dt_out, q.round_mode, g, p, states, &red, stream); break;
-    }
+    const bool launched = q.dt_in == DT_F32 ? fused_bits<DT_F32>(q.dt_out, q.round_mode, g, p, states, &red, stream)
+                                            : fused_bits<DT_BF16>(q.dt_out, q.round_mode, g, p, states, &red, stream);
     PQ_HIP(hipGetLastError());
-    return true;
+    return launched;
 }
 
 bool launch_fused_params_quantize(const QuantLaunch& q, void* state, void* device_param_record, hipStream_t stream, int num_cu) {
@@ -502,8 +540,8 @@ void launch_requantize(const RequantLaunch& r, hipStream_t stream, int num_cu) {
     PQ_HIP(hipGetLastError());
 }
 
-void launch_arm_slots(int32_t* slots, hipStream_t stream) {
-    hipLaunchKernelGGL(arm_slots_kernel, dim3(1), dim3(64), 0, stream, slots);
+void launch_arm_slots(int32_t* slots, hipStream_t stream, bool scan_state) {
+    hipLaunchKernelGGL(arm_slots_kernel, dim3(1), dim3(64), 0, stream, slots, scan_state ? 1 : 0);
     PQ_HIP(hipGetLastError());
 }
 
@@ -512,7 +550,16 @@ void launch_minmax_epilogue(int32_t* state, const MinmaxAction& action, bool rea
     PQ_HIP(hipGetLastError());
 }
 
-int minmax_state_ints() { return kMinmaxStateInts; }
+int minmax_state_ints() { return kMinmaxScanStateInts; }
+
+__global__ void __launch_bounds__(64) publish_seq_kernel(uint32_t* word, uint32_t seq) {
+    if (threadIdx.x == 0) __hip_atomic_store(word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+void launch_publish_seq(uint32_t* host_visible_word, uint32_t seq, hipStream_t stream) {
+    hipLaunchKernelGGL(publish_seq_kernel, dim3(1), dim3(64), 0, stream, host_visible_word, seq);
+    PQ_HIP(hipGetLastError());
+}
 
 void launch_minmax(const void* in, int dt_in, int64_t numel, int32_t* state, const MinmaxAction& action, hipStream_t stream, int num_cu) {
     if (numel <= 0) panic("launch_minmax: empty input (an armed state buffer already holds the identities)");

@@ -23,6 +23,7 @@ struct QuantLaunch {
     int ref_head;
     int64_t ref_total;
     int64_t ref_index0;
+    uint32_t barrier_timeout_us;   // fused launches: longest wait at the grid barrier before a block gives up its share (0 = 1 ms)
 };
 
 struct DequantLaunch {
@@ -91,9 +92,10 @@ void launch_dequantize_batch(const DequantBatchLaunch& d, hipStream_t stream);
 void launch_quantize(const QuantLaunch& q, hipStream_t stream, int num_cu);
 void launch_dequantize(const DequantLaunch& d, hipStream_t stream, int num_cu);
 void launch_requantize(const RequantLaunch& r, hipStream_t stream, int num_cu);
-// Min/max scan.  `state` is a minmax_state_ints() int32 device buffer armed once with launch_arm_slots: 64 slot key pairs on
-// separate 128-byte lines plus arrival counters.  The block that arrives last folds the slots, re-arms the buffer and runs
-// the epilogue inside the SAME launch, so a scan is one kernel and always leaves `state` armed:
+// Min/max scan.  `state` is a minmax_state_ints() int32 device buffer armed once with launch_arm_slots: one 8-byte result word
+// per block (the "gather" end: every block stores its word, the highest block folds them) and, for scans that accumulate
+// into one state (MM_NONE), 64 slot key pairs on separate 128-byte lines plus arrival counters.  Either way the block that finishes
+// the scan re-arms what it read and runs the epilogue inside the SAME launch, so a scan is one kernel and always leaves `state` armed:
 //   MM_KEYS_SET / MM_KEYS_MIN  dst = int32[2] device {key(min), key(-max)}, overwritten / accumulated with MIN
 //   MM_PUBLISH                 dst = device-visible address of a MinmaxMailboxHost in pinned fine-grained host memory
 //   MM_PARAMS                  dst = 16-byte device ParamRecord (scale, 1/scale, zero point) for `bits`-wide quantization
@@ -113,7 +115,7 @@ struct MinmaxMailboxHost {
 void launch_minmax(const void* in, int dt_in, int64_t numel, int32_t* state, const MinmaxAction& action, hipStream_t stream, int num_cu);
 // Fold + epilogue as a launch of its own (after MM_NONE scans, or on an armed buffer for an empty input: identities).
 void launch_minmax_epilogue(int32_t* state, const MinmaxAction& action, bool rearm, hipStream_t stream);
-void launch_arm_slots(int32_t* state, hipStream_t stream);
+void launch_arm_slots(int32_t* state, hipStream_t stream, bool scan_state = true);   // scan_state: a minmax_state_ints() buffer (slots + per-block words)
 int minmax_state_ints();
 // compute_quant_params + quantize in one launch with the tensor resident on chip between the two passes (fused_kernels.hpp).
 // q.inv_scale / q.zero_point / q.dyn_params are ignored: the parameters come from the data and are also written to
@@ -139,8 +141,12 @@ bool fused_launch_applies(const QuantLaunch& q, int num_cu);   // the test launc
 // fused call gives the same bytes.  Declared after DequantSumLaunch.
 bool launch_fused_reduce_quantize(const QuantLaunch& q, const DequantSumLaunch& terms, void* state, void* device_param_record, hipStream_t stream,
                                   int num_cu);
+// one-thread kernel: system-scope store of `seq` into a host-visible word, behind everything enqueued on `stream` so far
+void launch_publish_seq(uint32_t* host_visible_word, uint32_t seq, hipStream_t stream);
 size_t fused_state_bytes();
 void init_fused_state(void* state, hipStream_t stream);
+// blocks of fused launches on `state` that left their grid barrier early so far (synchronises `stream`)
+uint64_t fused_state_bailouts(const void* state, hipStream_t stream);
 
 // Aborts with the reference's panic convention (red message on stderr, abort()) on a HIP error.
 void check_hip(hipError_t e, const char* what, const char* file, int line);

@@ -36,6 +36,11 @@ constexpr int kMinmaxSlots = 64;          // key pairs per slot buffer
 constexpr int kMinmaxSlotStride = 32;     // int32 per slot: one 128-byte line each -- [0] key(min), [1] key(-max), [2] arrivals
 constexpr int kMinmaxSlotInts = kMinmaxSlots * kMinmaxSlotStride;
 constexpr int kMinmaxStateInts = kMinmaxSlotInts + kMinmaxSlotStride;   // + one line: [0] = slots whose blocks have all arrived
+// "Gather" end of a scan (minmax_block_end_gather): behind the slot area, one 8-byte {key(min), key(-max)} word per BLOCK.
+constexpr int kMinmaxGatherMax = 2048;                                  // grids up to this many blocks take the gather end
+constexpr int kMinmaxScanStateInts = kMinmaxStateInts + 2 * kMinmaxGatherMax;
+constexpr unsigned long long kMinmaxNotArrived = 0x7fffffff7fffffffull;   // both halves are keys of NaN patterns: never a block's result
+static_assert(kMinmaxStateInts % 2 == 0, "the gather words are 8-byte aligned");
 
 // What happens to the folded {key(min), key(-max)} pair once the last block of a scan has arrived.  The scan kernel runs
 // this itself (no second launch: a one-wave fold kernel costs 4-5 us, a quarter of the scan at numel 27 264 000).
@@ -64,13 +69,15 @@ struct MinmaxMailbox {
 };
 
 // src/piquant.cpp:245-258 in IEEE double (f64 division / round, correctly rounded conversions): bit-identical to the host
-// epilogue on every tested range.  A degenerate range gives (1.0, qmax >> 1) as in the reference (:249-252); a NaN or
-// negative scale cannot abort from the device and is produced as is.
+// epilogue on every tested range.  A degenerate range gives (1.0, qmax >> 1) as in the reference (:249-252).  The device cannot
+// abort like the synchronous call does on a negative scale (:373,379), and the one way to get there is max < min, i.e. the armed
+// identities (+FLT_MAX, -FLT_MAX): nothing was scanned (an empty tensor, or nothing but NaNs).  That case also gets the
+// degenerate record, so that no consumer of a device record ever sees a negative scale.
 __device__ __forceinline__ void quant_params_epilogue(int32_t k_min, int32_t k_negmax, int bits, float& scale, int64_t& zp) {
     const double r_min = static_cast<double>(key_to_float(k_min));
     const double r_max = static_cast<double>(-key_to_float(k_negmax));
     const uint64_t type_max = (uint64_t {1} << bits) - 1;
-    if (r_max == r_min) {
+    if (r_max <= r_min) {
         scale = 1.0f;
         zp = static_cast<int64_t>(type_max >> 1);
     } else {
@@ -103,15 +110,24 @@ __device__ __forceinline__ uint32_t fold_keys(int32_t* keys, float lo, float hi)
     return one;
 }
 
-// Arms a scan state buffer: identity keys (+FLT_MAX for min and for -max), all arrival counters zero.
-__global__ void __launch_bounds__(64) arm_slots_kernel(int32_t* state) {
+// Arms a scan state buffer: identity keys (+FLT_MAX for min and for -max), all arrival counters zero; with_gather != 0 (a
+// kMinmaxScanStateInts buffer, as opposed to the kMinmaxStateInts slot buffers inside the fused kernel's state) also empties the
+// per-block words of the gather end.
+__global__ void __launch_bounds__(64) arm_slots_kernel(int32_t* state, int with_gather) {
     if (threadIdx.x < kMinmaxSlots) {
         state[threadIdx.x * kMinmaxSlotStride + 0] = float_to_key(3.402823466e+38f);
         state[threadIdx.x * kMinmaxSlotStride + 1] = float_to_key(3.402823466e+38f);
         state[threadIdx.x * kMinmaxSlotStride + 2] = 0;
     }
     if (threadIdx.x == 0) state[kMinmaxSlotInts] = 0;
+    if (with_gather) {
+        unsigned long long* words = reinterpret_cast<unsigned long long*>(state + kMinmaxStateInts);
+        for (int i = threadIdx.x; i < kMinmaxGatherMax; i += 64) words[i] = kMinmaxNotArrived;
+    }
 }
+
+// What a finished scan does with its folded key pair (lane 0 of the finishing wave).
+__device__ __forceinline__ void minmax_action(int32_t k0, int32_t k1, const MinmaxEpilogue& ep);
 
 // One wave (all 64 lanes) folds the slots, re-arms them if asked and performs the epilogue action.
 __device__ __forceinline__ void minmax_finish(int32_t* state, int lane, const MinmaxEpilogue& ep, bool rearm) {
@@ -127,7 +143,10 @@ __device__ __forceinline__ void minmax_finish(int32_t* state, int lane, const Mi
         k0 = min(k0, __shfl_xor(k0, off, 64));
         k1 = min(k1, __shfl_xor(k1, off, 64));
     }
-    if (lane != 0) return;
+    if (lane == 0) minmax_action(k0, k1, ep);
+}
+
+__device__ __forceinline__ void minmax_action(int32_t k0, int32_t k1, const MinmaxEpilogue& ep) {
     if (ep.action == EP_KEYS_SET) {
         int32_t* keys = static_cast<int32_t*>(ep.dst);
         keys[0] = k0;
@@ -195,7 +214,54 @@ __device__ __forceinline__ void minmax_block_end(float lo, float hi, const float
     if (__builtin_amdgcn_readfirstlane(last)) minmax_finish(state, lane, ep, true);
 }
 
-template <int DT_IN, int U, bool NT, int BLOCK>
+// "Gather" end of a scan block, for grids of at most kMinmaxGatherMax blocks whose result goes somewhere (not EP_NONE).  Every block
+// stores its {key(min), key(-max)} word into its OWN slot with one plain device-scope store and is done -- no returning atomic,
+// no arrival counter.  The block with the highest index, after its own part of the scan, sweeps the words (wave 0, one 8-byte load
+// per lane and 64 slots) until none is empty, folds them, empties them again for the next scan and runs the epilogue.  Critical
+// path behind the slowest block: its store becoming visible plus one sweep (~2 memory round trips) instead of the slot
+// protocol's three or four dependent ones (two key atomics -> slot arrival -> slot-count arrival -> fold loads): measured
+// [tools/tune_kernels.hip mm] at numel 27 264 000.  Nobody waits for the sweeping block and it waits for nobody that needs its
+// CU, so residency does not matter: blocks that start late are simply seen late.
+template <int WAVES>
+__device__ __forceinline__ void minmax_block_end_gather(float lo, float hi, const float* s_lo, const float* s_hi, int32_t* state, const MinmaxEpilogue& ep) {
+    const int lane = threadIdx.x & 63;
+    if ((threadIdx.x >> 6) != 0) return;
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) {
+        lo = __builtin_fminf(lo, s_lo[w]);
+        hi = __builtin_fmaxf(hi, s_hi[w]);
+    }
+    unsigned long long* words = reinterpret_cast<unsigned long long*>(state + kMinmaxStateInts);
+    const uint32_t G = gridDim.x, me = blockIdx.x;
+    const unsigned long long mine = static_cast<unsigned long long>(static_cast<uint32_t>(float_to_key(lo))) |
+                                    (static_cast<unsigned long long>(static_cast<uint32_t>(float_to_key(-hi))) << 32);
+    if (me != G - 1) {
+        if (lane == 0) __hip_atomic_store(words + me, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    int32_t k0 = float_to_key(lo), k1 = float_to_key(-hi);   // the sweeping block's own result never travels through memory
+    for (uint32_t base = 0; base + 1 < G; base += 64) {      // slots [0, G - 1)
+        const uint32_t slot = base + lane;
+        unsigned long long w = slot + 1 < G ? kMinmaxNotArrived : ~0ull;
+        while (__any(w == kMinmaxNotArrived ? 1 : 0)) {
+            if (w == kMinmaxNotArrived) w = __hip_atomic_load(words + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__any(w == kMinmaxNotArrived ? 1 : 0)) __builtin_amdgcn_s_sleep(2);
+        }
+        if (slot + 1 < G) {
+            __hip_atomic_store(words + slot, kMinmaxNotArrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // armed for the next scan
+            k0 = min(k0, static_cast<int32_t>(static_cast<uint32_t>(w)));
+            k1 = min(k1, static_cast<int32_t>(static_cast<uint32_t>(w >> 32)));
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        k0 = min(k0, __shfl_xor(k0, off, 64));
+        k1 = min(k1, __shfl_xor(k1, off, 64));
+    }
+    if (lane == 0) minmax_action(k0, k1, ep);
+}
+
+template <int DT_IN, int U, bool NT, int BLOCK, bool GATHER = false>
 __global__ void __launch_bounds__(BLOCK) minmax_kernel(const void* __restrict__ in, int64_t numel, int32_t* state, MinmaxEpilogue ep) {
     constexpr int EPV = InVec<DT_IN>::EPV;
     constexpr int WAVES = BLOCK / 64;
@@ -248,11 +314,12 @@ __global__ void __launch_bounds__(BLOCK) minmax_kernel(const void* __restrict__ 
         s_hi[wave] = hi;
     }
     __syncthreads();
-    minmax_block_end<WAVES>(lo, hi, s_lo, s_hi, state, ep);
+    if constexpr (GATHER) minmax_block_end_gather<WAVES>(lo, hi, s_lo, s_hi, state, ep);
+    else minmax_block_end<WAVES>(lo, hi, s_lo, s_hi, state, ep);
 }
 
 // Same scan for buffers that are not 16-byte aligned.
-template <int DT_IN, int BLOCK>
+template <int DT_IN, int BLOCK, bool GATHER = false>
 __global__ void __launch_bounds__(BLOCK) minmax_scalar_kernel(const void* __restrict__ in, int64_t numel, int32_t* state, MinmaxEpilogue ep) {
     constexpr int WAVES = BLOCK / 64;
     float lo = 3.402823466e+38f, hi = -3.402823466e+38f;
@@ -271,7 +338,8 @@ __global__ void __launch_bounds__(BLOCK) minmax_scalar_kernel(const void* __rest
         s_hi[wave] = hi;
     }
     __syncthreads();
-    minmax_block_end<WAVES>(lo, hi, s_lo, s_hi, state, ep);
+    if constexpr (GATHER) minmax_block_end_gather<WAVES>(lo, hi, s_lo, s_hi, state, ep);
+    else minmax_block_end<WAVES>(lo, hi, s_lo, s_hi, state, ep);
 }
 
 }  // namespace pq

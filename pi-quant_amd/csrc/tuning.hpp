@@ -41,6 +41,7 @@ constexpr int kMinmaxU = 4;
 constexpr bool kMinmaxNT = true;
 constexpr int kMinmaxBlock = 256;
 constexpr int kMinmaxBlocksPerCU = 2;
+constexpr bool kMinmaxGatherEnd = true;   // end of a scan: per-block result words swept by the highest block (true) or slot atomics + arrival counters
 
 // fused params + quantize (fused_kernels.hpp): one 1024-thread block per CU (4 waves per SIMD, 128 VGPRs each); per thread 18
 // 16-byte vectors stay in registers and 9 more in LDS (144 KiB per block), all 27 loads issued before the first use.
@@ -58,6 +59,7 @@ constexpr int kFusedLdsRounds = 9;
 // tuned kernels (326 vs 298 us), so larger tensors take the two launches.
 constexpr int kFusedMaxRounds = 64;
 constexpr int kFusedReduceRegRounds = 10;   // the reduce variant needs registers for its terms (8 loads in flight): fewer resident vectors, no spills (80 MB)
+constexpr bool kFusedAllGather = true;   // grid barrier of the fused kernel: all-gather of per-block key words (true) or slot atomics + arrival counter + published word
 constexpr int kFusedMinRounds = 2;   // grid sizing for small tensors: vectors per thread before another block joins
 
 constexpr int kScalarBlock = 256;   // guarded kernels for misaligned buffers

@@ -165,6 +165,11 @@ class Context:
             C.piquant_hip_set_blocking(self._ctx, 1 if blocking else 0)
             self._blocking = bool(blocking)
 
+    def set_blocking_wait(self, mode: str) -> None:
+        """How a blocking call waits for the GPU: 'sync' (hipStreamSynchronize), 'write32' (the command processor writes a pinned host
+        word behind the kernel, the host spins on it) or 'kernel' (a one-thread kernel writes it); include/piquant_hip.h."""
+        C.piquant_hip_set_blocking_wait(self._ctx, {'sync': 0, 'write32': 1, 'kernel': 2}[mode])
+
     def assume_device_pointers(self, assume: bool) -> None:
         """Skip the native pointer classification for the calls that follow (all buffers are device or pinned memory).
         The ``*_ptr`` methods set it per call from their ``_device_ptrs`` argument (False unless the torch binding knows
@@ -266,6 +271,15 @@ class Context:
     def set_fusion(self, enabled: bool) -> None:
         """False: ``quantize_dynamic`` always runs the scan (with its parameter epilogue) and the quantize kernel as two launches (for A/B timing)."""
         C.piquant_hip_set_fusion(self._ctx, 1 if enabled else 0)
+
+    def set_barrier_timeout_us(self, microseconds: int) -> None:
+        """Longest wait of a block at the fused kernel's grid barrier before it hands its share over and frees its CU
+        (include/piquant_hip.h); 0 = default (1 ms)."""
+        C.piquant_hip_set_barrier_timeout_us(self._ctx, int(microseconds))
+
+    def barrier_bailouts(self) -> int:
+        """Blocks of this context's fused launches that ever left their barrier early (0 in normal operation; synchronises)."""
+        return int(C.piquant_hip_barrier_bailouts(self._ctx))
 
     def dequantize_dp_ptr(self, ptr_in: int, dtype_in: DataType, ptr_out: int, dtype_out: DataType, numel: int, params_ptr: int,
                           reduce_op: ReduceOp, _device_ptrs: bool = False) -> None:

@@ -1,0 +1,170 @@
+"""GPU: the fused kernel's grid barrier when its grid is NOT fully resident (VERDICT r01 "co-residency is assumed, not guaranteed").
+
+The one-launch params+quantize kernel waits at a grid barrier.  These tests put it where a plain launch gives no guarantee --
+other kernels holding CUs, two barrier kernels launched at the same moment from two threads -- and where round 1 spun until a
+trap: it must finish, and its bytes and parameter record must equal the two-launch path's (which equals the oracle, test_gpu_parity).
+"""
+import ctypes
+import subprocess
+import threading
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parent.parent
+N1 = 27_264_000
+
+
+@pytest.fixture(scope="module")
+def hog(tmp_path_factory):
+    so = tmp_path_factory.mktemp("hog") / "libcuhog.so"
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", str(ROOT / "tests" / "cu_hog.hip"), "-o", str(so)], check=True)
+    import piquant  # noqa: F401  (torch + libpiquant first: one HIP runtime in the process)
+
+    lib = ctypes.CDLL(str(so))
+    lib.cu_hog_launch.restype = ctypes.c_int
+    lib.cu_hog_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_void_p]
+    return lib
+
+
+def _reference(ctx, x, qdtype):
+    """two launches (scan with the parameter epilogue, then quantize): no grid barrier involved"""
+    import piquant
+
+    ctx.set_fusion(False)
+    q, rec = piquant.torch.quantize_dynamic(x, dtype=qdtype, ctx=ctx)
+    torch.cuda.synchronize()
+    ctx.set_fusion(True)
+    return piquant.torch.packed_bytes(q).clone(), rec.clone()
+
+
+@pytest.mark.parametrize("fdtype,qname", [(torch.float32, "uint8"), (torch.bfloat16, "quint4x2"), (torch.float32, "quint2x4")])
+def test_barrier_timeout_of_one_microsecond_still_gives_the_right_bytes(fdtype, qname):
+    """No hog needed to reach the hand-over path: with a 1 us limit every block that arrives more than 1 us before the last one
+    leaves, and the few blocks still there adopt ~250 shares from HBM.  Same bytes, same record -- and the path was really taken."""
+    import piquant
+
+    ctx = piquant.Context()
+    qdtype = getattr(torch, qname)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    for n in (N1, N1 + 5, 3_000_001):
+        x = torch.empty(n, device="cuda").uniform_(-1, 1, generator=g).to(fdtype)
+        want_q, want_rec = _reference(ctx, x, qdtype)
+        before = ctx.barrier_bailouts()
+        ctx.set_barrier_timeout_us(1)
+        for _ in range(3):
+            q, rec = piquant.torch.quantize_dynamic(x, dtype=qdtype, ctx=ctx)
+        torch.cuda.synchronize()
+        ctx.set_barrier_timeout_us(0)
+        assert torch.equal(piquant.torch.packed_bytes(q), want_q) and torch.equal(rec, want_rec), (n, qname)
+        if n >= N1:
+            assert ctx.barrier_bailouts() > before, "the 1 us limit never fired: the hand-over path was not exercised"
+        # and the state is fit for ordinary launches again
+        q2, rec2 = piquant.torch.quantize_dynamic(x, dtype=qdtype, ctx=ctx)
+        torch.cuda.synchronize()
+        assert torch.equal(piquant.torch.packed_bytes(q2), want_q) and torch.equal(rec2, want_rec)
+
+
+def test_fused_calls_next_to_a_kernel_that_holds_cus(hog):
+    """96 CUs are held for 30 ms by another stream; fused calls issued meanwhile cannot get their whole grid resident.  Round 1
+    would have waited (and trapped after ~2 s had the holder depended on it); now the resident blocks hand their shares over
+    after 200 us, the rest of the grid starts on the freed CUs, and the results are identical."""
+    import piquant
+
+    ctx = piquant.Context()
+    side = torch.cuda.Stream()
+    sink = torch.zeros(4, dtype=torch.int32, device="cuda")
+    g = torch.Generator(device="cuda")
+    g.manual_seed(4)
+    x = torch.empty(N1, device="cuda").uniform_(-1, 1, generator=g)
+    want_q, want_rec = _reference(ctx, x, torch.uint8)
+    ctx.set_barrier_timeout_us(200)
+    before = ctx.barrier_bailouts()
+    torch.cuda.synchronize()
+    assert hog.cu_hog_launch(ctypes.c_void_p(side.cuda_stream), 96, 30_000, ctypes.c_void_p(sink.data_ptr())) == 0
+    outs = []
+    for _ in range(8):
+        outs.append(piquant.torch.quantize_dynamic(x, dtype=torch.uint8, ctx=ctx))
+    torch.cuda.synchronize()
+    ctx.set_barrier_timeout_us(0)
+    for q, rec in outs:
+        assert torch.equal(q, want_q) and torch.equal(rec, want_rec)
+    assert ctx.barrier_bailouts() > before, "the holder never got in the way: nothing was tested"
+
+
+def test_reduce_variant_hands_over_too():
+    """the owner's step of the mesh all-reduce (acc + sum of dequantized chunks, quantized in the same launch) under a 1 us limit"""
+    import piquant
+
+    ctx = piquant.Context()
+    n = 3_408_000 * 4
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    acc = torch.empty(n, device="cuda").uniform_(-1, 1, generator=g)
+    chunks = [torch.empty(n, device="cuda").uniform_(-1, 1, generator=g) for _ in range(3)]
+    qs = [piquant.torch.quantize_dynamic(c, dtype=torch.uint8, ctx=ctx) for c in chunks]
+    ctx.set_fusion(False)
+    want_q, want_rec = piquant.torch.reduce_quantize_dynamic(acc.clone(), [q for q, _ in qs], [r for _, r in qs], dtype=torch.uint8, ctx=ctx)
+    torch.cuda.synchronize()
+    ctx.set_fusion(True)
+    before = ctx.barrier_bailouts()
+    ctx.set_barrier_timeout_us(1)
+    q, rec = piquant.torch.reduce_quantize_dynamic(acc.clone(), [q for q, _ in qs], [r for _, r in qs], dtype=torch.uint8, ctx=ctx)
+    torch.cuda.synchronize()
+    ctx.set_barrier_timeout_us(0)
+    assert torch.equal(q, want_q) and torch.equal(rec, want_rec)
+    assert ctx.barrier_bailouts() > before
+
+
+def test_two_threads_two_contexts_launch_fused_kernels_at_once():
+    """two threads, two contexts, two streams -- their barrier kernels must never end up interleaved between each
+    other's wait and record (capi.cpp FusedLaunchOrder holds the per-device lock across wait + launch + record)."""
+    import piquant
+
+    g = torch.Generator(device="cuda")
+    g.manual_seed(6)
+    xs = [torch.empty(N1, device="cuda").uniform_(-1, 1, generator=g) * (i + 1) for i in range(2)]
+    ref_ctx = piquant.Context()
+    wants = [_reference(ref_ctx, x, torch.uint8) for x in xs]
+    errors = []
+
+    def work(i):
+        try:
+            torch.cuda.set_device(0)
+            ctx = piquant.Context()
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                outs = [piquant.torch.quantize_dynamic(xs[i], dtype=torch.uint8, ctx=ctx) for _ in range(150)]
+            stream.synchronize()
+            for q, rec in outs[::10] + outs[-1:]:
+                if not (torch.equal(q, wants[i][0]) and torch.equal(rec, wants[i][1])):
+                    errors.append((i, "mismatch"))
+            if ctx.barrier_bailouts() != 0:
+                errors.append((i, f"{ctx.barrier_bailouts()} blocks left a barrier early although launches are ordered"))
+        except Exception as exc:   # noqa: BLE001
+            errors.append((i, repr(exc)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+
+
+def test_device_record_of_an_empty_or_all_nan_tensor_is_the_degenerate_one():
+    """nothing scanned (max < min, the armed identities) must not leave a negative scale in a device record."""
+    import piquant
+
+    ctx = piquant.Context()
+    for x in (torch.empty(0, device="cuda"), torch.full((1000,), float("nan"), device="cuda"), torch.empty(0, device="cuda", dtype=torch.bfloat16)):
+        for qdtype, zp in ((torch.uint8, 127), (torch.quint4x2, 7), (torch.quint2x4, 1)):
+            rec = piquant.torch.compute_quant_params_device(x, dtype=qdtype, ctx=ctx)
+            assert piquant.torch.params_to_host(rec) == (1.0, zp)
+            q, rec2 = piquant.torch.quantize_dynamic(x, dtype=qdtype, ctx=ctx)
+            assert piquant.torch.params_to_host(rec2) == (1.0, zp) and q.numel() == x.numel()

@@ -9,6 +9,7 @@
 #include "minmax_kernels.hpp"
 #include "quant_kernels.hpp"
 #include "requant_kernels.hpp"
+#include "tuning.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -263,17 +264,21 @@ static void run_requant(const Bufs& b, int64_t numel, int num_cu, double bytes_p
     report("requantize", name, us, bytes_per_elem * numel);
 }
 
-template <int DT_IN, int U, bool NT, int BLOCK>
+static std::vector<int> g_mm_caps = {1, 2, 4, 8, 16, 32};
+
+template <int DT_IN, int U, bool NT, int BLOCK, bool GATHER = false>
 static void run_minmax(const Bufs& b, int64_t numel, int num_cu, int32_t* keys) {
-    for (int cap : {2, 4, 8, 16, 32}) {
+    for (int cap : g_mm_caps) {
         const unsigned grid = static_cast<unsigned>(cap * num_cu);
+        if (GATHER && grid > static_cast<unsigned>(kMinmaxGatherMax)) continue;
         const double us = time_us([&](int i) {
-            // production protocol: the last block folds the slots into a key pair and re-arms the state inside the launch
-            hipLaunchKernelGGL((minmax_kernel<DT_IN, U, NT, BLOCK>), dim3(grid), dim3(BLOCK), 0, g_stream, b.in[i % SETS], numel, keys,
-                               MinmaxEpilogue {EP_KEYS_SET, 0, 0u, keys + kMinmaxStateInts});
+            // production protocol: the finishing block folds the per-block results into a key pair and re-arms the state inside the launch
+            hipLaunchKernelGGL((minmax_kernel<DT_IN, U, NT, BLOCK, GATHER>), dim3(grid), dim3(BLOCK), 0, g_stream, b.in[i % SETS], numel, keys,
+                               MinmaxEpilogue {EP_KEYS_SET, 0, 0u, keys + kMinmaxScanStateInts});
         });
         char name[160];
-        std::snprintf(name, sizeof name, "in=%s U=%d nt=%d block=%d cap=%d grid=%u", DT_IN == DT_F32 ? "f32" : "bf16", U, NT ? 1 : 0, BLOCK, cap, grid);
+        std::snprintf(name, sizeof name, "in=%s U=%d nt=%d block=%d end=%s cap=%d grid=%u", DT_IN == DT_F32 ? "f32" : "bf16", U, NT ? 1 : 0, BLOCK,
+                      GATHER ? "gather" : "slots", cap, grid);
         report("minmax", name, us, (DT_IN == DT_F32 ? 4.0 : 2.0) * numel);
     }
 }
@@ -299,17 +304,17 @@ static FusedGroups one_group(const void* in, void* out, int64_t numel, ParamReco
     return g;
 }
 
-template <int R_REG, int R_LDS, int LDS_BATCH, int BLOCK, int STP = ST_WT, int SB = 4>
+template <int R_REG, int R_LDS, int LDS_BATCH, int BLOCK, int STP = ST_WT, int SB = 4, bool AG = true>
 static void run_fused(const Bufs& b, const FusedBufs& f, int64_t numel, int num_cu, int32_t* slots) {
     const int64_t n_vec = numel / 4;
-    char name[128];
-    std::snprintf(name, sizeof name, "f32->u8 fused R_REG=%d R_LDS=%d batch=%d block=%d stream_batch=%d st=%s", R_REG, R_LDS, LDS_BATCH, BLOCK, SB,
-                  STP == ST_WT ? "wt" : (STP == ST_NT ? "nt" : "plain"));
+    char name[160];
+    std::snprintf(name, sizeof name, "f32->u8 fused R_REG=%d R_LDS=%d batch=%d block=%d stream_batch=%d st=%s barrier=%s", R_REG, R_LDS, LDS_BATCH, BLOCK, SB,
+                  STP == ST_WT ? "wt" : (STP == ST_NT ? "nt" : "plain"), AG ? "allgather" : "counter");
     if (fused_rounds(n_vec, num_cu, BLOCK) > R_REG + R_LDS)
         std::fprintf(stderr, "%s: %lld rounds, %d of them resident\n", name, static_cast<long long>(fused_rounds(n_vec, num_cu, BLOCK)), R_REG + R_LDS);
     QuantParams p {};
     auto launch = [&](int i) {
-        hipLaunchKernelGGL((fused_params_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, R_REG, R_LDS, LDS_BATCH, BLOCK, STP, false, SB>), dim3(num_cu), dim3(BLOCK), 0,
+        hipLaunchKernelGGL((fused_params_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, R_REG, R_LDS, LDS_BATCH, BLOCK, STP, false, SB, 0, AG>), dim3(num_cu), dim3(BLOCK), 0,
                            g_stream, one_group(b.in[i % SETS], b.out[i % SETS], numel, f.rec, num_cu), p, f.st, FusedReduce {});
     };
     // correctness first: same bytes and record as scan (with parameter epilogue) -> quantize
@@ -342,7 +347,7 @@ static void run_fused(const Bufs& b, const FusedBufs& f, int64_t numel, int num_
     report("fused", name, us, 5.0 * numel);
     // where block 0 spends its time (100 MHz wall clock): one launch on a quiet device
     CK(hipStreamSynchronize(g_stream));
-    hipLaunchKernelGGL((fused_params_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, R_REG, R_LDS, LDS_BATCH, BLOCK, STP, true, SB>), dim3(num_cu), dim3(BLOCK), 0, g_stream,
+    hipLaunchKernelGGL((fused_params_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, R_REG, R_LDS, LDS_BATCH, BLOCK, STP, true, SB, 0, AG>), dim3(num_cu), dim3(BLOCK), 0, g_stream,
                        one_group(b.in[3], b.out[3], numel, f.rec, num_cu), p, f.st, FusedReduce {});
     CK(hipStreamSynchronize(g_stream));
     std::vector<uint64_t> t(static_cast<size_t>(num_cu) * 8);
@@ -385,8 +390,8 @@ int main(int argc, char** argv) {
         CK(hipMemsetAsync(b.out[s], 0x5a, numel, g_stream));
     }
     int32_t* keys = nullptr;
-    CK(hipMalloc(reinterpret_cast<void**>(&keys), (kMinmaxStateInts + 64) * sizeof(int32_t)));   // scan state + a folded key pair behind it
-    hipLaunchKernelGGL(arm_slots_kernel, dim3(1), dim3(64), 0, g_stream, keys);
+    CK(hipMalloc(reinterpret_cast<void**>(&keys), (kMinmaxScanStateInts + 64) * sizeof(int32_t)));   // scan state + a folded key pair behind it
+    hipLaunchKernelGGL(arm_slots_kernel, dim3(1), dim3(64), 0, g_stream, keys, 1);
     CK(hipStreamSynchronize(g_stream));
 
     std::printf("family,variant,us_per_launch_best,algo_GBps,frac_of_8TBps,us_per_launch_worst\n");
@@ -647,6 +652,23 @@ int main(int argc, char** argv) {
         run_dequant<2, DT_BF16, OP_SET, 4, true, 5, 256>(b, 2 * numel, num_cu, 2.25);
         run_dequant<2, DT_F32, OP_SET, 4, true, 5, 256>(b, numel, num_cu, 4.25);
     }
+    if (only == "mm2") {
+        // interleaved A/B of the scan's end protocol at the production geometry and its neighbours
+        g_rounds = 1;
+        g_mm_caps = {1, 2, 4};
+        for (int pass = 0; pass < 5; ++pass) {
+            run_minmax<DT_F32, 4, true, 256, false>(b, numel, num_cu, keys);
+            run_minmax<DT_F32, 4, true, 256, true>(b, numel, num_cu, keys);
+            run_minmax<DT_F32, 8, true, 256, true>(b, numel, num_cu, keys);
+            run_minmax<DT_F32, 4, true, 512, true>(b, numel, num_cu, keys);
+            run_minmax<DT_F32, 8, true, 512, true>(b, numel, num_cu, keys);
+            run_minmax<DT_F32, 4, true, 1024, true>(b, numel, num_cu, keys);
+            run_minmax<DT_BF16, 4, true, 256, false>(b, numel, num_cu, keys);
+            run_minmax<DT_BF16, 4, true, 256, true>(b, numel, num_cu, keys);
+        }
+        g_mm_caps = {1, 2, 4, 8, 16, 32};
+        g_rounds = 3;
+    }
     if (only == "all" || only == "mm") {
         run_minmax<DT_F32, 2, true, 256>(b, numel, num_cu, keys);
         run_minmax<DT_F32, 4, true, 256>(b, numel, num_cu, keys);
@@ -661,8 +683,10 @@ int main(int argc, char** argv) {
         FusedBufs f {};
         CK(hipMalloc(reinterpret_cast<void**>(&f.st), sizeof(FusedState)));
         CK(hipMemset(f.st, 0, sizeof(FusedState)));
-        hipLaunchKernelGGL(arm_slots_kernel, dim3(1), dim3(64), 0, g_stream, &f.st->slots[0][0]);
-        hipLaunchKernelGGL(arm_slots_kernel, dim3(1), dim3(64), 0, g_stream, &f.st->slots[1][0]);
+        hipLaunchKernelGGL(arm_slots_kernel, dim3(1), dim3(64), 0, g_stream, &f.st->slots[0][0], 0);
+        hipLaunchKernelGGL(arm_slots_kernel, dim3(1), dim3(64), 0, g_stream, &f.st->slots[1][0], 0);
+        CK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&f.st->gathered[0][0]), static_cast<int>(static_cast<uint32_t>(kFusedNotArrived)),
+                             sizeof(f.st->gathered) / sizeof(uint32_t), g_stream));
         CK(hipMalloc(reinterpret_cast<void**>(&f.rec), 64));
         CK(hipMalloc(reinterpret_cast<void**>(&f.rec_ref), 64));
         CK(hipMalloc(reinterpret_cast<void**>(&f.out_ref), numel + 4096));
@@ -676,7 +700,7 @@ int main(int argc, char** argv) {
             using T = QuantTile<DT_F32, 8, 2, 128>;
             const int64_t n_tiles = numel / T::BLOCK_ELEMS;
             const double us = time_us([&](int i) {
-                hipLaunchKernelGGL((minmax_kernel<DT_F32, 4, true, 256>), dim3(2 * num_cu), dim3(256), 0, g_stream, static_cast<const void*>(b.in[i % SETS]), numel,
+                hipLaunchKernelGGL((minmax_kernel<DT_F32, 4, true, 256, kMinmaxGatherEnd>), dim3(2 * num_cu), dim3(256), 0, g_stream, static_cast<const void*>(b.in[i % SETS]), numel,
                                    keys, MinmaxEpilogue {EP_PARAMS, 8, 0u, f.rec_ref});
                 hipLaunchKernelGGL((quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, 2, true, mem_policy(true, ST_WT), 128>), dim3(static_cast<unsigned>(std::max<int64_t>(n_tiles, 1))),
                                    dim3(128), 0, g_stream, static_cast<const void*>(b.in[i % SETS]), static_cast<uint8_t*>(b.out[i % SETS]), numel, n_tiles, pd);
@@ -684,6 +708,9 @@ int main(int argc, char** argv) {
             report("fused", "f32->u8 two launches (scan with parameter epilogue, quantize)", us, 9.0 * numel);
         }
         run_fused<18, 9, 9, 1024>(b, f, numel, num_cu, keys);
+        run_fused<18, 9, 9, 1024, ST_WT, 4, false>(b, f, numel, num_cu, keys);
+        run_fused<18, 9, 9, 1024>(b, f, numel, num_cu, keys);
+        run_fused<18, 9, 9, 1024, ST_WT, 4, false>(b, f, numel, num_cu, keys);
         if (numel > 27264000) {
             run_fused<18, 9, 9, 1024, ST_WT, 2>(b, f, numel, num_cu, keys);
             run_fused<18, 9, 9, 1024, ST_WT, 6>(b, f, numel, num_cu, keys);
