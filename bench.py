@@ -38,7 +38,7 @@ import torch.distributed as dist  # noqa: E402
 NUMEL = 27_264_000
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 ALGO_BYTES_PER_ELEM = 5        # 4 B read + 1 B written
-DEFAULT_BLOCKING_WAIT = "sync"  # the library's default (capi.cpp kDefaultBlockingWait)
+DEFAULT_BLOCKING_WAIT = "kernel"  # the library's default (capi.cpp kDefaultBlockingWait)
 
 
 def parse():

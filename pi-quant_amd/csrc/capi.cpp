@@ -171,7 +171,7 @@ namespace {
 // factor, so chunk boundaries never split a packed byte or a 16-byte vector.
 constexpr size_t kStageChunkElems = size_t{1} << 24;
 
-constexpr int kDefaultBlockingWait = 0;   // WAIT_SYNC until the A/B says otherwise (profiles/r02_blocking_wait_ab.json)
+constexpr int kDefaultBlockingWait = 2;   // WAIT_KERNEL: 30.4 us per blocking fp32->uint8 call at numel 27 264 000 against 31.7 (WAIT_WRITE32) and 34.8 (WAIT_SYNC), profiles/r02_blocking_wait_ab.json
 
 // Completion wait of a blocking call (the reference's calls return after the pool has joined, src/piquant.cpp:203-210).
 //   WAIT_SYNC     hipStreamSynchronize: the runtime waits on the queue's completion signal (interrupt or its own polling).

@@ -133,45 +133,6 @@ __device__ __forceinline__ void add_reduce_terms(u32x4& raw, int64_t v, const Fu
     }
 }
 
-// The nearest step for a call whose data range is known (device_math.hpp, BoundedStep): per element a packed multiply and
-// add, the copysign, one v_med3_f32 and one v_cvt_i32_f32 give the signed offset t = q - zp; the fields are then assembled
-// by Horner steps w = (w << BITS) + t (v_lshl_add_u32, negative t borrow from the field above and the borrow is repaid
-// exactly when zp is added to every field at once): 4 integer instructions per four elements instead of 4 adds + 3 packs.
-// GENERIC selects the rounding of the reference's generic nearest step (std::round, quantize.inl:21-26 -- the only form fp32 ->
-// uint2 has) instead of the SIMD bodies' trunc(p + copysign(0.5, p)); under the same range condition its int64 arithmetic
-// gives the same integers as the clamp in the float domain, and a NaN again ends at the lower bound, i.e. 0.
-template <int DT_IN, int BITS, bool GENERIC = false>
-__device__ __forceinline__ void quantize_vec_bounded(const u32x4& raw, float inv_scale, const BoundedStep& b,
-                                                     uint32_t (&w)[(InVec<DT_IN>::EPV * BITS / 8) > 4 ? 2 : 1]) {
-#pragma clang fp contract(off)
-    constexpr int EPV = InVec<DT_IN>::EPV, WORDS = (EPV * BITS / 8) > 4 ? 2 : 1, EPW = EPV / WORDS;
-    float v[EPV];
-    InVec<DT_IN>::unpack(raw, v);
-    int32_t t[EPV];
-#pragma unroll
-    for (int e = 0; e < EPV; e += 2) {
-        const f32x2 x = {v[e], v[e + 1]};
-        const f32x2 prod = x * inv_scale;
-        f32x2 adj;
-        if constexpr (GENERIC) {
-            adj = f32x2 {roundf(prod[0]), roundf(prod[1])};
-        } else {
-            const f32x2 half = {__builtin_copysignf(0.5f, prod[0]), __builtin_copysignf(0.5f, prod[1])};
-            adj = prod + half;
-        }
-        t[e] = quant_nearest_bounded_offset(adj[0], b);
-        t[e + 1] = quant_nearest_bounded_offset(adj[1], b);
-    }
-#pragma unroll
-    for (int j = 0; j < WORDS; ++j) {
-        uint32_t acc = static_cast<uint32_t>(t[j * EPW + EPW - 1]);
-#pragma unroll
-        for (int e = EPW - 2; e >= 0; --e) acc = (acc << BITS) + static_cast<uint32_t>(t[j * EPW + e]);
-        w[j] = acc + b.zp_word;
-    }
-}
-
-
 // rounds of BLOCK vectors in one block's share when n_vec vectors are split evenly over G blocks
 __host__ __device__ inline int64_t fused_rounds(int64_t n_vec, int64_t G, int64_t block) {
     const int64_t per_block = (n_vec + G - 1) / G;
@@ -504,11 +465,7 @@ fused_params_quantize_kernel(FusedGroups groups, QuantParams p_arg, FusedState* 
     // per-element RNG keys: all indices of this thread lie in [first, first + 2^32) -- the resident tensor is far smaller
     [[maybe_unused]] ElementKeys keys {};
     if constexpr (MODE == RM_STOCH_ELEM) keys = element_keys_for(p, p.index_base + static_cast<uint64_t>(v_first) * EPV);
-    constexpr int FIELDS = 32 / BITS < EPV ? 32 / BITS : EPV;    // fields of a packed word that one vector fills
-    uint32_t zp_word = 0;
-#pragma unroll
-    for (int i = 0; i < FIELDS; ++i) zp_word |= static_cast<uint32_t>(p.zp32) << (i * BITS);
-    const BoundedStep bstep {-static_cast<float>(p.zp32), static_cast<float>(((1 << BITS) - 1) - p.zp32), zp_word};
+    const BoundedStep bstep = bounded_step_for<DT_IN, BITS>(p.zp32);
     // A block whose whole share lies inside the tensor (all but the last one or two) needs no per-vector bounds check.
     const bool full_share = (static_cast<int64_t>(block) + 1) * rounds_total * BLOCK <= n_vec;
     const bool short_step = (MODE == RM_NEAREST_FAST || MODE == RM_NEAREST_I64) && bounded_ok;   // grid-uniform: the data range decides

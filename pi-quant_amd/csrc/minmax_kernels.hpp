@@ -240,17 +240,34 @@ __device__ __forceinline__ void minmax_block_end_gather(float lo, float hi, cons
         return;
     }
     int32_t k0 = float_to_key(lo), k1 = float_to_key(-hi);   // the sweeping block's own result never travels through memory
-    for (uint32_t base = 0; base + 1 < G; base += 64) {      // slots [0, G - 1)
-        const uint32_t slot = base + lane;
-        unsigned long long w = slot + 1 < G ? kMinmaxNotArrived : ~0ull;
-        while (__any(w == kMinmaxNotArrived ? 1 : 0)) {
-            if (w == kMinmaxNotArrived) w = __hip_atomic_load(words + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__any(w == kMinmaxNotArrived ? 1 : 0)) __builtin_amdgcn_s_sleep(2);
+    const uint64_t t_begin = wall_clock64();
+    constexpr int LPL = 8;                                    // 8 x 64 slots per pass, all loads of a pass in flight together
+    for (uint32_t base = 0; base + 1 < G; base += 64 * LPL) {   // slots [0, G - 1)
+        unsigned long long w[LPL];
+#pragma unroll
+        for (int j = 0; j < LPL; ++j) w[j] = base + j * 64 + lane + 1 < G ? kMinmaxNotArrived : ~0ull;
+        for (;;) {
+            bool missing = false;
+#pragma unroll
+            for (int j = 0; j < LPL; ++j) {
+                if (w[j] == kMinmaxNotArrived) {
+                    w[j] = __hip_atomic_load(words + base + j * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    missing |= w[j] == kMinmaxNotArrived;
+                }
+            }
+            if (!__any(missing ? 1 : 0)) break;
+            __builtin_amdgcn_s_sleep(2);
+            // blocks that have not started yet are waited for (they need nothing from this one); ten seconds without them is a
+            // bug or a wedged device, and failing the launch beats hanging it
+            if (wall_clock64() - t_begin > 1000000000ull) __builtin_trap();
         }
-        if (slot + 1 < G) {
-            __hip_atomic_store(words + slot, kMinmaxNotArrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // armed for the next scan
-            k0 = min(k0, static_cast<int32_t>(static_cast<uint32_t>(w)));
-            k1 = min(k1, static_cast<int32_t>(static_cast<uint32_t>(w >> 32)));
+#pragma unroll
+        for (int j = 0; j < LPL; ++j) {
+            if (base + j * 64 + lane + 1 < G) {
+                __hip_atomic_store(words + base + j * 64 + lane, kMinmaxNotArrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // armed for the next scan
+                k0 = min(k0, static_cast<int32_t>(static_cast<uint32_t>(w[j])));
+                k1 = min(k1, static_cast<int32_t>(static_cast<uint32_t>(w[j] >> 32)));
+            }
         }
     }
 #pragma unroll

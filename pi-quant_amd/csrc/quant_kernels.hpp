@@ -146,6 +146,68 @@ __device__ __forceinline__ void quantize_vec(const u32x4& raw, const QuantParams
     }
 }
 
+// The nearest step for a call whose data range is known (device_math.hpp, BoundedStep): per element a packed multiply and
+// add, the copysign, one v_med3_f32 and one v_cvt_i32_f32 give the signed offset t = q - zp; the fields are then assembled
+// by Horner steps w = (w << BITS) + t (v_lshl_add_u32, negative t borrow from the field above and the borrow is repaid
+// exactly when zp is added to every field at once): 4 integer instructions per four elements instead of 4 adds + 3 packs.
+// GENERIC selects the rounding of the reference's generic nearest step (std::round, quantize.inl:21-26 -- the only form fp32 ->
+// uint2 has) instead of the SIMD bodies' trunc(p + copysign(0.5, p)); under the same range condition its int64 arithmetic
+// gives the same integers as the clamp in the float domain, and a NaN again ends at the lower bound, i.e. 0.
+template <int DT_IN, int BITS, bool GENERIC = false>
+__device__ __forceinline__ void quantize_vec_bounded(const u32x4& raw, float inv_scale, const BoundedStep& b,
+                                                     uint32_t (&w)[(InVec<DT_IN>::EPV * BITS / 8) > 4 ? 2 : 1]) {
+#pragma clang fp contract(off)
+    constexpr int EPV = InVec<DT_IN>::EPV, WORDS = (EPV * BITS / 8) > 4 ? 2 : 1, EPW = EPV / WORDS;
+    float v[EPV];
+    InVec<DT_IN>::unpack(raw, v);
+    int32_t t[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; e += 2) {
+        const f32x2 x = {v[e], v[e + 1]};
+        const f32x2 prod = x * inv_scale;
+        f32x2 adj;
+        if constexpr (GENERIC) {
+            adj = f32x2 {roundf(prod[0]), roundf(prod[1])};
+        } else {
+            const f32x2 half = {__builtin_copysignf(0.5f, prod[0]), __builtin_copysignf(0.5f, prod[1])};
+            adj = prod + half;
+        }
+        t[e] = quant_nearest_bounded_offset(adj[0], b);
+        t[e + 1] = quant_nearest_bounded_offset(adj[1], b);
+    }
+#pragma unroll
+    for (int j = 0; j < WORDS; ++j) {
+        uint32_t acc = static_cast<uint32_t>(t[j * EPW + EPW - 1]);
+#pragma unroll
+        for (int e = EPW - 2; e >= 0; --e) acc = (acc << BITS) + static_cast<uint32_t>(t[j * EPW + e]);
+        w[j] = acc + b.zp_word;
+    }
+}
+
+// BoundedStep of a zero point that lies inside the quantized range (0 <= zp <= 2^BITS - 1): the clamp bounds as floats and the
+// zero point replicated into every field of a packed word.
+template <int DT_IN, int BITS>
+__device__ __forceinline__ BoundedStep bounded_step_for(int32_t zp32) {
+    constexpr int EPV = InVec<DT_IN>::EPV;
+    constexpr int FIELDS = 32 / BITS < EPV ? 32 / BITS : EPV;    // fields of a packed word that one vector fills
+    uint32_t zp_word = 0;
+#pragma unroll
+    for (int i = 0; i < FIELDS; ++i) zp_word |= static_cast<uint32_t>(zp32) << (i * BITS);
+    return BoundedStep {-static_cast<float>(zp32), static_cast<float>(((1 << BITS) - 1) - zp32), zp_word};
+}
+
+// max(m, |elements of the vector|): NaNs are skipped (fmax returns the other operand), infinities are kept -- exactly what the
+// caller's range test wants: a NaN quantizes to 0 through the short step as through the long one, an infinity must take the long one.
+template <int DT_IN>
+__device__ __forceinline__ float vec_absmax(const u32x4& raw, float m) {
+    constexpr int EPV = InVec<DT_IN>::EPV;
+    float v[EPV];
+    InVec<DT_IN>::unpack(raw, v);
+#pragma unroll
+    for (int e = 0; e < EPV; e += 2) m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[e]), __builtin_fabsf(v[e + 1])), m);
+    return m;
+}
+
 // OB = 1, 2, 4 or 8 packed bytes of one input vector to `dst`
 template <int OB, int POLICY>
 __device__ __forceinline__ void store_packed(uint8_t* dst, const uint32_t (&w)[OB > 4 ? 2 : 1]) {
@@ -181,6 +243,10 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const u32x4* __restrict__ in16 = static_cast<const u32x4*>(in);
+    constexpr bool SHORT_CAPABLE = MODE == RM_NEAREST_FAST || MODE == RM_NEAREST_I64;
+    [[maybe_unused]] const bool short_ok = SHORT_CAPABLE && p.zp64 >= 0 && p.zp64 <= (1 << BITS) - 1;   // kernel-uniform
+    [[maybe_unused]] const BoundedStep bstep = bounded_step_for<DT_IN, BITS>(p.zp32);
+    [[maybe_unused]] const float abs_inv = __builtin_fabsf(p.inv_scale);
 
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t v0 = (tile * T::WAVES + wave) * T::WAVE_VECS;   // first input vector of this wave tile
@@ -192,8 +258,26 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
         uint32_t w[U][WORDS];
         [[maybe_unused]] ElementKeys keys {};
         if constexpr (MODE == RM_STOCH_ELEM) keys = element_keys_for(p, p.index_base + static_cast<uint64_t>(v0 + lane) * EPV);
+        // The short nearest step (quantize_vec_bounded: about half the instructions per element) is exact whenever the zero point lies
+        // inside the quantized range and no element of the wave's tile reaches the range where x86's cvttps2dq turns indefinite --
+        // decided per wave tile from max|x| * |1/scale| (one v_max3 per two elements and one compare per lane).  Ordinary data always
+        // takes it; a tile with an infinity or a huge value takes the long step, with the same bytes either way.
+        bool short_step = false;
+        if constexpr (SHORT_CAPABLE) {
+            if (short_ok) {
+                float amax = 0.0f;
 #pragma unroll
-        for (int k = 0; k < U; ++k) quantize_vec<DT_IN, BITS, MODE>(raw[k], p, keys, static_cast<uint64_t>(v0 + k * 64 + lane) * EPV, w[k]);
+                for (int k = 0; k < U; ++k) amax = vec_absmax<DT_IN>(raw[k], amax);
+                short_step = __all(__fmul_rn(amax, abs_inv) < 1.0e9f ? 1 : 0) != 0;
+            }
+        }
+        if (short_step) {
+#pragma unroll
+            for (int k = 0; k < U; ++k) quantize_vec_bounded<DT_IN, BITS, MODE == RM_NEAREST_I64>(raw[k], p.inv_scale, bstep, w[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < U; ++k) quantize_vec<DT_IN, BITS, MODE>(raw[k], p, keys, static_cast<uint64_t>(v0 + k * 64 + lane) * EPV, w[k]);
+        }
 
         uint8_t* o = out + v0 * OB;                                    // output of this wave tile
         if constexpr (!STAGE) {

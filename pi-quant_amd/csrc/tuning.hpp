@@ -35,12 +35,14 @@ constexpr KernelTune kDequantTune[2][3] = {
 // fused quantize->dequantize: plain 16-byte streams both ways, no LDS staging
 constexpr KernelTune kRequantTune = {2, false, kStream, 64, 0};   // profiles/r01_tune_requant.csv
 
-// min/max scan: few, long-lived blocks -- the end-of-block atomics serialise (~11 ns each), the read stream
-// itself saturates from 2 blocks per CU (18.0 us at numel 27 264 000 = 6.07 TB/s).
+// min/max scan: few, long-lived blocks -- the read stream saturates from 512 threads per CU with four 16-byte loads in flight per
+// lane, and the fewer blocks there are, the shorter the end of the scan (one result word per block to sweep).  Interleaved A/B at
+// numel 27 264 000 (profiles/r02_tune_minmax.csv): one 512-thread block per CU with the gather end 18.8 us, two 256-thread blocks per
+// CU 20.2 (gather end) / 19.9 (slot atomics, round 1's protocol), one 256-thread block per CU 21.3-21.9.
 constexpr int kMinmaxU = 4;
 constexpr bool kMinmaxNT = true;
-constexpr int kMinmaxBlock = 256;
-constexpr int kMinmaxBlocksPerCU = 2;
+constexpr int kMinmaxBlock = 512;
+constexpr int kMinmaxBlocksPerCU = 1;
 constexpr bool kMinmaxGatherEnd = true;   // end of a scan: per-block result words swept by the highest block (true) or slot atomics + arrival counters
 
 // fused params + quantize (fused_kernels.hpp): one 1024-thread block per CU (4 waves per SIMD, 128 VGPRs each); per thread 18

@@ -159,7 +159,8 @@ def compute_quant_params(
     _scan=local_minmax_keys,
 ) -> Tuple[float, int]:
     """Quantization parameters of the tensor whose shards are spread over ``group`` (identical on every rank)."""
-    assert dtype in _QUANT_TYPES, f'Unsupported quantized dtype: {dtype}'
+    if dtype not in _QUANT_TYPES:
+        raise ValueError(f'Unsupported quantized dtype: {dtype}')
     keys = _scan(local_shard, ctx)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=group)   # the path's only collective: 8 bytes
@@ -268,7 +269,8 @@ def _all_gather(mine: torch.Tensor, everyone: torch.Tensor, group) -> None:
 def ring_chunks(numel: int, world_size: int, packed_bits: int = 8, align: int = 4096):
     """Chunk boundaries of the ring: `world_size` contiguous chunks; interior boundaries are multiples of `align` elements
     (whole packed bytes and 16-byte vectors on both sides of every kernel); the last chunk keeps the ragged end."""
-    assert align % (8 // packed_bits if packed_bits < 8 else 1) == 0
+    if align % (8 // packed_bits if packed_bits < 8 else 1) != 0:
+        raise ValueError(f'align={align} must be a multiple of the pack factor')
     per = -(-numel // world_size)
     per = -(-per // align) * align
     bounds = [min(i * per, numel) for i in range(world_size)] + [numel]
@@ -284,8 +286,13 @@ def quantized_all_reduce(
     ctx: Optional[Context] = None,
     algorithm: str = 'direct',
     _ops=None,
+    _single_rank_collectives: bool = False,
 ) -> torch.Tensor:
     """In-place SUM all-reduce of a contiguous float32/bfloat16 tensor whose wire format is quantized.
+
+    (``_single_rank_collectives`` is a test hook: with a one-rank group the function normally returns at once; with the hook it
+    runs the whole schedule -- encode, the group's collectives with the rank as its own only peer, decode -- so that the RCCL
+    branches execute on a box with one GPU.  The result is then ``dequantize(quantize(x))``.)
 
     ``algorithm='direct'`` (the default: MI355X's xGMI is a point-to-point mesh) is the schedule of
     ``quantized_all_reduce_direct`` -- one all-to-all + one all-gather, every value quantized exactly twice, 78 us of kernel
@@ -301,13 +308,16 @@ def quantized_all_reduce(
     1 byte (uint8) / 0.5 (uint4) instead of 4, over the same 2(G-1)/G ring schedule; each xGMI link carries one
     point-to-point stream, which is what the per-link (not NVSwitch-style) bandwidth of MI355X wants.
     """
-    assert tensor.is_contiguous() and tensor.dtype in (torch.float32, torch.bfloat16)
-    assert algorithm in ('ring', 'direct')
+    if not (tensor.is_contiguous() and tensor.dtype in (torch.float32, torch.bfloat16)):
+        raise ValueError('quantized_all_reduce needs a contiguous float32 or bfloat16 tensor')
+    if algorithm not in ('ring', 'direct'):
+        raise ValueError(f"algorithm must be 'ring' or 'direct', got {algorithm!r}")
     if algorithm == 'direct':
-        return quantized_all_reduce_direct(tensor, quant_dtype=quant_dtype, round_mode=round_mode, group=group, ctx=ctx, _ops=_ops)
+        return quantized_all_reduce_direct(tensor, quant_dtype=quant_dtype, round_mode=round_mode, group=group, ctx=ctx, _ops=_ops,
+                                           _single_rank_collectives=_single_rank_collectives)
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    if world == 1:
+    if world == 1 and not _single_rank_collectives:
         return tensor
     ops = _ops or _DeviceOps(ctx)
     qdt = torch_to_piquant_dtype(quant_dtype)
@@ -339,6 +349,9 @@ def quantized_all_reduce(
             ops.reduce_encode([recv[:n_recv]], x_recv, nxt_send[:n_recv], quant_dtype, round_mode)
         send, nxt_send = nxt_send, send
         n_cur = n_recv
+    if world == 1 and n_cur:   # test hook only: the encoded chunk makes one trip through the transport, to this rank itself
+        _exchange(send[:n_cur], recv[:n_cur], nxt, prv, group)
+        send, recv = recv, send
 
     # ---- all-gather: the finished chunk's bytes (now in `send`) circulate unchanged ----
     x_own, n_own = wire((rank + 1) % world)
@@ -363,6 +376,7 @@ def quantized_all_reduce_direct(
     group: Optional[dist.ProcessGroup] = None,
     ctx: Optional[Context] = None,
     _ops=None,
+    _single_rank_collectives: bool = False,
 ) -> torch.Tensor:
     """In-place quantized SUM all-reduce for a point-to-point mesh (MI355X: every GPU has its own xGMI link to each of its 7 peers).
 
@@ -379,10 +393,11 @@ def quantized_all_reduce_direct(
     Every value is quantized exactly twice whatever the world size (a ring: up to G times), the wire carries the same
     2(G-1)/G x packed bytes per element, and the two collectives are what RCCL implements natively over the mesh.
     """
-    assert tensor.is_contiguous() and tensor.dtype in (torch.float32, torch.bfloat16)
+    if not (tensor.is_contiguous() and tensor.dtype in (torch.float32, torch.bfloat16)):
+        raise ValueError('quantized_all_reduce needs a contiguous float32 or bfloat16 tensor')
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    if world == 1:
+    if world == 1 and not _single_rank_collectives:
         return tensor
     ops = _ops or _DeviceOps(ctx)
     qdt = torch_to_piquant_dtype(quant_dtype)

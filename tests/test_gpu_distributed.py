@@ -36,6 +36,62 @@ def test_sharded_params_through_rccl(pg, oracle_mod):
     assert D.compute_quant_params(xbd, dtype=torch.quint8) == O.compute_quant_params(xb, O.BF16, O.UINT8)
 
 
+def test_transport_branches_run_on_rccl(pg):
+    """the `nccl` branches of _exchange / _all_to_all / _all_gather had never executed.  A one-rank RCCL group can run all
+    three (send/recv to self inside one group call, all_to_all_single, all_gather_into_tensor): device buffers, no host staging."""
+    import piquant.distributed as D
+
+    assert dist.get_backend() == "nccl"
+    g = torch.Generator(device="cuda")
+    g.manual_seed(9)
+    for nbytes in (16, 4097, 3_408_016):
+        send = torch.randint(0, 256, (nbytes,), dtype=torch.uint8, device="cuda", generator=g)
+        recv = torch.zeros_like(send)
+        D._exchange(send, recv, 0, 0, None)
+        torch.cuda.synchronize()
+        assert torch.equal(send, recv)
+        recv.zero_()
+        D._all_to_all(send, recv, None)
+        torch.cuda.synchronize()
+        assert torch.equal(send, recv)
+        everyone = torch.zeros_like(send)
+        D._all_gather(send, everyone, None)
+        torch.cuda.synchronize()
+        assert torch.equal(send, everyone)
+
+
+@pytest.mark.parametrize("algorithm", ["ring", "direct"])
+@pytest.mark.parametrize("fdtype,qname,numel", [(torch.float32, "uint8", 27_264_000), (torch.bfloat16, "quint4x2", 1_000_003), (torch.float32, "quint2x4", 4099)])
+def test_quantized_all_reduce_end_to_end_on_a_one_rank_rccl_group(pg, oracle_mod, algorithm, fdtype, qname, numel):
+    """The whole schedule with RCCL as the transport (test hook: the rank is its own only peer): fused encode, the group's collectives,
+    decode -- while a second stream keeps launching fused kernels, the combination VERDICT r01 called untested.  With one rank the
+    sum has one term, so every element must equal dequantize(quantize(x)) with parameters from x: checked against the oracle."""
+    import piquant
+    import piquant.distributed as D
+
+    O = oracle_mod
+    qdtype = getattr(torch, qname)
+    odt = {"uint8": O.UINT8, "quint4x2": O.UINT4, "quint2x4": O.UINT2}[qname]
+    g = torch.Generator(device="cuda")
+    g.manual_seed(10)
+    x = torch.empty(numel, device="cuda").uniform_(-1, 1, generator=g).to(fdtype)
+    host = x.view(torch.int16).cpu().numpy().view(np.uint16) if fdtype == torch.bfloat16 else x.cpu().numpy()
+    fdt = O.BF16 if fdtype == torch.bfloat16 else O.F32
+    # a second stream issuing barrier kernels of its own meanwhile
+    side, side_ctx = torch.cuda.Stream(), piquant.Context()
+    y = torch.empty(27_264_000, device="cuda").uniform_(-1, 1, generator=g)
+    with torch.cuda.stream(side):
+        side_out = [piquant.torch.quantize_dynamic(y, dtype=torch.uint8, ctx=side_ctx) for _ in range(40)]
+    t = x.clone()
+    D.quantized_all_reduce(t, quant_dtype=qdtype, algorithm=algorithm, _single_rank_collectives=True)
+    torch.cuda.synchronize()
+    scale, zp = O.compute_quant_params(host, fdt, odt)
+    want = O.dequantize(O.quantize(host, fdt, odt, scale, zp), odt, fdt, numel, scale, zp)
+    got = t.view(torch.int16).cpu().numpy().view(np.uint16) if fdtype == torch.bfloat16 else t.cpu().numpy()
+    assert np.array_equal(got.view(np.uint16 if fdtype == torch.bfloat16 else np.uint32), want.view(np.uint16 if fdtype == torch.bfloat16 else np.uint32))
+    assert all(torch.equal(q, side_out[0][0]) and torch.equal(r, side_out[0][1]) for q, r in side_out[1:])
+
+
 def test_keys_fold_like_an_all_reduce(pg, oracle_mod):
     """MIN over the key pairs of several shards == keys of the whole tensor: what all_reduce(MIN) computes."""
     import piquant
