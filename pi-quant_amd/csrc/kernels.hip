@@ -72,7 +72,7 @@ void quantize_bits(const QuantLaunch& q, const QuantParams& p, hipStream_t strea
 
 template <int BITS, int DT_OUT, int OP>
 void dequantize_t(const DequantLaunch& d, const DequantParams& p, hipStream_t stream, int num_cu) {
-    constexpr KernelTune t = kDequantTune[DT_OUT][bits_index(BITS)];
+    constexpr KernelTune t = OP == OP_ADD ? kDequantAddTune[DT_OUT][bits_index(BITS)] : kDequantTune[DT_OUT][bits_index(BITS)];
     using Tile = DequantTile<BITS, DT_OUT, t.u, t.block>;
     const uint8_t* in = static_cast<const uint8_t*>(d.in);
     if (!aligned16(d.in) || !aligned16(d.out)) {

@@ -248,14 +248,14 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
     [[maybe_unused]] const BoundedStep bstep = bounded_step_for<DT_IN, BITS>(p.zp32);
     [[maybe_unused]] const float abs_inv = __builtin_fabsf(p.inv_scale);
 
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t tile_stride = gridDim.x;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += tile_stride) {
         const int64_t v0 = (tile * T::WAVES + wave) * T::WAVE_VECS;   // first input vector of this wave tile
 
         u32x4 raw[U];
 #pragma unroll
         for (int k = 0; k < U; ++k) raw[k] = ld<NT_LD>(in16 + v0 + k * 64 + lane);
 
-        uint32_t w[U][WORDS];
         [[maybe_unused]] ElementKeys keys {};
         if constexpr (MODE == RM_STOCH_ELEM) keys = element_keys_for(p, p.index_base + static_cast<uint64_t>(v0 + lane) * EPV);
         // The short nearest step (quantize_vec_bounded: about half the instructions per element) is exact whenever the zero point lies
@@ -271,47 +271,54 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
                 short_step = __all(__fmul_rn(amax, abs_inv) < 1.0e9f ? 1 : 0) != 0;
             }
         }
+        uint8_t* o = out + v0 * OB;                                    // output of this wave tile
+        // stores of the tile's packed words; written once, called from both branches below so that the two quantization paths never
+        // have to merge their results (a merge costs a register copy per word)
+        auto put = [&](uint32_t (&w)[U][WORDS]) {
+            if constexpr (!STAGE) {
+#pragma unroll
+                for (int k = 0; k < U; ++k) store_packed<OB, NT_ST>(o + static_cast<int64_t>(k * 64 + lane) * OB, w[k]);
+            } else {
+                uint8_t* s = lds + wave * T::WAVE_OUT_BYTES;
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    uint8_t* dst = s + (k * 64 + lane) * OB;
+                    if constexpr (OB == 1) *dst = static_cast<uint8_t>(w[k][0]);
+                    else if constexpr (OB == 2) *reinterpret_cast<uint16_t*>(dst) = static_cast<uint16_t>(w[k][0]);
+                    else if constexpr (OB == 4) *reinterpret_cast<uint32_t*>(dst) = w[k][0];
+                    else *reinterpret_cast<u32x2*>(dst) = u32x2{w[k][0], w[k][1]};
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if constexpr (T::LANE_OUT_BYTES >= 16) {
+#pragma unroll
+                    for (int j = 0; j < T::LANE_OUT_BYTES / 16; ++j) {
+                        const u32x4 r = reinterpret_cast<const u32x4*>(s)[j * 64 + lane];
+                        st<NT_ST>(reinterpret_cast<u32x4*>(o) + j * 64 + lane, r);
+                    }
+                } else if constexpr (T::LANE_OUT_BYTES == 8) {
+                    st<NT_ST>(reinterpret_cast<u32x2*>(o) + lane, reinterpret_cast<const u32x2*>(s)[lane]);
+                } else if constexpr (T::LANE_OUT_BYTES == 4) {
+                    st<NT_ST>(reinterpret_cast<uint32_t*>(o) + lane, reinterpret_cast<const uint32_t*>(s)[lane]);
+                } else {
+                    st<NT_ST>(reinterpret_cast<uint16_t*>(o) + lane, reinterpret_cast<const uint16_t*>(s)[lane]);
+                }
+                // the next iteration's LDS writes must not pass this iteration's reads
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        };
         if (short_step) {
+            uint32_t w[U][WORDS];
 #pragma unroll
             for (int k = 0; k < U; ++k) quantize_vec_bounded<DT_IN, BITS, MODE == RM_NEAREST_I64>(raw[k], p.inv_scale, bstep, w[k]);
+            put(w);
         } else {
+            uint32_t w[U][WORDS];
 #pragma unroll
             for (int k = 0; k < U; ++k) quantize_vec<DT_IN, BITS, MODE>(raw[k], p, keys, static_cast<uint64_t>(v0 + k * 64 + lane) * EPV, w[k]);
-        }
-
-        uint8_t* o = out + v0 * OB;                                    // output of this wave tile
-        if constexpr (!STAGE) {
-#pragma unroll
-            for (int k = 0; k < U; ++k) store_packed<OB, NT_ST>(o + static_cast<int64_t>(k * 64 + lane) * OB, w[k]);
-        } else {
-            uint8_t* s = lds + wave * T::WAVE_OUT_BYTES;
-#pragma unroll
-            for (int k = 0; k < U; ++k) {
-                uint8_t* dst = s + (k * 64 + lane) * OB;
-                if constexpr (OB == 1) *dst = static_cast<uint8_t>(w[k][0]);
-                else if constexpr (OB == 2) *reinterpret_cast<uint16_t*>(dst) = static_cast<uint16_t>(w[k][0]);
-                else if constexpr (OB == 4) *reinterpret_cast<uint32_t*>(dst) = w[k][0];
-                else *reinterpret_cast<u32x2*>(dst) = u32x2{w[k][0], w[k][1]};
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if constexpr (T::LANE_OUT_BYTES >= 16) {
-#pragma unroll
-                for (int j = 0; j < T::LANE_OUT_BYTES / 16; ++j) {
-                    const u32x4 r = reinterpret_cast<const u32x4*>(s)[j * 64 + lane];
-                    st<NT_ST>(reinterpret_cast<u32x4*>(o) + j * 64 + lane, r);
-                }
-            } else if constexpr (T::LANE_OUT_BYTES == 8) {
-                st<NT_ST>(reinterpret_cast<u32x2*>(o) + lane, reinterpret_cast<const u32x2*>(s)[lane]);
-            } else if constexpr (T::LANE_OUT_BYTES == 4) {
-                st<NT_ST>(reinterpret_cast<uint32_t*>(o) + lane, reinterpret_cast<const uint32_t*>(s)[lane]);
-            } else {
-                st<NT_ST>(reinterpret_cast<uint16_t*>(o) + lane, reinterpret_cast<const uint16_t*>(s)[lane]);
-            }
-            // the next iteration's LDS writes must not pass this iteration's reads
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            put(w);
         }
     }
 

@@ -26,10 +26,17 @@ constexpr KernelTune kQuantTune[2][3] = {
     {{2, true, kStream, 64, 0}, {2, true, kStream, 64, 0}, {4, true, kStream, 256, 0}},
 };
 
-// dequantize, indexed [dt_out: f32,bf16][bits: 8,4,2]
+// dequantize, indexed [dt_out: f32,bf16][bits: 8,4,2]; SET and ADD separately -- ADD also streams the accumulator in, which moves the
+// optimum to small tiles.  bf16 entries re-measured after fp32 -> bf16 became one v_cvt_pk_bf16_f32 (profiles/r01_tune_finals_other_hw_bf16_cvt.csv,
+// profiles/r02_tune_half_size.csv): uint4 -> bf16 SET at numel 27 264 000 (BASELINE config 3) 11.6 us with 256-thread / U=4 tiles against
+// 12.4 with the 64-thread / U=2 tiles that are best for ADD (20.8 vs 22.4 us).
 constexpr KernelTune kDequantTune[2][3] = {
     {{2, true, kStream, 128, 0}, {4, true, kStream, 256, 0}, {4, true, kStream, 256, 0}},
-    {{4, true, kStream, 128, 0}, {2, true, kStream, 64, 0}, {2, true, kStream, 128, 0}},
+    {{2, true, kStream, 64, 0}, {4, true, kStream, 256, 0}, {4, true, kStream, 256, 0}},
+};
+constexpr KernelTune kDequantAddTune[2][3] = {
+    {{2, true, kStream, 128, 0}, {4, true, kStream, 256, 0}, {4, true, kStream, 256, 0}},
+    {{2, true, kStream, 64, 0}, {2, true, kStream, 64, 0}, {2, true, kStream, 128, 0}},
 };
 
 // fused quantize->dequantize: plain 16-byte streams both ways, no LDS staging

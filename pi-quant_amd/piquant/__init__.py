@@ -12,6 +12,7 @@ __version__ = '0.1.0'
 
 import ctypes as _C
 import importlib.util
+import threading
 import weakref
 from enum import Enum, unique
 from typing import Dict, Optional, Tuple, Union
@@ -72,7 +73,10 @@ class Context:
     pool there, ``__init__.py:65-70``) and ignored: the GPU grid does the partitioning.
     """
 
-    _defaults: Dict[int, 'Context'] = {}
+    # Default contexts are per (thread, device): a context carries the stream and the blocking / pointer modes of the call being
+    # made, so two threads driving different streams through one shared default context could swap each other's stream between
+    # "set the stream" and "make the call".  Contexts are cheap (a private stream, ~60 KiB of device state, two pinned words).
+    _tls = threading.local()
 
     def __init__(self, num_threads: Union[int, None] = None) -> None:
         self._num_threads = 0 if num_threads is None else int(num_threads)
@@ -88,14 +92,22 @@ class Context:
 
     @staticmethod
     def get(device_index: Optional[int] = None) -> 'Context':
-        """Default context (one per HIP device, created on first use)."""
+        """Default context of the calling thread (one per thread and HIP device, created on first use)."""
         if device_index is None:
             device_index = _current_device()
-        ctx = Context._defaults.get(device_index)
+        defaults = Context._thread_defaults()
+        ctx = defaults.get(device_index)
         if ctx is None:
             ctx = _make_on_device(device_index)
-            Context._defaults[device_index] = ctx
+            defaults[device_index] = ctx
         return ctx
+
+    @staticmethod
+    def _thread_defaults() -> Dict[int, 'Context']:
+        d = getattr(Context._tls, 'defaults', None)
+        if d is None:
+            d = Context._tls.defaults = {}
+        return d
 
     @property
     def device(self) -> int:

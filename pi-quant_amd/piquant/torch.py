@@ -98,7 +98,7 @@ def _native_handle(tensor: torch.Tensor, ctx: Optional[Context]) -> int:
     """Native context handle for a call through the C++ front end (default context of the tensor's device unless one is given)."""
     if ctx is None:
         index = tensor.device.index
-        ctx = Context._defaults.get(index) or Context.get(index)
+        ctx = Context._thread_defaults().get(index) or Context.get(index)
     return ctx._native_call()
 
 
@@ -106,10 +106,58 @@ def _quant_meta(tensor: torch.Tensor, quant_dtype: Optional[torch.dtype], shape)
     """Quantized dtype and logical shape of a dequantize input: from the tensor itself, or -- for a raw uint8 buffer of
     packed bytes -- from the ``quant_dtype=`` / ``shape=`` keywords."""
     if quant_dtype is not None and quant_dtype != tensor.dtype:
-        assert tensor.dtype == torch.uint8, 'quant_dtype= reinterprets a raw uint8 byte buffer'
-        assert shape is not None, 'shape= is required together with quant_dtype= for raw packed buffers'
+        _require(tensor.dtype == torch.uint8, 'quant_dtype= reinterprets a raw uint8 byte buffer')
+        _require(shape is not None, 'shape= is required together with quant_dtype= for raw packed buffers')
         return torch_to_piquant_dtype(quant_dtype), torch.Size(shape)
     return torch_to_piquant_dtype(tensor.dtype), tensor.shape
+
+
+# Argument checks of the additive entry points.  They raise (ValueError) rather than assert: a short, misplaced or non-contiguous
+# buffer handed to a kernel by raw pointer is an out-of-bounds device write, and `python -O` strips asserts.
+def _require(cond: bool, msg: str) -> None:
+    if not cond:
+        raise ValueError(msg)
+
+
+def _check_float_input(t: torch.Tensor, what: str = 'tensor') -> None:
+    _require(isinstance(t, torch.Tensor) and t.is_cuda and t.dtype in _DEQUANT_TYPES, f'{what} must be a float32 or bfloat16 ROCm device tensor')
+
+
+def _check_packed_out(out: torch.Tensor, dt: DataType, numel: int, device: torch.device, what: str = 'out') -> None:
+    """`out` receives `numel` quantized elements: a raw uint8 buffer of at least packed_nbytes bytes, or a quantized torch tensor of numel elements."""
+    _require(isinstance(out, torch.Tensor) and out.device == device and out.is_contiguous(), f'{what} must be a contiguous tensor on {device}')
+    if out.dtype == torch.uint8:
+        _require(out.numel() >= dt.packed_nbytes(numel), f'{what} holds {out.numel()} bytes, {dt.packed_nbytes(numel)} are needed for {numel} {dt.name} elements')
+    else:
+        _require(out.dtype in _QUANT_TYPES and torch_to_piquant_dtype(out.dtype) == dt and out.numel() == numel,
+                 f'{what} must be a {dt.name} tensor of {numel} elements (or a uint8 buffer of the packed bytes)')
+
+
+def _check_packed_in(t: torch.Tensor, dt: DataType, numel: int, device: torch.device, what: str) -> None:
+    """`t` supplies `numel` quantized elements: a raw uint8 buffer of at least packed_nbytes bytes, or a quantized torch tensor of that dtype."""
+    _require(isinstance(t, torch.Tensor) and t.device == device and t.is_contiguous(), f'{what} must be a contiguous tensor on {device}')
+    if t.dtype == torch.uint8:
+        _require(t.numel() >= dt.packed_nbytes(numel), f'{what} holds {t.numel()} bytes, {dt.packed_nbytes(numel)} are needed for {numel} {dt.name} elements')
+    else:
+        _require(t.dtype in _QUANT_TYPES and torch_to_piquant_dtype(t.dtype) == dt and t.numel() >= numel, f'{what} does not hold {numel} {dt.name} elements')
+
+
+def _check_float_out(out: torch.Tensor, dtype: torch.dtype, numel: int, device: torch.device, what: str = 'out') -> None:
+    _require(isinstance(out, torch.Tensor) and out.dtype == dtype and out.is_contiguous() and out.device == device and out.numel() == numel,
+             f'{what} must be a contiguous {dtype} tensor of {numel} elements on {device}')
+
+
+def _check_params(params: torch.Tensor, device: torch.device, what: str = 'params') -> None:
+    _require(isinstance(params, torch.Tensor) and params.dtype == torch.uint8 and params.device == device and params.is_contiguous() and
+             params.numel() >= PARAMS_NBYTES and params.data_ptr() % 8 == 0,
+             f'{what} must be a contiguous uint8 tensor of at least {PARAMS_NBYTES} bytes on {device}, 8-byte aligned (the device parameter record)')
+
+
+def _numel_of(shape) -> int:
+    n = 1
+    for s_ in shape:
+        n *= int(s_)
+    return n
 
 
 def compute_quant_params(tensor: torch.Tensor, *, dtype: torch.dtype, ctx: Optional[Context] = None) -> Tuple[float, int]:
@@ -145,8 +193,7 @@ def quantize(
     if out is None:
         out = torch.empty(tensor.shape, dtype=dtype, device=tensor.device)   # reference torch.py:87, plus the device
     else:
-        assert out.is_contiguous() and out.device == tensor.device
-        assert out.untyped_storage().nbytes() >= dtype_out.packed_nbytes(tensor.numel()), 'out= is too small'
+        _check_packed_out(out, dtype_out, tensor.numel(), tensor.device)
     ctx = _ctx_for(tensor, ctx)
     ctx.quantize_ptr(
         tensor.data_ptr(),
@@ -192,7 +239,7 @@ def dequantize(
             raise ValueError("reduce_op='add' accumulates into out=; pass the accumulator tensor")
         out = torch.empty(logical_shape, dtype=dtype, device=tensor.device)
     else:
-        assert out.dtype == dtype and out.is_contiguous() and out.device == tensor.device and out.numel() == numel
+        _check_float_out(out, dtype, numel, tensor.device)
     ctx = _ctx_for(tensor, ctx)
     ctx.dequantize_ptr(
         tensor.data_ptr(),
@@ -221,8 +268,8 @@ def quantize_dequantize(
 ) -> torch.Tensor:
     """out (op)= dequantize(quantize(tensor)) in one pass over HBM -- the reference's C++-only
     ``context::quantize_dequantize_fused`` (``include/piquant.hpp:276-285``); ``out`` may be ``tensor`` (in place)."""
-    assert quant_dtype in _QUANT_TYPES, f'Unsupported quantized dtype: {quant_dtype}'
-    assert tensor.dtype in _DEQUANT_TYPES and tensor.is_cuda, 'quantize_dequantize needs a float32/bfloat16 device tensor'
+    _require(quant_dtype in _QUANT_TYPES, f'Unsupported quantized dtype: {quant_dtype}')
+    _check_float_input(tensor)
     if not tensor.is_contiguous():
         tensor = tensor.contiguous()
     if out is None:
@@ -230,7 +277,7 @@ def quantize_dequantize(
             raise ValueError("reduce_op='add' accumulates into out=; pass the accumulator tensor")
         out = torch.empty_like(tensor)
     else:
-        assert out.dtype == tensor.dtype and out.is_contiguous() and out.device == tensor.device and out.numel() == tensor.numel()
+        _check_float_out(out, tensor.dtype, tensor.numel(), tensor.device)
     ctx = _ctx_for(tensor, ctx)
     ctx.quantize_dequantize_ptr(tensor.data_ptr(), torch_to_piquant_dtype(tensor.dtype), out.data_ptr(), torch_to_piquant_dtype(quant_dtype),
                                 tensor.numel(), scale, zero_point, _ROUND_MODES[round_mode], _REDUCE_OPS[reduce_op], _device_ptrs=True)
@@ -254,12 +301,13 @@ def params_to_host(params: torch.Tensor) -> Tuple[float, int]:
 def compute_quant_params_device(tensor: torch.Tensor, *, dtype: torch.dtype, ctx: Optional[Context] = None,
                                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Like ``compute_quant_params`` but asynchronous: the result is a 16-byte uint8 device tensor (the parameter record)."""
-    assert dtype in _QUANT_TYPES and tensor.is_cuda and tensor.dtype in _DEQUANT_TYPES
+    _require(dtype in _QUANT_TYPES, f'Unsupported quantized dtype: {dtype}')
+    _check_float_input(tensor)
     if not tensor.is_contiguous():
         tensor = tensor.contiguous()
     if out is None:
         out = torch.empty(PARAMS_NBYTES, dtype=torch.uint8, device=tensor.device)
-    assert out.dtype == torch.uint8 and out.numel() >= PARAMS_NBYTES and out.data_ptr() % 8 == 0
+    _check_params(out, tensor.device, 'out')
     ctx = _ctx_for(tensor, ctx)
     ctx.compute_quant_params_device_ptr(tensor.data_ptr(), torch_to_piquant_dtype(tensor.dtype), tensor.numel(), torch_to_piquant_dtype(dtype),
                                         out.data_ptr(), _device_ptrs=True)
@@ -271,14 +319,17 @@ def quantize_dynamic(tensor: torch.Tensor, *, dtype: torch.dtype, round_mode: st
     """``compute_quant_params`` + ``quantize`` in one asynchronous call, parameters computed and kept on the device.  Returns
     (quantized, parameter record).  A tensor that fits on the chip (up to ~113 MB on an MI355X) is read from HBM once, by a single
     kernel that keeps it in registers / LDS between the min/max pass and the quantization; larger ones take two launches (scan with the parameter epilogue, then quantize)."""
-    assert dtype in _QUANT_TYPES and tensor.is_cuda and tensor.dtype in _DEQUANT_TYPES
+    _require(dtype in _QUANT_TYPES, f'Unsupported quantized dtype: {dtype}')
+    _check_float_input(tensor)
     if not tensor.is_contiguous():
         tensor = tensor.contiguous()
     if params is None:
         params = torch.empty(PARAMS_NBYTES, dtype=torch.uint8, device=tensor.device)
-    assert params.dtype == torch.uint8 and params.numel() >= PARAMS_NBYTES and params.data_ptr() % 8 == 0
+    _check_params(params, tensor.device)
     if out is None:
         out = torch.empty(tensor.shape, dtype=dtype, device=tensor.device)
+    else:
+        _check_packed_out(out, torch_to_piquant_dtype(dtype), tensor.numel(), tensor.device)
     ctx = _ctx_for(tensor, ctx)
     ctx.quantize_dynamic_ptr(tensor.data_ptr(), torch_to_piquant_dtype(tensor.dtype), out.data_ptr(), torch_to_piquant_dtype(dtype), tensor.numel(),
                              params.data_ptr(), _ROUND_MODES[round_mode], _device_ptrs=True)
@@ -289,17 +340,20 @@ def dequantize_dynamic(tensor: torch.Tensor, params: torch.Tensor, *, dtype: tor
                        ctx: Optional[Context] = None, out: Optional[torch.Tensor] = None, quant_dtype: Optional[torch.dtype] = None,
                        shape=None) -> torch.Tensor:
     """``dequantize`` with (scale, zero_point) read from a device parameter record."""
-    assert dtype in _DEQUANT_TYPES and tensor.is_cuda and params.is_cuda
+    _require(dtype in _DEQUANT_TYPES, f'Unsupported dequantized dtype: {dtype}')
+    _require(isinstance(tensor, torch.Tensor) and tensor.is_cuda, 'dequantize_dynamic needs a ROCm device tensor')
     if not tensor.is_contiguous():
         tensor = tensor.contiguous()
     dtype_in, logical_shape = _quant_meta(tensor, quant_dtype, shape)
-    numel = 1
-    for s in logical_shape:
-        numel *= int(s)
+    numel = _numel_of(logical_shape)
+    _check_packed_in(tensor, dtype_in, numel, tensor.device, 'tensor')
+    _check_params(params, tensor.device)
     if out is None:
         if reduce_op == 'add':
             raise ValueError("reduce_op='add' accumulates into out=; pass the accumulator tensor")
         out = torch.empty(logical_shape, dtype=dtype, device=tensor.device)
+    else:
+        _check_float_out(out, dtype, numel, tensor.device)
     ctx = _ctx_for(tensor, ctx)
     ctx.dequantize_dp_ptr(tensor.data_ptr(), dtype_in, out.data_ptr(), torch_to_piquant_dtype(out.dtype), numel, params.data_ptr(),
                           _REDUCE_OPS[reduce_op], _device_ptrs=True)
@@ -311,19 +365,21 @@ def dequantize_sum(tensors, params, *, dtype: torch.dtype, reduce_op: str = 'set
     """out (op)= sum_i dequantize(tensors[i]) with (scale, zero_point) of input i read from the device record ``params[i]``: one pass
     over the accumulator instead of ``len(tensors)``; the result equals ``dequantize_dynamic`` applied in order (first with
     ``reduce_op``, the rest with 'add') bit for bit.  The reduction step of ``piquant.distributed.quantized_all_reduce``."""
-    assert dtype in _DEQUANT_TYPES and len(tensors) == len(params) and len(tensors) > 0
+    _require(dtype in _DEQUANT_TYPES, f'Unsupported dequantized dtype: {dtype}')
+    _require(len(tensors) == len(params) and len(tensors) > 0, 'dequantize_sum needs as many parameter records as tensors, and at least one')
     first = tensors[0]
-    assert all(t.is_cuda and t.is_contiguous() for t in tensors) and all(p.is_cuda for p in params)
+    _require(isinstance(first, torch.Tensor) and first.is_cuda, 'dequantize_sum needs ROCm device tensors')
     dtype_in, logical_shape = _quant_meta(first, quant_dtype, shape)
-    numel = 1
-    for s_ in logical_shape:
-        numel *= int(s_)
+    numel = _numel_of(logical_shape)
+    for i, (t, p) in enumerate(zip(tensors, params)):
+        _check_packed_in(t, dtype_in, numel, first.device, f'tensors[{i}]')
+        _check_params(p, first.device, f'params[{i}]')
     if out is None:
         if reduce_op == 'add':
             raise ValueError("reduce_op='add' accumulates into out=; pass the accumulator tensor")
         out = torch.empty(logical_shape, dtype=dtype, device=first.device)
     else:
-        assert out.dtype == dtype and out.is_contiguous() and out.device == first.device and out.numel() == numel
+        _check_float_out(out, dtype, numel, first.device)
     ctx = _ctx_for(first, ctx)
     ctx.dequantize_sum_ptr([t.data_ptr() for t in tensors], [p.data_ptr() for p in params], dtype_in, out.data_ptr(), torch_to_piquant_dtype(out.dtype),
                            numel, _REDUCE_OPS[reduce_op], _device_ptrs=True)
@@ -333,16 +389,23 @@ def dequantize_sum(tensors, params, *, dtype: torch.dtype, reduce_op: str = 'set
 def quantize_dynamic_batch(tensors, *, dtype: torch.dtype, round_mode: str = 'nearest', ctx: Optional[Context] = None, outs=None, params=None):
     """``quantize_dynamic`` for a list of independent tensors of one float dtype: each gets its own (scale, zero_point) and record,
     up to 16 of them are processed by ONE kernel launch.  Returns (list of quantized tensors, list of parameter records)."""
-    assert dtype in _QUANT_TYPES and len(tensors) > 0
+    _require(dtype in _QUANT_TYPES, f'Unsupported quantized dtype: {dtype}')
+    _require(len(tensors) > 0, 'quantize_dynamic_batch needs at least one tensor')
     fdt = tensors[0].dtype
-    assert fdt in _DEQUANT_TYPES and all(t.is_cuda and t.dtype == fdt for t in tensors)
+    for i, t in enumerate(tensors):
+        _check_float_input(t, f'tensors[{i}]')
+        _require(t.dtype == fdt and t.device == tensors[0].device, 'all tensors of a batch share one float dtype and one device')
     tensors = [t if t.is_contiguous() else t.contiguous() for t in tensors]
     if outs is None:
         outs = [torch.empty(t.shape, dtype=dtype, device=t.device) for t in tensors]
     if params is None:
         block = torch.empty(len(tensors) * PARAMS_NBYTES, dtype=torch.uint8, device=tensors[0].device)
         params = [block[i * PARAMS_NBYTES: (i + 1) * PARAMS_NBYTES] for i in range(len(tensors))]
-    assert len(outs) == len(params) == len(tensors)
+    _require(len(outs) == len(params) == len(tensors), 'outs= and params= must have one entry per tensor')
+    qdt = torch_to_piquant_dtype(dtype)
+    for i, (t, o, p) in enumerate(zip(tensors, outs, params)):
+        _check_packed_out(o, qdt, t.numel(), t.device, f'outs[{i}]')
+        _check_params(p, t.device, f'params[{i}]')
     ctx = _ctx_for(tensors[0], ctx)
     ctx.quantize_dynamic_batch_ptr([t.data_ptr() for t in tensors], torch_to_piquant_dtype(fdt), [o.data_ptr() for o in outs], torch_to_piquant_dtype(dtype),
                                    [t.numel() for t in tensors], [p.data_ptr() for p in params], _ROUND_MODES[round_mode], _device_ptrs=True)
@@ -353,21 +416,24 @@ def dequantize_dynamic_batch(tensors, params, *, dtype: torch.dtype, reduce_op: 
                              quant_dtype: Optional[torch.dtype] = None, shapes=None):
     """``dequantize_dynamic`` for a list of independent quantized tensors (raw uint8 buffers with ``quant_dtype=`` and ``shapes=``, or
     quantized torch tensors) in one launch per 16; ``outs`` are required for ``reduce_op='add'``."""
-    assert dtype in _DEQUANT_TYPES and len(tensors) == len(params) and len(tensors) > 0
+    _require(dtype in _DEQUANT_TYPES, f'Unsupported dequantized dtype: {dtype}')
+    _require(len(tensors) == len(params) and len(tensors) > 0, 'dequantize_dynamic_batch needs as many parameter records as tensors, and at least one')
+    _require(all(isinstance(t, torch.Tensor) and t.is_cuda for t in tensors), 'dequantize_dynamic_batch needs ROCm device tensors')
     metas = [_quant_meta(t, quant_dtype, None if shapes is None else shapes[i]) for i, t in enumerate(tensors)]
     dtype_in = metas[0][0]
-    assert all(m[0] == dtype_in for m in metas) and all(t.is_cuda and t.is_contiguous() for t in tensors)
-    numels = []
-    for _dt, shp in metas:
-        n = 1
-        for s_ in shp:
-            n *= int(s_)
-        numels.append(n)
+    _require(all(m[0] == dtype_in for m in metas), 'all tensors of a batch share one quantized dtype')
+    numels = [_numel_of(shp) for _dt, shp in metas]
+    device = tensors[0].device
+    for i, (t, p, n) in enumerate(zip(tensors, params, numels)):
+        _check_packed_in(t, dtype_in, n, device, f'tensors[{i}]')
+        _check_params(p, device, f'params[{i}]')
     if outs is None:
         if reduce_op == 'add':
             raise ValueError("reduce_op='add' accumulates into outs=; pass the accumulator tensors")
         outs = [torch.empty(m[1], dtype=dtype, device=t.device) for m, t in zip(metas, tensors)]
-    assert all(o.dtype == dtype and o.is_contiguous() and o.numel() == n for o, n in zip(outs, numels))
+    _require(len(outs) == len(tensors), 'outs= must have one entry per tensor')
+    for i, (o, n) in enumerate(zip(outs, numels)):
+        _check_float_out(o, dtype, n, device, f'outs[{i}]')
     ctx = _ctx_for(tensors[0], ctx)
     ctx.dequantize_dp_batch_ptr([t.data_ptr() for t in tensors], dtype_in, [o.data_ptr() for o in outs], torch_to_piquant_dtype(dtype), numels,
                                 [p.data_ptr() for p in params], _REDUCE_OPS[reduce_op], _device_ptrs=True)
@@ -379,12 +445,21 @@ def reduce_quantize_dynamic(acc: torch.Tensor, tensors, params, *, dtype: torch.
     """(quantize(acc + sum_i dequantize(tensors[i])), record): the owner's step of a mesh all-reduce as one call -- one kernel launch
     that never writes the sum to memory when it stays on chip.  ``tensors`` are raw uint8 buffers of packed ``dtype`` values with
     ``acc.numel()`` elements each, ``params`` their device records.  The contents of ``acc`` afterwards are unspecified."""
-    assert dtype in _QUANT_TYPES and acc.is_cuda and acc.is_contiguous() and acc.dtype in _DEQUANT_TYPES and len(tensors) == len(params)
-    assert all(t.is_cuda and t.is_contiguous() for t in tensors)
+    _require(dtype in _QUANT_TYPES, f'Unsupported quantized dtype: {dtype}')
+    _check_float_input(acc, 'acc')
+    _require(acc.is_contiguous(), 'acc must be contiguous')
+    _require(len(tensors) == len(params), 'reduce_quantize_dynamic needs as many parameter records as tensors')
+    qdt = torch_to_piquant_dtype(dtype)
+    for i, (t, p) in enumerate(zip(tensors, params)):
+        _check_packed_in(t, qdt, acc.numel(), acc.device, f'tensors[{i}]')
+        _check_params(p, acc.device, f'params[{i}]')
     if out is None:
         out = torch.empty(acc.shape, dtype=dtype, device=acc.device)
+    else:
+        _check_packed_out(out, qdt, acc.numel(), acc.device)
     if out_params is None:
         out_params = torch.empty(PARAMS_NBYTES, dtype=torch.uint8, device=acc.device)
+    _check_params(out_params, acc.device, 'out_params')
     ctx = _ctx_for(acc, ctx)
     ctx.reduce_quantize_dynamic_ptr(acc.data_ptr(), torch_to_piquant_dtype(acc.dtype), [t.data_ptr() for t in tensors], [p.data_ptr() for p in params],
                                     out.data_ptr(), torch_to_piquant_dtype(dtype), acc.numel(), out_params.data_ptr(), _ROUND_MODES[round_mode],

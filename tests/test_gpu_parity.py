@@ -1060,7 +1060,7 @@ def test_batched_dynamic_quantize_and_dequantize_equal_single_calls(O):
         scale, zp = O.compute_quant_params(xs[i], 0, 4)
         assert pt.params_to_host(recs[i]) == (scale, zp)
         assert np.array_equal(pt.packed_bytes(qs[i]).cpu().numpy(), O.quantize(xs[i], 0, 4, scale, zp))
-    assert pt.params_to_host(recs[1]) == O.compute_quant_params(xs[1], 0, 4)
+    assert pt.params_to_host(recs[1]) == (1.0, 127)   # nothing scanned: the degenerate record, never a negative scale (include/piquant_hip.h)
 
 
 def test_reduce_quantize_dynamic_equals_sum_then_quantize(O):

@@ -164,3 +164,35 @@ def test_native_front_end_matches_the_ctypes_path():
             pt.dequantize(a, scale=0.02, zero_point=100, dtype=torch.float32, reduce_op="add")
     finally:
         pt._native = native
+
+
+def test_reference_style_benchmark_harness_runs(tmp_path):
+    """the reference's two benchmark scripts re-stated on device tensors (python/benchmark/benchmark.py:16-72,
+    throughput_avg.py:9-42) must keep running: short run, schema of the JSON document, the scripts' own agreement check with
+    torch.quantize_per_tensor, and the bar chart when matplotlib is there."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    png = tmp_path / "quant_benchmark.png"
+    r = subprocess.run([sys.executable, str(root / "tools" / "reference_style_benchmarks.py"), "--gib", "0.25", "--runs", "50", "--plot", str(png)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout)
+    assert d["runs"] == 50 and "MI3" in d["device"]
+    bars = d["benchmark_py (NUMEL=1e6, 50 runs)"]
+    assert [b["dtype"] for b in bars] == ["quint8", "quint4x2", "quint2x4"]
+    for b in bars:
+        assert b["results_allclose_1e-1"] and b["torch_s_per_50"] > 0 and b["piquant_s_per_50"] > 0
+    head = d["README headline (numel=27264000, seconds per 50 runs)"]
+    assert head["piquant.torch.quantize (device)"] > 0 and head["elements_differing_from_torch"] < 27_264_000 // 1000
+    thr = d["throughput_avg_py (0.25 GiB float tensor, 10 iterations, allocation + sync inside the timed call)"]
+    assert len(thr) == 3 and all(t["quantize_GiB/s_of_float_input"] > 0 and t["dequantize_GiB/s_of_float_output"] > 0 for t in thr)
+    try:
+        import matplotlib  # noqa: F401
+    except ImportError:
+        assert d["plot"].startswith("matplotlib is not importable")
+    else:
+        assert d["plot"] == str(png) and png.stat().st_size > 5000

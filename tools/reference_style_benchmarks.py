@@ -8,8 +8,9 @@
 Same measurement conventions (wall clock around the Python-level call, result allocation included; here with a device
 synchronisation inside the timed region so the GPU work is counted).  torch.quantize_per_tensor runs on the same GPU for
 quint8 (PyTorch-ROCm implements it); for the packed dtypes PyTorch has no device kernel, so the torch column is measured
-on the host CPU like the reference does.  No plot is drawn (matplotlib is not part of this image); one JSON document is
-printed.  Usage: python tools/reference_style_benchmarks.py [--gib 8] > profiles/rNN_reference_style.json
+on the host CPU like the reference does.  One JSON document is printed; --plot FILE.png also draws the reference's grouped bar
+chart (python/benchmark/benchmark.py:60-72: seconds per NUM_RUNS runs, torch vs piquant per quantized dtype) when matplotlib
+can be imported.  Usage: python tools/reference_style_benchmarks.py [--gib 8] [--runs 1000] [--plot profiles/rNN_quant_benchmark.png] > profiles/rNN_reference_style.json
 """
 import argparse
 import json
@@ -52,7 +53,7 @@ def torch_vs_piquant():
         dq_t = torch.quantize_per_tensor(xt, scale=scale, zero_point=zp, dtype=qdt).dequantize().cpu()
         dq_p = piquant.torch.dequantize(piquant.torch.quantize(x, scale=scale, zero_point=zp, dtype=qdt), scale=scale, zero_point=zp,
                                         dtype=torch.float32).cpu()
-        rows.append({"dtype": str(qdt).replace("torch.", ""), "torch_s_per_1000": round(t_torch, 6), "piquant_s_per_1000": round(t_pi, 6),
+        rows.append({"dtype": str(qdt).replace("torch.", ""), f"torch_s_per_{NUM_RUNS}": round(t_torch, 6), f"piquant_s_per_{NUM_RUNS}": round(t_pi, 6),
                      "torch_device": "cuda" if on_gpu else "cpu (no device kernel in PyTorch for this dtype)",
                      "results_allclose_1e-1": bool(torch.allclose(dq_t, dq_p, atol=1e-1))})
     return rows
@@ -78,7 +79,7 @@ def readme_headline():
     a = torch.quantize_per_tensor(x, scale=scale, zero_point=zp, dtype=torch.quint8).int_repr()
     b = piquant.torch.packed_bytes(piquant.torch.quantize(x, scale=scale, zero_point=zp, dtype=torch.quint8))
     rows["elements_differing_from_torch"] = int((a.view(-1) != b).sum())   # torch rounds x/scale half-to-even, pi-quant x*(1/scale) half-away
-    rows["reference_published_s_per_1000"] = {"EPYC 9654 (AVX-512F)": 1.7, "EPYC 7742 (AVX2)": 2.8, "Apple M3 Pro (NEON)": 1.4,
+    rows["reference_published_s_per_1000_runs"] = {"EPYC 9654 (AVX-512F)": 1.7, "EPYC 7742 (AVX2)": 2.8, "Apple M3 Pro (NEON)": 1.4,
                                               "torch builtin on EPYC 9654": 11.0}
     return rows
 
@@ -110,13 +111,49 @@ def throughput(total_gib: float):
     return rows
 
 
+def plot(rows, path):
+    """The reference's chart (python/benchmark/benchmark.py:60-72): one pair of bars per quantized dtype.  Returns False without
+    matplotlib."""
+    try:
+        import matplotlib
+
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+    except ImportError:
+        return False
+    labels = [r["dtype"] for r in rows]
+    pos = list(range(len(labels)))
+    width = 0.35
+    fig, ax = plt.subplots(figsize=(7, 4))
+    ax.bar([p_ - width / 2 for p_ in pos], [r[f"torch_s_per_{NUM_RUNS}"] for r in rows], width, label="torch.quantize_per_tensor")
+    ax.bar([p_ + width / 2 for p_ in pos], [r[f"piquant_s_per_{NUM_RUNS}"] for r in rows], width, label="piquant.torch.quantize (MI355X)")
+    ax.set_ylabel(f"seconds per {NUM_RUNS} runs")
+    ax.set_xlabel("Quantized dtype")
+    ax.set_title(f"Quantization benchmark (numel={NUMEL}, {NUM_RUNS} runs)")
+    ax.set_xticks(pos)
+    ax.set_xticklabels(labels)
+    ax.set_yscale("log")
+    ax.legend()
+    fig.tight_layout()
+    fig.savefig(path, dpi=120)
+    return True
+
+
 def main():
+    global NUM_RUNS
     ap = argparse.ArgumentParser()
     ap.add_argument("--gib", type=float, default=8.0, help="size of the float tensor for the throughput part (reference: 32)")
+    ap.add_argument("--runs", type=int, default=NUM_RUNS, help="runs per timing (reference: 1000)")
+    ap.add_argument("--plot", default=None, help="write the reference's bar chart to this PNG")
     args = ap.parse_args()
-    out = {"device": torch.cuda.get_device_name(0), "README headline (numel=27264000, seconds per 1000 runs)": readme_headline(),
-           "benchmark_py (NUMEL=1e6, 1000 runs)": torch_vs_piquant(),
+    NUM_RUNS = args.runs
+    bars = torch_vs_piquant()
+    out = {"device": torch.cuda.get_device_name(0), "runs": NUM_RUNS,
+           f"README headline (numel=27264000, seconds per {NUM_RUNS} runs)": readme_headline(),
+           f"benchmark_py (NUMEL=1e6, {NUM_RUNS} runs)": bars,
            f"throughput_avg_py ({args.gib} GiB float tensor, 10 iterations, allocation + sync inside the timed call)": throughput(args.gib)}
+    if args.plot:
+        out["plot"] = args.plot if plot(bars, args.plot) else "matplotlib is not importable: no plot"
     print(json.dumps(out, indent=1))
 
 
