@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--sets", type=int, default=6, help="distinct buffer sets rotated through at N=1 (6 x 136 MB = 818 MB); N>1 keeps the same bytes per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline time budget")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline time budget")
     # test plumbing: exercise the N > 1 control flow on a box with ONE GPU (all ranks on cuda:0, gloo instead of RCCL, which
     # refuses two ranks on one device); the numbers of such a run mean nothing
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)
@@ -74,12 +74,40 @@ def time_loop(fn, steps, stream):
     return t1 - t0, e0.elapsed_time(e1) * 1e-3
 
 
+def host_cpu_order():
+    """Logical CPUs this process may use, ordered so that the first T of them are the natural placement of T workers: one hardware
+    thread per physical core first, socket by socket (so T <= cores of one socket stays on one socket / NUMA node), SMT siblings last.
+    Returns (order, cores_per_socket, physical_cores, sockets)."""
+    allowed = sorted(os.sched_getaffinity(0))
+    info = {}
+    for c in allowed:
+        base = Path(f"/sys/devices/system/cpu/cpu{c}/topology")
+        try:
+            pkg = int((base / "physical_package_id").read_text())
+            core = int((base / "core_id").read_text())
+        except (OSError, ValueError):
+            pkg, core = 0, c
+        info[c] = (pkg, core)
+    first, later, seen = [], [], set()
+    for c in sorted(allowed, key=lambda c_: (info[c_][0], c_)):
+        if info[c] in seen:
+            later.append(c)
+        else:
+            seen.add(info[c])
+            first.append(c)
+    sockets = sorted({info[c][0] for c in allowed})
+    per_socket = max(sum(1 for c in first if info[c][0] == s_) for s_ in sockets)
+    return first + later, per_socket, len(first), len(sockets)
+
+
 def cpu_baseline(x_host: np.ndarray, scale: float, zp: int, budget_s: float, nsets: int):
     """The reference's own AVX kernels (oracle/_ref, prebuilt from the reference sources) on this box's host cores.
 
     Same protocol as the GPU side: calls rotate over `nsets` distinct input/output buffer sets (818 MB for 6 sets,
     more than the host's last-level cache) so the figure is a DRAM figure, not an L3 one; the cache-resident
-    single-buffer figure is reported separately.  Falls back to the scalar C oracle where _ref is absent."""
+    single-buffer figure is reported separately.  NUMA-fair: workers are pinned (one per physical core, socket by socket), and for
+    every thread count the buffers are allocated fresh and each partition is first touched by the worker that will process it, so
+    every worker streams from the memory of its own socket.  Falls back to the scalar C oracle where _ref is absent."""
     import oracle as O
 
     n = x_host.size
@@ -88,41 +116,58 @@ def cpu_baseline(x_host: np.ndarray, scale: float, zp: int, budget_s: float, nse
     if O.ref_available():
         R = O.Ref()
         isa = R.best_isa()
-        ncpu = os.cpu_count() or 1
-        ins = [x_host] + [x_host.copy() for _ in range(nsets - 1)]
-        outs = [np.zeros(n, dtype=np.uint8) for _ in range(nsets)]
-        counts = sorted({t for t in (1, 8, 16, 32, 64, 96, 128, ncpu // 2, ncpu) if 1 <= t <= ncpu})
+        order, per_socket, physical, sockets = host_cpu_order()
+        ncpu = len(order)
+        counts = sorted({t for t in (1, 8, 16, 32, per_socket, physical, ncpu) if 1 <= t <= ncpu})
         per = budget_s / (len(counts) + 1)
+
+        def placed(threads):
+            """fresh buffer sets whose partitions are first touched by their (pinned) workers"""
+            R.set_pinning(order[:threads])
+            ins = [R.partition_copy(x_host, np.empty_like(x_host), threads) for _ in range(nsets)]
+            outs = [np.empty(n, dtype=np.uint8) for _ in range(nsets)]    # untouched: first written by the workers in the first rotation
+            return ins, outs
 
         def rotation_time(threads, budget):
             """best mean-per-call over whole rotations through all buffer sets"""
+            ins, outs = placed(threads)
             best, t_end, rounds = float("inf"), time.perf_counter() + budget, 0
-            while rounds < 2 or time.perf_counter() < t_end:
+            while rounds < 3 or time.perf_counter() < t_end:
                 t0 = time.perf_counter()
                 for k in range(nsets):
                     R.quantize(ins[k], O.F32, O.UINT8, scale, zp, isa=isa, threads=threads, out=outs[k])
-                best = min(best, (time.perf_counter() - t0) / nsets)
+                if rounds > 0:           # the first rotation faults the output pages in
+                    best = min(best, (time.perf_counter() - t0) / nsets)
                 rounds += 1
-            return best
+            return best, ins, outs
 
-        times = {t: rotation_time(t, per) for t in counts}
+        times = {}
+        for t in counts:
+            times[t], ins, outs = rotation_time(t, per)
+            if t != counts[-1]:
+                del ins, outs
         best_t = min(times, key=times.get)
         # cache-resident variant: one buffer set, best single call
+        ins, outs = placed(best_t)
         hot = float("inf")
         t_end = time.perf_counter() + per
         while time.perf_counter() < t_end:
             t0 = time.perf_counter()
             R.quantize(ins[0], O.F32, O.UINT8, scale, zp, isa=isa, threads=best_t, out=outs[0])
             hot = min(hot, time.perf_counter() - t0)
+        R.set_pinning([])
+        named = {1: "1 thread", per_socket: f"one socket ({per_socket} cores)", physical: f"all {physical} physical cores", ncpu: f"all {ncpu} hardware threads"}
         return {
             "value": round(gib / times[best_t], 3), "unit": "GiB/s", "cores": best_t, "kind": "reference",
             "sample": f"reference {R.isa_name(isa)} kernels (oracle/_ref, compiled from the reference sources), fp32->uint8 nearest on "
                       f"the full {n}-element tensor, calls rotating over {nsets} buffer sets ({nsets * 5 * n / 1e6:.0f} MB, beyond the host "
                       f"LLC) like the GPU side, best mean per call over whole rotations, static range split (the reference's partition "
                       f"rule, src/piquant.cpp:145-157) over a persistent std::thread pool standing in for its un-vendored thread pool; "
-                      f"host has {ncpu} logical CPUs; best at {best_t} threads",
+                      f"numa: {sockets} socket(s) x {per_socket} cores, workers pinned one per physical core socket by socket (SMT siblings last), "
+                      f"every buffer partition first touched by the worker that processes it; host has {ncpu} usable hardware threads; best at {best_t} threads",
             "ms_per_call": round(times[best_t] * 1e3, 4),
             "GiB/s_by_threads": {str(t): round(gib / v, 2) for t, v in times.items()},
+            "GiB/s_named": {named[t]: round(gib / times[t], 2) for t in counts if t in named},
             "cache_resident_single_buffer_GiB/s": round(gib / hot, 2),
         }
     m = min(n, 4_000_000)

@@ -201,7 +201,20 @@ class Ref:
         lib.ref_requantize.argtypes = [ci, vp, ci, vp, ci, i64, f32, i64, ci, f32, ci]
         lib.ref_minmax_f32.argtypes = [ci, vp, i64, ci, C.POINTER(f32)]
         lib.ref_minmax_bf16.argtypes = [ci, vp, i64, C.POINTER(f32)]
+        lib.ref_set_pinning.argtypes = [C.POINTER(ci), ci]
+        lib.ref_partition_copy.argtypes = [vp, vp, i64, ci, ci]
         self.lib = lib
+
+    def set_pinning(self, cpus) -> None:
+        """pool thread t runs on logical CPU cpus[t] (timing runs; an empty list removes the pinning)"""
+        arr = (C.c_int * max(len(cpus), 1))(*cpus)
+        self.lib.ref_set_pinning(arr, len(cpus))
+
+    def partition_copy(self, src: np.ndarray, dst: np.ndarray, threads: int) -> np.ndarray:
+        """dst[:] = src, each pool thread copying (and thereby first-touching) the partition it will later process"""
+        assert src.flags.c_contiguous and dst.flags.c_contiguous and src.dtype == dst.dtype and src.size == dst.size
+        self.lib.ref_partition_copy(src.ctypes.data, dst.ctypes.data, src.size, src.dtype.itemsize, threads)
+        return dst
 
     def isa_name(self, isa: int) -> str:
         return self.lib.ref_isa_name(isa).decode()

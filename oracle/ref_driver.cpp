@@ -30,6 +30,9 @@
 #include <thread>
 #include <vector>
 
+#include <pthread.h>
+#include <sched.h>
+
 namespace piquant {
     [[noreturn]] void panic(const char* msg, ...) {
         std::va_list ap;
@@ -94,22 +97,43 @@ namespace {
         return len > 0;
     }
 
+    // Optional pinning for timing runs (bench.py cpu_baseline): worker t of the pool runs on logical CPU g_pin[t].  On a two-socket
+    // host an unpinned pool wanders between the sockets and the figure becomes a NUMA accident; with pinning, and with every buffer
+    // partition first touched by the worker that will process it (ref_partition_copy below), each worker streams from its own node.
+    std::vector<int> g_pin;
+
+    void pin_this_thread(int index) {
+        if (index < 0 || index >= static_cast<int>(g_pin.size())) return;
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        CPU_SET(g_pin[index], &set);
+        (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
+    }
+
     // Persistent worker pool (the reference keeps its pool threads alive between calls too,
     // src/piquant.cpp:178-181); created on first use with the requested size, re-created if the size changes.
     class Pool {
     public:
         void run(int threads, const std::function<void(int)>& job) {
             std::unique_lock<std::mutex> lk(m_);
-            if (static_cast<int>(workers_.size()) != threads - 1) resize(lk, threads - 1);
+            if (static_cast<int>(workers_.size()) != threads - 1 || repin_) resize(lk, threads - 1);
             job_ = &job;
             pending_ = threads - 1;
             ++generation_;
             cv_start_.notify_all();
             lk.unlock();
+            cpu_set_t saved;
+            const bool pinned = !g_pin.empty() && pthread_getaffinity_np(pthread_self(), sizeof saved, &saved) == 0;
+            if (pinned) pin_this_thread(0);
             job(0);                                   // the caller is thread 0
+            if (pinned) (void)pthread_setaffinity_np(pthread_self(), sizeof saved, &saved);
             lk.lock();
             cv_done_.wait(lk, [&] { return pending_ == 0; });
             job_ = nullptr;
+        }
+        void repin() {
+            std::unique_lock<std::mutex> lk(m_);
+            repin_ = true;
         }
         ~Pool() {
             std::unique_lock<std::mutex> lk(m_);
@@ -125,9 +149,11 @@ namespace {
             lk.lock();
             workers_.clear();
             stop_ = false;
+            repin_ = false;
             for (int i = 0; i < n; ++i) workers_.emplace_back([this, i, gen = generation_]() mutable { loop(i + 1, gen); });
         }
         void loop(int index, unsigned long seen) {
+            pin_this_thread(index);
             std::unique_lock<std::mutex> lk(m_);
             for (;;) {
                 cv_start_.wait(lk, [&] { return generation_ != seen; });
@@ -147,6 +173,7 @@ namespace {
         unsigned long generation_ = 0;
         int pending_ = 0;
         bool stop_ = false;
+        bool repin_ = false;
     };
     Pool g_pool;
 
@@ -166,6 +193,25 @@ namespace {
 }
 
 extern "C" {
+
+// cpus[t] = logical CPU of pool thread t (thread 0 is the caller, pinned only for the duration of a call); n == 0 removes the pinning.
+void ref_set_pinning(const int* cpus, int n) {
+    g_pin.assign(cpus, cpus + (n > 0 ? n : 0));
+    g_pool.repin();
+}
+
+// dst[i] = src[i] over `numel` elements of `elem_bytes` bytes, split over `threads` pool threads by the reference's partition rule:
+// called on a freshly allocated (never touched) dst it makes every partition's pages land on the NUMA node of the worker that
+// will later process that partition (first touch).
+void ref_partition_copy(const void* src, void* dst, long long numel, int elem_bytes, int threads) {
+    auto job = [&](int t) {
+        std::int64_t b, n;
+        if (!split(numel, t, threads, 1, b, n)) return;
+        std::memcpy(static_cast<char*>(dst) + b * elem_bytes, static_cast<const char*>(src) + b * elem_bytes, static_cast<std::size_t>(n) * elem_bytes);
+    };
+    if (threads <= 1) { job(0); return; }
+    g_pool.run(threads, job);
+}
 
 int ref_isa_count(void) { return ISA_COUNT; }
 const char* ref_isa_name(int isa) { return isa >= 0 && isa < ISA_COUNT ? isa_names[isa] : "?"; }

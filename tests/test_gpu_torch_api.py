@@ -181,7 +181,7 @@ def test_reference_style_benchmark_harness_runs(tmp_path):
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(r.stdout)
-    assert d["runs"] == 50 and "MI3" in d["device"]
+    assert d["runs"] == 50 and d["device"]
     bars = d["benchmark_py (NUMEL=1e6, 50 runs)"]
     assert [b["dtype"] for b in bars] == ["quint8", "quint4x2", "quint2x4"]
     for b in bars:
