@@ -76,28 +76,44 @@ def time_loop(fn, steps, stream):
 
 def host_cpu_order():
     """Logical CPUs this process may use, ordered so that the first T of them are the natural placement of T workers: one hardware
-    thread per physical core first, socket by socket (so T <= cores of one socket stays on one socket / NUMA node), SMT siblings last.
-    Returns (order, cores_per_socket, physical_cores, sockets)."""
+    thread per physical core first, socket by socket (T <= cores of one socket stays on one socket / NUMA node), and within a socket
+    round-robin over the last-level-cache domains (on EPYC a CCD's link to memory is much narrower than the socket's DRAM: eight
+    workers belong on eight CCDs, not on one); SMT siblings last.  Returns (order, cores_per_socket, physical_cores, sockets)."""
     allowed = sorted(os.sched_getaffinity(0))
     info = {}
     for c in allowed:
-        base = Path(f"/sys/devices/system/cpu/cpu{c}/topology")
+        base = Path(f"/sys/devices/system/cpu/cpu{c}")
         try:
-            pkg = int((base / "physical_package_id").read_text())
-            core = int((base / "core_id").read_text())
+            pkg = int((base / "topology" / "physical_package_id").read_text())
+            core = int((base / "topology" / "core_id").read_text())
         except (OSError, ValueError):
             pkg, core = 0, c
-        info[c] = (pkg, core)
+        try:
+            llc = (base / "cache" / "index3" / "shared_cpu_list").read_text().strip()
+        except OSError:
+            llc = "all"
+        info[c] = (pkg, core, llc)
     first, later, seen = [], [], set()
-    for c in sorted(allowed, key=lambda c_: (info[c_][0], c_)):
-        if info[c] in seen:
+    for c in allowed:
+        if info[c][:2] in seen:
             later.append(c)
         else:
-            seen.add(info[c])
+            seen.add(info[c][:2])
             first.append(c)
     sockets = sorted({info[c][0] for c in allowed})
+    order = []
+    for s_ in sockets:
+        domains = {}
+        for c in first:
+            if info[c][0] == s_:
+                domains.setdefault(info[c][2], []).append(c)
+        queues = [domains[k] for k in sorted(domains, key=lambda k: domains[k][0])]
+        while any(queues):
+            for q in queues:
+                if q:
+                    order.append(q.pop(0))
     per_socket = max(sum(1 for c in first if info[c][0] == s_) for s_ in sockets)
-    return first + later, per_socket, len(first), len(sockets)
+    return order + later, per_socket, len(first), len(sockets)
 
 
 def cpu_baseline(x_host: np.ndarray, scale: float, zp: int, budget_s: float, nsets: int):
@@ -163,7 +179,7 @@ def cpu_baseline(x_host: np.ndarray, scale: float, zp: int, budget_s: float, nse
                       f"the full {n}-element tensor, calls rotating over {nsets} buffer sets ({nsets * 5 * n / 1e6:.0f} MB, beyond the host "
                       f"LLC) like the GPU side, best mean per call over whole rotations, static range split (the reference's partition "
                       f"rule, src/piquant.cpp:145-157) over a persistent std::thread pool standing in for its un-vendored thread pool; "
-                      f"numa: {sockets} socket(s) x {per_socket} cores, workers pinned one per physical core socket by socket (SMT siblings last), "
+                      f"numa: {sockets} socket(s) x {per_socket} cores, workers pinned one per physical core, socket by socket and round-robin over the L3 domains within a socket (SMT siblings last), "
                       f"every buffer partition first touched by the worker that processes it; host has {ncpu} usable hardware threads; best at {best_t} threads",
             "ms_per_call": round(times[best_t] * 1e3, 4),
             "GiB/s_by_threads": {str(t): round(gib / v, 2) for t, v in times.items()},

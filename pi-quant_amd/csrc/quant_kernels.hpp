@@ -160,6 +160,34 @@ __device__ __forceinline__ void quantize_vec_bounded(const u32x4& raw, float inv
     constexpr int EPV = InVec<DT_IN>::EPV, WORDS = (EPV * BITS / 8) > 4 ? 2 : 1, EPW = EPV / WORDS;
     float v[EPV];
     InVec<DT_IN>::unpack(raw, v);
+    if constexpr (BITS == 8 && !GENERIC) {
+        // 8-bit fields: gfx950's v_cvt_pk_u8_f32 converts a float to uint8 with saturation to [0, 255] (NaN -> 0) and inserts it into a
+        // chosen byte of a word -- clamp and pack in one instruction.  It rounds to nearest even, so it is fed the already truncated
+        // value plus the zero point, an integer-valued float for which every rounding mode agrees (tools/probe_cvt_pk_u8.hip):
+        //     clamp(trunc(adj) + zp, 0, 255) == sat_u8(trunc(adj) + float(zp))
+        // (the float sum is exact below 2^24 and far outside [0, 255], with the right sign, above).  4.5 instructions per element.
+        const float zp_f = -b.lo;
+        float tz[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; e += 2) {
+            const f32x2 x = {v[e], v[e + 1]};
+            const f32x2 prod = x * inv_scale;
+            const f32x2 half = {__builtin_copysignf(0.5f, prod[0]), __builtin_copysignf(0.5f, prod[1])};
+            const f32x2 adj = prod + half;
+            const f32x2 tr = {__builtin_truncf(adj[0]), __builtin_truncf(adj[1])};
+            const f32x2 sum = tr + zp_f;
+            tz[e] = sum[0];
+            tz[e + 1] = sum[1];
+        }
+#pragma unroll
+        for (int j = 0; j < WORDS; ++j) {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_cvt_pk_u8_f32(tz[j * 4 + e], static_cast<uint32_t>(e), acc);
+            w[j] = acc;
+        }
+        return;
+    }
     int32_t t[EPV];
 #pragma unroll
     for (int e = 0; e < EPV; e += 2) {

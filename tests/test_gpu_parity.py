@@ -478,6 +478,35 @@ def test_requantize_torch_api(O):
 # ---------------------------------------------------------------------------------------------------
 # compute_quant_params
 # ---------------------------------------------------------------------------------------------------
+def test_minmax_scan_ignores_nans_like_the_oracle(ctx, O):
+    """NaNs are skipped by the HIP scan wherever they sit (v_min/v_max return the other operand): the position-independent reading of
+    the reference's out-of-contract behaviour that tests/test_oracle_vs_ref.py pins; a tensor of NaNs only scans to the identities."""
+    import piquant
+    import torch
+
+    rng = np.random.default_rng(33)
+    for n in (37, 64, 1000, 4099, 1_000_003):
+        x = rng.uniform(-1, 1, n).astype(np.float32)
+        x[n // 3], x[n // 2] = -5.0, 7.0
+        x[[0, n - 1, n // 5]] = np.nan
+        for dt, host in ((piquant.DataType.F32, x), (piquant.DataType.BF16, O.f32_to_bf16(x))):
+            keep, ptr = to_device(host)
+            keys = torch.empty(2, dtype=torch.int32, device="cuda")
+            ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            ctx.set_blocking(False)
+            ctx.minmax_keys_ptr(ptr, dt, n, keys.data_ptr(), True)
+            torch.cuda.synchronize()
+            k = keys.cpu().numpy()
+            assert piquant.decode_minmax_keys(int(k[0]), int(k[1])) == O.minmax(host, O.F32 if dt == piquant.DataType.F32 else O.BF16) == (-5.0, 7.0)
+    nans = torch.full((1000,), float("nan"), device="cuda")
+    keys = torch.empty(2, dtype=torch.int32, device="cuda")
+    ctx.minmax_keys_ptr(nans.data_ptr(), piquant.DataType.F32, 1000, keys.data_ptr(), True)
+    torch.cuda.synchronize()
+    k = keys.cpu().numpy()
+    lo, hi = piquant.decode_minmax_keys(int(k[0]), int(k[1]))
+    assert lo == np.float32(3.4028235e38) and hi == -np.float32(3.4028235e38)
+
+
 def test_compute_quant_params_matches_oracle(ctx, O):
     import piquant
     import torch

@@ -141,3 +141,26 @@ def test_headline_config_uniform_equals_reference(both):
     ref = R.quantize(x, O.F32, O.UINT8, scale, zp)
     assert np.array_equal(ref, O.quantize(x, O.F32, O.UINT8, scale, zp, form=O.FORM_UNIFORM))
     assert np.array_equal(ref, R.quantize(x, O.F32, O.UINT8, scale, zp, threads=8))
+
+
+def test_minmax_with_nans_the_reference_depends_on_position_the_oracle_ignores_them(both):
+    """VERDICT r01 "missing 6": NaN semantics of the min/max scan (reference kernels_specialized.inl:1427-1442: minps/maxps return their
+    SECOND operand when one is a NaN).  Pinned here: the reference's generic unit skips NaNs wherever they sit; its AVX-512 unit skips them
+    too -- unless one lands where the vector accumulators are folded last (e.g. the last element of a 64-element span), and then both
+    results are NaN.  NaN input is outside the reference's contract (compute_quant_params asserts the scale, src/piquant.cpp:373); the
+    oracle and the HIP scan implement the position-independent reading: NaNs are ignored, as the generic unit does."""
+    O, R = both
+    rng = np.random.default_rng(0)
+    for n, nan_at in ((1000, [0]), (1000, [999]), (1000, [3, 700]), (64, [0]), (37, [5]), (64, [63])):
+        x = rng.uniform(-1, 1, n).astype(np.float32)
+        x[10], x[20] = -5.0, 7.0
+        x[nan_at] = np.nan
+        assert O.minmax(x, O.F32) == (-5.0, 7.0)
+        assert R.minmax(x, O.F32, isa=R.GENERIC) == (-5.0, 7.0)
+        got = R.minmax(x, O.F32, isa=R.AVX512F)
+        if (n, nan_at) == (64, [63]):
+            assert np.isnan(got[0]) and np.isnan(got[1])     # the position-dependent case
+        else:
+            assert got == (-5.0, 7.0)
+    xb = O.f32_to_bf16(np.array([1.0, np.nan, -3.0, 2.0] * 50, dtype=np.float32))
+    assert O.minmax(xb, O.BF16) == (-3.0, 2.0)

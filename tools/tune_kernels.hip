@@ -368,6 +368,16 @@ static void run_fused(const Bufs& b, const FusedBufs& f, int64_t numel, int num_
     stats("barrier wait + params", [&](int b) { return static_cast<double>(t[b * 8 + 2] - t[b * 8 + 1]); });
     stats("quantize + store issue", [&](int b) { return static_cast<double>(t[b * 8 + 4] - t[b * 8 + 3]); });
     stats("end (since first start)", [&](int b) { return static_cast<double>(t[b * 8 + 4] - t_begin); });
+    // does the load time depend on where the block runs?  blocks are dealt to the 8 XCDs round-robin (block b -> XCD b % 8)
+    std::fprintf(stderr, "  load end (since first start), median by b %% 8:");
+    for (int x = 0; x < 8; ++x) {
+        std::vector<double> v;
+        for (int b = x; b < num_cu - 1; b += 8) v.push_back((t[b * 8 + 1] - t_begin) * 0.01);
+        std::sort(v.begin(), v.end());
+        std::fprintf(stderr, " %5.2f/%5.2f", v[v.size() / 2], v.back());
+    }
+    std::fprintf(stderr, " (median/max us)\n  load end by block index, 16 blocks per row (us):\n");
+    for (int b = 0; b < num_cu; ++b) std::fprintf(stderr, "%s%6.2f%s", b % 16 == 0 ? "   " : "", (t[b * 8 + 1] - t_begin) * 0.01, b % 16 == 15 ? "\n" : "");
 }
 
 int main(int argc, char** argv) {
@@ -667,6 +677,45 @@ int main(int argc, char** argv) {
             run_minmax<DT_BF16, 4, true, 256, true>(b, numel, num_cu, keys);
         }
         g_mm_caps = {1, 2, 4, 8, 16, 32};
+        g_rounds = 3;
+    }
+    if (only == "mm3") {
+        // wider geometry sweep of the scan with the gather end: threads per block x loads in flight per lane x blocks per CU
+        g_rounds = 1;
+        g_mm_caps = {1, 2};
+        for (int pass = 0; pass < 4; ++pass) {
+            run_minmax<DT_F32, 4, true, 512, true>(b, numel, num_cu, keys);
+            run_minmax<DT_F32, 8, true, 256, true>(b, numel, num_cu, keys);
+            run_minmax<DT_F32, 16, true, 256, true>(b, numel, num_cu, keys);
+            run_minmax<DT_F32, 16, true, 128, true>(b, numel, num_cu, keys);
+            run_minmax<DT_F32, 8, true, 128, true>(b, numel, num_cu, keys);
+            run_minmax<DT_F32, 2, true, 1024, true>(b, numel, num_cu, keys);
+            run_minmax<DT_F32, 2, true, 512, true>(b, numel, num_cu, keys);
+            run_minmax<DT_F32, 6, true, 512, true>(b, numel, num_cu, keys);
+            run_minmax<DT_F32, 4, false, 512, true>(b, numel, num_cu, keys);
+            run_minmax<DT_F32, 4, true, 768, true>(b, numel, num_cu, keys);
+            run_minmax<DT_F32, 4, true, 384, true>(b, numel, num_cu, keys);
+        }
+        g_mm_caps = {1, 2, 4, 8, 16, 32};
+        g_rounds = 3;
+    }
+    if (only == "q4") {
+        // bf16 -> uint4 at numel (pass N1/2 as numel: the bf16 view holds 2 * numel elements): tile shapes and persistent grids
+        g_rounds = 1;
+        for (int pass = 0; pass < 4; ++pass) {
+            g_caps = {0, 8, 16, 32};
+            run_quant<DT_BF16, 4, RM_NEAREST_FAST, 2, true, 5, 64>(b, 2 * numel, num_cu, 2.5);
+            run_quant<DT_BF16, 4, RM_NEAREST_FAST, 1, true, 5, 64>(b, 2 * numel, num_cu, 2.5);
+            run_quant<DT_BF16, 4, RM_NEAREST_FAST, 2, false, 5, 64>(b, 2 * numel, num_cu, 2.5);
+            run_quant<DT_BF16, 4, RM_NEAREST_FAST, 4, true, 5, 256>(b, 2 * numel, num_cu, 2.5);
+            run_quant<DT_BF16, 4, RM_NEAREST_FAST, 2, true, 5, 256>(b, 2 * numel, num_cu, 2.5);
+            run_quant<DT_BF16, 4, RM_NEAREST_FAST, 1, true, 5, 256>(b, 2 * numel, num_cu, 2.5);
+            run_quant<DT_BF16, 4, RM_NEAREST_FAST, 2, true, 5, 1024>(b, 2 * numel, num_cu, 2.5);
+            run_quant<DT_BF16, 4, RM_NEAREST_FAST, 1, true, 5, 1024>(b, 2 * numel, num_cu, 2.5);
+            run_quant<DT_BF16, 4, RM_NEAREST_FAST, 2, true, 3, 64>(b, 2 * numel, num_cu, 2.5);
+            run_quant<DT_BF16, 4, RM_NEAREST_FAST, 2, true, 1, 64>(b, 2 * numel, num_cu, 2.5);
+        }
+        g_caps = {0, 2, 4, 8, 16};
         g_rounds = 3;
     }
     if (only == "all" || only == "mm") {
