@@ -258,9 +258,18 @@ def main():
     ptr_in = [t.data_ptr() for t in xs]
     ptr_out = [t.data_ptr() for t in outs]
 
+    # One step = one piquant_quantize call through the C ABI.  The call is made through ctypes with its nine arguments built once per
+    # buffer set: 3.9 us of host time per call instead of the 4.7 us of Context.quantize_ptr (enum lookups, asserts), which matters at
+    # N = 8, where a 3.4 M-element shard is a 4.9 us kernel and a slower host would leave the queue empty between launches
+    # (profiles/r02_host_call_cost.json).  The context is already stream-ordered, non-blocking and in device-pointer mode.
+    from piquant._bootstrap import C_LIB
+
+    ctx.assume_device_pointers(True)
+    c_quantize = C_LIB.piquant_quantize
+    call_args = [(ctx._ctx, ptr_in[k], DataType.F32.value, ptr_out[k], DataType.UINT8.value, n, scale, zp, RoundMode.NEAREST.value) for k in range(nsets)]
+
     def step(i):
-        k = i % nsets
-        ctx.quantize_ptr(ptr_in[k], DataType.F32, ptr_out[k], DataType.UINT8, n, scale, zp, RoundMode.NEAREST, _device_ptrs=True)
+        c_quantize(*call_args[i % nsets])
 
     PREWARM = 2000
     with torch.cuda.stream(stream):
@@ -389,8 +398,10 @@ def main():
                 wo.append(torch.empty(n_total, dtype=torch.uint8, device=dev))
             pwi, pwo = [t_.data_ptr() for t_ in wx], [t_.data_ptr() for t_ in wo]
 
+            wargs = [(ctx._ctx, pwi[k], DataType.F32.value, pwo[k], DataType.UINT8.value, n_total, scale, zp, RoundMode.NEAREST.value) for k in range(wsets)]
+
             def wstep(i):
-                ctx.quantize_ptr(pwi[i % wsets], DataType.F32, pwo[i % wsets], DataType.UINT8, n_total, scale, zp, RoundMode.NEAREST, _device_ptrs=True)
+                c_quantize(*wargs[i % wsets])
 
             with torch.cuda.stream(stream):
                 for i in range(max(args.warmup, 20)):
@@ -415,10 +426,11 @@ def main():
         extras = {"config5_sharded_compute_quant_params": config5}
         with torch.cuda.stream(stream):
             # same kernel with everything resident in the Infinity Cache (one 136 MB set): NOT the headline
-            w, e = time_loop(lambda i: ctx.quantize_ptr(ptr_in[0], DataType.F32, ptr_out[0], DataType.UINT8, n, scale, zp, RoundMode.NEAREST), 200, stream)
+            w, e = time_loop(lambda i: ctx.quantize_ptr(ptr_in[0], DataType.F32, ptr_out[0], DataType.UINT8, n, scale, zp, RoundMode.NEAREST, _device_ptrs=True), 200, stream)
             extras["warm_cache_single_set"] = {"GiB/s": round(gib_per_step * 200 / w, 1), "avg_launch_us": round(e / 200 * 1e6, 3)}
             # reference semantics: every call waits for completion (blocking context); A/B of the three ways to wait (capi.cpp wait_stream)
             ctx.set_blocking(True)
+            ctx.assume_device_pointers(True)      # step() makes the raw C call: the context must know these are device pointers
             blocking = {}
             for mode in ("sync", "write32", "kernel"):
                 ctx.set_blocking_wait(mode)

@@ -65,10 +65,13 @@ PIQUANT_EXPORT void piquant_hip_set_stochastic_per_element(piquant_context_t* ct
  * a few corner inputs (|x/scale| = 0.49999997, odd |x/scale| >= 2^23, bf16 ADD ties), and the
  * 1-3 element tail of uint2 -> f32 ADD stores instead of adding (dequantize.inl:72-86).  With this mode on, those
  * positions use the reference's scalar formulas, so every output byte equals what the reference's AVX-512 build writes
- * from a context with ONE pool thread (with T threads the reference's positions depend on its partition; not modelled).
- * Costs nothing on aligned bulk data (only the guarded tail path looks at it); a non-zero head sends the whole fp32 ->
- * uint8 call through the guarded (slower) kernel.  For golden-file regression against reference output, not production. */
+ * from a context with ONE pool thread.  A reference context with T pool threads splits the call into T partitions
+ * (src/piquant.cpp:145-157), each with its own head and tail: piquant_hip_set_reference_threads(ctx, T) reproduces those positions
+ * (default 1; only read in reference-layout mode).
+ * Costs nothing on aligned bulk data with T = 1 (only the guarded tail path looks at it); a non-zero head, or T > 1, sends the whole
+ * call through the guarded (slower) kernels.  For golden-file regression against reference output, not production. */
 PIQUANT_EXPORT void piquant_hip_set_reference_layout(piquant_context_t* ctx, int enabled);
+PIQUANT_EXPORT void piquant_hip_set_reference_threads(piquant_context_t* ctx, int threads);
 
 /* Fused quantize -> dequantize: out[i] (op)= dequantize(quantize(in[i])) without materialising the quantized tensor;
  * dtype_in_out (F32 or BF16) is the type of BOTH buffers, quant_dtype (UINT2/4/8) the type passed through; `out` may

@@ -140,6 +140,7 @@ struct piquant_context_t {
     float fixed_threshold = -1.0f;
     bool per_element = false;
     bool reference_layout = false;
+    int reference_threads = 1;             // piquant_hip_set_reference_threads: pool threads of the reference context reproduced in reference-layout mode
     uint64_t elem_seed = 0, elem_base = 0;
     std::mutex mu;
 
@@ -384,12 +385,16 @@ static void quantize_impl(piquant_context_t* ctx, const void* in, piquant_dtype_
     q.zero_point = zero_point;
     fill_round_mode(ctx, q, mode);
 
+    q.ref_out_align = -1;
     if (ctx->reference_layout) {
         q.ref_layout = true;
         q.ref_total = static_cast<int64_t>(numel);
+        q.ref_threads = ctx->reference_threads;
         // kernels_specialized.inl:52: fp32 -> uint8 peels scalar elements until the OUTPUT pointer (as the caller passed it) is 16-byte aligned
-        if (dtype_in == PIQUANT_DTYPE_F32 && dtype_out == PIQUANT_DTYPE_UINT8 && mode == PIQUANT_NEAREST)
+        if (dtype_in == PIQUANT_DTYPE_F32 && dtype_out == PIQUANT_DTYPE_UINT8 && mode == PIQUANT_NEAREST) {
             q.ref_head = static_cast<int>(std::min<size_t>(numel, (16u - (reinterpret_cast<uintptr_t>(out) & 15u)) & 15u));
+            q.ref_out_align = static_cast<int>(reinterpret_cast<uintptr_t>(out) & 15u);
+        }
     }
     const Resolved rin = ctx->resolve_ptr(in), rout = ctx->resolve_ptr(out);
     if (dyn_params) {
@@ -468,6 +473,7 @@ static void dequantize_impl(piquant_context_t* ctx, const void* in, piquant_dtyp
 
     d.ref_layout = ctx->reference_layout;
     d.ref_total = static_cast<int64_t>(numel);
+    d.ref_threads = ctx->reference_threads;
     const Resolved rin = ctx->resolve_ptr(in), rout = ctx->resolve_ptr(out);
     if (dyn_params) {
         const Resolved rp = resolve(dyn_params);
@@ -719,11 +725,15 @@ static void quantize_dynamic_one(piquant_context_t* ctx, QuantLaunch q, const vo
     q.in = in_dev;
     q.out = out_dev;
     q.numel = static_cast<int64_t>(numel);
+    q.ref_out_align = -1;
     if (ctx->reference_layout) {
         q.ref_layout = true;
         q.ref_total = q.numel;
-        if (q.dt_in == PIQUANT_DTYPE_F32 && q.dt_out == PIQUANT_DTYPE_UINT8 && q.round_mode == RM_NEAREST_FAST)
+        q.ref_threads = ctx->reference_threads;
+        if (q.dt_in == PIQUANT_DTYPE_F32 && q.dt_out == PIQUANT_DTYPE_UINT8 && q.round_mode == RM_NEAREST_FAST) {
             q.ref_head = static_cast<int>(std::min<size_t>(numel, (16u - (reinterpret_cast<uintptr_t>(out_as_passed) & 15u)) & 15u));
+            q.ref_out_align = static_cast<int>(reinterpret_cast<uintptr_t>(out_as_passed) & 15u);
+        }
     }
     // One launch with the tensor held on chip between the scan and the quantization when it fits; otherwise (or with fusion
     // switched off) the same result from two launches: the scan, whose last block writes the record, and a quantize that reads it.
@@ -1101,6 +1111,13 @@ void piquant_hip_set_reference_layout(piquant_context_t* ctx, int enabled) {
     if (!ctx) panic("piquant_hip_set_reference_layout: context is NULL");
     std::lock_guard<std::mutex> lock(ctx->mu);
     ctx->reference_layout = enabled != 0;
+}
+
+void piquant_hip_set_reference_threads(piquant_context_t* ctx, int threads) {
+    if (!ctx) panic("piquant_hip_set_reference_threads: context is NULL");
+    if (threads < 1 || threads > 65536) panic("piquant_hip_set_reference_threads: %d threads", threads);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->reference_threads = threads;
 }
 
 void piquant_hip_set_stochastic_per_element(piquant_context_t* ctx, int enabled, uint64_t seed, uint64_t index_base) {

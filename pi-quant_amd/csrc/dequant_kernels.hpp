@@ -30,7 +30,9 @@ __device__ __forceinline__ void dequant_store_scalar(const uint8_t* in, void* ou
         // SIMD block (64 / 128 / 256 elements for uint8 / uint4 / uint2->bf16; groups of 4 for the generic uint2->f32).
         const int64_t g = p.ref_index0 + i;
         constexpr int64_t BLK = BITS == 8 ? 64 : (BITS == 4 ? 128 : (DT_OUT == DT_BF16 ? 256 : 4));
-        if (g >= (p.ref_total / BLK) * BLK) {
+        int64_t begin = 0, len = p.ref_total;        // the tail is the tail of the element's partition (a T-thread reference context)
+        if (p.ref_threads > 1) ref_partition_of(g, p.ref_total, p.ref_threads, PACK, begin, len);
+        if (g - begin >= (len / BLK) * BLK) {
             if constexpr (DT_OUT == DT_F32) {
                 if constexpr (BITS == 2) {   // dequantize.inl:72-86: the 1-3 element tail always stores, ADD is ignored
                     static_cast<float*>(out)[i] = dequant_one<FORM>(q, p);

@@ -42,9 +42,11 @@ struct QuantParams {
     // scalar head/tail formula instead of the SIMD-body formula, for a context with one pool thread.  Positions are global
     // (ref_index0 = global index of this launch's element 0) so that chunked host staging keeps the layout of the whole call.
     int32_t ref_layout;
-    int32_t ref_head;         // leading elements processed by the scalar head loop (fp32 -> uint8 only, kernels_specialized.inl:52)
+    int32_t ref_head;         // leading elements processed by the scalar head loop (fp32 -> uint8 only, kernels_specialized.inl:52); ref_threads == 1
     int64_t ref_total;        // numel of the whole call
     int64_t ref_index0;
+    int32_t ref_threads;      // pool threads of the reference context being reproduced (>= 1): every partition has its own head and tail
+    int32_t ref_out_align;    // (output pointer as the caller passed it) & 15, or -1 when the pair has no scalar head: heads of the partitions
 };
 
 struct DequantParams {
@@ -56,6 +58,7 @@ struct DequantParams {
     int32_t ref_layout;       // as in QuantParams (tail formulas of the bf16 kernels, the uint2 -> f32 tail)
     int64_t ref_total;
     int64_t ref_index0;
+    int32_t ref_threads;      // as in QuantParams
 };
 
 // Kernel-entry resolution of the dynamic parameters (wave-uniform scalar loads; a no-op when dyn is null).
@@ -205,10 +208,37 @@ __device__ __forceinline__ uint32_t quant_nearest_tail32(float x, const QuantPar
     return quant_nearest_finish<QMAX>(r, p);
 }
 
-// true when global element g of a call lies in the reference's scalar head or tail (block = SIMD block of the kernel)
-__device__ __forceinline__ bool ref_scalar_position(const QuantParams& p, int64_t g, int64_t block) {
-    const int64_t body_end = p.ref_head + ((p.ref_total - p.ref_head) / block) * block;
-    return g < p.ref_head || g >= body_end;
+// Partition of a T-thread reference context that holds global element g (src/piquant.cpp:145-157): thread t covers [n t / T, n (t + 1) / T),
+// both ends aligned down to `pack` elements (a whole packed byte), the last thread keeps the ragged end.
+__device__ __forceinline__ void ref_partition_of(int64_t g, int64_t n, int64_t T, int64_t pack, int64_t& begin, int64_t& len) {
+    auto first = [&](int64_t t) {
+        const int64_t b = n * t / T;
+        return t >= T ? n : (pack > 1 ? b - b % pack : b);
+    };
+    int64_t t = ((g + 1) * T + n - 1) / n - 1;        // largest t with n t / T <= g, before the alignment moves the ends down
+    t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+    while (t > 0 && g < first(t)) --t;
+    while (t + 1 < T && g >= first(t + 1)) ++t;
+    begin = first(t);
+    len = first(t + 1) - begin;
+}
+
+// true when global element g of a call lies in the reference's scalar head or tail (block = SIMD block of the kernel, pack = elements
+// per packed output byte): of the whole call for a one-thread context, of its partition otherwise
+__device__ __forceinline__ bool ref_scalar_position(const QuantParams& p, int64_t g, int64_t block, int64_t pack) {
+    if (p.ref_threads <= 1) {
+        const int64_t body_end = p.ref_head + ((p.ref_total - p.ref_head) / block) * block;
+        return g < p.ref_head || g >= body_end;
+    }
+    int64_t begin, len;
+    ref_partition_of(g, p.ref_total, p.ref_threads, pack, begin, len);
+    int64_t head = 0;
+    if (p.ref_out_align >= 0) {   // fp32 -> uint8: the partition's output starts at out + begin bytes
+        head = (16 - ((p.ref_out_align + begin) & 15)) & 15;
+        head = head < len ? head : len;
+    }
+    const int64_t local = g - begin;
+    return local < head || local >= head + ((len - head) / block) * block;
 }
 
 // quantize.inl:21-26

@@ -32,7 +32,8 @@ void quantize_t(const QuantLaunch& q, const QuantParams& p, hipStream_t stream, 
     constexpr KernelTune t = kQuantTune[DT_IN][bits_index(BITS)];
     using Tile = QuantTile<DT_IN, BITS, t.u, t.block>;
     uint8_t* out = static_cast<uint8_t*>(q.out);
-    if (!aligned16(q.in) || !aligned16(q.out) || (q.ref_layout && q.ref_head != 0)) {   // a scalar head shifts every SIMD block: guarded kernel
+    // a scalar head shifts every SIMD block, and the partitions of a T-thread reference context put heads and tails inside the tensor: guarded kernel
+    if (!aligned16(q.in) || !aligned16(q.out) || (q.ref_layout && (q.ref_head != 0 || q.ref_threads > 1))) {
         constexpr int PACK = 8 / BITS;
         const int64_t nbytes = (q.numel + PACK - 1) / PACK;
         const unsigned grid = capped_grid((nbytes + kScalarBlock - 1) / kScalarBlock, 16, num_cu);
@@ -75,7 +76,7 @@ void dequantize_t(const DequantLaunch& d, const DequantParams& p, hipStream_t st
     constexpr KernelTune t = OP == OP_ADD ? kDequantAddTune[DT_OUT][bits_index(BITS)] : kDequantTune[DT_OUT][bits_index(BITS)];
     using Tile = DequantTile<BITS, DT_OUT, t.u, t.block>;
     const uint8_t* in = static_cast<const uint8_t*>(d.in);
-    if (!aligned16(d.in) || !aligned16(d.out)) {
+    if (!aligned16(d.in) || !aligned16(d.out) || (d.ref_layout && d.ref_threads > 1)) {   // partition tails inside the tensor: every element looks at its position
         const unsigned grid = capped_grid((d.numel + kScalarBlock - 1) / kScalarBlock, 16, num_cu);
         hipLaunchKernelGGL((dequantize_scalar_kernel<BITS, DT_OUT, OP>), dim3(grid), dim3(kScalarBlock), 0, stream, in, d.out, d.numel, p);
         return;
@@ -150,6 +151,8 @@ void launch_quantize(const QuantLaunch& q, hipStream_t stream, int num_cu) {
     p.ref_head = q.ref_head;
     p.ref_total = q.ref_total;
     p.ref_index0 = q.ref_index0;
+    p.ref_threads = q.ref_threads > 1 ? q.ref_threads : 1;
+    p.ref_out_align = q.ref_out_align;
     switch (q.dt_in) {
         case DT_F32: quantize_bits<DT_F32>(q, p, stream, num_cu); break;
         case DT_BF16: quantize_bits<DT_BF16>(q, p, stream, num_cu); break;
@@ -350,6 +353,7 @@ void launch_dequantize(const DequantLaunch& d, hipStream_t stream, int num_cu) {
     p.ref_layout = d.ref_layout ? 1 : 0;
     p.ref_total = d.ref_total;
     p.ref_index0 = d.ref_index0;
+    p.ref_threads = d.ref_threads > 1 ? d.ref_threads : 1;
     switch (d.dt_in) {
         case DT_UINT8: dequantize_out<8>(d, p, stream, num_cu); break;
         case DT_UINT4: dequantize_out<4>(d, p, stream, num_cu); break;

@@ -23,6 +23,8 @@ struct QuantLaunch {
     int ref_head;
     int64_t ref_total;
     int64_t ref_index0;
+    int ref_threads;          // pool threads of the reference context being reproduced (0 / 1: one partition)
+    int ref_out_align;        // (out as the caller passed it) & 15 for fp32 -> uint8 nearest, -1 otherwise
     uint32_t barrier_timeout_us;   // fused launches: longest wait at the grid barrier before a block gives up its share (0 = 1 ms)
 };
 
@@ -40,6 +42,7 @@ struct DequantLaunch {
     bool ref_layout;
     int64_t ref_total;
     int64_t ref_index0;
+    int ref_threads;
 };
 
 struct RequantLaunch {

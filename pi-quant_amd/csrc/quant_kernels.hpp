@@ -95,7 +95,7 @@ __device__ __forceinline__ void quantize_bytes_guarded(const void* in, uint8_t* 
             if (i >= numel) continue;
             const float x = InVec<DT_IN>::load_scalar(in, i);
             uint32_t q;
-            if (MODE == RM_NEAREST_FAST && p.ref_layout && ref_scalar_position(p, p.ref_index0 + i, BITS == 8 ? 64 : 16))
+            if (MODE == RM_NEAREST_FAST && p.ref_layout && ref_scalar_position(p, p.ref_index0 + i, BITS == 8 ? 64 : 16, PACK))
                 q = quant_nearest_tail32<QMAX>(x, p);      // reference-layout mode: the reference's scalar head/tail formula here
             else
                 q = quant_one<MODE, QMAX>(x, p, static_cast<uint64_t>(i));

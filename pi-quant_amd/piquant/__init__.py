@@ -201,9 +201,11 @@ class Context:
         """Opt-in: an independent threshold per element (counter hash of seed and global element index)."""
         C.piquant_hip_set_stochastic_per_element(self._ctx, 1 if enabled else 0, seed & 0xFFFFFFFFFFFFFFFF, index_base)
 
-    def set_reference_layout(self, enabled: bool) -> None:
-        """Opt-in: reproduce the reference's scalar head/tail formulas at the positions where its single-thread AVX-512 build
-        uses them (include/piquant_hip.h); off, every element takes the SIMD-body formula."""
+    def set_reference_layout(self, enabled: bool, threads: int = 1) -> None:
+        """Opt-in: reproduce the reference's scalar head/tail formulas at the positions where its AVX-512 build uses them
+        (include/piquant_hip.h), for a reference context with ``threads`` pool threads (each partition has its own head and tail);
+        off, every element takes the SIMD-body formula."""
+        C.piquant_hip_set_reference_threads(self._ctx, int(threads))
         C.piquant_hip_set_reference_layout(self._ctx, 1 if enabled else 0)
 
     def quantize_dequantize_ptr(self, ptr_in: int, dtype_in_out: DataType, ptr_out: int, quant_dtype: DataType, numel: int, scale: float,

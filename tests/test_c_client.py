@@ -115,3 +115,57 @@ def test_hip_client_device_buffers_match_oracle(tmp_path, oracle_mod):
     acc = O.dequantize(qs[2], O.UINT8, O.F32, half, params[2][0], params[2][1], O.ADD, out=acc)
     back[:half] = acc
     assert int(out[9], 16) == _fnv1a(back.tobytes())
+
+
+def _build_hip_client_ext(tmp_path):
+    exe = tmp_path / "hip_client_ext"
+    subprocess.run(["g++", "-std=c++20", "-Wall", "-Wextra", "-O2", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", f"-I{ROOT / 'include'}",
+                    str(ROOT / "tests" / "hip_client_ext.cpp"), f"-L{LIBDIR}", "-lpiquant", "-L/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{LIBDIR}",
+                    "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
+    return exe
+
+
+def test_hip_client_ext_compiles_and_links(tmp_path):
+    assert _build_hip_client_ext(tmp_path).exists()
+
+
+@pytest.mark.gpu
+def test_hip_client_ext_rest_of_the_extension_surface_matches_oracle(tmp_path, oracle_mod):
+    """26 additive exports, 4 of them tested at the C level.  This client drives the rest from a torch-free C++ process:
+    minmax_keys / decode / params_from_minmax, compute_quant_params_device + quantize_dp, quantize_dequantize, the stochastic controls,
+    the blocking-wait modes, the barrier limit + hand-over counter, reduce_quantize_dynamic, dequantize_dp_batch, reference layout."""
+    O = oracle_mod
+    n = 1_000_003
+    exe = _build_hip_client_ext(tmp_path)
+    out = subprocess.run([str(exe), str(n)], check=True, capture_output=True, text=True, timeout=300).stdout.split()
+    s = np.uint32(12345)
+    x = np.empty(n, dtype=np.float32)
+    with np.errstate(over="ignore"):
+        for i in range(n):
+            s ^= np.uint32(s << np.uint32(13))
+            s ^= np.uint32(s >> np.uint32(17))
+            s ^= np.uint32(s << np.uint32(5))
+            x[i] = np.float32(int(s) >> 8) * np.float32(2.0 / 16777216.0) - np.float32(1.0)
+    sc, zp = np.float32(1.0) / np.float32(127.0), 128
+    s4, z4 = O.compute_quant_params(x, O.F32, O.UINT4)
+    assert (np.float32(float(out[0])), int(out[1])) == (np.float32(s4), z4)
+    assert int(out[2], 16) == _fnv1a(O.quantize(x, O.F32, O.UINT4, s4, z4).tobytes())
+    assert int(out[3], 16) == _fnv1a(O.requantize(x, O.F32, O.UINT8, float(sc), zp).tobytes())
+    assert int(out[4], 16) == _fnv1a(O.quantize(x, O.F32, O.UINT8, float(sc), zp, O.STOCHASTIC, 0.25).tobytes())
+    assert int(out[5], 16) == _fnv1a(O.quantize_per_element(x, O.F32, O.UINT8, float(sc), zp, 0x1234567890abcdef, 77).tobytes())
+    q_near = O.quantize(x, O.F32, O.UINT8, float(sc), zp)
+    assert int(out[6], 16) == _fnv1a(q_near.tobytes()) and out[7] == "1"       # three wait modes, same bytes
+    s8, z8 = O.compute_quant_params(x, O.F32, O.UINT8)
+    q8 = O.quantize(x, O.F32, O.UINT8, s8, z8)
+    assert int(out[8], 16) == _fnv1a(q8.tobytes()) and out[9] == "1"           # the 1 us barrier limit changes nothing but the time
+    assert int(out[10]) >= 0
+    total = O.dequantize(q8, O.UINT8, O.F32, n, s8, z8, O.ADD, out=x.copy())
+    total = O.dequantize(q8, O.UINT8, O.F32, n, s8, z8, O.ADD, out=total)
+    ss, zs = O.compute_quant_params(total, O.F32, O.UINT8)
+    qs = O.quantize(total, O.F32, O.UINT8, ss, zs)
+    assert int(out[11], 16) == _fnv1a(qs.tobytes())
+    assert int(out[12], 16) == _fnv1a(O.dequantize(q8, O.UINT8, O.F32, n, s8, z8).tobytes())
+    assert int(out[13], 16) == _fnv1a(O.dequantize(qs, O.UINT8, O.F32, n, ss, zs).tobytes())
+    assert int(out[14], 16) == _fnv1a(O.quantize(x, O.F32, O.UINT8, float(sc), zp, form=O.FORM_REFERENCE).tobytes())
+    assert (np.float32(float(out[15])), int(out[16]), np.float32(float(out[17])), int(out[18])) == (np.float32(s8), z8, np.float32(ss), zs)
+    assert int(out[19]) == 0 and out[20] == "gfx950"

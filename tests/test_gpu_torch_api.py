@@ -196,3 +196,35 @@ def test_reference_style_benchmark_harness_runs(tmp_path):
         assert d["plot"].startswith("matplotlib is not importable")
     else:
         assert d["plot"] == str(png) and png.stat().st_size > 5000
+
+
+def test_default_context_is_per_thread_and_device():
+    """the shared default context carried the stream of the call being made; two threads on two streams could swap it between
+    set_stream and the call.  The default context is now per (thread, device)."""
+    import threading
+
+    import piquant
+
+    main = piquant.Context.get()
+    assert piquant.Context.get() is main
+    seen = {}
+
+    def work(i):
+        torch.cuda.set_device(0)
+        a = piquant.Context.get()
+        b = piquant.Context.get(0)
+        x = torch.full((1000,), float(i + 1), device="cuda")
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            q = piquant.torch.quantize(x, scale=0.5, zero_point=3, dtype=torch.uint8)
+        s.synchronize()
+        seen[i] = (a, b, int(q[0]))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert seen[0][0] is seen[0][1] and seen[1][0] is seen[1][1]
+    assert seen[0][0] is not seen[1][0] and seen[0][0] is not main and seen[1][0] is not main
+    assert (seen[0][2], seen[1][2]) == (5, 7)      # 1 / 0.5 + 3, 2 / 0.5 + 3
