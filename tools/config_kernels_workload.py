@@ -28,7 +28,7 @@ ap.add_argument("--numel", type=int, default=27_264_000)
 ap.add_argument("--calls", type=int, default=60)
 ap.add_argument("--big", action="store_true")
 args = ap.parse_args()
-N, SETS, CALLS = args.numel, 6, args.calls
+N, SETS, CALLS = args.numel, 12, args.calls   # 12 sets: the 68 MB bf16/uint4 launches also rotate over > 3x the 256 MiB Infinity Cache
 
 dev = torch.device("cuda")
 ctx = piquant.Context()

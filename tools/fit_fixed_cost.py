@@ -66,7 +66,7 @@ def main():
     times = {k: [] for k in kernels}
     with torch.cuda.stream(stream):
         for n in sizes:
-            sets = max(2, min(8, int(1.0e9 // (5 * n)) + 1))
+            sets = max(2, min(24, int(1.7e9 // (5 * n)) + 1))   # >= 818 MB of 5-byte traffic in rotation (4 sets at N1 * 4 ... 24 at N1 / 4): HBM, not Infinity Cache
             xs = [torch.empty(n, device=dev).uniform_(-1, 1) for _ in range(sets)]
             xb = [x.to(torch.bfloat16) for x in xs]
             q8 = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(sets)]

@@ -32,7 +32,7 @@ using namespace pq;
         }                                                                                      \
     } while (0)
 
-constexpr int SETS = 6;
+constexpr int SETS = 12;   // rotation slots: 12 x 136 MB at the headline size, 12 x 68 MB for the half-size (bf16) runs -- at least three times the 256 MiB Infinity Cache
 
 struct Bufs {
     void* in[SETS];
