@@ -216,33 +216,36 @@ __device__ __forceinline__ void minmax_block_end(float lo, float hi, const float
 
 // "Gather" end of a scan block, for grids of at most kMinmaxGatherMax blocks whose result goes somewhere (not EP_NONE).  Every block
 // stores its {key(min), key(-max)} word into its OWN slot with one plain device-scope store and is done -- no returning atomic,
-// no arrival counter.  The block with the highest index, after its own part of the scan, sweeps the words (wave 0, one 8-byte load
-// per lane and 64 slots) until none is empty, folds them, empties them again for the next scan and runs the epilogue.  Critical
+// no arrival counter.  The block with the highest index, after its own part of the scan, sweeps the words (every wave of the block
+// takes its share of the slots, eight 8-byte loads per lane in flight) until none is empty, folds them, empties them again for the
+// next scan and runs the epilogue.  Critical
 // path behind the slowest block: its store becoming visible plus one sweep (~2 memory round trips) instead of the slot
 // protocol's three or four dependent ones (two key atomics -> slot arrival -> slot-count arrival -> fold loads): measured
 // [tools/tune_kernels.hip mm] at numel 27 264 000.  Nobody waits for the sweeping block and it waits for nobody that needs its
 // CU, so residency does not matter: blocks that start late are simply seen late.
 template <int WAVES>
 __device__ __forceinline__ void minmax_block_end_gather(float lo, float hi, const float* s_lo, const float* s_hi, int32_t* state, const MinmaxEpilogue& ep) {
-    const int lane = threadIdx.x & 63;
-    if ((threadIdx.x >> 6) != 0) return;
-#pragma unroll
-    for (int w = 1; w < WAVES; ++w) {
-        lo = __builtin_fminf(lo, s_lo[w]);
-        hi = __builtin_fmaxf(hi, s_hi[w]);
-    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long* words = reinterpret_cast<unsigned long long*>(state + kMinmaxStateInts);
     const uint32_t G = gridDim.x, me = blockIdx.x;
-    const unsigned long long mine = static_cast<unsigned long long>(static_cast<uint32_t>(float_to_key(lo))) |
-                                    (static_cast<unsigned long long>(static_cast<uint32_t>(float_to_key(-hi))) << 32);
     if (me != G - 1) {
+        if (wave != 0) return;
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) {
+            lo = __builtin_fminf(lo, s_lo[w]);
+            hi = __builtin_fmaxf(hi, s_hi[w]);
+        }
+        const unsigned long long mine = static_cast<unsigned long long>(static_cast<uint32_t>(float_to_key(lo))) |
+                                        (static_cast<unsigned long long>(static_cast<uint32_t>(float_to_key(-hi))) << 32);
         if (lane == 0) __hip_atomic_store(words + me, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    int32_t k0 = float_to_key(lo), k1 = float_to_key(-hi);   // the sweeping block's own result never travels through memory
+    // The sweeping block: all its waves sweep, wave w the slot groups w, w + WAVES, ... of 512 slots each (8 loads per lane in flight),
+    // so that grids up to WAVES x 512 blocks are swept in ONE pass of loads; then the waves' results meet in LDS.
+    int32_t k0 = float_to_key(lo), k1 = float_to_key(-hi);   // this wave's own scan result never travels through memory
     const uint64_t t_begin = wall_clock64();
-    constexpr int LPL = 8;                                    // 8 x 64 slots per pass, all loads of a pass in flight together
-    for (uint32_t base = 0; base + 1 < G; base += 64 * LPL) {   // slots [0, G - 1)
+    constexpr int LPL = 8;
+    for (uint32_t base = static_cast<uint32_t>(wave) * 64 * LPL; base + 1 < G; base += WAVES * 64 * LPL) {   // slots [0, G - 1)
         unsigned long long w[LPL];
 #pragma unroll
         for (int j = 0; j < LPL; ++j) w[j] = base + j * 64 + lane + 1 < G ? kMinmaxNotArrived : ~0ull;
@@ -275,7 +278,20 @@ __device__ __forceinline__ void minmax_block_end_gather(float lo, float hi, cons
         k0 = min(k0, __shfl_xor(k0, off, 64));
         k1 = min(k1, __shfl_xor(k1, off, 64));
     }
-    if (lane == 0) minmax_action(k0, k1, ep);
+    __shared__ int32_t s_k0[WAVES], s_k1[WAVES];
+    if (lane == 0) {
+        s_k0[wave] = k0;
+        s_k1[wave] = k1;
+    }
+    __syncthreads();   // block-uniform: every thread of the sweeping block is here
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) {
+            k0 = min(k0, s_k0[w]);
+            k1 = min(k1, s_k1[w]);
+        }
+        minmax_action(k0, k1, ep);
+    }
 }
 
 template <int DT_IN, int U, bool NT, int BLOCK, bool GATHER = false>
@@ -289,32 +305,38 @@ __global__ void __launch_bounds__(BLOCK) minmax_kernel(const void* __restrict__ 
 
     float lo = 3.402823466e+38f, hi = -3.402823466e+38f;     // identities of the reference (:1422-1423)
 
-    int64_t v = tid;
-    // U independent vectors per trip: all loads issue before the first compare
-    for (; v + static_cast<int64_t>(U - 1) * nthreads < n_vec; v += static_cast<int64_t>(U) * nthreads) {
-        u32x4 raw[U];
-#pragma unroll
-        for (int k = 0; k < U; ++k) raw[k] = ld<NT>(in16 + v + k * nthreads);
-#pragma unroll
-        for (int k = 0; k < U; ++k) {
-            float f[EPV];
-            InVec<DT_IN>::unpack(raw[k], f);
-#pragma unroll
-            for (int e = 0; e < EPV; ++e) {
-                lo = __builtin_fminf(lo, f[e]);
-                hi = __builtin_fmaxf(hi, f[e]);
-            }
-        }
-    }
-    for (; v < n_vec; v += nthreads) {
+    auto fold = [&](const u32x4& raw) {
         float f[EPV];
-        InVec<DT_IN>::unpack(ld<NT>(in16 + v), f);
+        InVec<DT_IN>::unpack(raw, f);
 #pragma unroll
         for (int e = 0; e < EPV; ++e) {
             lo = __builtin_fminf(lo, f[e]);
             hi = __builtin_fmaxf(hi, f[e]);
         }
+    };
+    int64_t v = tid;
+    const int64_t round = static_cast<int64_t>(U) * nthreads;
+    // A rolling window of U loads per lane: as soon as a vector has been folded its register is refilled with the vector one round
+    // ahead, so every lane keeps U loads in flight from its first instruction to its last round.  (Issuing U loads, waiting for all of
+    // them and folding them before the next U -- round 1's loop -- lets a wave's loads in flight drop to zero once per round; with only
+    // eight waves per CU nothing else fills the gap.)
+    if (v + static_cast<int64_t>(U - 1) * nthreads < n_vec) {
+        u32x4 raw[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) raw[k] = ld<NT>(in16 + v + k * nthreads);
+        while (v + round + static_cast<int64_t>(U - 1) * nthreads < n_vec) {   // the next round is a full one too
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                fold(raw[k]);
+                raw[k] = ld<NT>(in16 + v + round + k * nthreads);
+            }
+            v += round;
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) fold(raw[k]);
+        v += round;
     }
+    for (; v < n_vec; v += nthreads) fold(ld<NT>(in16 + v));
     // ragged scalar tail (numel % EPV elements)
     for (int64_t i = n_vec * EPV + tid; i < numel; i += nthreads) {
         const float x = InVec<DT_IN>::load_scalar(in, i);

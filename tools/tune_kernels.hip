@@ -682,8 +682,11 @@ int main(int argc, char** argv) {
     if (only == "mm3") {
         // wider geometry sweep of the scan with the gather end: threads per block x loads in flight per lane x blocks per CU
         g_rounds = 1;
-        g_mm_caps = {1, 2};
+        g_mm_caps = {1, 2, 4, 8};
         for (int pass = 0; pass < 4; ++pass) {
+            run_minmax<DT_F32, 4, true, 256, true>(b, numel, num_cu, keys);
+            run_minmax<DT_F32, 2, true, 256, true>(b, numel, num_cu, keys);
+            run_minmax<DT_F32, 4, true, 256, false>(b, numel, num_cu, keys);
             run_minmax<DT_F32, 4, true, 512, true>(b, numel, num_cu, keys);
             run_minmax<DT_F32, 8, true, 256, true>(b, numel, num_cu, keys);
             run_minmax<DT_F32, 16, true, 256, true>(b, numel, num_cu, keys);
