@@ -246,15 +246,19 @@ fused_params_quantize_kernel(FusedGroups groups, QuantParams p_arg, FusedState* 
             u32x4 t[LDS_BATCH];
 #pragma unroll
             for (int j = 0; j < LDS_BATCH; ++j) {
-                const int64_t v = v_first + (R_REG + j0 + j) * round_vecs;
-                t[j] = ld<true>(in16 + (v < n_vec ? v : v_last));
+                if (R_REG + j0 + j < rounds) {   // block-uniform: a share may end inside a batch (the even deal gives 26 or 27 rounds)
+                    const int64_t v = v_first + (R_REG + j0 + j) * round_vecs;
+                    t[j] = ld<true>(in16 + (v < n_vec ? v : v_last));
+                }
             }
 #pragma unroll
             for (int j = 0; j < LDS_BATCH; ++j) {
-                const int64_t v = v_first + (R_REG + j0 + j) * round_vecs;
-                if constexpr (RED_BITS != 0) add_reduce_terms<DT_IN, RED_BITS>(t[j], v < n_vec ? v : v_last, red);
-                minmax_vec<DT_IN>(t[j], v < n_vec, lo, hi);
-                resident[(j0 + j) * BLOCK + tid] = t[j];
+                if (R_REG + j0 + j < rounds) {
+                    const int64_t v = v_first + (R_REG + j0 + j) * round_vecs;
+                    if constexpr (RED_BITS != 0) add_reduce_terms<DT_IN, RED_BITS>(t[j], v < n_vec ? v : v_last, red);
+                    minmax_vec<DT_IN>(t[j], v < n_vec, lo, hi);
+                    resident[(j0 + j) * BLOCK + tid] = t[j];
+                }
             }
         }
         // rounds that do not fit on chip: min/max only, STREAM_BATCH loads in flight per lane (never with reduce terms: the host
