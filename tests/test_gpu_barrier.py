@@ -172,3 +172,70 @@ def test_device_record_of_an_empty_or_all_nan_tensor_is_the_degenerate_one():
             assert piquant.torch.params_to_host(rec) == (1.0, zp)
             q, rec2 = piquant.torch.quantize_dynamic(x, dtype=qdtype, ctx=ctx)
             assert piquant.torch.params_to_host(rec2) == (1.0, zp) and q.numel() == x.numel()
+
+
+def test_batched_launch_hands_over_too():
+    """several tensors in one launch, each sub-grid with its own barrier and orphan bitmap, under a 1 us limit"""
+    import piquant
+
+    ctx = piquant.Context()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    xs = [torch.empty(n, device="cuda").uniform_(-1, 1, generator=g) * (i + 1) for i, n in enumerate((3_408_000, 1_000_003 + 1, 3_408_000, 4096, 2_000_000))]
+    ctx.set_fusion(False)
+    want = piquant.torch.quantize_dynamic_batch(xs, dtype=torch.uint8, ctx=ctx)
+    torch.cuda.synchronize()
+    ctx.set_fusion(True)
+    before = ctx.barrier_bailouts()
+    ctx.set_barrier_timeout_us(1)
+    for _ in range(3):
+        got = piquant.torch.quantize_dynamic_batch(xs, dtype=torch.uint8, ctx=ctx)
+    torch.cuda.synchronize()
+    ctx.set_barrier_timeout_us(0)
+    for (q, r), wq, wr in zip(zip(*got), *want):
+        assert torch.equal(q, wq) and torch.equal(r, wr)
+    assert ctx.barrier_bailouts() > before
+
+
+def _two_process_worker(rank, out_q):
+    import sys
+
+    root = Path(__file__).resolve().parent.parent
+    for p in (str(root), str(root / "pi-quant_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import piquant
+
+    torch.cuda.set_device(0)
+    ctx = piquant.Context()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(100 + rank)
+    x = torch.empty(N1, device="cuda").uniform_(-1, 1, generator=g)
+    ctx.set_fusion(False)
+    wq, wr = piquant.torch.quantize_dynamic(x, dtype=torch.uint8, ctx=ctx)
+    torch.cuda.synchronize()
+    ctx.set_fusion(True)
+    ok = True
+    for _ in range(10):
+        outs = [piquant.torch.quantize_dynamic(x, dtype=torch.uint8, ctx=ctx) for _ in range(30)]
+        torch.cuda.synchronize()
+        ok = ok and all(torch.equal(q, wq) and torch.equal(r, wr) for q, r in outs)
+    out_q.put((rank, ok, ctx.barrier_bailouts()))
+
+
+def test_two_processes_sharing_the_gpu_launch_fused_kernels():
+    """Two PROCESSES on one GPU, each issuing 300 barrier kernels with no coordination between them (nothing the library can order):
+    round 1 had to switch the fused path off for this.  Both must finish with the right bytes; how many blocks handed over is reported."""
+    import torch.multiprocessing as mp
+
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_two_process_worker, args=(r, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in results), results
+    print("hand-overs per process:", {r: b for r, _, b in results})

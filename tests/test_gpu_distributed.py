@@ -125,10 +125,9 @@ def _ring_gpu_worker(rank, world, port, numel, qname, out_q, algorithm="ring"):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    # several processes share ONE GPU here (not the deployment model, which is one process per GPU): the one-launch
-    # params + quantize kernel holds a grid barrier and two of them dispatched at the same instant by different processes could
-    # each take part of the CUs, so it is switched off -- the unfused path produces the same bytes
-    os.environ["PIQUANT_HIP_FUSION"] = "0"
+    # several processes share ONE GPU here (not the deployment model, which is one process per GPU).  Round 1 switched the one-launch
+    # params + quantize kernel off for this (two barrier kernels of different processes can each get part of the CUs); its waits are
+    # bounded now and a block that cannot be waited for hands its share over, so the fused path stays on
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import piquant.distributed as D
