@@ -30,13 +30,18 @@ constexpr KernelTune kQuantTune[2][3] = {
 // optimum to small tiles.  bf16 entries re-measured after fp32 -> bf16 became one v_cvt_pk_bf16_f32 (profiles/r01_tune_finals_other_hw_bf16_cvt.csv,
 // profiles/r02_tune_half_size.csv): uint4 -> bf16 SET at numel 27 264 000 (BASELINE config 3) 11.6 us with 256-thread / U=4 tiles against
 // 12.4 with the 64-thread / U=2 tiles that are best for ADD (20.8 vs 22.4 us).
+// Store policy under a rotation that is really cold (12 x 136 MB, profiles/r02_tune_dequant_store_policy.csv): the write-heavy bf16 outputs
+// of the packed types (0.25-0.5 B read, 2 B written per element) want NON-TEMPORAL stores with the 256-thread tiles -- uint4 -> bf16 at numel
+// 27 264 000: 11.5 us against 12.8 write-through (5.93 vs 5.34 TB/s), uint2 -> bf16 10.65 vs 11.4 -- while everything that reads at least as
+// much as it writes keeps write-through (fp32 -> uint8 22.6 vs 23.0 us non-temporal, uint8 -> fp32 22.4 vs 22.9).
+constexpr int kStreamNT = 1 | (1 << 1);   // nt loads + nt stores
 constexpr KernelTune kDequantTune[2][3] = {
     {{2, true, kStream, 128, 0}, {4, true, kStream, 256, 0}, {4, true, kStream, 256, 0}},
-    {{2, true, kStream, 64, 0}, {4, true, kStream, 256, 0}, {4, true, kStream, 256, 0}},
+    {{2, true, kStream, 64, 0}, {4, true, kStreamNT, 256, 0}, {4, true, kStreamNT, 256, 0}},
 };
 constexpr KernelTune kDequantAddTune[2][3] = {
     {{2, true, kStream, 128, 0}, {4, true, kStream, 256, 0}, {4, true, kStream, 256, 0}},
-    {{2, true, kStream, 64, 0}, {2, true, kStream, 64, 0}, {2, true, kStream, 128, 0}},
+    {{2, true, kStream, 64, 0}, {2, true, kStreamNT, 64, 0}, {2, true, kStream, 128, 0}},
 };
 
 // fused quantize->dequantize: plain 16-byte streams both ways, no LDS staging

@@ -702,6 +702,62 @@ int main(int argc, char** argv) {
         g_mm_caps = {1, 2, 4, 8, 16, 32};
         g_rounds = 3;
     }
+    if (only == "dqp") {
+        // dequantize family under cold rotation: store policy (5 = write-through, 3 = non-temporal) x tile shape.  Run with numel = 27264000:
+        // the bf16 outputs hold numel (N1) or 2 * numel elements in the 109 MB buffers.
+        g_rounds = 1;
+        g_caps = {0};
+        for (int pass = 0; pass < 4; ++pass) {
+#define DQP(BITS, DT, OP, N, BPE)                                  \
+    run_dequant<BITS, DT, OP, 4, true, 5, 256>(b, N, num_cu, BPE); \
+    run_dequant<BITS, DT, OP, 4, true, 3, 256>(b, N, num_cu, BPE); \
+    run_dequant<BITS, DT, OP, 2, true, 5, 128>(b, N, num_cu, BPE); \
+    run_dequant<BITS, DT, OP, 2, true, 3, 128>(b, N, num_cu, BPE); \
+    run_dequant<BITS, DT, OP, 2, true, 5, 64>(b, N, num_cu, BPE);  \
+    run_dequant<BITS, DT, OP, 2, true, 3, 64>(b, N, num_cu, BPE);  \
+    run_dequant<BITS, DT, OP, 4, true, 3, 512>(b, N, num_cu, BPE);
+            DQP(4, DT_BF16, OP_SET, numel, 2.5)
+            DQP(4, DT_BF16, OP_SET, 2 * numel, 2.5)
+            DQP(4, DT_BF16, OP_ADD, numel, 4.5)
+            DQP(8, DT_F32, OP_SET, numel, 5)
+            DQP(8, DT_F32, OP_ADD, numel, 9)
+            DQP(8, DT_BF16, OP_SET, numel, 3)
+            DQP(4, DT_F32, OP_SET, numel, 4.5)
+            DQP(2, DT_BF16, OP_SET, numel, 2.25)
+            DQP(2, DT_F32, OP_SET, numel, 4.25)
+#undef DQP
+        }
+        g_caps = {0, 2, 4, 8, 16};
+        g_rounds = 3;
+    }
+    if (only == "qp") {
+        // quantize family under cold rotation: store policy (5 = write-through, 3 = non-temporal, 1 = plain) at the production tiles; numel = 27264000
+        g_rounds = 1;
+        g_caps = {0};
+        for (int pass = 0; pass < 4; ++pass) {
+#define QP(DT, BITS, MODE, U_, BLK, N, BPE)                              \
+    run_quant<DT, BITS, MODE, U_, true, 5, BLK>(b, N, num_cu, BPE);      \
+    run_quant<DT, BITS, MODE, U_, true, 3, BLK>(b, N, num_cu, BPE);      \
+    run_quant<DT, BITS, MODE, U_, true, 1, BLK>(b, N, num_cu, BPE);
+            QP(DT_F32, 8, RM_NEAREST_FAST, 2, 128, numel, 5)
+            QP(DT_F32, 8, RM_STOCH_CALL, 2, 128, numel, 5)
+            QP(DT_F32, 4, RM_NEAREST_FAST, 2, 64, numel, 4.5)
+            QP(DT_F32, 2, RM_NEAREST_I64, 2, 64, numel, 4.25)
+            QP(DT_BF16, 8, RM_NEAREST_FAST, 2, 64, numel, 3)
+            QP(DT_BF16, 4, RM_NEAREST_FAST, 2, 64, numel, 2.5)
+            QP(DT_BF16, 4, RM_NEAREST_FAST, 2, 64, 2 * numel, 2.5)
+            QP(DT_BF16, 2, RM_NEAREST_FAST, 4, 256, numel, 2.25)
+#undef QP
+            run_requant<DT_F32, 8, OP_SET, 2, 5, 64>(b, numel, num_cu, 8);
+            run_requant<DT_F32, 8, OP_SET, 2, 3, 64>(b, numel, num_cu, 8);
+            run_requant<DT_F32, 8, OP_ADD, 2, 5, 64>(b, numel, num_cu, 12);
+            run_requant<DT_F32, 8, OP_ADD, 2, 3, 64>(b, numel, num_cu, 12);
+            run_requant<DT_BF16, 4, OP_SET, 2, 5, 64>(b, numel, num_cu, 4);
+            run_requant<DT_BF16, 4, OP_SET, 2, 3, 64>(b, numel, num_cu, 4);
+        }
+        g_caps = {0, 2, 4, 8, 16};
+        g_rounds = 3;
+    }
     if (only == "q4") {
         // bf16 -> uint4 at numel (pass N1/2 as numel: the bf16 view holds 2 * numel elements): tile shapes and persistent grids
         g_rounds = 1;
