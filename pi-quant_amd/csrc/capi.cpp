@@ -183,8 +183,12 @@ constexpr int kDefaultBlockingWait = 2;   // WAIT_KERNEL: 30.4 us per blocking f
 // busy-polling an event recorded after the kernel were measured in round 1: 36.7 / 34.9 vs 34.4 us for hipStreamSynchronize.)
 enum : int { WAIT_SYNC = 0, WAIT_WRITE32 = 1, WAIT_KERNEL = 2 };
 
+bool stream_is_capturing(hipStream_t s);
+
 void wait_stream(piquant_context_t* ctx) {
     hipStream_t stream = ctx->stream;
+    // a captured launch does not run until the graph is replayed: waiting for it here would never end
+    if (stream_is_capturing(stream)) panic("a blocking call cannot be captured into a hipGraph: make the context stream-ordered first (piquant_hip_set_blocking(ctx, 0))");
     if (ctx->wait_mode == WAIT_SYNC || !ctx->done_dev) {
         PQ_HIP(hipStreamSynchronize(stream));
         return;

@@ -59,7 +59,12 @@ at::Tensor quantize(int64_t handle, const at::Tensor& tensor, double scale, int6
     if (out_opt.has_value()) {
         out = *out_opt;
         TORCH_CHECK(out.is_contiguous() && out.device() == x.device(), "out= must be a contiguous tensor on the input's device");
-        TORCH_CHECK(static_cast<int64_t>(out.storage().nbytes()) >= packed_nbytes(x.numel(), dt_out), "out= is too small");
+        // the TENSOR must hold the result, not merely the storage it views: a short slice of a large buffer is too small
+        if (out.scalar_type() == at::kByte)
+            TORCH_CHECK(out.numel() >= packed_nbytes(x.numel(), dt_out), "out= holds ", out.numel(), " bytes, ", packed_nbytes(x.numel(), dt_out), " are needed");
+        else
+            TORCH_CHECK(!is_float_type(out.scalar_type()) && code_of(out.scalar_type()) == dt_out && out.numel() == x.numel(),
+                        "out= must be a quantized tensor of the requested dtype with the input's number of elements (or a uint8 buffer of the packed bytes)");
     } else {
         out = at::empty(x.sizes(), x.options().dtype(dtype));   // reference torch.py:87, plus the device
     }

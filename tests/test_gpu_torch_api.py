@@ -228,3 +228,49 @@ def test_default_context_is_per_thread_and_device():
     assert seen[0][0] is seen[0][1] and seen[1][0] is seen[1][1]
     assert seen[0][0] is not seen[1][0] and seen[0][0] is not main and seen[1][0] is not main
     assert (seen[0][2], seen[1][2]) == (5, 7)      # 1 / 0.5 + 3, 2 / 0.5 + 3
+
+
+def test_out_buffers_are_checked_by_the_tensor_not_by_its_storage():
+    """a short out= slice of a large buffer used to pass (the storage was large enough) and the kernel wrote past the slice."""
+    import piquant
+
+    x = torch.empty(1000, device="cuda").uniform_(-1, 1)
+    big = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    with pytest.raises((ValueError, RuntimeError)):
+        piquant.torch.quantize(x, scale=0.01, zero_point=128, dtype=torch.uint8, out=big[:999])
+    with pytest.raises((ValueError, RuntimeError)):
+        piquant.torch.quantize(x, scale=0.01, zero_point=8, dtype=torch.quint4x2, out=big[:499])
+    piquant.torch.quantize(x, scale=0.01, zero_point=8, dtype=torch.quint4x2, out=big[:500])           # exactly enough
+    rec = torch.empty(16, dtype=torch.uint8, device="cuda")
+    for bad in (dict(out=big[:999]), dict(params=rec[:8]), dict(params=torch.empty(16, dtype=torch.uint8)), dict(out=torch.zeros(1000, dtype=torch.uint8))):
+        with pytest.raises(ValueError):
+            piquant.torch.quantize_dynamic(x, dtype=torch.uint8, **bad)
+    q, r = piquant.torch.quantize_dynamic(x, dtype=torch.uint8)
+    with pytest.raises(ValueError):
+        piquant.torch.dequantize_dynamic(q, r, dtype=torch.float32, out=torch.empty(999, device="cuda"))
+    with pytest.raises(ValueError):
+        piquant.torch.dequantize_sum([q, q[:10]], [r, r], dtype=torch.float32)
+    with pytest.raises(ValueError):
+        piquant.torch.reduce_quantize_dynamic(x.clone(), [q[:999]], [r], dtype=torch.uint8)
+    assert bool((big[500:] == 0).all())
+
+
+def test_blocking_call_in_a_capture_aborts_with_a_message_instead_of_hanging():
+    import subprocess
+    import sys
+    import textwrap
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    code = textwrap.dedent(f"""
+        import sys; sys.path.insert(0, {str(root / 'pi-quant_amd')!r})
+        import torch, piquant
+        x = torch.zeros(4096, device='cuda'); q = torch.zeros(4096, dtype=torch.uint8, device='cuda')
+        ctx = piquant.Context(); s = torch.cuda.Stream(); ctx.set_stream(s.cuda_stream); ctx.set_blocking(True)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            ctx.quantize_ptr(x.data_ptr(), piquant.DataType.F32, q.data_ptr(), piquant.DataType.UINT8, 4096, 1.0, 0, piquant.RoundMode.NEAREST, _device_ptrs=True)
+        print('survived')
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == -6 and "cannot be captured" in r.stderr and "survived" not in r.stdout, (r.returncode, r.stderr[-400:])
