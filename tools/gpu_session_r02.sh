@@ -35,7 +35,7 @@ PY
     rccl)     rm -rf $OUT/rccl_trace; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -f csv -d "$OLDPWD/$OUT/rccl_trace" -o rccl -- python "$OLDPWD/tools/rccl_single_rank_workload.py" > "$OLDPWD/$OUT/rccl_workload.log" 2> "$OLDPWD/$OUT/rccl_trace.err"); echo "rccl rc=$?" | tee -a $OUT/session.log
               f=$(find $OUT/rccl_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -30 "$f"; tail -5 $OUT/rccl_workload.log ;;
     hostcost) timeout 600 python tools/host_call_cost.py > $OUT/host_call_cost.json 2> $OUT/host_call_cost.err; echo "hostcost rc=$?" | tee -a $OUT/session.log; cat $OUT/host_call_cost.json ;;
-    soak)     timeout 1300 python tools/parity_soak.py --seconds ${SOAK_SECONDS:-600} --seed ${SOAK_SEED:-202} > $OUT/parity_soak_r02.json 2> $OUT/parity_soak_r02.err; echo "soak rc=$?" | tee -a $OUT/session.log; cat $OUT/parity_soak_r02.json ;;
+    soak)     timeout $(( ${SOAK_SECONDS:-600} + 400 )) python tools/parity_soak.py --seconds ${SOAK_SECONDS:-600} --seed ${SOAK_SEED:-202} > $OUT/parity_soak_r02.json 2> $OUT/parity_soak_r02.err; echo "soak rc=$?" | tee -a $OUT/session.log; cat $OUT/parity_soak_r02.json ;;
     refbench) timeout 900 python tools/reference_style_benchmarks.py --plot $OUT/quant_benchmark.png > $OUT/reference_style.json 2> $OUT/reference_style.err; echo "refbench rc=$?" | tee -a $OUT/session.log ;;
   esac
 done
