@@ -160,6 +160,7 @@ static int g_rounds = 3;
 static std::vector<int> g_caps = {0, 2, 4, 8, 16};
 static unsigned g_dyn_lds = 0;   // extra dynamic LDS per block: an occupancy throttle for experiments
 static double g_last_max = 0;
+static bool g_verbose_phases = false;
 
 // best (minimum) of g_rounds timed batches; the slowest batch is kept in g_last_max as a noise indicator
 static double time_us(const std::function<void(int)>& launch) {
@@ -368,6 +369,28 @@ static void run_fused(const Bufs& b, const FusedBufs& f, int64_t numel, int num_
     stats("barrier wait + params", [&](int b) { return static_cast<double>(t[b * 8 + 2] - t[b * 8 + 1]); });
     stats("quantize + store issue", [&](int b) { return static_cast<double>(t[b * 8 + 4] - t[b * 8 + 3]); });
     stats("end (since first start)", [&](int b) { return static_cast<double>(t[b * 8 + 4] - t_begin); });
+    // launch-to-launch spread of the phases: 36 more stamped launches, rotating over the buffer sets, one line each
+    if (g_verbose_phases) {
+        for (int it = 0; it < 36; ++it) {
+            hipLaunchKernelGGL((fused_params_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, R_REG, R_LDS, LDS_BATCH, BLOCK, STP, true, SB, 0, AG>), dim3(num_cu), dim3(BLOCK), 0, g_stream,
+                               one_group(b.in[it % SETS], b.out[it % SETS], numel, f.rec, num_cu), p, f.st, FusedReduce {});
+            CK(hipStreamSynchronize(g_stream));
+            std::vector<uint64_t> u(static_cast<size_t>(num_cu) * 8);
+            CK(hipMemcpy(u.data(), f.stamps, u.size() * 8, hipMemcpyDeviceToHost));
+            uint64_t t0 = ~0ull, load_end = 0, open = 0, end = 0;
+            std::vector<double> p3;
+            for (int bb = 0; bb < num_cu; ++bb) {
+                t0 = std::min(t0, u[bb * 8]);
+                load_end = std::max(load_end, u[bb * 8 + 1]);
+                open = std::max(open, u[bb * 8 + 2]);
+                end = std::max(end, u[bb * 8 + 4]);
+                p3.push_back((u[bb * 8 + 4] - u[bb * 8 + 3]) * 0.01);
+            }
+            std::sort(p3.begin(), p3.end());
+            std::fprintf(stderr, "  launch %2d set %2d: last load done %6.2f  barrier open (last block) %6.2f  end %6.2f us   store phase median %5.2f max %5.2f\n", it, it % SETS,
+                         (load_end - t0) * 0.01, (open - t0) * 0.01, (end - t0) * 0.01, p3[p3.size() / 2], p3.back());
+        }
+    }
     // does the load time depend on where the block runs?  blocks are dealt to the 8 XCDs round-robin (block b -> XCD b % 8)
     std::fprintf(stderr, "  load end (since first start), median by b %% 8:");
     for (int x = 0; x < 8; ++x) {
@@ -787,7 +810,8 @@ int main(int argc, char** argv) {
         run_minmax<DT_BF16, 8, true, 256>(b, 2 * numel, num_cu, keys);
     }
 
-    if (only == "fused") {
+    if (only == "fused" || only == "fusedphases") {
+        g_verbose_phases = only == "fusedphases";
         FusedBufs f {};
         CK(hipMalloc(reinterpret_cast<void**>(&f.st), sizeof(FusedState)));
         CK(hipMemset(f.st, 0, sizeof(FusedState)));
