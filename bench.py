@@ -329,6 +329,8 @@ def main():
             "traffic": None,
             "kernel": "pq::quantize_kernel<f32,u8,nearest>", "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ELEM * n_max,
             "avg_launch_us": round(kernel_s * 1e6, 3), "timing": "HIP events on the launch stream around the K timed launches / K",
+            "rotation": f"{nsets} buffer sets = {nsets * ALGO_BYTES_PER_ELEM * n / 1e9:.2f} GB per GPU: cold (round 1 rotated 6 sets = 818 MB, which leaves the 256 MiB Infinity "
+                        "Cache serving part of the reads and reads ~1.1 us per launch faster; that figure: extras.rotation_of_6_sets_818MB_round1_protocol)",
         },
     }
     if world > 1:

@@ -270,7 +270,9 @@ static std::vector<int> g_mm_caps = {1, 2, 4, 8, 16, 32};
 template <int DT_IN, int U, bool NT, int BLOCK, bool GATHER = false>
 static void run_minmax(const Bufs& b, int64_t numel, int num_cu, int32_t* keys) {
     for (int cap : g_mm_caps) {
-        const unsigned grid = static_cast<unsigned>(cap * num_cu);
+        // cap 0: one round of U loads per block, as many blocks as that takes (the hardware's dispatcher balances the load)
+        const int64_t per_block = static_cast<int64_t>(BLOCK) * U * InVec<DT_IN>::EPV;
+        const unsigned grid = cap == 0 ? static_cast<unsigned>((numel + per_block - 1) / per_block) : static_cast<unsigned>(cap * num_cu);
         if (GATHER && grid > static_cast<unsigned>(kMinmaxGatherMax)) continue;
         const double us = time_us([&](int i) {
             // production protocol: the finishing block folds the per-block results into a key pair and re-arms the state inside the launch
@@ -698,6 +700,23 @@ int main(int argc, char** argv) {
             run_minmax<DT_F32, 4, true, 1024, true>(b, numel, num_cu, keys);
             run_minmax<DT_BF16, 4, true, 256, false>(b, numel, num_cu, keys);
             run_minmax<DT_BF16, 4, true, 256, true>(b, numel, num_cu, keys);
+        }
+        g_mm_caps = {1, 2, 4, 8, 16, 32};
+        g_rounds = 3;
+    }
+    if (only == "mm4") {
+        // many small blocks (dynamic dispatch) against the persistent grids, gather end
+        g_rounds = 1;
+        g_mm_caps = {0, 1};
+        for (int pass = 0; pass < 4; ++pass) {
+            run_minmax<DT_F32, 4, true, 512, true>(b, numel, num_cu, keys);
+            run_minmax<DT_F32, 4, true, 256, true>(b, numel, num_cu, keys);
+            run_minmax<DT_F32, 8, true, 256, true>(b, numel, num_cu, keys);
+            run_minmax<DT_F32, 8, true, 512, true>(b, numel, num_cu, keys);
+            run_minmax<DT_F32, 16, true, 256, true>(b, numel, num_cu, keys);
+            run_minmax<DT_F32, 8, true, 1024, true>(b, numel, num_cu, keys);
+            run_minmax<DT_F32, 4, true, 1024, true>(b, numel, num_cu, keys);
+            run_minmax<DT_F32, 2, true, 1024, true>(b, numel, num_cu, keys);
         }
         g_mm_caps = {1, 2, 4, 8, 16, 32};
         g_rounds = 3;
