@@ -331,7 +331,7 @@ struct DequantBatchArgs {
     int count;
 };
 
-template <int BITS, int DT_OUT, int OP, int U, int BLOCK>
+template <int BITS, int DT_OUT, int OP, int U, int BLOCK, int ST_POLICY = ST_WT>
 __global__ void __launch_bounds__(BLOCK) dequantize_batch_kernel(DequantBatchArgs a) {
     constexpr int EPV = DT_OUT == DT_F32 ? 4 : 8, IB = EPV * BITS / 8;
     constexpr int64_t TILE_VECS = static_cast<int64_t>(BLOCK) * U, TILE_ELEMS = TILE_VECS * EPV;
@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(BLOCK) dequantize_batch_kernel(DequantBatchArg
 #pragma unroll
                 for (int e = 0; e < 4; ++e) r[e] = f32x2_to_bf16x2_bits(acc[k][2 * e], acc[k][2 * e + 1]);
             }
-            st<ST_WT>(out16 + v0 + k * 64 + lane, r);
+            st<ST_POLICY>(out16 + v0 + k * 64 + lane, r);
         }
         return;
     }

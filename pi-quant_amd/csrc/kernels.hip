@@ -402,7 +402,9 @@ namespace {
 
 template <int BITS, int DT_OUT, int OP>
 void dequantize_batch_t(const DequantBatchLaunch& d, hipStream_t stream) {
-    constexpr int U = 2, BLOCK = 128;
+    // tile shape and store policy of the single-tensor kernel for this pair (tuning.hpp): the batch is the same stream of tiles
+    constexpr KernelTune t = OP == OP_ADD ? kDequantAddTune[DT_OUT][bits_index(BITS)] : kDequantTune[DT_OUT][bits_index(BITS)];
+    constexpr int U = t.u, BLOCK = t.block, ST = t.nt >> 1;
     constexpr int EPV = DT_OUT == DT_F32 ? 4 : 8;
     constexpr int64_t TILE_ELEMS = static_cast<int64_t>(BLOCK) * U * EPV;
     DequantBatchArgs a {};
@@ -420,7 +422,7 @@ void dequantize_batch_t(const DequantBatchLaunch& d, hipStream_t stream) {
     a.count = d.count;
     if (tiles == 0) return;
     if (tiles > (int64_t {1} << 31) - 1) panic("dequantize_batch: %lld tiles in one launch", static_cast<long long>(tiles));
-    hipLaunchKernelGGL((dequantize_batch_kernel<BITS, DT_OUT, OP, U, BLOCK>), dim3(static_cast<unsigned>(tiles)), dim3(BLOCK), 0, stream, a);
+    hipLaunchKernelGGL((dequantize_batch_kernel<BITS, DT_OUT, OP, U, BLOCK, ST>), dim3(static_cast<unsigned>(tiles)), dim3(BLOCK), 0, stream, a);
 }
 
 template <int BITS, int DT_OUT>
