@@ -159,6 +159,54 @@ def test_quantize_and_dequantize_shard_cover_the_tensor(oracle_mod, world, qname
         D.quantize_shard(xt, scale=scale, zero_point=zp, dtype=qdtype, rank=world, world_size=world, _quantize=q_op)
 
 
+def _shard_worker(rank, world, port, numel, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle as O
+        import piquant.distributed as D
+
+        x = np.random.default_rng(5).uniform(-2, 2, numel).astype(np.float32)     # every rank holds the same logical tensor
+        scale, zp = O.compute_quant_params(x, O.F32, O.UINT4)
+
+        def q_op(t, *, scale, zero_point, dtype, round_mode, ctx, out):
+            out.copy_(torch.from_numpy(O.quantize(t.numpy(), O.F32, O.UINT4, scale, zero_point)))
+            return out
+
+        # rank and world size come from the process group, as in bench.py --gpus N
+        piece, (b, e) = D.quantize_shard(torch.from_numpy(x), scale=scale, zero_point=zp, dtype=torch.quint4x2, _quantize=q_op)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (b, e, piece.numpy().tobytes()))
+        out_q.put((rank, gathered))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_quantize_shard_takes_rank_and_world_from_the_process_group(oracle_mod, world):
+    """the strong-scaling split of bench.py --gpus N over gloo: every rank quantizes shard_range(numel, rank, world) of one tensor and the
+    concatenation of what the ranks produced is the single-call result"""
+    O = oracle_mod
+    numel = 100_003
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, numel, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    x = np.random.default_rng(5).uniform(-2, 2, numel).astype(np.float32)
+    scale, zp = O.compute_quant_params(x, O.F32, O.UINT4)
+    want = O.quantize(x, O.F32, O.UINT4, scale, zp)
+    parts = sorted(results[0])
+    assert [p[0] for p in parts][0] == 0 and parts[-1][1] == numel and all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+    assert b"".join(p[2] for p in parts) == want.tobytes()
+    assert all(results[r] == results[0] for r in range(world))
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # quantized ring all-reduce: ring schedule, wire format and chunking over gloo; the three ops come from the oracle
 # (the HIP ops need a GPU -- tests/test_gpu_distributed.py runs the same schedule with them)
