@@ -60,11 +60,13 @@ at::Tensor quantize(int64_t handle, const at::Tensor& tensor, double scale, int6
         out = *out_opt;
         TORCH_CHECK(out.is_contiguous() && out.device() == x.device(), "out= must be a contiguous tensor on the input's device");
         // the TENSOR must hold the result, not merely the storage it views: a short slice of a large buffer is too small
-        if (out.scalar_type() == at::kByte)
-            TORCH_CHECK(out.numel() >= packed_nbytes(x.numel(), dt_out), "out= holds ", out.numel(), " bytes, ", packed_nbytes(x.numel(), dt_out), " are needed");
-        else
-            TORCH_CHECK(!is_float_type(out.scalar_type()) && code_of(out.scalar_type()) == dt_out && out.numel() == x.numel(),
-                        "out= must be a quantized tensor of the requested dtype with the input's number of elements (or a uint8 buffer of the packed bytes)");
+        if (out.scalar_type() == at::kByte) {
+            const int64_t need = static_cast<int64_t>(packed_nbytes(x.numel(), dt_out));
+            TORCH_CHECK(out.numel() >= need, "out= holds ", out.numel(), " bytes, ", need, " are needed");
+        } else {
+            const bool fits = !is_float_type(out.scalar_type()) && code_of(out.scalar_type()) == dt_out && out.numel() == x.numel();
+            TORCH_CHECK(fits, "out= must be a quantized tensor of the requested dtype with the input's number of elements (or a uint8 buffer of the packed bytes)");
+        }
     } else {
         out = at::empty(x.sizes(), x.options().dtype(dtype));   // reference torch.py:87, plus the device
     }
