@@ -2,7 +2,9 @@
 // and its own stream; tests/hip_client.cpp covers quantize_dynamic, the batched form, dequantize_dp and dequantize_sum.  Here:
 // minmax_keys + decode + params_from_minmax, compute_quant_params_device + quantize_dp, quantize_dequantize (requant), the stochastic
 // controls (pinned threshold, per-element counter hash), dequantize_dp_batch, reduce_quantize_dynamic, the three blocking-wait modes,
-// the barrier timeout + hand-over counter, reference-layout mode, piquant_hip_device / _version.  Prints one line of values and
+// the barrier timeout + hand-over counter, reference-layout mode (1 and 3 reference threads), fusion off, the stochastic seed,
+// assume_device_pointers, reset_stream, piquant_hip_device / _version.  (piquant_hip_compute_quant_params_dist needs an RCCL communicator:
+// tests/test_gpu_distributed.py drives it through ctypes.)  Prints one line of values and
 // FNV-1a checksums that tests/test_c_client.py compares with the oracle.
 //   g++ -std=c++20 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude tests/hip_client_ext.cpp -L<libdir> -lpiquant -L/opt/rocm/lib -lamdhip64
 #include <hip/hip_runtime_api.h>
@@ -53,7 +55,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(reinterpret_cast<void**>(&d_q2), n));
     CK(hipMalloc(reinterpret_cast<void**>(&d_q3), n));
     CK(hipMalloc(reinterpret_cast<void**>(&d_keys), 8));
-    CK(hipMalloc(reinterpret_cast<void**>(&d_rec), 4 * sizeof(piquant_hip_params_t)));
+    CK(hipMalloc(reinterpret_cast<void**>(&d_rec), 8 * sizeof(piquant_hip_params_t)));
     CK(hipMemcpyAsync(d_x, x.data(), n * 4, hipMemcpyHostToDevice, stream));
 
     piquant_context_t* ctx = piquant_context_create(0);
@@ -138,8 +140,41 @@ int main(int argc, char** argv) {
     piquant_hip_set_reference_layout(ctx, 1);
     piquant_quantize(ctx, d_x, PIQUANT_DTYPE_F32, d_q, PIQUANT_DTYPE_UINT8, n, 1.0f / 127.0f, 128, PIQUANT_NEAREST);
     std::printf("%016llx ", static_cast<unsigned long long>(pull_q(d_q, n)));
+    // [15] the same with the positions of a reference context of 3 pool threads (three partitions, each with its own tail)
+    piquant_hip_set_reference_threads(ctx, 3);
+    piquant_quantize(ctx, d_x, PIQUANT_DTYPE_F32, d_q, PIQUANT_DTYPE_UINT8, n, 1.0f / 127.0f, 128, PIQUANT_NEAREST);
+    std::printf("%016llx ", static_cast<unsigned long long>(pull_q(d_q, n)));
+    piquant_hip_set_reference_threads(ctx, 1);
     piquant_hip_set_reference_layout(ctx, 0);
-    piquant_hip_params_t rec[3];
+    // [16] fusion off: scan + quantize in two launches write the bytes and the record of the one-launch form
+    piquant_hip_set_fusion(ctx, 0);
+    piquant_hip_quantize_dynamic(ctx, d_x, PIQUANT_DTYPE_F32, d_q3, PIQUANT_DTYPE_UINT8, n, d_rec + 3, PIQUANT_NEAREST);
+    const uint64_t h_unfused = pull_q(d_q3, n);
+    piquant_hip_set_fusion(ctx, 1);
+    piquant_hip_params_t rec[4];
+    CK(hipMemcpy(rec, d_rec, sizeof rec, hipMemcpyDeviceToHost));
+    std::printf("%d ", h_unfused == h_bail && rec[3].scale == rec[1].scale && rec[3].zero_point == rec[1].zero_point ? 1 : 0);
+    // [17] a reseeded generator repeats its thresholds: two calls after seed 42 == two calls after seed 42 again, and the two calls of a pair
+    // use different draws
+    uint64_t h_seed[4];
+    for (int k = 0; k < 4; ++k) {
+        if (k % 2 == 0) piquant_hip_set_stochastic_seed(ctx, 42);
+        piquant_quantize(ctx, d_x, PIQUANT_DTYPE_F32, d_q, PIQUANT_DTYPE_UINT8, n, 1.0f / 127.0f, 128, PIQUANT_STOCHASTIC);
+        h_seed[k] = pull_q(d_q, n);
+    }
+    std::printf("%d ", h_seed[0] == h_seed[2] && h_seed[1] == h_seed[3] && h_seed[0] != h_seed[1] ? 1 : 0);
+    // [18] assume_device_pointers skips the pointer queries, same bytes; [19] back on the context's private stream, a blocking call
+    piquant_hip_assume_device_pointers(ctx, 1);
+    piquant_quantize(ctx, d_x, PIQUANT_DTYPE_F32, d_q, PIQUANT_DTYPE_UINT8, n, 1.0f / 127.0f, 128, PIQUANT_NEAREST);
+    std::printf("%d ", pull_q(d_q, n) == h_wait[0] ? 1 : 0);
+    piquant_hip_assume_device_pointers(ctx, 0);
+    CK(hipStreamSynchronize(stream));
+    piquant_hip_reset_stream(ctx);
+    piquant_hip_set_blocking(ctx, 1);
+    CK(hipMemset(d_q, 0, n));
+    piquant_quantize(ctx, d_x, PIQUANT_DTYPE_F32, d_q, PIQUANT_DTYPE_UINT8, n, 1.0f / 127.0f, 128, PIQUANT_NEAREST);
+    CK(hipMemcpy(q.data(), d_q, n, hipMemcpyDeviceToHost));
+    std::printf("%d ", fnv1a(q.data(), n) == h_wait[0] ? 1 : 0);
     CK(hipMemcpy(rec, d_rec, sizeof rec, hipMemcpyDeviceToHost));
     std::printf("%.9g %lld %.9g %lld %d %s\n", static_cast<double>(rec[1].scale), static_cast<long long>(rec[1].zero_point), static_cast<double>(rec[2].scale),
                 static_cast<long long>(rec[2].zero_point), piquant_hip_device(ctx), std::strstr(piquant_hip_version(), "gfx950") ? "gfx950" : "?");

@@ -167,5 +167,9 @@ def test_hip_client_ext_rest_of_the_extension_surface_matches_oracle(tmp_path, o
     assert int(out[12], 16) == _fnv1a(O.dequantize(q8, O.UINT8, O.F32, n, s8, z8).tobytes())
     assert int(out[13], 16) == _fnv1a(O.dequantize(qs, O.UINT8, O.F32, n, ss, zs).tobytes())
     assert int(out[14], 16) == _fnv1a(O.quantize(x, O.F32, O.UINT8, float(sc), zp, form=O.FORM_REFERENCE).tobytes())
-    assert (np.float32(float(out[15])), int(out[16]), np.float32(float(out[17])), int(out[18])) == (np.float32(s8), z8, np.float32(ss), zs)
-    assert int(out[19]) == 0 and out[20] == "gfx950"
+    wbuf = np.zeros(n + 32, dtype=np.uint8)
+    base = (-wbuf.ctypes.data) % 16                                            # hipMalloc'ed output: aligned, no head
+    assert int(out[15], 16) == _fnv1a(O.quantize(x, O.F32, O.UINT8, float(sc), zp, form=O.FORM_REFERENCE, threads=3, out=wbuf[base: base + n]).tobytes())
+    assert out[16:20] == ["1", "1", "1", "1"]                                  # fusion off, reseeding, assume_device_pointers, reset_stream
+    assert (np.float32(float(out[20])), int(out[21]), np.float32(float(out[22])), int(out[23])) == (np.float32(s8), z8, np.float32(ss), zs)
+    assert int(out[24]) == 0 and out[25] == "gfx950"

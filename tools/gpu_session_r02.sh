@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-2 GPU-box session.  Usage (repo root, via gpurun):  gpurun --timeout 2400 -- 'bash tools/gpu_session_r02.sh [phases...]'
-#   phases: smoke newtests tests tune_fused tune_mm tune_half bench bench2 fit pmc prof rccl refbench hostcost soak
+#   phases: smoke newtests tests tune_fused tune_mm tune_half bench bench2 fit pmc prof rccl refbench hostcost soak matrix
 # Everything lands under gpurun_out/ (merged back by gpurun).
 set -u
 cd "$(dirname "$0")/.."
@@ -36,6 +36,8 @@ PY
               f=$(find $OUT/rccl_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -30 "$f"; tail -5 $OUT/rccl_workload.log ;;
     hostcost) timeout 600 python tools/host_call_cost.py > $OUT/host_call_cost.json 2> $OUT/host_call_cost.err; echo "hostcost rc=$?" | tee -a $OUT/session.log; cat $OUT/host_call_cost.json ;;
     soak)     timeout $(( ${SOAK_SECONDS:-600} + 400 )) python tools/parity_soak.py --seconds ${SOAK_SECONDS:-600} --seed ${SOAK_SEED:-202} > $OUT/parity_soak_r02.json 2> $OUT/parity_soak_r02.err; echo "soak rc=$?" | tee -a $OUT/session.log; cat $OUT/parity_soak_r02.json ;;
+    matrix)   timeout 900 python tools/dtype_matrix.py > $OUT/dtype_matrix.json 2> $OUT/dtype_matrix.err; echo "matrix rc=$?" | tee -a $OUT/session.log
+              python -c "import json; d=json.load(open('$OUT/dtype_matrix.json')); [print(r['op'], r['in'], r['out'], r['mode'], r['us'], r['frac_of_peak']) for r in d['rows']]" ;;
     refbench) timeout 900 python tools/reference_style_benchmarks.py --plot $OUT/quant_benchmark.png > $OUT/reference_style.json 2> $OUT/reference_style.err; echo "refbench rc=$?" | tee -a $OUT/session.log ;;
   esac
 done
