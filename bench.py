@@ -491,14 +491,15 @@ def main():
                                                "note": "fused quantize->dequantize, 4 B read + 4 B written per element"}
             del y
             rec = torch.empty(16, dtype=torch.uint8, device=dev)
-            _, e = time_loop(lambda i: piquant.torch.quantize_dynamic(xs[i % nsets], dtype=torch.uint8, ctx=ctx, out=outs[i % nsets], params=rec),
-                             reps, stream)
+            rec_ptr = rec.data_ptr()
+            _, e = time_loop(lambda i: ctx.quantize_dynamic_ptr(ptr_in[i % nsets], DataType.F32, ptr_out[i % nsets], DataType.UINT8, n, rec_ptr, RoundMode.NEAREST,
+                                                                _device_ptrs=True), reps, stream)
             extras["quantize_dynamic_f32_u8"] = {"GB/s": gbs(5, e, reps), "avg_us_per_call": round(e / reps * 1e6, 3),
                                                  "note": "compute_quant_params + quantize as ONE launch: the tensor stays in VGPRs/LDS between the min/max pass and "
                                                          "the quantization (5 B/elem of HBM traffic, x read once); no host sync"}
             ctx.set_fusion(False)
-            _, e = time_loop(lambda i: piquant.torch.quantize_dynamic(xs[i % nsets], dtype=torch.uint8, ctx=ctx, out=outs[i % nsets], params=rec),
-                             reps, stream)
+            _, e = time_loop(lambda i: ctx.quantize_dynamic_ptr(ptr_in[i % nsets], DataType.F32, ptr_out[i % nsets], DataType.UINT8, n, rec_ptr, RoundMode.NEAREST,
+                                                                _device_ptrs=True), reps, stream)
             ctx.set_fusion(True)
             extras["quantize_dynamic_f32_u8_unfused"] = {"GB/s": gbs(9, e, reps), "avg_us_per_call": round(e / reps * 1e6, 3),
                                                          "note": "same call with fusion off: scan (parameter epilogue in its last block) + quantize, 9 B/elem: x read twice"}

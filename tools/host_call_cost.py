@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Host cost of one stream-ordered piquant_quantize call (what bounds a small shard: at 8 GPUs the headline tensor is 3.4 M elements
-per GPU, a ~4.5 us kernel): Context.quantize_ptr, the raw ctypes call with prebuilt arguments, and the same launches replayed from a
-hipGraph.  Prints one JSON line."""
+per GPU, a ~4.5 us kernel): Context.quantize_ptr, the raw ctypes call with prebuilt arguments, the same launches replayed from a
+hipGraph, and (numel 4096) the piquant.torch functions on device tensors.  Prints one JSON line."""
 import ctypes
 import json
 import sys
@@ -48,6 +48,14 @@ for n in (4096, 3_408_000):
         args = [(ctx._ctx, pin[k], 0, pout[k], 4, n, 0.0078431377, 128, 0) for k in range(sets)]
         fn = C.piquant_quantize
         r["ctypes piquant_quantize, prebuilt args"] = timed(lambda i: fn(*args[i % sets]))
+        if n == 4096:   # the Python surface of the reference on device tensors: piquant.torch.* (native binding) and the additive dynamic call
+            import piquant.torch as pt
+            rec = torch.empty(16, dtype=torch.uint8, device="cuda")
+            r["piquant.torch.quantize(out=)"] = timed(lambda i: pt.quantize(xs[i % sets], scale=0.0078431377, zero_point=128, dtype=torch.uint8, ctx=ctx, out=qs[i % sets]))
+            r["piquant.torch.dequantize(out=)"] = timed(lambda i: pt.dequantize(qs[i % sets], scale=0.0078431377, zero_point=128, dtype=torch.float32, ctx=ctx, out=xs[i % sets]))
+            r["piquant.torch.quantize_dynamic(out=, params=)"] = timed(lambda i: pt.quantize_dynamic(xs[i % sets], dtype=torch.uint8, ctx=ctx, out=qs[i % sets], params=rec))
+            ctx.set_stream(s.cuda_stream)
+            ctx.set_blocking(False)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=s):
             for k in range(sets):
