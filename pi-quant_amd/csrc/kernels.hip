@@ -121,7 +121,7 @@ void minmax_t(const void* in, int64_t numel, int32_t* state, const MinmaxEpilogu
     const int64_t per_block = static_cast<int64_t>(kMinmaxBlock) * kMinmaxU * EPV;
     const unsigned grid = capped_grid((numel + per_block - 1) / per_block, kMinmaxBlocksPerCU, num_cu);
     if (kMinmaxGatherEnd && ep.action != EP_NONE && grid <= static_cast<unsigned>(kMinmaxGatherMax))
-        hipLaunchKernelGGL((minmax_kernel<DT_IN, kMinmaxU, kMinmaxNT, kMinmaxBlock, true, kMinmaxDynFrac>), dim3(grid), dim3(kMinmaxBlock), 0, stream, in, numel, state, ep);
+        hipLaunchKernelGGL((minmax_kernel<DT_IN, kMinmaxU, kMinmaxNT, kMinmaxBlock, true>), dim3(grid), dim3(kMinmaxBlock), 0, stream, in, numel, state, ep);
     else
         hipLaunchKernelGGL((minmax_kernel<DT_IN, kMinmaxU, kMinmaxNT, kMinmaxBlock, false>), dim3(grid), dim3(kMinmaxBlock), 0, stream, in, numel, state, ep);
 }

@@ -38,11 +38,7 @@ constexpr int kMinmaxSlotInts = kMinmaxSlots * kMinmaxSlotStride;
 constexpr int kMinmaxStateInts = kMinmaxSlotInts + kMinmaxSlotStride;   // + one line: [0] = slots whose blocks have all arrived
 // "Gather" end of a scan (minmax_block_end_gather): behind the slot area, one 8-byte {key(min), key(-max)} word per BLOCK.
 constexpr int kMinmaxGatherMax = 2048;                                  // grids up to this many blocks take the gather end
-// Dynamic end of a persistent scan (minmax_kernel<..., DYN>): behind the gather words, one ticket counter per block group, each on its
-// own 128-byte line.
-constexpr int kMinmaxDynGroups = 16;
-constexpr int kMinmaxDynOffset = kMinmaxStateInts + 2 * kMinmaxGatherMax;
-constexpr int kMinmaxScanStateInts = kMinmaxDynOffset + kMinmaxDynGroups * kMinmaxSlotStride;
+constexpr int kMinmaxScanStateInts = kMinmaxStateInts + 2 * kMinmaxGatherMax;
 constexpr unsigned long long kMinmaxNotArrived = 0x7fffffff7fffffffull;   // both halves are keys of NaN patterns: never a block's result
 static_assert(kMinmaxStateInts % 2 == 0, "the gather words are 8-byte aligned");
 
@@ -127,7 +123,6 @@ __global__ void __launch_bounds__(64) arm_slots_kernel(int32_t* state, int with_
     if (with_gather) {
         unsigned long long* words = reinterpret_cast<unsigned long long*>(state + kMinmaxStateInts);
         for (int i = threadIdx.x; i < kMinmaxGatherMax; i += 64) words[i] = kMinmaxNotArrived;
-        if (threadIdx.x < kMinmaxDynGroups) state[kMinmaxDynOffset + threadIdx.x * kMinmaxSlotStride] = 0;
     }
 }
 
@@ -289,9 +284,6 @@ __device__ __forceinline__ void minmax_block_end_gather(float lo, float hi, cons
         s_k1[wave] = k1;
     }
     __syncthreads();   // block-uniform: every thread of the sweeping block is here
-    // every block has stored its word, i.e. taken its last ticket: the ticket counters of the dynamic end start the next scan at zero
-    if (threadIdx.x < kMinmaxDynGroups)
-        __hip_atomic_store(state + kMinmaxDynOffset + threadIdx.x * kMinmaxSlotStride, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int w = 1; w < WAVES; ++w) {
@@ -302,47 +294,14 @@ __device__ __forceinline__ void minmax_block_end_gather(float lo, float hi, cons
     }
 }
 
-// DYN > 0 (gather end only): the last 1/DYN of the tensor is not dealt in advance.  The blocks of a persistent grid do not stream at
-// the same rate -- the CUs of some XCDs get 10-15 % less HBM bandwidth than others, which ones changes from launch to launch -- and
-// with an even deal the scan ends when the slowest block does, 1.5-3 us after the median one.  So every block first scans its even
-// share of the leading (DYN-1)/DYN, and the rest goes in chunks of U x BLOCK vectors to whoever asks first: the 16 consecutive
-// blocks of a group (two from each XCD) draw tickets from the group's counter (ticket t of group g = chunk t * groups + g), one atomic
-// per 32 KiB chunk per block spread over 16 addresses; the ticket for chunk i + 3 is requested while chunk i is folded and chunk
-// i + 1 is being loaded, so neither the atomic's round trip nor the loads' latency is ever waited for.  min/max do not care who
-// scanned what: the result is the same.
-template <int DT_IN, int U, bool NT, int BLOCK, bool GATHER = false, int DYN = 0, int DBG = 0>
+template <int DT_IN, int U, bool NT, int BLOCK, bool GATHER = false>
 __global__ void __launch_bounds__(BLOCK) minmax_kernel(const void* __restrict__ in, int64_t numel, int32_t* state, MinmaxEpilogue ep) {
-    static_assert(DYN == 0 || GATHER, "the ticket counters are reset by the sweeping block of the gather end");
     constexpr int EPV = InVec<DT_IN>::EPV;
     constexpr int WAVES = BLOCK / 64;
     const u32x4* __restrict__ in16 = static_cast<const u32x4*>(in);
     const int64_t n_vec = numel / EPV;
     const int64_t tid = static_cast<int64_t>(blockIdx.x) * BLOCK + threadIdx.x;
     const int64_t nthreads = static_cast<int64_t>(gridDim.x) * BLOCK;
-    const int64_t round = static_cast<int64_t>(U) * nthreads;
-
-    // the dealt part [0, dealt) is a whole number of grid rounds; chunks [dealt + c * chunk, ...) for c < dyn_chunks are drawn
-    constexpr int64_t chunk = static_cast<int64_t>(U) * BLOCK;
-    int64_t dealt = n_vec, dyn_chunks = 0;
-    [[maybe_unused]] uint32_t* ticket_ctr = nullptr;
-    [[maybe_unused]] uint32_t tk0 = 0, tk1 = 0, tk2 = 0;
-    // group of a block: consecutive blocks go to the XCDs in turn, so blocks 8j .. 8j + 7 sit on eight different XCDs; a grid of 128 or
-    // more blocks has all 16 groups, a smaller one as many as it has eights of blocks
-    [[maybe_unused]] const int64_t dyn_group = (blockIdx.x >> 3) & (kMinmaxDynGroups - 1);
-    [[maybe_unused]] const int64_t dyn_groups = gridDim.x >= 8 * kMinmaxDynGroups ? kMinmaxDynGroups : (gridDim.x + 7) / 8;
-    if constexpr (DYN > 0) {
-        const int64_t rounds_all = n_vec / round;
-        if (rounds_all >= 2 * DYN) {                                  // long enough for a tail that is worth dealing late
-            dealt = (rounds_all - rounds_all / DYN) * round;
-            dyn_chunks = (n_vec - dealt) / chunk;
-            ticket_ctr = reinterpret_cast<uint32_t*>(state + kMinmaxDynOffset + dyn_group * kMinmaxSlotStride);
-            if (threadIdx.x == 0) {                                     // the first tickets: their round trips hide behind the dealt part
-                tk0 = __hip_atomic_fetch_add(ticket_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                tk1 = __hip_atomic_fetch_add(ticket_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                tk2 = __hip_atomic_fetch_add(ticket_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
 
     float lo = 3.402823466e+38f, hi = -3.402823466e+38f;     // identities of the reference (:1422-1423)
 
@@ -356,15 +315,16 @@ __global__ void __launch_bounds__(BLOCK) minmax_kernel(const void* __restrict__ 
         }
     };
     int64_t v = tid;
+    const int64_t round = static_cast<int64_t>(U) * nthreads;
     // A rolling window of U loads per lane: as soon as a vector has been folded its register is refilled with the vector one round
     // ahead, so every lane keeps U loads in flight from its first instruction to its last round.  (Issuing U loads, waiting for all of
     // them and folding them before the next U -- round 1's loop -- lets a wave's loads in flight drop to zero once per round; with only
     // eight waves per CU nothing else fills the gap.)
-    if (v + static_cast<int64_t>(U - 1) * nthreads < dealt) {
+    if (v + static_cast<int64_t>(U - 1) * nthreads < n_vec) {
         u32x4 raw[U];
 #pragma unroll
         for (int k = 0; k < U; ++k) raw[k] = ld<NT>(in16 + v + k * nthreads);
-        while (v + round + static_cast<int64_t>(U - 1) * nthreads < dealt) {   // the next round is a full one too
+        while (v + round + static_cast<int64_t>(U - 1) * nthreads < n_vec) {   // the next round is a full one too
 #pragma unroll
             for (int k = 0; k < U; ++k) {
                 fold(raw[k]);
@@ -372,78 +332,9 @@ __global__ void __launch_bounds__(BLOCK) minmax_kernel(const void* __restrict__ 
             }
             v += round;
         }
-        if constexpr (DYN > 0) {
-            if (dyn_chunks > 0) {
-                // the window rolls on into the drawn chunks: ticket i's vectors replace the last dealt round's as they are folded
-                __shared__ uint32_t s_ticket[4];
-                if (threadIdx.x == 0) {
-                    s_ticket[0] = tk0;
-                    s_ticket[1] = tk1;
-                }
-                __syncthreads();
-                // tickets are block-uniform: through readfirstlane they are scalars, the branches on them scalar branches, and each arm a
-                // straight run of folds and loads like the dealt loop's body (loads under a vector condition make the compiler wait for
-                // every load at every join)
-                int64_t c = static_cast<int64_t>(__builtin_amdgcn_readfirstlane(s_ticket[0])) * dyn_groups + dyn_group;
-                bool have = c < dyn_chunks;
-                if (have) {
 #pragma unroll
-                    for (int k = 0; k < U; ++k) {
-                        fold(raw[k]);
-                        raw[k] = ld<NT>(in16 + dealt + c * chunk + k * BLOCK + threadIdx.x);
-                    }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < U; ++k) fold(raw[k]);
-                }
-                uint32_t i = 0;
-                // DBG: tickets by formula (index of the block within its group + 16 per iteration); 1 = no atomics at all, 2 = atomics issued, results unused
-                [[maybe_unused]] const uint32_t within = (blockIdx.x & 7) | ((blockIdx.x >> 7) << 3);
-                if constexpr (DBG != 0) {
-                    __syncthreads();
-                    if (threadIdx.x == 0) { s_ticket[0] = within; s_ticket[1] = within + 16; }
-                    __syncthreads();
-                }
-                uint32_t pending = DBG != 0 ? within + 32 : tk2;                                    // thread 0: ticket i + 2, requested one iteration ago
-                while (have) {
-                    // A ticket is used two iterations after it was requested and published one iteration after: vector memory
-                    // returns in order, so looking at a ticket in the iteration that requested it would hold the wave's refills
-                    // behind the atomic's round trip.
-                    if (threadIdx.x == 0) {
-                        s_ticket[(i + 2) & 3] = pending;
-                        if constexpr (DBG == 0) pending = __hip_atomic_fetch_add(ticket_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ticket i + 3
-                        else {
-                            if constexpr (DBG == 2) __hip_atomic_fetch_add(ticket_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            pending = within + 16 * (i + 3);
-                        }
-                    }
-                    const int64_t cn = static_cast<int64_t>(__builtin_amdgcn_readfirstlane(s_ticket[(i + 1) & 3])) * dyn_groups + dyn_group;   // ticket i + 1
-                    const bool have_n = cn < dyn_chunks;
-                    if (have_n) {
-#pragma unroll
-                        for (int k = 0; k < U; ++k) {
-                            fold(raw[k]);
-                            raw[k] = ld<NT>(in16 + dealt + cn * chunk + k * BLOCK + threadIdx.x);
-                        }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < U; ++k) fold(raw[k]);
-                    }
-                    __syncthreads();
-                    ++i;
-                    have = have_n;
-                }
-                v = dealt + dyn_chunks * chunk + tid;                      // what is left is less than one chunk
-            } else {
-#pragma unroll
-                for (int k = 0; k < U; ++k) fold(raw[k]);
-                v += round;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < U; ++k) fold(raw[k]);
-            v += round;
-        }
+        for (int k = 0; k < U; ++k) fold(raw[k]);
+        v += round;
     }
     for (; v < n_vec; v += nthreads) fold(ld<NT>(in16 + v));
     // ragged scalar tail (numel % EPV elements)

@@ -55,7 +55,6 @@ constexpr int kMinmaxU = 4;
 constexpr bool kMinmaxNT = true;
 constexpr int kMinmaxBlock = 512;
 constexpr int kMinmaxBlocksPerCU = 1;
-constexpr int kMinmaxDynFrac = 0;         // > 0: the last 1/kMinmaxDynFrac of a scan is dealt by tickets (minmax_kernel DYN), gather end only
 constexpr bool kMinmaxGatherEnd = true;   // end of a scan: per-block result words swept by the highest block (true) or slot atomics + arrival counters
 
 // fused params + quantize (fused_kernels.hpp): one 1024-thread block per CU (4 waves per SIMD, 128 VGPRs each); per thread 18

@@ -267,7 +267,7 @@ static void run_requant(const Bufs& b, int64_t numel, int num_cu, double bytes_p
 
 static std::vector<int> g_mm_caps = {1, 2, 4, 8, 16, 32};
 
-template <int DT_IN, int U, bool NT, int BLOCK, bool GATHER = false, int DYN = 0, int DBG = 0>
+template <int DT_IN, int U, bool NT, int BLOCK, bool GATHER = false>
 static void run_minmax(const Bufs& b, int64_t numel, int num_cu, int32_t* keys) {
     for (int cap : g_mm_caps) {
         // cap 0: one round of U loads per block, as many blocks as that takes (the hardware's dispatcher balances the load)
@@ -276,18 +276,12 @@ static void run_minmax(const Bufs& b, int64_t numel, int num_cu, int32_t* keys) 
         if (GATHER && grid > static_cast<unsigned>(kMinmaxGatherMax)) continue;
         const double us = time_us([&](int i) {
             // production protocol: the finishing block folds the per-block results into a key pair and re-arms the state inside the launch
-            hipLaunchKernelGGL((minmax_kernel<DT_IN, U, NT, BLOCK, GATHER, DYN, DBG>), dim3(grid), dim3(BLOCK), 0, g_stream, b.in[i % SETS], numel, keys,
+            hipLaunchKernelGGL((minmax_kernel<DT_IN, U, NT, BLOCK, GATHER>), dim3(grid), dim3(BLOCK), 0, g_stream, b.in[i % SETS], numel, keys,
                                MinmaxEpilogue {EP_KEYS_SET, 0, 0u, keys + kMinmaxScanStateInts});
         });
-        // the result of one more scan of set 0, so that variants can be compared (the same two keys whatever the deal)
-        hipLaunchKernelGGL((minmax_kernel<DT_IN, U, NT, BLOCK, GATHER, DYN, DBG>), dim3(grid), dim3(BLOCK), 0, g_stream, b.in[0], numel, keys,
-                           MinmaxEpilogue {EP_KEYS_SET, 0, 0u, keys + kMinmaxScanStateInts});
-        int32_t got[2];
-        CK(hipMemcpyAsync(got, keys + kMinmaxScanStateInts, 8, hipMemcpyDeviceToHost, g_stream));
-        CK(hipStreamSynchronize(g_stream));
-        char name[200];
-        std::snprintf(name, sizeof name, "in=%s U=%d nt=%d block=%d end=%s dyn=%d dbg=%d cap=%d grid=%u keys=%08x:%08x", DT_IN == DT_F32 ? "f32" : "bf16", U, NT ? 1 : 0, BLOCK,
-                      GATHER ? "gather" : "slots", DYN, DBG, cap, grid, static_cast<unsigned>(got[0]), static_cast<unsigned>(got[1]));
+        char name[160];
+        std::snprintf(name, sizeof name, "in=%s U=%d nt=%d block=%d end=%s cap=%d grid=%u", DT_IN == DT_F32 ? "f32" : "bf16", U, NT ? 1 : 0, BLOCK,
+                      GATHER ? "gather" : "slots", cap, grid);
         report("minmax", name, us, (DT_IN == DT_F32 ? 4.0 : 2.0) * numel);
     }
 }
@@ -706,21 +700,6 @@ int main(int argc, char** argv) {
             run_minmax<DT_F32, 4, true, 1024, true>(b, numel, num_cu, keys);
             run_minmax<DT_BF16, 4, true, 256, false>(b, numel, num_cu, keys);
             run_minmax<DT_BF16, 4, true, 256, true>(b, numel, num_cu, keys);
-        }
-        g_mm_caps = {1, 2, 4, 8, 16, 32};
-        g_rounds = 3;
-    }
-    if (only == "mm5") {
-        // the dynamic end of the persistent scan (last 1/DYN of the tensor drawn by tickets) against the even deal
-        g_rounds = 1;
-        g_mm_caps = {1};
-        for (int pass = 0; pass < 5; ++pass) {
-            run_minmax<DT_F32, 4, true, 512, true, 0>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 4, true, 512, true, 4>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 4, true, 512, true, 4, 1>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 4, true, 512, true, 4, 2>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 4, true, 512, true, 8>(b, numel, num_cu, keys);
-            run_minmax<DT_BF16, 4, true, 512, true, 6>(b, numel, num_cu, keys);
         }
         g_mm_caps = {1, 2, 4, 8, 16, 32};
         g_rounds = 3;
