@@ -38,12 +38,12 @@ import torch.distributed as dist  # noqa: E402
 NUMEL = 27_264_000
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 ALGO_BYTES_PER_ELEM = 5        # 4 B read + 1 B written
-DEFAULT_BLOCKING_WAIT = "kernel"
+DEFAULT_BLOCKING_WAIT = "kernel"   # the library's default (csrc/context.cpp kDefaultBlockingWait)
 # Rotation that really is cold.  Round 1 rotated 6 sets (818 MB, SURVEY 8d asked for > 512 MB); measured in round 2 on the same box, same kernel:
 # 21.65 us per launch with 6 sets, 22.71 with 12 (1.6 GB), 22.86 with 24 (3.3 GB) -- with three times its capacity in rotation the 256 MiB
 # Infinity Cache still serves part of the reads.  The headline therefore rotates 24 sets; the 6-set figure is kept in extras for continuity.
 ROUND1_SETS = 6
-CPU_SETS = 6                     # the host side keeps 818 MB in rotation (beyond both sockets' L3), bounded so that the baseline stays a 20 s affair  # the library's default (capi.cpp kDefaultBlockingWait)
+CPU_SETS = 6                     # the host side keeps 818 MB in rotation (beyond both sockets' L3), bounded so that the baseline stays a 20 s affair
 
 
 def parse():
@@ -444,7 +444,7 @@ def main():
             extras["rotation_of_6_sets_818MB_round1_protocol"] = {"GiB/s": round(gib_per_step * 600 / w, 1), "avg_launch_us": round(e / 600 * 1e6, 3),
                                                                "GB/s": gbs_plain(5, e, 600),
                                                                "note": "what round 1 reported as the headline: three times the Infinity Cache's size in rotation is not enough to keep it out"}
-            # reference semantics: every call waits for completion (blocking context); A/B of the three ways to wait (capi.cpp wait_stream)
+            # reference semantics: every call waits for completion (blocking context); A/B of the three ways to wait (csrc/context.cpp wait_stream)
             ctx.set_blocking(True)
             ctx.assume_device_pointers(True)      # step() makes the raw C call: the context must know these are device pointers
             blocking = {}

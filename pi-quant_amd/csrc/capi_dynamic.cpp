@@ -1,0 +1,316 @@
+// The additive entry points of include/piquant_hip.h that have no twin in piquant.h: one-pass sums and batches of dequantize,
+// the reference's C++-only quantize_dequantize_fused, and compute_quant_params + quantize as one call (one launch when the tensor
+// fits on the chip), its batched form and the reduce variant.
+#include "context.hpp"
+
+using namespace pq;
+
+extern "C" {
+
+void piquant_hip_dequantize_sum(piquant_context_t* ctx, const void* const* inputs, const piquant_hip_params_t* const* device_params, size_t count,
+                                piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out, size_t numel, piquant_reduce_op_t op) {
+    if (!ctx) panic("piquant_hip_dequantize_sum: context is NULL");
+    const dtype_row& dti = dtype_of(dtype_in);
+    const dtype_row& dto = dtype_of(dtype_out);
+    if (!dti.quant) panic("dequantize: input dtype (%s) must be a quantized type", dti.name);
+    if (dto.quant) panic("dequantize: output dtype (%s) must be a dequantized type", dto.name);
+    if (op != PIQUANT_REDUCE_OP_SET && op != PIQUANT_REDUCE_OP_ADD) panic("dequantize: invalid reduce op %d", static_cast<int>(op));
+    if (count == 0 || numel == 0) return;
+    if (!inputs || !device_params || !out) panic("dequantize_sum: NULL argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    const Resolved rout = ctx->resolve_ptr(out);
+    if (rout.pageable) panic("piquant_hip_dequantize_sum needs device (or pinned) buffers");
+    // more inputs than one launch takes: the first launch carries the caller's op, the following ones accumulate
+    for (size_t first = 0; first < count; first += kDequantSumMaxInputs) {
+        DequantSumLaunch d {};
+        d.count = static_cast<int>(std::min<size_t>(kDequantSumMaxInputs, count - first));
+        for (int i = 0; i < d.count; ++i) {
+            if (!inputs[first + i] || !device_params[first + i]) panic("dequantize_sum: NULL input %zu", first + i);
+            const Resolved ri = ctx->resolve_ptr(inputs[first + i]), rp = resolve(device_params[first + i]);
+            if (ri.pageable || rp.pageable) panic("piquant_hip_dequantize_sum needs device (or pinned) buffers");
+            d.in[i] = ri.dev;
+            d.params[i] = rp.dev;
+        }
+        d.out = rout.dev;
+        d.numel = static_cast<int64_t>(numel);
+        d.dt_in = dtype_in;
+        d.dt_out = dtype_out;
+        d.op = (first == 0 && op == PIQUANT_REDUCE_OP_SET) ? OP_SET : OP_ADD;
+        launch_dequantize_sum(d, ctx->stream, ctx->num_cu);
+    }
+    if (ctx->blocking) wait_stream(ctx);
+}
+
+void piquant_hip_dequantize_dp_batch(piquant_context_t* ctx, const void* const* inputs, piquant_dtype_t dtype_in, void* const* outputs,
+                                     piquant_dtype_t dtype_out, const size_t* numels, const piquant_hip_params_t* const* device_params, size_t count,
+                                     piquant_reduce_op_t op) {
+    if (!ctx) panic("piquant_hip_dequantize_dp_batch: context is NULL");
+    const dtype_row& dti = dtype_of(dtype_in);
+    const dtype_row& dto = dtype_of(dtype_out);
+    if (!dti.quant) panic("dequantize: input dtype (%s) must be a quantized type", dti.name);
+    if (dto.quant) panic("dequantize: output dtype (%s) must be a dequantized type", dto.name);
+    if (op != PIQUANT_REDUCE_OP_SET && op != PIQUANT_REDUCE_OP_ADD) panic("dequantize: invalid reduce op %d", static_cast<int>(op));
+    if (count == 0) return;
+    if (!inputs || !outputs || !numels || !device_params) panic("piquant_hip_dequantize_dp_batch: NULL argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    size_t i = 0;
+    while (i < count) {
+        DequantBatchLaunch d {};
+        d.dt_in = dtype_in;
+        d.dt_out = dtype_out;
+        d.op = op == PIQUANT_REDUCE_OP_ADD ? OP_ADD : OP_SET;
+        while (i < count && d.count < kDequantBatchMaxInputs) {
+            if (numels[i] != 0) {
+                if (!inputs[i] || !outputs[i] || !device_params[i]) panic("dequantize: NULL buffer %zu", i);
+                const Resolved ri = ctx->resolve_ptr(inputs[i]), ro = ctx->resolve_ptr(outputs[i]), rp = resolve(device_params[i]);
+                if (ri.pageable || ro.pageable || rp.pageable) panic("piquant_hip_dequantize_dp_batch needs device (or pinned) buffers");
+                d.in[d.count] = ri.dev;
+                d.out[d.count] = ro.dev;
+                d.params[d.count] = rp.dev;
+                d.numel[d.count] = static_cast<int64_t>(numels[i]);
+                ++d.count;
+            }
+            ++i;
+        }
+        launch_dequantize_batch(d, ctx->stream);
+    }
+    if (ctx->blocking) wait_stream(ctx);
+}
+
+void piquant_hip_quantize_dequantize(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in_out, void* out, piquant_dtype_t quant_dtype,
+                                     size_t numel, float scale, int64_t zero_point, piquant_round_mode_t mode, piquant_reduce_op_t op) {
+    if (!ctx) panic("piquant_hip_quantize_dequantize: context is NULL");
+    // reference src/piquant.cpp:353-355
+    if (dtype_of(dtype_in_out).quant) panic("quantize_dequantize: input dtype must be a dequantized type");
+    if (!dtype_of(quant_dtype).quant) panic("quantize_dequantize: quant dtype must be a quantized type");
+    if (mode != PIQUANT_NEAREST && mode != PIQUANT_STOCHASTIC) panic("quantize_dequantize: invalid round mode %d", static_cast<int>(mode));
+    if (op != PIQUANT_REDUCE_OP_SET && op != PIQUANT_REDUCE_OP_ADD) panic("quantize_dequantize: invalid reduce op %d", static_cast<int>(op));
+    if (numel == 0) return;
+    if (!in || !out) panic("quantize_dequantize: NULL buffer");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    const Resolved rin = ctx->resolve_ptr(in), rout = ctx->resolve_ptr(out);
+    if (rin.pageable || rout.pageable) panic("quantize_dequantize: device (or pinned) buffers required");
+    RequantLaunch r {};
+    r.in = rin.dev;
+    r.out = rout.dev;
+    r.numel = static_cast<int64_t>(numel);
+    r.dt_inout = dtype_in_out;
+    r.quant_dtype = quant_dtype;
+    r.op = op == PIQUANT_REDUCE_OP_ADD ? OP_ADD : OP_SET;
+    r.scale = scale;
+    {   // bfp16_t(scale): round to nearest even, NaN quieted (reference include/piquant.hpp:86-90)
+        uint32_t u;
+        __builtin_memcpy(&u, &scale, 4);
+        uint32_t b = (u & 0x7fffffffu) > 0x7f800000u ? ((u >> 16) | 64u) : ((u + (0x7fffu + ((u >> 16) & 1u))) >> 16);
+        b <<= 16;
+        __builtin_memcpy(&r.scale_bf16, &b, 4);
+    }
+    r.inv_scale = 1.0f / scale;
+    r.zero_point = zero_point;
+    if (mode == PIQUANT_NEAREST) r.round_mode = RM_NEAREST_I64;
+    else if (ctx->per_element) {
+        r.round_mode = RM_STOCH_ELEM;
+        r.seed = ctx->elem_seed;
+        r.index_base = ctx->elem_base;
+    } else {
+        r.round_mode = RM_STOCH_CALL;
+        r.threshold = draw_threshold(ctx);
+    }
+    launch_requantize(r, ctx->stream, ctx->num_cu);
+    if (ctx->blocking) wait_stream(ctx);
+}
+
+// compute_quant_params + quantize of ONE tensor on resolved device pointers; `q` carries dtypes and the round-mode fields.
+// Caller holds ctx->mu and the device guard.
+static void quantize_dynamic_one(piquant_context_t* ctx, QuantLaunch q, const void* in_dev, void* out_dev, const void* out_as_passed, size_t numel,
+                                 void* params_dev) {
+    MinmaxAction params_action;
+    params_action.action = MM_PARAMS;
+    params_action.bits = dtype_of(static_cast<piquant_dtype_t>(q.dt_out)).bits;
+    params_action.dst = params_dev;
+    if (numel == 0) {   // parameters of an empty tensor: the device epilogue writes the degenerate record (1.0, qmax >> 1) for the armed identities
+        scan(ctx, nullptr, static_cast<piquant_dtype_t>(q.dt_in), 0, params_action);
+        return;
+    }
+    q.in = in_dev;
+    q.out = out_dev;
+    q.numel = static_cast<int64_t>(numel);
+    q.ref_out_align = -1;
+    if (ctx->reference_layout) {
+        q.ref_layout = true;
+        q.ref_total = q.numel;
+        q.ref_threads = ctx->reference_threads;
+        if (q.dt_in == PIQUANT_DTYPE_F32 && q.dt_out == PIQUANT_DTYPE_UINT8 && q.round_mode == RM_NEAREST_FAST) {
+            q.ref_head = static_cast<int>(std::min<size_t>(numel, (16u - (reinterpret_cast<uintptr_t>(out_as_passed) & 15u)) & 15u));
+            q.ref_out_align = static_cast<int>(reinterpret_cast<uintptr_t>(out_as_passed) & 15u);
+        }
+    }
+    // One launch with the tensor held on chip between the scan and the quantization when it fits; otherwise (or with fusion
+    // switched off) the same result from two launches: the scan, whose last block writes the record, and a quantize that reads it.
+    bool fused = false;
+    if (ctx->fusion && fused_launch_applies(q, ctx->num_cu)) {
+        FusedLaunchOrder order(ctx->device, ctx->stream);
+        q.barrier_timeout_us = ctx->barrier_timeout_us;
+        fused = launch_fused_params_quantize(q, ctx->d_fused, params_dev, ctx->stream, ctx->num_cu);
+        if (fused) order.launched();
+    }
+    if (!fused) {
+        scan(ctx, in_dev, static_cast<piquant_dtype_t>(q.dt_in), numel, params_action);
+        q.dyn_params = params_dev;
+        launch_quantize(q, ctx->stream, ctx->num_cu);
+    }
+}
+
+static void check_dynamic_types(piquant_dtype_t dtype_in, piquant_dtype_t dtype_out, piquant_round_mode_t mode) {
+    const dtype_row& dti = dtype_of(dtype_in);
+    const dtype_row& dto = dtype_of(dtype_out);
+    if (dti.quant) panic("quantize: input dtype (%s) must be a dequantized type", dti.name);
+    if (!dto.quant) panic("quantize: output dtype (%s) must be a quantized type", dto.name);
+    if (mode != PIQUANT_NEAREST && mode != PIQUANT_STOCHASTIC) panic("quantize: invalid round mode %d", static_cast<int>(mode));
+}
+
+void piquant_hip_quantize_dynamic(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out, size_t numel,
+                                  piquant_hip_params_t* device_params, piquant_round_mode_t mode) {
+    if (!ctx) panic("piquant_hip_quantize_dynamic: context is NULL");
+    check_dynamic_types(dtype_in, dtype_out, mode);
+    if (!device_params) panic("piquant_hip_quantize_dynamic: NULL parameter record");
+    if (numel != 0 && (!in || !out)) panic("quantize: NULL buffer");
+
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    const Resolved rp = resolve(device_params);
+    if (rp.pageable) panic("piquant_hip_quantize_dynamic: the parameter record must live in device (or pinned) memory");
+    QuantLaunch q {};
+    q.dt_in = dtype_in;
+    q.dt_out = dtype_out;
+    fill_round_mode(ctx, q, mode);
+    if (numel == 0) {
+        quantize_dynamic_one(ctx, q, nullptr, nullptr, nullptr, 0, rp.dev);
+    } else {
+        const Resolved rin = ctx->resolve_ptr(in), rout = ctx->resolve_ptr(out);
+        if (rin.pageable || rout.pageable) panic("piquant_hip_quantize_dynamic needs device (or pinned) buffers");
+        quantize_dynamic_one(ctx, q, rin.dev, rout.dev, out, numel, rp.dev);
+    }
+    if (ctx->blocking) wait_stream(ctx);
+}
+
+void piquant_hip_quantize_dynamic_batch(piquant_context_t* ctx, const void* const* inputs, piquant_dtype_t dtype_in, void* const* outputs,
+                                        piquant_dtype_t dtype_out, const size_t* numels, piquant_hip_params_t* const* device_params, size_t count,
+                                        piquant_round_mode_t mode) {
+    if (!ctx) panic("piquant_hip_quantize_dynamic_batch: context is NULL");
+    check_dynamic_types(dtype_in, dtype_out, mode);
+    if (count == 0) return;
+    if (!inputs || !outputs || !numels || !device_params) panic("piquant_hip_quantize_dynamic_batch: NULL argument");
+
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    QuantLaunch q {};
+    q.dt_in = dtype_in;
+    q.dt_out = dtype_out;
+    fill_round_mode(ctx, q, mode);   // stochastic: ONE threshold for the whole batch, as one call of the reference has one
+    struct Item {
+        const void* in;
+        void* out;
+        const void* out_as_passed;
+        size_t numel;
+        void* params;
+    };
+    std::vector<Item> items(count);
+    for (size_t i = 0; i < count; ++i) {
+        if (!device_params[i]) panic("piquant_hip_quantize_dynamic_batch: NULL parameter record %zu", i);
+        const Resolved rp = resolve(device_params[i]);
+        if (rp.pageable) panic("piquant_hip_quantize_dynamic_batch: parameter records must live in device (or pinned) memory");
+        items[i] = {nullptr, nullptr, outputs[i], numels[i], rp.dev};
+        if (numels[i] == 0) continue;
+        if (!inputs[i] || !outputs[i]) panic("quantize: NULL buffer %zu", i);
+        const Resolved rin = ctx->resolve_ptr(inputs[i]), rout = ctx->resolve_ptr(outputs[i]);
+        if (rin.pageable || rout.pageable) panic("piquant_hip_quantize_dynamic_batch needs device (or pinned) buffers");
+        items[i].in = rin.dev;
+        items[i].out = rout.dev;
+    }
+    // Up to kFusedBatchMax non-empty tensors per launch: one sub-grid, one barrier, one parameter record each.  Whatever does not
+    // qualify (fusion off, reference-layout mode, a misaligned or oversized tensor in the group) goes one tensor at a time.
+    size_t i = 0;
+    while (i < count) {
+        FusedBatch b {};
+        size_t j = i;
+        while (j < count && b.count < kFusedBatchMax) {
+            if (items[j].numel != 0) {
+                b.in[b.count] = items[j].in;
+                b.out[b.count] = items[j].out;
+                b.numel[b.count] = static_cast<int64_t>(items[j].numel);
+                b.params[b.count] = items[j].params;
+                ++b.count;
+            }
+            ++j;
+        }
+        bool fused = false;
+        if (ctx->fusion && !ctx->reference_layout && b.count > 1) {
+            FusedLaunchOrder order(ctx->device, ctx->stream);
+            q.barrier_timeout_us = ctx->barrier_timeout_us;
+            fused = launch_fused_params_quantize_batch(q, b, ctx->d_fused, ctx->stream, ctx->num_cu);
+            if (fused) order.launched();
+        }
+        for (size_t k = i; k < j; ++k) {
+            if (fused && items[k].numel != 0) continue;
+            quantize_dynamic_one(ctx, q, items[k].in, items[k].out, items[k].out_as_passed, items[k].numel, items[k].params);
+        }
+        i = j;
+    }
+    if (ctx->blocking) wait_stream(ctx);
+}
+
+void piquant_hip_reduce_quantize_dynamic(piquant_context_t* ctx, void* acc, piquant_dtype_t dtype_acc, const void* const* inputs,
+                                         const piquant_hip_params_t* const* input_params, size_t count, void* out, piquant_dtype_t dtype_out, size_t numel,
+                                         piquant_hip_params_t* device_params, piquant_round_mode_t mode) {
+    if (!ctx) panic("piquant_hip_reduce_quantize_dynamic: context is NULL");
+    check_dynamic_types(dtype_acc, dtype_out, mode);
+    if (!device_params) panic("piquant_hip_reduce_quantize_dynamic: NULL parameter record");
+    if (numel == 0 || count == 0) {   // nothing to add (or nothing at all): the plain call
+        piquant_hip_quantize_dynamic(ctx, acc, dtype_acc, out, dtype_out, numel, device_params, mode);
+        return;
+    }
+    if (!acc || !out || !inputs || !input_params) panic("piquant_hip_reduce_quantize_dynamic: NULL argument");
+    bool fused = false;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        DeviceGuard guard(ctx->device);
+        const Resolved rp = resolve(device_params), racc = ctx->resolve_ptr(acc), rout = ctx->resolve_ptr(out);
+        if (rp.pageable || racc.pageable || rout.pageable) panic("piquant_hip_reduce_quantize_dynamic needs device (or pinned) buffers");
+        if (ctx->fusion && !ctx->reference_layout && count <= static_cast<size_t>(kDequantSumMaxInputs)) {
+            QuantLaunch q {};
+            q.in = racc.dev;
+            q.out = rout.dev;
+            q.numel = static_cast<int64_t>(numel);
+            q.dt_in = dtype_acc;
+            q.dt_out = dtype_out;
+            fill_round_mode(ctx, q, mode);
+            DequantSumLaunch terms {};
+            terms.count = static_cast<int>(count);
+            terms.dt_in = dtype_out;
+            for (size_t i = 0; i < count; ++i) {
+                if (!inputs[i] || !input_params[i]) panic("piquant_hip_reduce_quantize_dynamic: NULL input %zu", i);
+                const Resolved ri = ctx->resolve_ptr(inputs[i]), rq = resolve(input_params[i]);
+                if (ri.pageable || rq.pageable) panic("piquant_hip_reduce_quantize_dynamic needs device (or pinned) buffers");
+                terms.in[i] = ri.dev;
+                terms.params[i] = rq.dev;
+            }
+            {
+                FusedLaunchOrder order(ctx->device, ctx->stream);
+                q.barrier_timeout_us = ctx->barrier_timeout_us;
+                fused = launch_fused_reduce_quantize(q, terms, ctx->d_fused, rp.dev, ctx->stream, ctx->num_cu);
+                if (fused) order.launched();
+            }
+            if (fused && ctx->blocking) wait_stream(ctx);
+        }
+    }
+    if (fused) return;
+    // the same result in two steps (and with `acc` updated on the way): one-pass sum into acc, then parameters + quantize
+    piquant_hip_dequantize_sum(ctx, inputs, input_params, count, dtype_out, acc, dtype_acc, numel, PIQUANT_REDUCE_OP_ADD);
+    piquant_hip_quantize_dynamic(ctx, acc, dtype_acc, out, dtype_out, numel, device_params, mode);
+}
+
+}  // extern "C"

@@ -1,0 +1,320 @@
+// The context behind piquant_context_t: creation, the knobs of include/piquant_hip.h, the completion wait of blocking calls and the
+// per-device ordering of grid-barrier launches.  It replaces the reference's context/pimpl (src/piquant.cpp:107-211); the thread
+// pool and its static range split disappear -- a HIP grid covers the whole range in one launch.
+#include "context.hpp"
+
+namespace pq {
+
+// Reference convention (src/piquant.cpp:88-98): red message on stderr, then abort().
+void panic(const char* fmt, ...) {
+    std::va_list ap;
+    va_start(ap, fmt);
+    std::fputs("\x1b[31m", stderr);
+    std::vfprintf(stderr, fmt, ap);
+    std::fputs("\x1b[0m\n", stderr);
+    std::fflush(stderr);
+    va_end(ap);
+    std::abort();
+}
+
+void check_hip(hipError_t e, const char* what, const char* file, int line) {
+    if (e != hipSuccess) panic("%s:%d HIP call failed: %s -> %s", file, line, what, hipGetErrorString(e));
+}
+
+namespace {
+// include/piquant.hpp:144-150 of the reference
+constexpr dtype_row kDtypes[5] = {{"f32", 32, false}, {"bf16", 16, false}, {"uint2", 2, true}, {"uint4", 4, true}, {"uint8", 8, true}};
+}  // namespace
+
+const dtype_row& dtype_of(int dt) {
+    if (dt < 0 || dt > 4) panic("invalid dtype code %d", dt);
+    return kDtypes[dt];
+}
+
+size_t span_bytes(size_t numel, int dt) {
+    const int bits = dtype_of(dt).bits;
+    if (bits >= 8) return numel * static_cast<size_t>(bits / 8);
+    const size_t per = 8 / bits;
+    return (numel + per - 1) / per;
+}
+
+Resolved resolve(const void* p) {
+    hipPointerAttribute_t a {};
+    const hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();   // unknown to the runtime == ordinary host memory
+        return {true, nullptr};
+    }
+    switch (a.type) {
+        case hipMemoryTypeDevice:
+        case hipMemoryTypeManaged: return {false, const_cast<void*>(p)};
+        case hipMemoryTypeHost: return {false, a.devicePointer ? a.devicePointer : const_cast<void*>(p)};   // pinned: read over PCIe in place
+        default: return {true, nullptr};
+    }
+}
+
+namespace {
+constexpr int kDefaultBlockingWait = 2;   // WAIT_KERNEL: 30.4 us per blocking fp32->uint8 call at numel 27 264 000 against 31.7 (WAIT_WRITE32) and 34.8 (WAIT_SYNC), profiles/r02_blocking_wait_ab.json
+}  // namespace
+
+void wait_stream(piquant_context_t* ctx) {
+    hipStream_t stream = ctx->stream;
+    // a captured launch does not run until the graph is replayed: waiting for it here would never end
+    if (stream_is_capturing(stream)) panic("a blocking call cannot be captured into a hipGraph: make the context stream-ordered first (piquant_hip_set_blocking(ctx, 0))");
+    if (ctx->wait_mode == WAIT_SYNC || !ctx->done_dev) {
+        PQ_HIP(hipStreamSynchronize(stream));
+        return;
+    }
+    const uint32_t seq = ++ctx->done_seq;
+    if (ctx->wait_mode == WAIT_WRITE32) {
+        if (hipStreamWriteValue32(stream, ctx->done_dev, seq, 0) != hipSuccess) {   // not supported for this memory / runtime: stay with the runtime's wait
+            (void)hipGetLastError();
+            ctx->wait_mode = WAIT_SYNC;
+            PQ_HIP(hipStreamSynchronize(stream));
+            return;
+        }
+    } else {
+        launch_publish_seq(static_cast<uint32_t*>(ctx->done_dev), seq, stream);
+    }
+    volatile uint32_t* flag = ctx->done;
+    for (uint32_t spins = 0;; ++spins) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return;
+        if ((spins & 0x3fff) == 0x3fff) {   // every ~50 us: has the stream drained (or failed) without the word becoming visible?
+            const hipError_t q = hipStreamQuery(stream);
+            if (q == hipSuccess) {
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return;
+                PQ_HIP(hipStreamSynchronize(stream));
+                return;
+            }
+            if (q != hipErrorNotReady) PQ_HIP(q);
+        }
+        __builtin_ia32_pause();
+    }
+}
+
+// Two grid-barrier kernels dispatched at the same moment from different streams could each take part of the CUs and make each
+// other's blocks wait for their barrier timeout (fused_kernels.hpp: never a deadlock, but the orphan pick-up that follows is slow).
+// Launches on ONE stream are ordered by the stream.  The first time a second stream issues a fused launch on a device, the
+// device is synchronised once and from then on every fused launch records an event that the next fused launch on a different
+// stream waits for.  A process that keeps to one stream pays nothing.
+struct FusedOrder {
+    std::mutex mu;
+    hipStream_t last_stream = nullptr;
+    bool seen = false;
+    bool multi_stream = false;
+    hipEvent_t last = nullptr;
+};
+
+FusedOrder& fused_order(int device) {
+    static FusedOrder per_device[64];
+    return per_device[device & 63];
+}
+
+bool stream_is_capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+}
+
+FusedLaunchOrder::FusedLaunchOrder(int device, hipStream_t stream) : o_(fused_order(device)), stream_(stream), lock_(o_.mu, std::defer_lock) {
+        if (stream_is_capturing(stream)) return;
+        lock_.lock();
+        if (o_.seen && o_.last_stream != stream) {
+            if (!o_.multi_stream) {
+                // once per device and process: whatever the first stream still has in flight finishes before the second stream's
+                // first fused launch (no event exists yet to wait for).  Not fatal if the runtime refuses (another thread capturing).
+                if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+                PQ_HIP(hipEventCreateWithFlags(&o_.last, hipEventDisableTiming));
+                o_.multi_stream = true;
+            } else {
+                PQ_HIP(hipStreamWaitEvent(stream, o_.last, 0));
+            }
+        }
+        o_.seen = true;
+        o_.last_stream = stream;
+    }
+
+void FusedLaunchOrder::launched() {
+        if (lock_.owns_lock() && o_.multi_stream) PQ_HIP(hipEventRecord(o_.last, stream_));
+    }
+
+float draw_threshold(piquant_context_t* ctx) {
+    if (ctx->fixed_threshold >= 0.0f) return ctx->fixed_threshold;
+    return std::uniform_real_distribution<float>{0.0f, 1.0f}(ctx->rng);   // reference src/piquant.cpp:199-200
+}
+
+void fill_round_mode(piquant_context_t* ctx, QuantLaunch& q, piquant_round_mode_t mode) {
+    if (mode == PIQUANT_NEAREST) q.round_mode = RM_NEAREST_FAST;
+    else if (ctx->per_element) {
+        q.round_mode = RM_STOCH_ELEM;
+        q.seed = ctx->elem_seed;
+        q.index_base = ctx->elem_base;
+    } else {
+        q.round_mode = RM_STOCH_CALL;
+        q.threshold = draw_threshold(ctx);
+    }
+}
+
+}  // namespace pq
+
+using namespace pq;
+
+extern "C" {
+
+piquant_context_t* piquant_context_create(size_t num_threads) {
+    (void)num_threads;   // sized the reference's CPU pool (src/piquant.cpp:178-181); the GPU grid replaces it
+    int count = 0;
+    const hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        panic("piquant_context_create: no HIP device available (%s) -- this library has no CPU path",
+              e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    auto* ctx = new piquant_context_t;
+    PQ_HIP(hipGetDevice(&ctx->device));
+    PQ_HIP(hipDeviceGetAttribute(&ctx->num_cu, hipDeviceAttributeMultiprocessorCount, ctx->device));
+    PQ_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    PQ_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_state), static_cast<size_t>(minmax_state_ints()) * sizeof(int32_t)));
+    launch_arm_slots(ctx->d_state, nullptr);
+    PQ_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_dist_keys), 2 * sizeof(int32_t)));
+    PQ_HIP(hipMalloc(&ctx->d_fused, fused_state_bytes()));
+    init_fused_state(ctx->d_fused, nullptr);
+    PQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_keys), 2 * sizeof(int32_t), hipHostMallocDefault));
+    if (hipHostMalloc(reinterpret_cast<void**>(&ctx->mailbox), sizeof(MinmaxMailboxHost), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+        hipHostGetDevicePointer(&ctx->mailbox_dev, ctx->mailbox, 0) == hipSuccess) {
+        ctx->mailbox->keys[0] = ctx->mailbox->keys[1] = 0;
+        ctx->mailbox->seq = 0;
+    } else {
+        (void)hipGetLastError();
+        ctx->mailbox_dev = nullptr;   // no fine-grained host memory: compute_quant_params falls back to D2H + sync
+    }
+    if (hipHostMalloc(reinterpret_cast<void**>(&ctx->done), 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+        hipHostGetDevicePointer(&ctx->done_dev, ctx->done, 0) == hipSuccess) {
+        *ctx->done = 0;
+    } else {
+        (void)hipGetLastError();
+        ctx->done_dev = nullptr;
+    }
+    ctx->wait_mode = kDefaultBlockingWait;
+    if (const char* env = std::getenv("PIQUANT_HIP_BLOCKING_WAIT")) {
+        const std::string m(env);
+        ctx->wait_mode = m == "write32" ? WAIT_WRITE32 : (m == "kernel" ? WAIT_KERNEL : WAIT_SYNC);
+    }
+    PQ_HIP(hipDeviceSynchronize());   // the arming memsets ran on the null stream; scans may run on any stream
+    if (const char* env = std::getenv("PIQUANT_HIP_FUSION")) ctx->fusion = !(env[0] == '0' && env[1] == '\0');
+    if (const char* env = std::getenv("PIQUANT_HIP_BARRIER_TIMEOUT_US")) ctx->barrier_timeout_us = static_cast<uint32_t>(std::strtoul(env, nullptr, 10));
+    std::random_device rd;
+    ctx->rng.seed((static_cast<uint64_t>(rd()) << 32) ^ rd());
+    return ctx;
+}
+
+void piquant_context_destroy(piquant_context_t* ctx) {
+    if (!ctx) return;
+    {
+        DeviceGuard g(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        for (auto& s : ctx->stage_stream)
+            if (s) (void)hipStreamDestroy(s);
+        for (auto& p : ctx->stage_in)
+            if (p) (void)hipFree(p);
+        for (auto& p : ctx->stage_out)
+            if (p) (void)hipFree(p);
+        if (ctx->d_state) (void)hipFree(ctx->d_state);
+        if (ctx->d_fused) (void)hipFree(ctx->d_fused);
+        if (ctx->h_keys) (void)hipHostFree(ctx->h_keys);
+        if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
+        if (ctx->done) (void)hipHostFree(ctx->done);
+        if (ctx->d_dist_keys) (void)hipFree(ctx->d_dist_keys);
+        if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    }
+    delete ctx;
+}
+
+void piquant_hip_set_fusion(piquant_context_t* ctx, int enabled) {
+    if (!ctx) panic("piquant_hip_set_fusion: context is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->fusion = enabled != 0;
+}
+
+void piquant_hip_set_barrier_timeout_us(piquant_context_t* ctx, uint32_t microseconds) {
+    if (!ctx) panic("piquant_hip_set_barrier_timeout_us: context is NULL");
+    if (microseconds > 40000000u) panic("piquant_hip_set_barrier_timeout_us: %u us is beyond the 40 s the tick counter holds", microseconds);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->barrier_timeout_us = microseconds;
+}
+
+uint64_t piquant_hip_barrier_bailouts(piquant_context_t* ctx) {
+    if (!ctx) panic("piquant_hip_barrier_bailouts: context is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    return fused_state_bailouts(ctx->d_fused, ctx->stream);
+}
+
+void piquant_hip_set_stream(piquant_context_t* ctx, void* hip_stream) {
+    if (!ctx) panic("piquant_hip_set_stream: context is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->stream = static_cast<hipStream_t>(hip_stream);   // NULL == the legacy default stream, as everywhere in HIP
+}
+
+void piquant_hip_reset_stream(piquant_context_t* ctx) {
+    if (!ctx) panic("piquant_hip_reset_stream: context is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->stream = ctx->own_stream;
+}
+
+void piquant_hip_assume_device_pointers(piquant_context_t* ctx, int assume) {
+    if (!ctx) panic("piquant_hip_assume_device_pointers: context is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->assume_device = assume != 0;
+}
+
+void piquant_hip_set_blocking(piquant_context_t* ctx, int blocking) {
+    if (!ctx) panic("piquant_hip_set_blocking: context is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->blocking = blocking != 0;
+}
+
+void piquant_hip_set_blocking_wait(piquant_context_t* ctx, int mode) {
+    if (!ctx) panic("piquant_hip_set_blocking_wait: context is NULL");
+    if (mode < WAIT_SYNC || mode > WAIT_KERNEL) panic("piquant_hip_set_blocking_wait: invalid mode %d", mode);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->wait_mode = mode;
+}
+
+void piquant_hip_set_stochastic_threshold(piquant_context_t* ctx, float threshold) {
+    if (!ctx) panic("piquant_hip_set_stochastic_threshold: context is NULL");
+    if (threshold >= 1.0f || std::isnan(threshold)) panic("stochastic threshold must be < 1 (or negative to draw per call), got %g", static_cast<double>(threshold));
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->fixed_threshold = threshold;
+}
+
+void piquant_hip_set_stochastic_seed(piquant_context_t* ctx, uint64_t seed) {
+    if (!ctx) panic("piquant_hip_set_stochastic_seed: context is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->rng.seed(seed);
+}
+
+void piquant_hip_set_reference_layout(piquant_context_t* ctx, int enabled) {
+    if (!ctx) panic("piquant_hip_set_reference_layout: context is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->reference_layout = enabled != 0;
+}
+
+void piquant_hip_set_reference_threads(piquant_context_t* ctx, int threads) {
+    if (!ctx) panic("piquant_hip_set_reference_threads: context is NULL");
+    if (threads < 1 || threads > 65536) panic("piquant_hip_set_reference_threads: %d threads", threads);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->reference_threads = threads;
+}
+
+void piquant_hip_set_stochastic_per_element(piquant_context_t* ctx, int enabled, uint64_t seed, uint64_t index_base) {
+    if (!ctx) panic("piquant_hip_set_stochastic_per_element: context is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->per_element = enabled != 0;
+    ctx->elem_seed = seed;
+    ctx->elem_base = index_base;
+}
+
+int piquant_hip_device(const piquant_context_t* ctx) { return ctx ? ctx->device : -1; }
+
+const char* piquant_hip_version(void) { return "piquant-hip 0.1.0 gfx950"; }
+
+}  // extern "C"

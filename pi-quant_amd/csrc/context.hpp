@@ -1,0 +1,169 @@
+// Host side shared by the translation units behind the C ABI (context.cpp, capi.cpp, capi_dynamic.cpp): the context object, pointer
+// classification, the completion wait of blocking calls and the ordering of launches that carry a grid barrier.
+#pragma once
+
+#include "piquant.h"
+#include "piquant_hip.h"
+
+#include "device_math.hpp"
+#include "dequant_kernels.hpp"   // OP_* enum only (host side)
+#include "launch.hpp"
+
+#include <hip/hip_runtime_api.h>
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <limits>
+#include <mutex>
+#include <random>
+#include <string>
+#include <vector>
+
+namespace pq {
+
+struct dtype_row {
+    const char* name;
+    int bits;
+    bool quant;
+};
+const dtype_row& dtype_of(int dt);
+
+// Bytes holding `numel` elements: numel*stride for float/uint8, ceil(numel/(8/bits)) for packed types
+// (reference src/capi.cpp:41-42,69-70, src/piquant_internal.hpp:41-44).
+size_t span_bytes(size_t numel, int dt);
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        PQ_HIP(hipGetDevice(&prev));
+        if (prev != dev) PQ_HIP(hipSetDevice(dev));
+        else prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// Where a caller's buffer lives.
+struct Resolved {
+    bool pageable;     // plain host memory: must be staged through device scratch
+    void* dev;         // device-accessible address when !pageable
+};
+
+Resolved resolve(const void* p);
+
+}  // namespace pq
+
+struct piquant_context_t {
+    int device = 0;
+    int num_cu = 256;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;          // stream work is enqueued on (own_stream unless the caller set one)
+    hipStream_t stage_stream[2] = {nullptr, nullptr};
+    bool blocking = true;
+    bool assume_device = false;            // skip hipPointerGetAttributes (piquant_hip_assume_device_pointers)
+
+    // Min/max scan state (minmax_kernels.hpp): slot keys + arrival counters.  Every scan leaves it armed.
+    int32_t* d_state = nullptr;
+    int32_t* h_keys = nullptr;             // pinned int32[2]: D2H landing zone of the folded keys (fallback / sharded path)
+    pq::MinmaxMailboxHost* mailbox = nullptr;  // pinned fine-grained host memory the fold kernel publishes into
+    void* mailbox_dev = nullptr;           // its device-visible address
+    uint32_t mailbox_seq = 0;
+    int32_t* d_dist_keys = nullptr;        // {key(min), key(-max)} buffer the RCCL all-reduce of the *_dist call runs on
+    hipStream_t scan_stream = nullptr;     // stream of the previous scan (scans of one context must not overlap)
+    void* d_fused = nullptr;               // FusedState of the one-launch params + quantize kernel (fused_kernels.hpp)
+    bool fusion = true;                    // piquant_hip_set_fusion
+    uint32_t barrier_timeout_us = 0;       // piquant_hip_set_barrier_timeout_us (0 = the kernel's default, 1 ms)
+    int wait_mode = 0;                     // how a blocking call waits (WAIT_*, piquant_hip_set_blocking_wait)
+    uint32_t* done = nullptr;              // pinned, host-coherent completion word of blocking calls ...
+    void* done_dev = nullptr;              // ... and its device-visible address
+    uint32_t done_seq = 0;
+
+    // device scratch for host-pointer calls, grown on demand
+    void* stage_in[2] = {nullptr, nullptr};
+    void* stage_out[2] = {nullptr, nullptr};
+    size_t stage_in_cap = 0, stage_out_cap = 0;
+
+    std::mt19937_64 rng;
+    float fixed_threshold = -1.0f;
+    bool per_element = false;
+    bool reference_layout = false;
+    int reference_threads = 1;             // piquant_hip_set_reference_threads: pool threads of the reference context reproduced in reference-layout mode
+    uint64_t elem_seed = 0, elem_base = 0;
+    std::mutex mu;
+
+    pq::Resolved resolve_ptr(const void* p) const { return assume_device ? pq::Resolved{false, const_cast<void*>(p)} : pq::resolve(p); }
+
+    void ensure_stage(size_t in_bytes, size_t out_bytes) {
+        if (in_bytes > stage_in_cap) {
+            for (auto& p : stage_in) {
+                if (p) PQ_HIP(hipFree(p));
+                PQ_HIP(hipMalloc(&p, in_bytes));
+            }
+            stage_in_cap = in_bytes;
+        }
+        if (out_bytes > stage_out_cap) {
+            for (auto& p : stage_out) {
+                if (p) PQ_HIP(hipFree(p));
+                PQ_HIP(hipMalloc(&p, out_bytes));
+            }
+            stage_out_cap = out_bytes;
+        }
+        for (auto& s : stage_stream)
+            if (!s) PQ_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    }
+};
+
+namespace pq {
+
+// Host buffers are processed in chunks of this many elements: a multiple of every tile size and pack
+// factor, so chunk boundaries never split a packed byte or a 16-byte vector.
+constexpr size_t kStageChunkElems = size_t{1} << 24;
+
+// Completion wait of a blocking call (the reference's calls return after the pool has joined, src/piquant.cpp:203-210).
+//   WAIT_SYNC     hipStreamSynchronize: the runtime waits on the queue's completion signal (interrupt or its own polling).
+//   WAIT_WRITE32  hipStreamWriteValue32 behind the kernel: the command processor stores the call's sequence number into a pinned,
+//                 host-coherent word once everything earlier on the stream has completed; the host spins on that word.
+//   WAIT_KERNEL   the same word written by a one-thread kernel launched behind the work (system-scope store).
+// Measured A/B at numel 27 264 000 (fp32 -> uint8, 21.9 us kernel): profiles/r02_blocking_wait_ab.json.  (Polling hipStreamQuery or
+// busy-polling an event recorded after the kernel were measured in round 1: 36.7 / 34.9 vs 34.4 us for hipStreamSynchronize.)
+enum : int { WAIT_SYNC = 0, WAIT_WRITE32 = 1, WAIT_KERNEL = 2 };
+
+bool stream_is_capturing(hipStream_t s);
+void wait_stream(piquant_context_t* ctx);   // completion wait of a blocking call; caller holds ctx->mu
+
+struct FusedOrder;
+
+// Wait for the previous fused launch of the device, launch, record: ONE critical section (the per-device mutex is held from the
+// constructor to the destructor), so two threads with two contexts cannot slip a launch between each other's wait and record.
+// A capturing stream takes no part: a graph is replayed as a unit, and fused nodes that end up on parallel branches of one graph
+// are covered by the kernel's own bounded barrier wait.
+class FusedLaunchOrder {
+  public:
+    FusedLaunchOrder(int device, hipStream_t stream);
+    // call after a fused kernel was actually enqueued
+    void launched();
+
+  private:
+    FusedOrder& o_;
+    hipStream_t stream_;
+    std::unique_lock<std::mutex> lock_;
+};
+
+float draw_threshold(piquant_context_t* ctx);
+
+// round-mode fields of a launch: NEAREST, one threshold per call (src/piquant.cpp:197-201) or the per-element extension
+void fill_round_mode(piquant_context_t* ctx, QuantLaunch& q, piquant_round_mode_t mode);
+
+// Min/max scan of x with `action` as its epilogue (launch.hpp): one launch for device input; staged chunks plus a fold launch
+// for pageable host input; for an empty input the fold of the armed state (the identities, reference
+// kernels_specialized.inl:1422-1423).  Stream-ordered on ctx->stream except for host input, which completes before returning.
+// Caller holds ctx->mu and the device guard.
+void scan(piquant_context_t* ctx, const void* x, piquant_dtype_t dtype, size_t n, const MinmaxAction& action);
+
+}  // namespace pq

@@ -35,7 +35,7 @@
 //           performed before that block's last look at the barrier, hence before the barrier opens, hence before any
 //           survivor reads the bitmap: no share is missed.
 // Two barrier kernels launched at the same instant from different streams therefore only delay each other; the host layer still
-// orders them within a process (capi.cpp, FusedOrder) because the slow path is slow.
+// orders them within a process (context.cpp, FusedLaunchOrder) because the slow path is slow.
 //
 // Capacity: (R_REG + R_LDS) x 16 B x BLOCK threads x grid blocks (113 MB with the production 18 + 9 rounds of 1024 threads
 // on 256 CUs, tuning.hpp).  A somewhat larger tensor keeps that much on chip and streams the rest of every block's share

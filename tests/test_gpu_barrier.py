@@ -127,7 +127,7 @@ def test_reduce_variant_hands_over_too():
 
 def test_two_threads_two_contexts_launch_fused_kernels_at_once():
     """two threads, two contexts, two streams -- their barrier kernels must never end up interleaved between each
-    other's wait and record (capi.cpp FusedLaunchOrder holds the per-device lock across wait + launch + record)."""
+    other's wait and record (csrc/context.cpp FusedLaunchOrder holds the per-device lock across wait + launch + record)."""
     import piquant
 
     g = torch.Generator(device="cuda")
