@@ -480,13 +480,13 @@ fused_params_quantize_kernel(FusedGroups groups, QuantParams p_arg, FusedState* 
     const BoundedStep bstep = bounded_step_for<DT_IN, BITS>(p.zp32);
     // A block whose whole share lies inside the tensor (all but the last one or two) needs no per-vector bounds check.
     const bool full_share = (first_round + rounds_total) * BLOCK <= n_vec;
-    const bool short_step = (MODE == RM_NEAREST_FAST || MODE == RM_NEAREST_I64) && bounded_ok;   // grid-uniform: the data range decides
+    const bool short_step = bounded_ok;   // grid-uniform: the data range decides (every rounding mode has a short step)
     auto emit = [&](auto bounded_tag, auto full_tag) {
         constexpr bool BOUNDED = decltype(bounded_tag)::value, FULL = decltype(full_tag)::value;
         auto one = [&](const u32x4& raw, int64_t v) {
             if (FULL || v < n_vec) {
                 uint32_t w[WORDS];
-                if constexpr (BOUNDED) quantize_vec_bounded<DT_IN, BITS, MODE == RM_NEAREST_I64>(raw, p.inv_scale, bstep, w);
+                if constexpr (BOUNDED) quantize_vec_short<DT_IN, BITS, MODE>(raw, p, keys, static_cast<uint64_t>(v) * EPV, bstep, w);
                 else quantize_vec<DT_IN, BITS, MODE>(raw, p, keys, static_cast<uint64_t>(v) * EPV, w);
                 store_packed<OB, ST_POLICY>(out + v * OB, w);
             }
@@ -514,7 +514,7 @@ fused_params_quantize_kernel(FusedGroups groups, QuantParams p_arg, FusedState* 
                 const int64_t v = v_first + (k0 + j) * round_vecs;
                 if (k0 + j < rounds_total && v < n_vec) {
                     uint32_t w[WORDS];
-                    if constexpr (BOUNDED) quantize_vec_bounded<DT_IN, BITS, MODE == RM_NEAREST_I64>(t[j], p.inv_scale, bstep, w);
+                    if constexpr (BOUNDED) quantize_vec_short<DT_IN, BITS, MODE>(t[j], p, keys, static_cast<uint64_t>(v) * EPV, bstep, w);
                     else quantize_vec<DT_IN, BITS, MODE>(t[j], p, keys, static_cast<uint64_t>(v) * EPV, w);
                     store_packed<OB, ST_POLICY>(out + v * OB, w);
                 }
@@ -572,7 +572,7 @@ fused_params_quantize_kernel(FusedGroups groups, QuantParams p_arg, FusedState* 
                 u32x4 t = ld<true>(in16 + v);
                 if constexpr (RED_BITS != 0) add_reduce_terms<DT_IN, RED_BITS>(t, v, red);
                 uint32_t w[WORDS];
-                if (short_step) quantize_vec_bounded<DT_IN, BITS, MODE == RM_NEAREST_I64>(t, p.inv_scale, bstep, w);
+                if (short_step) quantize_vec_short<DT_IN, BITS, MODE>(t, p, okeys, static_cast<uint64_t>(v) * EPV, bstep, w);
                 else quantize_vec<DT_IN, BITS, MODE>(t, p, okeys, static_cast<uint64_t>(v) * EPV, w);
                 store_packed<OB, ST_POLICY>(out + v * OB, w);
             }

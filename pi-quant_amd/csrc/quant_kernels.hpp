@@ -212,6 +212,73 @@ __device__ __forceinline__ void quantize_vec_bounded(const u32x4& raw, float inv
     }
 }
 
+// The stochastic step (quantize.inl:8-19) under the same range condition: r = x * inv, tr = trunc(r), adj = +-1 towards the sign of r
+// when the call's (or the element's) threshold is below |r - tr|, and tr + adj -- an integer-valued float below 2^31 -- then takes
+// the float-domain clamp of the nearest step instead of the reference's int64 add and clamp: the same integers, for the same reason
+// (trunc and the clamp commute on integers; beyond 2^24 the sum with the zero point may round but is far outside [0, QMAX]; a NaN
+// gives adj = 0, tr = NaN and ends at the lower bound, 0, where the reference's INT64_MIN + zp is clamped to).  copysign(1, r) stands
+// for "if r < 0, adj = -adj": the two differ only for r = -0.0, where |r - tr| = 0 is never above a threshold and adj is 0 anyway.
+// About 7 instructions per element instead of the 64-bit path's ~20 -- what makes the bf16 inputs (eight elements per 16 bytes)
+// stream at the nearest step's rate.
+template <int DT_IN, int BITS, int MODE>
+__device__ __forceinline__ void quantize_vec_bounded_stochastic(const u32x4& raw, const QuantParams& p, const ElementKeys& keys, uint64_t e0,
+                                                                const BoundedStep& b, uint32_t (&w)[(InVec<DT_IN>::EPV * BITS / 8) > 4 ? 2 : 1]) {
+#pragma clang fp contract(off)
+    static_assert(MODE == RM_STOCH_CALL || MODE == RM_STOCH_ELEM, "stochastic modes only");
+    constexpr int EPV = InVec<DT_IN>::EPV, WORDS = (EPV * BITS / 8) > 4 ? 2 : 1, EPW = EPV / WORDS;
+    float v[EPV];
+    InVec<DT_IN>::unpack(raw, v);
+    float s[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; e += 2) {
+        const f32x2 x = {v[e], v[e + 1]};
+        const f32x2 r = x * p.inv_scale;
+        const f32x2 tr = {__builtin_truncf(r[0]), __builtin_truncf(r[1])};
+        const f32x2 d = r - tr;
+        float t0 = p.threshold, t1 = p.threshold;
+        if constexpr (MODE == RM_STOCH_ELEM) {
+            t0 = element_threshold(keys, p.index_base + e0 + e);
+            t1 = element_threshold(keys, p.index_base + e0 + e + 1);
+        }
+        const f32x2 adj = {t0 < __builtin_fabsf(d[0]) ? __builtin_copysignf(1.0f, r[0]) : 0.0f,
+                           t1 < __builtin_fabsf(d[1]) ? __builtin_copysignf(1.0f, r[1]) : 0.0f};
+        const f32x2 sum = tr + adj;
+        s[e] = sum[0];
+        s[e + 1] = sum[1];
+    }
+    if constexpr (BITS == 8) {
+        const float zp_f = -b.lo;
+#pragma unroll
+        for (int j = 0; j < WORDS; ++j) {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                const f32x2 pair = {s[j * 4 + e], s[j * 4 + e + 1]};
+                const f32x2 tz = pair + zp_f;
+                acc = __builtin_amdgcn_cvt_pk_u8_f32(tz[0], static_cast<uint32_t>(e), acc);
+                acc = __builtin_amdgcn_cvt_pk_u8_f32(tz[1], static_cast<uint32_t>(e + 1), acc);
+            }
+            w[j] = acc;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < WORDS; ++j) {
+            uint32_t acc = static_cast<uint32_t>(quant_nearest_bounded_offset(s[j * EPW + EPW - 1], b));
+#pragma unroll
+            for (int e = EPW - 2; e >= 0; --e) acc = (acc << BITS) + static_cast<uint32_t>(quant_nearest_bounded_offset(s[j * EPW + e], b));
+            w[j] = acc + b.zp_word;
+        }
+    }
+}
+
+// The short step of whatever rounding mode the kernel was built for.
+template <int DT_IN, int BITS, int MODE>
+__device__ __forceinline__ void quantize_vec_short(const u32x4& raw, const QuantParams& p, const ElementKeys& keys, uint64_t e0, const BoundedStep& b,
+                                                   uint32_t (&w)[(InVec<DT_IN>::EPV * BITS / 8) > 4 ? 2 : 1]) {
+    if constexpr (MODE == RM_NEAREST_FAST || MODE == RM_NEAREST_I64) quantize_vec_bounded<DT_IN, BITS, MODE == RM_NEAREST_I64>(raw, p.inv_scale, b, w);
+    else quantize_vec_bounded_stochastic<DT_IN, BITS, MODE>(raw, p, keys, e0, b, w);
+}
+
 // BoundedStep of a zero point that lies inside the quantized range (0 <= zp <= 2^BITS - 1): the clamp bounds as floats and the
 // zero point replicated into every field of a packed word.
 template <int DT_IN, int BITS>
@@ -271,7 +338,7 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const u32x4* __restrict__ in16 = static_cast<const u32x4*>(in);
-    constexpr bool SHORT_CAPABLE = MODE == RM_NEAREST_FAST || MODE == RM_NEAREST_I64;
+    constexpr bool SHORT_CAPABLE = true;   // every rounding mode has a short step (quantize_vec_short)
     [[maybe_unused]] const bool short_ok = SHORT_CAPABLE && p.zp64 >= 0 && p.zp64 <= (1 << BITS) - 1;   // kernel-uniform
     [[maybe_unused]] const BoundedStep bstep = bounded_step_for<DT_IN, BITS>(p.zp32);
     [[maybe_unused]] const float abs_inv = __builtin_fabsf(p.inv_scale);
@@ -286,7 +353,7 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
 
         [[maybe_unused]] ElementKeys keys {};
         if constexpr (MODE == RM_STOCH_ELEM) keys = element_keys_for(p, p.index_base + static_cast<uint64_t>(v0 + lane) * EPV);
-        // The short nearest step (quantize_vec_bounded: about half the instructions per element) is exact whenever the zero point lies
+        // The short step (quantize_vec_short: about half the instructions per element for nearest, a third for stochastic) is exact whenever the zero point lies
         // inside the quantized range and no element of the wave's tile reaches the range where x86's cvttps2dq turns indefinite --
         // decided per wave tile from max|x| * |1/scale| (one v_max3 per two elements and one compare per lane).  Ordinary data always
         // takes it; a tile with an infinity or a huge value takes the long step, with the same bytes either way.
@@ -340,7 +407,7 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
         if (short_step) {
             uint32_t w[U][WORDS];
 #pragma unroll
-            for (int k = 0; k < U; ++k) quantize_vec_bounded<DT_IN, BITS, MODE == RM_NEAREST_I64>(raw[k], p.inv_scale, bstep, w[k]);
+            for (int k = 0; k < U; ++k) quantize_vec_short<DT_IN, BITS, MODE>(raw[k], p, keys, static_cast<uint64_t>(v0 + k * 64 + lane) * EPV, bstep, w[k]);
             put(w);
         } else {
             uint32_t w[U][WORDS];

@@ -39,9 +39,12 @@ constexpr KernelTune kDequantTune[2][3] = {
     {{2, true, kStream, 128, 0}, {4, true, kStream, 256, 0}, {4, true, kStream, 256, 0}},
     {{2, true, kStream, 64, 0}, {4, true, kStreamNT, 256, 0}, {4, true, kStreamNT, 256, 0}},
 };
+// ADD, cold sweep of the pairs above plus profiles/r02_tune_dequant_add.csv for the rest: small tiles everywhere (the accumulator is a second
+// input stream); uint2 -> bf16 19.6 us with 64-thread tiles and non-temporal stores against 23.3 with the 128-thread write-through tiles it had,
+// uint2 -> fp32 35.7 vs 38.3, uint4 -> fp32 36.8 vs 37.8, uint8 -> bf16 22.7 vs 23.2.
 constexpr KernelTune kDequantAddTune[2][3] = {
-    {{2, true, kStream, 128, 0}, {4, true, kStream, 256, 0}, {4, true, kStream, 256, 0}},
-    {{2, true, kStream, 64, 0}, {2, true, kStreamNT, 64, 0}, {2, true, kStream, 128, 0}},
+    {{2, true, kStream, 128, 0}, {2, true, kStream, 128, 0}, {2, true, kStreamNT, 128, 0}},
+    {{2, true, kStreamNT, 64, 0}, {2, true, kStreamNT, 64, 0}, {2, true, kStreamNT, 64, 0}},
 };
 
 // fused quantize->dequantize: plain 16-byte streams both ways, no LDS staging

@@ -165,6 +165,49 @@ def test_fuzz_all_pairs_over_the_whole_float_range(ctx, O):
     ctx.set_stochastic_threshold(None)
 
 
+def test_stochastic_short_step_edges(ctx, O):
+    """The stochastic step has a float-domain short form (quant_kernels.hpp quantize_vec_bounded_stochastic) taken per wave tile when the
+    zero point lies inside the quantized range and max|x| * |1/scale| < 1e9.  Its corners against the oracle's int64 form: fractional
+    parts equal to the threshold (not above: no step), threshold 0 (every fraction steps away from zero), -0.0, integers at and above
+    2^24 (no fraction left), products just below and just above 1e9 (the second sends its whole tile through the long step), NaN and
+    infinities in otherwise ordinary tiles, zero points at both ends of the range and just outside it."""
+    rng = np.random.default_rng(4242)
+    n = 64 * 1024 + 37
+    base = rng.uniform(-300, 300, n).astype(np.float32)
+    frac = np.float32(0.375)
+    base[::7] = np.trunc(base[::7]) + np.copysign(frac, base[::7])          # |r - trunc r| == 0.375 exactly at scale 1
+    base[1::97] = np.float32(-0.0)
+    base[2::101] = np.float32(16777216.0)
+    base[3::103] = np.float32(-16777217.0)
+    base[4::107] = np.float32(0.99999994)
+    base[5::109] = np.float32(-0.99999994)
+    cases = {"ordinary": base.copy()}
+    for name, val in (("below_1e9", 9.9999994e8), ("above_1e9", 1.0000001e9), ("nan", np.nan), ("inf", np.inf), ("ninf", -np.inf), ("huge", 3.0e38)):
+        y = base.copy()
+        y[rng.choice(n, 9)] = np.float32(val)
+        cases[name] = y
+    for name, x in cases.items():
+        xb = O.f32_to_bf16(x)
+        for dt_in, xin in ((0, x), (1, xb)):
+            for dt_out, qmax in ((4, 255), (3, 15), (2, 3)):
+                for zp in (0, qmax // 2, qmax, -1, qmax + 1):
+                    for scale in (1.0, 0.5, 3.0):
+                        for tau in (0.0, 0.375, 0.37499997, 0.99999994):
+                            ctx.set_stochastic_threshold(tau)
+                            got = gpu_quantize(ctx, xin, dt_in, dt_out, scale, zp, 1)
+                            want = O.quantize(xin, dt_in, dt_out, scale, zp, 1, tau)
+                            assert np.array_equal(got, want), (name, dt_in, dt_out, zp, scale, tau, np.nonzero(got != want)[0][:4])
+    ctx.set_stochastic_threshold(None)
+    # the per-element thresholds take the same short step
+    import piquant
+    x = cases["ordinary"]
+    for dt_out in (4, 3, 2):
+        ctx.set_stochastic_per_element(True, seed=0xfeed, index_base=(1 << 32) - 5000)
+        got = gpu_quantize(ctx, x, 0, dt_out, 0.5, 1, 1)
+        ctx.set_stochastic_per_element(False)
+        assert np.array_equal(got, O.quantize_per_element(x, O.F32, dt_out, 0.5, 1, 0xfeed, (1 << 32) - 5000))
+
+
 def test_extreme_zero_points_wrap_like_the_reference(ctx, O):
     """int64 zero points are narrowed to int32 on the fast paths and kept on the generic ones (quantize.inl:111 vs :15)."""
     rng = np.random.default_rng(5)

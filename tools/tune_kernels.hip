@@ -772,6 +772,30 @@ int main(int argc, char** argv) {
         g_caps = {0, 2, 4, 8, 16};
         g_rounds = 3;
     }
+    if (only == "dqa") {
+        // the ADD side of the dequantize pairs that the dqp sweep left out, cold rotation, numel = 27264000
+        g_rounds = 1;
+        g_caps = {0};
+        for (int pass = 0; pass < 4; ++pass) {
+#define DQA(BITS, DT, BPE)                                                \
+    run_dequant<BITS, DT, OP_ADD, 4, true, 5, 256>(b, numel, num_cu, BPE); \
+    run_dequant<BITS, DT, OP_ADD, 4, true, 3, 256>(b, numel, num_cu, BPE); \
+    run_dequant<BITS, DT, OP_ADD, 2, true, 5, 256>(b, numel, num_cu, BPE); \
+    run_dequant<BITS, DT, OP_ADD, 2, true, 5, 128>(b, numel, num_cu, BPE); \
+    run_dequant<BITS, DT, OP_ADD, 2, true, 3, 128>(b, numel, num_cu, BPE); \
+    run_dequant<BITS, DT, OP_ADD, 2, true, 5, 64>(b, numel, num_cu, BPE);  \
+    run_dequant<BITS, DT, OP_ADD, 2, true, 3, 64>(b, numel, num_cu, BPE);  \
+    run_dequant<BITS, DT, OP_ADD, 4, true, 5, 128>(b, numel, num_cu, BPE); \
+    run_dequant<BITS, DT, OP_ADD, 4, true, 3, 128>(b, numel, num_cu, BPE);
+            DQA(2, DT_BF16, 4.25)
+            DQA(2, DT_F32, 8.25)
+            DQA(8, DT_BF16, 5)
+            DQA(4, DT_F32, 8.5)
+#undef DQA
+        }
+        g_caps = {0, 2, 4, 8, 16};
+        g_rounds = 3;
+    }
     if (only == "qp") {
         // quantize family under cold rotation: store policy (5 = write-through, 3 = non-temporal, 1 = plain) at the production tiles; numel = 27264000
         g_rounds = 1;
