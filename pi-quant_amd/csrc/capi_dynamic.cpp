@@ -155,7 +155,6 @@ static void quantize_dynamic_one(piquant_context_t* ctx, QuantLaunch q, const vo
         FusedLaunchOrder order(ctx->device, ctx->stream);
         q.barrier_timeout_us = ctx->barrier_timeout_us;
         fused = launch_fused_params_quantize(q, ctx->d_fused, params_dev, ctx->stream, ctx->num_cu);
-        if (fused) order.launched();
     }
     if (!fused) {
         scan(ctx, in_dev, static_cast<piquant_dtype_t>(q.dt_in), numel, params_action);
@@ -252,7 +251,6 @@ void piquant_hip_quantize_dynamic_batch(piquant_context_t* ctx, const void* cons
             FusedLaunchOrder order(ctx->device, ctx->stream);
             q.barrier_timeout_us = ctx->barrier_timeout_us;
             fused = launch_fused_params_quantize_batch(q, b, ctx->d_fused, ctx->stream, ctx->num_cu);
-            if (fused) order.launched();
         }
         for (size_t k = i; k < j; ++k) {
             if (fused && items[k].numel != 0) continue;
@@ -302,7 +300,6 @@ void piquant_hip_reduce_quantize_dynamic(piquant_context_t* ctx, void* acc, piqu
                 FusedLaunchOrder order(ctx->device, ctx->stream);
                 q.barrier_timeout_us = ctx->barrier_timeout_us;
                 fused = launch_fused_reduce_quantize(q, terms, ctx->d_fused, rp.dev, ctx->stream, ctx->num_cu);
-                if (fused) order.launched();
             }
             if (fused && ctx->blocking) wait_stream(ctx);
         }

@@ -139,19 +139,17 @@ void wait_stream(piquant_context_t* ctx);   // completion wait of a blocking cal
 
 struct FusedOrder;
 
-// Wait for the previous fused launch of the device, launch, record: ONE critical section (the per-device mutex is held from the
-// constructor to the destructor), so two threads with two contexts cannot slip a launch between each other's wait and record.
+// Order behind the previous fused launch of the device (when it went to another stream), then launch: ONE critical section (the
+// per-device mutex is held from the constructor to the destructor), so two threads with two contexts cannot slip a launch between
+// each other's hand-over and launch.
 // A capturing stream takes no part: a graph is replayed as a unit, and fused nodes that end up on parallel branches of one graph
 // are covered by the kernel's own bounded barrier wait.
 class FusedLaunchOrder {
   public:
     FusedLaunchOrder(int device, hipStream_t stream);
-    // call after a fused kernel was actually enqueued
-    void launched();
 
   private:
     FusedOrder& o_;
-    hipStream_t stream_;
     std::unique_lock<std::mutex> lock_;
 };
 
