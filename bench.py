@@ -444,6 +444,12 @@ def main():
             extras["rotation_of_6_sets_818MB_round1_protocol"] = {"GiB/s": round(gib_per_step * 600 / w, 1), "avg_launch_us": round(e / 600 * 1e6, 3),
                                                                "GB/s": gbs_plain(5, e, 600),
                                                                "note": "what round 1 reported as the headline: three times the Infinity Cache's size in rotation is not enough to keep it out"}
+            # cold inputs, ONE output buffer: what a caller that quantizes tensor after tensor into the same staging buffer sees (the 27 MB of
+            # output stay in the Infinity Cache; every input byte still comes from HBM).  NOT the headline, which writes to cold buffers too.
+            reuse_args = [(ctx._ctx, ptr_in[k], DataType.F32.value, ptr_out[0], DataType.UINT8.value, n, scale, zp, RoundMode.NEAREST.value) for k in range(nsets)]
+            w, e = time_loop(lambda i: c_quantize(*reuse_args[i % nsets]), 600, stream)
+            extras["cold_inputs_one_output_buffer"] = {"GiB/s": round(gib_per_step * 600 / w, 1), "avg_launch_us": round(e / 600 * 1e6, 3), "GB/s": gbs_plain(5, e, 600),
+                                                       "note": f"inputs rotate over the {nsets} cold sets, every launch writes the same 27 MB output buffer"}
             # reference semantics: every call waits for completion (blocking context); A/B of the three ways to wait (csrc/context.cpp wait_stream)
             ctx.set_blocking(True)
             ctx.assume_device_pointers(True)      # step() makes the raw C call: the context must know these are device pointers
