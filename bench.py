@@ -278,6 +278,11 @@ def main():
         c_quantize(*call_args[i % nsets])
 
     PREWARM = 2000
+    if use_dist:
+        # The first collective of a process group sets the communicator up (hundreds of milliseconds with RCCL).  Done here, the barrier next
+        # to the timed region is a ~30 us affair; done there, the GPU would sit idle long enough to drop its clocks and the K timed steps
+        # (0.45 ms at K = 20) would run on the ramp: measured with a one-rank RCCL group, 23.6 us per launch instead of 22.1.
+        dist.barrier()
     with torch.cuda.stream(stream):
         for i in range(PREWARM):         # untimed pre-warm (~45 ms at N=1) so short K/W runs are not measured on ramping clocks;
             step(i)                      # reported as config.prewarm_launches
