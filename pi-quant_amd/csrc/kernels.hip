@@ -42,7 +42,7 @@ void quantize_t(const QuantLaunch& q, const QuantParams& p, hipStream_t stream, 
     }
     const int64_t n_tiles = q.numel / Tile::BLOCK_ELEMS;
     const unsigned grid = capped_grid(n_tiles, t.blocks_per_cu, num_cu);
-    hipLaunchKernelGGL((quantize_kernel<DT_IN, BITS, MODE, t.u, t.stage, t.nt, t.block>), dim3(grid), dim3(t.block), 0, stream,
+    hipLaunchKernelGGL((quantize_kernel<DT_IN, BITS, MODE, t.u, t.stage, t.nt, t.block, kQuantShortStep>), dim3(grid), dim3(t.block), 0, stream,
                        q.in, out, q.numel, n_tiles, p);
 }
 

@@ -323,7 +323,7 @@ struct QuantTile {
     static constexpr int64_t BLOCK_ELEMS = static_cast<int64_t>(WAVES) * WAVE_VECS * EPV;
 };
 
-template <int DT_IN, int BITS, int MODE, int U, bool STAGE, int NT, int BLOCK>
+template <int DT_IN, int BITS, int MODE, int U, bool STAGE, int NT, int BLOCK, bool ALLOW_SHORT = true>
 __global__ void __launch_bounds__(BLOCK)
 quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t numel, int64_t n_tiles, QuantParams p_arg) {
     const QuantParams p = resolved(p_arg);
@@ -338,7 +338,7 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const u32x4* __restrict__ in16 = static_cast<const u32x4*>(in);
-    constexpr bool SHORT_CAPABLE = true;   // every rounding mode has a short step (quantize_vec_short)
+    constexpr bool SHORT_CAPABLE = ALLOW_SHORT;   // every rounding mode has a short step (quantize_vec_short); the launcher decides who uses it
     [[maybe_unused]] const bool short_ok = SHORT_CAPABLE && p.zp64 >= 0 && p.zp64 <= (1 << BITS) - 1;   // kernel-uniform
     [[maybe_unused]] const BoundedStep bstep = bounded_step_for<DT_IN, BITS>(p.zp32);
     [[maybe_unused]] const float abs_inv = __builtin_fabsf(p.inv_scale);

@@ -26,6 +26,14 @@ constexpr KernelTune kQuantTune[2][3] = {
     {{2, true, kStream, 64, 0}, {2, true, kStream, 64, 0}, {4, true, kStream, 256, 0}},
 };
 
+// The per-tile short step of the streaming quantize kernels (quant_kernels.hpp, quantize_vec_short): on.  It halves the arithmetic; its range
+// test (max|x| over the tile, a wave-wide vote, a branch) makes a wave wait for all its loads before it computes, which costs the fp32 inputs
+// nothing measurable and is repaid on the bf16 inputs (twice the elements per byte).  A/B through the library, all 12 quantize operators at
+// numel 27 264 000, hipGraph replay over 24 cold sets (tools/dtype_matrix.py): on / off = bf16->uint8 15.0 / 15.5 us, bf16->uint4 13.1 / 13.5,
+// bf16->uint2 12.5 / 13.3, fp32->uint8 23.1 / 23.2, fp32->uint4 20.6 / 20.6, fp32->uint2 19.5 / 19.5.  (The tune harness' own A/B, mode `shortab`,
+// disagrees by +-0.4 us from run to run at this size -- it launches from the host over fewer sets -- and is not what this was decided on.)
+constexpr bool kQuantShortStep = true;
+
 // dequantize, indexed [dt_out: f32,bf16][bits: 8,4,2]; SET and ADD separately -- ADD also streams the accumulator in, which moves the
 // optimum to small tiles.  bf16 entries re-measured after fp32 -> bf16 became one v_cvt_pk_bf16_f32 (profiles/r01_tune_finals_other_hw_bf16_cvt.csv,
 // profiles/r02_tune_half_size.csv): uint4 -> bf16 SET at numel 27 264 000 (BASELINE config 3) 11.6 us with 256-thread / U=4 tiles against

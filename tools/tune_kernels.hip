@@ -32,11 +32,12 @@ using namespace pq;
         }                                                                                      \
     } while (0)
 
-constexpr int SETS = 12;   // rotation slots: 12 x 136 MB at the headline size, 12 x 68 MB for the half-size (bf16) runs -- at least three times the 256 MiB Infinity Cache
+// rotation slots: 12 x 136 MB at the headline size; more for smaller tensors, so that at least 1.6 GB (and 330 MB of OUTPUT alone: more than the
+// 256 MiB Infinity Cache, which would otherwise absorb the stores) are in rotation at every size -- set in main()
+static int SETS = 12;
 
 struct Bufs {
-    void* in[SETS];
-    void* out[SETS];
+    std::vector<void*> in, out;
 };
 
 __global__ void fill_uniform(float* p, int64_t n, uint32_t seed) {
@@ -134,7 +135,9 @@ __global__ void __launch_bounds__(BLOCK) quant_policy_kernel(const u32x4* __rest
         u32x4 raw[U];
 #pragma unroll
         for (int k = 0; k < U; ++k) raw[k] = asm_load<LDP>(in16 + v0 + k * 64 + lane);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the loaded registers are operands of the wait: without that the compiler, which does not track asm loads, hoists the arithmetic
+        // above it and the kernel computes on registers the loads have not written yet (round 1's version did: its rows are void)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3])::"memory");
         uint32_t* s = lds + wave * U * 64;
 #pragma unroll
         for (int k = 0; k < U; ++k) {
@@ -202,7 +205,7 @@ static QuantParams qparams() {
     return p;
 }
 
-template <int DT_IN, int BITS, int MODE, int U, bool STAGE, int NT, int BLOCK>
+template <int DT_IN, int BITS, int MODE, int U, bool STAGE, int NT, int BLOCK, bool ALLOW_SHORT = true>
 static void run_quant(const Bufs& b, int64_t numel, int num_cu, double bytes_per_elem) {
     using T = QuantTile<DT_IN, BITS, U, BLOCK>;
     const int64_t n_tiles = numel / T::BLOCK_ELEMS;
@@ -211,12 +214,12 @@ static void run_quant(const Bufs& b, int64_t numel, int num_cu, double bytes_per
         int64_t g = cap == 0 ? n_tiles : std::min<int64_t>(n_tiles, static_cast<int64_t>(cap) * num_cu);
         const unsigned grid = static_cast<unsigned>(std::max<int64_t>(g, 1));
         const double us = time_us([&](int i) {
-            hipLaunchKernelGGL((quantize_kernel<DT_IN, BITS, MODE, U, STAGE, NT, BLOCK>), dim3(grid), dim3(BLOCK), g_dyn_lds, g_stream, b.in[i % SETS],
+            hipLaunchKernelGGL((quantize_kernel<DT_IN, BITS, MODE, U, STAGE, NT, BLOCK, ALLOW_SHORT>), dim3(grid), dim3(BLOCK), g_dyn_lds, g_stream, b.in[i % SETS],
                                static_cast<uint8_t*>(b.out[i % SETS]), numel, n_tiles, p);
         });
         char name[160];
-        std::snprintf(name, sizeof name, "in=%s bits=%d mode=%d U=%d stage=%d nt=%d block=%d lds=%u cap=%d grid=%u", DT_IN == DT_F32 ? "f32" : "bf16", BITS, MODE, U,
-                      STAGE ? 1 : 0, NT, BLOCK, g_dyn_lds, cap, grid);
+        std::snprintf(name, sizeof name, "in=%s bits=%d mode=%d U=%d stage=%d nt=%d block=%d short=%d lds=%u cap=%d grid=%u", DT_IN == DT_F32 ? "f32" : "bf16", BITS, MODE, U,
+                      STAGE ? 1 : 0, NT, BLOCK, ALLOW_SHORT ? 1 : 0, g_dyn_lds, cap, grid);
         report("quantize", name, us, bytes_per_elem * numel);
     }
 }
@@ -417,7 +420,11 @@ int main(int argc, char** argv) {
     CK(hipGetDeviceProperties(&prop, dev));
     std::fprintf(stderr, "device %s, %d CUs, numel %lld, reps %d\n", prop.name, num_cu, static_cast<long long>(numel), g_reps);
 
+    SETS = static_cast<int>(std::min<int64_t>(1024, std::max<int64_t>(12, (1640000000ll + 5 * numel - 1) / (5 * numel))));
+    std::fprintf(stderr, "%d buffer sets in rotation (%.2f GB)\n", SETS, 5.0 * numel * SETS / 1e9);
     Bufs b {};
+    b.in.resize(SETS);
+    b.out.resize(SETS);
     for (int s = 0; s < SETS; ++s) {
         CK(hipMalloc(&b.in[s], numel * 4 + 4096));
         CK(hipMalloc(&b.out[s], numel + 4096));
@@ -515,7 +522,38 @@ int main(int argc, char** argv) {
                 hipLaunchKernelGGL((quant_policy_kernel<1, 3, 256>), dim3(static_cast<unsigned>(nt256)), dim3(256), 0, g_stream,
                                    static_cast<const u32x4*>(b.in[i % SETS]), static_cast<uint8_t*>(b.out[i % SETS]), nt256, p);
             });
-            report("policy", "asm ld=nt st=sc0sc1 U=4 block=256", us, 5.0 * numel);
+            report("policy", "asm ld=nt st=sc0sc1 U=4 block=256 (waits for its loads)", us, 5.0 * numel);
+        }
+        g_caps = {0, 2, 4, 8, 16};
+        g_rounds = 3;
+    }
+    if (only == "shortab") {
+        // the short step on/off, per dtype pair and tile, cold at whatever numel is given (fp32 inputs are not VALU-limited: does the
+        // per-tile range test cost more than the shorter step saves?)
+        g_rounds = 1;
+        g_caps = {0};
+        const int64_t nt256 = numel / (4 * 4 * 64 * 4);
+        const QuantParams p = qparams();
+        for (int pass = 0; pass < 6; ++pass) {
+#define AB(DT, BITS, MODE, U_, BLK, N, BPE)                                    \
+    run_quant<DT, BITS, MODE, U_, true, 5, BLK, true>(b, N, num_cu, BPE);      \
+    run_quant<DT, BITS, MODE, U_, true, 5, BLK, false>(b, N, num_cu, BPE);
+            AB(DT_F32, 8, RM_NEAREST_FAST, 2, 128, numel, 5)
+            AB(DT_F32, 8, RM_NEAREST_FAST, 4, 256, numel, 5)
+            AB(DT_F32, 8, RM_NEAREST_FAST, 2, 64, numel, 5)
+            AB(DT_F32, 8, RM_STOCH_CALL, 2, 128, numel, 5)
+            AB(DT_F32, 4, RM_NEAREST_FAST, 2, 64, numel, 4.5)
+            AB(DT_F32, 2, RM_NEAREST_I64, 2, 64, numel, 4.25)
+            AB(DT_BF16, 8, RM_NEAREST_FAST, 2, 64, numel, 3)
+            AB(DT_BF16, 4, RM_NEAREST_FAST, 2, 64, numel, 2.5)
+            AB(DT_BF16, 4, RM_STOCH_CALL, 2, 64, numel, 2.5)
+            AB(DT_BF16, 2, RM_NEAREST_FAST, 4, 256, numel, 2.25)
+#undef AB
+            const double us = time_us([&](int i) {
+                hipLaunchKernelGGL((quant_policy_kernel<1, 3, 256>), dim3(static_cast<unsigned>(nt256)), dim3(256), 0, g_stream,
+                                   static_cast<const u32x4*>(b.in[i % SETS]), static_cast<uint8_t*>(b.out[i % SETS]), nt256, p);
+            });
+            report("policy", "asm ld=nt st=sc0sc1 U=4 block=256 (waits for its loads)", us, 5.0 * numel);
         }
         g_caps = {0, 2, 4, 8, 16};
         g_rounds = 3;
