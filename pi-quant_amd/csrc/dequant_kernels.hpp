@@ -99,6 +99,11 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
     const int wave = threadIdx.x >> 6;
     u32x4* out16 = static_cast<u32x4*>(out);
 
+    // ragged tail: by the first block, before its tiles (quant_kernels.hpp explains why not by the last one, after)
+    if (n_tiles * T::BLOCK_ELEMS < numel && blockIdx.x == 0) {
+        for (int64_t i = n_tiles * T::BLOCK_ELEMS + threadIdx.x; i < numel; i += BLOCK) dequant_store_scalar<BITS, DT_OUT, OP>(in, out, i, p);
+    }
+
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t v0 = (tile * T::WAVES + wave) * T::WAVE_VECS;     // first output vector of this wave tile
         const uint8_t* src = in + v0 * IB;
@@ -184,10 +189,6 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
         }
     }
 
-    const int64_t done = n_tiles * T::BLOCK_ELEMS;
-    if (done < numel && blockIdx.x == gridDim.x - 1) {
-        for (int64_t i = done + threadIdx.x; i < numel; i += BLOCK) dequant_store_scalar<BITS, DT_OUT, OP>(in, out, i, p);
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

@@ -13,7 +13,7 @@
 // Without STAGE each lane stores its OB bytes directly (still contiguous across the wave).
 //
 // The kernel is a grid-stride loop over block tiles (WAVES wave tiles); the ragged tail (numel not a
-// multiple of the block tile) is finished by the last block with a guarded per-byte path inside the SAME
+// multiple of the block tile) is done by the first block with a guarded per-byte path inside the SAME
 // launch, so a call is always exactly one kernel (a second launch would cost ~1.5 us on a ~20 us kernel).
 #pragma once
 
@@ -343,6 +343,15 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
     [[maybe_unused]] const BoundedStep bstep = bounded_step_for<DT_IN, BITS>(p.zp32);
     [[maybe_unused]] const float abs_inv = __builtin_fabsf(p.inv_scale);
 
+    // Ragged tail (numel not a multiple of the block tile): the FIRST block does it, before its tiles.  The guarded path takes ~1 us for a
+    // few hundred elements; at the end of the last block -- where it used to be -- that microsecond was the end of the kernel (13 632 000
+    // elements with 1 024-element tiles: 13.2 us against 12.3 for a tile size that divides the tensor); block 0 starts first and has
+    // finished both long before the stream has.
+    if (n_tiles * T::BLOCK_ELEMS < numel && blockIdx.x == 0) {
+        constexpr int PACK = 8 / BITS;
+        quantize_bytes_guarded<DT_IN, BITS, MODE>(in, out, numel, n_tiles * T::BLOCK_ELEMS / PACK, (numel + PACK - 1) / PACK, p, threadIdx.x, BLOCK);
+    }
+
     const int64_t tile_stride = gridDim.x;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += tile_stride) {
         const int64_t v0 = (tile * T::WAVES + wave) * T::WAVE_VECS;   // first input vector of this wave tile
@@ -417,12 +426,6 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
         }
     }
 
-    // ragged tail, finished by the last block of the same launch
-    const int64_t done = n_tiles * T::BLOCK_ELEMS;
-    if (done < numel && blockIdx.x == gridDim.x - 1) {
-        constexpr int PACK = 8 / BITS;
-        quantize_bytes_guarded<DT_IN, BITS, MODE>(in, out, numel, done / PACK, (numel + PACK - 1) / PACK, p, threadIdx.x, BLOCK);
-    }
 }
 
 }  // namespace pq

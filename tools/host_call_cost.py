@@ -22,7 +22,7 @@ s = torch.cuda.Stream()
 ctx.set_stream(s.cuda_stream)
 ctx.set_blocking(False)
 for n in (4096, 3_408_000):
-    sets = 48
+    sets = 192   # 3.3 GB in rotation at 3 408 000 elements, as bench.py --gpus 8 has: inputs AND outputs come from / go to HBM
     xs = [torch.empty(n, device="cuda").uniform_(-1, 1) for _ in range(sets)]
     qs = [torch.empty(n, dtype=torch.uint8, device="cuda") for _ in range(sets)]
     pin, pout = [t.data_ptr() for t in xs], [t.data_ptr() for t in qs]
