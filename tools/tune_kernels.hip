@@ -862,6 +862,30 @@ int main(int argc, char** argv) {
         g_caps = {0, 2, 4, 8, 16};
         g_rounds = 3;
     }
+    if (only == "bfq") {
+        // bf16 -> uint4 / uint2 nearest, tile shapes x store policy, really cold: pass N1/2 as numel (the bf16 view holds 2 * numel elements;
+        // the rotation is sized for 5 B per fp32 element of `numel`, i.e. 2.5 B per bf16 element of the view: > 330 MB of outputs)
+        g_rounds = 1;
+        g_caps = {0};
+        for (int pass = 0; pass < 4; ++pass) {
+#define BFQ(BITS, BPE)                                                                    \
+    run_quant<DT_BF16, BITS, RM_NEAREST_FAST, 2, true, 5, 64>(b, 2 * numel, num_cu, BPE);   \
+    run_quant<DT_BF16, BITS, RM_NEAREST_FAST, 2, true, 3, 64>(b, 2 * numel, num_cu, BPE);   \
+    run_quant<DT_BF16, BITS, RM_NEAREST_FAST, 1, true, 5, 64>(b, 2 * numel, num_cu, BPE);   \
+    run_quant<DT_BF16, BITS, RM_NEAREST_FAST, 2, true, 5, 128>(b, 2 * numel, num_cu, BPE);  \
+    run_quant<DT_BF16, BITS, RM_NEAREST_FAST, 1, true, 5, 128>(b, 2 * numel, num_cu, BPE);  \
+    run_quant<DT_BF16, BITS, RM_NEAREST_FAST, 4, true, 5, 128>(b, 2 * numel, num_cu, BPE);  \
+    run_quant<DT_BF16, BITS, RM_NEAREST_FAST, 2, true, 5, 256>(b, 2 * numel, num_cu, BPE);  \
+    run_quant<DT_BF16, BITS, RM_NEAREST_FAST, 4, true, 5, 256>(b, 2 * numel, num_cu, BPE);  \
+    run_quant<DT_BF16, BITS, RM_NEAREST_FAST, 4, true, 3, 256>(b, 2 * numel, num_cu, BPE);  \
+    run_quant<DT_BF16, BITS, RM_NEAREST_FAST, 1, true, 5, 256>(b, 2 * numel, num_cu, BPE);
+            BFQ(4, 2.5)      // (uint8 output of the 2 * numel view would need 2 * numel bytes: the output buffers hold numel)
+            BFQ(2, 2.25)
+#undef BFQ
+        }
+        g_caps = {0, 2, 4, 8, 16};
+        g_rounds = 3;
+    }
     if (only == "q4") {
         // bf16 -> uint4 at numel (pass N1/2 as numel: the bf16 view holds 2 * numel elements): tile shapes and persistent grids
         g_rounds = 1;
