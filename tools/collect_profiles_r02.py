@@ -9,7 +9,7 @@ gpurun_out/ (scratch) into profiles/ (tracked), named r02_*.  Run after the sess
   host_call_cost.json             -> r02_host_call_cost.json
   rccl_trace/*kernel_stats.csv    -> r02_rccl_single_rank_kernel_stats.csv
   reference_style.json (+ png)    -> r02_reference_style_benchmarks.json, r02_quant_benchmark.png
-  parity_soak_r02.json            -> r02_parity_soak.json
+  parity_soak_r02.json            -> r02_parity_soak_latest.json
   bench_n2_shared.json            -> r02_bench_two_ranks_sharing_one_gpu.json
   tune_*.csv                      -> r02_tune_*.csv
 """
@@ -55,7 +55,8 @@ def main():
     done += copy_json("fixed_cost_fit.json", f"{R}_fixed_cost_fit.json")
     done += copy_json("host_call_cost.json", f"{R}_host_call_cost.json")
     done += copy_json("reference_style.json", f"{R}_reference_style_benchmarks.json")
-    done += copy_json("parity_soak_r02.json", f"{R}_parity_soak.json")
+    done += copy_json("dtype_matrix.json", f"{R}_dtype_matrix.json")
+    done += copy_json("parity_soak_r02.json", f"{R}_parity_soak_latest.json")   # the named runs (15 / 25 / 30 / 40 min) are copied by hand
     done += copy_json("bench_n2_shared.json", f"{R}_bench_two_ranks_sharing_one_gpu.json")
     if (OUT / "quant_benchmark.png").exists():
         shutil.copy(OUT / "quant_benchmark.png", PROF / f"{R}_quant_benchmark.png")

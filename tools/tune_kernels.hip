@@ -915,6 +915,37 @@ int main(int argc, char** argv) {
         run_minmax<DT_BF16, 8, true, 256>(b, 2 * numel, num_cu, keys);
     }
 
+    if (only == "pair") {
+        // The reference's own two-call sequence -- compute_quant_params(x), then quantize(x) -- on the same tensor, cold rotation otherwise:
+        // can the scan leave x in the 256 MiB Infinity Cache for the quantize pass (109 MB at the headline size)?  Load policy of the scan
+        // (nt / plain) x load policy of the quantize (nt / plain); us per PAIR.
+        ParamRecord* rec = nullptr;
+        CK(hipMalloc(reinterpret_cast<void**>(&rec), 64));
+        QuantParams pd {};
+        pd.dyn = rec;
+        using T = QuantTile<DT_F32, 8, 2, 128>;
+        const int64_t n_tiles = numel / T::BLOCK_ELEMS;
+        const unsigned qgrid = static_cast<unsigned>(std::max<int64_t>(n_tiles, 1));
+        g_rounds = 1;
+        for (int pass = 0; pass < 5; ++pass) {
+#define PAIR(SCAN_NT, Q_NT, LABEL)                                                                                                                         \
+    {                                                                                                                                                      \
+        const double us = time_us([&](int i) {                                                                                                             \
+            hipLaunchKernelGGL((minmax_kernel<DT_F32, 4, SCAN_NT, 512, true>), dim3(num_cu), dim3(512), 0, g_stream, static_cast<const void*>(b.in[i % SETS]),  \
+                               numel, keys, MinmaxEpilogue {EP_PARAMS, 8, 0u, rec});                                                                       \
+            hipLaunchKernelGGL((quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, 2, true, mem_policy(Q_NT, ST_WT), 128>), dim3(qgrid), dim3(128), 0, g_stream,    \
+                               static_cast<const void*>(b.in[i % SETS]), static_cast<uint8_t*>(b.out[i % SETS]), numel, n_tiles, pd);                        \
+        });                                                                                                                                                \
+        report("pair", LABEL, us, 9.0 * numel);                                                                                                            \
+    }
+            PAIR(true, true, "scan nt loads, quantize nt loads (production)")
+            PAIR(false, true, "scan plain loads, quantize nt loads")
+            PAIR(false, false, "scan plain loads, quantize plain loads")
+            PAIR(true, false, "scan nt loads, quantize plain loads")
+#undef PAIR
+        }
+        g_rounds = 3;
+    }
     if (only == "fused" || only == "fusedphases") {
         g_verbose_phases = only == "fusedphases";
         FusedBufs f {};
