@@ -38,6 +38,27 @@ def main():
     plain.set_fusion(False)
     t_end = time.time() + args.seconds
     it = elems = bad = 0
+    fail_dir = ROOT / "gpurun_out"
+
+    def check(ok, kind, **what):
+        """counts a failed comparison and leaves what is needed to replay it: one JSON line on stderr, the arrays in gpurun_out/soak_fail_<it>_<kind>.npz"""
+        nonlocal bad
+        if ok:
+            return
+        bad += 1
+        arrays = {k: v for k, v in what.items() if isinstance(v, np.ndarray)}
+        scalars = {k: (v if isinstance(v, (int, float, str, bool)) else repr(v)) for k, v in what.items() if not isinstance(v, np.ndarray)}
+        try:
+            g, w = np.ascontiguousarray(arrays["got"]).view(np.uint8).reshape(-1), np.ascontiguousarray(arrays["want"]).view(np.uint8).reshape(-1)
+            diff = np.nonzero(g != w)[0] if g.shape == w.shape else np.array([-1])
+            scalars["differing_bytes"] = int(diff.size)
+            scalars["first_differing_bytes"] = [int(i) for i in diff[:8]]
+        except Exception as exc:   # the report must not stop the run
+            scalars["diff_error"] = repr(exc)
+        print(json.dumps({"soak_mismatch": kind, "iteration": it, "seed": args.seed, **scalars}), file=sys.stderr, flush=True)
+        if bad <= 20:
+            fail_dir.mkdir(exist_ok=True)
+            np.savez_compressed(fail_dir / f"soak_fail_{it}_{kind}.npz", **arrays)
     kinds = {"quantize": 0, "dequantize": 0, "requantize": 0, "dynamic": 0, "dequantize_sum": 0, "reduce_quantize": 0, "batch": 0}
     tq = {4: torch.quint8, 3: torch.quint4x2, 2: torch.quint2x4}
     while time.time() < t_end:
@@ -55,18 +76,21 @@ def main():
         op = int(rng.integers(0, 2))
 
         got = gpu_quantize(ctx, xin, dt_f, dt_q, scale, zp, rm)
-        bad += int(not np.array_equal(got, O.quantize(xin, dt_f, dt_q, scale, zp, rm, tau)))
+        want = O.quantize(xin, dt_f, dt_q, scale, zp, rm, tau)
+        check(np.array_equal(got, want), "quantize", n=n, dt_f=dt_f, dt_q=dt_q, scale=scale, zp=zp, rm=rm, tau=tau, wild=wild, x=xin, got=got, want=want)
         kinds["quantize"] += 1
 
         q = rng.integers(0, 256, O.packed_numel(n, dt_q)).astype(np.uint8)
         prev = (_fuzz_values(rng, n) if wild else rng.uniform(-5, 5, n).astype(np.float32))
         prev = prev if dt_f == 0 else O.f32_to_bf16(prev)
         got = gpu_dequantize(ctx, q, dt_q, dt_f, n, scale, zp, op, prev=prev)
-        bad += int(not same_floats(got, O.dequantize(q, dt_q, dt_f, n, scale, zp, op, out=prev.copy())))
+        want = O.dequantize(q, dt_q, dt_f, n, scale, zp, op, out=prev.copy())
+        check(same_floats(got, want), "dequantize", n=n, dt_f=dt_f, dt_q=dt_q, scale=scale, zp=zp, op=op, wild=wild, q=q, prev=prev, got=got, want=want)
         kinds["dequantize"] += 1
 
         got = gpu_requantize(ctx, xin, dt_f, dt_q, scale, zp, rm, op, prev)
-        bad += int(not same_floats(got, O.requantize(xin, dt_f, dt_q, scale, zp, rm, tau, op, out=prev.copy())))
+        want = O.requantize(xin, dt_f, dt_q, scale, zp, rm, tau, op, out=prev.copy())
+        check(same_floats(got, want), "requantize", n=n, dt_f=dt_f, dt_q=dt_q, scale=scale, zp=zp, rm=rm, tau=tau, op=op, wild=wild, x=xin, prev=prev, got=got, want=want)
         kinds["requantize"] += 1
         elems += 3 * n
 
@@ -76,7 +100,8 @@ def main():
             for c in (ctx, plain):
                 c.set_stochastic_threshold(tau if rm else None)
                 got, got_p = gpu_quantize_dynamic(c, xin, dt_f, dt_q, rm)
-                bad += int(got_p != want_p or not np.array_equal(got, want))
+                check(got_p == want_p and np.array_equal(got, want), "dynamic_fused" if c is ctx else "dynamic_two_launches", n=n, dt_f=dt_f, dt_q=dt_q, rm=rm, tau=tau,
+                      got_params=got_p, want_params=want_p, x=xin, got=got, want=want)
             kinds["dynamic"] += 2
             elems += 2 * n
             K = int(rng.integers(1, 5))
@@ -94,7 +119,7 @@ def main():
                 acc = torch.from_numpy(prev).cuda() if dt_f == 0 else torch.from_numpy(prev.view(np.int16)).cuda().view(torch.bfloat16)
                 pt.dequantize_sum(qs, recs, dtype=fdt, reduce_op="add", out=acc, quant_dtype=tq[dt_q], shape=(n,))
                 got_acc = acc.cpu().numpy() if dt_f == 0 else acc.view(torch.int16).cpu().numpy().view(np.uint16)
-                bad += int(not same_floats(got_acc, want_acc))
+                check(same_floats(got_acc, want_acc), "dequantize_sum", n=n, dt_f=dt_f, dt_q=dt_q, K=K, prev=prev, got=got_acc, want=want_acc)
                 kinds["dequantize_sum"] += 1
                 elems += K * n
                 # the same sum re-quantized in one call (parameters from the sum)
@@ -103,8 +128,9 @@ def main():
                 rq, rrec = pt.reduce_quantize_dynamic(acc2, qs, recs, dtype=tq[dt_q], round_mode="stochastic" if rm else "nearest", ctx=ctx)
                 wp = O.compute_quant_params(want_acc, dt_f, dt_q)
                 if wp[0] > 0 and np.isfinite(wp[0]):
-                    bad += int(pt.params_to_host(rrec) != wp or not np.array_equal(pt.packed_bytes(rq).cpu().numpy(),
-                                                                                  O.quantize(want_acc, dt_f, dt_q, wp[0], wp[1], rm, tau)))
+                    got_rq, want_rq = pt.packed_bytes(rq).cpu().numpy(), O.quantize(want_acc, dt_f, dt_q, wp[0], wp[1], rm, tau)
+                    check(pt.params_to_host(rrec) == wp and np.array_equal(got_rq, want_rq), "reduce_quantize", n=n, dt_f=dt_f, dt_q=dt_q, K=K, rm=rm, tau=tau,
+                          got_params=pt.params_to_host(rrec), want_params=wp, acc=want_acc, got=got_rq, want=want_rq)
                     kinds["reduce_quantize"] += 1
                     elems += n
         if not wild and it % 7 == 0:   # several tensors per launch, then back
@@ -119,8 +145,9 @@ def main():
                 wp = O.compute_quant_params(a, dt_f, dt_q)
                 wq = O.quantize(a, dt_f, dt_q, wp[0], wp[1])
                 go = oo.cpu().numpy() if dt_f == 0 else oo.view(torch.int16).cpu().numpy().view(np.uint16)
-                bad += int(pt.params_to_host(rr) != wp or not np.array_equal(pt.packed_bytes(qq).cpu().numpy(), wq)
-                           or not same_floats(go, O.dequantize(wq, dt_q, dt_f, a.size, wp[0], wp[1])))
+                gq = pt.packed_bytes(qq).cpu().numpy()
+                check(pt.params_to_host(rr) == wp and np.array_equal(gq, wq) and same_floats(go, O.dequantize(wq, dt_q, dt_f, a.size, wp[0], wp[1])), "batch",
+                      n=int(a.size), sizes=sizes, dt_f=dt_f, dt_q=dt_q, got_params=pt.params_to_host(rr), want_params=wp, x=a, got=gq, want=wq, got_dequantized=go)
                 elems += 2 * a.size
             kinds["batch"] += len(sizes)
     print(json.dumps({"seconds": args.seconds, "seed": args.seed, "iterations": it, "checks": kinds, "elements_compared": elems, "mismatching_checks": bad,
