@@ -241,6 +241,12 @@ __device__ __forceinline__ bool ref_scalar_position(const QuantParams& p, int64_
     return local < head || local >= head + ((len - head) / block) * block;
 }
 
+// v_min_f32 / v_max_f32 return the other operand when one is a QUIET NaN -- which is how every min/max fold of this library skips NaNs --
+// but kernels run in IEEE mode, where a SIGNALING NaN operand makes the result a (quiet) NaN; the next fold then skips that NaN and with
+// it everything folded before: a running extreme is silently lost.  (Found by the parity soak: an fp32 bit-pattern fuzz draws signaling
+// NaNs too.)  Canonicalising an input first (v_max_f32 x, x) quiets it, and the fold skips it like any other NaN.
+__device__ __forceinline__ float quieted(float x) { return __builtin_canonicalizef(x); }
+
 // quantize.inl:21-26
 template <int QMAX>
 __device__ __forceinline__ uint32_t quant_nearest_i64(float x, const QuantParams& p) {

@@ -152,8 +152,9 @@ __device__ __forceinline__ void minmax_vec(const u32x4& raw, bool valid, float& 
     InVec<DT_IN>::unpack(raw, f);
 #pragma unroll
     for (int e = 0; e < EPV; ++e) {
-        lo = __builtin_fminf(lo, valid ? f[e] : lo);
-        hi = __builtin_fmaxf(hi, valid ? f[e] : hi);
+        const float x = quieted(f[e]);   // a signaling NaN would poison the fold (device_math.hpp)
+        lo = __builtin_fminf(lo, valid ? x : lo);
+        hi = __builtin_fmaxf(hi, valid ? x : hi);
     }
 }
 
@@ -287,7 +288,7 @@ fused_params_quantize_kernel(FusedGroups groups, QuantParams p_arg, FusedState* 
         }
     }
     if (block == 0 && tid < numel - n_vec * EPV) {   // the numel % EPV scalar elements
-        const float x = InVec<DT_IN>::load_scalar(in, n_vec * EPV + tid);
+        const float x = quieted(InVec<DT_IN>::load_scalar(in, n_vec * EPV + tid));
         lo = __builtin_fminf(lo, x);
         hi = __builtin_fmaxf(hi, x);
     }

@@ -13,7 +13,7 @@
 // own 128-byte line (slot = blockIdx % slots), and the block that arrives last folds the slots and runs the call's
 // epilogue (keys, host mailbox or parameter record) inside the same launch.
 // Device-scope atomics are coherent across the 8 XCDs' L2s.
-// NaNs are ignored (v_min/v_max return the non-NaN operand); the reference leaves NaN inputs unspecified.
+// NaNs are ignored (inputs are quieted, and v_min/v_max return the non-NaN operand of a quiet NaN); the reference leaves NaN inputs unspecified.
 #pragma once
 
 #include "quant_kernels.hpp"
@@ -310,8 +310,9 @@ __global__ void __launch_bounds__(BLOCK) minmax_kernel(const void* __restrict__ 
         InVec<DT_IN>::unpack(raw, f);
 #pragma unroll
         for (int e = 0; e < EPV; ++e) {
-            lo = __builtin_fminf(lo, f[e]);
-            hi = __builtin_fmaxf(hi, f[e]);
+            const float x = quieted(f[e]);   // a signaling NaN would poison the fold (device_math.hpp)
+            lo = __builtin_fminf(lo, x);
+            hi = __builtin_fmaxf(hi, x);
         }
     };
     int64_t v = tid;
@@ -339,7 +340,7 @@ __global__ void __launch_bounds__(BLOCK) minmax_kernel(const void* __restrict__ 
     for (; v < n_vec; v += nthreads) fold(ld<NT>(in16 + v));
     // ragged scalar tail (numel % EPV elements)
     for (int64_t i = n_vec * EPV + tid; i < numel; i += nthreads) {
-        const float x = InVec<DT_IN>::load_scalar(in, i);
+        const float x = quieted(InVec<DT_IN>::load_scalar(in, i));
         lo = __builtin_fminf(lo, x);
         hi = __builtin_fmaxf(hi, x);
     }
@@ -364,7 +365,7 @@ __global__ void __launch_bounds__(BLOCK) minmax_scalar_kernel(const void* __rest
     float lo = 3.402823466e+38f, hi = -3.402823466e+38f;
     const int64_t nthreads = static_cast<int64_t>(gridDim.x) * BLOCK;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * BLOCK + threadIdx.x; i < numel; i += nthreads) {
-        const float x = InVec<DT_IN>::load_scalar(in, i);
+        const float x = quieted(InVec<DT_IN>::load_scalar(in, i));
         lo = __builtin_fminf(lo, x);
         hi = __builtin_fmaxf(hi, x);
     }

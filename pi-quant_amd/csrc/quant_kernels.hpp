@@ -291,15 +291,21 @@ __device__ __forceinline__ BoundedStep bounded_step_for(int32_t zp32) {
     return BoundedStep {-static_cast<float>(zp32), static_cast<float>(((1 << BITS) - 1) - zp32), zp_word};
 }
 
-// max(m, |elements of the vector|): NaNs are skipped (fmax returns the other operand), infinities are kept -- exactly what the
-// caller's range test wants: a NaN quantizes to 0 through the short step as through the long one, an infinity must take the long one.
+// Range test of the short step, one vector at a time: m = max(m, |elements|) and `nan` |= "a NaN is among them".  A tile with a NaN takes
+// the long step like one with an infinity or a huge value: v_max skips a quiet NaN but is POISONED by a signaling one (IEEE mode: the result
+// is a NaN, which the next v_max skips together with the maximum so far), so the maximum of a tile that holds NaNs cannot be trusted --
+// the parity soak found the case: a value beyond 10^9 * scale followed, in the same lane, by a signaling NaN, and the tile took the short
+// step.  One v_cmp_u_f32 per two elements tells.
 template <int DT_IN>
-__device__ __forceinline__ float vec_absmax(const u32x4& raw, float m) {
+__device__ __forceinline__ float vec_absmax(const u32x4& raw, float m, bool& nan) {
     constexpr int EPV = InVec<DT_IN>::EPV;
     float v[EPV];
     InVec<DT_IN>::unpack(raw, v);
 #pragma unroll
-    for (int e = 0; e < EPV; e += 2) m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[e]), __builtin_fabsf(v[e + 1])), m);
+    for (int e = 0; e < EPV; e += 2) {
+        m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[e]), __builtin_fabsf(v[e + 1])), m);
+        nan |= __builtin_isunordered(v[e], v[e + 1]);
+    }
     return m;
 }
 
@@ -365,14 +371,15 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
         // The short step (quantize_vec_short: about half the instructions per element for nearest, a third for stochastic) is exact whenever the zero point lies
         // inside the quantized range and no element of the wave's tile reaches the range where x86's cvttps2dq turns indefinite --
         // decided per wave tile from max|x| * |1/scale| (one v_max3 per two elements and one compare per lane).  Ordinary data always
-        // takes it; a tile with an infinity or a huge value takes the long step, with the same bytes either way.
+        // takes it; a tile with a NaN, an infinity or a huge value takes the long step, with the same bytes either way.
         bool short_step = false;
         if constexpr (SHORT_CAPABLE) {
             if (short_ok) {
                 float amax = 0.0f;
+                bool nan = false;
 #pragma unroll
-                for (int k = 0; k < U; ++k) amax = vec_absmax<DT_IN>(raw[k], amax);
-                short_step = __all(__fmul_rn(amax, abs_inv) < 1.0e9f ? 1 : 0) != 0;
+                for (int k = 0; k < U; ++k) amax = vec_absmax<DT_IN>(raw[k], amax, nan);
+                short_step = __all(!nan && __fmul_rn(amax, abs_inv) < 1.0e9f ? 1 : 0) != 0;
             }
         }
         uint8_t* o = out + v0 * OB;                                    // output of this wave tile

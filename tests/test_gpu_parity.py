@@ -208,6 +208,77 @@ def test_stochastic_short_step_edges(ctx, O):
         assert np.array_equal(got, O.quantize_per_element(x, O.F32, dt_out, 0.5, 1, 0xfeed, (1 << 32) - 5000))
 
 
+def gpu_compute_params(ctx, x, dt_in, dt_q):
+    """piquant_compute_quant_params_* on a device copy of x -> (scale, zero_point)"""
+    import piquant
+    import torch
+
+    keep, ptr = to_device(x)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    fn = ctx.compute_quant_params_ptr_float32 if dt_in == 0 else ctx.compute_quant_params_ptr_bfloat16
+    got = fn(ptr, piquant.DataType(dt_q), x.size)
+    del keep
+    return got
+
+
+def test_signaling_nans_do_not_poison_range_tests_or_scans(ctx, O):
+    """Found by the parity soak (seed 777, iteration 110 308: one byte of 1.5 M).  v_min/v_max skip a QUIET NaN, but kernels run in IEEE mode, where
+    a SIGNALING NaN operand turns the result into a NaN -- which the next min/max then skips together with everything folded before it.  So
+    (a) the short step's range test forgot a value beyond 10^9 * scale that was followed, in the same lane, by a signaling NaN, and the tile
+    took the short step (255 where the reference's cvttps2dq indefinite gives 0); (b) a min/max scan forgot its running extremes after a
+    signaling NaN.  np.nan is quiet, which is why the NaN tests above never saw it; an fp32 bit-pattern fuzz draws both kinds."""
+    import piquant
+    rng = np.random.default_rng(110308)
+    SNAN32, SNAN16 = 0x7f800001, 0x7f81
+    # (a) quantize: a huge value first, signaling NaNs later in the same lane's elements (element 4l..4l+3 of vector l, then vector 64 + l, ...)
+    for dt_in in (0, 1):
+        for dt_out, qmax in ((4, 255), (3, 15), (2, 3)):
+            for rm, tau in ((0, 0.0), (1, 0.3)):
+                n = 64 * 1024 + 3
+                x = rng.uniform(-100, 100, n).astype(np.float32)
+                xin = x if dt_in == 0 else O.f32_to_bf16(x)
+                bits = xin.view(np.uint32) if dt_in == 0 else xin.view(np.uint16)
+                huge = np.array([3.0e9, -3.0e9, 2.6e38], dtype=np.float32)
+                hb = huge.view(np.uint32) if dt_in == 0 else O.f32_to_bf16(huge).view(np.uint16)
+                epv = 4 if dt_in == 0 else 8
+                for j, lane in enumerate(rng.choice(4000, 60, replace=False)):
+                    base = int(lane) * epv
+                    bits[base] = hb[j % 3]                                   # first element of the lane's first vector
+                    bits[base + 2 + (j % (epv - 2))] = SNAN32 if dt_in == 0 else SNAN16   # a later element of the same vector ...
+                    if j % 2:
+                        bits[base + 64 * epv + (j % epv)] = SNAN32 if dt_in == 0 else SNAN16   # ... or of the lane's next vector
+                ctx.set_stochastic_threshold(tau if rm else None)
+                for scale, zp in ((1.0, qmax // 2), (0.5, 0), (1.0e-3, qmax)):
+                    got = gpu_quantize(ctx, xin, dt_in, dt_out, scale, zp, rm)
+                    want = O.quantize(xin, dt_in, dt_out, scale, zp, rm, tau)
+                    assert np.array_equal(got, want), (dt_in, dt_out, rm, scale, zp, np.nonzero(got != want)[0][:6])
+    ctx.set_stochastic_threshold(None)
+    # the block the soak tripped over, as data: elements [129 024, 130 048) of its 1 504 358-element fp32 tensor (uint32 bit patterns), scale 9.33e28, zp 105
+    from pathlib import Path
+    blk = np.load(Path(__file__).resolve().parent / "golden" / "soak_seed777_it110308_block126_f32.npy").view(np.float32)
+    for lead in (0, 1024, 129_024):       # at the front, behind one ordinary block, and where it sat
+        xs = np.concatenate([rng.uniform(-1, 1, lead).astype(np.float32), blk, rng.uniform(-1, 1, 102).astype(np.float32)])
+        got = gpu_quantize(ctx, xs, 0, 4, 9.331063715550025e+28, 105, 0)
+        assert np.array_equal(got, O.quantize(xs, 0, 4, 9.331063715550025e+28, 105)), lead
+    # (b) scans: the extremes come first, signaling NaNs are sprinkled over the rest
+    for dt_in in (0, 1):
+        for n in (70_001, 1_000_003, 27_264_000 // 8):
+            x = rng.uniform(-1, 1, n).astype(np.float32)
+            x[0], x[1] = -5.0, 7.0
+            xin = x if dt_in == 0 else O.f32_to_bf16(x)
+            bits = xin.view(np.uint32) if dt_in == 0 else xin.view(np.uint16)
+            bits[rng.choice(np.arange(2, n), n // 100, replace=False)] = SNAN32 if dt_in == 0 else SNAN16
+            for dt_q in (4, 3, 2):
+                want_p = O.compute_quant_params(xin, dt_in, dt_q)
+                assert gpu_compute_params(ctx, xin, dt_in, dt_q) == want_p, (dt_in, n, dt_q)
+                for fused in (True, False):
+                    c = piquant.Context()
+                    c.set_fusion(fused)
+                    got, got_p = gpu_quantize_dynamic(c, xin, dt_in, dt_q)
+                    assert got_p == want_p, (dt_in, n, dt_q, fused, got_p, want_p)
+                    assert np.array_equal(got, O.quantize(xin, dt_in, dt_q, want_p[0], want_p[1])), (dt_in, n, dt_q, fused)
+
+
 def test_extreme_zero_points_wrap_like_the_reference(ctx, O):
     """int64 zero points are narrowed to int32 on the fast paths and kept on the generic ones (quantize.inl:111 vs :15)."""
     rng = np.random.default_rng(5)

@@ -164,3 +164,22 @@ def test_minmax_with_nans_the_reference_depends_on_position_the_oracle_ignores_t
             assert got == (-5.0, 7.0)
     xb = O.f32_to_bf16(np.array([1.0, np.nan, -3.0, 2.0] * 50, dtype=np.float32))
     assert O.minmax(xb, O.BF16) == (-3.0, 2.0)
+
+
+def test_the_block_the_round2_soak_tripped_over(both):
+    """tests/golden/soak_seed777_it110308_block126_f32.npy: 1 024 fp32 bit patterns of a fuzz tensor -- among them 2.6e38 (a product beyond 2^31 at
+    scale 9.33e28: the reference's cvttps2dq turns indefinite, INT_MIN + zp clamps to 0) and a SIGNALING NaN in the same 256-element span.  The HIP
+    kernel's range test was poisoned by the signaling NaN and wrote 255 there; what the byte must be is pinned here by the reference's own
+    kernels (its AVX-512 units) and by the oracle."""
+    from pathlib import Path
+
+    O, R = both
+    blk = np.load(Path(__file__).resolve().parent / "golden" / "soak_seed777_it110308_block126_f32.npy").view(np.float32)
+    bits = blk.view(np.uint32)
+    assert int((((bits & 0x7f800000) == 0x7f800000) & ((bits & 0x007fffff) != 0) & ((bits & 0x00400000) == 0)).sum()) == 1   # one signaling NaN
+    scale, zp = 9.331063715550025e+28, 105
+    want = O.quantize(blk, O.F32, O.UINT8, scale, zp)
+    assert want[130_019 - 129_024] == 0
+    for isa in (R.AVX512F, R.AVX512F_BF16):
+        if R.supported(isa):
+            assert np.array_equal(R.quantize(blk, O.F32, O.UINT8, scale, zp, isa=isa), want), R.isa_name(isa)

@@ -3,8 +3,8 @@
 
 Every iteration draws a configuration (dtype pair, rounding mode, store op, ragged size up to 2 M elements, scale over 60
 decades, zero point from the int64 range or a sane one, any fp32 bit pattern as data incl. NaN/inf/denormals, or ordinary
-data) and checks quantize, dequantize, the fused quantize->dequantize, dynamic (params + quantize, fused and unfused) and
-dequantize_sum.  Prints one JSON line: iterations, elements compared, mismatches (must be 0).
+data) and checks quantize, dequantize, the fused quantize->dequantize, the min/max scan, dynamic (params + quantize, fused and unfused)
+and dequantize_sum.  Prints one JSON line: iterations, elements compared, mismatches (must be 0).
 
   python tools/parity_soak.py --seconds 600 [--seed 1]        (tests/ holds the short, deterministic versions)
 """
@@ -93,6 +93,19 @@ def main():
         check(same_floats(got, want), "requantize", n=n, dt_f=dt_f, dt_q=dt_q, scale=scale, zp=zp, rm=rm, tau=tau, op=op, wild=wild, x=xin, prev=prev, got=got, want=want)
         kinds["requantize"] += 1
         elems += 3 * n
+
+        # min/max scan on whatever the data is (NaNs of both kinds are skipped, infinities count); numeric comparison: -0.0 == 0.0
+        xd = torch.from_numpy(xin.view(np.uint8)).cuda()
+        keys_d = torch.empty(2, dtype=torch.int32, device="cuda")
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.set_blocking(False)
+        ctx.minmax_keys_ptr(xd.data_ptr(), piquant.DataType(dt_f), n, keys_d.data_ptr(), True)
+        k = keys_d.cpu().numpy()
+        got_mm, want_mm = piquant.decode_minmax_keys(int(k[0]), int(k[1])), O.minmax(xin, dt_f)
+        check(float(got_mm[0]) == float(want_mm[0]) and float(got_mm[1]) == float(want_mm[1]), "minmax", n=n, dt_f=dt_f, wild=wild, got_minmax=got_mm,
+              want_minmax=want_mm, x=xin)
+        kinds["minmax"] = kinds.get("minmax", 0) + 1
+        elems += n
 
         if not wild:   # data-derived parameters need a positive finite scale
             want_p = O.compute_quant_params(xin, dt_f, dt_q)
