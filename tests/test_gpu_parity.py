@@ -260,6 +260,18 @@ def test_signaling_nans_do_not_poison_range_tests_or_scans(ctx, O):
         xs = np.concatenate([rng.uniform(-1, 1, lead).astype(np.float32), blk, rng.uniform(-1, 1, 102).astype(np.float32)])
         got = gpu_quantize(ctx, xs, 0, 4, 9.331063715550025e+28, 105, 0)
         assert np.array_equal(got, O.quantize(xs, 0, 4, 9.331063715550025e+28, 105)), lead
+    # quieting an input must not flush it: a tensor of denormals scans to denormal extremes
+    import torch
+    den = np.array([3, 1, 7, 0x80000005, 0x80000002, 4] * 700, dtype=np.uint32).view(np.float32)
+    keep, ptr = to_device(den)
+    keys_d = torch.empty(2, dtype=torch.int32, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_blocking(False)
+    ctx.minmax_keys_ptr(ptr, piquant.DataType.F32, den.size, keys_d.data_ptr(), True)
+    k = keys_d.cpu().numpy()
+    lo, hi = piquant.decode_minmax_keys(int(k[0]), int(k[1]))
+    assert np.float32(lo).view(np.uint32) == 0x80000005 and np.float32(hi).view(np.uint32) == 7, (lo, hi)
+    ctx.set_blocking(True)
     # (b) scans: the extremes come first, signaling NaNs are sprinkled over the rest
     for dt_in in (0, 1):
         for n in (70_001, 1_000_003, 27_264_000 // 8):
