@@ -103,3 +103,23 @@ def test_short_stochastic_step_equals_the_reference_step_inside_its_range(oracle
                     want = O.quantize(xin, dt_in, dt_out, scale, zp, O.STOCHASTIC, tau)
                     got = short_stochastic(xf, inv, zp, dt_out, tau)
                     assert np.array_equal(got, want), (dt_out, scale, zp, tau, dt_in, np.nonzero(got != want)[0][:5])
+
+
+def test_oracle_treats_signaling_nans_like_quiet_ones(oracle_mod):
+    """The checker's side of tests/test_gpu_parity.py::test_signaling_nans_do_not_poison_range_tests_or_scans: in the oracle a NaN is a NaN --
+    skipped by the min/max restatement wherever it sits, quantized to what the reference's indefinite conversion clamps to."""
+    O = oracle_mod
+    x = np.array([-5.0, 7.0, 1.0, 2.0, 3.0, 0.5, -0.5, 6.0], dtype=np.float32)
+    for nan_bits in (0x7f800001, 0xff800001, 0x7fc00000, 0x7fa00000):
+        for pos in (2, 5, 7):
+            y = x.copy()
+            y.view(np.uint32)[pos] = nan_bits
+            assert O.minmax(y, O.F32) == (-5.0, 7.0)
+            q = O.quantize(y, O.F32, O.UINT8, 1.0, 10)
+            assert q[pos] == 0 and q[0] == 5 and q[1] == 17
+            q = O.quantize(y, O.F32, O.UINT8, 1.0, 10, O.STOCHASTIC, 0.3)
+            assert q[pos] == 0
+    yb = O.f32_to_bf16(x)
+    yb.view(np.uint16)[3] = 0x7f81          # a signaling NaN in bf16
+    assert O.minmax(yb, O.BF16) == (-5.0, 7.0)
+    assert O.quantize(yb, O.BF16, O.UINT4, 1.0, 3)[1] & 0xf0 == 0   # element 3 = high nibble of byte 1
