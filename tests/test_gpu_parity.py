@@ -289,6 +289,10 @@ def test_signaling_nans_do_not_poison_range_tests_or_scans(ctx, O):
                     got, got_p = gpu_quantize_dynamic(c, xin, dt_in, dt_q)
                     assert got_p == want_p, (dt_in, n, dt_q, fused, got_p, want_p)
                     assert np.array_equal(got, O.quantize(xin, dt_in, dt_q, want_p[0], want_p[1])), (dt_in, n, dt_q, fused)
+                    # the one-launch kernel takes the short step for the whole grid (the data range decides): NaN elements go through it, both roundings
+                    c.set_stochastic_threshold(0.4375)
+                    got, got_p = gpu_quantize_dynamic(c, xin, dt_in, dt_q, 1)
+                    assert got_p == want_p and np.array_equal(got, O.quantize(xin, dt_in, dt_q, want_p[0], want_p[1], 1, 0.4375)), (dt_in, n, dt_q, fused, "stochastic")
 
 
 def test_extreme_zero_points_wrap_like_the_reference(ctx, O):
