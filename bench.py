@@ -218,6 +218,10 @@ def main():
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: for N > 1 launch through torch.distributed.run"
     if args.share_gpu:
         local_rank = 0
+    elif world > torch.cuda.device_count():
+        # fail at once and loudly: RCCL with two ranks on one device does not fail, it hangs
+        sys.exit(f"bench.py: WORLD_SIZE={world} but only {torch.cuda.device_count()} visible device(s); one rank per GPU "
+                 "(--share-gpu with --backend gloo is test plumbing for one-GPU boxes)")
     torch.cuda.set_device(local_rank if use_dist else 0)
     if use_dist:
         if args.backend == "nccl":

@@ -84,7 +84,16 @@ struct DequantTile {
 
 template <int BITS, int DT_OUT, int OP, int U, bool STAGE, int NT, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
-dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int64_t n_tiles, DequantParams p_arg) {
+dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int64_t n_tiles, float scale, float bias, const ParamRecord* dyn, int32_t zp32,
+                  uint32_t tile_stride, DequantParams p_arg, int head) {
+    // scale / bias / dyn / zp32 repeat fields of p_arg and tile_stride is gridDim.x, as scalar arguments so that they arrive preloaded in SGPRs
+    // (quantize_kernel explains)
+    p_arg.scale = scale;
+    p_arg.bias = bias;
+    p_arg.dyn = dyn;
+    p_arg.zp32 = zp32;
+    // the arguments describe the BODY of the call; `head` leading elements (a whole number of packed bytes) in front of it were peeled by the
+    // launcher so that `out` is 16-byte aligned, and block 0 does them element by element (quant_kernels.hpp)
     const DequantParams p = resolved(p_arg);
     using T = DequantTile<BITS, DT_OUT, U, BLOCK>;
     constexpr int EPV = T::EPV, IB = T::IB;
@@ -100,11 +109,18 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
     u32x4* out16 = static_cast<u32x4*>(out);
 
     // ragged tail: by the first block, before its tiles (quant_kernels.hpp explains why not by the last one, after)
-    if (n_tiles * T::BLOCK_ELEMS < numel && blockIdx.x == 0) {
+    if (blockIdx.x == 0) {
         for (int64_t i = n_tiles * T::BLOCK_ELEMS + threadIdx.x; i < numel; i += BLOCK) dequant_store_scalar<BITS, DT_OUT, OP>(in, out, i, p);
+        if (head > 0) {
+            DequantParams ph = p;
+            ph.ref_index0 -= head;
+            const uint8_t* in0 = in - head / (8 / BITS);
+            void* out0 = static_cast<uint8_t*>(out) - static_cast<int64_t>(head) * (DT_OUT == DT_F32 ? 4 : 2);
+            for (int i = threadIdx.x; i < head; i += BLOCK) dequant_store_scalar<BITS, DT_OUT, OP>(in0, out0, i, ph);
+        }
     }
 
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += tile_stride) {
         const int64_t v0 = (tile * T::WAVES + wave) * T::WAVE_VECS;     // first output vector of this wave tile
         const uint8_t* src = in + v0 * IB;
 
@@ -189,6 +205,12 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
         }
     }
 
+}
+
+template <int BITS, int DT_OUT, int OP, int U, bool STAGE, int NT, int BLOCK>
+inline void launch_dequantize_kernel(unsigned grid, hipStream_t stream, const uint8_t* in, void* out, int64_t numel, int64_t n_tiles, const DequantParams& p, int head) {
+    hipLaunchKernelGGL((dequantize_kernel<BITS, DT_OUT, OP, U, STAGE, NT, BLOCK>), dim3(grid), dim3(BLOCK), 0, stream, in, out, numel, n_tiles, p.scale, p.bias, p.dyn,
+                       p.zp32, grid, p, head);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

@@ -18,7 +18,9 @@ enum : int { DT_F32 = 0, DT_BF16 = 1, DT_UINT2 = 2, DT_UINT4 = 3, DT_UINT8 = 4 }
 //   RM_NEAREST_I64  : the reference's generic scalar formula, std::round in int64 (only f32 -> uint2 has no fast path)
 //   RM_STOCH_CALL   : stochastic, one threshold per call (the reference's behaviour)
 //   RM_STOCH_ELEM   : stochastic, counter-hash threshold per element (extension)
-enum : int { RM_NEAREST_FAST = 0, RM_NEAREST_I64 = 1, RM_STOCH_CALL = 2, RM_STOCH_ELEM = 3 };
+//   RM_COPY         : tune harness only -- no arithmetic at all (a vector's dwords are xor-ed into its packed word): the streaming kernel's
+//                     traffic, tile shape, LDS staging and store policy with nothing else, i.e. the ceiling its real modes are measured against
+enum : int { RM_NEAREST_FAST = 0, RM_NEAREST_I64 = 1, RM_STOCH_CALL = 2, RM_STOCH_ELEM = 3, RM_COPY = 4 };
 
 // Quantization parameters living in DEVICE memory (16 bytes), written by params_from_slots_kernel and read by the
 // kernels when QuantParams::dyn / DequantParams::dyn is set: the "dynamic" path, where (scale, zero_point) never
@@ -29,15 +31,18 @@ struct ParamRecord {
     int64_t zero_point;
 };
 
+// Field order matters: the leading 14 dwords of a kernel's arguments arrive preloaded in SGPRs (Makefile, -amdgpu-kernarg-preload-count) --
+// the four pointer / size arguments of the streaming kernels plus the first 24 bytes of this struct -- so that a wave's first global loads
+// and its decision "static or device-resident parameters" wait for no s_load.
 struct QuantParams {
     float inv_scale;      // 1.0f / scale, divided on the host in fp32 (kernels_specialized.inl:42, quantize.inl:129)
     int32_t zp32;         // zero point narrowed to int32 as at the fast-path call sites (quantize.inl:111)
+    const ParamRecord* dyn;   // nullable: take inv_scale / zero point from device memory instead of the fields around it
     int64_t zp64;         // zero point as passed (generic + stochastic paths keep int64, quantize.inl:15,24)
     float threshold;      // RM_STOCH_CALL
     uint32_t seed_lo;     // RM_STOCH_ELEM
     uint32_t seed_hi;
     uint64_t index_base;  // RM_STOCH_ELEM: global index of element 0 of this launch
-    const ParamRecord* dyn;   // nullable: take inv_scale / zero point from device memory instead of the fields above
     // Opt-in "reference layout" (piquant_hip_set_reference_layout): reproduce WHERE the reference's AVX-512 build applies its
     // scalar head/tail formula instead of the SIMD-body formula, for a context with one pool thread.  Positions are global
     // (ref_index0 = global index of this launch's element 0) so that chunked host staging keeps the layout of the whole call.
@@ -52,9 +57,9 @@ struct QuantParams {
 struct DequantParams {
     float scale;
     float bias;           // -(float)zp32 * scale, multiplied on the host (kernels_specialized.inl:1204,1325)
+    const ParamRecord* dyn;   // nullable, as in QuantParams (and placed for the same reason)
     int32_t zp32;
     int64_t zp64;
-    const ParamRecord* dyn;   // nullable, as in QuantParams
     int32_t ref_layout;       // as in QuantParams (tail formulas of the bf16 kernels, the uint2 -> f32 tail)
     int64_t ref_total;
     int64_t ref_index0;
@@ -305,7 +310,8 @@ __device__ __forceinline__ float element_threshold(const ElementKeys& k, uint64_
 
 template <int MODE, int QMAX>
 __device__ __forceinline__ uint32_t quant_one(float x, const QuantParams& p, uint64_t elem_index) {
-    if constexpr (MODE == RM_NEAREST_FAST) return quant_nearest_fast<QMAX>(x, p);
+    if constexpr (MODE == RM_COPY) return __float_as_uint(x) & static_cast<uint32_t>(QMAX);
+    else if constexpr (MODE == RM_NEAREST_FAST) return quant_nearest_fast<QMAX>(x, p);
     else if constexpr (MODE == RM_NEAREST_I64) return quant_nearest_i64<QMAX>(x, p);
     else if constexpr (MODE == RM_STOCH_CALL) return quant_stochastic<QMAX>(x, p, p.threshold);
     else return quant_stochastic<QMAX>(x, p, element_threshold(p, p.index_base + elem_index));

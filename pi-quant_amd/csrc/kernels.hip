@@ -32,18 +32,30 @@ void quantize_t(const QuantLaunch& q, const QuantParams& p, hipStream_t stream, 
     constexpr KernelTune t = kQuantTune[DT_IN][bits_index(BITS)];
     using Tile = QuantTile<DT_IN, BITS, t.u, t.block>;
     uint8_t* out = static_cast<uint8_t*>(q.out);
-    // a scalar head shifts every SIMD block, and the partitions of a T-thread reference context put heads and tails inside the tensor: guarded kernel
-    if (!aligned16(q.in) || !aligned16(q.out) || (q.ref_layout && (q.ref_head != 0 || q.ref_threads > 1))) {
-        constexpr int PACK = 8 / BITS;
+    constexpr int PACK = 8 / BITS, ESIZE = DT_IN == DT_F32 ? 4 : 2;
+    // Buffers that are not 16-byte aligned (a slice x[1:], a shard at an odd offset): the vector kernel runs on them too.  Its loads may
+    // start anywhere an element may; its 16-byte stores are aligned by peeling `head` leading elements (a whole number of packed bytes)
+    // into the guarded path of block 0 -- the reference's shape (scalar head until the output is aligned, unaligned loads in the body,
+    // kernels_specialized.inl:52-82).
+    const int64_t head_bytes = static_cast<int64_t>((16u - (reinterpret_cast<uintptr_t>(q.out) & 15u)) & 15u);
+    const int64_t head = head_bytes * PACK;
+    // The guarded kernel remains for: inputs that are not even element-aligned, tensors that end inside the head, and reference-layout mode
+    // whenever scalar positions lie inside the tensor (a scalar head shifts every SIMD block, and the partitions of a T-thread reference
+    // context put heads and tails everywhere).
+    if (reinterpret_cast<uintptr_t>(q.in) % ESIZE != 0 || head >= q.numel || (q.ref_layout && (q.ref_head != 0 || q.ref_threads > 1 || head != 0))) {
         const int64_t nbytes = (q.numel + PACK - 1) / PACK;
         const unsigned grid = capped_grid((nbytes + kScalarBlock - 1) / kScalarBlock, 16, num_cu);
         hipLaunchKernelGGL((quantize_scalar_kernel<DT_IN, BITS, MODE>), dim3(grid), dim3(kScalarBlock), 0, stream, q.in, out, q.numel, p);
         return;
     }
-    const int64_t n_tiles = q.numel / Tile::BLOCK_ELEMS;
+    QuantParams body = p;
+    body.index_base += static_cast<uint64_t>(head);
+    body.ref_index0 += head;
+    const int64_t numel = q.numel - head;
+    const int64_t n_tiles = numel / Tile::BLOCK_ELEMS;
     const unsigned grid = capped_grid(n_tiles, t.blocks_per_cu, num_cu);
-    hipLaunchKernelGGL((quantize_kernel<DT_IN, BITS, MODE, t.u, t.stage, t.nt, t.block, kQuantShortStep>), dim3(grid), dim3(t.block), 0, stream,
-                       q.in, out, q.numel, n_tiles, p);
+    launch_quantize_kernel<DT_IN, BITS, MODE, t.u, t.stage, t.nt, t.block, kQuantShortStep, kQuantVariant>(
+        grid, 0, stream, static_cast<const void*>(static_cast<const uint8_t*>(q.in) + head * ESIZE), out + head_bytes, numel, n_tiles, body, static_cast<int>(head));
 }
 
 template <int DT_IN, int BITS>
@@ -76,15 +88,28 @@ void dequantize_t(const DequantLaunch& d, const DequantParams& p, hipStream_t st
     constexpr KernelTune t = OP == OP_ADD ? kDequantAddTune[DT_OUT][bits_index(BITS)] : kDequantTune[DT_OUT][bits_index(BITS)];
     using Tile = DequantTile<BITS, DT_OUT, t.u, t.block>;
     const uint8_t* in = static_cast<const uint8_t*>(d.in);
-    if (!aligned16(d.in) || !aligned16(d.out) || (d.ref_layout && d.ref_threads > 1)) {   // partition tails inside the tensor: every element looks at its position
+    constexpr int PACK = 8 / BITS, ESIZE = DT_OUT == DT_F32 ? 4 : 2;
+    // Misaligned buffers take the vector kernel too (quantize_t above).  The packed input may start at any byte; the 16-byte stores -- and
+    // for ADD the loads of the accumulator -- are aligned by peeling leading elements into block 0's element-wise path when that many
+    // elements are a whole number of packed bytes, and run misaligned otherwise (a uint4 tensor decoded to an fp32 slice that starts one
+    // float past a 16-byte boundary: the body cannot begin inside a packed byte).
+    const uintptr_t oa = reinterpret_cast<uintptr_t>(d.out);
+    int64_t head = static_cast<int64_t>((16u - (oa & 15u)) & 15u) / ESIZE;
+    if (head % PACK != 0) head = 0;
+    // element-wise kernel: an output that is not element-aligned, a tensor that ends inside the head, and reference-layout mode when tails
+    // lie inside the tensor (partitions of a T-thread context) or the tiles would not start at element 0
+    if (oa % ESIZE != 0 || head >= d.numel || (d.ref_layout && (d.ref_threads > 1 || head != 0))) {
         const unsigned grid = capped_grid((d.numel + kScalarBlock - 1) / kScalarBlock, 16, num_cu);
         hipLaunchKernelGGL((dequantize_scalar_kernel<BITS, DT_OUT, OP>), dim3(grid), dim3(kScalarBlock), 0, stream, in, d.out, d.numel, p);
         return;
     }
-    const int64_t n_tiles = d.numel / Tile::BLOCK_ELEMS;
+    DequantParams body = p;
+    body.ref_index0 += head;
+    const int64_t numel = d.numel - head;
+    const int64_t n_tiles = numel / Tile::BLOCK_ELEMS;
     const unsigned grid = capped_grid(n_tiles, t.blocks_per_cu, num_cu);
-    hipLaunchKernelGGL((dequantize_kernel<BITS, DT_OUT, OP, t.u, t.stage, t.nt, t.block>), dim3(grid), dim3(t.block), 0, stream, in,
-                       d.out, d.numel, n_tiles, p);
+    launch_dequantize_kernel<BITS, DT_OUT, OP, t.u, t.stage, t.nt, t.block>(grid, stream, in + head / PACK, static_cast<void*>(static_cast<uint8_t*>(d.out) + head * ESIZE),
+                                                                            numel, n_tiles, body, static_cast<int>(head));
 }
 
 template <int BITS, int DT_OUT>
@@ -110,7 +135,7 @@ void minmax_t(const void* in, int64_t numel, int32_t* state, const MinmaxEpilogu
     constexpr int EPV = InVec<DT_IN>::EPV;
     // scans that deliver a result end with the gather protocol; scans that leave their keys in the slots (EP_NONE: several staged
     // chunks of a host buffer folding into one state) keep the slot atomics
-    if (!aligned16(in)) {
+    if (reinterpret_cast<uintptr_t>(in) % (DT_IN == DT_F32 ? 4 : 2) != 0) {   // not even element-aligned; anything else is scanned with (possibly misaligned) 16-byte loads
         const unsigned grid = capped_grid((numel + kMinmaxBlock - 1) / kMinmaxBlock, 8, num_cu);
         if (kMinmaxGatherEnd && ep.action != EP_NONE && grid <= static_cast<unsigned>(kMinmaxGatherMax))
             hipLaunchKernelGGL((minmax_scalar_kernel<DT_IN, kMinmaxBlock, true>), dim3(grid), dim3(kMinmaxBlock), 0, stream, in, numel, state, ep);
@@ -483,7 +508,8 @@ template <int DT, int BITS, int MODE, int OP>
 void requantize_t(const RequantLaunch& r, const QuantParams& qp, const DequantParams& dp, float scale_bf16, hipStream_t stream, int num_cu) {
     constexpr KernelTune t = kRequantTune;
     constexpr int EPV = InVec<DT>::EPV;
-    if (!aligned16(r.in) || !aligned16(r.out)) {
+    constexpr int ESIZE = DT == DT_F32 ? 4 : 2;
+    if (reinterpret_cast<uintptr_t>(r.in) % ESIZE != 0 || reinterpret_cast<uintptr_t>(r.out) % ESIZE != 0) {   // element-aligned buffers stream through the vector kernel
         const unsigned grid = capped_grid((r.numel + kScalarBlock - 1) / kScalarBlock, 16, num_cu);
         hipLaunchKernelGGL((requantize_scalar_kernel<DT, BITS, MODE, OP>), dim3(grid), dim3(kScalarBlock), 0, stream, r.in, r.out, r.numel, qp, dp,
                            scale_bf16);

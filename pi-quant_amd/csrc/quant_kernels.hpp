@@ -32,10 +32,17 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 enum : int { ST_PLAIN = 0, ST_NT = 1, ST_WT = 2 };
 constexpr int mem_policy(bool nt_loads, int store_policy) { return (nt_loads ? 1 : 0) | (store_policy << 1); }
 
+// Global-memory accesses go through byte-aligned views of their type: gfx950 under ROCm runs with unaligned access enabled, and the
+// compiler emits the same global_load_dwordx4 / global_store_dwordx4 whatever alignment it is told (checked in the ISA), so one kernel
+// serves 16-byte-aligned buffers and buffers that are only element-aligned (a torch slice x[1:], a shard at an odd offset) -- the
+// reference does the same with loadu + an aligned store stream (kernels_specialized.inl:52-82).  The launcher peels a scalar head so
+// that the STORE stream is 16-byte aligned whenever the packing allows it; the loads simply run misaligned.
 template <bool NT, typename T>
 __device__ __forceinline__ T ld(const T* p) {
-    if constexpr (NT) return __builtin_nontemporal_load(p);
-    else return *p;
+    typedef T unaligned_t __attribute__((aligned(1)));
+    const unaligned_t* q = reinterpret_cast<const unaligned_t*>(p);
+    if constexpr (NT) return __builtin_nontemporal_load(q);
+    else return *q;
 }
 
 // Nothing in these kernels reads the stored bytes back, so the asm forms need no waitcnt bookkeeping (the hardware
@@ -45,8 +52,9 @@ __device__ __forceinline__ T ld(const T* p) {
 // fused requant kernel, which recomputes `res` right after the store, wrote corrupted vectors.
 template <int POLICY, typename T>
 __device__ __forceinline__ void st(T* p, T v) {
+    typedef T unaligned_t __attribute__((aligned(1)));
     if constexpr (POLICY == ST_NT) {
-        __builtin_nontemporal_store(v, p);
+        __builtin_nontemporal_store(v, reinterpret_cast<unaligned_t*>(p));
     } else if constexpr (POLICY == ST_WT) {
         if constexpr (sizeof(T) == 16) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
         else if constexpr (sizeof(T) == 8) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
@@ -54,7 +62,7 @@ __device__ __forceinline__ void st(T* p, T v) {
         else if constexpr (sizeof(T) == 2) asm volatile("global_store_short %0, %1, off sc0 sc1" ::"v"(p), "v"(static_cast<uint32_t>(v)) : "memory");
         else asm volatile("global_store_byte %0, %1, off sc0 sc1" ::"v"(p), "v"(static_cast<uint32_t>(v)) : "memory");
     } else {
-        *p = v;
+        *reinterpret_cast<unaligned_t*>(p) = v;
     }
 }
 
@@ -309,6 +317,22 @@ __device__ __forceinline__ float vec_absmax(const u32x4& raw, float m, bool& nan
     return m;
 }
 
+// The same test for bf16 inputs on the raw words: the magnitude bits of both halves of a dword (raw & 0x7fff7fff) are folded with ONE packed
+// unsigned 16-bit maximum, and bit patterns order like the magnitudes they encode with every NaN above infinity -- so the maximum cannot be
+// poisoned, a NaN anywhere makes the tile's maximum a NaN pattern (the range test then fails like the float form's does), and no float copy
+// of the elements is needed for the test: two integer instructions per two elements instead of a v_max3_f32 + v_cmp_u_f32 on unpacked
+// floats, and -- what matters more -- the unpack of the quantize step is no longer shared with the test, so its {low, high} pairs land in
+// the adjacent registers v_pk_mul_f32 wants (the shared form cost a v_mov_b32 per element).
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t vec_absmax_bits_bf16(const u32x4& raw, uint32_t m) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        m = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, m), __builtin_bit_cast(u16x2, raw[e] & 0x7fff7fffu)));
+    return m;
+}
+// the folded word as the float it stands for: max |x| over the tile, or a NaN if the tile holds one
+__device__ __forceinline__ float absmax_bits_to_float(uint32_t m) { return __uint_as_float(max(m & 0xffffu, m >> 16) << 16); }
+
 // OB = 1, 2, 4 or 8 packed bytes of one input vector to `dst`
 template <int OB, int POLICY>
 __device__ __forceinline__ void store_packed(uint8_t* dst, const uint32_t (&w)[OB > 4 ? 2 : 1]) {
@@ -329,9 +353,23 @@ struct QuantTile {
     static constexpr int64_t BLOCK_ELEMS = static_cast<int64_t>(WAVES) * WAVE_VECS * EPV;
 };
 
-template <int DT_IN, int BITS, int MODE, int U, bool STAGE, int NT, int BLOCK, bool ALLOW_SHORT = true>
+// VAR: experiment switches of the tune harness (tools/tune_kernels.hip `bf16`); production = kQuantVariant (tuning.hpp).
+//   bit 0  bf16 inputs: range test of the short step on the raw words (vec_absmax_bits_bf16) instead of on unpacked floats
+//   bit 1  hot path laid out straight: block 0's head / tail work and the long step are marked unlikely
+enum : int { QV_RAW_RANGE_TEST = 1, QV_STRAIGHT_HOT_PATH = 2 };
+template <int DT_IN, int BITS, int MODE, int U, bool STAGE, int NT, int BLOCK, bool ALLOW_SHORT = true, int VAR = 0>
 __global__ void __launch_bounds__(BLOCK)
-quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t numel, int64_t n_tiles, QuantParams p_arg) {
+quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t numel, int64_t n_tiles, float inv_scale, int32_t zp32,
+                const ParamRecord* dyn, uint32_t flags, uint32_t tile_stride, QuantParams p_arg, int head) {
+    // `in` / `out` / `numel` / the positions in `p_arg` describe the BODY of the call: the launcher has peeled `head` leading elements (a whole
+    // number of packed bytes) so that `out` is 16-byte aligned; block 0 quantizes them through the guarded path below, like the ragged tail.
+    // The nine scalar arguments in front of p_arg are 14 dwords, and those arrive preloaded in SGPRs (Makefile: -amdgpu-kernarg-preload-count;
+    // aggregates are never preloaded): inv_scale / zp32 / dyn repeat fields of p_arg, flags bit 0 says "0 <= zero point <= 2^BITS - 1" (the
+    // host's test of the 64-bit zero point), tile_stride is gridDim.x -- so that a wave's first global loads, the choice between immediate
+    // and device-resident parameters and the short-step decision wait for no s_load of the kernarg segment or of the dispatch packet.
+    p_arg.inv_scale = inv_scale;
+    p_arg.zp32 = zp32;
+    p_arg.dyn = dyn;
     const QuantParams p = resolved(p_arg);
     using T = QuantTile<DT_IN, BITS, U, BLOCK>;
     constexpr int EPV = T::EPV, OB = T::OB;
@@ -344,8 +382,11 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const u32x4* __restrict__ in16 = static_cast<const u32x4*>(in);
-    constexpr bool SHORT_CAPABLE = ALLOW_SHORT;   // every rounding mode has a short step (quantize_vec_short); the launcher decides who uses it
-    [[maybe_unused]] const bool short_ok = SHORT_CAPABLE && p.zp64 >= 0 && p.zp64 <= (1 << BITS) - 1;   // kernel-uniform
+    constexpr bool SHORT_CAPABLE = ALLOW_SHORT && MODE != RM_COPY;   // every rounding mode has a short step (quantize_vec_short); the launcher decides who uses it
+    // kernel-uniform; written so that only the device-resident-parameter path looks at a 64-bit zero point (the immediate one is not preloaded)
+    uint32_t zp_in_range = flags & 1u;
+    if (dyn != nullptr) zp_in_range = dyn->zero_point >= 0 && dyn->zero_point <= (1 << BITS) - 1 ? 1u : 0u;
+    [[maybe_unused]] const bool short_ok = SHORT_CAPABLE && zp_in_range != 0;
     [[maybe_unused]] const BoundedStep bstep = bounded_step_for<DT_IN, BITS>(p.zp32);
     [[maybe_unused]] const float abs_inv = __builtin_fabsf(p.inv_scale);
 
@@ -353,12 +394,19 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
     // few hundred elements; at the end of the last block -- where it used to be -- that microsecond was the end of the kernel (13 632 000
     // elements with 1 024-element tiles: 13.2 us against 12.3 for a tile size that divides the tensor); block 0 starts first and has
     // finished both long before the stream has.
-    if (n_tiles * T::BLOCK_ELEMS < numel && blockIdx.x == 0) {
+    if (__builtin_expect(blockIdx.x == 0, (VAR & QV_STRAIGHT_HOT_PATH) ? 0 : 1)) {
         constexpr int PACK = 8 / BITS;
-        quantize_bytes_guarded<DT_IN, BITS, MODE>(in, out, numel, n_tiles * T::BLOCK_ELEMS / PACK, (numel + PACK - 1) / PACK, p, threadIdx.x, BLOCK);
+        if (n_tiles * T::BLOCK_ELEMS < numel)
+            quantize_bytes_guarded<DT_IN, BITS, MODE>(in, out, numel, n_tiles * T::BLOCK_ELEMS / PACK, (numel + PACK - 1) / PACK, p, threadIdx.x, BLOCK);
+        if (head > 0) {   // the scalar head in front of an output that is not 16-byte aligned (the reference's own shape, kernels_specialized.inl:52-56)
+            QuantParams ph = p;
+            ph.index_base -= static_cast<uint64_t>(head);
+            ph.ref_index0 -= head;
+            quantize_bytes_guarded<DT_IN, BITS, MODE>(static_cast<const uint8_t*>(in) - static_cast<int64_t>(head) * (DT_IN == DT_F32 ? 4 : 2), out - head / PACK,
+                                                      head, 0, head / PACK, ph, threadIdx.x, BLOCK);
+        }
     }
 
-    const int64_t tile_stride = gridDim.x;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += tile_stride) {
         const int64_t v0 = (tile * T::WAVES + wave) * T::WAVE_VECS;   // first input vector of this wave tile
 
@@ -375,11 +423,18 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
         bool short_step = false;
         if constexpr (SHORT_CAPABLE) {
             if (short_ok) {
-                float amax = 0.0f;
-                bool nan = false;
+                if constexpr (DT_IN == DT_BF16 && (VAR & QV_RAW_RANGE_TEST) != 0) {
+                    uint32_t m = 0;
 #pragma unroll
-                for (int k = 0; k < U; ++k) amax = vec_absmax<DT_IN>(raw[k], amax, nan);
-                short_step = __all(!nan && __fmul_rn(amax, abs_inv) < 1.0e9f ? 1 : 0) != 0;
+                    for (int k = 0; k < U; ++k) m = vec_absmax_bits_bf16(raw[k], m);
+                    short_step = __all(__fmul_rn(absmax_bits_to_float(m), abs_inv) < 1.0e9f ? 1 : 0) != 0;   // false for a NaN maximum
+                } else {
+                    float amax = 0.0f;
+                    bool nan = false;
+#pragma unroll
+                    for (int k = 0; k < U; ++k) amax = vec_absmax<DT_IN>(raw[k], amax, nan);
+                    short_step = __all(!nan && __fmul_rn(amax, abs_inv) < 1.0e9f ? 1 : 0) != 0;
+                }
             }
         }
         uint8_t* o = out + v0 * OB;                                    // output of this wave tile
@@ -420,7 +475,16 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
                 __builtin_amdgcn_wave_barrier();
             }
         };
-        if (short_step) {
+        if constexpr (MODE == RM_COPY) {   // tune harness: the kernel without its arithmetic
+            uint32_t w[U][WORDS];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                w[k][0] = raw[k][0] ^ raw[k][1];
+                w[k][WORDS - 1] = raw[k][2] ^ raw[k][3];
+                if constexpr (WORDS == 1) w[k][0] = raw[k][0] ^ raw[k][1] ^ raw[k][2] ^ raw[k][3];
+            }
+            put(w);
+        } else if (__builtin_expect(short_step, 1)) {
             uint32_t w[U][WORDS];
 #pragma unroll
             for (int k = 0; k < U; ++k) quantize_vec_short<DT_IN, BITS, MODE>(raw[k], p, keys, static_cast<uint64_t>(v0 + k * 64 + lane) * EPV, bstep, w[k]);
@@ -433,6 +497,15 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
         }
     }
 
+}
+
+// Host side of the argument convention above: one place that knows which fields travel as preloaded scalars.
+template <int DT_IN, int BITS, int MODE, int U, bool STAGE, int NT, int BLOCK, bool ALLOW_SHORT = true, int VAR = 0>
+inline void launch_quantize_kernel(unsigned grid, unsigned dyn_lds, hipStream_t stream, const void* in, uint8_t* out, int64_t numel, int64_t n_tiles, const QuantParams& p,
+                                   int head) {
+    const uint32_t flags = p.zp64 >= 0 && p.zp64 <= (1 << BITS) - 1 ? 1u : 0u;
+    hipLaunchKernelGGL((quantize_kernel<DT_IN, BITS, MODE, U, STAGE, NT, BLOCK, ALLOW_SHORT, VAR>), dim3(grid), dim3(BLOCK), dyn_lds, stream, in, out, numel, n_tiles,
+                       p.inv_scale, p.zp32, p.dyn, flags, grid, p, head);
 }
 
 }  // namespace pq

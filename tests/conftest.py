@@ -19,6 +19,7 @@ GOLDEN = Path(__file__).resolve().parent / "golden"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a ROCm GPU (MI355X); deselected by -m 'not gpu'")
+    config.addinivalue_line("markers", "slow: takes minutes (eight bench.py ranks sharing the GPU); still part of -m gpu")
 
 
 @pytest.fixture(scope="session")

@@ -337,6 +337,69 @@ def test_misaligned_device_pointers(ctx, O, off_in, off_out):
         assert same_floats(got, O.dequantize(q, 4, dt_f, n, 0.02, 9, 1, out=p.copy()))
 
 
+# Round 3: buffers that are only element-aligned run through the VECTOR kernels (misaligned 16-byte loads; a scalar head peeled by block 0 so
+# that the store stream is aligned, or misaligned stores where the head would not be a whole packed byte) -- reference shape:
+# kernels_specialized.inl:52-82.  Every pair, both ops, both rounding modes, sizes around the tile edges, the offsets a torch slice produces.
+@pytest.mark.parametrize("off_in,off_out", [(4, 0), (0, 4), (4, 4), (8, 1), (2, 15), (12, 8), (6, 2)])
+def test_misaligned_pointers_take_the_vector_path_bit_exact(ctx, O, off_in, off_out):
+    rng = np.random.default_rng(1000 + off_in * 16 + off_out)
+    for n in (15, 16, 17, 100, 4096 + 15, 8192 + 16, 70_001, 1_000_003):
+        x = rng.uniform(-1, 1, n).astype(np.float32)
+        if n > 50:
+            x[rng.choice(n, 5, replace=False)] = [np.nan, np.inf, -1e30, 3e9, 0.0]
+        for dt_in, xin in ((0, x), (1, O.f32_to_bf16(x))):
+            esize = 4 if dt_in == 0 else 2
+            oi = off_in - off_in % esize           # a float array is at least element-aligned
+            for dt_out, qmax in ((4, 255), (3, 15), (2, 3)):
+                scale = float(np.float32(2.0 / qmax))
+                for rm, tau in ((0, 0.0), (1, 0.3)):
+                    ctx.set_stochastic_threshold(tau if rm else None)
+                    got = gpu_quantize(ctx, xin, dt_in, dt_out, scale, qmax // 2, rm, offset_in=oi, offset_out=off_out)
+                    want = O.quantize(xin, dt_in, dt_out, scale, qmax // 2, rm, tau, form=O.FORM_UNIFORM)
+                    assert np.array_equal(got, want), (n, dt_in, dt_out, rm, np.nonzero(got != want)[0][:5])
+        ctx.set_stochastic_threshold(None)
+        prev = rng.uniform(-1, 1, n).astype(np.float32)
+        for dt_q in (4, 3, 2):
+            q = rng.integers(0, 256, O.packed_numel(n, dt_q)).astype(np.uint8)
+            for dt_f in (0, 1):
+                esize = 4 if dt_f == 0 else 2
+                oo = off_out - off_out % esize
+                pv = prev if dt_f == 0 else O.f32_to_bf16(prev)
+                for op in (0, 1):
+                    got = gpu_dequantize(ctx, q, dt_q, dt_f, n, 0.02, 9, op, prev=pv, offset_in=off_in, offset_out=oo)
+                    assert same_floats(got, O.dequantize(q, dt_q, dt_f, n, 0.02, 9, op, out=pv.copy())), (n, dt_q, dt_f, op)
+
+
+def test_misaligned_minmax_scan(ctx, O):
+    import piquant
+    import torch
+
+    rng = np.random.default_rng(5)
+    for n in (7, 1000, 1_000_003):
+        x = rng.uniform(-3, 3, n).astype(np.float32)
+        for dt, xin, off in ((piquant.DataType.F32, x, 4), (piquant.DataType.F32, x, 12), (piquant.DataType.BF16, O.f32_to_bf16(x), 2), (piquant.DataType.BF16, O.f32_to_bf16(x), 10)):
+            keep, ptr = to_device(xin, off)
+            assert ptr % 16 == off
+            keys = torch.empty(2, dtype=torch.int32, device="cuda")
+            ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            ctx.minmax_keys_ptr(ptr, dt, n, keys.data_ptr(), init=True)
+            k = keys.cpu()
+            xf = xin if xin.dtype == np.float32 else O.bf16_to_f32(xin)
+            assert piquant.decode_minmax_keys(int(k[0]), int(k[1])) == (float(xf.min()), float(xf.max()))
+            del keep
+
+
+def test_misaligned_full_size_slice_of_a_tensor(ctx, O, big_x):
+    """x[1:] of the BASELINE tensor (4-byte-aligned input) and an output that starts 3 bytes into its buffer, at N1 - 1 elements: bit-exact."""
+    x = big_x[1:]
+    scale, zp = O.compute_quant_params(big_x, O.F32, O.UINT8)
+    got = gpu_quantize(ctx, x, 0, 4, scale, zp, 0, offset_in=4, offset_out=3)
+    want = O.quantize(x, 0, 4, scale, zp)
+    assert np.array_equal(got, want)
+    back = gpu_dequantize(ctx, want, 4, 0, x.size, scale, zp, 0, offset_in=3, offset_out=4)
+    assert same_floats(back, O.dequantize(want, 4, 0, x.size, scale, zp, 0))
+
+
 def test_host_pointers_are_staged_through_the_gpu(ctx, O):
     """The reference's callers pass host memory; the drop-in stages it over PCIe in 2^24-element chunks."""
     rng = np.random.default_rng(77)

@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Median / min over the interleaved passes of a tools/tune_kernels CSV, one line per variant."""
+import csv
+import statistics
+import sys
+from collections import OrderedDict
+
+rows = OrderedDict()
+with open(sys.argv[1]) as f:
+    for r in csv.reader(f):
+        if len(r) < 4 or r[0] in ("family",) or r[0].startswith("#"):
+            continue
+        try:
+            rows.setdefault((r[0], r[1]), []).append((float(r[2]), float(r[3])))
+        except ValueError:
+            pass
+print(f"{'family':12s} {'variant':96s} {'med us':>8s} {'min us':>8s} {'GB/s(med)':>10s} {'frac':>6s}  n")
+for (fam, var), v in rows.items():
+    us = [a for a, _ in v]
+    med = statistics.median(us)
+    gbs = v[0][1] * v[0][0] / med
+    print(f"{fam:12s} {var:96s} {med:8.3f} {min(us):8.3f} {gbs:10.1f} {gbs / 8000:6.3f}  {len(us)}")

@@ -214,14 +214,75 @@ static void run_quant(const Bufs& b, int64_t numel, int num_cu, double bytes_per
         int64_t g = cap == 0 ? n_tiles : std::min<int64_t>(n_tiles, static_cast<int64_t>(cap) * num_cu);
         const unsigned grid = static_cast<unsigned>(std::max<int64_t>(g, 1));
         const double us = time_us([&](int i) {
-            hipLaunchKernelGGL((quantize_kernel<DT_IN, BITS, MODE, U, STAGE, NT, BLOCK, ALLOW_SHORT>), dim3(grid), dim3(BLOCK), g_dyn_lds, g_stream, b.in[i % SETS],
-                               static_cast<uint8_t*>(b.out[i % SETS]), numel, n_tiles, p);
+            launch_quantize_kernel<DT_IN, BITS, MODE, U, STAGE, NT, BLOCK, ALLOW_SHORT>(grid, g_dyn_lds, g_stream, b.in[i % SETS], static_cast<uint8_t*>(b.out[i % SETS]), numel, n_tiles, p, 0);
         });
         char name[160];
         std::snprintf(name, sizeof name, "in=%s bits=%d mode=%d U=%d stage=%d nt=%d block=%d short=%d lds=%u cap=%d grid=%u", DT_IN == DT_F32 ? "f32" : "bf16", BITS, MODE, U,
                       STAGE ? 1 : 0, NT, BLOCK, ALLOW_SHORT ? 1 : 0, g_dyn_lds, cap, grid);
         report("quantize", name, us, bytes_per_elem * numel);
     }
+}
+
+// U(-1,1) rounded to bf16 (the harness' fp32 buffers reinterpreted as bf16 hold random exponents -- NaNs in nearly every tile, so every tile
+// takes the long step: not what a bf16 tensor looks like)
+__global__ void fill_uniform_bf16(uint16_t* p, int64_t n, uint32_t seed) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t h = mix32(static_cast<uint32_t>(i) ^ seed);
+        p[i] = static_cast<uint16_t>(f32_to_bf16_bits(static_cast<float>(h >> 8) * (2.0f / 16777216.0f) - 1.0f));
+    }
+}
+
+// Round 3: the production kernel, one tile per block, with parameters that let the short step run (zero point inside the range of the
+// output type), optional byte offsets of both buffers (misaligned pointers: the launcher's head peel is repeated here) and the VAR switches.
+// MODE = RM_COPY is the same kernel with no arithmetic: the ceiling for this traffic, tile shape and store policy.
+template <int DT_IN, int BITS, int MODE, int U, bool STAGE, int NT, int BLOCK, int VAR>
+static void run_quant3(const Bufs& b, int64_t numel, double bytes_per_elem, int off_in = 0, int off_out = 0, bool peel = true) {
+    using T = QuantTile<DT_IN, BITS, U, BLOCK>;
+    constexpr int PACK = 8 / BITS, ESIZE = DT_IN == DT_F32 ? 4 : 2, QMAX = (1 << BITS) - 1;
+    QuantParams p {};
+    p.inv_scale = 1.0f / (2.0f / QMAX);
+    p.zp32 = QMAX / 2;
+    p.zp64 = QMAX / 2;
+    p.threshold = 0.37f;
+    const int64_t head_bytes = peel ? (16 - off_out % 16) % 16 : 0, head = head_bytes * PACK;
+    const int64_t body = numel - head, n_tiles = body / T::BLOCK_ELEMS;
+    const unsigned grid = static_cast<unsigned>(std::max<int64_t>(n_tiles, 1));
+    QuantParams pb = p;
+    pb.index_base += head;
+    const double us = time_us([&](int i) {
+        launch_quantize_kernel<DT_IN, BITS, MODE, U, STAGE, NT, BLOCK, true, VAR>(grid, 0, g_stream, static_cast<const uint8_t*>(b.in[i % SETS]) + off_in + head * ESIZE,
+                                                                                 static_cast<uint8_t*>(b.out[i % SETS]) + off_out + head_bytes, body, n_tiles, pb,
+                                                                                 static_cast<int>(head));
+    });
+    char name[200];
+    std::snprintf(name, sizeof name, "in=%s bits=%d mode=%s U=%d block=%d nt=%d var=%d off_in=%d off_out=%d head=%d", DT_IN == DT_F32 ? "f32" : "bf16", BITS,
+                  MODE == RM_COPY ? "copy" : (MODE == RM_NEAREST_FAST || MODE == RM_NEAREST_I64 ? "nearest" : "stochastic"), U, BLOCK, NT, VAR, off_in, off_out,
+                  static_cast<int>(head));
+    report("quantize3", name, us, bytes_per_elem * numel);
+}
+
+template <int BITS, int DT_OUT, int OP, int U, bool STAGE, int NT, int BLOCK>
+static void run_dequant3(const Bufs& b, int64_t numel, double bytes_per_elem, int off_in, int off_out, bool peel) {
+    using T = DequantTile<BITS, DT_OUT, U, BLOCK>;
+    constexpr int PACK = 8 / BITS, ESIZE = DT_OUT == DT_F32 ? 4 : 2, QMAX = (1 << BITS) - 1;
+    DequantParams p {};
+    p.scale = 2.0f / QMAX;
+    p.zp32 = QMAX / 2;
+    p.zp64 = QMAX / 2;
+    p.bias = -static_cast<float>(p.zp32) * p.scale;
+    int64_t head = peel ? ((16 - off_out % 16) % 16) / ESIZE : 0;
+    if (head % PACK != 0) head = 0;
+    const int64_t body = numel - head, n_tiles = body / T::BLOCK_ELEMS;
+    const unsigned grid = static_cast<unsigned>(std::max<int64_t>(n_tiles, 1));
+    const double us = time_us([&](int i) {   // roles swapped: the small buffer (b.out) is the packed input, the big one (b.in) the float output
+        launch_dequantize_kernel<BITS, DT_OUT, OP, U, STAGE, NT, BLOCK>(grid, g_stream, static_cast<const uint8_t*>(b.out[i % SETS]) + off_in + head / PACK,
+                                                                        static_cast<uint8_t*>(b.in[i % SETS]) + off_out + head * ESIZE, body, n_tiles, p, static_cast<int>(head));
+    });
+    char name[200];
+    std::snprintf(name, sizeof name, "bits=%d out=%s op=%s U=%d block=%d nt=%d off_in=%d off_out=%d head=%d", BITS, DT_OUT == DT_F32 ? "f32" : "bf16", OP == OP_ADD ? "add" : "set",
+                  U, BLOCK, NT, off_in, off_out, static_cast<int>(head));
+    report("dequantize3", name, us, bytes_per_elem * numel);
 }
 
 template <int BITS, int DT_OUT, int OP, int U, bool STAGE, int NT, int BLOCK>
@@ -238,8 +299,7 @@ static void run_dequant(const Bufs& b, int64_t numel, int num_cu, double bytes_p
         const unsigned grid = static_cast<unsigned>(std::max<int64_t>(g, 1));
         // roles swapped: the small buffer (b.out) is the packed input, the big one (b.in) the float output
         const double us = time_us([&](int i) {
-            hipLaunchKernelGGL((dequantize_kernel<BITS, DT_OUT, OP, U, STAGE, NT, BLOCK>), dim3(grid), dim3(BLOCK), 0, g_stream,
-                               static_cast<const uint8_t*>(b.out[i % SETS]), b.in[i % SETS], numel, n_tiles, p);
+            launch_dequantize_kernel<BITS, DT_OUT, OP, U, STAGE, NT, BLOCK>(grid, g_stream, static_cast<const uint8_t*>(b.out[i % SETS]), b.in[i % SETS], numel, n_tiles, p, 0);
         });
         char name[160];
         std::snprintf(name, sizeof name, "bits=%d out=%s op=%d U=%d stage=%d nt=%d block=%d cap=%d grid=%u", BITS, DT_OUT == DT_F32 ? "f32" : "bf16", OP, U,
@@ -335,8 +395,7 @@ static void run_fused(const Bufs& b, const FusedBufs& f, int64_t numel, int num_
         pd.dyn = f.rec_ref;
         using T = QuantTile<DT_F32, 8, 2, 128>;
         const int64_t n_tiles = numel / T::BLOCK_ELEMS;
-        hipLaunchKernelGGL((quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, 2, true, mem_policy(true, ST_WT), 128>), dim3(static_cast<unsigned>(std::max<int64_t>(n_tiles, 1))),
-                           dim3(128), 0, g_stream, static_cast<const void*>(b.in[0]), f.out_ref, numel, n_tiles, pd);
+        launch_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, 2, true, mem_policy(true, ST_WT), 128>(static_cast<unsigned>(std::max<int64_t>(n_tiles, 1)), 0, g_stream, static_cast<const void*>(b.in[0]), f.out_ref, numel, n_tiles, pd, 0);
         CK(hipStreamSynchronize(g_stream));
         std::vector<uint8_t> a(numel), c(numel);
         ParamRecord ra, rc;
@@ -421,6 +480,7 @@ int main(int argc, char** argv) {
     std::fprintf(stderr, "device %s, %d CUs, numel %lld, reps %d\n", prop.name, num_cu, static_cast<long long>(numel), g_reps);
 
     SETS = static_cast<int>(std::min<int64_t>(1024, std::max<int64_t>(12, (1640000000ll + 5 * numel - 1) / (5 * numel))));
+    if (const char* e = std::getenv("TUNE_SETS")) SETS = std::max(1, std::atoi(e));
     std::fprintf(stderr, "%d buffer sets in rotation (%.2f GB)\n", SETS, 5.0 * numel * SETS / 1e9);
     Bufs b {};
     b.in.resize(SETS);
@@ -498,6 +558,87 @@ int main(int argc, char** argv) {
         run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, 5, 128>(b, numel, num_cu, 5);
         run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, 5, 64>(b, numel, num_cu, 5);
         run_quant<DT_F32, 8, RM_NEAREST_FAST, 8, true, 5, 64>(b, numel, num_cu, 5);
+    }
+    if (only == "bf16") {
+        // Round 3: the bf16-input quantizers against a copy with their exact traffic.  numel = bf16 elements (default 27 264 000 = config 3:
+        // 54.5 MB in, 13.6 MB out for uint4); run with TUNE_SETS=40 so that 2.7 GB (545 MB of output) rotate.  Every variant is the production
+        // kernel template; "copy" has no arithmetic (RM_COPY), var = QV_* switches.  Interleaved passes, one timed batch each.
+        for (int s_ = 0; s_ < SETS; ++s_)
+            hipLaunchKernelGGL(fill_uniform_bf16, dim3(4096), dim3(256), 0, g_stream, static_cast<uint16_t*>(b.in[s_]), numel, 0x9e3779b9u * (s_ + 1));
+        CK(hipStreamSynchronize(g_stream));
+        g_rounds = 1;
+        for (int pass = 0; pass < 6; ++pass) {
+#define ROW(BITS, MODE, U_, BLK, BPE)                                                       \
+    run_quant3<DT_BF16, BITS, RM_COPY, U_, true, 5, BLK, 0>(b, numel, BPE);                 \
+    run_quant3<DT_BF16, BITS, MODE, U_, true, 5, BLK, 0>(b, numel, BPE);                    \
+    run_quant3<DT_BF16, BITS, MODE, U_, true, 5, BLK, 1>(b, numel, BPE);                    \
+    run_quant3<DT_BF16, BITS, MODE, U_, true, 5, BLK, 3>(b, numel, BPE);
+            ROW(4, RM_NEAREST_FAST, 2, 64, 2.5)
+            ROW(4, RM_STOCH_CALL, 2, 64, 2.5)
+            ROW(8, RM_NEAREST_FAST, 2, 64, 3.0)
+            ROW(8, RM_STOCH_CALL, 2, 64, 3.0)
+            ROW(2, RM_NEAREST_FAST, 4, 256, 2.25)
+            ROW(2, RM_STOCH_CALL, 4, 256, 2.25)
+            // other tiles for config 3, copy and best variant
+            ROW(4, RM_NEAREST_FAST, 4, 64, 2.5)
+            ROW(4, RM_NEAREST_FAST, 2, 128, 2.5)
+            ROW(4, RM_NEAREST_FAST, 4, 256, 2.5)
+            ROW(4, RM_NEAREST_FAST, 1, 64, 2.5)
+            ROW(2, RM_NEAREST_FAST, 2, 64, 2.25)
+#undef ROW
+            run_quant3<DT_BF16, 4, RM_COPY, 2, true, 3, 64, 0>(b, numel, 2.5);   // non-temporal stores
+            run_quant3<DT_BF16, 4, RM_NEAREST_FAST, 2, true, 3, 64, 3>(b, numel, 2.5);
+        }
+        g_rounds = 3;
+    }
+    if (only == "f32var") {
+        // fp32 inputs: copy ceiling and the VAR switches (bit 0 does nothing for fp32; bit 1 is the code layout)
+        g_rounds = 1;
+        for (int pass = 0; pass < 6; ++pass) {
+            run_quant3<DT_F32, 8, RM_COPY, 2, true, 5, 128, 0>(b, numel, 5);
+            run_quant3<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 128, 0>(b, numel, 5);
+            run_quant3<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 128, 2>(b, numel, 5);
+            run_quant3<DT_F32, 8, RM_STOCH_CALL, 2, true, 5, 128, 0>(b, numel, 5);
+            run_quant3<DT_F32, 8, RM_STOCH_CALL, 2, true, 5, 128, 2>(b, numel, 5);
+            run_quant3<DT_F32, 4, RM_COPY, 2, true, 5, 64, 0>(b, numel, 4.5);
+            run_quant3<DT_F32, 4, RM_NEAREST_FAST, 2, true, 5, 64, 0>(b, numel, 4.5);
+            run_quant3<DT_F32, 4, RM_NEAREST_FAST, 2, true, 5, 64, 2>(b, numel, 4.5);
+            run_quant3<DT_F32, 2, RM_COPY, 2, true, 5, 64, 0>(b, numel, 4.25);
+            run_quant3<DT_F32, 2, RM_NEAREST_I64, 2, true, 5, 64, 0>(b, numel, 4.25);
+            run_quant3<DT_F32, 2, RM_NEAREST_I64, 2, true, 5, 64, 2>(b, numel, 4.25);
+        }
+        g_rounds = 3;
+    }
+    if (only == "mis") {
+        // Round 3: buffers that are not 16-byte aligned, through the vector kernels (round 2 sent them to a one-byte-per-thread kernel).
+        // off_in / off_out in bytes; head = elements peeled in front so that the store stream is aligned (0 with peel off: misaligned stores)
+        g_rounds = 1;
+        for (int pass = 0; pass < 5; ++pass) {
+            run_quant3<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 128, 3>(b, numel - 64, 5, 0, 0);
+            run_quant3<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 128, 3>(b, numel - 64, 5, 4, 0);       // x[1:] -> fresh output
+            run_quant3<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 128, 3>(b, numel - 64, 5, 4, 1);       // both off: head of 15 bytes
+            run_quant3<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 128, 3>(b, numel - 64, 5, 4, 1, false);   // same, no peel: misaligned 16-byte stores
+            run_quant3<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 128, 3>(b, numel - 64, 5, 0, 8);
+            run_quant3<DT_F32, 4, RM_NEAREST_FAST, 2, true, 5, 64, 3>(b, numel - 64, 4.5, 4, 3);
+            run_dequant3<8, DT_F32, OP_SET, 2, true, 5, 128>(b, numel - 64, 5, 0, 0, true);
+            run_dequant3<8, DT_F32, OP_SET, 2, true, 5, 128>(b, numel - 64, 5, 1, 0, true);            // q[1:] -> fresh output
+            run_dequant3<8, DT_F32, OP_SET, 2, true, 5, 128>(b, numel - 64, 5, 1, 4, true);            // into out[1:]: head 3
+            run_dequant3<8, DT_F32, OP_SET, 2, true, 5, 128>(b, numel - 64, 5, 1, 4, false);           // same, misaligned stores
+            run_dequant3<8, DT_F32, OP_ADD, 2, true, 5, 128>(b, numel - 64, 9, 0, 0, true);
+            run_dequant3<8, DT_F32, OP_ADD, 2, true, 5, 128>(b, numel - 64, 9, 1, 4, true);
+            run_dequant3<8, DT_F32, OP_ADD, 2, true, 5, 128>(b, numel - 64, 9, 1, 4, false);
+            run_dequant3<4, DT_F32, OP_SET, 4, true, 5, 256>(b, numel - 64, 4.5, 1, 4, true);          // uint4 -> out[1:]: head 3 is not a whole byte -> misaligned stores
+        }
+        g_mm_caps = {1};
+        for (int pass = 0; pass < 5; ++pass) {
+            run_minmax<DT_F32, 4, true, 512, true>(b, numel - 64, num_cu, keys);
+            Bufs shifted = b;
+            for (auto& q : shifted.in) q = static_cast<uint8_t*>(q) + 4;
+            run_minmax<DT_F32, 4, true, 512, true>(shifted, numel - 64, num_cu, keys);
+            std::printf("# previous row: input pointers + 4 bytes\n");
+        }
+        g_mm_caps = {1, 2, 4, 8, 16, 32};
+        g_rounds = 3;
     }
     if (only == "finals") {
         // interleaved A/B of the finalists: 6 passes over the list, one timed batch each (noise shows as spread)
@@ -637,8 +778,7 @@ int main(int argc, char** argv) {
             using T = QuantTile<DT_F32, 8, 2, 1024>;
             const int64_t nt = n / T::BLOCK_ELEMS;
             const double us = time_us([&](int i) {
-                hipLaunchKernelGGL((quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, 2, true, 3, 1024>), dim3(static_cast<unsigned>(nt)), dim3(1024), 0, g_stream,
-                                   b.in[i % SETS], static_cast<uint8_t*>(b.out[i % SETS]), n, nt, p);
+                launch_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, 2, true, 3, 1024>(static_cast<unsigned>(nt), 0, g_stream, b.in[i % SETS], static_cast<uint8_t*>(b.out[i % SETS]), n, nt, p, 0);
             });
             report("size", "f32->u8 U=2 block=1024 numel=" + std::to_string(n), us, 5.0 * n);
         }
@@ -655,8 +795,7 @@ int main(int argc, char** argv) {
                 CK(hipEventRecord(e0, g_stream));
                 CK(hipStreamWaitEvent(s2, e0, 0));
                 for (int i = 0; i < g_reps; ++i)
-                    hipLaunchKernelGGL((quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, 2, true, 3, 1024>), dim3(static_cast<unsigned>(nt)), dim3(1024), 0,
-                                       (i & 1) ? s2 : g_stream, b.in[i % SETS], static_cast<uint8_t*>(b.out[i % SETS]), numel, nt, p);
+                    launch_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, 2, true, 3, 1024>(static_cast<unsigned>(nt), 0, (i & 1) ? s2 : g_stream, b.in[i % SETS], static_cast<uint8_t*>(b.out[i % SETS]), numel, nt, p, 0);
                 CK(hipEventRecord(j, s2));
                 CK(hipStreamWaitEvent(g_stream, j, 0));
                 CK(hipEventRecord(e1, g_stream));
@@ -933,8 +1072,7 @@ int main(int argc, char** argv) {
         const double us = time_us([&](int i) {                                                                                                             \
             hipLaunchKernelGGL((minmax_kernel<DT_F32, 4, SCAN_NT, 512, true>), dim3(num_cu), dim3(512), 0, g_stream, static_cast<const void*>(b.in[i % SETS]),  \
                                numel, keys, MinmaxEpilogue {EP_PARAMS, 8, 0u, rec});                                                                       \
-            hipLaunchKernelGGL((quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, 2, true, mem_policy(Q_NT, ST_WT), 128>), dim3(qgrid), dim3(128), 0, g_stream,    \
-                               static_cast<const void*>(b.in[i % SETS]), static_cast<uint8_t*>(b.out[i % SETS]), numel, n_tiles, pd);                        \
+            launch_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, 2, true, mem_policy(Q_NT, ST_WT), 128>(qgrid, 0, g_stream, static_cast<const void*>(b.in[i % SETS]), static_cast<uint8_t*>(b.out[i % SETS]), numel, n_tiles, pd, 0);                        \
         });                                                                                                                                                \
         report("pair", LABEL, us, 9.0 * numel);                                                                                                            \
     }
@@ -970,8 +1108,7 @@ int main(int argc, char** argv) {
             const double us = time_us([&](int i) {
                 hipLaunchKernelGGL((minmax_kernel<DT_F32, 4, true, 256, kMinmaxGatherEnd>), dim3(2 * num_cu), dim3(256), 0, g_stream, static_cast<const void*>(b.in[i % SETS]), numel,
                                    keys, MinmaxEpilogue {EP_PARAMS, 8, 0u, f.rec_ref});
-                hipLaunchKernelGGL((quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, 2, true, mem_policy(true, ST_WT), 128>), dim3(static_cast<unsigned>(std::max<int64_t>(n_tiles, 1))),
-                                   dim3(128), 0, g_stream, static_cast<const void*>(b.in[i % SETS]), static_cast<uint8_t*>(b.out[i % SETS]), numel, n_tiles, pd);
+                launch_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, 2, true, mem_policy(true, ST_WT), 128>(static_cast<unsigned>(std::max<int64_t>(n_tiles, 1)), 0, g_stream, static_cast<const void*>(b.in[i % SETS]), static_cast<uint8_t*>(b.out[i % SETS]), numel, n_tiles, pd, 0);
             });
             report("fused", "f32->u8 two launches (scan with parameter epilogue, quantize)", us, 9.0 * numel);
         }
