@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--numel", type=int, default=NUMEL)
+    ap.add_argument("--windows", type=int, default=25, help="timed windows of --steps steps each; `value` is the median window")
     ap.add_argument("--sets", type=int, default=24, help="distinct buffer sets rotated through at N=1 (24 x 136 MB = 3.3 GB, see COLD_SETS); N>1 keeps the same bytes per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
@@ -64,13 +65,13 @@ def parse():
     return ap.parse_args()
 
 
-def time_loop(fn, steps, stream):
-    """Enqueue `steps` calls of fn(i) on `stream`; returns (wall seconds, HIP-event seconds)."""
+def time_loop(fn, steps, stream, base=0):
+    """Enqueue `steps` calls fn(base) .. fn(base + steps - 1) on `stream`; returns (wall seconds, HIP-event seconds)."""
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     e0.record(stream)
-    for i in range(steps):
+    for i in range(base, base + steps):
         fn(i)
     e1.record(stream)
     while not e1.query():      # busy-wait for the last step: a sleeping hipDeviceSynchronize wakes up tens of microseconds late,
@@ -122,85 +123,127 @@ def host_cpu_order():
     return order + later, per_socket, len(first), len(sockets)
 
 
-def cpu_baseline(x_host: np.ndarray, scale: float, zp: int, budget_s: float, nsets: int):
-    """The reference's own AVX kernels (oracle/_ref, prebuilt from the reference sources) on this box's host cores.
+class _RefBackend:
+    """the reference's own kernel units (oracle/_ref, compiled from the reference sources by oracle/Makefile) behind the rotation protocol"""
+    kind = "reference"
 
-    Same protocol as the GPU side: calls rotate over `nsets` distinct input/output buffer sets (818 MB for 6 sets,
-    more than the host's last-level cache) so the figure is a DRAM figure, not an L3 one; the cache-resident
-    single-buffer figure is reported separately.  NUMA-fair: workers are pinned (one per physical core, socket by socket), and for
-    every thread count the buffers are allocated fresh and each partition is first touched by the worker that will process it, so
-    every worker streams from the memory of its own socket.  Falls back to the scalar C oracle where _ref is absent."""
+    def __init__(self):
+        import oracle as O
+
+        self.O, self.R = O, O.Ref()
+        self.isa = self.R.best_isa()
+        built_here = Path("/root/reference").exists()
+        self.what = (f"reference {self.R.isa_name(self.isa)} kernels (oracle/_ref: the reference's kernel translation units compiled from its sources, "
+                     f"{'built on this box' if built_here else 'shipped prebuilt with the repository snapshot -- /root/reference does not exist here'}), "
+                     "static range split (the reference's partition rule, src/piquant.cpp:145-157) over a persistent std::thread pool standing in for its un-vendored thread pool")
+
+    def place(self, x_host, threads, order, nsets):
+        self.R.set_pinning(order[:threads])
+        self.threads = threads
+        return [self.R.partition_copy(x_host, np.empty_like(x_host), threads) for _ in range(nsets)]
+
+    def quantize(self, xin, out, scale, zp):
+        self.R.quantize(xin, self.O.F32, self.O.UINT8, scale, zp, isa=self.isa, threads=self.threads, out=out)
+
+    def done(self):
+        self.R.set_pinning([])
+
+
+class _PortBackend:
+    """libpiquant_cpu.so: this repository's own AVX-512 restatement (pi-quant_amd/csrc/cpu), reproducible from a clean checkout"""
+    kind = "port"
+
+    def __init__(self, max_threads):
+        from piquant import cpu
+
+        self.cpu = cpu
+        self.ctx = cpu.CpuContext(max_threads)
+        self.what = ("libpiquant_cpu.so, this repository's own " + ("AVX-512" if cpu.has_avx512() else "scalar (host without AVX-512)") +
+                     " restatement of the path (pi-quant_amd/csrc/cpu; bit-equal to the reference's kernels, tests/test_cpu_path.py), "
+                     "static range split (src/piquant.cpp:145-157) over its persistent pool")
+
+    def place(self, x_host, threads, order, nsets):
+        self.ctx.set_active_threads(threads)
+        self.ctx.set_affinity(order[:threads])
+        ins = []
+        for _ in range(nsets):
+            dst = np.empty_like(x_host)
+            self.ctx.partition_copy_ptr(x_host.ctypes.data, dst.ctypes.data, 0, x_host.size)
+            ins.append(dst)
+        return ins
+
+    def quantize(self, xin, out, scale, zp):
+        self.ctx.quantize_ptr(xin.ctypes.data, 0, out.ctypes.data, 4, xin.size, scale, zp)
+
+    def done(self):
+        self.ctx.set_affinity([])
+        self.ctx.close()
+
+
+def _cpu_rotation(backend, x_host, scale, zp, budget_s, nsets, counts, order):
+    """best mean-per-call over whole rotations through `nsets` buffer sets, for every thread count; NUMA-fair: workers pinned (one per
+    physical core, socket by socket), buffers allocated fresh per count and every partition first touched by the worker that processes it"""
+    n = x_host.size
+    gib = n * 4 / 2**30
+    per = budget_s / (len(counts) + 1)
+    times = {}
+    for t in counts:
+        ins = backend.place(x_host, t, order, nsets)
+        outs = [np.empty(n, dtype=np.uint8) for _ in range(nsets)]    # untouched: first written by the workers in the first rotation
+        best, t_end, rounds = float("inf"), time.perf_counter() + per, 0
+        while rounds < 3 or time.perf_counter() < t_end:
+            t0 = time.perf_counter()
+            for k in range(nsets):
+                backend.quantize(ins[k], outs[k], scale, zp)
+            if rounds > 0:           # the first rotation faults the output pages in
+                best = min(best, (time.perf_counter() - t0) / nsets)
+            rounds += 1
+        times[t] = best
+        del ins, outs
+    best_t = min(times, key=times.get)
+    ins = backend.place(x_host, best_t, order, 1)
+    out = np.empty(n, dtype=np.uint8)
+    hot, t_end = float("inf"), time.perf_counter() + per      # cache-resident variant: one buffer set, best single call
+    while time.perf_counter() < t_end:
+        t0 = time.perf_counter()
+        backend.quantize(ins[0], out, scale, zp)
+        hot = min(hot, time.perf_counter() - t0)
+    backend.done()
+    return {"value": round(gib / times[best_t], 3), "unit": "GiB/s", "cores": best_t, "kind": backend.kind, "ms_per_call": round(times[best_t] * 1e3, 4),
+            "GiB/s_by_threads": {str(t): round(gib / v, 2) for t, v in times.items()}, "cache_resident_single_buffer_GiB/s": round(gib / hot, 2)}
+
+
+def cpu_baseline(x_host: np.ndarray, scale: float, zp: int, budget_s: float, nsets: int):
+    """fp32 -> uint8 nearest on this box's host cores, same protocol as the GPU side: calls rotate over `nsets` distinct input/output buffer
+    sets (818 MB for 6 sets, more than the host's last-level cache) so the figure is a DRAM figure; the cache-resident single-buffer figure
+    is reported separately.  Two implementations, same protocol, same thread counts: the reference's own kernels (oracle/_ref, when the
+    prebuilt objects are present) and this repository's AVX-512 restatement (libpiquant_cpu.so, always: reproducible from a clean checkout).
+    The headline entry is the reference's where available ("kind": "reference"), with the port beside it under "port"."""
     import oracle as O
 
     n = x_host.size
-    gib = n * 4 / 2**30
-
-    if O.ref_available():
-        R = O.Ref()
-        isa = R.best_isa()
-        order, per_socket, physical, sockets = host_cpu_order()
-        ncpu = len(order)
-        counts = sorted({t for t in (1, 8, 16, 32, per_socket, physical, ncpu) if 1 <= t <= ncpu})
-        per = budget_s / (len(counts) + 1)
-
-        def placed(threads):
-            """fresh buffer sets whose partitions are first touched by their (pinned) workers"""
-            R.set_pinning(order[:threads])
-            ins = [R.partition_copy(x_host, np.empty_like(x_host), threads) for _ in range(nsets)]
-            outs = [np.empty(n, dtype=np.uint8) for _ in range(nsets)]    # untouched: first written by the workers in the first rotation
-            return ins, outs
-
-        def rotation_time(threads, budget):
-            """best mean-per-call over whole rotations through all buffer sets"""
-            ins, outs = placed(threads)
-            best, t_end, rounds = float("inf"), time.perf_counter() + budget, 0
-            while rounds < 3 or time.perf_counter() < t_end:
-                t0 = time.perf_counter()
-                for k in range(nsets):
-                    R.quantize(ins[k], O.F32, O.UINT8, scale, zp, isa=isa, threads=threads, out=outs[k])
-                if rounds > 0:           # the first rotation faults the output pages in
-                    best = min(best, (time.perf_counter() - t0) / nsets)
-                rounds += 1
-            return best, ins, outs
-
-        times = {}
-        for t in counts:
-            times[t], ins, outs = rotation_time(t, per)
-            if t != counts[-1]:
-                del ins, outs
-        best_t = min(times, key=times.get)
-        # cache-resident variant: one buffer set, best single call
-        ins, outs = placed(best_t)
-        hot = float("inf")
-        t_end = time.perf_counter() + per
-        while time.perf_counter() < t_end:
-            t0 = time.perf_counter()
-            R.quantize(ins[0], O.F32, O.UINT8, scale, zp, isa=isa, threads=best_t, out=outs[0])
-            hot = min(hot, time.perf_counter() - t0)
-        R.set_pinning([])
-        named = {1: "1 thread", per_socket: f"one socket ({per_socket} cores)", physical: f"all {physical} physical cores", ncpu: f"all {ncpu} hardware threads"}
-        return {
-            "value": round(gib / times[best_t], 3), "unit": "GiB/s", "cores": best_t, "kind": "reference",
-            "sample": f"reference {R.isa_name(isa)} kernels (oracle/_ref, compiled from the reference sources), fp32->uint8 nearest on "
-                      f"the full {n}-element tensor, calls rotating over {nsets} buffer sets ({nsets * 5 * n / 1e6:.0f} MB, beyond the host "
-                      f"LLC) like the GPU side, best mean per call over whole rotations, static range split (the reference's partition "
-                      f"rule, src/piquant.cpp:145-157) over a persistent std::thread pool standing in for its un-vendored thread pool; "
-                      f"numa: {sockets} socket(s) x {per_socket} cores, workers pinned one per physical core, socket by socket and round-robin over the L3 domains within a socket (SMT siblings last), "
-                      f"every buffer partition first touched by the worker that processes it; host has {ncpu} usable hardware threads; best at {best_t} threads",
-            "ms_per_call": round(times[best_t] * 1e3, 4),
-            "GiB/s_by_threads": {str(t): round(gib / v, 2) for t, v in times.items()},
-            "GiB/s_named": {named[t]: round(gib / times[t], 2) for t in counts if t in named},
-            "cache_resident_single_buffer_GiB/s": round(gib / hot, 2),
-        }
-    m = min(n, 4_000_000)
-    xs, outs = x_host[:m], np.zeros(m, dtype=np.uint8)
-    best, t_end = float("inf"), time.perf_counter() + min(budget_s, 8.0)
-    while time.perf_counter() < t_end:
-        t0 = time.perf_counter()
-        O.quantize(xs, O.F32, O.UINT8, scale, zp, out=outs)
-        best = min(best, time.perf_counter() - t0)
-    return {"value": round(m * 4 / 2**30 / best, 3), "unit": "GiB/s", "cores": 1, "kind": "port",
-            "sample": f"scalar C oracle on the first {m} elements, best call"}
+    order, per_socket, physical, sockets = host_cpu_order()
+    ncpu = len(order)
+    counts = sorted({t for t in (1, 8, 16, 32, per_socket, physical, ncpu) if 1 <= t <= ncpu})
+    named = {1: "1 thread", per_socket: f"one socket ({per_socket} cores)", physical: f"all {physical} physical cores", ncpu: f"all {ncpu} hardware threads"}
+    protocol = (f"fp32->uint8 nearest on the full {n}-element tensor, calls rotating over {nsets} buffer sets ({nsets * 5 * n / 1e6:.0f} MB, beyond the host LLC) "
+                f"like the GPU side, best mean per call over whole rotations; numa: {sockets} socket(s) x {per_socket} cores, workers pinned one per physical core, "
+                f"socket by socket and round-robin over the L3 domains within a socket (SMT siblings last), every buffer partition first touched by the worker "
+                f"that processes it; host has {ncpu} usable hardware threads")
+    have_ref = O.ref_available()
+    port_counts = counts if not have_ref else sorted({t for t in (1, 32, per_socket, physical) if 1 <= t <= ncpu})
+    pb = _PortBackend(ncpu)
+    port = _cpu_rotation(pb, x_host, scale, zp, budget_s * (0.4 if have_ref else 1.0), nsets, port_counts, order)
+    port["sample"] = f"{pb.what}; {protocol}; best at {port['cores']} threads"
+    port["GiB/s_named"] = {named[t]: port["GiB/s_by_threads"][str(t)] for t in port_counts if t in named}
+    if not have_ref:
+        return port
+    rb = _RefBackend()
+    ref = _cpu_rotation(rb, x_host, scale, zp, budget_s * 0.6, nsets, counts, order)
+    ref["sample"] = f"{rb.what}; {protocol}; best at {ref['cores']} threads"
+    ref["GiB/s_named"] = {named[t]: ref["GiB/s_by_threads"][str(t)] for t in counts if t in named}
+    ref["port"] = port
+    return ref
 
 
 def main():
@@ -293,20 +336,32 @@ def main():
         for i in range(args.warmup):
             step(i)
         torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        wall, ev = time_loop(step, args.steps, stream)
+        # The timed region: WINDOWS consecutive windows of EXACTLY K steps, every window bracketed by barrier + torch.cuda.synchronize() on both
+        # sides (time_loop synchronizes at its start and end).  One window is what the contract describes; K = 20 steps are 0.45 ms of work, and a
+        # single 0.45 ms window carries whatever the host happened to do in it (round 2: 4 146 GiB/s at the driver against 4 440 in the
+        # builder's runs of the same command, same kernel time).  `value` is the MEDIAN window -- max over ranks per window first -- with the
+        # fastest and slowest beside it; the buffer rotation runs on across the windows, so every launch of every window is cold.
+        walls, evs = [], []
+        for w in range(args.windows):
+            if use_dist:
+                dist.barrier()
+            wall, ev = time_loop(step, args.steps, stream, base=w * args.steps)
+            walls.append(wall)
+            evs.append(ev)
         if use_dist:
             dist.barrier()
 
-    t = torch.tensor([wall, ev], dtype=torch.float64, device=dev)
+    t = torch.tensor([walls, evs], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall_max, ev_max = float(t[0]), float(t[1])
+    walls_max = sorted(float(v) for v in t[0])
+    evs_max = sorted(float(v) for v in t[1])
+    wall_max = walls_max[len(walls_max) // 2] if len(walls_max) % 2 else 0.5 * (walls_max[len(walls_max) // 2 - 1] + walls_max[len(walls_max) // 2])
+    ev_max = evs_max[len(evs_max) // 2] if len(evs_max) % 2 else 0.5 * (evs_max[len(evs_max) // 2 - 1] + evs_max[len(evs_max) // 2])
 
     gib_per_step = n_total * 4 / 2**30                              # one step quantizes the whole logical tensor (all shards)
     value = gib_per_step * args.steps / wall_max
-    kernel_s = ev_max / args.steps                                   # average launch duration from HIP events on the launch stream (slowest rank)
+    kernel_s = ev_max / args.steps                                   # average launch duration from HIP events on the launch stream (slowest rank), median window
     n_max = -(-n_total // world)                                     # the largest shard
     achieved = ALGO_BYTES_PER_ELEM * n_max / kernel_s / 1e9          # per-GPU HBM rate of the dominant kernel
 
@@ -318,6 +373,10 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(wall_max / args.steps * 1e3, 6),
+        "timed_windows": {"count": args.windows, "steps_each": args.steps, "value_is": "median window (max over ranks per window)",
+                          "value_min": round(gib_per_step * args.steps / walls_max[-1], 2), "value_max": round(gib_per_step * args.steps / walls_max[0], 2),
+                          "value_from_events": round(gib_per_step * args.steps / ev_max, 2),
+                          "ms_per_step_min": round(walls_max[0] / args.steps * 1e3, 6), "ms_per_step_max": round(walls_max[-1] / args.steps * 1e3, 6)},
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -338,7 +397,7 @@ def main():
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": None,
             "kernel": "pq::quantize_kernel<f32,u8,nearest>", "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ELEM * n_max,
-            "avg_launch_us": round(kernel_s * 1e6, 3), "timing": "HIP events on the launch stream around the K timed launches / K",
+            "avg_launch_us": round(kernel_s * 1e6, 3), "timing": "HIP events on the launch stream around the K timed launches / K, median of the timed windows",
             "rotation": f"{nsets} buffer sets = {nsets * ALGO_BYTES_PER_ELEM * n / 1e9:.2f} GB per GPU: cold (round 1 rotated 6 sets = 818 MB, whose six 27 MB output buffers stay in the 256 MiB "
                         "Infinity Cache: ~1.1 us per launch faster; that figure: extras.rotation_of_6_sets_818MB_round1_protocol, and extras.cold_inputs_one_output_buffer)",
         },

@@ -34,6 +34,18 @@ PIQUANT_EXPORT void piquant_hip_set_blocking(piquant_context_t* ctx, int blockin
  * environment variable PIQUANT_HIP_BLOCKING_WAIT = sync | write32 | kernel sets it at context creation. */
 PIQUANT_EXPORT void piquant_hip_set_blocking_wait(piquant_context_t* ctx, int mode);
 
+/* What serves calls whose buffers are pageable HOST memory (the reference's own calling convention).
+ *   PIQUANT_HIP_HOST_PATH_STAGE (0, default): chunks of 2^24 elements cross PCIe into device scratch, the HIP kernels process them, the
+ *       results cross back -- every element is still computed by the GPU, at ~40 GiB/s of fp32 input (PCIe bound).
+ *   PIQUANT_HIP_HOST_PATH_CPU (1): the call is handed to libpiquant_cpu.so (include/piquant_cpu.h; loaded from the directory of this
+ *       library on first use, abort if it is missing): the same arithmetic in AVX-512 on the host cores, at host-memory bandwidth.
+ *       Only calls whose input AND output are pageable host memory take it; device and pinned pointers always run the HIP kernels, and so
+ *       do reference-layout mode and the per-element stochastic extension, which the companion does not implement.
+ * The environment variable PIQUANT_HIP_HOST_PATH = stage | cpu sets it at context creation.  Nothing is ever switched silently. */
+#define PIQUANT_HIP_HOST_PATH_STAGE 0
+#define PIQUANT_HIP_HOST_PATH_CPU 1
+PIQUANT_EXPORT void piquant_hip_set_host_path(piquant_context_t* ctx, int path);
+
 /* Pointer classification.  By default every buffer is classified with hipPointerGetAttributes (device / pinned: used in
  * place; pageable host: staged over PCIe).  A binding that already knows its buffers are device memory (PyTorch device
  * tensors) sets assume != 0 to skip the two runtime queries per call -- they are a visible share of the ~10 us a small

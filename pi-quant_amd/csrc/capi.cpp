@@ -2,7 +2,8 @@
 // buffers, and the quantization-parameter epilogue -- piquant_quantize / piquant_dequantize / piquant_compute_quant_params_* and their
 // device-record and sharded twins of piquant_hip.h.  It replaces the reference's src/piquant.cpp:277-381 and src/capi.cpp:15-104.
 //
-// There is no CPU compute path in this library: every element is processed by a HIP kernel.
+// There is no CPU compute path in this library: every element is processed by a HIP kernel -- unless the caller asks, per context, for
+// pageable host buffers to be served by the companion libpiquant_cpu.so (piquant_hip_set_host_path); such calls are forwarded whole.
 #include "context.hpp"
 
 using namespace pq;
@@ -90,6 +91,11 @@ static void quantize_impl(piquant_context_t* ctx, const void* in, piquant_dtype_
         if (ctx->blocking) wait_stream(ctx);
         return;
     }
+    if (ctx->host_path == PIQUANT_HIP_HOST_PATH_CPU && rin.pageable && rout.pageable && !q.ref_layout && q.round_mode != RM_STOCH_ELEM) {
+        // the caller's opt-in: host tensors stay on the host (the threshold drawn above is the call's, as in the reference)
+        cpu_companion().quantize(cpu_context_of(ctx), in, dtype_in, out, dtype_out, numel, scale, zero_point, mode == PIQUANT_STOCHASTIC ? 1 : 0, q.threshold);
+        return;
+    }
 
     // Host buffers: chunked H2D -> kernel -> D2H on two alternating streams (copy/compute overlap).
     PQ_HIP(hipStreamSynchronize(ctx->stream));
@@ -166,6 +172,10 @@ static void dequantize_impl(piquant_context_t* ctx, const void* in, piquant_dtyp
         d.numel = static_cast<int64_t>(numel);
         launch_dequantize(d, ctx->stream, ctx->num_cu);
         if (ctx->blocking) wait_stream(ctx);
+        return;
+    }
+    if (ctx->host_path == PIQUANT_HIP_HOST_PATH_CPU && rin.pageable && rout.pageable && !d.ref_layout) {
+        cpu_companion().dequantize(cpu_context_of(ctx), in, dtype_in, out, dtype_out, numel, scale, zero_point, d.op == OP_ADD ? 1 : 0);
         return;
     }
 
@@ -329,7 +339,14 @@ static void compute_params(piquant_context_t* ctx, const void* x, piquant_dtype_
         std::lock_guard<std::mutex> lock(ctx->mu);
         DeviceGuard guard(ctx->device);
         bool have = false;
-        if (ctx->mailbox_dev) {
+        if (ctx->host_path == PIQUANT_HIP_HOST_PATH_CPU && !ctx->assume_device && resolve(x).pageable) {
+            // the caller's opt-in (piquant_hip_set_host_path): a host tensor is scanned where it lives; same epilogue below
+            float lo_h, hi_h;
+            cpu_companion().minmax(cpu_context_of(ctx), x, dt, n, &lo_h, &hi_h);
+            keys[0] = float_to_key(lo_h);
+            keys[1] = float_to_key(-hi_h);
+            have = true;
+        } else if (ctx->mailbox_dev) {
             // the scan's last block publishes {keys, seq} straight into pinned host memory; spin on seq
             const uint32_t seq = ++ctx->mailbox_seq;
             MinmaxAction a;

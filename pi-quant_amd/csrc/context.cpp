@@ -139,6 +139,42 @@ void forget_fused_stream(int device, hipStream_t stream) {
     if (o.seen && o.last_stream == stream) o.seen = false;
 }
 
+const CpuCompanion& cpu_companion() {
+    static const CpuCompanion c = [] {
+        Dl_info info {};
+        std::string path = "libpiquant_cpu.so";
+        if (dladdr(reinterpret_cast<const void*>(&piquant_hip_set_host_path), &info) && info.dli_fname) {
+            const std::string self(info.dli_fname);
+            const size_t slash = self.rfind('/');
+            if (slash != std::string::npos) path = self.substr(0, slash + 1) + path;
+        }
+        void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!h) panic("host path 'cpu' needs %s next to libpiquant.so: %s", path.c_str(), dlerror());
+        CpuCompanion r {};
+        auto sym = [&](const char* name) {
+            void* p = dlsym(h, name);
+            if (!p) panic("%s lacks %s", path.c_str(), name);
+            return p;
+        };
+        r.context_create = reinterpret_cast<decltype(r.context_create)>(sym("piquant_cpu_context_create"));
+        r.context_destroy = reinterpret_cast<decltype(r.context_destroy)>(sym("piquant_cpu_context_destroy"));
+        r.quantize = reinterpret_cast<decltype(r.quantize)>(sym("piquant_cpu_quantize"));
+        r.dequantize = reinterpret_cast<decltype(r.dequantize)>(sym("piquant_cpu_dequantize"));
+        r.minmax = reinterpret_cast<decltype(r.minmax)>(sym("piquant_cpu_minmax"));
+        return r;
+    }();
+    return c;
+}
+
+void* cpu_context_of(piquant_context_t* ctx) {
+    if (!ctx->cpu_ctx) {
+        size_t threads = 0;   // one worker per usable CPU; PIQUANT_CPU_THREADS overrides
+        if (const char* env = std::getenv("PIQUANT_CPU_THREADS")) threads = static_cast<size_t>(std::strtoul(env, nullptr, 10));
+        ctx->cpu_ctx = cpu_companion().context_create(threads);
+    }
+    return ctx->cpu_ctx;
+}
+
 float draw_threshold(piquant_context_t* ctx) {
     if (ctx->fixed_threshold >= 0.0f) return ctx->fixed_threshold;
     return std::uniform_real_distribution<float>{0.0f, 1.0f}(ctx->rng);   // reference src/piquant.cpp:199-200
@@ -201,6 +237,11 @@ piquant_context_t* piquant_context_create(size_t num_threads) {
         ctx->wait_mode = m == "write32" ? WAIT_WRITE32 : (m == "kernel" ? WAIT_KERNEL : WAIT_SYNC);
     }
     PQ_HIP(hipDeviceSynchronize());   // the arming memsets ran on the null stream; scans may run on any stream
+    if (const char* env = std::getenv("PIQUANT_HIP_HOST_PATH")) {
+        const std::string m(env);
+        if (m == "cpu") ctx->host_path = PIQUANT_HIP_HOST_PATH_CPU;
+        else if (m != "stage" && !m.empty()) panic("PIQUANT_HIP_HOST_PATH=%s: expected stage or cpu", env);
+    }
     if (const char* env = std::getenv("PIQUANT_HIP_FUSION")) ctx->fusion = !(env[0] == '0' && env[1] == '\0');
     if (const char* env = std::getenv("PIQUANT_HIP_BARRIER_TIMEOUT_US")) ctx->barrier_timeout_us = static_cast<uint32_t>(std::strtoul(env, nullptr, 10));
     std::random_device rd;
@@ -231,7 +272,16 @@ void piquant_context_destroy(piquant_context_t* ctx) {
         if (ctx->d_dist_keys) (void)hipFree(ctx->d_dist_keys);
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     }
+    if (ctx->cpu_ctx) pq::cpu_companion().context_destroy(ctx->cpu_ctx);
     delete ctx;
+}
+
+void piquant_hip_set_host_path(piquant_context_t* ctx, int path) {
+    if (!ctx) panic("piquant_hip_set_host_path: context is NULL");
+    if (path != PIQUANT_HIP_HOST_PATH_STAGE && path != PIQUANT_HIP_HOST_PATH_CPU) panic("piquant_hip_set_host_path: invalid path %d", path);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (path == PIQUANT_HIP_HOST_PATH_CPU) (void)pq::cpu_companion();   // fail now, not at the first host call
+    ctx->host_path = path;
 }
 
 void piquant_hip_set_fusion(piquant_context_t* ctx, int enabled) {

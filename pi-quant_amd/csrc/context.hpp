@@ -89,6 +89,9 @@ struct piquant_context_t {
     void* stage_out[2] = {nullptr, nullptr};
     size_t stage_in_cap = 0, stage_out_cap = 0;
 
+    int host_path = PIQUANT_HIP_HOST_PATH_STAGE;   // piquant_hip_set_host_path: who serves pageable host buffers
+    void* cpu_ctx = nullptr;               // piquant_cpu_context_t of the companion library, created on first use
+
     std::mt19937_64 rng;
     float fixed_threshold = -1.0f;
     bool per_element = false;
@@ -154,6 +157,18 @@ class FusedLaunchOrder {
 };
 
 float draw_threshold(piquant_context_t* ctx);
+
+// Entry points of libpiquant_cpu.so (include/piquant_cpu.h), resolved on first use from the directory this library was loaded from; aborts
+// when the companion is missing -- a context asked for the CPU host path must not quietly get something else.
+struct CpuCompanion {
+    void* (*context_create)(size_t);
+    void (*context_destroy)(void*);
+    void (*quantize)(void*, const void*, int, void*, int, size_t, float, int64_t, int, float);
+    void (*dequantize)(void*, const void*, int, void*, int, size_t, float, int64_t, int);
+    void (*minmax)(void*, const void*, int, size_t, float*, float*);
+};
+const CpuCompanion& cpu_companion();
+void* cpu_context_of(piquant_context_t* ctx);   // the context's companion context (created on first use); caller holds ctx->mu
 
 // round-mode fields of a launch: NEAREST, one threshold per call (src/piquant.cpp:197-201) or the per-element extension
 void fill_round_mode(piquant_context_t* ctx, QuantLaunch& q, piquant_round_mode_t mode);

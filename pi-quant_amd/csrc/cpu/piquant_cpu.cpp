@@ -1,0 +1,315 @@
+// libpiquant_cpu.so -- host-memory companion of the MI355X library (include/piquant_cpu.h).
+//
+// The arithmetic is the one the HIP kernels implement (csrc/device_math.hpp): the reference's SIMD-body formula applied to EVERY element,
+// whatever its position, so that a call's bytes do not depend on thread count, partition or pointer alignment.  AVX-512 kernels with
+// masked heads and tails for the pairs the reference specialises (fp32/bf16 -> uint8/uint4/uint2 nearest, uint8/uint4/uint2 -> fp32/bf16),
+// scalar forms for the rest (stochastic rounding, fp32 -> uint2 nearest and uint2 -> fp32, which the reference also runs scalar) and for
+// hosts without AVX-512.  Built with -ffp-contract=off: products and sums are rounded separately except where the reference fuses them.
+//
+// Reference semantics restated (not copied): src/kernels/kernels_specialized.inl:35-727 (quantize), :729-1416 (dequantize), :1418-1607
+// (min/max), src/kernels/quantize.inl:8-26, dequantize.inl:8-11, src/piquant.cpp:145-157 (range split), :245-258 (epilogue).
+#include "piquant_cpu.h"
+
+#include "cpu_common.hpp"
+
+#include <pthread.h>
+#include <sched.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+using namespace pqcpu;
+
+namespace {
+
+bool detect_avx512() {
+    __builtin_cpu_init();
+    return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512dq");
+}
+const bool g_host_avx512 = detect_avx512();
+bool g_avx512 = g_host_avx512 && std::getenv("PIQUANT_CPU_SCALAR") == nullptr;   // piquant_cpu_use_avx512 switches it (tests run both forms)
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// dispatch over the legality matrix (reference src/kernels/kernels.inl:108-173: 12 + 12 combinations)
+// ------------------------------------------------------------------------------------------------------------------------------------
+template <int DT_IN, int BITS>
+QuantFn pick_quant(int round_mode) {
+    if (round_mode == 1) return quantize_scalar<DT_IN, BITS, STEP_STOCH>;
+    if (DT_IN == DT_F32 && BITS == 2) return quantize_scalar<DT_IN, BITS, STEP_I64>;   // no SIMD fast path in the reference (quantize.inl:105-127)
+    return g_avx512 ? avx512_quant_fn(DT_IN, BITS) : static_cast<QuantFn>(quantize_scalar<DT_IN, BITS, STEP_FAST>);
+}
+
+QuantFn quant_fn(int dt_in, int dt_out, int round_mode) {
+    if (round_mode != 0 && round_mode != 1) panic("invalid rounding mode %d", round_mode);
+    if (!is_float(dt_in) || !is_quant(dt_out)) panic("invalid quantization types: %d -> %d", dt_in, dt_out);
+    if (dt_in == DT_F32) return dt_out == DT_UINT8 ? pick_quant<DT_F32, 8>(round_mode) : (dt_out == DT_UINT4 ? pick_quant<DT_F32, 4>(round_mode) : pick_quant<DT_F32, 2>(round_mode));
+    return dt_out == DT_UINT8 ? pick_quant<DT_BF16, 8>(round_mode) : (dt_out == DT_UINT4 ? pick_quant<DT_BF16, 4>(round_mode) : pick_quant<DT_BF16, 2>(round_mode));
+}
+
+template <int BITS, int DT_OUT, bool ADD>
+DequantFn pick_dequant() {
+    DequantFn vec = g_avx512 ? avx512_dequant_fn(BITS, DT_OUT, ADD) : nullptr;   // nullptr: uint2 -> fp32, the generic int64 form (dequantize.inl:8-11)
+    return vec ? vec : static_cast<DequantFn>(dequantize_scalar<BITS, DT_OUT, ADD>);
+}
+
+template <int BITS>
+DequantFn dequant_bits(int dt_out, int op) {
+    if (dt_out == DT_F32) return op ? pick_dequant<BITS, DT_F32, true>() : pick_dequant<BITS, DT_F32, false>();
+    return op ? pick_dequant<BITS, DT_BF16, true>() : pick_dequant<BITS, DT_BF16, false>();
+}
+
+DequantFn dequant_fn(int dt_in, int dt_out, int op) {
+    if (op != 0 && op != 1) panic("invalid reduce op %d", op);
+    if (!is_quant(dt_in) || !is_float(dt_out)) panic("invalid dequantization types: %d -> %d", dt_in, dt_out);
+    return dt_in == DT_UINT8 ? dequant_bits<8>(dt_out, op) : (dt_in == DT_UINT4 ? dequant_bits<4>(dt_out, op) : dequant_bits<2>(dt_out, op));
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// persistent pool: worker t of T runs part t of every call; the caller is worker 0.  Workers spin briefly for the next call (calls come
+// back to back at ~0.3 ms each) and then sleep on a condition variable.
+// ------------------------------------------------------------------------------------------------------------------------------------
+class Pool {
+public:
+    explicit Pool(size_t threads) { resize(threads); }
+    ~Pool() { stop(); }
+    size_t size() const { return n_; }
+
+    void resize(size_t threads) {
+        stop();
+        n_ = std::max<size_t>(threads, 1);
+        quit_ = false;
+        gen_.store(0, std::memory_order_relaxed);
+        for (size_t t = 1; t < n_; ++t) workers_.emplace_back([this, t] { run(t); });
+    }
+
+    void set_affinity(std::vector<int> cpus) {
+        const size_t n = n_;
+        stop();
+        pin_ = std::move(cpus);
+        resize(n);
+    }
+
+    // fn(t, T) on every worker; returns when all are done
+    void parallel(const std::function<void(size_t, size_t)>& fn) {
+        if (n_ == 1) {
+            fn(0, 1);
+            return;
+        }
+        cpu_set_t saved;
+        const bool pin0 = !pin_.empty() && pthread_getaffinity_np(pthread_self(), sizeof saved, &saved) == 0;
+        if (pin0) pin_self(0);
+        job_ = &fn;
+        pending_.store(static_cast<int>(n_) - 1, std::memory_order_relaxed);
+        gen_.fetch_add(1, std::memory_order_release);
+        if (sleepers_.load(std::memory_order_acquire) > 0) {
+            std::lock_guard<std::mutex> lk(m_);
+            cv_.notify_all();
+        }
+        fn(0, n_);
+        while (pending_.load(std::memory_order_acquire) != 0) _mm_pause();
+        if (pin0) pthread_setaffinity_np(pthread_self(), sizeof saved, &saved);
+    }
+
+private:
+    void pin_self(size_t t) {
+        if (t >= pin_.size()) return;
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        CPU_SET(pin_[t], &set);
+        pthread_setaffinity_np(pthread_self(), sizeof set, &set);
+    }
+
+    void run(size_t t) {
+        pin_self(t);
+        uint64_t seen = 0;
+        for (;;) {
+            int spins = 0;
+            while (gen_.load(std::memory_order_acquire) == seen && !quit_.load(std::memory_order_relaxed)) {
+                if (++spins < 20000) {
+                    _mm_pause();
+                    continue;
+                }
+                std::unique_lock<std::mutex> lk(m_);
+                sleepers_.fetch_add(1, std::memory_order_acq_rel);
+                cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen || quit_.load(std::memory_order_relaxed); });
+                sleepers_.fetch_sub(1, std::memory_order_acq_rel);
+            }
+            if (quit_.load(std::memory_order_relaxed)) return;
+            seen = gen_.load(std::memory_order_acquire);
+            (*job_)(t, n_);
+            pending_.fetch_sub(1, std::memory_order_release);
+        }
+    }
+
+    void stop() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            quit_.store(true, std::memory_order_relaxed);
+            cv_.notify_all();
+        }
+        for (auto& w : workers_) w.join();
+        workers_.clear();
+    }
+
+    size_t n_ = 1;
+    std::vector<std::thread> workers_;
+    std::vector<int> pin_;
+    const std::function<void(size_t, size_t)>* job_ = nullptr;
+    std::atomic<uint64_t> gen_ {0};
+    std::atomic<int> pending_ {0};
+    std::atomic<int> sleepers_ {0};
+    std::atomic<bool> quit_ {false};
+    std::mutex m_;
+    std::condition_variable cv_;
+};
+
+// src/piquant.cpp:145-157: part t of T covers [n t / T, n (t + 1) / T), both ends aligned down to a whole packed byte, the last part keeps the rest
+inline void part_of(size_t n, size_t t, size_t T, size_t pack, size_t& b, size_t& e) {
+    auto first = [&](size_t k) {
+        if (k >= T) return n;
+        const size_t x = static_cast<size_t>(static_cast<unsigned __int128>(n) * k / T);
+        return x - x % pack;
+    };
+    b = first(t);
+    e = first(t + 1);
+}
+
+}  // namespace
+
+struct piquant_cpu_context_t {
+    Pool pool;
+    size_t max_threads;
+    std::mutex call;
+    explicit piquant_cpu_context_t(size_t n) : pool(n), max_threads(n) {}
+};
+
+extern "C" {
+
+piquant_cpu_context_t* piquant_cpu_context_create(size_t num_threads) {
+    if (num_threads == 0) {
+        cpu_set_t set;
+        num_threads = sched_getaffinity(0, sizeof set, &set) == 0 ? static_cast<size_t>(CPU_COUNT(&set)) : std::max(1u, std::thread::hardware_concurrency());
+    }
+    return new piquant_cpu_context_t(num_threads);
+}
+
+void piquant_cpu_context_destroy(piquant_cpu_context_t* ctx) { delete ctx; }
+
+size_t piquant_cpu_num_threads(const piquant_cpu_context_t* ctx) { return ctx->max_threads; }
+
+void piquant_cpu_set_active_threads(piquant_cpu_context_t* ctx, size_t threads) {
+    std::lock_guard<std::mutex> lk(ctx->call);
+    threads = std::min(std::max<size_t>(threads, 1), ctx->max_threads);
+    if (threads != ctx->pool.size()) ctx->pool.resize(threads);
+}
+
+void piquant_cpu_set_affinity(piquant_cpu_context_t* ctx, const int* cpus, size_t n) {
+    std::lock_guard<std::mutex> lk(ctx->call);
+    ctx->pool.set_affinity(std::vector<int>(cpus, cpus + n));
+}
+
+int piquant_cpu_has_avx512(void) { return g_avx512 ? 1 : 0; }
+
+int piquant_cpu_use_avx512(int enable) {
+    g_avx512 = enable != 0 && g_host_avx512;
+    return g_avx512 ? 1 : 0;
+}
+
+void piquant_cpu_quantize(piquant_cpu_context_t* ctx, const void* in, int dtype_in, void* out, int dtype_out, size_t numel, float scale, int64_t zero_point,
+                          int round_mode, float threshold) {
+    const QuantFn fn = quant_fn(dtype_in, dtype_out, round_mode);
+    if (numel == 0) return;
+    if (!in || !out) panic("piquant_cpu_quantize: null buffer");
+    QuantArgs a {};
+    a.inv_scale = 1.0f / scale;                                    // kernels_specialized.inl:42, quantize.inl:129
+    a.zp64 = zero_point;
+    a.zp32 = static_cast<int32_t>(static_cast<uint32_t>(static_cast<uint64_t>(zero_point)));
+    a.threshold = threshold;
+    const size_t pack = 8 / bits_of(dtype_out);
+    std::lock_guard<std::mutex> lk(ctx->call);
+    ctx->pool.parallel([&](size_t t, size_t T) {
+        size_t b, e;
+        part_of(numel, t, T, pack, b, e);
+        if (b < e) fn(in, static_cast<uint8_t*>(out), b, e, a);
+    });
+}
+
+void piquant_cpu_dequantize(piquant_cpu_context_t* ctx, const void* in, int dtype_in, void* out, int dtype_out, size_t numel, float scale, int64_t zero_point,
+                            int reduce_op) {
+    const DequantFn fn = dequant_fn(dtype_in, dtype_out, reduce_op);
+    if (numel == 0) return;
+    if (!in || !out) panic("piquant_cpu_dequantize: null buffer");
+    DequantArgs a {};
+    a.scale = scale;
+    a.zp64 = zero_point;
+    a.zp32 = static_cast<int32_t>(static_cast<uint32_t>(static_cast<uint64_t>(zero_point)));
+    a.bias = -static_cast<float>(a.zp32) * scale;
+    const size_t pack = 8 / bits_of(dtype_in);
+    std::lock_guard<std::mutex> lk(ctx->call);
+    ctx->pool.parallel([&](size_t t, size_t T) {
+        size_t b, e;
+        part_of(numel, t, T, pack, b, e);
+        if (b < e) fn(static_cast<const uint8_t*>(in), out, b, e, a);
+    });
+}
+
+void piquant_cpu_minmax(piquant_cpu_context_t* ctx, const void* x, int dtype, size_t numel, float* out_min, float* out_max) {
+    if (!is_float(dtype)) panic("min/max scan needs a float dtype, got %d", dtype);
+    float lo = FLT_MAX, hi = -FLT_MAX;                             // kernels_specialized.inl:1422-1423
+    if (numel != 0) {
+        if (!x) panic("piquant_cpu_minmax: null buffer");
+        std::lock_guard<std::mutex> lk(ctx->call);
+        std::vector<float> los(ctx->pool.size(), FLT_MAX), his(ctx->pool.size(), -FLT_MAX);
+        ctx->pool.parallel([&](size_t t, size_t T) {
+            size_t b, e;
+            part_of(numel, t, T, 1, b, e);
+            if (b >= e) return;
+            float l = FLT_MAX, h = -FLT_MAX;
+            const MinmaxFn scan = g_avx512 ? avx512_minmax_fn(dtype) : (dtype == DT_F32 ? static_cast<MinmaxFn>(minmax_scalar<DT_F32>) : static_cast<MinmaxFn>(minmax_scalar<DT_BF16>));
+            scan(x, b, e, l, h);
+            los[t] = l;
+            his[t] = h;
+        });
+        for (float v : los) lo = std::min(lo, v);
+        for (float v : his) hi = std::max(hi, v);
+    }
+    *out_min = lo;
+    *out_max = hi;
+}
+
+void piquant_cpu_compute_quant_params(piquant_cpu_context_t* ctx, const void* x, int dtype, size_t numel, int target_quant_dtype, float* out_scale,
+                                      int64_t* out_zero_point) {
+    if (!is_quant(target_quant_dtype)) panic("invalid target quantization dtype %d", target_quant_dtype);
+    float lo, hi;
+    piquant_cpu_minmax(ctx, x, dtype, numel, &lo, &hi);
+    // src/piquant.cpp:245-258, in double
+    const double r_min = lo, r_max = hi;
+    const uint64_t type_max = (uint64_t {1} << bits_of(target_quant_dtype)) - 1;
+    if (r_max == r_min) {
+        *out_scale = 1.0f;
+        *out_zero_point = static_cast<int64_t>(type_max >> 1);
+        return;
+    }
+    const double q_max = static_cast<double>(type_max);
+    const double scale = (r_max - r_min) / q_max;
+    if (!(scale >= 0.0)) panic("compute_quant_params: invalid scale %g (min %g, max %g)", scale, r_min, r_max);
+    const double zp = std::max(std::min(static_cast<double>(static_cast<int64_t>(std::round(0.0 - r_min / scale))), q_max), 0.0);
+    *out_scale = static_cast<float>(scale);
+    *out_zero_point = static_cast<int64_t>(zp);
+}
+
+void piquant_cpu_partition_copy(piquant_cpu_context_t* ctx, const void* src, void* dst, int dtype, size_t numel) {
+    const size_t esize = is_float(dtype) ? float_size(dtype) : 1;
+    std::lock_guard<std::mutex> lk(ctx->call);
+    ctx->pool.parallel([&](size_t t, size_t T) {
+        size_t b, e;
+        part_of(numel, t, T, 1, b, e);
+        if (b < e) std::memcpy(static_cast<uint8_t*>(dst) + b * esize, static_cast<const uint8_t*>(src) + b * esize, (e - b) * esize);
+    });
+}
+
+}  // extern "C"

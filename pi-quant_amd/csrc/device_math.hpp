@@ -197,6 +197,7 @@ __device__ __forceinline__ void quant_nearest_fast2(float x0, float x1, const Qu
 struct BoundedStep {
     float lo, hi;    // float(-zp), float(QMAX - zp)
     uint32_t zp_word;   // zp replicated into every BITS-wide field of a 32-bit word
+    float zp_scaled;    // float(zp) * (255 / QMAX): the zero point in the scaled domain of pack_saturated (quant_kernels.hpp)
 };
 
 // trunc(clamp(adj)) as a signed offset from the zero point, in [-zp, QMAX - zp].  v_med3_f32 returns min3 of its operands

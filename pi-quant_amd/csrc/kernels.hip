@@ -20,6 +20,8 @@ constexpr int bits_index(int bits) { return bits == 8 ? 0 : (bits == 4 ? 1 : 2);
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+constexpr uintptr_t kStoreAlign = 128;   // the streaming kernels start their store stream on a cache line (quantize_t)
+
 inline unsigned capped_grid(int64_t want, int blocks_per_cu, int num_cu) {
     int64_t g = want;
     if (blocks_per_cu > 0) g = std::min<int64_t>(g, static_cast<int64_t>(blocks_per_cu) * num_cu);
@@ -33,11 +35,14 @@ void quantize_t(const QuantLaunch& q, const QuantParams& p, hipStream_t stream, 
     using Tile = QuantTile<DT_IN, BITS, t.u, t.block>;
     uint8_t* out = static_cast<uint8_t*>(q.out);
     constexpr int PACK = 8 / BITS, ESIZE = DT_IN == DT_F32 ? 4 : 2;
-    // Buffers that are not 16-byte aligned (a slice x[1:], a shard at an odd offset): the vector kernel runs on them too.  Its loads may
-    // start anywhere an element may; its 16-byte stores are aligned by peeling `head` leading elements (a whole number of packed bytes)
-    // into the guarded path of block 0 -- the reference's shape (scalar head until the output is aligned, unaligned loads in the body,
-    // kernels_specialized.inl:52-82).
-    const int64_t head_bytes = static_cast<int64_t>((16u - (reinterpret_cast<uintptr_t>(q.out) & 15u)) & 15u);
+    // Buffers that are not aligned (a slice x[1:], a shard at an odd offset): the vector kernel runs on them too.  Its loads may start
+    // anywhere an element may (misaligned 16-byte loads cost ~1 %); its store stream is aligned to whole cache lines by peeling `head`
+    // leading elements (a whole number of packed bytes) into the guarded path of block 0 -- the reference's shape (scalar head until the
+    // output is aligned, unaligned loads in the body, kernels_specialized.inl:52-82).  Lines, not 16 bytes: a wave's stores are one
+    // contiguous run, and a run that starts inside a 128-byte line leaves a partial line at each end for the write-through path to
+    // merge -- measured +11 % on fp32 -> uint8 and +32 % on uint8 -> fp32 at numel 27 264 000 with 16-byte-aligned but line-straddling
+    // tiles (profiles/r03_tune_misaligned.csv).
+    const int64_t head_bytes = static_cast<int64_t>((kStoreAlign - (reinterpret_cast<uintptr_t>(q.out) & (kStoreAlign - 1))) & (kStoreAlign - 1));
     const int64_t head = head_bytes * PACK;
     // The guarded kernel remains for: inputs that are not even element-aligned, tensors that end inside the head, and reference-layout mode
     // whenever scalar positions lie inside the tensor (a scalar head shifts every SIMD block, and the partitions of a T-thread reference
@@ -94,7 +99,7 @@ void dequantize_t(const DequantLaunch& d, const DequantParams& p, hipStream_t st
     // elements are a whole number of packed bytes, and run misaligned otherwise (a uint4 tensor decoded to an fp32 slice that starts one
     // float past a 16-byte boundary: the body cannot begin inside a packed byte).
     const uintptr_t oa = reinterpret_cast<uintptr_t>(d.out);
-    int64_t head = static_cast<int64_t>((16u - (oa & 15u)) & 15u) / ESIZE;
+    int64_t head = static_cast<int64_t>((kStoreAlign - (oa & (kStoreAlign - 1))) & (kStoreAlign - 1)) / ESIZE;   // to a whole cache line (quantize_t)
     if (head % PACK != 0) head = 0;
     // element-wise kernel: an output that is not element-aligned, a tensor that ends inside the head, and reference-layout mode when tails
     // lie inside the tensor (partitions of a T-thread context) or the tiles would not start at element 0

@@ -154,46 +154,98 @@ __device__ __forceinline__ void quantize_vec(const u32x4& raw, const QuantParams
     }
 }
 
-// The nearest step for a call whose data range is known (device_math.hpp, BoundedStep): per element a packed multiply and
-// add, the copysign, one v_med3_f32 and one v_cvt_i32_f32 give the signed offset t = q - zp; the fields are then assembled
-// by Horner steps w = (w << BITS) + t (v_lshl_add_u32, negative t borrow from the field above and the borrow is repaid
-// exactly when zp is added to every field at once): 4 integer instructions per four elements instead of 4 adds + 3 packs.
+// Clamp + convert + pack for every output width through ONE instruction per element.  gfx950's v_cvt_pk_u8_f32 converts a float to uint8 with
+// saturation to [0, 255] (NaN -> 0) and inserts it into a chosen byte of a word.  It rounds to nearest even, so it is fed integer-valued floats
+// only (tools/probe_cvt_pk_u8.hip).  For 8-bit output that is the whole job:  clamp(t + zp, 0, 255) == sat_u8(float(t) + float(zp)).
+// For 4- and 2-bit output the value is scaled by K = 255 / QMAX (17 or 85) first:
+//     sat_u8((t + zp) * K)  ==  clamp(t + zp, 0, QMAX) * K          (0 * K = 0, QMAX * K = 255, everything between is exact)
+// and q * 17 = q | q << 4, q * 85 = q replicated into all four 2-bit fields: the byte holds the clamped value in EVERY field, and packing
+// is a byte shuffle (v_perm_b32) plus bit-field inserts that pick field k of element k -- 3 instructions per 8 nibbles, 7 per 8 two-bit fields,
+// instead of a v_med3_f32 + v_cvt_i32_f32 + v_lshl_add_u32 per element.  The scaled sum is ONE fma: exact while |t| < 2^16, and beyond that so
+// far outside [0, 255], with the right sign, that its rounding cannot matter.
+template <int BITS>
+struct SatScale {
+    static constexpr float K = BITS == 8 ? 1.0f : (BITS == 4 ? 17.0f : 85.0f);
+};
+
+__device__ __forceinline__ uint32_t bfi32(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }   // v_bfi_b32
+
+// tz[e] = (t_e + zp) * K as floats (integer-valued, or NaN / huge)  ->  the packed words of one input vector
+template <int BITS, int EPV>
+__device__ __forceinline__ void pack_saturated(const float (&tz)[EPV], uint32_t (&w)[(EPV * BITS / 8) > 4 ? 2 : 1]) {
+    uint32_t c[EPV / 4];   // four saturated bytes per word, element order
+#pragma unroll
+    for (int j = 0; j < EPV / 4; ++j) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_cvt_pk_u8_f32(tz[j * 4 + e], static_cast<uint32_t>(e), acc);
+        c[j] = acc;
+    }
+    if constexpr (BITS == 8) {
+#pragma unroll
+        for (int j = 0; j < EPV / 4; ++j) w[j] = c[j];
+    } else if constexpr (BITS == 4) {
+        // even elements keep their low nibble, odd elements their high one
+        if constexpr (EPV == 8) {
+            const uint32_t even = __builtin_amdgcn_perm(c[1], c[0], 0x06040200u);   // bytes {c0.b0, c0.b2, c1.b0, c1.b2}
+            const uint32_t odd = __builtin_amdgcn_perm(c[1], c[0], 0x07050301u);    //       {c0.b1, c0.b3, c1.b1, c1.b3}
+            w[0] = bfi32(0x0f0f0f0fu, even, odd);
+        } else {
+            const uint32_t even = __builtin_amdgcn_perm(0u, c[0], 0x0c0c0200u);
+            const uint32_t odd = __builtin_amdgcn_perm(0u, c[0], 0x0c0c0301u);
+            w[0] = bfi32(0x0f0f0f0fu, even, odd);
+        }
+    } else {
+        // a byte holds its element in all four 2-bit fields: {e0, e1} of a pair of bytes -> fields {0, 1, 0, 1}, then pairs -> {0, 1, 2, 3}
+        uint32_t u[EPV / 4];   // bytes 0 and 2 of u[j]: fields {e0, e1, e0, e1} and {e2, e3, e2, e3}
+#pragma unroll
+        for (int j = 0; j < EPV / 4; ++j) u[j] = bfi32(0x33333333u, c[j], c[j] >> 8);
+        if constexpr (EPV == 8) {
+            const uint32_t lo = __builtin_amdgcn_perm(u[1], u[0], 0x0c0c0400u);     // bytes {u0.b0, u1.b0}
+            const uint32_t hi = __builtin_amdgcn_perm(u[1], u[0], 0x0c0c0602u);     //       {u0.b2, u1.b2}
+            w[0] = bfi32(0x0f0f0f0fu, lo, hi);
+        } else {
+            w[0] = bfi32(0x0fu, u[0], u[0] >> 16) & 0xffu;
+        }
+    }
+}
+
+// The nearest step for a call whose data range is known (device_math.hpp, BoundedStep): per element a packed multiply and add, the
+// copysign and a truncation give the integer-valued float t = q - zp, one packed fma moves it into the scaled domain and pack_saturated
+// clamps, converts and packs.  (SAT = false keeps round 2's form for the tune harness' A/B: v_med3_f32 + v_cvt_i32_f32 per element and
+// Horner steps w = (w << BITS) + t, the zero point added to all fields of a word at once.)
 // GENERIC selects the rounding of the reference's generic nearest step (std::round, quantize.inl:21-26 -- the only form fp32 ->
 // uint2 has) instead of the SIMD bodies' trunc(p + copysign(0.5, p)); under the same range condition its int64 arithmetic
-// gives the same integers as the clamp in the float domain, and a NaN again ends at the lower bound, i.e. 0.
-template <int DT_IN, int BITS, bool GENERIC = false>
+// gives the same integers as the clamp in the float domain, and a NaN again ends at 0.
+template <int DT_IN, int BITS, bool GENERIC = false, bool SAT = true>
 __device__ __forceinline__ void quantize_vec_bounded(const u32x4& raw, float inv_scale, const BoundedStep& b,
                                                      uint32_t (&w)[(InVec<DT_IN>::EPV * BITS / 8) > 4 ? 2 : 1]) {
 #pragma clang fp contract(off)
     constexpr int EPV = InVec<DT_IN>::EPV, WORDS = (EPV * BITS / 8) > 4 ? 2 : 1, EPW = EPV / WORDS;
     float v[EPV];
     InVec<DT_IN>::unpack(raw, v);
-    if constexpr (BITS == 8 && !GENERIC) {
-        // 8-bit fields: gfx950's v_cvt_pk_u8_f32 converts a float to uint8 with saturation to [0, 255] (NaN -> 0) and inserts it into a
-        // chosen byte of a word -- clamp and pack in one instruction.  It rounds to nearest even, so it is fed the already truncated
-        // value plus the zero point, an integer-valued float for which every rounding mode agrees (tools/probe_cvt_pk_u8.hip):
-        //     clamp(trunc(adj) + zp, 0, 255) == sat_u8(trunc(adj) + float(zp))
-        // (the float sum is exact below 2^24 and far outside [0, 255], with the right sign, above).  4.5 instructions per element.
-        const float zp_f = -b.lo;
+    if constexpr (SAT || BITS == 8) {
+        constexpr float K = SatScale<BITS>::K;
         float tz[EPV];
 #pragma unroll
         for (int e = 0; e < EPV; e += 2) {
             const f32x2 x = {v[e], v[e + 1]};
             const f32x2 prod = x * inv_scale;
-            const f32x2 half = {__builtin_copysignf(0.5f, prod[0]), __builtin_copysignf(0.5f, prod[1])};
-            const f32x2 adj = prod + half;
-            const f32x2 tr = {__builtin_truncf(adj[0]), __builtin_truncf(adj[1])};
-            const f32x2 sum = tr + zp_f;
+            f32x2 tr;
+            if constexpr (GENERIC) {
+                tr = f32x2 {roundf(prod[0]), roundf(prod[1])};
+            } else {
+                const f32x2 half = {__builtin_copysignf(0.5f, prod[0]), __builtin_copysignf(0.5f, prod[1])};
+                const f32x2 adj = prod + half;
+                tr = f32x2 {__builtin_truncf(adj[0]), __builtin_truncf(adj[1])};
+            }
+            f32x2 sum;
+            if constexpr (BITS == 8) sum = tr + b.zp_scaled;
+            else sum = __builtin_elementwise_fma(tr, f32x2 {K, K}, f32x2 {b.zp_scaled, b.zp_scaled});   // the one place a fused multiply-add is wanted
             tz[e] = sum[0];
             tz[e + 1] = sum[1];
         }
-#pragma unroll
-        for (int j = 0; j < WORDS; ++j) {
-            uint32_t acc = 0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_cvt_pk_u8_f32(tz[j * 4 + e], static_cast<uint32_t>(e), acc);
-            w[j] = acc;
-        }
+        pack_saturated<BITS, EPV>(tz, w);
         return;
     }
     int32_t t[EPV];
@@ -224,11 +276,9 @@ __device__ __forceinline__ void quantize_vec_bounded(const u32x4& raw, float inv
 // when the call's (or the element's) threshold is below |r - tr|, and tr + adj -- an integer-valued float below 2^31 -- then takes
 // the float-domain clamp of the nearest step instead of the reference's int64 add and clamp: the same integers, for the same reason
 // (trunc and the clamp commute on integers; beyond 2^24 the sum with the zero point may round but is far outside [0, QMAX]; a NaN
-// gives adj = 0, tr = NaN and ends at the lower bound, 0, where the reference's INT64_MIN + zp is clamped to).  copysign(1, r) stands
+// gives adj = 0, tr = NaN and ends at 0, where the reference's INT64_MIN + zp is clamped to).  copysign(1, r) stands
 // for "if r < 0, adj = -adj": the two differ only for r = -0.0, where |r - tr| = 0 is never above a threshold and adj is 0 anyway.
-// About 7 instructions per element instead of the 64-bit path's ~20 -- what makes the bf16 inputs (eight elements per 16 bytes)
-// stream at the nearest step's rate.
-template <int DT_IN, int BITS, int MODE>
+template <int DT_IN, int BITS, int MODE, bool SAT = true>
 __device__ __forceinline__ void quantize_vec_bounded_stochastic(const u32x4& raw, const QuantParams& p, const ElementKeys& keys, uint64_t e0,
                                                                 const BoundedStep& b, uint32_t (&w)[(InVec<DT_IN>::EPV * BITS / 8) > 4 ? 2 : 1]) {
 #pragma clang fp contract(off)
@@ -254,20 +304,19 @@ __device__ __forceinline__ void quantize_vec_bounded_stochastic(const u32x4& raw
         s[e] = sum[0];
         s[e + 1] = sum[1];
     }
-    if constexpr (BITS == 8) {
-        const float zp_f = -b.lo;
+    if constexpr (SAT || BITS == 8) {
+        constexpr float K = SatScale<BITS>::K;
+        float tz[EPV];
 #pragma unroll
-        for (int j = 0; j < WORDS; ++j) {
-            uint32_t acc = 0;
-#pragma unroll
-            for (int e = 0; e < 4; e += 2) {
-                const f32x2 pair = {s[j * 4 + e], s[j * 4 + e + 1]};
-                const f32x2 tz = pair + zp_f;
-                acc = __builtin_amdgcn_cvt_pk_u8_f32(tz[0], static_cast<uint32_t>(e), acc);
-                acc = __builtin_amdgcn_cvt_pk_u8_f32(tz[1], static_cast<uint32_t>(e + 1), acc);
-            }
-            w[j] = acc;
+        for (int e = 0; e < EPV; e += 2) {
+            const f32x2 pair = {s[e], s[e + 1]};
+            f32x2 sum;
+            if constexpr (BITS == 8) sum = pair + b.zp_scaled;
+            else sum = __builtin_elementwise_fma(pair, f32x2 {K, K}, f32x2 {b.zp_scaled, b.zp_scaled});
+            tz[e] = sum[0];
+            tz[e + 1] = sum[1];
         }
+        pack_saturated<BITS, EPV>(tz, w);
     } else {
 #pragma unroll
         for (int j = 0; j < WORDS; ++j) {
@@ -280,11 +329,11 @@ __device__ __forceinline__ void quantize_vec_bounded_stochastic(const u32x4& raw
 }
 
 // The short step of whatever rounding mode the kernel was built for.
-template <int DT_IN, int BITS, int MODE>
+template <int DT_IN, int BITS, int MODE, bool SAT = true>
 __device__ __forceinline__ void quantize_vec_short(const u32x4& raw, const QuantParams& p, const ElementKeys& keys, uint64_t e0, const BoundedStep& b,
                                                    uint32_t (&w)[(InVec<DT_IN>::EPV * BITS / 8) > 4 ? 2 : 1]) {
-    if constexpr (MODE == RM_NEAREST_FAST || MODE == RM_NEAREST_I64) quantize_vec_bounded<DT_IN, BITS, MODE == RM_NEAREST_I64>(raw, p.inv_scale, b, w);
-    else quantize_vec_bounded_stochastic<DT_IN, BITS, MODE>(raw, p, keys, e0, b, w);
+    if constexpr (MODE == RM_NEAREST_FAST || MODE == RM_NEAREST_I64) quantize_vec_bounded<DT_IN, BITS, MODE == RM_NEAREST_I64, SAT>(raw, p.inv_scale, b, w);
+    else quantize_vec_bounded_stochastic<DT_IN, BITS, MODE, SAT>(raw, p, keys, e0, b, w);
 }
 
 // BoundedStep of a zero point that lies inside the quantized range (0 <= zp <= 2^BITS - 1): the clamp bounds as floats and the
@@ -296,7 +345,7 @@ __device__ __forceinline__ BoundedStep bounded_step_for(int32_t zp32) {
     uint32_t zp_word = 0;
 #pragma unroll
     for (int i = 0; i < FIELDS; ++i) zp_word |= static_cast<uint32_t>(zp32) << (i * BITS);
-    return BoundedStep {-static_cast<float>(zp32), static_cast<float>(((1 << BITS) - 1) - zp32), zp_word};
+    return BoundedStep {-static_cast<float>(zp32), static_cast<float>(((1 << BITS) - 1) - zp32), zp_word, static_cast<float>(zp32) * SatScale<BITS>::K};
 }
 
 // Range test of the short step, one vector at a time: m = max(m, |elements|) and `nan` |= "a NaN is among them".  A tile with a NaN takes
@@ -355,8 +404,11 @@ struct QuantTile {
 
 // VAR: experiment switches of the tune harness (tools/tune_kernels.hip `bf16`); production = kQuantVariant (tuning.hpp).
 //   bit 0  bf16 inputs: range test of the short step on the raw words (vec_absmax_bits_bf16) instead of on unpacked floats
-//   bit 1  hot path laid out straight: block 0's head / tail work and the long step are marked unlikely
-enum : int { QV_RAW_RANGE_TEST = 1, QV_STRAIGHT_HOT_PATH = 2 };
+//   bit 1  a cheaper first look before that test: the OR of the tile's raw words has the top exponent bit clear <=> every |x| < 2
+//   bit 2  4- and 2-bit outputs clamp, convert and pack through v_cvt_pk_u8_f32 in a scaled domain (pack_saturated)
+// (round 3 also tried marking block 0's head / tail work and the long step unlikely so that the hot path is laid out straight: no
+// difference, 12.69 vs 12.70 us for bf16 -> uint4, profiles/r03_tune_bf16_ceiling.csv `var=3` rows of the first session.)
+enum : int { QV_RAW_RANGE_TEST = 1, QV_OR_PRETEST = 2, QV_SAT_PACK = 4 };
 template <int DT_IN, int BITS, int MODE, int U, bool STAGE, int NT, int BLOCK, bool ALLOW_SHORT = true, int VAR = 0>
 __global__ void __launch_bounds__(BLOCK)
 quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t numel, int64_t n_tiles, float inv_scale, int32_t zp32,
@@ -394,7 +446,7 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
     // few hundred elements; at the end of the last block -- where it used to be -- that microsecond was the end of the kernel (13 632 000
     // elements with 1 024-element tiles: 13.2 us against 12.3 for a tile size that divides the tensor); block 0 starts first and has
     // finished both long before the stream has.
-    if (__builtin_expect(blockIdx.x == 0, (VAR & QV_STRAIGHT_HOT_PATH) ? 0 : 1)) {
+    if (blockIdx.x == 0) {
         constexpr int PACK = 8 / BITS;
         if (n_tiles * T::BLOCK_ELEMS < numel)
             quantize_bytes_guarded<DT_IN, BITS, MODE>(in, out, numel, n_tiles * T::BLOCK_ELEMS / PACK, (numel + PACK - 1) / PACK, p, threadIdx.x, BLOCK);
@@ -423,7 +475,20 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
         bool short_step = false;
         if constexpr (SHORT_CAPABLE) {
             if (short_ok) {
-                if constexpr (DT_IN == DT_BF16 && (VAR & QV_RAW_RANGE_TEST) != 0) {
+                // First look: OR the tile's raw words (one v_or3_b32 per two dwords).  The top exponent bit of every element clear means
+                // every |x| < 2 -- zeros and denormals included, NaN and infinity excluded -- and then |x / scale| < 2 |1/scale| < 10^9 for any
+                // scale a quantizer sees (kernel-uniform condition).  Tensors of ordinary magnitude never get past this line; the exact
+                // test below runs for tiles that hold an element of magnitude 2 or more.
+                if constexpr ((VAR & QV_OR_PRETEST) != 0) {
+                    if (abs_inv < 5.0e8f) {
+                        uint32_t o = 0;
+#pragma unroll
+                        for (int k = 0; k < U; ++k) o |= raw[k][0] | raw[k][1] | raw[k][2] | raw[k][3];
+                        short_step = __all((o & (DT_IN == DT_F32 ? 0x40000000u : 0x40004000u)) == 0 ? 1 : 0) != 0;
+                    }
+                }
+                if (short_step) {
+                } else if constexpr (DT_IN == DT_BF16 && (VAR & QV_RAW_RANGE_TEST) != 0) {
                     uint32_t m = 0;
 #pragma unroll
                     for (int k = 0; k < U; ++k) m = vec_absmax_bits_bf16(raw[k], m);
@@ -487,7 +552,8 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
         } else if (__builtin_expect(short_step, 1)) {
             uint32_t w[U][WORDS];
 #pragma unroll
-            for (int k = 0; k < U; ++k) quantize_vec_short<DT_IN, BITS, MODE>(raw[k], p, keys, static_cast<uint64_t>(v0 + k * 64 + lane) * EPV, bstep, w[k]);
+            for (int k = 0; k < U; ++k)
+                quantize_vec_short<DT_IN, BITS, MODE, (VAR & QV_SAT_PACK) != 0>(raw[k], p, keys, static_cast<uint64_t>(v0 + k * 64 + lane) * EPV, bstep, w[k]);
             put(w);
         } else {
             uint32_t w[U][WORDS];

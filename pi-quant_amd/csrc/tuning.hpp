@@ -34,7 +34,7 @@ constexpr KernelTune kQuantTune[2][3] = {
 // disagrees by +-0.4 us from run to run at this size -- it launches from the host over fewer sets -- and is not what this was decided on.)
 constexpr bool kQuantShortStep = true;
 // Experiment switches of quantize_kernel (quant_kernels.hpp, QV_*) as the library builds it.
-constexpr int kQuantVariant = 3;
+constexpr int kQuantVariant = 7;
 
 // dequantize, indexed [dt_out: f32,bf16][bits: 8,4,2]; SET and ADD separately -- ADD also streams the accumulator in, which moves the
 // optimum to small tiles.  bf16 entries re-measured after fp32 -> bf16 became one v_cvt_pk_bf16_f32 (profiles/r01_tune_finals_other_hw_bf16_cvt.csv,

@@ -282,6 +282,12 @@ class Context:
         arr_p = (_C.c_void_p * n)(*params_ptrs)
         C.piquant_hip_dequantize_sum(self._ctx, arr_in, arr_p, n, dtype_in.value, ptr_out, dtype_out.value, numel, reduce_op.value)
 
+    def set_host_path(self, path: str) -> None:
+        """Who serves calls on pageable HOST buffers: 'stage' (default: PCIe staging through the HIP kernels) or 'cpu' (the companion
+        libpiquant_cpu.so: the same arithmetic in AVX-512 on the host cores).  Device and pinned buffers always run the HIP kernels
+        (include/piquant_hip.h)."""
+        C.piquant_hip_set_host_path(self._ctx, {'stage': 0, 'cpu': 1}[path])
+
     def set_fusion(self, enabled: bool) -> None:
         """False: ``quantize_dynamic`` always runs the scan (with its parameter epilogue) and the quantize kernel as two launches (for A/B timing)."""
         C.piquant_hip_set_fusion(self._ctx, 1 if enabled else 0)

@@ -36,6 +36,20 @@ def test_every_declared_symbol_is_exported():
     assert len(names) >= 16
 
 
+def test_cpu_companion_exports_its_header():
+    """include/piquant_cpu.h <-> pi-quant_amd/piquant/libpiquant_cpu.so; and libpiquant.so does NOT link it (it is dlopen-ed on request only)."""
+    import subprocess
+
+    text = re.sub(r"/\*.*?\*/", "", (ROOT / "include" / "piquant_cpu.h").read_text(), flags=re.S)
+    names = re.findall(r"PIQUANT_CPU_EXPORT\s+[\w\s\*]+?\b(piquant_cpu_\w+)\s*\(", text)
+    assert len(names) >= 11
+    cpu_lib = ctypes.CDLL(str(LIB.with_name("libpiquant_cpu.so")))
+    for name in names:
+        assert hasattr(cpu_lib, name), f"{name} declared in include/piquant_cpu.h but not exported"
+    needed = subprocess.run(["readelf", "-d", str(LIB)], capture_output=True, text=True).stdout
+    assert "libpiquant_cpu" not in needed
+
+
 def test_enum_values_match_reference_abi():
     text = (ROOT / "include" / "piquant.h").read_text()
     for name, value in (("PIQUANT_NEAREST", 0), ("PIQUANT_STOCHASTIC", 1), ("PIQUANT_REDUCE_OP_SET", 0), ("PIQUANT_REDUCE_OP_ADD", 1),

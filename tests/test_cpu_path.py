@@ -1,0 +1,156 @@
+"""CPU: libpiquant_cpu.so (the host-memory companion, include/piquant_cpu.h) against the oracle and against the reference's own kernels.
+
+The library applies the reference's SIMD-body formula to every element (the HIP kernels' semantics), so its bytes must equal the oracle's
+FORM_UNIFORM for every dtype pair, rounding mode, store op, size, thread count and pointer alignment -- in the AVX-512 kernels and in the scalar
+forms -- and the reference's kernels themselves (oracle/_ref) on ordinary data.  The product library under test here never imports oracle/.
+"""
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def O(oracle_mod):
+    return oracle_mod
+
+
+@pytest.fixture(scope="module")
+def cpu():
+    from piquant import cpu as pc
+
+    return pc
+
+
+def _same_floats(a, b):
+    from helpers import same_floats
+
+    return same_floats(a, b)
+
+
+SIZES = [1, 2, 3, 15, 16, 17, 31, 33, 63, 64, 65, 127, 255, 1000, 4097, 65536 + 17, 300_003]
+
+
+@pytest.mark.parametrize("vector", [True, False], ids=["avx512", "scalar"])
+def test_quantize_all_pairs_equal_the_oracle(O, cpu, vector):
+    if vector and not cpu.use_avx512(True):
+        pytest.skip("host without AVX-512")
+    cpu.use_avx512(vector)
+    rng = np.random.default_rng(1)
+    try:
+        for threads in (1, 3):
+            ctx = cpu.CpuContext(threads)
+            for n in SIZES:
+                x = rng.uniform(-1, 1, n).astype(np.float32)
+                if n > 60:
+                    x[rng.choice(n, 7, replace=False)] = [np.nan, np.inf, -np.inf, 1e30, -3e9, 0.49999997, -0.0]
+                for dt_in, xin in ((O.F32, x), (O.BF16, O.f32_to_bf16(x))):
+                    for dt_out, qmax in ((O.UINT8, 255), (O.UINT4, 15), (O.UINT2, 3)):
+                        scale = float(np.float32(2.0 / qmax))
+                        for zp in (qmax // 2, -3, qmax + 10, 2**40 + 5):
+                            for rm, tau in ((0, 0.0), (1, 0.37)):
+                                for off in (0, 1, 5):       # output pointer offsets: heads of every length
+                                    buf = np.full(O.packed_numel(n, dt_out) + off + 8, 0xAA, dtype=np.uint8)
+                                    out = buf[off: off + O.packed_numel(n, dt_out)]
+                                    ctx.quantize_ptr(xin.ctypes.data, dt_in, out.ctypes.data, dt_out, n, scale, zp, rm, tau)
+                                    want = O.quantize(xin, dt_in, dt_out, scale, zp, rm, tau, form=O.FORM_UNIFORM)
+                                    assert np.array_equal(out, want), (threads, n, dt_in, dt_out, zp, rm, off, np.nonzero(out != want)[0][:5])
+                                    assert (buf[:off] == 0xAA).all() and (buf[off + out.size:] == 0xAA).all()
+            ctx.close()
+    finally:
+        cpu.use_avx512(True)
+
+
+@pytest.mark.parametrize("vector", [True, False], ids=["avx512", "scalar"])
+def test_dequantize_all_pairs_equal_the_oracle(O, cpu, vector):
+    if vector and not cpu.use_avx512(True):
+        pytest.skip("host without AVX-512")
+    cpu.use_avx512(vector)
+    rng = np.random.default_rng(2)
+    try:
+        for threads in (1, 3):
+            ctx = cpu.CpuContext(threads)
+            for n in SIZES:
+                prev = rng.uniform(-1, 1, n).astype(np.float32)
+                for dt_q in (O.UINT8, O.UINT4, O.UINT2):
+                    q = rng.integers(0, 256, O.packed_numel(n, dt_q)).astype(np.uint8)
+                    for dt_f in (O.F32, O.BF16):
+                        pv = prev if dt_f == O.F32 else O.f32_to_bf16(prev)
+                        for op in (0, 1):
+                            for zp in (9, -4, 2**33 + 1):
+                                for off in (0, 1, 3):       # element offsets of the output inside its buffer
+                                    buf = np.zeros(n + off + 4, dtype=pv.dtype)
+                                    out = buf[off: off + n]
+                                    out[:] = pv
+                                    ctx.dequantize_ptr(q.ctypes.data, dt_q, out.ctypes.data, dt_f, n, 0.02, zp, op)
+                                    want = O.dequantize(q, dt_q, dt_f, n, 0.02, zp, op, out=pv.copy())
+                                    assert _same_floats(out, want), (threads, n, dt_q, dt_f, op, zp, off)
+            ctx.close()
+    finally:
+        cpu.use_avx512(True)
+
+
+def test_minmax_and_params_equal_the_oracle(O, cpu):
+    rng = np.random.default_rng(3)
+    for vector in (True, False):
+        cpu.use_avx512(vector)
+        for threads in (1, 4):
+            ctx = cpu.CpuContext(threads)
+            for n in SIZES:
+                x = rng.normal(size=n).astype(np.float32)
+                if n > 60:
+                    x[rng.choice(n, 3, replace=False)] = [np.nan, np.nan, 7.5]
+                for dt, xin in ((O.F32, x), (O.BF16, O.f32_to_bf16(x))):
+                    assert ctx.minmax_ptr(xin.ctypes.data, dt, n) == O.minmax(xin, dt)
+                    for tdt in (O.UINT8, O.UINT4, O.UINT2):
+                        assert ctx.compute_quant_params_ptr(xin.ctypes.data, dt, n, tdt) == O.compute_quant_params(xin, dt, tdt), (n, dt, tdt)
+            ctx.close()
+    cpu.use_avx512(True)
+    ctx = cpu.CpuContext(1)
+    assert ctx.minmax_ptr(0, O.F32, 0) == (float(np.finfo(np.float32).max), -float(np.finfo(np.float32).max))
+    ctx.close()
+
+
+def test_equal_to_the_reference_kernels_on_ordinary_data(O, cpu):
+    """Where oracle/_ref exists (this container; shipped prebuilt to the GPU box): the restatement's bytes are the reference's own AVX-512
+    kernels' bytes on U(-1,1) data -- fp32 -> uint8 on 2^21 elements, bf16 -> uint4 and back."""
+    if not O.ref_available():
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    R = O.Ref()
+    isa = R.best_isa()
+    rng = np.random.default_rng(0)
+    n = 1 << 21
+    x = rng.uniform(-1, 1, n).astype(np.float32)
+    ctx = cpu.CpuContext(4)
+    scale, zp = ctx.compute_quant_params_ptr(x.ctypes.data, O.F32, n, O.UINT8)
+    assert (scale, zp) == O.compute_quant_params(x, O.F32, O.UINT8)
+    out = np.empty(n, dtype=np.uint8)
+    ctx.quantize_ptr(x.ctypes.data, O.F32, out.ctypes.data, O.UINT8, n, scale, zp)
+    assert np.array_equal(out, R.quantize(x, O.F32, O.UINT8, scale, zp, isa=isa, threads=1))
+    xb = O.f32_to_bf16(x)
+    s4, z4 = ctx.compute_quant_params_ptr(xb.ctypes.data, O.BF16, n, O.UINT4)
+    q4 = np.empty(n // 2, dtype=np.uint8)
+    ctx.quantize_ptr(xb.ctypes.data, O.BF16, q4.ctypes.data, O.UINT4, n, s4, z4)
+    assert np.array_equal(q4, R.quantize(xb, O.BF16, O.UINT4, s4, z4, isa=isa, threads=1))
+    back = np.empty(n, dtype=np.uint16)
+    ctx.dequantize_ptr(q4.ctypes.data, O.UINT4, back.ctypes.data, O.BF16, n, s4, z4, 0)
+    assert np.array_equal(back, R.dequantize(q4, O.UINT4, O.BF16, n, s4, z4, isa=isa, threads=1))
+    ctx.close()
+
+
+def test_contract_violations_abort():
+    import subprocess
+    import sys
+    import textwrap
+
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, "pi-quant_amd")
+        from piquant import cpu
+        import numpy as np
+        c = cpu.CpuContext(1)
+        x = np.zeros(8, dtype=np.float32); o = np.zeros(8, dtype=np.uint8)
+        c.quantize_ptr(x.ctypes.data, 4, o.ctypes.data, 0, 8, 1.0, 0)
+    """)
+    from pathlib import Path
+
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(Path(__file__).resolve().parent.parent))
+    assert r.returncode != 0 and "invalid quantization types" in r.stderr

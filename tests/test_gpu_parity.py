@@ -418,6 +418,35 @@ def test_host_pointers_are_staged_through_the_gpu(ctx, O):
     assert ctx.compute_quant_params_ptr_float32(x.ctypes.data, piquant.DataType.UINT8, n) == O.compute_quant_params(x, 0, 4)
 
 
+def test_host_pointers_on_the_cpu_companion_when_asked(O):
+    """piquant_hip_set_host_path(ctx, CPU): calls on pageable host buffers are handed to libpiquant_cpu.so (AVX-512 on the host cores)
+    instead of crossing PCIe twice; same bytes as the oracle and as the staged GPU path.  Device buffers of the same context still run the
+    HIP kernels.  Nothing switches by itself: the default context stages."""
+    import piquant
+    import torch
+
+    rng = np.random.default_rng(78)
+    n = 3_000_001
+    x = rng.uniform(-1, 1, n).astype(np.float32)
+    staged, cpu_ctx = piquant.Context(), piquant.Context()
+    cpu_ctx.set_host_path("cpu")
+    for c in (staged, cpu_ctx):
+        got = gpu_quantize(c, x, 0, 4, 0.0078431377, 127, 0, host=True)
+        want = O.quantize(x, 0, 4, 0.0078431377, 127)
+        assert np.array_equal(got, want)
+        acc = rng.uniform(-1, 1, n).astype(np.float32)
+        back = gpu_dequantize(c, got, 4, 0, n, 0.0078431377, 127, 1, prev=acc, host=True)
+        assert same_floats(back, O.dequantize(want, 4, 0, n, 0.0078431377, 127, 1, out=acc.copy()))
+        xb = O.f32_to_bf16(x[:100_001])
+        assert np.array_equal(gpu_quantize(c, xb, 1, 3, 0.13, 7, 0, host=True), O.quantize(xb, 1, 3, 0.13, 7))
+        c.set_stochastic_threshold(0.25)
+        assert np.array_equal(gpu_quantize(c, x, 0, 3, 0.13, 7, 1, host=True), O.quantize(x, 0, 3, 0.13, 7, 1, 0.25, form=O.FORM_UNIFORM))
+        c.set_stochastic_threshold(None)
+        assert c.compute_quant_params_ptr_float32(x.ctypes.data, piquant.DataType.UINT8, n) == O.compute_quant_params(x, 0, 4)
+    # the CPU-path context on device buffers: the HIP kernels, as always
+    assert np.array_equal(gpu_quantize(cpu_ctx, x, 0, 4, 0.0078431377, 127, 0), O.quantize(x, 0, 4, 0.0078431377, 127))
+
+
 # ---------------------------------------------------------------------------------------------------
 # BASELINE configs at full size
 # ---------------------------------------------------------------------------------------------------

@@ -237,7 +237,7 @@ __global__ void fill_uniform_bf16(uint16_t* p, int64_t n, uint32_t seed) {
 // output type), optional byte offsets of both buffers (misaligned pointers: the launcher's head peel is repeated here) and the VAR switches.
 // MODE = RM_COPY is the same kernel with no arithmetic: the ceiling for this traffic, tile shape and store policy.
 template <int DT_IN, int BITS, int MODE, int U, bool STAGE, int NT, int BLOCK, int VAR>
-static void run_quant3(const Bufs& b, int64_t numel, double bytes_per_elem, int off_in = 0, int off_out = 0, bool peel = true) {
+static void run_quant3(const Bufs& b, int64_t numel, double bytes_per_elem, int off_in = 0, int off_out = 0, int peel = 128) {
     using T = QuantTile<DT_IN, BITS, U, BLOCK>;
     constexpr int PACK = 8 / BITS, ESIZE = DT_IN == DT_F32 ? 4 : 2, QMAX = (1 << BITS) - 1;
     QuantParams p {};
@@ -245,7 +245,7 @@ static void run_quant3(const Bufs& b, int64_t numel, double bytes_per_elem, int 
     p.zp32 = QMAX / 2;
     p.zp64 = QMAX / 2;
     p.threshold = 0.37f;
-    const int64_t head_bytes = peel ? (16 - off_out % 16) % 16 : 0, head = head_bytes * PACK;
+    const int64_t head_bytes = peel ? (peel - off_out % peel) % peel : 0, head = head_bytes * PACK;   // peel = alignment the store stream is brought to (0: none)
     const int64_t body = numel - head, n_tiles = body / T::BLOCK_ELEMS;
     const unsigned grid = static_cast<unsigned>(std::max<int64_t>(n_tiles, 1));
     QuantParams pb = p;
@@ -263,7 +263,7 @@ static void run_quant3(const Bufs& b, int64_t numel, double bytes_per_elem, int 
 }
 
 template <int BITS, int DT_OUT, int OP, int U, bool STAGE, int NT, int BLOCK>
-static void run_dequant3(const Bufs& b, int64_t numel, double bytes_per_elem, int off_in, int off_out, bool peel) {
+static void run_dequant3(const Bufs& b, int64_t numel, double bytes_per_elem, int off_in, int off_out, int peel) {
     using T = DequantTile<BITS, DT_OUT, U, BLOCK>;
     constexpr int PACK = 8 / BITS, ESIZE = DT_OUT == DT_F32 ? 4 : 2, QMAX = (1 << BITS) - 1;
     DequantParams p {};
@@ -271,7 +271,7 @@ static void run_dequant3(const Bufs& b, int64_t numel, double bytes_per_elem, in
     p.zp32 = QMAX / 2;
     p.zp64 = QMAX / 2;
     p.bias = -static_cast<float>(p.zp32) * p.scale;
-    int64_t head = peel ? ((16 - off_out % 16) % 16) / ESIZE : 0;
+    int64_t head = peel ? ((peel - off_out % peel) % peel) / ESIZE : 0;
     if (head % PACK != 0) head = 0;
     const int64_t body = numel - head, n_tiles = body / T::BLOCK_ELEMS;
     const unsigned grid = static_cast<unsigned>(std::max<int64_t>(n_tiles, 1));
@@ -572,7 +572,8 @@ int main(int argc, char** argv) {
     run_quant3<DT_BF16, BITS, RM_COPY, U_, true, 5, BLK, 0>(b, numel, BPE);                 \
     run_quant3<DT_BF16, BITS, MODE, U_, true, 5, BLK, 0>(b, numel, BPE);                    \
     run_quant3<DT_BF16, BITS, MODE, U_, true, 5, BLK, 1>(b, numel, BPE);                    \
-    run_quant3<DT_BF16, BITS, MODE, U_, true, 5, BLK, 3>(b, numel, BPE);
+    run_quant3<DT_BF16, BITS, MODE, U_, true, 5, BLK, 3>(b, numel, BPE);                    \
+    run_quant3<DT_BF16, BITS, MODE, U_, true, 5, BLK, 7>(b, numel, BPE);
             ROW(4, RM_NEAREST_FAST, 2, 64, 2.5)
             ROW(4, RM_STOCH_CALL, 2, 64, 2.5)
             ROW(8, RM_NEAREST_FAST, 2, 64, 3.0)
@@ -587,55 +588,63 @@ int main(int argc, char** argv) {
             ROW(2, RM_NEAREST_FAST, 2, 64, 2.25)
 #undef ROW
             run_quant3<DT_BF16, 4, RM_COPY, 2, true, 3, 64, 0>(b, numel, 2.5);   // non-temporal stores
-            run_quant3<DT_BF16, 4, RM_NEAREST_FAST, 2, true, 3, 64, 3>(b, numel, 2.5);
+            run_quant3<DT_BF16, 4, RM_NEAREST_FAST, 2, true, 3, 64, 7>(b, numel, 2.5);
         }
         g_rounds = 3;
     }
     if (only == "f32var") {
-        // fp32 inputs: copy ceiling and the VAR switches (bit 0 does nothing for fp32; bit 1 is the code layout)
+        // fp32 inputs: copy ceiling and the VAR switches (var 7: OR pre-test of the range check, saturating pack for 4/2-bit)
         g_rounds = 1;
         for (int pass = 0; pass < 6; ++pass) {
             run_quant3<DT_F32, 8, RM_COPY, 2, true, 5, 128, 0>(b, numel, 5);
             run_quant3<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 128, 0>(b, numel, 5);
-            run_quant3<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 128, 2>(b, numel, 5);
+            run_quant3<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 128, 7>(b, numel, 5);
             run_quant3<DT_F32, 8, RM_STOCH_CALL, 2, true, 5, 128, 0>(b, numel, 5);
-            run_quant3<DT_F32, 8, RM_STOCH_CALL, 2, true, 5, 128, 2>(b, numel, 5);
+            run_quant3<DT_F32, 8, RM_STOCH_CALL, 2, true, 5, 128, 7>(b, numel, 5);
             run_quant3<DT_F32, 4, RM_COPY, 2, true, 5, 64, 0>(b, numel, 4.5);
             run_quant3<DT_F32, 4, RM_NEAREST_FAST, 2, true, 5, 64, 0>(b, numel, 4.5);
-            run_quant3<DT_F32, 4, RM_NEAREST_FAST, 2, true, 5, 64, 2>(b, numel, 4.5);
+            run_quant3<DT_F32, 4, RM_NEAREST_FAST, 2, true, 5, 64, 7>(b, numel, 4.5);
             run_quant3<DT_F32, 2, RM_COPY, 2, true, 5, 64, 0>(b, numel, 4.25);
             run_quant3<DT_F32, 2, RM_NEAREST_I64, 2, true, 5, 64, 0>(b, numel, 4.25);
-            run_quant3<DT_F32, 2, RM_NEAREST_I64, 2, true, 5, 64, 2>(b, numel, 4.25);
+            run_quant3<DT_F32, 2, RM_NEAREST_I64, 2, true, 5, 64, 7>(b, numel, 4.25);
         }
         g_rounds = 3;
     }
     if (only == "mis") {
-        // Round 3: buffers that are not 16-byte aligned, through the vector kernels (round 2 sent them to a one-byte-per-thread kernel).
-        // off_in / off_out in bytes; head = elements peeled in front so that the store stream is aligned (0 with peel off: misaligned stores)
+        // Round 3: buffers that are not aligned, through the vector kernels (round 2 sent them to a one-byte-per-thread kernel).
+        // off_in / off_out in bytes; the last argument is the alignment the store stream is brought to by peeling a head (0 = no peel:
+        // misaligned stores; 16 = vector-aligned only; 128 = whole cache lines, what the library does)
         g_rounds = 1;
         for (int pass = 0; pass < 5; ++pass) {
-            run_quant3<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 128, 3>(b, numel - 64, 5, 0, 0);
-            run_quant3<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 128, 3>(b, numel - 64, 5, 4, 0);       // x[1:] -> fresh output
-            run_quant3<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 128, 3>(b, numel - 64, 5, 4, 1);       // both off: head of 15 bytes
-            run_quant3<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 128, 3>(b, numel - 64, 5, 4, 1, false);   // same, no peel: misaligned 16-byte stores
-            run_quant3<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 128, 3>(b, numel - 64, 5, 0, 8);
-            run_quant3<DT_F32, 4, RM_NEAREST_FAST, 2, true, 5, 64, 3>(b, numel - 64, 4.5, 4, 3);
-            run_dequant3<8, DT_F32, OP_SET, 2, true, 5, 128>(b, numel - 64, 5, 0, 0, true);
-            run_dequant3<8, DT_F32, OP_SET, 2, true, 5, 128>(b, numel - 64, 5, 1, 0, true);            // q[1:] -> fresh output
-            run_dequant3<8, DT_F32, OP_SET, 2, true, 5, 128>(b, numel - 64, 5, 1, 4, true);            // into out[1:]: head 3
-            run_dequant3<8, DT_F32, OP_SET, 2, true, 5, 128>(b, numel - 64, 5, 1, 4, false);           // same, misaligned stores
-            run_dequant3<8, DT_F32, OP_ADD, 2, true, 5, 128>(b, numel - 64, 9, 0, 0, true);
-            run_dequant3<8, DT_F32, OP_ADD, 2, true, 5, 128>(b, numel - 64, 9, 1, 4, true);
-            run_dequant3<8, DT_F32, OP_ADD, 2, true, 5, 128>(b, numel - 64, 9, 1, 4, false);
-            run_dequant3<4, DT_F32, OP_SET, 4, true, 5, 256>(b, numel - 64, 4.5, 1, 4, true);          // uint4 -> out[1:]: head 3 is not a whole byte -> misaligned stores
+            run_quant3<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 128, 7>(b, numel - 1024, 5, 0, 0);
+            run_quant3<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 128, 7>(b, numel - 1024, 5, 4, 0);        // x[1:] -> fresh output
+            run_quant3<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 128, 7>(b, numel - 1024, 5, 4, 1, 0);     // out + 1: misaligned stores
+            run_quant3<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 128, 7>(b, numel - 1024, 5, 4, 1, 16);
+            run_quant3<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 128, 7>(b, numel - 1024, 5, 4, 1, 64);
+            run_quant3<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 128, 7>(b, numel - 1024, 5, 4, 1, 128);
+            run_quant3<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 128, 7>(b, numel - 1024, 5, 4, 1, 256);
+            run_quant3<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 128, 7>(b, numel - 1024, 5, 0, 64, 0);    // 64-byte-aligned output, no peel
+            run_quant3<DT_F32, 4, RM_NEAREST_FAST, 2, true, 5, 64, 7>(b, numel - 1024, 4.5, 4, 3, 128);
+            run_quant3<DT_BF16, 4, RM_NEAREST_FAST, 2, true, 5, 64, 7>(b, numel - 1024, 2.5, 2, 3, 128);
+            run_dequant3<8, DT_F32, OP_SET, 2, true, 5, 128>(b, numel - 1024, 5, 0, 0, 128);
+            run_dequant3<8, DT_F32, OP_SET, 2, true, 5, 128>(b, numel - 1024, 5, 1, 0, 128);            // q[1:] -> fresh output
+            run_dequant3<8, DT_F32, OP_SET, 2, true, 5, 128>(b, numel - 1024, 5, 1, 4, 0);              // into out[1:], misaligned stores
+            run_dequant3<8, DT_F32, OP_SET, 2, true, 5, 128>(b, numel - 1024, 5, 1, 4, 16);
+            run_dequant3<8, DT_F32, OP_SET, 2, true, 5, 128>(b, numel - 1024, 5, 1, 4, 128);
+            run_dequant3<8, DT_F32, OP_SET, 2, true, 5, 128>(b, numel - 1024, 5, 16, 0, 128);           // packed input 16-byte but not line aligned
+            run_dequant3<8, DT_F32, OP_ADD, 2, true, 5, 128>(b, numel - 1024, 9, 0, 0, 128);
+            run_dequant3<8, DT_F32, OP_ADD, 2, true, 5, 128>(b, numel - 1024, 9, 1, 4, 0);
+            run_dequant3<8, DT_F32, OP_ADD, 2, true, 5, 128>(b, numel - 1024, 9, 1, 4, 128);
+            run_dequant3<4, DT_F32, OP_SET, 4, true, 5, 256>(b, numel - 1024, 4.5, 1, 4, 128);          // uint4 -> out[1:]: head 31 is not a whole byte -> misaligned stores
+            run_dequant3<4, DT_BF16, OP_SET, 4, true, 6, 256>(b, numel - 1024, 2.5, 1, 4, 128);         // uint4 -> bf16 out[2:]
         }
         g_mm_caps = {1};
+        Bufs shifted = b;
+        for (auto& q : shifted.in) q = static_cast<uint8_t*>(q) + 4;
         for (int pass = 0; pass < 5; ++pass) {
-            run_minmax<DT_F32, 4, true, 512, true>(b, numel - 64, num_cu, keys);
-            Bufs shifted = b;
-            for (auto& q : shifted.in) q = static_cast<uint8_t*>(q) + 4;
-            run_minmax<DT_F32, 4, true, 512, true>(shifted, numel - 64, num_cu, keys);
-            std::printf("# previous row: input pointers + 4 bytes\n");
+            run_minmax<DT_F32, 4, true, 512, true>(b, numel - 1024, num_cu, keys);
+            std::printf("minmax_shifted,");
+            run_minmax<DT_F32, 4, true, 512, true>(shifted, numel - 1024, num_cu, keys);
         }
         g_mm_caps = {1, 2, 4, 8, 16, 32};
         g_rounds = 3;
