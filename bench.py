@@ -44,7 +44,8 @@ DEFAULT_BLOCKING_WAIT = "kernel"   # the library's default (csrc/context.cpp kDe
 # 6-set rotation (164 MB) stay in the 256 MiB Infinity Cache and absorb the stores (extras.cold_inputs_one_output_buffer: 24 cold inputs into ONE
 # output buffer run at the 6-set rate).  The headline therefore rotates 24 sets, inputs and outputs; the 6-set figure is kept in extras for continuity.
 ROUND1_SETS = 6
-CPU_SETS = 6                     # the host side keeps 818 MB in rotation (beyond both sockets' L3), bounded so that the baseline stays a 20 s affair
+CPU_SETS = 16                    # the host side keeps 2.2 GB in rotation: four times the 2 x 256 MB of L3 of the GPU box's two sockets (with 6 sets = 818 MB, pinned
+                                 # workers that always meet the same partitions got a large part of their reads from their own CCD's L3: 1 300 GiB/s "from DRAM")
 
 
 def parse():

@@ -12,8 +12,12 @@ namespace pq {
 
 void scan(piquant_context_t* ctx, const void* x, piquant_dtype_t dtype, size_t n, const MinmaxAction& action) {
     // scans of one context share one state buffer: they must not overlap, which stream order guarantees on one stream
-    if (ctx->scan_stream && ctx->scan_stream != ctx->stream && !stream_is_capturing(ctx->stream)) PQ_HIP(hipStreamSynchronize(ctx->scan_stream));
+    // (a handle that went stale despite the rule "replace a stream before destroying it" gives an error here, not an abort: its work is over)
+    if (ctx->scan_stream && ctx->scan_stream != ctx->stream && !stream_is_capturing(ctx->stream) && !stream_is_capturing(ctx->scan_stream) &&
+        hipStreamSynchronize(ctx->scan_stream) != hipSuccess)
+        (void)hipGetLastError();
     ctx->scan_stream = ctx->stream;
+    order_context_state(ctx);   // captured scans of one context on parallel branches of a graph become successors of each other
     if (n == 0) {
         launch_minmax_epilogue(ctx->d_state, action, false, ctx->stream);
         return;

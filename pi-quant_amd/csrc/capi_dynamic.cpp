@@ -152,7 +152,8 @@ static void quantize_dynamic_one(piquant_context_t* ctx, QuantLaunch q, const vo
     // switched off) the same result from two launches: the scan, whose last block writes the record, and a quantize that reads it.
     bool fused = false;
     if (ctx->fusion && fused_launch_applies(q, ctx->num_cu)) {
-        FusedLaunchOrder order(ctx->device, ctx->stream);
+        order_context_state(ctx);
+                FusedLaunchOrder order(ctx->device, ctx->stream);
         q.barrier_timeout_us = ctx->barrier_timeout_us;
         fused = launch_fused_params_quantize(q, ctx->d_fused, params_dev, ctx->stream, ctx->num_cu);
     }
@@ -248,7 +249,8 @@ void piquant_hip_quantize_dynamic_batch(piquant_context_t* ctx, const void* cons
         }
         bool fused = false;
         if (ctx->fusion && !ctx->reference_layout && b.count > 1) {
-            FusedLaunchOrder order(ctx->device, ctx->stream);
+            order_context_state(ctx);
+                FusedLaunchOrder order(ctx->device, ctx->stream);
             q.barrier_timeout_us = ctx->barrier_timeout_us;
             fused = launch_fused_params_quantize_batch(q, b, ctx->d_fused, ctx->stream, ctx->num_cu);
         }
@@ -273,6 +275,8 @@ void piquant_hip_reduce_quantize_dynamic(piquant_context_t* ctx, void* acc, piqu
     }
     if (!acc || !out || !inputs || !input_params) panic("piquant_hip_reduce_quantize_dynamic: NULL argument");
     bool fused = false;
+    bool drew = false;      // a per-call stochastic threshold was drawn for the fused attempt: the two-step path below must use the SAME one,
+    float drawn = 0.0f;     // or the bytes (and every later draw of a seeded context) would depend on whether fusion was tried
     {
         std::lock_guard<std::mutex> lock(ctx->mu);
         DeviceGuard guard(ctx->device);
@@ -286,6 +290,10 @@ void piquant_hip_reduce_quantize_dynamic(piquant_context_t* ctx, void* acc, piqu
             q.dt_in = dtype_acc;
             q.dt_out = dtype_out;
             fill_round_mode(ctx, q, mode);
+            if (q.round_mode == RM_STOCH_CALL) {
+                drew = true;
+                drawn = q.threshold;
+            }
             DequantSumLaunch terms {};
             terms.count = static_cast<int>(count);
             terms.dt_in = dtype_out;
@@ -297,6 +305,7 @@ void piquant_hip_reduce_quantize_dynamic(piquant_context_t* ctx, void* acc, piqu
                 terms.params[i] = rq.dev;
             }
             {
+                order_context_state(ctx);
                 FusedLaunchOrder order(ctx->device, ctx->stream);
                 q.barrier_timeout_us = ctx->barrier_timeout_us;
                 fused = launch_fused_reduce_quantize(q, terms, ctx->d_fused, rp.dev, ctx->stream, ctx->num_cu);
@@ -306,8 +315,18 @@ void piquant_hip_reduce_quantize_dynamic(piquant_context_t* ctx, void* acc, piqu
     }
     if (fused) return;
     // the same result in two steps (and with `acc` updated on the way): one-pass sum into acc, then parameters + quantize
+    float saved = -1.0f;
+    if (drew) {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        saved = ctx->fixed_threshold;
+        ctx->fixed_threshold = drawn;
+    }
     piquant_hip_dequantize_sum(ctx, inputs, input_params, count, dtype_out, acc, dtype_acc, numel, PIQUANT_REDUCE_OP_ADD);
     piquant_hip_quantize_dynamic(ctx, acc, dtype_acc, out, dtype_out, numel, device_params, mode);
+    if (drew) {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        ctx->fixed_threshold = saved;
+    }
 }
 
 }  // extern "C"

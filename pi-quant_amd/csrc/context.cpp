@@ -103,6 +103,7 @@ struct FusedOrder {
     std::mutex mu;
     hipStream_t last_stream = nullptr;
     bool seen = false;
+    bool pending = false;      // `handover` was recorded behind the last fused launch of a stream that has been detached since: wait for the EVENT
     hipEvent_t handover = nullptr;
 };
 
@@ -119,7 +120,10 @@ bool stream_is_capturing(hipStream_t s) {
 FusedLaunchOrder::FusedLaunchOrder(int device, hipStream_t stream) : o_(fused_order(device)), lock_(o_.mu, std::defer_lock) {
     if (stream_is_capturing(stream)) return;
     lock_.lock();
-    if (o_.seen && o_.last_stream != stream) {
+    if (o_.pending) {   // the previous fused stream was handed back by its context; its last launch is behind this event
+        if (hipStreamWaitEvent(stream, o_.handover, 0) != hipSuccess) (void)hipGetLastError();
+        o_.pending = false;
+    } else if (o_.seen && o_.last_stream != stream) {
         // Ordering is a courtesy, not a requirement (the kernels' barrier waits are bounded): if the previous stream cannot take an
         // event any more -- destroyed by its owner, or capturing by now -- the launch simply goes ahead.
         bool ordered = false;
@@ -137,6 +141,38 @@ void forget_fused_stream(int device, hipStream_t stream) {
     FusedOrder& o = fused_order(device);
     std::lock_guard<std::mutex> lock(o.mu);
     if (o.seen && o.last_stream == stream) o.seen = false;
+}
+
+// A stream its context stops using while it may still be running a fused launch (piquant_hip_set_stream to another stream): the owner may
+// destroy it next, so the handle must not be kept -- but the ordering must.  The hand-over event is recorded NOW, while the stream is
+// certainly alive, and the next fused launch of the device waits for the event instead of touching the stream.
+void detach_fused_stream(int device, hipStream_t stream) {
+    FusedOrder& o = fused_order(device);
+    std::lock_guard<std::mutex> lock(o.mu);
+    if (!o.seen || o.last_stream != stream) return;
+    o.seen = false;
+    o.last_stream = nullptr;
+    if (stream_is_capturing(stream)) return;
+    if (!o.handover && hipEventCreateWithFlags(&o.handover, hipEventDisableTiming) != hipSuccess) o.handover = nullptr;
+    if (o.handover && hipEventRecord(o.handover, stream) == hipSuccess) o.pending = true;
+    else (void)hipGetLastError();
+}
+
+void order_context_state(piquant_context_t* ctx) {
+    hipStream_t s = ctx->stream;
+    if (!stream_is_capturing(s)) {
+        ctx->capture_stream = nullptr;
+        return;
+    }
+    if (ctx->capture_stream && ctx->capture_stream != s && stream_is_capturing(ctx->capture_stream)) {
+        if (!ctx->capture_edge) PQ_HIP(hipEventCreateWithFlags(&ctx->capture_edge, hipEventDisableTiming));
+        const hipError_t e1 = hipEventRecord(ctx->capture_edge, ctx->capture_stream);
+        const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(s, ctx->capture_edge, 0) : e1;
+        if (e2 != hipSuccess)
+            panic("two capturing streams use the scan / barrier state of one piquant context and cannot be ordered (%s): use one context per stream",
+                  hipGetErrorString(e2));
+    }
+    ctx->capture_stream = s;
 }
 
 const CpuCompanion& cpu_companion() {
@@ -195,6 +231,21 @@ void fill_round_mode(piquant_context_t* ctx, QuantLaunch& q, piquant_round_mode_
 }  // namespace pq
 
 using namespace pq;
+
+// The context moves from its current stream to `next`.  A caller's stream may be destroyed once it has been replaced (that is the
+// documented rule: reset or replace a stream BEFORE destroying it), so no handle of it may survive here: scans still in flight on it are
+// finished now (scans of one context share one state buffer and must not overlap with the next stream's), and a fused launch still in
+// flight is turned into an event the next fused launch waits for.  The context's own stream is never destroyed before the context.
+static void leave_stream(piquant_context_t* ctx, hipStream_t next) {
+    hipStream_t old = ctx->stream;
+    if (old == next) return;
+    DeviceGuard guard(ctx->device);
+    if (ctx->scan_stream && ctx->scan_stream != next) {
+        if (!stream_is_capturing(ctx->scan_stream) && hipStreamSynchronize(ctx->scan_stream) != hipSuccess) (void)hipGetLastError();
+        ctx->scan_stream = nullptr;
+    }
+    if (old != ctx->own_stream) detach_fused_stream(ctx->device, old);
+}
 
 extern "C" {
 
@@ -272,6 +323,7 @@ void piquant_context_destroy(piquant_context_t* ctx) {
         if (ctx->d_dist_keys) (void)hipFree(ctx->d_dist_keys);
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     }
+    if (ctx->capture_edge) (void)hipEventDestroy(ctx->capture_edge);
     if (ctx->cpu_ctx) pq::cpu_companion().context_destroy(ctx->cpu_ctx);
     delete ctx;
 }
@@ -307,12 +359,14 @@ uint64_t piquant_hip_barrier_bailouts(piquant_context_t* ctx) {
 void piquant_hip_set_stream(piquant_context_t* ctx, void* hip_stream) {
     if (!ctx) panic("piquant_hip_set_stream: context is NULL");
     std::lock_guard<std::mutex> lock(ctx->mu);
+    leave_stream(ctx, static_cast<hipStream_t>(hip_stream));
     ctx->stream = static_cast<hipStream_t>(hip_stream);   // NULL == the legacy default stream, as everywhere in HIP
 }
 
 void piquant_hip_reset_stream(piquant_context_t* ctx) {
     if (!ctx) panic("piquant_hip_reset_stream: context is NULL");
     std::lock_guard<std::mutex> lock(ctx->mu);
+    leave_stream(ctx, ctx->own_stream);
     ctx->stream = ctx->own_stream;
 }
 

@@ -76,6 +76,8 @@ struct piquant_context_t {
     uint32_t mailbox_seq = 0;
     int32_t* d_dist_keys = nullptr;        // {key(min), key(-max)} buffer the RCCL all-reduce of the *_dist call runs on
     hipStream_t scan_stream = nullptr;     // stream of the previous scan (scans of one context must not overlap)
+    hipStream_t capture_stream = nullptr;  // capturing stream that last used the scan / barrier state (order_context_state)
+    hipEvent_t capture_edge = nullptr;     // event that turns "used by another capturing stream" into a graph edge
     void* d_fused = nullptr;               // FusedState of the one-launch params + quantize kernel (fused_kernels.hpp)
     bool fusion = true;                    // piquant_hip_set_fusion
     uint32_t barrier_timeout_us = 0;       // piquant_hip_set_barrier_timeout_us (0 = the kernel's default, 1 ms)
@@ -157,6 +159,18 @@ class FusedLaunchOrder {
 };
 
 float draw_threshold(piquant_context_t* ctx);
+
+// The scan state (d_state) and the fused kernel's barrier state (d_fused) are per CONTEXT.  Outside capture, launches that use them are
+// serialised by stream order plus the synchronise-on-stream-change in scan() and FusedLaunchOrder.  Inside capture those are skipped (a
+// capturing stream cannot be synchronised), so two captured launches of one context on parallel branches of one graph -- two side streams
+// forked inside a capture -- would share the state concurrently: keys of different tensors mixed, silently wrong parameters.  This makes
+// the second launch a graph successor of the first: an event recorded on the capturing stream that used the state last and waited for
+// by the one about to (both legal inside capture; they become a graph edge).  If the two streams capture different graphs HIP refuses
+// the wait, and so does this library: abort with the advice to use one context per stream.  Caller holds ctx->mu; call it before
+// every scan and every fused launch.
+void order_context_state(piquant_context_t* ctx);
+// A stream the caller is about to stop using (piquant_hip_set_stream / reset_stream): nothing may keep its handle.
+void detach_fused_stream(int device, hipStream_t stream);
 
 // Entry points of libpiquant_cpu.so (include/piquant_cpu.h), resolved on first use from the directory this library was loaded from; aborts
 // when the companion is missing -- a context asked for the CPU host path must not quietly get something else.

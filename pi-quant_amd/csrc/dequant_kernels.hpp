@@ -82,7 +82,9 @@ struct DequantTile {
     static constexpr int64_t BLOCK_ELEMS = static_cast<int64_t>(WAVES) * WAVE_VECS * EPV;
 };
 
-template <int BITS, int DT_OUT, int OP, int U, bool STAGE, int NT, int BLOCK>
+// COPY_ONLY (tune harness): no arithmetic -- every output word is the vector's packed input word -- i.e. this kernel's traffic, tile shape,
+// LDS staging and store policy alone: the ceiling the real kernel is measured against.
+template <int BITS, int DT_OUT, int OP, int U, bool STAGE, int NT, int BLOCK, bool COPY_ONLY = false>
 __global__ void __launch_bounds__(BLOCK)
 dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int64_t n_tiles, float scale, float bias, const ParamRecord* dyn, int32_t zp32,
                   uint32_t tile_stride, DequantParams p_arg, int head) {
@@ -178,6 +180,12 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
 
 #pragma unroll
         for (int k = 0; k < U; ++k) {
+            if constexpr (COPY_ONLY) {
+                u32x4 r = {w[k][0], w[k][WORDS - 1], w[k][0], w[k][WORDS - 1]};
+                if constexpr (OP == OP_ADD) r ^= old[k];
+                st<NT_ST>(out16 + v0 + k * 64 + lane, r);
+                continue;
+            }
             float f[EPV];
 #pragma unroll
             for (int e = 0; e < EPV; ++e) {
@@ -207,10 +215,10 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
 
 }
 
-template <int BITS, int DT_OUT, int OP, int U, bool STAGE, int NT, int BLOCK>
+template <int BITS, int DT_OUT, int OP, int U, bool STAGE, int NT, int BLOCK, bool COPY_ONLY = false>
 inline void launch_dequantize_kernel(unsigned grid, hipStream_t stream, const uint8_t* in, void* out, int64_t numel, int64_t n_tiles, const DequantParams& p, int head) {
-    hipLaunchKernelGGL((dequantize_kernel<BITS, DT_OUT, OP, U, STAGE, NT, BLOCK>), dim3(grid), dim3(BLOCK), 0, stream, in, out, numel, n_tiles, p.scale, p.bias, p.dyn,
-                       p.zp32, grid, p, head);
+    hipLaunchKernelGGL((dequantize_kernel<BITS, DT_OUT, OP, U, STAGE, NT, BLOCK, COPY_ONLY>), dim3(grid), dim3(BLOCK), 0, stream, in, out, numel, n_tiles, p.scale, p.bias,
+                       p.dyn, p.zp32, grid, p, head);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

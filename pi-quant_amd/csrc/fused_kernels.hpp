@@ -179,17 +179,31 @@ __device__ __forceinline__ unsigned long long fused_params_word(int32_t k0, int3
 // path).  true ("all-gather"): every block stores its own {key(min), key(-max)} word into its own slot with ONE store and then
 // sweeps all G slots (wave 0, up to four 8-byte loads per lane) until none is empty; everybody derives the parameters itself
 // (a double-precision division per block is nothing) -- one store propagation plus one sweep on the critical path.
+// The eight scalars in front of `groups` repeat tensor 0 and the grid shape: 13 dwords that arrive preloaded in SGPRs (Makefile,
+// -amdgpu-kernarg-preload-count; aggregates are never preloaded), so that the single-tensor launch -- the common one -- issues its first
+// loads without the two dependent s_loads of the kernarg segment (blocks_per_group, then the indexed pointers) it used to start with.
+// LEAD = false ignores them (the tune harness' A/B).
 template <int DT_IN, int BITS, int MODE, int R_REG, int R_LDS, int LDS_BATCH, int BLOCK, int ST_POLICY = ST_WT, bool TIMING = false, int STREAM_BATCH = 4,
-          int RED_BITS = 0, bool AG = true>
+          int RED_BITS = 0, bool AG = true, bool LEAD = true>
 __global__ void __launch_bounds__(BLOCK)
-fused_params_quantize_kernel(FusedGroups groups, QuantParams p_arg, FusedState* states, FusedReduce red) {
+fused_params_quantize_kernel(const void* in0, uint8_t* out0, int64_t numel0, ParamRecord* params0, FusedState* states, int count, int blocks_per_group,
+                             uint32_t bail_ticks_arg, FusedGroups groups, QuantParams p_arg, FusedReduce red) {
     // Block -> (tensor, block within the tensor's sub-grid).  With one tensor this is the identity.
-    const int group = static_cast<int>(blockIdx.x) / groups.blocks_per_group;
-    const uint32_t block = blockIdx.x - static_cast<uint32_t>(group) * groups.blocks_per_group;
-    const void* __restrict__ in = groups.in[group];
-    uint8_t* __restrict__ out = groups.out[group];
-    const int64_t numel = groups.numel[group];
-    ParamRecord* params_out = groups.params[group];
+    int group = 0;
+    uint32_t block = blockIdx.x;
+    const void* __restrict__ in = in0;
+    uint8_t* __restrict__ out = out0;
+    int64_t numel = numel0;
+    ParamRecord* params_out = params0;
+    if (!LEAD || count > 1) {
+        group = static_cast<int>(blockIdx.x) / groups.blocks_per_group;
+        block = blockIdx.x - static_cast<uint32_t>(group) * groups.blocks_per_group;
+        in = groups.in[group];
+        out = groups.out[group];
+        numel = groups.numel[group];
+        params_out = groups.params[group];
+    }
+    if (!LEAD) blocks_per_group = groups.blocks_per_group;
     FusedState* st = states + group;
     static_assert(R_LDS % LDS_BATCH == 0, "the LDS-resident rounds are loaded in whole batches");
     constexpr int EPV = InVec<DT_IN>::EPV, OB = EPV * BITS / 8, WAVES = BLOCK / 64;
@@ -199,7 +213,7 @@ fused_params_quantize_kernel(FusedGroups groups, QuantParams p_arg, FusedState* 
     __shared__ float s_lo[WAVES], s_hi[WAVES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t G = groups.blocks_per_group;
+    const int64_t G = blocks_per_group;
     const int64_t n_vec = numel / EPV;
     constexpr int64_t round_vecs = BLOCK;
     // A share is rounds_total rounds long (whole rounds, dealt evenly: fused_first_round); the first R_REG + R_LDS of them stay on chip, the rest (tensors larger than the chip
@@ -320,7 +334,8 @@ fused_params_quantize_kernel(FusedGroups groups, QuantParams p_arg, FusedState* 
             lo = __builtin_fminf(lo, s_lo[w]);   // every lane of wave 0 holds the wave result; fold the other waves in all lanes
             hi = __builtin_fmaxf(hi, s_hi[w]);
         }
-        const uint32_t bail_ticks = groups.bail_ticks != 0 ? groups.bail_ticks : 100000u;   // 100 MHz ticks: 1 ms
+        const uint32_t bail_raw = LEAD ? bail_ticks_arg : groups.bail_ticks;
+        const uint32_t bail_ticks = bail_raw != 0 ? bail_raw : 100000u;   // 100 MHz ticks: 1 ms
         const uint64_t t_arrive = wall_clock64();
         const uint32_t my_word = block >> 5, my_bit = 1u << (block & 31);
         bool leave = false;
@@ -587,6 +602,13 @@ fused_params_quantize_kernel(FusedGroups groups, QuantParams p_arg, FusedState* 
         }
         __syncthreads();   // s_claim is rewritten in the next round
     }
+}
+
+// Host side of the argument convention above.
+template <typename Kernel>
+inline void launch_fused_kernel(Kernel kernel, unsigned grid, unsigned block, hipStream_t stream, const FusedGroups& g, const QuantParams& p, FusedState* states,
+                                const FusedReduce& red) {
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, g.in[0], g.out[0], g.numel[0], g.params[0], states, g.count, g.blocks_per_group, g.bail_ticks, g, p, red);
 }
 
 }  // namespace pq

@@ -59,7 +59,10 @@ void quantize_t(const QuantLaunch& q, const QuantParams& p, hipStream_t stream, 
     const int64_t numel = q.numel - head;
     const int64_t n_tiles = numel / Tile::BLOCK_ELEMS;
     const unsigned grid = capped_grid(n_tiles, t.blocks_per_cu, num_cu);
-    launch_quantize_kernel<DT_IN, BITS, MODE, t.u, t.stage, t.nt, t.block, kQuantShortStep, kQuantVariant>(
+    // the saturating pack wins wherever it was measured except bf16 -> uint2 nearest, where its 2-bit shuffle costs more than the
+    // Horner steps it replaces (11.74 vs 11.50 us; stochastic rounding, which needs no truncation before it: 12.84 vs 13.10; profiles/r03_tune_bf16_ceiling.csv)
+    constexpr int kVariant = (DT_IN == DT_BF16 && BITS == 2 && (MODE == RM_NEAREST_FAST || MODE == RM_NEAREST_I64)) ? (kQuantVariant & ~QV_SAT_PACK) : kQuantVariant;
+    launch_quantize_kernel<DT_IN, BITS, MODE, t.u, t.stage, t.nt, t.block, kQuantShortStep, kVariant>(
         grid, 0, stream, static_cast<const void*>(static_cast<const uint8_t*>(q.in) + head * ESIZE), out + head_bytes, numel, n_tiles, body, static_cast<int>(head));
 }
 
@@ -212,12 +215,12 @@ bool fused_launch(const FusedGroups& g, const QuantParams& p, FusedState* states
         auto kernel = fused_params_quantize_kernel<DT_IN, BITS, MODE, kFusedRegRounds, kFusedLdsRounds, kFusedLdsRounds, kFusedBlock, ST_WT, false, 4, 0, kFusedAllGather>;
         static const bool fits = fused_kernel_fits(kernel);
         if (!fits) return false;
-        hipLaunchKernelGGL(kernel, grid, dim3(kFusedBlock), 0, stream, g, p, states, FusedReduce {});
+        launch_fused_kernel(kernel, grid.x, kFusedBlock, stream, g, p, states, FusedReduce {});
     } else {   // the terms to add have the quantized type this call produces (chunks of one all-reduce)
         auto kernel = fused_params_quantize_kernel<DT_IN, BITS, MODE, kFusedReduceRegRounds, kFusedLdsRounds, kFusedLdsRounds, kFusedBlock, ST_WT, false, 4, BITS, kFusedAllGather>;
         static const bool fits = fused_kernel_fits(kernel);
         if (!fits) return false;
-        hipLaunchKernelGGL(kernel, grid, dim3(kFusedBlock), 0, stream, g, p, states, *red);
+        launch_fused_kernel(kernel, grid.x, kFusedBlock, stream, g, p, states, *red);
     }
     return true;
 }

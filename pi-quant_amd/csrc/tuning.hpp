@@ -23,8 +23,10 @@ constexpr int kStream = 1 | (2 << 1);
 // (profiles/r01_tune_finals_other*.csv).
 constexpr KernelTune kQuantTune[2][3] = {
     {{2, true, kStream, 128, 0}, {2, true, kStream, 64, 0}, {2, true, kStream, 64, 0}},
-    {{2, true, kStream, 64, 0}, {2, true, kStream, 64, 0}, {4, true, kStream, 256, 0}},
+    {{2, true, kStream, 64, 0}, {2, true, kStream, 64, 0}, {2, true, kStream, 64, 0}},
 };
+// (bf16 -> uint2 had 256-thread / U=4 tiles until round 3: with real bf16 data -- the harness used to feed random bit patterns, NaNs in every
+// tile, which never took the short step -- 64-thread / U=2 tiles are faster for it too, 11.50 vs 11.81 us, profiles/r03_tune_bf16_ceiling.csv)
 
 // The per-tile short step of the streaming quantize kernels (quant_kernels.hpp, quantize_vec_short): on.  It halves the arithmetic; its range
 // test (max|x| over the tile, a wave-wide vote, a branch) makes a wave wait for all its loads before it computes, which costs the fp32 inputs
@@ -33,7 +35,13 @@ constexpr KernelTune kQuantTune[2][3] = {
 // bf16->uint2 12.5 / 13.3, fp32->uint8 23.1 / 23.2, fp32->uint4 20.6 / 20.6, fp32->uint2 19.5 / 19.5.  (The tune harness' own A/B, mode `shortab`,
 // disagrees by +-0.4 us from run to run at this size -- it launches from the host over fewer sets -- and is not what this was decided on.)
 constexpr bool kQuantShortStep = true;
-// Experiment switches of quantize_kernel (quant_kernels.hpp, QV_*) as the library builds it.
+// Switches of quantize_kernel's short step (quant_kernels.hpp, QV_*) as the library builds it, from the interleaved A/B against a copy kernel
+// with the same traffic, tile and store policy (tools/tune_kernels.hip `bf16`, profiles/r03_tune_bf16_ceiling.csv; numel 27 264 000, 40 cold sets;
+// copy / round 2's step / +raw-word range test / +OR first look / +saturating pack):
+//   bf16 -> uint4 nearest 12.05 / 12.87 / 12.66 / 12.63 / 12.57 us, stochastic 12.05 / 14.68 / 14.10 / 13.90 / 13.43
+//   bf16 -> uint8 nearest 14.16 / 14.81 / 14.63 / 14.61 / 14.62,    stochastic 14.16 / 15.25 / 15.27 / 15.13 / 15.11
+//   bf16 -> uint2 nearest 10.77 / 12.37 / 11.66 / 11.50 / 11.74 (64-thread tiles), stochastic 10.95 / 13.69 / 13.67 / 13.10 / 12.84 (256-thread tiles)
+// fp32 inputs sit on their copy ceiling either way (22.50 copy / 22.74 / 22.75 for fp32 -> uint8; profiles/r03_tune_f32_ceiling.csv).
 constexpr int kQuantVariant = 7;
 
 // dequantize, indexed [dt_out: f32,bf16][bits: 8,4,2]; SET and ADD separately -- ADD also streams the accumulator in, which moves the

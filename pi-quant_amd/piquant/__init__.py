@@ -77,6 +77,18 @@ class Context:
     # made, so two threads driving different streams through one shared default context could swap each other's stream between
     # "set the stream" and "make the call".  Contexts are cheap (a private stream, ~60 KiB of device state, two pinned words).
     _tls = threading.local()
+    # Policy applied to a DEFAULT context -- fusion, barrier timeout, blocking-wait mode, stochastic seed / threshold, reference layout,
+    # host path -- is process-wide intent ("fusion off", "seeded run"), but default contexts are per thread: without this record the
+    # default context an autograd or DDP comm-hook thread gets on first use would silently lack what the main thread configured.  Setters
+    # called on any default context are recorded here and replayed into every default context created afterwards (explicit contexts are
+    # nobody's template and inherit nothing).
+    _default_policy: Dict[str, tuple] = {}
+    _default_policy_lock = threading.Lock()
+
+    def _record_policy(self, name: str, *args) -> None:
+        if getattr(self, '_is_default', False):
+            with Context._default_policy_lock:
+                Context._default_policy[name] = args
 
     def __init__(self, num_threads: Union[int, None] = None) -> None:
         self._num_threads = 0 if num_threads is None else int(num_threads)
@@ -99,6 +111,11 @@ class Context:
         ctx = defaults.get(device_index)
         if ctx is None:
             ctx = _make_on_device(device_index)
+            with Context._default_policy_lock:
+                policy = dict(Context._default_policy)
+            for name, args in policy.items():      # what earlier default contexts were told (see _default_policy)
+                getattr(ctx, name)(*args)
+            ctx._is_default = True
             defaults[device_index] = ctx
         return ctx
 
@@ -180,6 +197,7 @@ class Context:
     def set_blocking_wait(self, mode: str) -> None:
         """How a blocking call waits for the GPU: 'sync' (hipStreamSynchronize), 'write32' (the command processor writes a pinned host
         word behind the kernel, the host spins on it) or 'kernel' (a one-thread kernel writes it); include/piquant_hip.h."""
+        self._record_policy('set_blocking_wait', mode)
         C.piquant_hip_set_blocking_wait(self._ctx, {'sync': 0, 'write32': 1, 'kernel': 2}[mode])
 
     def assume_device_pointers(self, assume: bool) -> None:
@@ -192,19 +210,23 @@ class Context:
 
     def set_stochastic_threshold(self, threshold: Optional[float]) -> None:
         """Pin the per-call stochastic threshold in [0,1) (None: draw a fresh one per call, the default)."""
+        self._record_policy('set_stochastic_threshold', threshold)
         C.piquant_hip_set_stochastic_threshold(self._ctx, -1.0 if threshold is None else float(threshold))
 
     def set_stochastic_seed(self, seed: int) -> None:
+        self._record_policy('set_stochastic_seed', seed)
         C.piquant_hip_set_stochastic_seed(self._ctx, seed & 0xFFFFFFFFFFFFFFFF)
 
     def set_stochastic_per_element(self, enabled: bool, seed: int = 0, index_base: int = 0) -> None:
         """Opt-in: an independent threshold per element (counter hash of seed and global element index)."""
+        self._record_policy('set_stochastic_per_element', enabled, seed, index_base)
         C.piquant_hip_set_stochastic_per_element(self._ctx, 1 if enabled else 0, seed & 0xFFFFFFFFFFFFFFFF, index_base)
 
     def set_reference_layout(self, enabled: bool, threads: int = 1) -> None:
         """Opt-in: reproduce the reference's scalar head/tail formulas at the positions where its AVX-512 build uses them
         (include/piquant_hip.h), for a reference context with ``threads`` pool threads (each partition has its own head and tail);
         off, every element takes the SIMD-body formula."""
+        self._record_policy('set_reference_layout', enabled, threads)
         C.piquant_hip_set_reference_threads(self._ctx, int(threads))
         C.piquant_hip_set_reference_layout(self._ctx, 1 if enabled else 0)
 
@@ -286,15 +308,18 @@ class Context:
         """Who serves calls on pageable HOST buffers: 'stage' (default: PCIe staging through the HIP kernels) or 'cpu' (the companion
         libpiquant_cpu.so: the same arithmetic in AVX-512 on the host cores).  Device and pinned buffers always run the HIP kernels
         (include/piquant_hip.h)."""
+        self._record_policy('set_host_path', path)
         C.piquant_hip_set_host_path(self._ctx, {'stage': 0, 'cpu': 1}[path])
 
     def set_fusion(self, enabled: bool) -> None:
         """False: ``quantize_dynamic`` always runs the scan (with its parameter epilogue) and the quantize kernel as two launches (for A/B timing)."""
+        self._record_policy('set_fusion', enabled)
         C.piquant_hip_set_fusion(self._ctx, 1 if enabled else 0)
 
     def set_barrier_timeout_us(self, microseconds: int) -> None:
         """Longest wait of a block at the fused kernel's grid barrier before it hands its share over and frees its CU
         (include/piquant_hip.h); 0 = default (1 ms)."""
+        self._record_policy('set_barrier_timeout_us', microseconds)
         C.piquant_hip_set_barrier_timeout_us(self._ctx, int(microseconds))
 
     def barrier_bailouts(self) -> int:

@@ -853,6 +853,90 @@ def test_dynamic_pipeline_equals_the_two_step_path_and_is_graph_capturable(O):
         assert same_floats(y.cpu().numpy(), O.dequantize(wq, 4, 0, n, scale, zp))
 
 
+def test_one_context_on_two_forked_streams_inside_one_capture(O):
+    """Round-2 advisor finding: inside capture the context's own serialisation is skipped, so two fused / scan launches of ONE context
+    captured on parallel branches of a graph (two side streams forked inside the capture) shared the barrier and scan state concurrently
+    and could mix the keys of different tensors.  Now the second launch is made a graph successor of the first (event edge inside the
+    capture): both tensors get their own parameters and bytes on every replay, fused and unfused."""
+    import piquant
+    import torch
+
+    rng = np.random.default_rng(91)
+    n = 5_000_000
+    for fusion in (True, False):
+        c = piquant.Context()
+        c.set_fusion(fusion)
+        xa, xb = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        qa, qb = torch.zeros(n, dtype=torch.uint8, device="cuda"), torch.zeros(n, dtype=torch.uint8, device="cuda")
+        ra, rb = torch.zeros(16, dtype=torch.uint8, device="cuda"), torch.zeros(16, dtype=torch.uint8, device="cuda")
+        main, side = torch.cuda.Stream(), torch.cuda.Stream()
+        with torch.cuda.stream(main):
+            piquant.torch.quantize_dynamic(xa, dtype=torch.uint8, ctx=c, out=qa, params=ra)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(main):
+            with torch.cuda.graph(g, stream=main):
+                side.wait_stream(main)                      # fork: `side` joins the capture
+                piquant.torch.quantize_dynamic(xa, dtype=torch.uint8, ctx=c, out=qa, params=ra)
+                with torch.cuda.stream(side):
+                    piquant.torch.quantize_dynamic(xb, dtype=torch.uint8, ctx=c, out=qb, params=rb)
+                main.wait_stream(side)                      # join
+        for ka, kb in ((1.0, 40.0), (25.0, 0.5), (3.0, 3.0)):
+            da = (rng.normal(size=n) * ka).astype(np.float32)
+            db = (rng.normal(size=n) * kb + 2.0).astype(np.float32)
+            xa.copy_(torch.from_numpy(da))
+            xb.copy_(torch.from_numpy(db))
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            for data, q, rec in ((da, qa, ra), (db, qb, rb)):
+                scale, zp = piquant.torch.params_to_host(rec)
+                assert (scale, zp) == O.compute_quant_params(data, 0, 4), (fusion, ka, kb)
+                assert np.array_equal(q.cpu().numpy(), O.quantize(data, 0, 4, scale, zp))
+        assert c.barrier_bailouts() == 0 if hasattr(c, "barrier_bailouts") else True
+
+
+def test_stream_can_be_destroyed_after_it_has_been_replaced(ctx, O):
+    """A caller's stream handed to set_stream may be destroyed once the context has moved to another stream: no scan or fused launch that
+    follows may touch the old handle (round-2 advisor finding: the fused-launch order and the scan kept it)."""
+    import piquant
+    import torch
+
+    rng = np.random.default_rng(92)
+    x = rng.uniform(-1, 1, 2_000_000).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    c = piquant.Context()
+    for _ in range(3):
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            q, rec = piquant.torch.quantize_dynamic(xd, dtype=torch.uint8, ctx=c)
+            sp = piquant.torch.compute_quant_params(xd, dtype=torch.quint8, ctx=c)
+        c.reset_stream()
+        del s                                   # torch returns pooled streams, so also force real handle churn below
+        torch.cuda.synchronize()
+        assert piquant.torch.params_to_host(rec) == sp == O.compute_quant_params(x, 0, 4)
+    import ctypes
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    for _ in range(3):
+        h = ctypes.c_void_p()
+        assert hip.hipStreamCreate(ctypes.byref(h)) == 0
+        c.set_stream(h.value)
+        c.set_blocking(False)
+        out = torch.empty(x.size, dtype=torch.uint8, device="cuda")
+        recb = torch.zeros(16, dtype=torch.uint8, device="cuda")
+        c.quantize_dynamic_ptr(xd.data_ptr(), piquant.DataType.F32, out.data_ptr(), piquant.DataType.UINT8, x.size, recb.data_ptr(), piquant.RoundMode.NEAREST, _device_ptrs=True)
+        c.reset_stream()                        # the context lets go of the handle ...
+        assert hip.hipStreamSynchronize(h) == 0
+        assert hip.hipStreamDestroy(h) == 0     # ... so it may die
+        out2 = torch.empty(x.size, dtype=torch.uint8, device="cuda")
+        c.quantize_dynamic_ptr(xd.data_ptr(), piquant.DataType.F32, out2.data_ptr(), piquant.DataType.UINT8, x.size, recb.data_ptr(), piquant.RoundMode.NEAREST, _device_ptrs=True)
+        c.set_blocking(True)
+        s_, z_ = c.compute_quant_params_ptr_float32(xd.data_ptr(), piquant.DataType.UINT8, x.size, _device_ptrs=True)
+        torch.cuda.synchronize()
+        assert (s_, z_) == O.compute_quant_params(x, 0, 4) and torch.equal(out, out2)
+
+
 def test_minmax_keys_accumulate_across_calls(ctx, O):
     """init=0 folds further scans into the same keys: the building block of the multi-GPU reduction."""
     import piquant

@@ -262,8 +262,8 @@ static void run_quant3(const Bufs& b, int64_t numel, double bytes_per_elem, int 
     report("quantize3", name, us, bytes_per_elem * numel);
 }
 
-template <int BITS, int DT_OUT, int OP, int U, bool STAGE, int NT, int BLOCK>
-static void run_dequant3(const Bufs& b, int64_t numel, double bytes_per_elem, int off_in, int off_out, int peel) {
+template <int BITS, int DT_OUT, int OP, int U, bool STAGE, int NT, int BLOCK, bool COPY_ONLY = false>
+static void run_dequant3(const Bufs& b, int64_t numel, double bytes_per_elem, int off_in = 0, int off_out = 0, int peel = 128) {
     using T = DequantTile<BITS, DT_OUT, U, BLOCK>;
     constexpr int PACK = 8 / BITS, ESIZE = DT_OUT == DT_F32 ? 4 : 2, QMAX = (1 << BITS) - 1;
     DequantParams p {};
@@ -276,12 +276,12 @@ static void run_dequant3(const Bufs& b, int64_t numel, double bytes_per_elem, in
     const int64_t body = numel - head, n_tiles = body / T::BLOCK_ELEMS;
     const unsigned grid = static_cast<unsigned>(std::max<int64_t>(n_tiles, 1));
     const double us = time_us([&](int i) {   // roles swapped: the small buffer (b.out) is the packed input, the big one (b.in) the float output
-        launch_dequantize_kernel<BITS, DT_OUT, OP, U, STAGE, NT, BLOCK>(grid, g_stream, static_cast<const uint8_t*>(b.out[i % SETS]) + off_in + head / PACK,
+        launch_dequantize_kernel<BITS, DT_OUT, OP, U, STAGE, NT, BLOCK, COPY_ONLY>(grid, g_stream, static_cast<const uint8_t*>(b.out[i % SETS]) + off_in + head / PACK,
                                                                         static_cast<uint8_t*>(b.in[i % SETS]) + off_out + head * ESIZE, body, n_tiles, p, static_cast<int>(head));
     });
     char name[200];
-    std::snprintf(name, sizeof name, "bits=%d out=%s op=%s U=%d block=%d nt=%d off_in=%d off_out=%d head=%d", BITS, DT_OUT == DT_F32 ? "f32" : "bf16", OP == OP_ADD ? "add" : "set",
-                  U, BLOCK, NT, off_in, off_out, static_cast<int>(head));
+    std::snprintf(name, sizeof name, "bits=%d out=%s op=%s%s U=%d block=%d nt=%d off_in=%d off_out=%d head=%d", BITS, DT_OUT == DT_F32 ? "f32" : "bf16",
+                  OP == OP_ADD ? "add" : "set", COPY_ONLY ? " COPY" : "", U, BLOCK, NT, off_in, off_out, static_cast<int>(head));
     report("dequantize3", name, us, bytes_per_elem * numel);
 }
 
@@ -370,18 +370,17 @@ static FusedGroups one_group(const void* in, void* out, int64_t numel, ParamReco
     return g;
 }
 
-template <int R_REG, int R_LDS, int LDS_BATCH, int BLOCK, int STP = ST_WT, int SB = 4, bool AG = true>
+template <int R_REG, int R_LDS, int LDS_BATCH, int BLOCK, int STP = ST_WT, int SB = 4, bool AG = true, bool LEAD = true>
 static void run_fused(const Bufs& b, const FusedBufs& f, int64_t numel, int num_cu, int32_t* slots) {
     const int64_t n_vec = numel / 4;
     char name[160];
-    std::snprintf(name, sizeof name, "f32->u8 fused R_REG=%d R_LDS=%d batch=%d block=%d stream_batch=%d st=%s barrier=%s", R_REG, R_LDS, LDS_BATCH, BLOCK, SB,
-                  STP == ST_WT ? "wt" : (STP == ST_NT ? "nt" : "plain"), AG ? "allgather" : "counter");
+    std::snprintf(name, sizeof name, "f32->u8 fused R_REG=%d R_LDS=%d batch=%d block=%d stream_batch=%d st=%s barrier=%s args=%s", R_REG, R_LDS, LDS_BATCH, BLOCK, SB,
+                  STP == ST_WT ? "wt" : (STP == ST_NT ? "nt" : "plain"), AG ? "allgather" : "counter", LEAD ? "preloaded" : "from-struct");
     if (fused_rounds(n_vec, num_cu, BLOCK) > R_REG + R_LDS)
         std::fprintf(stderr, "%s: %lld rounds, %d of them resident\n", name, static_cast<long long>(fused_rounds(n_vec, num_cu, BLOCK)), R_REG + R_LDS);
     QuantParams p {};
     auto launch = [&](int i) {
-        hipLaunchKernelGGL((fused_params_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, R_REG, R_LDS, LDS_BATCH, BLOCK, STP, false, SB, 0, AG>), dim3(num_cu), dim3(BLOCK), 0,
-                           g_stream, one_group(b.in[i % SETS], b.out[i % SETS], numel, f.rec, num_cu), p, f.st, FusedReduce {});
+        launch_fused_kernel(fused_params_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, R_REG, R_LDS, LDS_BATCH, BLOCK, STP, false, SB, 0, AG, LEAD>, num_cu, BLOCK, g_stream, one_group(b.in[i % SETS], b.out[i % SETS], numel, f.rec, num_cu), p, f.st, FusedReduce {});
     };
     // correctness first: same bytes and record as scan (with parameter epilogue) -> quantize
     CK(hipMemsetAsync(b.out[0], 0x5a, numel, g_stream));
@@ -412,8 +411,7 @@ static void run_fused(const Bufs& b, const FusedBufs& f, int64_t numel, int num_
     report("fused", name, us, 5.0 * numel);
     // where block 0 spends its time (100 MHz wall clock): one launch on a quiet device
     CK(hipStreamSynchronize(g_stream));
-    hipLaunchKernelGGL((fused_params_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, R_REG, R_LDS, LDS_BATCH, BLOCK, STP, true, SB, 0, AG>), dim3(num_cu), dim3(BLOCK), 0, g_stream,
-                       one_group(b.in[3], b.out[3], numel, f.rec, num_cu), p, f.st, FusedReduce {});
+    launch_fused_kernel(fused_params_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, R_REG, R_LDS, LDS_BATCH, BLOCK, STP, true, SB, 0, AG, LEAD>, num_cu, BLOCK, g_stream, one_group(b.in[3], b.out[3], numel, f.rec, num_cu), p, f.st, FusedReduce {});
     CK(hipStreamSynchronize(g_stream));
     std::vector<uint64_t> t(static_cast<size_t>(num_cu) * 8);
     CK(hipMemcpy(t.data(), f.stamps, t.size() * 8, hipMemcpyDeviceToHost));
@@ -436,8 +434,7 @@ static void run_fused(const Bufs& b, const FusedBufs& f, int64_t numel, int num_
     // launch-to-launch spread of the phases: 36 more stamped launches, rotating over the buffer sets, one line each
     if (g_verbose_phases) {
         for (int it = 0; it < 36; ++it) {
-            hipLaunchKernelGGL((fused_params_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, R_REG, R_LDS, LDS_BATCH, BLOCK, STP, true, SB, 0, AG>), dim3(num_cu), dim3(BLOCK), 0, g_stream,
-                               one_group(b.in[it % SETS], b.out[it % SETS], numel, f.rec, num_cu), p, f.st, FusedReduce {});
+            launch_fused_kernel(fused_params_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, R_REG, R_LDS, LDS_BATCH, BLOCK, STP, true, SB, 0, AG, LEAD>, num_cu, BLOCK, g_stream, one_group(b.in[it % SETS], b.out[it % SETS], numel, f.rec, num_cu), p, f.st, FusedReduce {});
             CK(hipStreamSynchronize(g_stream));
             std::vector<uint64_t> u(static_cast<size_t>(num_cu) * 8);
             CK(hipMemcpy(u.data(), f.stamps, u.size() * 8, hipMemcpyDeviceToHost));
@@ -589,6 +586,12 @@ int main(int argc, char** argv) {
 #undef ROW
             run_quant3<DT_BF16, 4, RM_COPY, 2, true, 3, 64, 0>(b, numel, 2.5);   // non-temporal stores
             run_quant3<DT_BF16, 4, RM_NEAREST_FAST, 2, true, 3, 64, 7>(b, numel, 2.5);
+            run_quant3<DT_BF16, 4, RM_STOCH_CALL, 2, true, 3, 64, 7>(b, numel, 2.5);
+            run_quant3<DT_BF16, 8, RM_NEAREST_FAST, 2, true, 3, 64, 7>(b, numel, 3.0);
+            run_quant3<DT_BF16, 2, RM_NEAREST_FAST, 2, true, 3, 64, 3>(b, numel, 2.25);
+            run_quant3<DT_BF16, 2, RM_STOCH_CALL, 2, true, 5, 64, 7>(b, numel, 2.25);
+            run_quant3<DT_BF16, 2, RM_STOCH_CALL, 2, true, 5, 64, 3>(b, numel, 2.25);
+            run_quant3<DT_BF16, 2, RM_STOCH_CALL, 2, true, 3, 64, 7>(b, numel, 2.25);
         }
         g_rounds = 3;
     }
@@ -607,6 +610,30 @@ int main(int argc, char** argv) {
             run_quant3<DT_F32, 2, RM_COPY, 2, true, 5, 64, 0>(b, numel, 4.25);
             run_quant3<DT_F32, 2, RM_NEAREST_I64, 2, true, 5, 64, 0>(b, numel, 4.25);
             run_quant3<DT_F32, 2, RM_NEAREST_I64, 2, true, 5, 64, 7>(b, numel, 4.25);
+        }
+        g_rounds = 3;
+    }
+    if (only == "dq") {
+        // Round 3: every dequantize operator with its production tile (tuning.hpp) against the same kernel without arithmetic.  numel elements
+        // of output; the float side lives in the big buffers (109 MB each), so bf16 outputs of 2 x numel would not fit: numel for all.
+        g_rounds = 1;
+        for (int pass = 0; pass < 5; ++pass) {
+#define DQ(BITS, DT, OP, U_, NT_, BLK, BPE)                                      \
+    run_dequant3<BITS, DT, OP, U_, true, NT_, BLK, true>(b, numel, BPE);         \
+    run_dequant3<BITS, DT, OP, U_, true, NT_, BLK, false>(b, numel, BPE);
+            DQ(8, DT_F32, OP_SET, 2, 5, 128, 5)
+            DQ(4, DT_F32, OP_SET, 4, 5, 256, 4.5)
+            DQ(2, DT_F32, OP_SET, 4, 5, 256, 4.25)
+            DQ(8, DT_BF16, OP_SET, 2, 5, 64, 3)
+            DQ(4, DT_BF16, OP_SET, 4, 3, 256, 2.5)
+            DQ(2, DT_BF16, OP_SET, 4, 3, 256, 2.25)
+            DQ(8, DT_F32, OP_ADD, 2, 5, 128, 9)
+            DQ(4, DT_F32, OP_ADD, 2, 5, 128, 8.5)
+            DQ(2, DT_F32, OP_ADD, 2, 3, 128, 8.25)
+            DQ(8, DT_BF16, OP_ADD, 2, 3, 64, 5)
+            DQ(4, DT_BF16, OP_ADD, 2, 3, 64, 4.5)
+            DQ(2, DT_BF16, OP_ADD, 2, 3, 64, 4.25)
+#undef DQ
         }
         g_rounds = 3;
     }
@@ -1093,7 +1120,7 @@ int main(int argc, char** argv) {
         }
         g_rounds = 3;
     }
-    if (only == "fused" || only == "fusedphases") {
+    if (only == "fused" || only == "fusedphases" || only == "fused3") {
         g_verbose_phases = only == "fusedphases";
         FusedBufs f {};
         CK(hipMalloc(reinterpret_cast<void**>(&f.st), sizeof(FusedState)));
@@ -1120,6 +1147,15 @@ int main(int argc, char** argv) {
                 launch_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, 2, true, mem_policy(true, ST_WT), 128>(static_cast<unsigned>(std::max<int64_t>(n_tiles, 1)), 0, g_stream, static_cast<const void*>(b.in[i % SETS]), static_cast<uint8_t*>(b.out[i % SETS]), numel, n_tiles, pd, 0);
             });
             report("fused", "f32->u8 two launches (scan with parameter epilogue, quantize)", us, 9.0 * numel);
+        }
+        if (only == "fused3") {
+            // round 3: tensor 0 and the grid shape as preloaded scalar arguments against the round-2 form (everything from the kernarg structs)
+            for (int pass = 0; pass < 5; ++pass) {
+                run_fused<18, 9, 9, 1024, ST_WT, 4, true, true>(b, f, numel, num_cu, keys);
+                run_fused<18, 9, 9, 1024, ST_WT, 4, true, false>(b, f, numel, num_cu, keys);
+                run_fused<18, 9, 9, 1024, ST_NT, 4, true, true>(b, f, numel, num_cu, keys);
+            }
+            return 0;
         }
         run_fused<18, 9, 9, 1024>(b, f, numel, num_cu, keys);
         run_fused<18, 9, 9, 1024, ST_WT, 4, false>(b, f, numel, num_cu, keys);
