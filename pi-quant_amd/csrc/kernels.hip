@@ -31,7 +31,8 @@ inline unsigned capped_grid(int64_t want, int blocks_per_cu, int num_cu) {
 
 template <int DT_IN, int BITS, int MODE>
 void quantize_t(const QuantLaunch& q, const QuantParams& p, hipStream_t stream, int num_cu) {
-    constexpr KernelTune t = kQuantTune[DT_IN][bits_index(BITS)];
+    constexpr bool kStochastic = MODE == RM_STOCH_CALL || MODE == RM_STOCH_ELEM;
+    constexpr KernelTune t = kStochastic ? kQuantTuneStochastic[DT_IN][bits_index(BITS)] : kQuantTune[DT_IN][bits_index(BITS)];
     using Tile = QuantTile<DT_IN, BITS, t.u, t.block>;
     uint8_t* out = static_cast<uint8_t*>(q.out);
     constexpr int PACK = 8 / BITS, ESIZE = DT_IN == DT_F32 ? 4 : 2;
@@ -151,12 +152,17 @@ void minmax_t(const void* in, int64_t numel, int32_t* state, const MinmaxEpilogu
             hipLaunchKernelGGL((minmax_scalar_kernel<DT_IN, kMinmaxBlock, false>), dim3(grid), dim3(kMinmaxBlock), 0, stream, in, numel, state, ep);
         return;
     }
+    // element-aligned but not vector-aligned input: the scan starts at the next 16-byte boundary and block 0 folds the few elements before it
+    constexpr int ESIZE = DT_IN == DT_F32 ? 4 : 2;
+    const int head = static_cast<int>(std::min<int64_t>(static_cast<int64_t>((16u - (reinterpret_cast<uintptr_t>(in) & 15u)) & 15u) / ESIZE, numel));
+    in = static_cast<const uint8_t*>(in) + static_cast<int64_t>(head) * ESIZE;
+    numel -= head;
     const int64_t per_block = static_cast<int64_t>(kMinmaxBlock) * kMinmaxU * EPV;
     const unsigned grid = capped_grid((numel + per_block - 1) / per_block, kMinmaxBlocksPerCU, num_cu);
     if (kMinmaxGatherEnd && ep.action != EP_NONE && grid <= static_cast<unsigned>(kMinmaxGatherMax))
-        hipLaunchKernelGGL((minmax_kernel<DT_IN, kMinmaxU, kMinmaxNT, kMinmaxBlock, true>), dim3(grid), dim3(kMinmaxBlock), 0, stream, in, numel, state, ep);
+        hipLaunchKernelGGL((minmax_kernel<DT_IN, kMinmaxU, kMinmaxNT, kMinmaxBlock, true>), dim3(grid), dim3(kMinmaxBlock), 0, stream, in, numel, state, ep, head);
     else
-        hipLaunchKernelGGL((minmax_kernel<DT_IN, kMinmaxU, kMinmaxNT, kMinmaxBlock, false>), dim3(grid), dim3(kMinmaxBlock), 0, stream, in, numel, state, ep);
+        hipLaunchKernelGGL((minmax_kernel<DT_IN, kMinmaxU, kMinmaxNT, kMinmaxBlock, false>), dim3(grid), dim3(kMinmaxBlock), 0, stream, in, numel, state, ep, head);
 }
 
 MinmaxEpilogue to_epilogue(const MinmaxAction& a) {

@@ -294,8 +294,11 @@ __device__ __forceinline__ void minmax_block_end_gather(float lo, float hi, cons
     }
 }
 
+// `head`: leading elements in FRONT of `in` (fewer than a vector; block 0 folds them one by one): the launcher moves `in` up to the next
+// 16-byte boundary, so that a scan of a tensor that is only element-aligned (x[1:]) still runs on aligned vector loads -- which elements
+// share a vector is of no consequence to a min/max.
 template <int DT_IN, int U, bool NT, int BLOCK, bool GATHER = false>
-__global__ void __launch_bounds__(BLOCK) minmax_kernel(const void* __restrict__ in, int64_t numel, int32_t* state, MinmaxEpilogue ep) {
+__global__ void __launch_bounds__(BLOCK) minmax_kernel(const void* __restrict__ in, int64_t numel, int32_t* state, MinmaxEpilogue ep, int head = 0) {
     constexpr int EPV = InVec<DT_IN>::EPV;
     constexpr int WAVES = BLOCK / 64;
     const u32x4* __restrict__ in16 = static_cast<const u32x4*>(in);
@@ -341,6 +344,11 @@ __global__ void __launch_bounds__(BLOCK) minmax_kernel(const void* __restrict__ 
     // ragged scalar tail (numel % EPV elements)
     for (int64_t i = n_vec * EPV + tid; i < numel; i += nthreads) {
         const float x = quieted(InVec<DT_IN>::load_scalar(in, i));
+        lo = __builtin_fminf(lo, x);
+        hi = __builtin_fmaxf(hi, x);
+    }
+    if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < head) {   // the elements in front of the first aligned vector
+        const float x = quieted(InVec<DT_IN>::load_scalar(in, static_cast<int64_t>(threadIdx.x) - head));
         lo = __builtin_fminf(lo, x);
         hi = __builtin_fmaxf(hi, x);
     }

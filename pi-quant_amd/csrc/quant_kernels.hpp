@@ -463,8 +463,24 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
         const int64_t v0 = (tile * T::WAVES + wave) * T::WAVE_VECS;   // first input vector of this wave tile
 
         u32x4 raw[U];
+        if (DT_IN == DT_BF16 && (reinterpret_cast<uintptr_t>(in) & 2u) != 0) {
+            // A bf16 tensor that starts on an odd element (x[1:]): 16-byte loads that are not even dword-aligned are split by the memory
+            // pipeline (measured: 16.9 us instead of 12.6 for bf16 -> uint4 at numel 27 264 000).  Kernel-uniform detour: load the vector
+            // from 2 bytes earlier (dword-aligned; the two bytes belong to the same allocation -- no allocation starts at 2 mod 4) plus
+            // the dword that holds its last element, and shift the five dwords into place (4 x v_alignbit_b32).
+            const uint8_t* base = static_cast<const uint8_t*>(in) - 2;
 #pragma unroll
-        for (int k = 0; k < U; ++k) raw[k] = ld<NT_LD>(in16 + v0 + k * 64 + lane);
+            for (int k = 0; k < U; ++k) {
+                const uint8_t* a = base + (v0 + k * 64 + lane) * 16;
+                const u32x4 t = ld<NT_LD>(reinterpret_cast<const u32x4*>(a));
+                const uint32_t n = ld<NT_LD>(reinterpret_cast<const uint32_t*>(a + 16));
+                raw[k] = u32x4 {__builtin_amdgcn_alignbit(t[1], t[0], 16), __builtin_amdgcn_alignbit(t[2], t[1], 16), __builtin_amdgcn_alignbit(t[3], t[2], 16),
+                                __builtin_amdgcn_alignbit(n, t[3], 16)};
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < U; ++k) raw[k] = ld<NT_LD>(in16 + v0 + k * 64 + lane);
+        }
 
         [[maybe_unused]] ElementKeys keys {};
         if constexpr (MODE == RM_STOCH_ELEM) keys = element_keys_for(p, p.index_base + static_cast<uint64_t>(v0 + lane) * EPV);

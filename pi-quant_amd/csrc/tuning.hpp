@@ -14,6 +14,9 @@ struct KernelTune {
 
 // nt loads + write-through stores: the measured best for every kernel of the path (quant_kernels.hpp, st<>)
 constexpr int kStream = 1 | (2 << 1);
+// ... except where round 3's sweep with real bf16 data says otherwise: bf16 -> uint8 nearest with non-temporal stores 14.28 us against 14.60
+// write-through (its copy ceiling: 14.14); bf16 -> uint4 is a tie (12.47 vs 12.52) and its stochastic form prefers write-through (13.39 vs 13.73)
+constexpr int kStreamNT8 = 1 | (1 << 1);
 
 // quantize, indexed [dt_in: f32,bf16][bits: 8,4,2].
 // Interleaved A/B sweeps on MI355X (profiles/r01_tune_finals_*.csv, numel 27 264 000, one tile per block): small
@@ -23,7 +26,14 @@ constexpr int kStream = 1 | (2 << 1);
 // (profiles/r01_tune_finals_other*.csv).
 constexpr KernelTune kQuantTune[2][3] = {
     {{2, true, kStream, 128, 0}, {2, true, kStream, 64, 0}, {2, true, kStream, 64, 0}},
-    {{2, true, kStream, 64, 0}, {2, true, kStream, 64, 0}, {2, true, kStream, 64, 0}},
+    {{2, true, kStreamNT8, 64, 0}, {2, true, kStream, 64, 0}, {2, true, kStream, 64, 0}},
+};
+// Stochastic rounding does ~40 % more arithmetic per element than nearest, which moves one optimum: bf16 -> uint2 (eight elements per 16
+// bytes in, two bytes out) wants the 256-thread / U=4 tile back, 12.75 vs 13.15 us; every other pair keeps its nearest tile
+// (profiles/r03_tune_bf16_ceiling.csv).
+constexpr KernelTune kQuantTuneStochastic[2][3] = {
+    {{2, true, kStream, 128, 0}, {2, true, kStream, 64, 0}, {2, true, kStream, 64, 0}},
+    {{2, true, kStream, 64, 0}, {2, true, kStream, 64, 0}, {4, true, kStream, 256, 0}},
 };
 // (bf16 -> uint2 had 256-thread / U=4 tiles until round 3: with real bf16 data -- the harness used to feed random bit patterns, NaNs in every
 // tile, which never took the short step -- 64-thread / U=2 tiles are faster for it too, 11.50 vs 11.81 us, profiles/r03_tune_bf16_ceiling.csv)

@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Copies the judged summaries of the round-3 GPU sessions (tools/gpu_session_r03.sh, tools/pmc_all_kernels.sh, the one-off tools) from
+gpurun_out/ (scratch) into profiles/ (tracked), named r03_*.  Run after the sessions:  python tools/collect_profiles_r03.py
+
+  bench.json                      -> r03_bench.json (+ r03_blocking_wait_ab.json: the three wait modes of a blocking call)
+  prof/ (rocprofv3 --stats of bench.py)  -> r03_bench_kernel_stats.csv, r03_bench_kernel_stats_summary.json, r03_bench_under_rocprof.json
+  pmc_all/summary.json            -> r03_pmc_all_kernels.json ; profiles/hbm_traffic.json (what bench.py reports as roofline.traffic)
+  fixed_cost_fit.json             -> r03_fixed_cost_fit.json
+  host_call_cost.json             -> r03_host_call_cost.json
+  rccl_trace/*kernel_stats.csv    -> r03_rccl_single_rank_kernel_stats.csv
+  reference_style.json (+ png)    -> r03_reference_style_benchmarks.json, r03_quant_benchmark.png
+  parity_soak_r02.json            -> r03_parity_soak_latest.json
+  bench_n2_shared.json            -> r03_bench_two_ranks_sharing_one_gpu.json
+  tune_*.csv                      -> r03_tune_*.csv
+"""
+import csv
+import json
+import shutil
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+OUT, PROF = ROOT / "gpurun_out", ROOT / "profiles"
+R = "r02"
+
+
+def copy_json(src, dst):
+    p = OUT / src
+    if p.exists() and p.stat().st_size:
+        json.loads(p.read_text())
+        shutil.copy(p, PROF / dst)
+        return [dst]
+    return []
+
+
+def stats_csv(src_glob, dst):
+    stats = next(iter(sorted(OUT.glob(src_glob))), None)
+    if not stats:
+        return None
+    rows = list(csv.DictReader(stats.open()))
+    with (PROF / dst).open("w", newline="") as f:
+        w = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for r in rows:
+            name = r["Name"] if len(r["Name"]) < 240 else r["Name"][:200] + " ...<truncated>"
+            w.writerow([name, int(r["Calls"]), int(r["TotalDurationNs"]), float(r["AverageNs"]), float(r["Percentage"]), int(r["MinNs"]), int(r["MaxNs"]),
+                        float(r["StdDev"])])
+    return rows
+
+
+def main():
+    PROF.mkdir(exist_ok=True)
+    done = []
+    done += copy_json("bench.json", f"{R}_bench.json")
+    done += copy_json("prof_bench.json", f"{R}_bench_under_rocprof.json")
+    done += copy_json("fixed_cost_fit.json", f"{R}_fixed_cost_fit.json")
+    done += copy_json("host_call_cost.json", f"{R}_host_call_cost.json")
+    done += copy_json("reference_style.json", f"{R}_reference_style_benchmarks.json")
+    done += copy_json("dtype_matrix.json", f"{R}_dtype_matrix.json")
+    done += copy_json("parity_soak_r02.json", f"{R}_parity_soak_latest.json")   # the named runs (15 / 25 / 30 / 40 min) are copied by hand
+    done += copy_json("bench_n2_shared.json", f"{R}_bench_two_ranks_sharing_one_gpu.json")
+    if (OUT / "quant_benchmark.png").exists():
+        shutil.copy(OUT / "quant_benchmark.png", PROF / f"{R}_quant_benchmark.png")
+        done.append(f"{R}_quant_benchmark.png")
+    if (OUT / "bench.json").exists():
+        b = json.loads((OUT / "bench.json").read_text())
+        bl = b.get("extras", {}).get("blocking_calls")
+        if bl:
+            (PROF / f"{R}_blocking_wait_ab.json").write_text(json.dumps({
+                "what": "piquant_quantize fp32->uint8 at numel 27264000 on a blocking context (the reference's semantics: the call returns when its result is complete), "
+                        "300 calls per mode on rotating buffers; kernel alone: see roofline.avg_launch_us",
+                "kernel_avg_launch_us": b["roofline"]["avg_launch_us"], "modes": bl["by_wait_mode"], "default": bl["wait"],
+                "modes_explained": {"sync": "hipStreamSynchronize", "write32": "hipStreamWriteValue32 of a sequence number into a pinned host-coherent word + host spin",
+                                    "kernel": "the same word written by a one-thread kernel launched behind the work + host spin"}}, indent=1) + "\n")
+            done.append(f"{R}_blocking_wait_ab.json")
+    rows = stats_csv("prof/**/*kernel_stats.csv", f"{R}_bench_kernel_stats.csv")
+    if rows:
+        digest = {"command": "rocprofv3 --kernel-trace --stats -f csv -- python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-extras",
+                  "kernels": [{"kernel": r["Name"][:120], "calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 3), "min_us": round(int(r["MinNs"]) / 1e3, 3),
+                               "max_us": round(int(r["MaxNs"]) / 1e3, 3), "percent": float(r["Percentage"])} for r in rows[:8]]}
+        (PROF / f"{R}_bench_kernel_stats_summary.json").write_text(json.dumps(digest, indent=1) + "\n")
+        done += [f"{R}_bench_kernel_stats.csv", f"{R}_bench_kernel_stats_summary.json"]
+    if stats_csv("rccl_trace/**/*kernel_stats.csv", f"{R}_rccl_single_rank_kernel_stats.csv"):
+        done.append(f"{R}_rccl_single_rank_kernel_stats.csv")
+    pmc = OUT / "pmc_all" / "summary.json"
+    if pmc.exists() and pmc.stat().st_size:
+        d = json.loads(pmc.read_text())
+        (PROF / f"{R}_pmc_all_kernels.json").write_text(json.dumps({
+            "command": "bash tools/pmc_all_kernels.sh: rocprofv3 --kernel-trace {--stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_* (two groups)} -- python tools/config_kernels_workload.py "
+                       "(60 stream-ordered launches of every kernel of the BASELINE configs at numel 27264000, rotating buffers); separate passes, kernel-trace only",
+            "units": "per launch: median of the counters over the launches; fetch_MB = FETCH_SIZE KiB x 2 (gfx950: 128-B requests tallied at 64 B, guides/MI355X_MICROARCH.md HBM section), "
+                     "write_MB = WRITE_SIZE KiB; avg/min/max_us from the --stats pass; X/SQ_WAVE_CYCLES = share of the waves' resident cycles",
+            "kernels": d}, indent=1) + "\n")
+        done.append(f"{R}_pmc_all_kernels.json")
+        k = next((v for name, v in d.items() if name.startswith("pq::quantize_kernel<0, 8, 0,")), None)
+        if k and "fetch_MB" in k and "write_MB" in k:
+            (PROF / "hbm_traffic.json").write_text(json.dumps({"quantize_f32_u8": {
+                "bytes_per_launch": round((k["fetch_MB"] + k["write_MB"]) * 1e6), "fetch_bytes": round(k["fetch_MB"] * 1e6), "write_bytes": round(k["write_MB"] * 1e6),
+                "algorithmic_bytes": 136320000,
+                "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, kernel-trace only) over tools/config_kernels_workload.py; median over 60 launches at numel "
+                          "27264000; FETCH_SIZE KiB x2 (gfx950 128-B requests tallied at 64 B, guides/MI355X_MICROARCH.md HBM section), WRITE_SIZE KiB as reported; "
+                          f"raw summaries in profiles/{R}_pmc_all_kernels.json"}}, indent=1) + "\n")
+            done.append("hbm_traffic.json")
+    for src, dst in (("tune_fused.csv", "tune_fused_barrier_ab.csv"), ("tune_mm.csv", "tune_minmax.csv"), ("tune_mm3.csv", "tune_minmax_wide.csv"), ("tune_half.csv", "tune_half_size.csv"),
+                     ("tune_q4.csv", "tune_bf16_u4.csv")):
+        if (OUT / src).exists() and (OUT / src).stat().st_size:
+            shutil.copy(OUT / src, PROF / f"{R}_{dst}")
+            done.append(f"{R}_{dst}")
+    err = OUT / "tune_fused.err"
+    if err.exists():
+        keep = [ln for ln in err.read_text().splitlines() if any(t in ln for t in ("differ", "start skew", "load + minmax", "barrier wait", "quantize + store", "end (", "median by b"))]
+        (PROF / f"{R}_tune_fused_phases.txt").write_text("\n".join(keep) + "\n")
+        done.append(f"{R}_tune_fused_phases.txt")
+    print("\n".join(done))
+
+
+if __name__ == "__main__":
+    main()

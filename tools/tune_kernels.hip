@@ -592,6 +592,11 @@ int main(int argc, char** argv) {
             run_quant3<DT_BF16, 2, RM_STOCH_CALL, 2, true, 5, 64, 7>(b, numel, 2.25);
             run_quant3<DT_BF16, 2, RM_STOCH_CALL, 2, true, 5, 64, 3>(b, numel, 2.25);
             run_quant3<DT_BF16, 2, RM_STOCH_CALL, 2, true, 3, 64, 7>(b, numel, 2.25);
+            run_quant3<DT_BF16, 4, RM_STOCH_CALL, 4, true, 5, 256, 7>(b, numel, 2.5);
+            run_quant3<DT_BF16, 4, RM_STOCH_CALL, 2, true, 5, 128, 7>(b, numel, 2.5);
+            run_quant3<DT_BF16, 8, RM_STOCH_CALL, 4, true, 5, 256, 7>(b, numel, 3.0);
+            run_quant3<DT_BF16, 8, RM_STOCH_CALL, 2, true, 3, 64, 7>(b, numel, 3.0);
+            run_quant3<DT_BF16, 8, RM_STOCH_CALL, 2, true, 5, 128, 7>(b, numel, 3.0);
         }
         g_rounds = 3;
     }
