@@ -110,17 +110,6 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
     const int wave = threadIdx.x >> 6;
     u32x4* out16 = static_cast<u32x4*>(out);
 
-    // ragged tail: by the first block, before its tiles (quant_kernels.hpp explains why not by the last one, after)
-    if (blockIdx.x == 0) {
-        for (int64_t i = n_tiles * T::BLOCK_ELEMS + threadIdx.x; i < numel; i += BLOCK) dequant_store_scalar<BITS, DT_OUT, OP>(in, out, i, p);
-        if (head > 0) {
-            DequantParams ph = p;
-            ph.ref_index0 -= head;
-            const uint8_t* in0 = in - head / (8 / BITS);
-            void* out0 = static_cast<uint8_t*>(out) - static_cast<int64_t>(head) * (DT_OUT == DT_F32 ? 4 : 2);
-            for (int i = threadIdx.x; i < head; i += BLOCK) dequant_store_scalar<BITS, DT_OUT, OP>(in0, out0, i, ph);
-        }
-    }
 
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += tile_stride) {
         const int64_t v0 = (tile * T::WAVES + wave) * T::WAVE_VECS;     // first output vector of this wave tile
@@ -213,6 +202,18 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
         }
     }
 
+    // ragged tail and head, element by element, dealt over the threads of the whole grid after the tiles (quant_kernels.hpp explains)
+    if (n_tiles * T::BLOCK_ELEMS < numel || head > 0) {   // kernel-uniform
+        const int64_t gtid = static_cast<int64_t>(blockIdx.x) * BLOCK + threadIdx.x, gthreads = static_cast<int64_t>(tile_stride) * BLOCK;
+        for (int64_t i = n_tiles * T::BLOCK_ELEMS + gtid; i < numel; i += gthreads) dequant_store_scalar<BITS, DT_OUT, OP>(in, out, i, p);
+        if (head > 0) {
+            DequantParams ph = p;
+            ph.ref_index0 -= head;
+            const uint8_t* in0 = in - head / (8 / BITS);
+            void* out0 = static_cast<uint8_t*>(out) - static_cast<int64_t>(head) * (DT_OUT == DT_F32 ? 4 : 2);
+            for (int64_t i = gtid; i < head; i += gthreads) dequant_store_scalar<BITS, DT_OUT, OP>(in0, out0, i, ph);
+        }
+    }
 }
 
 template <int BITS, int DT_OUT, int OP, int U, bool STAGE, int NT, int BLOCK, bool COPY_ONLY = false>

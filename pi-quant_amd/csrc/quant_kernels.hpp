@@ -13,8 +13,8 @@
 // Without STAGE each lane stores its OB bytes directly (still contiguous across the wave).
 //
 // The kernel is a grid-stride loop over block tiles (WAVES wave tiles); the ragged tail (numel not a
-// multiple of the block tile) is done by the first block with a guarded per-byte path inside the SAME
-// launch, so a call is always exactly one kernel (a second launch would cost ~1.5 us on a ~20 us kernel).
+// multiple of the block tile) is done by a guarded per-byte path inside the SAME launch, dealt over the threads of
+// the whole grid, so a call is always exactly one kernel (a second launch would cost ~1.5 us on a ~20 us kernel).
 #pragma once
 
 #include "device_math.hpp"
@@ -442,23 +442,6 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
     [[maybe_unused]] const BoundedStep bstep = bounded_step_for<DT_IN, BITS>(p.zp32);
     [[maybe_unused]] const float abs_inv = __builtin_fabsf(p.inv_scale);
 
-    // Ragged tail (numel not a multiple of the block tile): the FIRST block does it, before its tiles.  The guarded path takes ~1 us for a
-    // few hundred elements; at the end of the last block -- where it used to be -- that microsecond was the end of the kernel (13 632 000
-    // elements with 1 024-element tiles: 13.2 us against 12.3 for a tile size that divides the tensor); block 0 starts first and has
-    // finished both long before the stream has.
-    if (blockIdx.x == 0) {
-        constexpr int PACK = 8 / BITS;
-        if (n_tiles * T::BLOCK_ELEMS < numel)
-            quantize_bytes_guarded<DT_IN, BITS, MODE>(in, out, numel, n_tiles * T::BLOCK_ELEMS / PACK, (numel + PACK - 1) / PACK, p, threadIdx.x, BLOCK);
-        if (head > 0) {   // the scalar head in front of an output that is not 16-byte aligned (the reference's own shape, kernels_specialized.inl:52-56)
-            QuantParams ph = p;
-            ph.index_base -= static_cast<uint64_t>(head);
-            ph.ref_index0 -= head;
-            quantize_bytes_guarded<DT_IN, BITS, MODE>(static_cast<const uint8_t*>(in) - static_cast<int64_t>(head) * (DT_IN == DT_F32 ? 4 : 2), out - head / PACK,
-                                                      head, 0, head / PACK, ph, threadIdx.x, BLOCK);
-        }
-    }
-
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += tile_stride) {
         const int64_t v0 = (tile * T::WAVES + wave) * T::WAVE_VECS;   // first input vector of this wave tile
 
@@ -579,6 +562,25 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
         }
     }
 
+    // What the tiles do not cover -- the ragged tail (numel not a multiple of the block tile) and the scalar head in front of an output that
+    // is not line-aligned (the reference's own shape, kernels_specialized.inl:52-56) -- goes through the guarded path, one packed byte per
+    // thread, dealt over the threads of the WHOLE grid and done after a block's tile.  Round 2 gave all of it to block 0 before its tile:
+    // up to a tile of elements on 64 threads is a chain of eight to sixteen dependent memory round trips, ~4 us -- invisible behind a 22 us
+    // fp32 -> uint8 launch, a third of a 12.5 us bf16 -> uint4 one (16.7 us at numel 27 262 726, profiles/r03_tune_misaligned.csv).  Dealt
+    // out, every thread that has any work has one byte.
+    constexpr int PACK = 8 / BITS;
+    const bool ragged = n_tiles * T::BLOCK_ELEMS < numel;
+    if (ragged || head > 0) {   // kernel-uniform
+        const int64_t gtid = static_cast<int64_t>(blockIdx.x) * BLOCK + threadIdx.x, gthreads = static_cast<int64_t>(tile_stride) * BLOCK;
+        if (ragged) quantize_bytes_guarded<DT_IN, BITS, MODE>(in, out, numel, n_tiles * T::BLOCK_ELEMS / PACK, (numel + PACK - 1) / PACK, p, gtid, gthreads);
+        if (head > 0) {
+            QuantParams ph = p;
+            ph.index_base -= static_cast<uint64_t>(head);
+            ph.ref_index0 -= head;
+            quantize_bytes_guarded<DT_IN, BITS, MODE>(static_cast<const uint8_t*>(in) - static_cast<int64_t>(head) * (DT_IN == DT_F32 ? 4 : 2), out - head / PACK,
+                                                      head, 0, head / PACK, ph, gtid, gthreads);
+        }
+    }
 }
 
 // Host side of the argument convention above: one place that knows which fields travel as preloaded scalars.

@@ -92,10 +92,6 @@ requantize_kernel(const void* in, void* out, int64_t numel, int64_t n_tiles, Qua
     u32x4* out16 = static_cast<u32x4*>(out);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-    // ragged tail: by the first block, before its tiles (quant_kernels.hpp explains why not by the last one, after)
-    if (n_tiles * TILE_VECS * EPV < numel && blockIdx.x == 0)
-        for (int64_t i = n_tiles * TILE_VECS * EPV + threadIdx.x; i < numel; i += BLOCK) requant_scalar<DT, BITS, MODE, OP>(in, out, i, qp, dp, scale_bf16);
-
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t v0 = tile * TILE_VECS + static_cast<int64_t>(wave) * U * 64;
         u32x4 raw[U], old[OP == OP_ADD ? U : 1];
@@ -113,6 +109,9 @@ requantize_kernel(const void* in, void* out, int64_t numel, int64_t n_tiles, Qua
             st<NT_ST>(out16 + v0 + k * 64 + lane, res);
         }
     }
+    // ragged tail, element by element, dealt over the threads of the whole grid after the tiles (quant_kernels.hpp explains)
+    for (int64_t i = n_tiles * TILE_VECS * EPV + static_cast<int64_t>(blockIdx.x) * BLOCK + threadIdx.x; i < numel; i += static_cast<int64_t>(gridDim.x) * BLOCK)
+        requant_scalar<DT, BITS, MODE, OP>(in, out, i, qp, dp, scale_bf16);
 }
 
 }  // namespace pq

@@ -9,7 +9,7 @@ gpurun_out/ (scratch) into profiles/ (tracked), named r03_*.  Run after the sess
   host_call_cost.json             -> r03_host_call_cost.json
   rccl_trace/*kernel_stats.csv    -> r03_rccl_single_rank_kernel_stats.csv
   reference_style.json (+ png)    -> r03_reference_style_benchmarks.json, r03_quant_benchmark.png
-  parity_soak_r02.json            -> r03_parity_soak_latest.json
+  parity_soak_r03.json            -> r03_parity_soak_latest.json
   bench_n2_shared.json            -> r03_bench_two_ranks_sharing_one_gpu.json
   tune_*.csv                      -> r03_tune_*.csv
 """
@@ -20,12 +20,20 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 OUT, PROF = ROOT / "gpurun_out", ROOT / "profiles"
-R = "r02"
+R = "r03"
+
+
+# gpurun_out/ is scratch and still holds what earlier rounds left there: only what this round's sessions wrote is collected
+CUTOFF = float(__import__("os").environ.get("COLLECT_SINCE_EPOCH", "0")) or (ROOT / "tools" / "gpu_session_r03.sh").stat().st_mtime - 3600.0
+
+
+def fresh(p):
+    return p.exists() and p.stat().st_size > 0 and p.stat().st_mtime >= CUTOFF
 
 
 def copy_json(src, dst):
     p = OUT / src
-    if p.exists() and p.stat().st_size:
+    if fresh(p):
         json.loads(p.read_text())
         shutil.copy(p, PROF / dst)
         return [dst]
@@ -33,7 +41,7 @@ def copy_json(src, dst):
 
 
 def stats_csv(src_glob, dst):
-    stats = next(iter(sorted(OUT.glob(src_glob))), None)
+    stats = next(iter(sorted(p for p in OUT.glob(src_glob) if fresh(p))), None)
     if not stats:
         return None
     rows = list(csv.DictReader(stats.open()))
@@ -56,12 +64,12 @@ def main():
     done += copy_json("host_call_cost.json", f"{R}_host_call_cost.json")
     done += copy_json("reference_style.json", f"{R}_reference_style_benchmarks.json")
     done += copy_json("dtype_matrix.json", f"{R}_dtype_matrix.json")
-    done += copy_json("parity_soak_r02.json", f"{R}_parity_soak_latest.json")   # the named runs (15 / 25 / 30 / 40 min) are copied by hand
+    done += copy_json("parity_soak_r03.json", f"{R}_parity_soak_latest.json")   # the named runs (15 / 25 / 30 / 40 min) are copied by hand
     done += copy_json("bench_n2_shared.json", f"{R}_bench_two_ranks_sharing_one_gpu.json")
-    if (OUT / "quant_benchmark.png").exists():
+    if fresh(OUT / "quant_benchmark.png"):
         shutil.copy(OUT / "quant_benchmark.png", PROF / f"{R}_quant_benchmark.png")
         done.append(f"{R}_quant_benchmark.png")
-    if (OUT / "bench.json").exists():
+    if fresh(OUT / "bench.json"):
         b = json.loads((OUT / "bench.json").read_text())
         bl = b.get("extras", {}).get("blocking_calls")
         if bl:
@@ -82,7 +90,7 @@ def main():
     if stats_csv("rccl_trace/**/*kernel_stats.csv", f"{R}_rccl_single_rank_kernel_stats.csv"):
         done.append(f"{R}_rccl_single_rank_kernel_stats.csv")
     pmc = OUT / "pmc_all" / "summary.json"
-    if pmc.exists() and pmc.stat().st_size:
+    if fresh(pmc):
         d = json.loads(pmc.read_text())
         (PROF / f"{R}_pmc_all_kernels.json").write_text(json.dumps({
             "command": "bash tools/pmc_all_kernels.sh: rocprofv3 --kernel-trace {--stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_* (two groups)} -- python tools/config_kernels_workload.py "
@@ -100,16 +108,11 @@ def main():
                           "27264000; FETCH_SIZE KiB x2 (gfx950 128-B requests tallied at 64 B, guides/MI355X_MICROARCH.md HBM section), WRITE_SIZE KiB as reported; "
                           f"raw summaries in profiles/{R}_pmc_all_kernels.json"}}, indent=1) + "\n")
             done.append("hbm_traffic.json")
-    for src, dst in (("tune_fused.csv", "tune_fused_barrier_ab.csv"), ("tune_mm.csv", "tune_minmax.csv"), ("tune_mm3.csv", "tune_minmax_wide.csv"), ("tune_half.csv", "tune_half_size.csv"),
-                     ("tune_q4.csv", "tune_bf16_u4.csv")):
-        if (OUT / src).exists() and (OUT / src).stat().st_size:
+    for src, dst in (("tune_bf16.csv", "tune_bf16_ceiling.csv"), ("tune_f32var.csv", "tune_f32_ceiling.csv"), ("tune_mis.csv", "tune_misaligned.csv"),
+                     ("tune_fused3.csv", "tune_fused_preloaded_args.csv")):
+        if fresh(OUT / src):
             shutil.copy(OUT / src, PROF / f"{R}_{dst}")
             done.append(f"{R}_{dst}")
-    err = OUT / "tune_fused.err"
-    if err.exists():
-        keep = [ln for ln in err.read_text().splitlines() if any(t in ln for t in ("differ", "start skew", "load + minmax", "barrier wait", "quantize + store", "end (", "median by b"))]
-        (PROF / f"{R}_tune_fused_phases.txt").write_text("\n".join(keep) + "\n")
-        done.append(f"{R}_tune_fused_phases.txt")
     print("\n".join(done))
 
 
