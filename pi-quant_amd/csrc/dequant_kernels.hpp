@@ -86,12 +86,12 @@ struct DequantTile {
 // LDS staging and store policy alone: the ceiling the real kernel is measured against.
 template <int BITS, int DT_OUT, int OP, int U, bool STAGE, int NT, int BLOCK, bool COPY_ONLY = false>
 __global__ void __launch_bounds__(BLOCK)
-dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int64_t n_tiles, float scale, float bias, const ParamRecord* dyn, int32_t zp32,
-                  uint32_t tile_stride, DequantParams p_arg, int head) {
-    // scale / bias / dyn / zp32 repeat fields of p_arg and tile_stride is gridDim.x, as scalar arguments so that they arrive preloaded in SGPRs
-    // (quantize_kernel explains)
+dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int64_t n_tiles, float scale, int head, const ParamRecord* dyn, int32_t zp32,
+                  uint32_t tile_stride, DequantParams p_arg) {
+    // scale / dyn / zp32 repeat fields of p_arg, tile_stride is gridDim.x and head is the launcher's, as scalar arguments so that they arrive
+    // preloaded in SGPRs (quantize_kernel explains); the bias is formed here as the host forms it (kernels_specialized.inl:1204)
     p_arg.scale = scale;
-    p_arg.bias = bias;
+    p_arg.bias = __fmul_rn(-static_cast<float>(zp32), scale);
     p_arg.dyn = dyn;
     p_arg.zp32 = zp32;
     // the arguments describe the BODY of the call; `head` leading elements (a whole number of packed bytes) in front of it were peeled by the
@@ -218,8 +218,8 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
 
 template <int BITS, int DT_OUT, int OP, int U, bool STAGE, int NT, int BLOCK, bool COPY_ONLY = false>
 inline void launch_dequantize_kernel(unsigned grid, hipStream_t stream, const uint8_t* in, void* out, int64_t numel, int64_t n_tiles, const DequantParams& p, int head) {
-    hipLaunchKernelGGL((dequantize_kernel<BITS, DT_OUT, OP, U, STAGE, NT, BLOCK, COPY_ONLY>), dim3(grid), dim3(BLOCK), 0, stream, in, out, numel, n_tiles, p.scale, p.bias,
-                       p.dyn, p.zp32, grid, p, head);
+    hipLaunchKernelGGL((dequantize_kernel<BITS, DT_OUT, OP, U, STAGE, NT, BLOCK, COPY_ONLY>), dim3(grid), dim3(BLOCK), 0, stream, in, out, numel, n_tiles, p.scale, head,
+                       p.dyn, p.zp32, grid, p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

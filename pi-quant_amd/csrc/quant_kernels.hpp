@@ -412,13 +412,16 @@ enum : int { QV_RAW_RANGE_TEST = 1, QV_OR_PRETEST = 2, QV_SAT_PACK = 4 };
 template <int DT_IN, int BITS, int MODE, int U, bool STAGE, int NT, int BLOCK, bool ALLOW_SHORT = true, int VAR = 0>
 __global__ void __launch_bounds__(BLOCK)
 quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t numel, int64_t n_tiles, float inv_scale, int32_t zp32,
-                const ParamRecord* dyn, uint32_t flags, uint32_t tile_stride, QuantParams p_arg, int head) {
+                const ParamRecord* dyn, uint32_t flags, uint32_t tile_stride, QuantParams p_arg) {
     // `in` / `out` / `numel` / the positions in `p_arg` describe the BODY of the call: the launcher has peeled `head` leading elements (a whole
     // number of packed bytes) so that `out` is 16-byte aligned; block 0 quantizes them through the guarded path below, like the ragged tail.
     // The nine scalar arguments in front of p_arg are 14 dwords, and those arrive preloaded in SGPRs (Makefile: -amdgpu-kernarg-preload-count;
     // aggregates are never preloaded): inv_scale / zp32 / dyn repeat fields of p_arg, flags bit 0 says "0 <= zero point <= 2^BITS - 1" (the
-    // host's test of the 64-bit zero point), tile_stride is gridDim.x -- so that a wave's first global loads, the choice between immediate
-    // and device-resident parameters and the short-step decision wait for no s_load of the kernarg segment or of the dispatch packet.
+    // host's test of the 64-bit zero point) and bits 16-31 carry `head`, tile_stride is gridDim.x -- so that a wave's first global loads,
+    // the choice between immediate and device-resident parameters and the short-step decision wait for no s_load of the kernarg segment
+    // or of the dispatch packet.  (`head` travelled as a trailing argument for a day: the compiler hoists its s_load to the kernel's
+    // first instruction and the next lgkmcnt wait -- in front of the first global loads -- waits for it: +0.4 us on every quantize launch.)
+    const int head = static_cast<int>(flags >> 16);
     p_arg.inv_scale = inv_scale;
     p_arg.zp32 = zp32;
     p_arg.dyn = dyn;
@@ -587,9 +590,9 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
 template <int DT_IN, int BITS, int MODE, int U, bool STAGE, int NT, int BLOCK, bool ALLOW_SHORT = true, int VAR = 0>
 inline void launch_quantize_kernel(unsigned grid, unsigned dyn_lds, hipStream_t stream, const void* in, uint8_t* out, int64_t numel, int64_t n_tiles, const QuantParams& p,
                                    int head) {
-    const uint32_t flags = p.zp64 >= 0 && p.zp64 <= (1 << BITS) - 1 ? 1u : 0u;
+    const uint32_t flags = (p.zp64 >= 0 && p.zp64 <= (1 << BITS) - 1 ? 1u : 0u) | (static_cast<uint32_t>(head) << 16);   // head < 128 * 4 elements
     hipLaunchKernelGGL((quantize_kernel<DT_IN, BITS, MODE, U, STAGE, NT, BLOCK, ALLOW_SHORT, VAR>), dim3(grid), dim3(BLOCK), dyn_lds, stream, in, out, numel, n_tiles,
-                       p.inv_scale, p.zp32, p.dyn, flags, grid, p, head);
+                       p.inv_scale, p.zp32, p.dyn, flags, grid, p);
 }
 
 }  // namespace pq
