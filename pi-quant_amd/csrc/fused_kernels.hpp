@@ -232,18 +232,14 @@ fused_params_quantize_kernel(const void* in0, uint8_t* out0, int64_t numel0, Par
         }
     };
     stamp(0);
-    const uint32_t gen = __hip_atomic_load(&st->generation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (block == 0) {   // re-arm the buffer the NEXT launch will use: the previous launch read it, and that launch has completed
-        if constexpr (AG) {
-            if (tid < kFusedMaxBlocks) st->gathered[(gen & 1) ^ 1][tid] = kFusedNotArrived;
-        } else {
-            if (tid < kMinmaxSlots) {
-                int32_t* idle = st->slots[(gen & 1) ^ 1];
-                idle[tid * kMinmaxSlotStride + 0] = float_to_key(3.402823466e+38f);
-                idle[tid * kMinmaxSlotStride + 1] = float_to_key(3.402823466e+38f);
-            }
-        }
-    }
+    // The generation word is needed at the barrier, not before: its load is issued first and nothing looks at it until phase 1 is over.
+    // (Until round 3 block 0's re-arming of the idle slot buffer stood here and used it at once -- which put an `s_waitcnt vmcnt(0)`, one
+    // full device-scope memory round trip, in front of every block's first data load.)
+    // A plain (scalar-cache) load is enough: the word was last written by the PREVIOUS launch, which has completed, the scalar cache is
+    // invalidated at every kernel start, and this launch changes it only after every block has arrived -- hence started, hence read it.
+    // A vector load here, atomic or not, is followed at once by a v_readfirstlane of its result (the value is wave-uniform and the compiler
+    // wants it in an SGPR) and therefore by `s_waitcnt vmcnt(0)`; an s_load's wait lands where the value is first used.
+    const uint32_t gen = *const_cast<const uint32_t*>(&st->generation);
 
     // ---- phase 1: load everything once; rounds [0, R_REG) stay in registers, [R_REG, R_REG + R_LDS) in LDS -------------
     float lo = 3.402823466e+38f, hi = -3.402823466e+38f;
@@ -298,6 +294,17 @@ fused_params_quantize_kernel(const void* in0, uint8_t* out0, int64_t numel0, Par
                 const int64_t v = v_first + k * round_vecs;
                 if constexpr (RED_BITS != 0) add_reduce_terms<DT_IN, RED_BITS>(r[k], v < n_vec ? v : v_last, red);
                 minmax_vec<DT_IN>(r[k], v < n_vec, lo, hi);
+            }
+        }
+    }
+    if (block == 0) {   // re-arm the buffer the NEXT launch will use: the previous launch read it, and that launch has completed
+        if constexpr (AG) {
+            if (tid < kFusedMaxBlocks) st->gathered[(gen & 1) ^ 1][tid] = kFusedNotArrived;
+        } else {
+            if (tid < kMinmaxSlots) {
+                int32_t* idle = st->slots[(gen & 1) ^ 1];
+                idle[tid * kMinmaxSlotStride + 0] = float_to_key(3.402823466e+38f);
+                idle[tid * kMinmaxSlotStride + 1] = float_to_key(3.402823466e+38f);
             }
         }
     }
