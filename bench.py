@@ -418,6 +418,46 @@ def main():
         except Exception:
             pass
 
+    # The same K steps replayed from a hipGraph (every stream-ordered call of the library is capturable): what is left of a step when the host's
+    # per-launch work is taken out of it.  At N = 1 that is little (a launch is 4 us of host time behind a 22.7 us kernel); at N = 8 a shard is a
+    # 5 us kernel and the host, not the GPU, sets the pace of directly issued steps.  Runs on every rank (barriers); extras, never `value`.
+    graphed = None
+    if not args.no_extras:
+        try:
+            with torch.cuda.stream(stream):
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream):
+                    for i in range(args.steps):
+                        step(i)
+                gw = []
+                for _ in range(3 + min(args.windows, 15)):
+                    if use_dist:
+                        dist.barrier()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    g.replay()
+                    eg = torch.cuda.Event()
+                    eg.record(stream)
+                    while not eg.query():
+                        pass
+                    gw.append(time.perf_counter() - t0)
+                    torch.cuda.synchronize()
+                gw = gw[3:]
+            tg = torch.tensor(gw, dtype=torch.float64, device=dev)
+            if use_dist:
+                dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+            gs = sorted(float(v) for v in tg)
+            gmed = gs[len(gs) // 2]
+            graphed = {"GiB/s": round(gib_per_step * args.steps / gmed, 2), "ms_per_step": round(gmed / args.steps * 1e3, 6), "windows": len(gs),
+                       "GiB/s_min": round(gib_per_step * args.steps / gs[-1], 2), "GiB/s_max": round(gib_per_step * args.steps / gs[0], 2),
+                       "note": f"the K = {args.steps} steps of a window captured once into a hipGraph and replayed; same barrier + synchronize bracket, median window, max over ranks"}
+            del g
+            ctx.set_stream(stream.cuda_stream)
+            ctx.set_blocking(False)
+        except Exception as exc:
+            graphed = {"error": repr(exc)}
+
     # BASELINE configs[4]: compute_quant_params over a 2^30-element fp32 tensor sharded across the ranks -- every rank scans
     # its shard in HBM, ONE 8-byte all_reduce(MIN) over RCCL/xGMI, identical double-precision epilogue everywhere.  Runs on
     # every rank (it contains the collective); reported next to the headline, not as `value`.
@@ -498,9 +538,9 @@ def main():
             weak = {"error": repr(exc)}
 
     if rank == 0 and not args.no_extras and world > 1:
-        result["extras"] = {"config5_sharded_compute_quant_params": config5, "weak_scaling_own_tensor_per_gpu": weak}
+        result["extras"] = {"steps_replayed_from_a_hipgraph": graphed, "config5_sharded_compute_quant_params": config5, "weak_scaling_own_tensor_per_gpu": weak}
     if rank == 0 and not args.no_extras and world == 1:     # the single-GPU side measurements stay out of the multi-rank runs
-        extras = {"config5_sharded_compute_quant_params": config5}
+        extras = {"steps_replayed_from_a_hipgraph": graphed, "config5_sharded_compute_quant_params": config5}
 
         def gbs_plain(bytes_per_elem, ev_s, reps):
             return round(bytes_per_elem * n / (ev_s / reps) / 1e9, 1)

@@ -160,9 +160,9 @@ void minmax_t(const void* in, int64_t numel, int32_t* state, const MinmaxEpilogu
     const int64_t per_block = static_cast<int64_t>(kMinmaxBlock) * kMinmaxU * EPV;
     const unsigned grid = capped_grid((numel + per_block - 1) / per_block, kMinmaxBlocksPerCU, num_cu);
     if (kMinmaxGatherEnd && ep.action != EP_NONE && grid <= static_cast<unsigned>(kMinmaxGatherMax))
-        hipLaunchKernelGGL((minmax_kernel<DT_IN, kMinmaxU, kMinmaxNT, kMinmaxBlock, true>), dim3(grid), dim3(kMinmaxBlock), 0, stream, in, numel, state, ep, head);
+        launch_minmax_kernel<DT_IN, kMinmaxU, kMinmaxNT, kMinmaxBlock, true>(grid, stream, in, numel, state, ep, head);
     else
-        hipLaunchKernelGGL((minmax_kernel<DT_IN, kMinmaxU, kMinmaxNT, kMinmaxBlock, false>), dim3(grid), dim3(kMinmaxBlock), 0, stream, in, numel, state, ep, head);
+        launch_minmax_kernel<DT_IN, kMinmaxU, kMinmaxNT, kMinmaxBlock, false>(grid, stream, in, numel, state, ep, head);
 }
 
 MinmaxEpilogue to_epilogue(const MinmaxAction& a) {

@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(64) minmax_epilogue_kernel(int32_t* state, Min
 // re-arms keys and counters for the next scan, and runs the epilogue: a scan is always ONE launch that leaves the state
 // buffer armed, which also makes it replayable inside a hipGraph without any bookkeeping on the host.
 template <int WAVES>
-__device__ __forceinline__ void minmax_block_end(float lo, float hi, const float* s_lo, const float* s_hi, int32_t* state, const MinmaxEpilogue& ep) {
+__device__ __forceinline__ void minmax_block_end(float lo, float hi, const float* s_lo, const float* s_hi, int32_t* state, const MinmaxEpilogue& ep, uint32_t G) {
     const int lane = threadIdx.x & 63;
     if ((threadIdx.x >> 6) != 0) return;
     uint32_t last = 0;
@@ -194,7 +194,7 @@ __device__ __forceinline__ void minmax_block_end(float lo, float hi, const float
             lo = __builtin_fminf(lo, s_lo[w]);
             hi = __builtin_fmaxf(hi, s_hi[w]);
         }
-        const uint32_t G = gridDim.x, slot = blockIdx.x % kMinmaxSlots;
+        const uint32_t slot = blockIdx.x % kMinmaxSlots;
         int32_t* my = state + slot * kMinmaxSlotStride;
         const uint32_t one = fold_keys(my, lo, hi);
         if (ep.action != EP_NONE) {
@@ -224,10 +224,10 @@ __device__ __forceinline__ void minmax_block_end(float lo, float hi, const float
 // [tools/tune_kernels.hip mm] at numel 27 264 000.  Nobody waits for the sweeping block and it waits for nobody that needs its
 // CU, so residency does not matter: blocks that start late are simply seen late.
 template <int WAVES>
-__device__ __forceinline__ void minmax_block_end_gather(float lo, float hi, const float* s_lo, const float* s_hi, int32_t* state, const MinmaxEpilogue& ep) {
+__device__ __forceinline__ void minmax_block_end_gather(float lo, float hi, const float* s_lo, const float* s_hi, int32_t* state, const MinmaxEpilogue& ep, uint32_t G) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long* words = reinterpret_cast<unsigned long long*>(state + kMinmaxStateInts);
-    const uint32_t G = gridDim.x, me = blockIdx.x;
+    const uint32_t me = blockIdx.x;
     if (me != G - 1) {
         if (wave != 0) return;
 #pragma unroll
@@ -297,14 +297,20 @@ __device__ __forceinline__ void minmax_block_end_gather(float lo, float hi, cons
 // `head`: leading elements in FRONT of `in` (fewer than a vector; block 0 folds them one by one): the launcher moves `in` up to the next
 // 16-byte boundary, so that a scan of a tensor that is only element-aligned (x[1:]) still runs on aligned vector loads -- which elements
 // share a vector is of no consequence to a min/max.
+// Everything arrives as scalars -- 13 dwords, preloaded in SGPRs with the wave (Makefile, -amdgpu-kernarg-preload-count; an aggregate would
+// end the preloaded prefix): the epilogue's fields, the head and the grid size (gridDim.x read from the dispatch packet is an s_load too).
+// Until round 3 the epilogue struct, the head and gridDim were s_loaded at the kernel's first instructions and WAITED for before the
+// first global load: one scalar-cache round trip in front of a scan whose 2 048 waves all start at the same instant.
 template <int DT_IN, int U, bool NT, int BLOCK, bool GATHER = false>
-__global__ void __launch_bounds__(BLOCK) minmax_kernel(const void* __restrict__ in, int64_t numel, int32_t* state, MinmaxEpilogue ep, int head = 0) {
+__global__ void __launch_bounds__(BLOCK) minmax_kernel(const void* __restrict__ in, int64_t numel, int32_t* state, void* ep_dst, int ep_action, int ep_bits, uint32_t ep_seq,
+                                                        int head, uint32_t grid) {
+    const MinmaxEpilogue ep {ep_action, ep_bits, ep_seq, ep_dst};
     constexpr int EPV = InVec<DT_IN>::EPV;
     constexpr int WAVES = BLOCK / 64;
     const u32x4* __restrict__ in16 = static_cast<const u32x4*>(in);
     const int64_t n_vec = numel / EPV;
     const int64_t tid = static_cast<int64_t>(blockIdx.x) * BLOCK + threadIdx.x;
-    const int64_t nthreads = static_cast<int64_t>(gridDim.x) * BLOCK;
+    const int64_t nthreads = static_cast<int64_t>(grid) * BLOCK;
 
     float lo = 3.402823466e+38f, hi = -3.402823466e+38f;     // identities of the reference (:1422-1423)
 
@@ -362,11 +368,17 @@ __global__ void __launch_bounds__(BLOCK) minmax_kernel(const void* __restrict__ 
         s_hi[wave] = hi;
     }
     __syncthreads();
-    if constexpr (GATHER) minmax_block_end_gather<WAVES>(lo, hi, s_lo, s_hi, state, ep);
-    else minmax_block_end<WAVES>(lo, hi, s_lo, s_hi, state, ep);
+    if constexpr (GATHER) minmax_block_end_gather<WAVES>(lo, hi, s_lo, s_hi, state, ep, grid);
+    else minmax_block_end<WAVES>(lo, hi, s_lo, s_hi, state, ep, grid);
 }
 
-// Same scan for buffers that are not 16-byte aligned.
+// Host side of the argument convention above.
+template <int DT_IN, int U, bool NT, int BLOCK, bool GATHER = false>
+inline void launch_minmax_kernel(unsigned grid, hipStream_t stream, const void* in, int64_t numel, int32_t* state, const MinmaxEpilogue& ep, int head = 0) {
+    hipLaunchKernelGGL((minmax_kernel<DT_IN, U, NT, BLOCK, GATHER>), dim3(grid), dim3(BLOCK), 0, stream, in, numel, state, ep.dst, ep.action, ep.bits, ep.seq, head, grid);
+}
+
+// Same scan for buffers that are not even element-aligned.
 template <int DT_IN, int BLOCK, bool GATHER = false>
 __global__ void __launch_bounds__(BLOCK) minmax_scalar_kernel(const void* __restrict__ in, int64_t numel, int32_t* state, MinmaxEpilogue ep) {
     constexpr int WAVES = BLOCK / 64;
@@ -386,8 +398,8 @@ __global__ void __launch_bounds__(BLOCK) minmax_scalar_kernel(const void* __rest
         s_hi[wave] = hi;
     }
     __syncthreads();
-    if constexpr (GATHER) minmax_block_end_gather<WAVES>(lo, hi, s_lo, s_hi, state, ep);
-    else minmax_block_end<WAVES>(lo, hi, s_lo, s_hi, state, ep);
+    if constexpr (GATHER) minmax_block_end_gather<WAVES>(lo, hi, s_lo, s_hi, state, ep, gridDim.x);
+    else minmax_block_end<WAVES>(lo, hi, s_lo, s_hi, state, ep, gridDim.x);
 }
 
 }  // namespace pq

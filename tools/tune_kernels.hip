@@ -339,7 +339,7 @@ static void run_minmax(const Bufs& b, int64_t numel, int num_cu, int32_t* keys) 
         if (GATHER && grid > static_cast<unsigned>(kMinmaxGatherMax)) continue;
         const double us = time_us([&](int i) {
             // production protocol: the finishing block folds the per-block results into a key pair and re-arms the state inside the launch
-            hipLaunchKernelGGL((minmax_kernel<DT_IN, U, NT, BLOCK, GATHER>), dim3(grid), dim3(BLOCK), 0, g_stream, b.in[i % SETS], numel, keys,
+            launch_minmax_kernel<DT_IN, U, NT, BLOCK, GATHER>(grid, g_stream, b.in[i % SETS], numel, keys,
                                MinmaxEpilogue {EP_KEYS_SET, 0, 0u, keys + kMinmaxScanStateInts});
         });
         char name[160];
@@ -388,7 +388,7 @@ static void run_fused(const Bufs& b, const FusedBufs& f, int64_t numel, int num_
     CK(hipStreamSynchronize(g_stream));
     CK(hipGetLastError());
     {
-        hipLaunchKernelGGL((minmax_kernel<DT_F32, 4, true, 256>), dim3(2 * num_cu), dim3(256), 0, g_stream, static_cast<const void*>(b.in[0]), numel, slots,
+        launch_minmax_kernel<DT_F32, 4, true, 256>(2 * num_cu, g_stream, static_cast<const void*>(b.in[0]), numel, slots,
                            MinmaxEpilogue {EP_PARAMS, 8, 0u, f.rec_ref});
         QuantParams pd {};
         pd.dyn = f.rec_ref;
@@ -1111,7 +1111,7 @@ int main(int argc, char** argv) {
 #define PAIR(SCAN_NT, Q_NT, LABEL)                                                                                                                         \
     {                                                                                                                                                      \
         const double us = time_us([&](int i) {                                                                                                             \
-            hipLaunchKernelGGL((minmax_kernel<DT_F32, 4, SCAN_NT, 512, true>), dim3(num_cu), dim3(512), 0, g_stream, static_cast<const void*>(b.in[i % SETS]),  \
+            launch_minmax_kernel<DT_F32, 4, SCAN_NT, 512, true>(num_cu, g_stream, static_cast<const void*>(b.in[i % SETS]),  \
                                numel, keys, MinmaxEpilogue {EP_PARAMS, 8, 0u, rec});                                                                       \
             launch_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, 2, true, mem_policy(Q_NT, ST_WT), 128>(qgrid, 0, g_stream, static_cast<const void*>(b.in[i % SETS]), static_cast<uint8_t*>(b.out[i % SETS]), numel, n_tiles, pd, 0);                        \
         });                                                                                                                                                \
@@ -1147,7 +1147,7 @@ int main(int argc, char** argv) {
             using T = QuantTile<DT_F32, 8, 2, 128>;
             const int64_t n_tiles = numel / T::BLOCK_ELEMS;
             const double us = time_us([&](int i) {
-                hipLaunchKernelGGL((minmax_kernel<DT_F32, 4, true, 256, kMinmaxGatherEnd>), dim3(2 * num_cu), dim3(256), 0, g_stream, static_cast<const void*>(b.in[i % SETS]), numel,
+                launch_minmax_kernel<DT_F32, 4, true, 256, kMinmaxGatherEnd>(2 * num_cu, g_stream, static_cast<const void*>(b.in[i % SETS]), numel,
                                    keys, MinmaxEpilogue {EP_PARAMS, 8, 0u, f.rec_ref});
                 launch_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, 2, true, mem_policy(true, ST_WT), 128>(static_cast<unsigned>(std::max<int64_t>(n_tiles, 1)), 0, g_stream, static_cast<const void*>(b.in[i % SETS]), static_cast<uint8_t*>(b.out[i % SETS]), numel, n_tiles, pd, 0);
             });
