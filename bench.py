@@ -427,7 +427,9 @@ def main():
             with torch.cuda.stream(stream):
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=stream):
+                # thread_local: with RCCL the process group's watchdog thread polls events while this thread captures; in the default (global)
+                # mode that would invalidate the capture
+                with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
                     for i in range(args.steps):
                         step(i)
                 gw = []
