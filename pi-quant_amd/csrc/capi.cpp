@@ -16,6 +16,10 @@ void scan(piquant_context_t* ctx, const void* x, piquant_dtype_t dtype, size_t n
     if (ctx->scan_stream && ctx->scan_stream != ctx->stream && !stream_is_capturing(ctx->stream) && !stream_is_capturing(ctx->scan_stream) &&
         hipStreamSynchronize(ctx->scan_stream) != hipSuccess)
         (void)hipGetLastError();
+    if (ctx->scan_left_pending && !stream_is_capturing(ctx->stream)) {   // a scan on a stream the context has left since (context.cpp, leave_stream)
+        if (hipStreamWaitEvent(ctx->stream, ctx->scan_left, 0) != hipSuccess) (void)hipGetLastError();
+        ctx->scan_left_pending = false;
+    }
     ctx->scan_stream = ctx->stream;
     order_context_state(ctx);   // captured scans of one context on parallel branches of a graph become successors of each other
     if (n == 0) {

@@ -234,14 +234,20 @@ using namespace pq;
 
 // The context moves from its current stream to `next`.  A caller's stream may be destroyed once it has been replaced (that is the
 // documented rule: reset or replace a stream BEFORE destroying it), so no handle of it may survive here: scans still in flight on it are
-// finished now (scans of one context share one state buffer and must not overlap with the next stream's), and a fused launch still in
-// flight is turned into an event the next fused launch waits for.  The context's own stream is never destroyed before the context.
+// turned into an event the next scan waits for (scans of one context share one state buffer and must not overlap), and a fused launch still
+// in flight into an event the next fused launch waits for.  The context's own stream is never destroyed before the context.
 static void leave_stream(piquant_context_t* ctx, hipStream_t next) {
     hipStream_t old = ctx->stream;
     if (old == next) return;
     DeviceGuard guard(ctx->device);
     if (ctx->scan_stream && ctx->scan_stream != next) {
-        if (!stream_is_capturing(ctx->scan_stream) && hipStreamSynchronize(ctx->scan_stream) != hipSuccess) (void)hipGetLastError();
+        // no host wait here (a caller who scans on one stream and quantizes on another must not be stalled by switching): an event behind the
+        // scan, which the next scan -- the only thing that shares the state buffer -- makes its stream wait for
+        if (!stream_is_capturing(ctx->scan_stream)) {
+            if (!ctx->scan_left && hipEventCreateWithFlags(&ctx->scan_left, hipEventDisableTiming) != hipSuccess) ctx->scan_left = nullptr;
+            if (ctx->scan_left && hipEventRecord(ctx->scan_left, ctx->scan_stream) == hipSuccess) ctx->scan_left_pending = true;
+            else if (hipStreamSynchronize(ctx->scan_stream) != hipSuccess) (void)hipGetLastError();
+        }
         ctx->scan_stream = nullptr;
     }
     if (old != ctx->own_stream) detach_fused_stream(ctx->device, old);
@@ -324,6 +330,7 @@ void piquant_context_destroy(piquant_context_t* ctx) {
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     }
     if (ctx->capture_edge) (void)hipEventDestroy(ctx->capture_edge);
+    if (ctx->scan_left) (void)hipEventDestroy(ctx->scan_left);
     if (ctx->cpu_ctx) pq::cpu_companion().context_destroy(ctx->cpu_ctx);
     delete ctx;
 }

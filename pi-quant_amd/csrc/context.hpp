@@ -76,6 +76,8 @@ struct piquant_context_t {
     uint32_t mailbox_seq = 0;
     int32_t* d_dist_keys = nullptr;        // {key(min), key(-max)} buffer the RCCL all-reduce of the *_dist call runs on
     hipStream_t scan_stream = nullptr;     // stream of the previous scan (scans of one context must not overlap)
+    hipEvent_t scan_left = nullptr;        // recorded behind the last scan of a stream the context has left since (leave_stream) ...
+    bool scan_left_pending = false;        // ... and not yet waited for by a scan on the stream that followed
     hipStream_t capture_stream = nullptr;  // capturing stream that last used the scan / barrier state (order_context_state)
     hipEvent_t capture_edge = nullptr;     // event that turns "used by another capturing stream" into a graph edge
     void* d_fused = nullptr;               // FusedState of the one-launch params + quantize kernel (fused_kernels.hpp)

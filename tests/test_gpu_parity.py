@@ -937,6 +937,34 @@ def test_stream_can_be_destroyed_after_it_has_been_replaced(ctx, O):
         assert (s_, z_) == O.compute_quant_params(x, 0, 4) and torch.equal(out, out2)
 
 
+def test_scans_on_two_streams_of_one_context_do_not_overlap(O):
+    """Scans of one context share one state buffer.  A long scan on stream A followed at once by a scan of other data on stream B: the context
+    records an event behind the first when it leaves A and B waits for it -- no host wait, and both results right (keys of the two tensors never mix)."""
+    import piquant
+    import torch
+
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    big = torch.empty(1 << 28, dtype=torch.float32, device="cuda").uniform_(-1.0, 1.0, generator=g)
+    big[123] = -3.0
+    big[-7] = 2.5
+    small = torch.empty(100_003, dtype=torch.float32, device="cuda").uniform_(10.0, 20.0, generator=g)
+    lo_s, hi_s = float(small.min()), float(small.max())
+    c = piquant.Context()
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    ka, kb = torch.empty(2, dtype=torch.int32, device="cuda"), torch.empty(2, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    c.set_blocking(False)
+    for _ in range(5):
+        c.set_stream(a.cuda_stream)
+        c.minmax_keys_ptr(big.data_ptr(), piquant.DataType.F32, big.numel(), ka.data_ptr(), init=True, _device_ptrs=True)
+        c.set_stream(b.cuda_stream)
+        c.minmax_keys_ptr(small.data_ptr(), piquant.DataType.F32, small.numel(), kb.data_ptr(), init=True, _device_ptrs=True)
+        torch.cuda.synchronize()
+        assert piquant.decode_minmax_keys(int(ka[0]), int(ka[1])) == (-3.0, 2.5)
+        assert piquant.decode_minmax_keys(int(kb[0]), int(kb[1])) == (lo_s, hi_s)
+
+
 def test_minmax_keys_accumulate_across_calls(ctx, O):
     """init=0 folds further scans into the same keys: the building block of the multi-GPU reduction."""
     import piquant
