@@ -20,11 +20,13 @@ struct DequantForm {
     static constexpr int value = DT_OUT == DT_F32 ? (BITS == 2 ? DQ_I64 : DQ_SUBMUL) : (BITS == 8 ? DQ_SUBMUL : DQ_FMA);
 };
 
+// `shift`: bits in front of element 0 inside in[0] (a body that starts in the middle of a packed byte, dequantize_kernel); 0 everywhere else
 template <int BITS, int DT_OUT, int OP>
-__device__ __forceinline__ void dequant_store_scalar(const uint8_t* in, void* out, int64_t i, const DequantParams& p) {
+__device__ __forceinline__ void dequant_store_scalar(const uint8_t* in, void* out, int64_t i, const DequantParams& p, int shift = 0) {
     constexpr int PACK = 8 / BITS;
     constexpr int FORM = DequantForm<BITS, DT_OUT>::value;
-    const uint32_t q = (in[i / PACK] >> ((i % PACK) * BITS)) & ((1u << BITS) - 1u);
+    const int64_t bit = i * BITS + shift;
+    const uint32_t q = (in[bit >> 3] >> (bit & 7)) & ((1u << BITS) - 1u);
     if (p.ref_layout) {
         // Reference-layout mode: element g of the call sits in the reference's scalar tail when it is past the last whole
         // SIMD block (64 / 128 / 256 elements for uint8 / uint4 / uint2->bf16; groups of 4 for the generic uint2->f32).
@@ -88,6 +90,12 @@ template <int BITS, int DT_OUT, int OP, int U, bool STAGE, int NT, int BLOCK, bo
 __global__ void __launch_bounds__(BLOCK)
 dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int64_t n_tiles, float scale, int head, const ParamRecord* dyn, int32_t zp32,
                   uint32_t tile_stride, DequantParams p_arg) {
+    // `head` carries two numbers: bits 0-15 the elements peeled in front of the body, bits 16-18 `shift` = the bits of in[0] that belong to
+    // those peeled elements when their number is not a whole packed byte (a uint4 tensor decoded into a float slice that starts an odd number
+    // of elements before a cache line: the body then starts in the middle of a byte, and every vector's packed bits are funnel-shifted into
+    // place -- one more LDS byte and one v_alignbit_b32 per vector instead of misaligned stores for the whole call, 31.0 -> ~21 us)
+    const int shift = (head >> 16) & 7;
+    head &= 0xffff;
     // scale / dyn / zp32 repeat fields of p_arg, tile_stride is gridDim.x and head is the launcher's, as scalar arguments so that they arrive
     // preloaded in SGPRs (quantize_kernel explains); the bias is formed here as the host forms it (kernels_specialized.inl:1204)
     p_arg.scale = scale;
@@ -104,7 +112,7 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
     constexpr bool NT_LD = (NT & 1) != 0;   // see mem_policy()
     constexpr int NT_ST = NT >> 1;
 
-    __shared__ __attribute__((aligned(16))) uint8_t lds[STAGE ? T::WAVES * T::WAVE_IN_BYTES : 16];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[STAGE ? T::WAVES * (T::WAVE_IN_BYTES + 16) : 16];   // + the byte behind a wave's slice (shift != 0)
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -134,9 +142,15 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
                     w[k][0] = t[0];
                     w[k][WORDS - 1] = t[1];
                 }
+                if constexpr (BITS < 8) {
+                    if (shift != 0) {   // kernel-uniform
+                        const uint32_t nb = ld<NT_LD>(s + IB);
+                        w[k][0] = IB == 4 ? __builtin_amdgcn_alignbit(nb, w[k][0], shift) : ((w[k][0] | (nb << (8 * (IB & 3)))) >> shift);
+                    }
+                }
             }
         } else {
-            uint8_t* s = lds + wave * T::WAVE_IN_BYTES;
+            uint8_t* s = lds + wave * (T::WAVE_IN_BYTES + 16);
             if constexpr (T::LANE_IN_BYTES >= 16) {
 #pragma unroll
                 for (int j = 0; j < T::LANE_IN_BYTES / 16; ++j)
@@ -147,6 +161,9 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
                 reinterpret_cast<uint32_t*>(s)[lane] = ld<NT_LD>(reinterpret_cast<const uint32_t*>(src) + lane);
             } else {
                 reinterpret_cast<uint16_t*>(s)[lane] = ld<NT_LD>(reinterpret_cast<const uint16_t*>(src) + lane);
+            }
+            if constexpr (BITS < 8) {
+                if (shift != 0 && lane == 0) s[T::WAVE_IN_BYTES] = ld<NT_LD>(src + T::WAVE_IN_BYTES);   // the byte the last vector's bits run into
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -161,6 +178,12 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
                     const u32x2 t = *reinterpret_cast<const u32x2*>(r);
                     w[k][0] = t[0];
                     w[k][WORDS - 1] = t[1];
+                }
+                if constexpr (BITS < 8) {
+                    if (shift != 0) {   // kernel-uniform
+                        const uint32_t nb = r[IB];
+                        w[k][0] = IB == 4 ? __builtin_amdgcn_alignbit(nb, w[k][0], shift) : ((w[k][0] | (nb << (8 * (IB & 3)))) >> shift);
+                    }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -205,11 +228,11 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
     // ragged tail and head, element by element, dealt over the threads of the whole grid after the tiles (quant_kernels.hpp explains)
     if (n_tiles * T::BLOCK_ELEMS < numel || head > 0) {   // kernel-uniform
         const int64_t gtid = static_cast<int64_t>(blockIdx.x) * BLOCK + threadIdx.x, gthreads = static_cast<int64_t>(tile_stride) * BLOCK;
-        for (int64_t i = n_tiles * T::BLOCK_ELEMS + gtid; i < numel; i += gthreads) dequant_store_scalar<BITS, DT_OUT, OP>(in, out, i, p);
+        for (int64_t i = n_tiles * T::BLOCK_ELEMS + gtid; i < numel; i += gthreads) dequant_store_scalar<BITS, DT_OUT, OP>(in, out, i, p, shift);
         if (head > 0) {
             DequantParams ph = p;
             ph.ref_index0 -= head;
-            const uint8_t* in0 = in - head / (8 / BITS);
+            const uint8_t* in0 = in - head / (8 / BITS);   // floor: with shift != 0 the body's first byte also holds the head's last elements
             void* out0 = static_cast<uint8_t*>(out) - static_cast<int64_t>(head) * (DT_OUT == DT_F32 ? 4 : 2);
             for (int64_t i = gtid; i < head; i += gthreads) dequant_store_scalar<BITS, DT_OUT, OP>(in0, out0, i, ph);
         }

@@ -98,13 +98,12 @@ void dequantize_t(const DequantLaunch& d, const DequantParams& p, hipStream_t st
     using Tile = DequantTile<BITS, DT_OUT, t.u, t.block>;
     const uint8_t* in = static_cast<const uint8_t*>(d.in);
     constexpr int PACK = 8 / BITS, ESIZE = DT_OUT == DT_F32 ? 4 : 2;
-    // Misaligned buffers take the vector kernel too (quantize_t above).  The packed input may start at any byte; the 16-byte stores -- and
-    // for ADD the loads of the accumulator -- are aligned by peeling leading elements into block 0's element-wise path when that many
-    // elements are a whole number of packed bytes, and run misaligned otherwise (a uint4 tensor decoded to an fp32 slice that starts one
-    // float past a 16-byte boundary: the body cannot begin inside a packed byte).
+    // Misaligned buffers take the vector kernel too (quantize_t above).  The packed input may start at any byte -- or, when the number of
+    // peeled elements is not a whole packed byte, at any BIT: the kernel then shifts every vector's packed bits into place -- and the
+    // 16-byte stores (for ADD also the loads of the accumulator) start on a cache line.
     const uintptr_t oa = reinterpret_cast<uintptr_t>(d.out);
-    int64_t head = static_cast<int64_t>((kStoreAlign - (oa & (kStoreAlign - 1))) & (kStoreAlign - 1)) / ESIZE;   // to a whole cache line (quantize_t)
-    if (head % PACK != 0) head = 0;
+    const int64_t head = static_cast<int64_t>((kStoreAlign - (oa & (kStoreAlign - 1))) & (kStoreAlign - 1)) / ESIZE;   // to a whole cache line (quantize_t)
+    const int shift = static_cast<int>(head % PACK) * BITS;   // != 0: the body starts inside a packed byte and the kernel funnel-shifts its input (dequant_kernels.hpp)
     // element-wise kernel: an output that is not element-aligned, a tensor that ends inside the head, and reference-layout mode when tails
     // lie inside the tensor (partitions of a T-thread context) or the tiles would not start at element 0
     if (oa % ESIZE != 0 || head >= d.numel || (d.ref_layout && (d.ref_threads > 1 || head != 0))) {
@@ -118,7 +117,7 @@ void dequantize_t(const DequantLaunch& d, const DequantParams& p, hipStream_t st
     const int64_t n_tiles = numel / Tile::BLOCK_ELEMS;
     const unsigned grid = capped_grid(n_tiles, t.blocks_per_cu, num_cu);
     launch_dequantize_kernel<BITS, DT_OUT, OP, t.u, t.stage, t.nt, t.block>(grid, stream, in + head / PACK, static_cast<void*>(static_cast<uint8_t*>(d.out) + head * ESIZE),
-                                                                            numel, n_tiles, body, static_cast<int>(head));
+                                                                            numel, n_tiles, body, static_cast<int>(head) | (shift << 16));
 }
 
 template <int BITS, int DT_OUT>

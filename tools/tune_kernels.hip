@@ -271,13 +271,13 @@ static void run_dequant3(const Bufs& b, int64_t numel, double bytes_per_elem, in
     p.zp32 = QMAX / 2;
     p.zp64 = QMAX / 2;
     p.bias = -static_cast<float>(p.zp32) * p.scale;
-    int64_t head = peel ? ((peel - off_out % peel) % peel) / ESIZE : 0;
-    if (head % PACK != 0) head = 0;
+    const int64_t head = peel ? ((peel - off_out % peel) % peel) / ESIZE : 0;
+    const int shift = static_cast<int>(head % PACK) * BITS;   // the body starts inside a packed byte: the kernel funnel-shifts (dequant_kernels.hpp)
     const int64_t body = numel - head, n_tiles = body / T::BLOCK_ELEMS;
     const unsigned grid = static_cast<unsigned>(std::max<int64_t>(n_tiles, 1));
     const double us = time_us([&](int i) {   // roles swapped: the small buffer (b.out) is the packed input, the big one (b.in) the float output
         launch_dequantize_kernel<BITS, DT_OUT, OP, U, STAGE, NT, BLOCK, COPY_ONLY>(grid, g_stream, static_cast<const uint8_t*>(b.out[i % SETS]) + off_in + head / PACK,
-                                                                        static_cast<uint8_t*>(b.in[i % SETS]) + off_out + head * ESIZE, body, n_tiles, p, static_cast<int>(head));
+                                                                        static_cast<uint8_t*>(b.in[i % SETS]) + off_out + head * ESIZE, body, n_tiles, p, static_cast<int>(head) | (shift << 16));
     });
     char name[200];
     std::snprintf(name, sizeof name, "bits=%d out=%s op=%s%s U=%d block=%d nt=%d off_in=%d off_out=%d head=%d", BITS, DT_OUT == DT_F32 ? "f32" : "bf16",
@@ -667,8 +667,12 @@ int main(int argc, char** argv) {
             run_dequant3<8, DT_F32, OP_ADD, 2, true, 5, 128>(b, numel - 1024, 9, 0, 0, 128);
             run_dequant3<8, DT_F32, OP_ADD, 2, true, 5, 128>(b, numel - 1024, 9, 1, 4, 0);
             run_dequant3<8, DT_F32, OP_ADD, 2, true, 5, 128>(b, numel - 1024, 9, 1, 4, 128);
-            run_dequant3<4, DT_F32, OP_SET, 4, true, 5, 256>(b, numel - 1024, 4.5, 1, 4, 128);          // uint4 -> out[1:]: head 31 is not a whole byte -> misaligned stores
-            run_dequant3<4, DT_BF16, OP_SET, 4, true, 6, 256>(b, numel - 1024, 2.5, 1, 4, 128);         // uint4 -> bf16 out[2:]
+            run_dequant3<4, DT_F32, OP_SET, 4, true, 5, 256>(b, numel - 1024, 4.5, 0, 0, 128);
+            run_dequant3<4, DT_F32, OP_SET, 4, true, 5, 256>(b, numel - 1024, 4.5, 1, 4, 0);            // uint4 -> out[1:], misaligned stores (what round 3 did first)
+            run_dequant3<4, DT_F32, OP_SET, 4, true, 5, 256>(b, numel - 1024, 4.5, 1, 4, 128);          // head 31 is not a whole byte: the body is funnel-shifted by 4 bits
+            run_dequant3<2, DT_F32, OP_ADD, 2, true, 3, 128>(b, numel - 1024, 8.25, 1, 4, 128);         // uint2, shift 6
+            run_dequant3<4, DT_BF16, OP_SET, 4, true, 3, 256>(b, numel - 1024, 2.5, 0, 0, 128);
+            run_dequant3<4, DT_BF16, OP_SET, 4, true, 3, 256>(b, numel - 1024, 2.5, 1, 2, 128);         // uint4 -> bf16 out[1:]: head 63, shift 4
         }
         g_mm_caps = {1};
         Bufs shifted = b;
