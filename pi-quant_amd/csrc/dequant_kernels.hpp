@@ -86,7 +86,9 @@ struct DequantTile {
 
 // COPY_ONLY (tune harness): no arithmetic -- every output word is the vector's packed input word -- i.e. this kernel's traffic, tile shape,
 // LDS staging and store policy alone: the ceiling the real kernel is measured against.
-template <int BITS, int DT_OUT, int OP, int U, bool STAGE, int NT, int BLOCK, bool COPY_ONLY = false>
+// SHIFTED: the body starts inside a packed byte (`head` bits 16-18 = the bits in front of it); its own instantiation, so that the ordinary
+// kernels carry none of it (as a run-time branch it cost the 256-thread bf16-output kernels 0.4 us: 11.7 -> 12.1 us for uint4 -> bf16).
+template <int BITS, int DT_OUT, int OP, int U, bool STAGE, int NT, int BLOCK, bool COPY_ONLY = false, bool SHIFTED = false>
 __global__ void __launch_bounds__(BLOCK)
 dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int64_t n_tiles, float scale, int head, const ParamRecord* dyn, int32_t zp32,
                   uint32_t tile_stride, DequantParams p_arg) {
@@ -94,7 +96,7 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
     // those peeled elements when their number is not a whole packed byte (a uint4 tensor decoded into a float slice that starts an odd number
     // of elements before a cache line: the body then starts in the middle of a byte, and every vector's packed bits are funnel-shifted into
     // place -- one more LDS byte and one v_alignbit_b32 per vector instead of misaligned stores for the whole call, 31.0 -> ~21 us)
-    const int shift = (head >> 16) & 7;
+    const int shift = SHIFTED ? (head >> 16) & 7 : 0;
     head &= 0xffff;
     // scale / dyn / zp32 repeat fields of p_arg, tile_stride is gridDim.x and head is the launcher's, as scalar arguments so that they arrive
     // preloaded in SGPRs (quantize_kernel explains); the bias is formed here as the host forms it (kernels_specialized.inl:1204)
@@ -112,7 +114,8 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
     constexpr bool NT_LD = (NT & 1) != 0;   // see mem_policy()
     constexpr int NT_ST = NT >> 1;
 
-    __shared__ __attribute__((aligned(16))) uint8_t lds[STAGE ? T::WAVES * (T::WAVE_IN_BYTES + 16) : 16];   // + the byte behind a wave's slice (shift != 0)
+    constexpr int SLICE = T::WAVE_IN_BYTES + (SHIFTED ? 16 : 0);   // + the byte behind a wave's slice
+    __shared__ __attribute__((aligned(16))) uint8_t lds[STAGE ? T::WAVES * SLICE : 16];
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -142,15 +145,15 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
                     w[k][0] = t[0];
                     w[k][WORDS - 1] = t[1];
                 }
-                if constexpr (BITS < 8) {
-                    if (shift != 0) {   // kernel-uniform
+                if constexpr (SHIFTED) {
+                    {
                         const uint32_t nb = ld<NT_LD>(s + IB);
                         w[k][0] = IB == 4 ? __builtin_amdgcn_alignbit(nb, w[k][0], shift) : ((w[k][0] | (nb << (8 * (IB & 3)))) >> shift);
                     }
                 }
             }
         } else {
-            uint8_t* s = lds + wave * (T::WAVE_IN_BYTES + 16);
+            uint8_t* s = lds + wave * SLICE;
             if constexpr (T::LANE_IN_BYTES >= 16) {
 #pragma unroll
                 for (int j = 0; j < T::LANE_IN_BYTES / 16; ++j)
@@ -162,8 +165,8 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
             } else {
                 reinterpret_cast<uint16_t*>(s)[lane] = ld<NT_LD>(reinterpret_cast<const uint16_t*>(src) + lane);
             }
-            if constexpr (BITS < 8) {
-                if (shift != 0 && lane == 0) s[T::WAVE_IN_BYTES] = ld<NT_LD>(src + T::WAVE_IN_BYTES);   // the byte the last vector's bits run into
+            if constexpr (SHIFTED) {
+                if (lane == 0) s[T::WAVE_IN_BYTES] = ld<NT_LD>(src + T::WAVE_IN_BYTES);   // the byte the last vector's bits run into
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -179,8 +182,8 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
                     w[k][0] = t[0];
                     w[k][WORDS - 1] = t[1];
                 }
-                if constexpr (BITS < 8) {
-                    if (shift != 0) {   // kernel-uniform
+                if constexpr (SHIFTED) {
+                    {
                         const uint32_t nb = r[IB];
                         w[k][0] = IB == 4 ? __builtin_amdgcn_alignbit(nb, w[k][0], shift) : ((w[k][0] | (nb << (8 * (IB & 3)))) >> shift);
                     }
@@ -241,6 +244,13 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
 
 template <int BITS, int DT_OUT, int OP, int U, bool STAGE, int NT, int BLOCK, bool COPY_ONLY = false>
 inline void launch_dequantize_kernel(unsigned grid, hipStream_t stream, const uint8_t* in, void* out, int64_t numel, int64_t n_tiles, const DequantParams& p, int head) {
+    if constexpr (BITS < 8 && !COPY_ONLY) {
+        if ((head >> 16) != 0) {   // the body starts inside a packed byte
+            hipLaunchKernelGGL((dequantize_kernel<BITS, DT_OUT, OP, U, STAGE, NT, BLOCK, false, true>), dim3(grid), dim3(BLOCK), 0, stream, in, out, numel, n_tiles, p.scale,
+                               head, p.dyn, p.zp32, grid, p);
+            return;
+        }
+    }
     hipLaunchKernelGGL((dequantize_kernel<BITS, DT_OUT, OP, U, STAGE, NT, BLOCK, COPY_ONLY>), dim3(grid), dim3(BLOCK), 0, stream, in, out, numel, n_tiles, p.scale, head,
                        p.dyn, p.zp32, grid, p);
 }
