@@ -406,11 +406,8 @@ fused_params_quantize_kernel(const void* in0, uint8_t* out0, int64_t numel0, Par
                     k0 = min(k0, static_cast<int32_t>(static_cast<uint32_t>(seen[j])));
                     k1 = min(k1, static_cast<int32_t>(static_cast<uint32_t>(seen[j] >> 32)));
                 }
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    k0 = min(k0, __shfl_xor(k0, off, 64));
-                    k1 = min(k1, __shfl_xor(k1, off, 64));
-                }
+                k0 = wave_min_i32(k0);
+                k1 = wave_min_i32(k1);
                 float scale;
                 int64_t zp;
                 pub = fused_params_word(k0, k1, BITS, 0u, scale, zp);
@@ -439,11 +436,8 @@ fused_params_quantize_kernel(const void* in0, uint8_t* out0, int64_t numel0, Par
                 static_assert(kMinmaxSlots == 64, "one lane per slot");
                 int32_t k0 = __hip_atomic_load(slots + lane * kMinmaxSlotStride + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 int32_t k1 = __hip_atomic_load(slots + lane * kMinmaxSlotStride + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    k0 = min(k0, __shfl_xor(k0, off, 64));
-                    k1 = min(k1, __shfl_xor(k1, off, 64));
-                }
+                k0 = wave_min_i32(k0);
+                k1 = wave_min_i32(k1);
                 float scale;
                 int64_t zp;
                 pub = fused_params_word(k0, k1, BITS, tag, scale, zp);

@@ -1,8 +1,8 @@
 // Min/max scan for compute_quant_params on gfx950 (reference src/kernels/kernels_specialized.inl:1418-1607).
 //
 // Pure read stream, 4 B/elem (fp32) or 2 B/elem (bf16): grid-stride loop, U coalesced 16-byte loads in
-// flight per lane, v_min_f32/v_max_f32 per element, then a wave64 butterfly (__shfl_xor, lowered to DPP /
-// ds_swizzle), an LDS fold across the block's waves and at most ONE atomicMin per block on each of two int32
+// flight per lane, v_min_f32/v_max_f32 per element, then a wave64 reduction by DPP (wave_min / wave_max below, no LDS round
+// trips), an LDS fold across the block's waves and at most ONE atomicMin per block on each of two int32
 // keys of the block's SLOT.  Keys are order-preserving int32 images of floats; a slot holds {key(min),
 // key(-max)} so that both reduce with MIN -- which is also the only collective a multi-GPU caller needs (one
 // 2 x int32 MIN all-reduce).
@@ -18,18 +18,51 @@
 
 #include "quant_kernels.hpp"
 
+#include <type_traits>
+
 namespace pq {
 
+// wave64 reductions by data-parallel primitives: six v_min/v_max with a DPP source (quad swaps, row shifts by 4 and 8, then the gfx9
+// row broadcasts 15 and 31) leave the result in lane 63, one v_readlane spreads it.  The butterfly of __shfl_xor this replaces compiles to six
+// DEPENDENT ds_bpermute_b32 per chain -- an LDS round trip each, ~0.2 us on the critical path at the end of every scan block.
+// A lane whose DPP source does not exist (row shift at a row's start, lanes outside the row mask) keeps its own value (`old` = v), and
+// min / max of a value with itself changes nothing.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = __builtin_fminf(v, __shfl_xor(v, off, 64));
-    return v;
+    v = __builtin_fminf(v, dpp_f32<0xb1, 0xf>(v));     // quad_perm [1,0,3,2]
+    v = __builtin_fminf(v, dpp_f32<0x4e, 0xf>(v));     // quad_perm [2,3,0,1]
+    v = __builtin_fminf(v, dpp_f32<0x114, 0xf>(v));    // row_shr:4
+    v = __builtin_fminf(v, dpp_f32<0x118, 0xf>(v));    // row_shr:8
+    v = __builtin_fminf(v, dpp_f32<0x142, 0xa>(v));    // row_bcast:15 into rows 1 and 3
+    v = __builtin_fminf(v, dpp_f32<0x143, 0xc>(v));    // row_bcast:31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
+    v = __builtin_fmaxf(v, dpp_f32<0xb1, 0xf>(v));
+    v = __builtin_fmaxf(v, dpp_f32<0x4e, 0xf>(v));
+    v = __builtin_fmaxf(v, dpp_f32<0x114, 0xf>(v));
+    v = __builtin_fmaxf(v, dpp_f32<0x118, 0xf>(v));
+    v = __builtin_fmaxf(v, dpp_f32<0x142, 0xa>(v));
+    v = __builtin_fmaxf(v, dpp_f32<0x143, 0xc>(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// the same for the int32 keys (the folds at the end of a scan and at the fused kernel's barrier)
+__device__ __forceinline__ int32_t wave_min_i32(int32_t v) {
+    auto dpp = [](int32_t x, auto ctrl, auto mask) { return __builtin_amdgcn_update_dpp(x, x, decltype(ctrl)::value, decltype(mask)::value, 0xf, false); };
+    using std::integral_constant;
+    v = min(v, dpp(v, integral_constant<int, 0xb1> {}, integral_constant<int, 0xf> {}));
+    v = min(v, dpp(v, integral_constant<int, 0x4e> {}, integral_constant<int, 0xf> {}));
+    v = min(v, dpp(v, integral_constant<int, 0x114> {}, integral_constant<int, 0xf> {}));
+    v = min(v, dpp(v, integral_constant<int, 0x118> {}, integral_constant<int, 0xf> {}));
+    v = min(v, dpp(v, integral_constant<int, 0x142> {}, integral_constant<int, 0xa> {}));
+    v = min(v, dpp(v, integral_constant<int, 0x143> {}, integral_constant<int, 0xc> {}));
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 constexpr int kMinmaxSlots = 64;          // key pairs per slot buffer
@@ -138,11 +171,8 @@ __device__ __forceinline__ void minmax_finish(int32_t* state, int lane, const Mi
         __hip_atomic_store(state + lane * kMinmaxSlotStride + 0, float_to_key(3.402823466e+38f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(state + lane * kMinmaxSlotStride + 1, float_to_key(3.402823466e+38f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        k0 = min(k0, __shfl_xor(k0, off, 64));
-        k1 = min(k1, __shfl_xor(k1, off, 64));
-    }
+    k0 = wave_min_i32(k0);
+    k1 = wave_min_i32(k1);
     if (lane == 0) minmax_action(k0, k1, ep);
 }
 
@@ -273,11 +303,8 @@ __device__ __forceinline__ void minmax_block_end_gather(float lo, float hi, cons
             }
         }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        k0 = min(k0, __shfl_xor(k0, off, 64));
-        k1 = min(k1, __shfl_xor(k1, off, 64));
-    }
+    k0 = wave_min_i32(k0);
+    k1 = wave_min_i32(k1);
     __shared__ int32_t s_k0[WAVES], s_k1[WAVES];
     if (lane == 0) {
         s_k0[wave] = k0;
