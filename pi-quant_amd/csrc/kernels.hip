@@ -158,12 +158,9 @@ void minmax_t(const void* in, int64_t numel, int32_t* state, const MinmaxEpilogu
     numel -= head;
     const int64_t per_block = static_cast<int64_t>(kMinmaxBlock) * kMinmaxU * EPV;
     const unsigned grid = capped_grid((numel + per_block - 1) / per_block, kMinmaxBlocksPerCU, num_cu);
-    if (kMinmaxGatherEnd && ep.action != EP_NONE && grid <= static_cast<unsigned>(kMinmaxGatherMax)) {
-        // tensors of five rounds or more (numel 10 485 760 fp32 on 256 CUs) end with a pool of chunks handed out by ticket, so that the XCDs finish together
-        const uint32_t static_rounds = kMinmaxBalanced ? minmax_static_rounds<DT_IN, kMinmaxU, kMinmaxBlock>(numel, grid) : 0;
-        if (static_rounds != 0) launch_minmax_kernel<DT_IN, kMinmaxU, kMinmaxNT, kMinmaxBlock, true, true>(grid, stream, in, numel, state, ep, head, static_rounds);
-        else launch_minmax_kernel<DT_IN, kMinmaxU, kMinmaxNT, kMinmaxBlock, true>(grid, stream, in, numel, state, ep, head);
-    } else
+    if (kMinmaxGatherEnd && ep.action != EP_NONE && grid <= static_cast<unsigned>(kMinmaxGatherMax))
+        launch_minmax_kernel<DT_IN, kMinmaxU, kMinmaxNT, kMinmaxBlock, true>(grid, stream, in, numel, state, ep, head);
+    else
         launch_minmax_kernel<DT_IN, kMinmaxU, kMinmaxNT, kMinmaxBlock, false>(grid, stream, in, numel, state, ep, head);
 }
 

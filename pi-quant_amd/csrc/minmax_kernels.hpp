@@ -18,7 +18,6 @@
 
 #include "quant_kernels.hpp"
 
-#include <algorithm>
 #include <type_traits>
 
 namespace pq {
@@ -72,11 +71,7 @@ constexpr int kMinmaxSlotInts = kMinmaxSlots * kMinmaxSlotStride;
 constexpr int kMinmaxStateInts = kMinmaxSlotInts + kMinmaxSlotStride;   // + one line: [0] = slots whose blocks have all arrived
 // "Gather" end of a scan (minmax_block_end_gather): behind the slot area, one 8-byte {key(min), key(-max)} word per BLOCK.
 constexpr int kMinmaxGatherMax = 2048;                                  // grids up to this many blocks take the gather end
-// Behind the gather words: the ticket counters of the balanced scan (minmax_kernel, BALANCED), one 128-byte line each.
-constexpr int kMinmaxTicketCounters = 128;
-constexpr int kMinmaxTicketStride = 32;   // uint32 per counter
-constexpr int kMinmaxTicketInts = kMinmaxStateInts + 2 * kMinmaxGatherMax;
-constexpr int kMinmaxScanStateInts = kMinmaxTicketInts + kMinmaxTicketCounters * kMinmaxTicketStride;
+constexpr int kMinmaxScanStateInts = kMinmaxStateInts + 2 * kMinmaxGatherMax;
 constexpr unsigned long long kMinmaxNotArrived = 0x7fffffff7fffffffull;   // both halves are keys of NaN patterns: never a block's result
 static_assert(kMinmaxStateInts % 2 == 0, "the gather words are 8-byte aligned");
 
@@ -161,7 +156,6 @@ __global__ void __launch_bounds__(64) arm_slots_kernel(int32_t* state, int with_
     if (with_gather) {
         unsigned long long* words = reinterpret_cast<unsigned long long*>(state + kMinmaxStateInts);
         for (int i = threadIdx.x; i < kMinmaxGatherMax; i += 64) words[i] = kMinmaxNotArrived;
-        for (int i = threadIdx.x; i < kMinmaxTicketCounters; i += 64) state[kMinmaxTicketInts + i * kMinmaxTicketStride] = 0;
     }
 }
 
@@ -259,9 +253,7 @@ __device__ __forceinline__ void minmax_block_end(float lo, float hi, const float
 // protocol's three or four dependent ones (two key atomics -> slot arrival -> slot-count arrival -> fold loads): measured
 // [tools/tune_kernels.hip mm] at numel 27 264 000.  Nobody waits for the sweeping block and it waits for nobody that needs its
 // CU, so residency does not matter: blocks that start late are simply seen late.
-// BALANCED: the scan drew tickets (minmax_kernel); every wave has seen its last ticket before its block's word is stored, so once the sweep
-// has seen all words nobody draws any more and the sweeping block zeroes the counters for the next scan.
-template <int WAVES, bool BALANCED = false>
+template <int WAVES>
 __device__ __forceinline__ void minmax_block_end_gather(float lo, float hi, const float* s_lo, const float* s_hi, int32_t* state, const MinmaxEpilogue& ep, uint32_t G) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long* words = reinterpret_cast<unsigned long long*>(state + kMinmaxStateInts);
@@ -319,10 +311,6 @@ __device__ __forceinline__ void minmax_block_end_gather(float lo, float hi, cons
         s_k1[wave] = k1;
     }
     __syncthreads();   // block-uniform: every thread of the sweeping block is here
-    if constexpr (BALANCED) {
-        for (int i = threadIdx.x; i < kMinmaxTicketCounters; i += WAVES * 64)
-            __hip_atomic_store(reinterpret_cast<uint32_t*>(state) + kMinmaxTicketInts + i * kMinmaxTicketStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int w = 1; w < WAVES; ++w) {
@@ -340,22 +328,9 @@ __device__ __forceinline__ void minmax_block_end_gather(float lo, float hi, cons
 // end the preloaded prefix): the epilogue's fields, the head and the grid size (gridDim.x read from the dispatch packet is an s_load too).
 // Until round 3 the epilogue struct, the head and gridDim were s_loaded at the kernel's first instructions and WAITED for before the
 // first global load: one scalar-cache round trip in front of a scan whose 2 048 waves all start at the same instant.
-//
-// BALANCED (round 3; gather end only).  Workgroups go to the eight XCDs by index modulo 8 whatever the XCDs' progress, and the XCDs do not get
-// equal shares of the memory system: measured with per-block time stamps (tools/diag_xcd_skew.hip, profiles/r03_xcd_skew*.txt), the XCDs
-// of an evenly split read-only scan finish 2 us apart at numel 27 264 000 and 13 us apart (65 .. 78 us) at 2^27 elements -- differently
-// in every launch, and rotating the address pieces over the XCDs changes nothing, so it is arbitration, not address mapping -- and the
-// scan ends with its slowest XCD while the others idle.  So only the first `static_rounds` rounds are dealt out evenly; the rest of the
-// tensor is a pool of 4 KB wave chunks (64 lanes x U vectors) handed out by ticket: a wave draws from one of 128 counters, each shared
-// by sixteen waves -- two on every XCD -- and ticket t of counter k names pool chunk k + 128 t.  The waves that come back first draw most:
-// the pool goes to the XCDs in proportion to their speed and all of them run dry together.  A ticket is drawn one chunk ahead (the
-// atomic's round trip hides behind the chunk in between, and the rolling window of U loads per lane never drains); a wave stops at its
-// first ticket beyond the pool, so every drawn chunk is scanned and every counter sees exactly its pool size plus at most sixteen
-// tickets.  The sweeping block of the gather end zeroes the counters (minmax_block_end_gather).
-template <int DT_IN, int U, bool NT, int BLOCK, bool GATHER = false, bool BALANCED = false>
+template <int DT_IN, int U, bool NT, int BLOCK, bool GATHER = false>
 __global__ void __launch_bounds__(BLOCK) minmax_kernel(const void* __restrict__ in, int64_t numel, int32_t* state, void* ep_dst, int ep_action, int ep_bits, uint32_t ep_seq,
-                                                        int head, uint32_t grid, uint32_t static_rounds) {
-    static_assert(!BALANCED || GATHER, "the ticket counters are re-armed by the gather end");
+                                                        int head, uint32_t grid) {
     const MinmaxEpilogue ep {ep_action, ep_bits, ep_seq, ep_dst};
     constexpr int EPV = InVec<DT_IN>::EPV;
     constexpr int WAVES = BLOCK / 64;
@@ -378,47 +353,6 @@ __global__ void __launch_bounds__(BLOCK) minmax_kernel(const void* __restrict__ 
     };
     int64_t v = tid;
     const int64_t round = static_cast<int64_t>(U) * nthreads;
-    if constexpr (BALANCED) {
-        // static_rounds >= 2 full rounds exist (launcher)
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int64_t n_vec_static = static_cast<int64_t>(static_rounds) * round;
-        const uint32_t n_chunks = static_cast<uint32_t>((n_vec - n_vec_static) / (64 * U));
-        const uint32_t k = ((blockIdx.x >> 3) * WAVES + wave) & (kMinmaxTicketCounters - 1);
-        uint32_t* counter = reinterpret_cast<uint32_t*>(state) + kMinmaxTicketInts + k * kMinmaxTicketStride;
-        auto draw = [&]() -> uint32_t {
-            uint32_t t = 0;
-            if (lane == 0) t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return t;
-        };
-        u32x4 raw[U];
-#pragma unroll
-        for (int j = 0; j < U; ++j) raw[j] = ld<NT>(in16 + v + j * nthreads);
-        uint32_t ticket = 0;
-        for (uint32_t r = 1; r < static_rounds; ++r) {
-            if (r == static_rounds - 1) ticket = draw();   // in flight for the whole last static round
-            v += round;
-#pragma unroll
-            for (int j = 0; j < U; ++j) {
-                fold(raw[j]);
-                raw[j] = ld<NT>(in16 + v + j * nthreads);
-            }
-        }
-        uint32_t chunk = k + kMinmaxTicketCounters * static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(ticket));
-        if (chunk < n_chunks) ticket = draw();
-        while (chunk < n_chunks) {
-            const u32x4* c = in16 + n_vec_static + static_cast<int64_t>(chunk) * (64 * U) + lane;
-#pragma unroll
-            for (int j = 0; j < U; ++j) {
-                fold(raw[j]);
-                raw[j] = ld<NT>(c + j * 64);
-            }
-            chunk = k + kMinmaxTicketCounters * static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(ticket));   // drawn before these loads: returns before them
-            if (chunk < n_chunks) ticket = draw();
-        }
-#pragma unroll
-        for (int j = 0; j < U; ++j) fold(raw[j]);
-        v = n_vec_static + static_cast<int64_t>(n_chunks) * (64 * U) + tid;   // fewer than a chunk of vectors are left
-    } else
     // A rolling window of U loads per lane: as soon as a vector has been folded its register is refilled with the vector one round
     // ahead, so every lane keeps U loads in flight from its first instruction to its last round.  (Issuing U loads, waiting for all of
     // them and folding them before the next U -- round 1's loop -- lets a wave's loads in flight drop to zero once per round; with only
@@ -461,28 +395,14 @@ __global__ void __launch_bounds__(BLOCK) minmax_kernel(const void* __restrict__ 
         s_hi[wave] = hi;
     }
     __syncthreads();
-    if constexpr (GATHER) minmax_block_end_gather<WAVES, BALANCED>(lo, hi, s_lo, s_hi, state, ep, grid);
+    if constexpr (GATHER) minmax_block_end_gather<WAVES>(lo, hi, s_lo, s_hi, state, ep, grid);
     else minmax_block_end<WAVES>(lo, hi, s_lo, s_hi, state, ep, grid);
 }
 
-// Rounds of a balanced scan that are dealt out evenly; 0 = the tensor is too small to balance (fewer than kMinmaxBalanceMinRounds rounds).
-constexpr int kMinmaxBalanceMinRounds = 5;
-constexpr int kMinmaxBalancePoolPercent = 20;
-template <int DT_IN, int U, int BLOCK>
-inline uint32_t minmax_static_rounds(int64_t numel, unsigned grid, int pool_percent = kMinmaxBalancePoolPercent) {
-    if (grid % 8 != 0) return 0;   // the counters are shared by groups of eight consecutive blocks, one per XCD
-    const int64_t rounds = numel / InVec<DT_IN>::EPV / (static_cast<int64_t>(U) * grid * BLOCK);
-    if (rounds < kMinmaxBalanceMinRounds) return 0;
-    const int64_t pool = (rounds * pool_percent + 99) / 100;
-    return static_cast<uint32_t>(std::min<int64_t>(std::max<int64_t>(rounds - pool, 2), 0x7fffffff));
-}
-
 // Host side of the argument convention above.
-template <int DT_IN, int U, bool NT, int BLOCK, bool GATHER = false, bool BALANCED = false>
-inline void launch_minmax_kernel(unsigned grid, hipStream_t stream, const void* in, int64_t numel, int32_t* state, const MinmaxEpilogue& ep, int head = 0,
-                                 uint32_t static_rounds = 0) {
-    hipLaunchKernelGGL((minmax_kernel<DT_IN, U, NT, BLOCK, GATHER, BALANCED>), dim3(grid), dim3(BLOCK), 0, stream, in, numel, state, ep.dst, ep.action, ep.bits, ep.seq, head,
-                       grid, static_rounds);
+template <int DT_IN, int U, bool NT, int BLOCK, bool GATHER = false>
+inline void launch_minmax_kernel(unsigned grid, hipStream_t stream, const void* in, int64_t numel, int32_t* state, const MinmaxEpilogue& ep, int head = 0) {
+    hipLaunchKernelGGL((minmax_kernel<DT_IN, U, NT, BLOCK, GATHER>), dim3(grid), dim3(BLOCK), 0, stream, in, numel, state, ep.dst, ep.action, ep.bits, ep.seq, head, grid);
 }
 
 // Same scan for buffers that are not even element-aligned.

@@ -86,7 +86,6 @@ constexpr int kMinmaxU = 4;
 constexpr bool kMinmaxNT = true;
 constexpr int kMinmaxBlock = 512;
 constexpr int kMinmaxBlocksPerCU = 1;
-constexpr bool kMinmaxBalanced = true;    // gather-end scans of five rounds or more hand their last fifth out by ticket (minmax_kernels.hpp, BALANCED)
 constexpr bool kMinmaxGatherEnd = true;   // end of a scan: per-block result words swept by the highest block (true) or slot atomics + arrival counters
 
 // fused params + quantize (fused_kernels.hpp): one 1024-thread block per CU (4 waves per SIMD, 128 VGPRs each); per thread 18

@@ -172,6 +172,7 @@ int main(int argc, char** argv) {
     piquant_hip_reset_stream(ctx);
     piquant_hip_set_blocking(ctx, 1);
     CK(hipMemset(d_q, 0, n));
+    CK(hipDeviceSynchronize());   // the memset runs on the null stream, the context's private stream does not wait for that one
     piquant_quantize(ctx, d_x, PIQUANT_DTYPE_F32, d_q, PIQUANT_DTYPE_UINT8, n, 1.0f / 127.0f, 128, PIQUANT_NEAREST);
     CK(hipMemcpy(q.data(), d_q, n, hipMemcpyDeviceToHost));
     std::printf("%d ", fnv1a(q.data(), n) == h_wait[0] ? 1 : 0);

@@ -26,10 +26,8 @@ for ph in $PHASES; do
                python tools/summarize_tune.py $OUT/tune_dq.csv ;;
     tune_fused3) TUNE_SETS=24 timeout 900 ./tools/tune_kernels 27264000 200 fused3 > $OUT/tune_fused3.csv 2> $OUT/tune_fused3.err; echo "tune_fused3 rc=$?" | tee -a $OUT/session.log
                python tools/summarize_tune.py $OUT/tune_fused3.csv ;;
-    tune_mmbal) TUNE_SETS=24 timeout 900 ./tools/tune_kernels 27264000 200 mmbal > $OUT/tune_mmbal.csv 2> $OUT/tune_mmbal.err; echo "tune_mmbal rc=$?" | tee -a $OUT/session.log
-               TUNE_SETS=8 timeout 900 ./tools/tune_kernels 134217728 60 mmbal > $OUT/tune_mmbal_2p27.csv 2>> $OUT/tune_mmbal.err; echo "tune_mmbal 2^27 rc=$?" | tee -a $OUT/session.log
-               cat $OUT/tune_mmbal.err | head -5
-               python tools/summarize_tune.py $OUT/tune_mmbal.csv; python tools/summarize_tune.py $OUT/tune_mmbal_2p27.csv ;;
+    xcd)      timeout 300 ./tools/diag_xcd_skew > $OUT/xcd_skew.txt 2>&1; timeout 300 ./tools/diag_xcd_skew 134217728 > $OUT/xcd_skew_2p27.txt 2>&1; echo "xcd rc=$?" | tee -a $OUT/session.log
+              grep "launches\|first start ->" $OUT/xcd_skew.txt ;;
     bench)    timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" | tee -a $OUT/session.log; cut -c1-1500 $OUT/bench.json; tail -5 $OUT/bench.err ;;
     benchlong) timeout 900 python bench.py > $OUT/bench_long.json 2> $OUT/bench_long.err; echo "benchlong rc=$?" | tee -a $OUT/session.log; cut -c1-1500 $OUT/bench_long.json ;;
     wall)     timeout 600 python tools/diag_wall_overhead.py > $OUT/diag_wall_overhead.txt 2>&1; echo "wall rc=$?" | tee -a $OUT/session.log; cat $OUT/diag_wall_overhead.txt ;;

@@ -330,8 +330,6 @@ static void run_requant(const Bufs& b, int64_t numel, int num_cu, double bytes_p
 
 static std::vector<int> g_mm_caps = {1, 2, 4, 8, 16, 32};
 
-static int g_mm_pool_percent = 0;   // > 0: the balanced scan (minmax_kernel BALANCED) with this share of the rounds in the ticket pool
-
 template <int DT_IN, int U, bool NT, int BLOCK, bool GATHER = false>
 static void run_minmax(const Bufs& b, int64_t numel, int num_cu, int32_t* keys) {
     for (int cap : g_mm_caps) {
@@ -339,28 +337,6 @@ static void run_minmax(const Bufs& b, int64_t numel, int num_cu, int32_t* keys) 
         const int64_t per_block = static_cast<int64_t>(BLOCK) * U * InVec<DT_IN>::EPV;
         const unsigned grid = cap == 0 ? static_cast<unsigned>((numel + per_block - 1) / per_block) : static_cast<unsigned>(cap * num_cu);
         if (GATHER && grid > static_cast<unsigned>(kMinmaxGatherMax)) continue;
-        if constexpr (GATHER) {
-            if (g_mm_pool_percent > 0) {
-                const uint32_t sr = minmax_static_rounds<DT_IN, U, BLOCK>(numel, grid, g_mm_pool_percent);
-                if (sr == 0) continue;
-                int32_t want[2], got[2];
-                launch_minmax_kernel<DT_IN, U, NT, BLOCK, true>(grid, g_stream, b.in[0], numel, keys, MinmaxEpilogue {EP_KEYS_SET, 0, 0u, keys + kMinmaxScanStateInts});
-                CK(hipMemcpyAsync(want, keys + kMinmaxScanStateInts, 8, hipMemcpyDeviceToHost, g_stream));
-                launch_minmax_kernel<DT_IN, U, NT, BLOCK, true, true>(grid, g_stream, b.in[0], numel, keys, MinmaxEpilogue {EP_KEYS_SET, 0, 0u, keys + kMinmaxScanStateInts}, 0, sr);
-                CK(hipMemcpyAsync(got, keys + kMinmaxScanStateInts, 8, hipMemcpyDeviceToHost, g_stream));
-                CK(hipStreamSynchronize(g_stream));
-                if (want[0] != got[0] || want[1] != got[1]) std::fprintf(stderr, "BALANCED SCAN MISMATCH: keys %d %d vs %d %d\n", got[0], got[1], want[0], want[1]);
-                const double us = time_us([&](int i) {
-                    launch_minmax_kernel<DT_IN, U, NT, BLOCK, true, true>(grid, g_stream, b.in[i % SETS], numel, keys, MinmaxEpilogue {EP_KEYS_SET, 0, 0u, keys + kMinmaxScanStateInts},
-                                                                        0, sr);
-                });
-                char name[160];
-                std::snprintf(name, sizeof name, "in=%s U=%d nt=%d block=%d end=gather cap=%d grid=%u balanced pool=%d%% static_rounds=%u", DT_IN == DT_F32 ? "f32" : "bf16", U,
-                              NT ? 1 : 0, BLOCK, cap, grid, g_mm_pool_percent, sr);
-                report("minmax", name, us, (DT_IN == DT_F32 ? 4.0 : 2.0) * numel);
-                continue;
-            }
-        }
         const double us = time_us([&](int i) {
             // production protocol: the finishing block folds the per-block results into a key pair and re-arms the state inside the launch
             launch_minmax_kernel<DT_IN, U, NT, BLOCK, GATHER>(grid, g_stream, b.in[i % SETS], numel, keys,
@@ -706,25 +682,6 @@ int main(int argc, char** argv) {
             std::printf("minmax_shifted,");
             run_minmax<DT_F32, 4, true, 512, true>(shifted, numel - 1024, num_cu, keys);
         }
-        g_mm_caps = {1, 2, 4, 8, 16, 32};
-        g_rounds = 3;
-    }
-    if (only == "mmbal") {
-        // interleaved A/B: the evenly split scan against the balanced one (ticket pool of 10 / 20 / 30 % of the rounds), one and two blocks per CU
-        g_rounds = 1;
-        g_mm_caps = {1, 2};
-        for (int pass = 0; pass < 6; ++pass) {
-            for (int pct : {0, 10, 20, 30}) {
-                g_mm_pool_percent = pct;
-                run_minmax<DT_F32, 4, true, 512, true>(b, numel, num_cu, keys);
-            }
-            for (int pct : {0, 20}) {
-                g_mm_pool_percent = pct;
-                run_minmax<DT_BF16, 4, true, 512, true>(b, numel, num_cu, keys);
-                run_minmax<DT_F32, 4, true, 256, true>(b, numel, num_cu, keys);
-            }
-        }
-        g_mm_pool_percent = 0;
         g_mm_caps = {1, 2, 4, 8, 16, 32};
         g_rounds = 3;
     }
