@@ -460,6 +460,41 @@ def main():
         except Exception as exc:
             graphed = {"error": repr(exc)}
 
+    # Independent calls issued alternately on two streams (a context each): a stream runs its kernels one after the other, and the ~2 us in which
+    # a launch ramps up and drains move no bytes; on two streams the next tensor's ramp runs under this one's drain.  What a
+    # caller with many tensors and no order between them can have; extras, never `value` (whose steps share ONE stream, as a plain caller's do).
+    two_streams = None
+    if not args.no_extras and world == 1:
+        try:
+            s2 = [torch.cuda.Stream(), torch.cuda.Stream()]
+            c2 = [piquant.Context(), piquant.Context()]
+            for c, s in zip(c2, s2):
+                c.set_stream(s.cuda_stream)
+                c.set_blocking(False)
+                c.assume_device_pointers(True)
+            a2 = [[(c._ctx,) + call_args[k][1:] for k in range(nsets)] for c in c2]
+            tw = []
+            for w in range(13):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(w * args.steps, (w + 1) * args.steps):
+                    c_quantize(*a2[i & 1][i % nsets])
+                ends = [torch.cuda.Event(), torch.cuda.Event()]
+                for e, s in zip(ends, s2):
+                    e.record(s)
+                while not (ends[0].query() and ends[1].query()):
+                    pass
+                tw.append(time.perf_counter() - t0)
+                torch.cuda.synchronize()
+            tw = sorted(tw[3:])
+            tmed = tw[len(tw) // 2]
+            two_streams = {"GiB/s": round(gib_per_step * args.steps / tmed, 2), "ms_per_step": round(tmed / args.steps * 1e3, 6), "windows": len(tw),
+                           "note": f"the same K = {args.steps} calls per window, even ones on one stream and odd ones on another (two contexts); wall clock from the first call "
+                                   "to the completion of both streams, median window"}
+            del c2
+        except Exception as exc:
+            two_streams = {"error": repr(exc)}
+
     # BASELINE configs[4]: compute_quant_params over a 2^30-element fp32 tensor sharded across the ranks -- every rank scans
     # its shard in HBM, ONE 8-byte all_reduce(MIN) over RCCL/xGMI, identical double-precision epilogue everywhere.  Runs on
     # every rank (it contains the collective); reported next to the headline, not as `value`.
@@ -542,7 +577,7 @@ def main():
     if rank == 0 and not args.no_extras and world > 1:
         result["extras"] = {"steps_replayed_from_a_hipgraph": graphed, "config5_sharded_compute_quant_params": config5, "weak_scaling_own_tensor_per_gpu": weak}
     if rank == 0 and not args.no_extras and world == 1:     # the single-GPU side measurements stay out of the multi-rank runs
-        extras = {"steps_replayed_from_a_hipgraph": graphed, "config5_sharded_compute_quant_params": config5}
+        extras = {"steps_replayed_from_a_hipgraph": graphed, "independent_calls_on_two_streams": two_streams, "config5_sharded_compute_quant_params": config5}
 
         def gbs_plain(bytes_per_elem, ev_s, reps):
             return round(bytes_per_elem * n / (ev_s / reps) / 1e9, 1)
