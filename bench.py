@@ -44,6 +44,7 @@ DEFAULT_BLOCKING_WAIT = "kernel"   # the library's default (csrc/context.cpp kDe
 # 6-set rotation (164 MB) stay in the 256 MiB Infinity Cache and absorb the stores (extras.cold_inputs_one_output_buffer: 24 cold inputs into ONE
 # output buffer run at the 6-set rate).  The headline therefore rotates 24 sets, inputs and outputs; the 6-set figure is kept in extras for continuity.
 ROUND1_SETS = 6
+EXTRAS_LIMIT_S = float(os.environ.get("PIQUANT_BENCH_EXTRAS_LIMIT_S", "240"))   # N > 1: the side measurements (graph replay, config 5, weak scaling) get this long before the headline is printed without them
 CPU_SETS = 16                    # the host side keeps 2.2 GB in rotation: four times the 2 x 256 MB of L3 of the GPU box's two sockets (with 6 sets = 818 MB, pinned
                                  # workers that always meet the same partitions got a large part of their reads from their own CCD's L3: 1 300 GiB/s "from DRAM")
 
@@ -421,17 +422,56 @@ def main():
     # The same K steps replayed from a hipGraph (every stream-ordered call of the library is capturable): what is left of a step when the host's
     # per-launch work is taken out of it.  At N = 1 that is little (a launch is 4 us of host time behind a 22.7 us kernel); at N = 8 a shard is a
     # 5 us kernel and the host, not the GPU, sets the pace of directly issued steps.  Runs on every rank (barriers); extras, never `value`.
+    # From here on nothing may cost the headline.  With N > 1 the side measurements below contain collectives, and a collective that one rank
+    # never reaches (an exception on that rank only) hangs the others for RCCL's ten-minute timeout: every rank arms a watchdog that, when the
+    # side measurements overrun, prints the line without them (rank 0) and leaves the process.
+    import threading
+
+    line_lock = threading.Lock()
+    line_printed = [False]
+
+    def emit(res):
+        with line_lock:
+            if rank == 0 and not line_printed[0]:
+                sys.stdout.flush()
+                os.write(real_stdout, (json.dumps(res) + "\n").encode())
+            line_printed[0] = True
+
+    watchdog = None
+    if world > 1 and not args.no_extras:
+        def bail():
+            headline = dict(result)
+            headline["extras"] = {"error": f"the multi-rank side measurements did not finish within {EXTRAS_LIMIT_S} s; headline only"}
+            emit(headline)
+            os._exit(0)
+
+        watchdog = threading.Timer(EXTRAS_LIMIT_S, bail)
+        watchdog.daemon = True
+        watchdog.start()
+
     graphed = None
     if not args.no_extras:
         try:
+            g, captured = None, 1
+            try:
+                with torch.cuda.stream(stream):
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    # thread_local: with RCCL the process group's watchdog thread polls events while this thread captures; in the default (global)
+                    # mode that would invalidate the capture
+                    with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+                        for i in range(args.steps):
+                            step(i)
+            except Exception as exc:
+                captured, capture_error = 0, repr(exc)
+            if use_dist:      # the replay loop below has barriers: every rank runs it or none does
+                flag = torch.tensor([captured], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag[0]) == 0 and captured:
+                    captured, capture_error = 0, "capture failed on another rank"
+            if not captured:
+                raise RuntimeError(capture_error)
             with torch.cuda.stream(stream):
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                # thread_local: with RCCL the process group's watchdog thread polls events while this thread captures; in the default (global)
-                # mode that would invalidate the capture
-                with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
-                    for i in range(args.steps):
-                        step(i)
                 gw = []
                 for _ in range(3 + min(args.windows, 15)):
                     if use_dist:
@@ -719,9 +759,9 @@ def main():
         except Exception as exc:   # the baseline is a reported figure, never a reason to lose the GPU measurement
             result["cpu_baseline"] = {"value": None, "unit": "GiB/s", "cores": 0, "kind": "port", "sample": f"failed: {exc!r}"}
 
-    if rank == 0:
-        sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(result) + "\n").encode())
+    if watchdog is not None:
+        watchdog.cancel()
+    emit(result)
     if use_dist:
         dist.destroy_process_group()
 

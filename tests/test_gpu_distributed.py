@@ -411,3 +411,28 @@ def test_bench_two_ranks_sharing_the_gpu():
     assert c5["result_correct"] and c5["numel_per_gpu"] == (1 << 30) // 2 and "gloo" in c5["note"]
     weak = d["extras"]["weak_scaling_own_tensor_per_gpu"]
     assert weak["scaling"] == "weak" and weak["numel_per_gpu"] == 27_264_000 and weak["GiB/s"] > 0
+
+
+def test_bench_headline_survives_side_measurements_that_overrun():
+    """N > 1: the side measurements behind the headline contain collectives; when they do not finish in time (a rank that never reaches a
+    collective hangs the others for RCCL's timeout) every rank's watchdog ends the run and rank 0 prints the headline without them."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PIQUANT_BENCH_EXTRAS_LIMIT_S="0.0005")   # fires while the first side measurement is being set up
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(root / "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--backend", "gloo",
+                        "--share-gpu"], capture_output=True, text=True, timeout=600, cwd=str(root), env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["value"] > 0 and 0 < d["roofline"]["frac"] < 1
+    assert "did not finish" in d["extras"]["error"]
