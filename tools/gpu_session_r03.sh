@@ -26,6 +26,17 @@ for ph in $PHASES; do
                python tools/summarize_tune.py $OUT/tune_dq.csv ;;
     tune_fused3) TUNE_SETS=24 timeout 900 ./tools/tune_kernels 27264000 200 fused3 > $OUT/tune_fused3.csv 2> $OUT/tune_fused3.err; echo "tune_fused3 rc=$?" | tee -a $OUT/session.log
                python tools/summarize_tune.py $OUT/tune_fused3.csv ;;
+    tune_cap) TUNE_SETS=40 timeout 900 ./tools/tune_kernels 27264000 200 cap > $OUT/tune_cap.csv 2> $OUT/tune_cap.err; echo "tune_cap rc=$?" | tee -a $OUT/session.log
+               python tools/summarize_tune.py $OUT/tune_cap.csv ;;
+    tune_cap2) TUNE_SETS=40 timeout 900 ./tools/tune_kernels 27264000 200 cap2 > $OUT/tune_cap2.csv 2> $OUT/tune_cap2.err; echo "tune_cap2 rc=$?" | tee -a $OUT/session.log
+               python tools/summarize_tune.py $OUT/tune_cap2.csv ;;
+    tune_cap3) : > $OUT/tune_cap3.csv
+               for n in 2097152 4194304 6815744 9000000 13632000 20000000 27264000 67108864 134217728; do
+                 sets=$(( 3000000000 / (n * 5 / 2) )); [ $sets -gt 200 ] && sets=200; [ $sets -lt 8 ] && sets=8
+                 echo "# numel $n sets $sets" >> $OUT/tune_cap3.csv
+                 TUNE_SETS=$sets timeout 300 ./tools/tune_kernels $n 200 cap3 > $OUT/tune_cap3_one.csv 2>> $OUT/tune_cap3.err
+                 echo "numel $n"; python tools/summarize_tune.py $OUT/tune_cap3_one.csv | cut -c1-150; cat $OUT/tune_cap3_one.csv >> $OUT/tune_cap3.csv
+               done; echo "tune_cap3 rc=$?" | tee -a $OUT/session.log ;;
     xcd)      timeout 300 ./tools/diag_xcd_skew > $OUT/xcd_skew.txt 2>&1; timeout 300 ./tools/diag_xcd_skew 134217728 > $OUT/xcd_skew_2p27.txt 2>&1; echo "xcd rc=$?" | tee -a $OUT/session.log
               grep "launches\|first start ->" $OUT/xcd_skew.txt ;;
     bench)    timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" | tee -a $OUT/session.log; cut -c1-1500 $OUT/bench.json; tail -5 $OUT/bench.err ;;

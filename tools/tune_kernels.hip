@@ -236,6 +236,8 @@ __global__ void fill_uniform_bf16(uint16_t* p, int64_t n, uint32_t seed) {
 // Round 3: the production kernel, one tile per block, with parameters that let the short step run (zero point inside the range of the
 // output type), optional byte offsets of both buffers (misaligned pointers: the launcher's head peel is repeated here) and the VAR switches.
 // MODE = RM_COPY is the same kernel with no arithmetic: the ceiling for this traffic, tile shape and store policy.
+static int g_q3_cap = 0, g_num_cu = 256;   // > 0: at most this many blocks per CU, every block strides over the tiles (tile_stride = grid)
+
 template <int DT_IN, int BITS, int MODE, int U, bool STAGE, int NT, int BLOCK, int VAR>
 static void run_quant3(const Bufs& b, int64_t numel, double bytes_per_elem, int off_in = 0, int off_out = 0, int peel = 128) {
     using T = QuantTile<DT_IN, BITS, U, BLOCK>;
@@ -247,7 +249,8 @@ static void run_quant3(const Bufs& b, int64_t numel, double bytes_per_elem, int 
     p.threshold = 0.37f;
     const int64_t head_bytes = peel ? (peel - off_out % peel) % peel : 0, head = head_bytes * PACK;   // peel = alignment the store stream is brought to (0: none)
     const int64_t body = numel - head, n_tiles = body / T::BLOCK_ELEMS;
-    const unsigned grid = static_cast<unsigned>(std::max<int64_t>(n_tiles, 1));
+    unsigned grid = static_cast<unsigned>(std::max<int64_t>(n_tiles, 1));
+    if (g_q3_cap > 0) grid = std::min<unsigned>(grid, static_cast<unsigned>(g_q3_cap * g_num_cu));
     QuantParams pb = p;
     pb.index_base += head;
     const double us = time_us([&](int i) {
@@ -256,9 +259,9 @@ static void run_quant3(const Bufs& b, int64_t numel, double bytes_per_elem, int 
                                                                                  static_cast<int>(head));
     });
     char name[200];
-    std::snprintf(name, sizeof name, "in=%s bits=%d mode=%s U=%d block=%d nt=%d var=%d off_in=%d off_out=%d head=%d", DT_IN == DT_F32 ? "f32" : "bf16", BITS,
+    std::snprintf(name, sizeof name, "in=%s bits=%d mode=%s U=%d block=%d nt=%d var=%d off_in=%d off_out=%d head=%d%s", DT_IN == DT_F32 ? "f32" : "bf16", BITS,
                   MODE == RM_COPY ? "copy" : (MODE == RM_NEAREST_FAST || MODE == RM_NEAREST_I64 ? "nearest" : "stochastic"), U, BLOCK, NT, VAR, off_in, off_out,
-                  static_cast<int>(head));
+                  static_cast<int>(head), g_q3_cap > 0 ? (" cap=" + std::to_string(g_q3_cap)).c_str() : "");
     report("quantize3", name, us, bytes_per_elem * numel);
 }
 
@@ -640,6 +643,78 @@ int main(int argc, char** argv) {
             DQ(2, DT_BF16, OP_ADD, 2, 3, 64, 4.25)
 #undef DQ
         }
+        g_rounds = 3;
+    }
+    if (only == "cap") {
+        // persistent grids for the streaming quantizers: at most `cap` blocks per CU striding over the tiles instead of one block per tile
+        g_rounds = 1;
+        g_num_cu = num_cu;
+        for (int pass = 0; pass < 5; ++pass) {
+            for (int cap : {0, 64, 32, 16, 8}) {
+                g_q3_cap = cap;
+                run_quant3<DT_F32, 8, RM_COPY, 2, true, 5, 128, 0>(b, numel, 5.0);
+                run_quant3<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 128, 7>(b, numel, 5.0);
+            }
+        }
+        for (int s_ = 0; s_ < SETS; ++s_)   // bf16 data of ordinary magnitude (random fp32 bits read as bf16 pairs hold NaNs: every tile would take the long step)
+            hipLaunchKernelGGL(fill_uniform_bf16, dim3(4096), dim3(256), 0, g_stream, static_cast<uint16_t*>(b.in[s_]), numel, 0x9e3779b9u * (s_ + 1));
+        CK(hipStreamSynchronize(g_stream));
+        for (int pass = 0; pass < 5; ++pass) {
+            for (int cap : {0, 64, 32, 16, 8}) {
+                g_q3_cap = cap;
+                run_quant3<DT_BF16, 4, RM_COPY, 2, true, 5, 64, 0>(b, numel, 2.5);
+                run_quant3<DT_BF16, 4, RM_NEAREST_FAST, 2, true, 5, 64, 7>(b, numel, 2.5);
+                run_quant3<DT_BF16, 4, RM_STOCH_CALL, 2, true, 5, 64, 7>(b, numel, 2.5);
+                run_quant3<DT_BF16, 2, RM_STOCH_CALL, 4, true, 5, 256, 7>(b, numel, 2.25);
+                run_quant3<DT_BF16, 8, RM_NEAREST_FAST, 2, true, 3, 64, 7>(b, numel, 3.0);
+            }
+        }
+        g_q3_cap = 0;
+        g_rounds = 3;
+    }
+    if (only == "cap2") {
+        // second look at the one place the persistent grid won: stochastic rounding on bf16 inputs (most arithmetic per byte)
+        g_rounds = 1;
+        g_num_cu = num_cu;
+        for (int s_ = 0; s_ < SETS; ++s_)
+            hipLaunchKernelGGL(fill_uniform_bf16, dim3(4096), dim3(256), 0, g_stream, static_cast<uint16_t*>(b.in[s_]), numel, 0x9e3779b9u * (s_ + 1));
+        CK(hipStreamSynchronize(g_stream));
+        for (int pass = 0; pass < 5; ++pass) {
+            for (int cap : {0, 4, 6, 8, 10, 12, 16}) {
+                g_q3_cap = cap;
+                run_quant3<DT_BF16, 2, RM_STOCH_CALL, 4, true, 5, 256, 7>(b, numel, 2.25);
+                run_quant3<DT_BF16, 4, RM_STOCH_CALL, 4, true, 5, 256, 7>(b, numel, 2.5);
+                run_quant3<DT_BF16, 8, RM_STOCH_CALL, 4, true, 5, 256, 7>(b, numel, 3.0);
+                run_quant3<DT_BF16, 2, RM_NEAREST_FAST, 4, true, 5, 256, 3>(b, numel, 2.25);
+                run_quant3<DT_BF16, 2, RM_STOCH_CALL, 2, true, 5, 256, 7>(b, numel, 2.25);
+            }
+            for (int cap : {0, 40, 48, 64, 80, 96, 128}) {
+                g_q3_cap = cap;
+                run_quant3<DT_BF16, 4, RM_STOCH_CALL, 2, true, 5, 64, 7>(b, numel, 2.5);
+                run_quant3<DT_BF16, 8, RM_STOCH_CALL, 2, true, 5, 64, 7>(b, numel, 3.0);
+                run_quant3<DT_BF16, 2, RM_NEAREST_FAST, 2, true, 5, 64, 3>(b, numel, 2.25);
+            }
+        }
+        g_q3_cap = 0;
+        g_rounds = 3;
+    }
+    if (only == "cap3") {
+        // the persistent grid of bf16 -> uint2 / uint4 stochastic at other sizes (run once per numel)
+        g_rounds = 1;
+        g_num_cu = num_cu;
+        for (int s_ = 0; s_ < SETS; ++s_)
+            hipLaunchKernelGGL(fill_uniform_bf16, dim3(4096), dim3(256), 0, g_stream, static_cast<uint16_t*>(b.in[s_]), numel, 0x9e3779b9u * (s_ + 1));
+        CK(hipStreamSynchronize(g_stream));
+        for (int pass = 0; pass < 5; ++pass) {
+            for (int cap : {0, 6, 8}) {
+                g_q3_cap = cap;
+                run_quant3<DT_BF16, 2, RM_STOCH_CALL, 4, true, 5, 256, 7>(b, numel, 2.25);
+                run_quant3<DT_BF16, 4, RM_STOCH_CALL, 4, true, 5, 256, 7>(b, numel, 2.5);
+            }
+            g_q3_cap = 0;
+            run_quant3<DT_BF16, 4, RM_STOCH_CALL, 2, true, 5, 64, 7>(b, numel, 2.5);
+        }
+        g_q3_cap = 0;
         g_rounds = 3;
     }
     if (only == "mis") {
