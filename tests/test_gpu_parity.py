@@ -1395,12 +1395,19 @@ def test_dequantize_sum_equals_sequential_adds(O):
                         want = prev_in.copy()
                         for i in range(K):
                             want = O.dequantize(qs[i].cpu().numpy(), dt_q, dt_f, n, hp[i][0], hp[i][1], 1 if (op == "add" or i > 0) else 0, out=want)
-                        for off in (0, 1) if n == 1000 else (0,):
+                        for off in (0, 1) if n in (1000, 300_001) else (0,):
                             buf = torch.zeros(n + 8 if dt_f == 0 else n + 16, dtype=fdt, device="cuda")
                             acc = buf[off: off + n]
                             src = torch.from_numpy(prev_in).cuda() if dt_f == 0 else torch.from_numpy(prev_in.view(np.int16)).cuda().view(torch.bfloat16)
                             acc.copy_(src)
-                            pt.dequantize_sum(qs, recs, dtype=fdt, reduce_op=op, out=acc, quant_dtype=tq[dt_q], shape=(n,))
+                            qs_in = qs
+                            if off:   # packed inputs that start on odd bytes as well: with an element-aligned accumulator the vector path takes all of it
+                                qs_in = []
+                                for i, q in enumerate(qs):
+                                    holder = torch.zeros(q.numel() + 16, dtype=torch.uint8, device="cuda")
+                                    holder[1 + 2 * (i % 3): 1 + 2 * (i % 3) + q.numel()].copy_(q)
+                                    qs_in.append(holder[1 + 2 * (i % 3): 1 + 2 * (i % 3) + q.numel()])
+                            pt.dequantize_sum(qs_in, recs, dtype=fdt, reduce_op=op, out=acc, quant_dtype=tq[dt_q], shape=(n,))
                             got = acc.cpu().numpy() if dt_f == 0 else acc.view(torch.int16).cpu().numpy().view(np.uint16)
                             assert same_floats(got, want), (n, dt_q, f_name, K, op, off)
                             assert bool((buf[:off] == 0).all()) and bool((buf[off + n:] == 0).all())
@@ -1464,6 +1471,29 @@ def test_batched_dynamic_quantize_and_dequantize_equal_single_calls(O):
         assert pt.params_to_host(recs[i]) == (scale, zp)
         assert np.array_equal(pt.packed_bytes(qs[i]).cpu().numpy(), O.quantize(xs[i], 0, 4, scale, zp))
     assert pt.params_to_host(recs[1]) == (1.0, 127)   # nothing scanned: the degenerate record, never a negative scale (include/piquant_hip.h)
+    # batched dequantize into slices that are only element-aligned, from packed inputs on odd bytes: still the vector path, same floats
+    for dt_q in (4, 3, 2):
+        for dt_f, fdt in ((0, torch.float32), (1, torch.bfloat16)):
+            xs = [rng.uniform(-2, 1, n).astype(np.float32) for n in (300_001, 4099, 70_000)]
+            xd = [torch.from_numpy(x).cuda() for x in xs]
+            qs, recs = pt.quantize_dynamic_batch(xd, dtype=tq[dt_q], ctx=ctx)
+            qb = [pt.packed_bytes(q) for q in qs]
+            odd = []
+            for i, q in enumerate(qb):
+                holder = torch.zeros(q.numel() + 8, dtype=torch.uint8, device="cuda")
+                holder[1 + i: 1 + i + q.numel()].copy_(q)
+                odd.append(holder[1 + i: 1 + i + q.numel()])
+            bufs = [torch.full((x.size + 8,), 1.0, dtype=fdt, device="cuda") for x in xs]
+            outs = [b[1 + i: 1 + i + x.size] for i, (b, x) in enumerate(zip(bufs, xs))]
+            pt.dequantize_dynamic_batch(odd, recs, dtype=fdt, reduce_op="add", outs=outs, quant_dtype=tq[dt_q], shapes=[(x.size,) for x in xs], ctx=ctx)
+            for i, x in enumerate(xs):
+                scale, zp = pt.params_to_host(recs[i])
+                ones = np.ones(x.size, np.float32) if dt_f == 0 else O.f32_to_bf16(np.ones(x.size, np.float32))
+                want = O.dequantize(qb[i].cpu().numpy(), dt_q, dt_f, x.size, scale, zp, 1, out=ones)
+                got = outs[i].cpu().numpy() if dt_f == 0 else outs[i].view(torch.int16).cpu().numpy().view(np.uint16)
+                assert same_floats(got, want), (dt_q, dt_f, i)
+                edge = bufs[i].float()
+                assert bool((edge[: 1 + i] == 1).all()) and bool((edge[1 + i + x.size:] == 1).all())
 
 
 def test_reduce_quantize_dynamic_equals_sum_then_quantize(O):
