@@ -198,6 +198,7 @@ struct BoundedStep {
     float lo, hi;    // float(-zp), float(QMAX - zp)
     uint32_t zp_word;   // zp replicated into every BITS-wide field of a 32-bit word
     float zp_scaled;    // float(zp) * (255 / QMAX): the zero point in the scaled domain of pack_saturated (quant_kernels.hpp)
+    float zp_norm;      // (float(zp) + 0.3 QMAX / 65535) / QMAX: the zero point in the normalised domain of pack_normalised, a third of a 16-bit step up
 };
 
 // trunc(clamp(adj)) as a signed offset from the zero point, in [-zp, QMAX - zp].  v_med3_f32 returns min3 of its operands

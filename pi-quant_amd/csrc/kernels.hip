@@ -60,9 +60,7 @@ void quantize_t(const QuantLaunch& q, const QuantParams& p, hipStream_t stream, 
     const int64_t numel = q.numel - head;
     const int64_t n_tiles = numel / Tile::BLOCK_ELEMS;
     const unsigned grid = capped_grid(n_tiles, t.blocks_per_cu, num_cu);
-    // the saturating pack wins wherever it was measured except bf16 -> uint2 nearest, where its 2-bit shuffle costs more than the
-    // Horner steps it replaces (11.74 vs 11.50 us; stochastic rounding, which needs no truncation before it: 12.84 vs 13.10; profiles/r03_tune_bf16_ceiling.csv)
-    constexpr int kVariant = (DT_IN == DT_BF16 && BITS == 2 && (MODE == RM_NEAREST_FAST || MODE == RM_NEAREST_I64)) ? (kQuantVariant & ~QV_SAT_PACK) : kQuantVariant;
+    constexpr int kVariant = BITS == 8 ? kQuantVariant : kQuantVariantSubByte;   // tuning.hpp
     launch_quantize_kernel<DT_IN, BITS, MODE, t.u, t.stage, t.nt, t.block, kQuantShortStep, kVariant>(
         grid, 0, stream, static_cast<const void*>(static_cast<const uint8_t*>(q.in) + head * ESIZE), out + head_bytes, numel, n_tiles, body, static_cast<int>(head));
 }

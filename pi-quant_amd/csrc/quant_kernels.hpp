@@ -210,6 +210,51 @@ __device__ __forceinline__ void pack_saturated(const float (&tz)[EPV], uint32_t 
     }
 }
 
+// Two elements per conversion (round 3).  v_cvt_pknorm_u16_f32 turns two floats into two 16-bit fields, each clamp(x, 0, 1) * 65535 rounded to
+// nearest, NaN -> 0 (tools/probe_cvt_pknorm_u16.hip on the MI355X, profiles/r03_probe_cvt_pknorm_u16.txt).  Fed tn = (t + zp) / QMAX -- one fma,
+// t * (1 / QMAX) + zp_norm -- the field is clamp(t + zp, 0, QMAX) * (65535 / QMAX), and 65535 / QMAX is 257, 4369 = 0x1111 or 21845 = 0x5555: the clamped
+// value in EVERY BITS-wide field of the 16.  (zp_norm sits 0.3 of a 16-bit step above zp / QMAX: the fma's error is 0.013 of a step, so the product
+// lands at k * 65535 / QMAX + 0.3 +- 0.013 whatever the rounding -- the probe checks every zero point and every t + zp in [-300, 600] for the three
+// widths; beyond that range the fma is far outside [0, 1] with the right sign.)  Which two elements share a conversion is free, and chosen so that
+// the packing is bit-field inserts between whole words:
+//   4 bits, 8 elements   P(e0,e2) P(e4,e6) P(e1,e3) P(e5,e7); v_perm gathers the low bytes of the halves -> {e0,e2,e4,e6} and {e1,e3,e5,e7}, one v_bfi
+//                        takes low nibbles from the first and high nibbles from the second: 4 + 3 instructions (8 + 3 through v_cvt_pk_u8_f32)
+//   2 bits, 8 elements   A = P(e0,e4) B = P(e1,e5) C = P(e2,e6) D = P(e3,e7); bfi(0x3333.., A, B) and bfi(0x3333.., C, D) interleave fields, bfi(0x0f0f.., .., ..)
+//                        nibbles: the low half holds byte {e0,e1,e2,e3}, the high half {e4,e5,e6,e7}; one v_perm: 4 + 4 (8 + 7)
+//   8 bits               P(e0,e1) P(e2,e3) -> one v_perm per four elements: 2 + 1 (4)
+template <int BITS, int EPV>
+__device__ __forceinline__ void pack_normalised(const float (&tn)[EPV], uint32_t (&w)[(EPV * BITS / 8) > 4 ? 2 : 1]) {
+    auto P = [](float a, float b) -> uint32_t {
+        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+        const u16x2 r = __builtin_amdgcn_cvt_pknorm_u16(a, b);
+        return __builtin_bit_cast(uint32_t, r);
+    };
+    constexpr uint32_t LOW_BYTES = 0x06040200u;   // v_perm_b32(hi, lo): {lo.b0, lo.b2, hi.b0, hi.b2}
+    if constexpr (BITS == 8) {
+#pragma unroll
+        for (int j = 0; j < EPV / 4; ++j) w[j] = __builtin_amdgcn_perm(P(tn[4 * j + 2], tn[4 * j + 3]), P(tn[4 * j], tn[4 * j + 1]), LOW_BYTES);
+    } else if constexpr (BITS == 4) {
+        if constexpr (EPV == 8) {
+            const uint32_t even = __builtin_amdgcn_perm(P(tn[4], tn[6]), P(tn[0], tn[2]), LOW_BYTES);
+            const uint32_t odd = __builtin_amdgcn_perm(P(tn[5], tn[7]), P(tn[1], tn[3]), LOW_BYTES);
+            w[0] = bfi32(0x0f0f0f0fu, even, odd);
+        } else {
+            const uint32_t m = bfi32(0x0f0f0f0fu, P(tn[0], tn[2]), P(tn[1], tn[3]));   // low half: e0 | e1 << 4, high half: e2 | e3 << 4 (in both bytes)
+            w[0] = __builtin_amdgcn_perm(0u, m, 0x0c0c0200u);
+        }
+    } else {
+        if constexpr (EPV == 8) {
+            const uint32_t t1 = bfi32(0x33333333u, P(tn[0], tn[4]), P(tn[1], tn[5]));   // fields {e0,e1,e0,e1,..} | {e4,e5,..}
+            const uint32_t t2 = bfi32(0x33333333u, P(tn[2], tn[6]), P(tn[3], tn[7]));   //        {e2,e3,e2,e3,..} | {e6,e7,..}
+            const uint32_t u = bfi32(0x0f0f0f0fu, t1, t2);                              // bytes  {e0,e1,e2,e3}    | {e4,e5,e6,e7}
+            w[0] = __builtin_amdgcn_perm(0u, u, 0x0c0c0200u);
+        } else {
+            const uint32_t t = bfi32(0x33333333u, P(tn[0], tn[2]), P(tn[1], tn[3]));    // {e0,e1,..} | {e2,e3,..}
+            w[0] = bfi32(0x0fu, t, t >> 16) & 0xffu;
+        }
+    }
+}
+
 // The nearest step for a call whose data range is known (device_math.hpp, BoundedStep): per element a packed multiply and add, the
 // copysign and a truncation give the integer-valued float t = q - zp, one packed fma moves it into the scaled domain and pack_saturated
 // clamps, converts and packs.  (SAT = false keeps round 2's form for the tune harness' A/B: v_med3_f32 + v_cvt_i32_f32 per element and
@@ -217,15 +262,16 @@ __device__ __forceinline__ void pack_saturated(const float (&tz)[EPV], uint32_t 
 // GENERIC selects the rounding of the reference's generic nearest step (std::round, quantize.inl:21-26 -- the only form fp32 ->
 // uint2 has) instead of the SIMD bodies' trunc(p + copysign(0.5, p)); under the same range condition its int64 arithmetic
 // gives the same integers as the clamp in the float domain, and a NaN again ends at 0.
-template <int DT_IN, int BITS, bool GENERIC = false, bool SAT = true>
+enum : int { PACK_HORNER = 0, PACK_SATURATED = 1, PACK_NORMALISED = 2 };
+template <int DT_IN, int BITS, bool GENERIC = false, int PACK = PACK_SATURATED>
 __device__ __forceinline__ void quantize_vec_bounded(const u32x4& raw, float inv_scale, const BoundedStep& b,
                                                      uint32_t (&w)[(InVec<DT_IN>::EPV * BITS / 8) > 4 ? 2 : 1]) {
 #pragma clang fp contract(off)
     constexpr int EPV = InVec<DT_IN>::EPV, WORDS = (EPV * BITS / 8) > 4 ? 2 : 1, EPW = EPV / WORDS;
     float v[EPV];
     InVec<DT_IN>::unpack(raw, v);
-    if constexpr (SAT || BITS == 8) {
-        constexpr float K = SatScale<BITS>::K;
+    if constexpr (PACK != PACK_HORNER || BITS == 8) {
+        constexpr float K = SatScale<BITS>::K, R = 1.0f / static_cast<float>((1 << BITS) - 1);
         float tz[EPV];
 #pragma unroll
         for (int e = 0; e < EPV; e += 2) {
@@ -240,12 +286,14 @@ __device__ __forceinline__ void quantize_vec_bounded(const u32x4& raw, float inv
                 tr = f32x2 {__builtin_truncf(adj[0]), __builtin_truncf(adj[1])};
             }
             f32x2 sum;
-            if constexpr (BITS == 8) sum = tr + b.zp_scaled;
+            if constexpr (PACK == PACK_NORMALISED) sum = __builtin_elementwise_fma(tr, f32x2 {R, R}, f32x2 {b.zp_norm, b.zp_norm});
+            else if constexpr (BITS == 8) sum = tr + b.zp_scaled;
             else sum = __builtin_elementwise_fma(tr, f32x2 {K, K}, f32x2 {b.zp_scaled, b.zp_scaled});   // the one place a fused multiply-add is wanted
             tz[e] = sum[0];
             tz[e + 1] = sum[1];
         }
-        pack_saturated<BITS, EPV>(tz, w);
+        if constexpr (PACK == PACK_NORMALISED) pack_normalised<BITS, EPV>(tz, w);
+        else pack_saturated<BITS, EPV>(tz, w);
         return;
     }
     int32_t t[EPV];
@@ -278,7 +326,7 @@ __device__ __forceinline__ void quantize_vec_bounded(const u32x4& raw, float inv
 // (trunc and the clamp commute on integers; beyond 2^24 the sum with the zero point may round but is far outside [0, QMAX]; a NaN
 // gives adj = 0, tr = NaN and ends at 0, where the reference's INT64_MIN + zp is clamped to).  copysign(1, r) stands
 // for "if r < 0, adj = -adj": the two differ only for r = -0.0, where |r - tr| = 0 is never above a threshold and adj is 0 anyway.
-template <int DT_IN, int BITS, int MODE, bool SAT = true>
+template <int DT_IN, int BITS, int MODE, int PACK = PACK_SATURATED>
 __device__ __forceinline__ void quantize_vec_bounded_stochastic(const u32x4& raw, const QuantParams& p, const ElementKeys& keys, uint64_t e0,
                                                                 const BoundedStep& b, uint32_t (&w)[(InVec<DT_IN>::EPV * BITS / 8) > 4 ? 2 : 1]) {
 #pragma clang fp contract(off)
@@ -304,19 +352,21 @@ __device__ __forceinline__ void quantize_vec_bounded_stochastic(const u32x4& raw
         s[e] = sum[0];
         s[e + 1] = sum[1];
     }
-    if constexpr (SAT || BITS == 8) {
-        constexpr float K = SatScale<BITS>::K;
+    if constexpr (PACK != PACK_HORNER || BITS == 8) {
+        constexpr float K = SatScale<BITS>::K, R = 1.0f / static_cast<float>((1 << BITS) - 1);
         float tz[EPV];
 #pragma unroll
         for (int e = 0; e < EPV; e += 2) {
             const f32x2 pair = {s[e], s[e + 1]};
             f32x2 sum;
-            if constexpr (BITS == 8) sum = pair + b.zp_scaled;
+            if constexpr (PACK == PACK_NORMALISED) sum = __builtin_elementwise_fma(pair, f32x2 {R, R}, f32x2 {b.zp_norm, b.zp_norm});
+            else if constexpr (BITS == 8) sum = pair + b.zp_scaled;
             else sum = __builtin_elementwise_fma(pair, f32x2 {K, K}, f32x2 {b.zp_scaled, b.zp_scaled});
             tz[e] = sum[0];
             tz[e + 1] = sum[1];
         }
-        pack_saturated<BITS, EPV>(tz, w);
+        if constexpr (PACK == PACK_NORMALISED) pack_normalised<BITS, EPV>(tz, w);
+        else pack_saturated<BITS, EPV>(tz, w);
     } else {
 #pragma unroll
         for (int j = 0; j < WORDS; ++j) {
@@ -329,11 +379,11 @@ __device__ __forceinline__ void quantize_vec_bounded_stochastic(const u32x4& raw
 }
 
 // The short step of whatever rounding mode the kernel was built for.
-template <int DT_IN, int BITS, int MODE, bool SAT = true>
+template <int DT_IN, int BITS, int MODE, int PACK = PACK_SATURATED>
 __device__ __forceinline__ void quantize_vec_short(const u32x4& raw, const QuantParams& p, const ElementKeys& keys, uint64_t e0, const BoundedStep& b,
                                                    uint32_t (&w)[(InVec<DT_IN>::EPV * BITS / 8) > 4 ? 2 : 1]) {
-    if constexpr (MODE == RM_NEAREST_FAST || MODE == RM_NEAREST_I64) quantize_vec_bounded<DT_IN, BITS, MODE == RM_NEAREST_I64, SAT>(raw, p.inv_scale, b, w);
-    else quantize_vec_bounded_stochastic<DT_IN, BITS, MODE, SAT>(raw, p, keys, e0, b, w);
+    if constexpr (MODE == RM_NEAREST_FAST || MODE == RM_NEAREST_I64) quantize_vec_bounded<DT_IN, BITS, MODE == RM_NEAREST_I64, PACK>(raw, p.inv_scale, b, w);
+    else quantize_vec_bounded_stochastic<DT_IN, BITS, MODE, PACK>(raw, p, keys, e0, b, w);
 }
 
 // BoundedStep of a zero point that lies inside the quantized range (0 <= zp <= 2^BITS - 1): the clamp bounds as floats and the
@@ -345,7 +395,9 @@ __device__ __forceinline__ BoundedStep bounded_step_for(int32_t zp32) {
     uint32_t zp_word = 0;
 #pragma unroll
     for (int i = 0; i < FIELDS; ++i) zp_word |= static_cast<uint32_t>(zp32) << (i * BITS);
-    return BoundedStep {-static_cast<float>(zp32), static_cast<float>(((1 << BITS) - 1) - zp32), zp_word, static_cast<float>(zp32) * SatScale<BITS>::K};
+    constexpr float QMAX = static_cast<float>((1 << BITS) - 1);
+    return BoundedStep {-static_cast<float>(zp32), static_cast<float>(((1 << BITS) - 1) - zp32), zp_word, static_cast<float>(zp32) * SatScale<BITS>::K,
+                        (static_cast<float>(zp32) + 0.3f * QMAX / 65535.0f) * (1.0f / QMAX)};
 }
 
 // Range test of the short step, one vector at a time: m = max(m, |elements|) and `nan` |= "a NaN is among them".  A tile with a NaN takes
@@ -408,7 +460,8 @@ struct QuantTile {
 //   bit 2  4- and 2-bit outputs clamp, convert and pack through v_cvt_pk_u8_f32 in a scaled domain (pack_saturated)
 // (round 3 also tried marking block 0's head / tail work and the long step unlikely so that the hot path is laid out straight: no
 // difference, 12.69 vs 12.70 us for bf16 -> uint4, profiles/r03_tune_bf16_ceiling.csv `var=3` rows of the first session.)
-enum : int { QV_RAW_RANGE_TEST = 1, QV_OR_PRETEST = 2, QV_SAT_PACK = 4 };
+//   bit 3  ... two elements per conversion through v_cvt_pknorm_u16_f32 in a normalised domain instead (pack_normalised; wins over bit 2)
+enum : int { QV_RAW_RANGE_TEST = 1, QV_OR_PRETEST = 2, QV_SAT_PACK = 4, QV_NORM_PACK = 8 };
 template <int DT_IN, int BITS, int MODE, int U, bool STAGE, int NT, int BLOCK, bool ALLOW_SHORT = true, int VAR = 0>
 __global__ void __launch_bounds__(BLOCK)
 quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t numel, int64_t n_tiles, float inv_scale, int32_t zp32,
@@ -555,7 +608,8 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
             uint32_t w[U][WORDS];
 #pragma unroll
             for (int k = 0; k < U; ++k)
-                quantize_vec_short<DT_IN, BITS, MODE, (VAR & QV_SAT_PACK) != 0>(raw[k], p, keys, static_cast<uint64_t>(v0 + k * 64 + lane) * EPV, bstep, w[k]);
+                quantize_vec_short<DT_IN, BITS, MODE, (VAR & QV_NORM_PACK) != 0 ? PACK_NORMALISED : ((VAR & QV_SAT_PACK) != 0 ? PACK_SATURATED : PACK_HORNER)>(
+                    raw[k], p, keys, static_cast<uint64_t>(v0 + k * 64 + lane) * EPV, bstep, w[k]);
             put(w);
         } else {
             uint32_t w[U][WORDS];

@@ -52,7 +52,11 @@ constexpr bool kQuantShortStep = true;
 //   bf16 -> uint8 nearest 14.16 / 14.81 / 14.63 / 14.61 / 14.62,    stochastic 14.16 / 15.25 / 15.27 / 15.13 / 15.11
 //   bf16 -> uint2 nearest 10.77 / 12.37 / 11.66 / 11.50 / 11.74 (64-thread tiles), stochastic 10.95 / 13.69 / 13.67 / 13.10 / 12.84 (256-thread tiles)
 // fp32 inputs sit on their copy ceiling either way (22.50 copy / 22.74 / 22.75 for fp32 -> uint8; profiles/r03_tune_f32_ceiling.csv).
-constexpr int kQuantVariant = 7;
+// Round 3, later: + two elements per conversion (QV_NORM_PACK, pack_normalised; profiles/r03_tune_normalised_pack.csv, same protocol, saturating pack -> this):
+//   bf16 -> uint4 nearest 12.56 -> 12.53, stochastic 13.48 -> 13.33; bf16 -> uint2 nearest 11.56 (Horner form) -> 11.45, stochastic 12.95 -> 12.48;
+//   fp32 -> uint2 19.64 -> 19.57 / 19.92 -> 19.73; 8-bit outputs gain nothing (one v_perm per four elements against nothing) and keep the saturating pack.
+constexpr int kQuantVariant = 7;                              // 8-bit outputs
+constexpr int kQuantVariantSubByte = 7 | 8;                   // 4- and 2-bit outputs: QV_NORM_PACK on top
 
 // dequantize, indexed [dt_out: f32,bf16][bits: 8,4,2]; SET and ADD separately -- ADD also streams the accumulator in, which moves the
 // optimum to small tiles.  bf16 entries re-measured after fp32 -> bf16 became one v_cvt_pk_bf16_f32 (profiles/r01_tune_finals_other_hw_bf16_cvt.csv,

@@ -717,6 +717,45 @@ int main(int argc, char** argv) {
         g_q3_cap = 0;
         g_rounds = 3;
     }
+    if (only == "norm") {
+        // pack_normalised (two elements per v_cvt_pknorm_u16_f32, var bit 3) against pack_saturated (var 7) and the Horner form (var 3), production tiles
+        g_rounds = 1;
+        for (int pass = 0; pass < 6; ++pass) {
+            run_quant3<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 128, 7>(b, numel, 5.0);
+            run_quant3<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 128, 15>(b, numel, 5.0);
+            run_quant3<DT_F32, 8, RM_STOCH_CALL, 2, true, 5, 128, 7>(b, numel, 5.0);
+            run_quant3<DT_F32, 8, RM_STOCH_CALL, 2, true, 5, 128, 15>(b, numel, 5.0);
+            run_quant3<DT_F32, 4, RM_NEAREST_FAST, 2, true, 5, 64, 7>(b, numel, 4.5);
+            run_quant3<DT_F32, 4, RM_NEAREST_FAST, 2, true, 5, 64, 15>(b, numel, 4.5);
+            run_quant3<DT_F32, 4, RM_STOCH_CALL, 2, true, 5, 64, 7>(b, numel, 4.5);
+            run_quant3<DT_F32, 4, RM_STOCH_CALL, 2, true, 5, 64, 15>(b, numel, 4.5);
+            run_quant3<DT_F32, 2, RM_NEAREST_I64, 2, true, 5, 64, 7>(b, numel, 4.25);
+            run_quant3<DT_F32, 2, RM_NEAREST_I64, 2, true, 5, 64, 15>(b, numel, 4.25);
+            run_quant3<DT_F32, 2, RM_STOCH_CALL, 2, true, 5, 64, 7>(b, numel, 4.25);
+            run_quant3<DT_F32, 2, RM_STOCH_CALL, 2, true, 5, 64, 15>(b, numel, 4.25);
+        }
+        for (int s_ = 0; s_ < SETS; ++s_)
+            hipLaunchKernelGGL(fill_uniform_bf16, dim3(4096), dim3(256), 0, g_stream, static_cast<uint16_t*>(b.in[s_]), numel, 0x9e3779b9u * (s_ + 1));
+        CK(hipStreamSynchronize(g_stream));
+        for (int pass = 0; pass < 6; ++pass) {
+            run_quant3<DT_BF16, 8, RM_NEAREST_FAST, 2, true, 3, 64, 7>(b, numel, 3.0);
+            run_quant3<DT_BF16, 8, RM_NEAREST_FAST, 2, true, 3, 64, 15>(b, numel, 3.0);
+            run_quant3<DT_BF16, 8, RM_STOCH_CALL, 2, true, 5, 64, 7>(b, numel, 3.0);
+            run_quant3<DT_BF16, 8, RM_STOCH_CALL, 2, true, 5, 64, 15>(b, numel, 3.0);
+            run_quant3<DT_BF16, 4, RM_COPY, 2, true, 5, 64, 0>(b, numel, 2.5);
+            run_quant3<DT_BF16, 4, RM_NEAREST_FAST, 2, true, 5, 64, 7>(b, numel, 2.5);
+            run_quant3<DT_BF16, 4, RM_NEAREST_FAST, 2, true, 5, 64, 15>(b, numel, 2.5);
+            run_quant3<DT_BF16, 4, RM_STOCH_CALL, 2, true, 5, 64, 7>(b, numel, 2.5);
+            run_quant3<DT_BF16, 4, RM_STOCH_CALL, 2, true, 5, 64, 15>(b, numel, 2.5);
+            run_quant3<DT_BF16, 2, RM_COPY, 2, true, 5, 64, 0>(b, numel, 2.25);
+            run_quant3<DT_BF16, 2, RM_NEAREST_FAST, 2, true, 5, 64, 3>(b, numel, 2.25);
+            run_quant3<DT_BF16, 2, RM_NEAREST_FAST, 2, true, 5, 64, 15>(b, numel, 2.25);
+            run_quant3<DT_BF16, 2, RM_STOCH_CALL, 4, true, 5, 256, 7>(b, numel, 2.25);
+            run_quant3<DT_BF16, 2, RM_STOCH_CALL, 4, true, 5, 256, 15>(b, numel, 2.25);
+            run_quant3<DT_BF16, 2, RM_STOCH_CALL, 2, true, 5, 64, 15>(b, numel, 2.25);
+        }
+        g_rounds = 3;
+    }
     if (only == "mis") {
         // Round 3: buffers that are not aligned, through the vector kernels (round 2 sent them to a one-byte-per-thread kernel).
         // off_in / off_out in bytes; the last argument is the alignment the store stream is brought to by peeling a head (0 = no peel:
