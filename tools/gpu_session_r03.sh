@@ -39,6 +39,8 @@ for ph in $PHASES; do
                done; echo "tune_cap3 rc=$?" | tee -a $OUT/session.log ;;
     tune_norm) TUNE_SETS=40 timeout 900 ./tools/tune_kernels 27264000 200 norm > $OUT/tune_norm.csv 2> $OUT/tune_norm.err; echo "tune_norm rc=$?" | tee -a $OUT/session.log
                python tools/summarize_tune.py $OUT/tune_norm.csv ;;
+    tune_geo) TUNE_SETS=40 timeout 900 ./tools/tune_kernels 27264000 200 geo > $OUT/tune_geo.csv 2> $OUT/tune_geo.err; echo "tune_geo rc=$?" | tee -a $OUT/session.log
+               python tools/summarize_tune.py $OUT/tune_geo.csv ;;
     xcd)      timeout 300 ./tools/diag_xcd_skew > $OUT/xcd_skew.txt 2>&1; timeout 300 ./tools/diag_xcd_skew 134217728 > $OUT/xcd_skew_2p27.txt 2>&1; echo "xcd rc=$?" | tee -a $OUT/session.log
               grep "launches\|first start ->" $OUT/xcd_skew.txt ;;
     bench)    timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" | tee -a $OUT/session.log; cut -c1-1500 $OUT/bench.json; tail -5 $OUT/bench.err ;;

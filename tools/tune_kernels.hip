@@ -756,6 +756,33 @@ int main(int argc, char** argv) {
         }
         g_rounds = 3;
     }
+    if (only == "geo") {
+        // tile geometry of the bf16-input quantizers once more, on the final step (normalised pack): U x block
+        g_rounds = 1;
+        for (int s_ = 0; s_ < SETS; ++s_)
+            hipLaunchKernelGGL(fill_uniform_bf16, dim3(4096), dim3(256), 0, g_stream, static_cast<uint16_t*>(b.in[s_]), numel, 0x9e3779b9u * (s_ + 1));
+        CK(hipStreamSynchronize(g_stream));
+        for (int pass = 0; pass < 4; ++pass) {
+#define GEO(BITS, MODE, VAR_, BPE)                                                    \
+    run_quant3<DT_BF16, BITS, MODE, 2, true, 5, 64, VAR_>(b, numel, BPE);             \
+    run_quant3<DT_BF16, BITS, MODE, 2, true, 5, 128, VAR_>(b, numel, BPE);            \
+    run_quant3<DT_BF16, BITS, MODE, 2, true, 5, 256, VAR_>(b, numel, BPE);            \
+    run_quant3<DT_BF16, BITS, MODE, 4, true, 5, 64, VAR_>(b, numel, BPE);             \
+    run_quant3<DT_BF16, BITS, MODE, 4, true, 5, 128, VAR_>(b, numel, BPE);            \
+    run_quant3<DT_BF16, BITS, MODE, 4, true, 5, 256, VAR_>(b, numel, BPE);            \
+    run_quant3<DT_BF16, BITS, MODE, 4, true, 5, 512, VAR_>(b, numel, BPE);            \
+    run_quant3<DT_BF16, BITS, MODE, 8, true, 5, 64, VAR_>(b, numel, BPE);             \
+    run_quant3<DT_BF16, BITS, MODE, 8, true, 5, 128, VAR_>(b, numel, BPE);            \
+    run_quant3<DT_BF16, BITS, MODE, 8, true, 5, 256, VAR_>(b, numel, BPE);
+            GEO(2, RM_STOCH_CALL, 15, 2.25)
+            GEO(4, RM_STOCH_CALL, 15, 2.5)
+            GEO(8, RM_STOCH_CALL, 7, 3.0)
+            GEO(2, RM_NEAREST_FAST, 15, 2.25)
+            GEO(4, RM_NEAREST_FAST, 15, 2.5)
+#undef GEO
+        }
+        g_rounds = 3;
+    }
     if (only == "mis") {
         // Round 3: buffers that are not aligned, through the vector kernels (round 2 sent them to a one-byte-per-thread kernel).
         // off_in / off_out in bytes; the last argument is the alignment the store stream is brought to by peeling a head (0 = no peel:
