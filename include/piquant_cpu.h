@@ -26,7 +26,9 @@ extern "C" {
 
 typedef struct piquant_cpu_context_t piquant_cpu_context_t;
 
-/* num_threads = 0: one worker per CPU this process may run on.  The calling thread is worker 0. */
+/* num_threads = 0: one worker per PHYSICAL core this process may run on (a second hardware thread of a core adds nothing to kernels that wait for
+ * DRAM).  The calling thread is worker 0.  quantize / dequantize cut every worker's share -- its partition by the reference's rule,
+ * src/piquant.cpp:145-157 -- into 256 KiB chunks, a worker takes its own chunks first and then the others': results are those of any split. */
 PIQUANT_CPU_EXPORT piquant_cpu_context_t* piquant_cpu_context_create(size_t num_threads);
 PIQUANT_CPU_EXPORT void piquant_cpu_context_destroy(piquant_cpu_context_t* ctx);
 PIQUANT_CPU_EXPORT size_t piquant_cpu_num_threads(const piquant_cpu_context_t* ctx);

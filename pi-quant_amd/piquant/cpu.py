@@ -38,7 +38,8 @@ def lib() -> C.CDLL:
 
 
 class CpuContext:
-    """A pool of `num_threads` workers (0 = one per usable CPU); calls take raw host addresses, dtype / mode codes are those of piquant.h."""
+    """A pool of `num_threads` workers (0 = one per usable physical core); calls take raw host addresses, dtype / mode codes are those of piquant.h.
+    quantize / dequantize hand every worker's share out in 256 KiB chunks (own share first, then the others'): a busy core costs a chunk, not the call."""
 
     def __init__(self, num_threads: int = 0):
         self._lib = lib()
