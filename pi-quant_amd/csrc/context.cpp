@@ -204,7 +204,7 @@ const CpuCompanion& cpu_companion() {
 
 void* cpu_context_of(piquant_context_t* ctx) {
     if (!ctx->cpu_ctx) {
-        size_t threads = 0;   // one worker per usable CPU; PIQUANT_CPU_THREADS overrides
+        size_t threads = 0;   // one worker per usable physical core; PIQUANT_CPU_THREADS overrides
         if (const char* env = std::getenv("PIQUANT_CPU_THREADS")) threads = static_cast<size_t>(std::strtoul(env, nullptr, 10));
         ctx->cpu_ctx = cpu_companion().context_create(threads);
     }
