@@ -204,7 +204,7 @@ struct piquant_cpu_context_t {
 
 namespace {
 
-// fn(b, e) over [0, numel) in chunks of kChunkElems, the shares cut like part_of (whole packed bytes); results must not depend on where a
+// fn(b, e, worker) over [0, numel) in chunks of kChunkElems, the shares cut like part_of (whole packed bytes); results must not depend on where a
 // chunk ends -- true of every kernel of this library (each element is computed by the SIMD-body formula, tails are masked vectors)
 template <typename F>
 void parallel_chunks(piquant_cpu_context_t* ctx, size_t numel, size_t pack, const F& fn) {
@@ -222,7 +222,7 @@ void parallel_chunks(piquant_cpu_context_t* ctx, size_t numel, size_t pack, cons
                 if (s.next.load(std::memory_order_relaxed) >= s.end) break;
                 const size_t b = s.next.fetch_add(kChunkElems, std::memory_order_relaxed);
                 if (b >= s.end) break;
-                fn(b, std::min(b + kChunkElems, s.end));
+                fn(b, std::min(b + kChunkElems, s.end), t);
             }
         }
     });
@@ -299,7 +299,7 @@ void piquant_cpu_quantize(piquant_cpu_context_t* ctx, const void* in, int dtype_
     a.threshold = threshold;
     const size_t pack = 8 / bits_of(dtype_out);
     std::lock_guard<std::mutex> lk(ctx->call);
-    parallel_chunks(ctx, numel, pack, [&](size_t b, size_t e) { fn(in, static_cast<uint8_t*>(out), b, e, a); });
+    parallel_chunks(ctx, numel, pack, [&](size_t b, size_t e, size_t) { fn(in, static_cast<uint8_t*>(out), b, e, a); });
 }
 
 void piquant_cpu_dequantize(piquant_cpu_context_t* ctx, const void* in, int dtype_in, void* out, int dtype_out, size_t numel, float scale, int64_t zero_point,
@@ -314,7 +314,7 @@ void piquant_cpu_dequantize(piquant_cpu_context_t* ctx, const void* in, int dtyp
     a.bias = -static_cast<float>(a.zp32) * scale;
     const size_t pack = 8 / bits_of(dtype_in);
     std::lock_guard<std::mutex> lk(ctx->call);
-    parallel_chunks(ctx, numel, pack, [&](size_t b, size_t e) { fn(static_cast<const uint8_t*>(in), out, b, e, a); });
+    parallel_chunks(ctx, numel, pack, [&](size_t b, size_t e, size_t) { fn(static_cast<const uint8_t*>(in), out, b, e, a); });
 }
 
 void piquant_cpu_minmax(piquant_cpu_context_t* ctx, const void* x, int dtype, size_t numel, float* out_min, float* out_max) {
@@ -323,19 +323,17 @@ void piquant_cpu_minmax(piquant_cpu_context_t* ctx, const void* x, int dtype, si
     if (numel != 0) {
         if (!x) panic("piquant_cpu_minmax: null buffer");
         std::lock_guard<std::mutex> lk(ctx->call);
-        std::vector<float> los(ctx->pool.size(), FLT_MAX), his(ctx->pool.size(), -FLT_MAX);
-        ctx->pool.parallel([&](size_t t, size_t T) {
-            size_t b, e;
-            part_of(numel, t, T, 1, b, e);
-            if (b >= e) return;
-            float l = FLT_MAX, h = -FLT_MAX;
-            const MinmaxFn scan = g_avx512 ? avx512_minmax_fn(dtype) : (dtype == DT_F32 ? static_cast<MinmaxFn>(minmax_scalar<DT_F32>) : static_cast<MinmaxFn>(minmax_scalar<DT_BF16>));
-            scan(x, b, e, l, h);
-            los[t] = l;
-            his[t] = h;
-        });
-        for (float v : los) lo = std::min(lo, v);
-        for (float v : his) hi = std::max(hi, v);
+        // per-worker extremes, one cache line each; the scans skip NaNs (both forms), so the extremes of any set of chunks are those of their elements
+        struct alignas(64) Extremes {
+            float lo = FLT_MAX, hi = -FLT_MAX;
+        };
+        std::vector<Extremes> ex(ctx->pool.size());
+        const MinmaxFn scan = g_avx512 ? avx512_minmax_fn(dtype) : (dtype == DT_F32 ? static_cast<MinmaxFn>(minmax_scalar<DT_F32>) : static_cast<MinmaxFn>(minmax_scalar<DT_BF16>));
+        parallel_chunks(ctx, numel, 1, [&](size_t b, size_t e, size_t t) { scan(x, b, e, ex[t].lo, ex[t].hi); });
+        for (const Extremes& v : ex) {
+            lo = std::min(lo, v.lo);
+            hi = std::max(hi, v.hi);
+        }
     }
     *out_min = lo;
     *out_max = hi;
