@@ -14,10 +14,13 @@ value = the tensor's fp32 bytes x K / max-over-ranks time.  At N = 1 the shard i
 see ROUND1_SETS below): the number is an HBM number.  The weak-scaling variant (every rank its own 27 264 000-element tensor, the data-parallel
 gradient case) is timed separately into extras.weak_scaling_own_tensor_per_gpu for N > 1.
 
-Launch: python bench.py [--gpus 1]            or, for N > 1,
+Launch: python bench.py [--gpus N]            (N > 1 without a launcher environment: bench.py starts its own N ranks through
+                                                torch.distributed.run on 127.0.0.1 and a free port, and hands their one line on)
         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-               bench.py --gpus N --steps K --warmup W
-Prints ONE JSON line on rank 0.
+               bench.py --gpus N --steps K --warmup W        (the driver's form for N > 1: used as it is)
+Prints ONE JSON line on rank 0.  For N > 1 the line validates itself: `ranks_seen` (what the process group reports, and the devices behind
+the ranks), `shard_bit_exact` (every rank's output bytes of tensor 0 against the checker on its shard_range, outside the timed region) and
+`n1_reference` (rank 0 alone, the whole tensor, same protocol: the N = 1 point of the same run).
 """
 import argparse
 import json
@@ -248,8 +251,190 @@ def cpu_baseline(x_host: np.ndarray, scale: float, zp: int, budget_s: float, nse
     return ref
 
 
+def shard_check(x_dev, out_dev, scale, zp):
+    """This rank's output bytes of buffer set 0 against the checker -- the repository's C restatement of the reference arithmetic
+    (oracle/, test infrastructure; never on the product path and never inside a timed region) run on the same shard on the host."""
+    try:
+        import oracle as O
+
+        want = O.quantize(x_dev.cpu().numpy(), O.F32, O.UINT8, scale, zp)
+        return bool(np.array_equal(out_dev.cpu().numpy(), want))
+    except Exception as exc:      # a box without the prebuilt checker: say so, do not claim
+        print(f"bench.py: shard check unavailable: {exc!r}", file=sys.stderr, flush=True)
+        return None
+
+
+def device_identity(dev):
+    props = torch.cuda.get_device_properties(dev)
+    ident = getattr(props, "uuid", None)
+    if ident is None:
+        ident = f"pci {getattr(props, 'pci_domain_id', 0):04x}:{getattr(props, 'pci_bus_id', -1):02x}:{getattr(props, 'pci_device_id', -1):02x}"
+    return f"cuda:{dev.index} {props.name} {ident}"
+
+
+def gather_objects(obj, world, use_dist):
+    if not use_dist:
+        return [obj]
+    got = [None] * world
+    dist.all_gather_object(got, obj)
+    return got
+
+
+def max_over_ranks(seconds, dev, use_dist):
+    t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+    if use_dist:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t[0])
+
+
+def fp32_all_reduce(t):
+    """SUM all-reduce of a device fp32 tensor: RCCL moves it as it is; backends without device collectives (gloo in the one-GPU tests) are staged"""
+    if dist.get_backend() == "nccl":
+        dist.all_reduce(t)
+        return
+    h = t.cpu()
+    dist.all_reduce(h)
+    t.copy_(h)
+
+
+def all_reduce_extras(args, pqd, dev, rank, world, n_total):
+    """SURVEY 8(f2) / 8(e2) on N > 1 ranks: both schedules of the quantized all-reduce against the fp32 all-reduce of the same 109 MB tensor, the
+    bare 8-byte MIN all-reduce, and what the collective adds to compute_quant_params.  Runs on every rank (collectives inside)."""
+    nccl = args.backend == "nccl"
+    warm, reps = (3, 10) if nccl else (1, 2)
+    g = torch.Generator(device=dev)
+    g.manual_seed(9000 + rank)
+    x = torch.empty(n_total, dtype=torch.float32, device=dev).uniform_(-1.0, 1.0, generator=g)
+    exact = x.clone()
+    fp32_all_reduce(exact)
+    copies = [torch.empty_like(x) for _ in range(warm + reps)]
+    out = {"numel": n_total, "MB_fp32": round(n_total * 4 / 1e6, 1), "ranks": world, "backend": "RCCL" if nccl else args.backend,
+           "reps": reps, "timing": "wall clock from a barrier to torch.cuda.synchronize() over `reps` all-reduces of distinct tensors, max over ranks",
+           "design_prediction": "DESIGN.md section 7 (8 GPUs, uint8 wire): direct/mesh 78 us of kernels per rank around ~45 us of wire (2 x 7/8 x 27 MB over 7 xGMI links), "
+                                "ring 152 us of kernels + 14 hops; fp32 RCCL all-reduce moves 4x the bytes"}
+
+    def timed(fn):
+        for c in copies:
+            c.copy_(x)
+        for c in copies[:warm]:
+            fn(c)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for c in copies[warm:]:
+            fn(c)
+        torch.cuda.synchronize()
+        return max_over_ranks((time.perf_counter() - t0) / reps, dev, True)
+
+    t = timed(fp32_all_reduce)
+    out["all_reduce_fp32"] = {"ms": round(t * 1e3, 4), "algbw_GB/s": round(n_total * 4 / t / 1e9, 1)}
+    for algo in ("direct", "ring"):
+        try:
+            t = timed(lambda c, a=algo: pqd.quantized_all_reduce(c, quant_dtype=torch.uint8, algorithm=a))
+            res = copies[-1]
+            err = float((res - exact).abs().max())
+            # every rank must hold the same bits (all ranks decode the same gathered bytes)
+            digest = res.view(torch.int32).to(torch.int64).sum().reshape(1)
+            lo, hi = digest.clone(), digest.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            # every value is quantized twice (direct) or up to G times (ring) on a grid of (range / 255): per quantization half a step of
+            # a range that is at most 2 (one rank's values) resp. 2 G (the sum)
+            bound = (world * (2.0 / 255) + 2.0 * world / 255) * 0.5 * (1 if algo == "direct" else world) + 1e-5
+            out[f"quantized_all_reduce_{algo}_u8"] = {"ms": round(t * 1e3, 4), "algbw_GB/s": round(n_total * 4 / t / 1e9, 1),
+                                                        "speedup_vs_fp32": round(out["all_reduce_fp32"]["ms"] / (t * 1e3), 3),
+                                                        "max_abs_err_vs_fp32_sum": round(err, 6), "err_bound": round(bound, 6), "within_bound": err <= bound,
+                                                        "ranks_bit_identical": int(lo[0]) == int(hi[0])}
+        except Exception as exc:
+            out[f"quantized_all_reduce_{algo}_u8"] = {"error": repr(exc)}
+    del copies, exact
+    # the path's only collective: 2 x int32 MIN
+    keys = torch.zeros(2, dtype=torch.int32, device=dev)
+    for _ in range(5):
+        dist.all_reduce(keys, op=dist.ReduceOp.MIN)
+    torch.cuda.synchronize()
+    dist.barrier()
+    kreps = 100 if nccl else 20
+    t0 = time.perf_counter()
+    for _ in range(kreps):
+        dist.all_reduce(keys, op=dist.ReduceOp.MIN)
+        torch.cuda.synchronize()
+    out["min_all_reduce_8_bytes"] = {"us_per_call": round(max_over_ranks((time.perf_counter() - t0) / kreps, dev, True) * 1e6, 2),
+                                     "note": "dist.all_reduce(int32[2], MIN) + synchronize, one at a time: latency, not bandwidth"}
+    return out, x
+
+
+def native_dist_entry(args, ctx, shard, dev, rank, world, want):
+    """piquant_hip_compute_quant_params_dist (csrc/capi.cpp: scan + ncclAllReduce(2 x int32, ncclMin) on the context's stream + epilogue, no Python
+    between them) on a communicator of its own over all ranks: rank 0 draws the unique id, the process group carries it to the others."""
+    import ctypes
+
+    from piquant import DataType
+
+    rccl = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+
+    rccl.ncclGetUniqueId.argtypes = [ctypes.POINTER(UniqueId)]
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+    uid = UniqueId()
+    box = [None]
+    if rank == 0:
+        assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+        box[0] = bytes(ctypes.string_at(ctypes.addressof(uid), 128))
+    dist.broadcast_object_list(box, src=0)
+    ctypes.memmove(ctypes.addressof(uid), box[0], 128)
+    comm = ctypes.c_void_p()
+    rc = rccl.ncclCommInitRank(ctypes.byref(comm), world, uid, rank)
+    if rc != 0:
+        raise RuntimeError(f"ncclCommInitRank -> {rc}")
+    try:
+        for _ in range(3):
+            got = ctx.compute_quant_params_dist_ptr(shard.data_ptr(), DataType.F32, shard.numel(), DataType.UINT8, comm.value)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            got = ctx.compute_quant_params_dist_ptr(shard.data_ptr(), DataType.F32, shard.numel(), DataType.UINT8, comm.value)
+        t = max_over_ranks((time.perf_counter() - t0) / 20, dev, True)
+    finally:
+        rccl.ncclCommDestroy(comm)
+    return {"ms_per_call": round(t * 1e3, 5), "result": list(got), "result_correct": tuple(got) == want,
+            "note": f"C entry point on its own {world}-rank RCCL communicator: scan, ncclAllReduce, 8-byte D2H, epilogue -- one call, synchronous"}
+
+
+def launch_own_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment (RANK / MASTER_ADDR): start the N ranks here -- the same
+    torch.distributed.run command the driver uses for N > 1, rendezvous on 127.0.0.1 (the container hostname may not resolve) and a port that is
+    free right now -- and pass their exit code on.  Rank 0 of the children prints the one JSON line on the stdout they inherit."""
+    import socket
+    import subprocess
+
+    if not args.share_gpu:
+        seen = torch.cuda.device_count()
+        if args.gpus > seen:      # loud and at once: RCCL with two ranks on one device does not fail, it hangs
+            sys.exit(f"bench.py: --gpus {args.gpus} but only {seen} visible device(s); one rank per GPU "
+                     "(--share-gpu with --backend gloo is test plumbing for one-GPU boxes)")
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the host driver only supports dmabuf IPC (RCCL between processes needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")                # torch.distributed.run would set 1 (and say so on stderr); the CPU legs size their own pools
+    env["PIQUANT_BENCH_SELF_LAUNCHED"] = "1"
+    print(f"bench.py: --gpus {args.gpus} without a launcher environment: starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and not ("RANK" in os.environ and "MASTER_ADDR" in os.environ):
+        launch_own_ranks(args)
     # The contract is ONE JSON line on stdout.  Native libraries (RCCL prints a version banner at communicator creation)
     # write to fd 1 behind Python's back, so everything but the final line is diverted to stderr at the fd level.
     sys.stdout.flush()
@@ -260,7 +445,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU: the product has no CPU path"
     use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ      # launched by torch.distributed.run (any N, also N=1)
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: for N > 1 launch through torch.distributed.run"
+    if args.gpus != world:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher environment says WORLD_SIZE={world}: pass --gpus {world}, or run without a launcher "
+                 "(bench.py starts its own ranks)")
     if args.share_gpu:
         local_rank = 0
     elif world > torch.cuda.device_count():
@@ -353,6 +540,11 @@ def main():
         if use_dist:
             dist.barrier()
 
+    # Self-validation, outside the timed region and before any side measurement reuses the buffers: every rank compares the bytes the timed
+    # calls left in output buffer 0 with the checker run on ITS shard of tensor 0, and says which device it ran on.
+    mine = {"rank": rank, "shard": [b0, e0], "bit_exact": shard_check(xs[0], outs[0], scale, zp), "device": device_identity(dev)}
+    per_rank = gather_objects(mine, world, use_dist)
+
     t = torch.tensor([walls, evs], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -404,6 +596,13 @@ def main():
                         "Infinity Cache: ~1.1 us per launch faster; that figure: extras.rotation_of_6_sets_818MB_round1_protocol, and extras.cold_inputs_one_output_buffer)",
         },
     }
+    result["shard_bit_exact"] = [r["bit_exact"] for r in per_rank]
+    result["self_check"] = {"what": "output bytes of buffer set 0 after the timed region == the checker (oracle/: C restatement of the reference arithmetic, pinned against "
+                                    "the reference's own kernels in tests/) on each rank's shard_range of tensor 0; null = checker not available on this box",
+                            "shards": [r["shard"] for r in per_rank], "all_bit_exact": all(r["bit_exact"] is True for r in per_rank)}
+    result["ranks_seen"] = {"world_size": dist.get_world_size() if use_dist else 1, "backend": (dist.get_backend() if use_dist else None),
+                            "launcher": ("bench.py's own torch.distributed.run" if os.environ.get("PIQUANT_BENCH_SELF_LAUNCHED") else "external") if use_dist else None,
+                            "devices": [r["device"] for r in per_rank], "distinct_devices": len({r["device"] for r in per_rank})}
     if world > 1:
         result["roofline"]["scope"] = (f"per GPU: each launch moves {ALGO_BYTES_PER_ELEM * n_max} algorithmic bytes; at {n_max} elements per GPU a launch is "
                                        "dominated by its fixed ~2.4 us dispatch ramp/drain (DESIGN.md section 4), so the per-GPU fraction falls with N")
@@ -438,16 +637,68 @@ def main():
             line_printed[0] = True
 
     watchdog = None
+    side = {}      # N > 1: side measurements as they finish (what the watchdog's line carries)
     if world > 1 and not args.no_extras:
         def bail():
             headline = dict(result)
-            headline["extras"] = {"error": f"the multi-rank side measurements did not finish within {EXTRAS_LIMIT_S} s; headline only"}
+            headline["extras"] = dict(side, error=f"the multi-rank side measurements did not finish within {EXTRAS_LIMIT_S} s; headline and what had finished by then")
             emit(headline)
             os._exit(0)
 
         watchdog = threading.Timer(EXTRAS_LIMIT_S, bail)
         watchdog.daemon = True
         watchdog.start()
+
+    # N > 1: the N = 1 point of the SAME run -- rank 0 alone quantizes the whole tensor with the headline's protocol (K steps per window, cold
+    # rotation of args.sets full-size sets) while the other ranks wait at the barrier behind it.
+    n1_ref = None
+    if world > 1 and not args.no_extras:
+        try:
+            if rank == 0:
+                rx, ro = [], []
+                for s_ in range(args.sets):
+                    g = torch.Generator(device=dev)
+                    g.manual_seed(700_000 + s_)
+                    rx.append(torch.empty(n_total, dtype=torch.float32, device=dev).uniform_(-1.0, 1.0, generator=g))
+                    ro.append(torch.empty(n_total, dtype=torch.uint8, device=dev))
+                rargs = [(ctx._ctx, rx[k].data_ptr(), DataType.F32.value, ro[k].data_ptr(), DataType.UINT8.value, n_total, scale, zp, RoundMode.NEAREST.value)
+                         for k in range(args.sets)]
+
+                def rstep(i):
+                    c_quantize(*rargs[i % args.sets])
+
+                with torch.cuda.stream(stream):
+                    for i in range(200 + args.warmup):
+                        rstep(i)
+                    rw, re = [], []
+                    for w in range(min(args.windows, 15)):
+                        a, b_ = time_loop(rstep, args.steps, stream, base=w * args.steps)
+                        rw.append(a)
+                        re.append(b_)
+                rw.sort()
+                re.sort()
+                rmed, remed = rw[len(rw) // 2], re[len(re) // 2]
+                n1_ref = {"GiB/s": round(gib_per_step * args.steps / rmed, 2), "ms_per_step": round(rmed / args.steps * 1e3, 6),
+                          "avg_launch_us": round(remed / args.steps * 1e6, 3), "roofline_frac": round(ALGO_BYTES_PER_ELEM * n_total / (remed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                          "bit_exact": shard_check(rx[0], ro[0], scale, zp), "windows": len(rw),
+                          "note": f"rank 0 alone, the whole {n_total}-element tensor on one GPU, {args.sets} cold buffer sets, median window of K = {args.steps} steps: "
+                                  "the N = 1 point measured inside this N > 1 run (compare with the driver's N = 1 line)"}
+                del rx, ro
+        except Exception as exc:
+            n1_ref = {"error": repr(exc)}
+        result["n1_reference"] = n1_ref      # in the line even if a later side measurement runs into the watchdog
+        dist.barrier()
+
+    all_reduce, native5 = None, None
+    if world > 1 and not args.no_extras:
+        try:
+            all_reduce, _x = all_reduce_extras(args, pqd, dev, rank, world, n_total)
+            del _x
+        except Exception as exc:
+            all_reduce = {"error": repr(exc)}
+        side["all_reduce_109MB"] = all_reduce
+        ctx.set_stream(stream.cuda_stream)
+        ctx.set_blocking(False)
 
     graphed = None
     if not args.no_extras:
@@ -499,6 +750,7 @@ def main():
             ctx.set_blocking(False)
         except Exception as exc:
             graphed = {"error": repr(exc)}
+        side["steps_replayed_from_a_hipgraph"] = graphed
 
     # Independent calls issued alternately on two streams (a context each): a stream runs its kernels one after the other, and the ~2 us in which
     # a launch ramps up and drains move no bytes; on two streams the next tensor's ramp runs under this one's drain.  What a
@@ -570,6 +822,26 @@ def main():
                        "note": "HIP scan of the local shard + " + (f"one 8-byte all_reduce(MIN) over {'RCCL' if args.backend == 'nccl' else args.backend} ({world} ranks)"
                                                                   if world > 1 else "no collective (one rank: the all-reduce is skipped)") +
                                " + host epilogue, synchronous per call"}
+            if world > 1:
+                # the same call without its collective (local scan + 8-byte D2H + epilogue): what the all-reduce adds
+                with torch.cuda.stream(stream):
+                    for _ in range(3):
+                        pqd.local_minmax_keys(shard, ctx).cpu()
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    t0 = time.perf_counter()
+                    for _ in range(20):
+                        pqd.local_minmax_keys(shard, ctx).cpu()
+                    tl = max_over_ranks((time.perf_counter() - t0) / 20, dev, True)
+                config5["ms_per_call_without_collective"] = round(tl * 1e3, 5)
+                config5["collective_adds_ms"] = round((float(t5t[0]) - tl) * 1e3, 5)
+                if args.backend == "nccl":
+                    try:
+                        ctx.set_blocking(True)
+                        native5 = native_dist_entry(args, ctx, shard, dev, rank, world, want5)
+                    except Exception as exc:
+                        native5 = {"error": repr(exc)}
+                    config5["native_entry_piquant_hip_compute_quant_params_dist"] = native5
             del shard
             ctx.set_stream(stream.cuda_stream)
             ctx.set_blocking(False)
@@ -577,6 +849,7 @@ def main():
             config5 = {"error": repr(exc)}
             ctx.set_stream(stream.cuda_stream)
             ctx.set_blocking(False)
+        side["config5_sharded_compute_quant_params"] = config5
 
     # N > 1: the weak-scaling variant next to the strong-scaling headline -- every rank quantizes its OWN full-size tensor (the
     # data-parallel gradient case), same protocol; runs on every rank, reported under extras.
@@ -615,7 +888,8 @@ def main():
             weak = {"error": repr(exc)}
 
     if rank == 0 and not args.no_extras and world > 1:
-        result["extras"] = {"steps_replayed_from_a_hipgraph": graphed, "config5_sharded_compute_quant_params": config5, "weak_scaling_own_tensor_per_gpu": weak}
+        result["extras"] = {"steps_replayed_from_a_hipgraph": graphed, "config5_sharded_compute_quant_params": config5, "weak_scaling_own_tensor_per_gpu": weak,
+                            "all_reduce_109MB": all_reduce}
     if rank == 0 and not args.no_extras and world == 1:     # the single-GPU side measurements stay out of the multi-rank runs
         extras = {"steps_replayed_from_a_hipgraph": graphed, "independent_calls_on_two_streams": two_streams, "config5_sharded_compute_quant_params": config5}
 
@@ -641,7 +915,7 @@ def main():
             ctx.set_blocking(True)
             ctx.assume_device_pointers(True)      # step() makes the raw C call: the context must know these are device pointers
             blocking = {}
-            for mode in ("sync", "write32", "kernel"):
+            for mode in ("sync", "write32", "kernel", "event"):
                 ctx.set_blocking_wait(mode)
                 for i in range(20):
                     step(i)
@@ -654,7 +928,8 @@ def main():
             ctx.set_blocking(False)
             extras["blocking_calls"] = dict(blocking[DEFAULT_BLOCKING_WAIT], wait=DEFAULT_BLOCKING_WAIT, by_wait_mode=blocking,
                                             note="piquant_quantize returning after completion, as the reference's calls do; sync = hipStreamSynchronize, "
-                                                 "write32 = hipStreamWriteValue32 into a pinned host word + host spin, kernel = one-thread kernel writing that word")
+                                                 "write32 = hipStreamWriteValue32 into a pinned host word + host spin, kernel = one-thread kernel writing that word, "
+                                                 "event = the work kernel's own stop event (hipExtLaunchKernelGGL) polled with hipEventQuery")
 
             def gbs(bytes_per_elem, ev_s, reps):
                 return round(bytes_per_elem * n / (ev_s / reps) / 1e9, 1)
@@ -724,19 +999,9 @@ def main():
                                                        "note": "full C-ABI call through piquant.torch: scan whose last block publishes the keys into a pinned host mailbox + host spin + double epilogue"}
             ctx.set_stream(stream.cuda_stream)
             ctx.set_blocking(False)
-        # the reference's own calling convention: host buffers in, host buffers out (staged over PCIe, never `value`)
+        # the reference's own calling convention: host buffers in, host buffers out, blocking (never `value`)
         if xs0_host is not None:
-            hctx = piquant.Context()
-            hout = np.empty(n, dtype=np.uint8)
-            hctx.quantize_ptr(xs0_host.ctypes.data, DataType.F32, hout.ctypes.data, DataType.UINT8, n, scale, zp, RoundMode.NEAREST)
-            t0 = time.perf_counter()
-            for _ in range(3):
-                hctx.quantize_ptr(xs0_host.ctypes.data, DataType.F32, hout.ctypes.data, DataType.UINT8, n, scale, zp, RoundMode.NEAREST)
-            th = (time.perf_counter() - t0) / 3
-            extras["host_pointers_pcie_inclusive"] = {"GiB/s": round(gib_per_step / th, 2), "ms_per_call": round(th * 1e3, 3),
-                                                      "note": "pageable host in/out, chunked H2D -> kernel -> D2H on two streams (the default for host buffers)"}
-            try:   # the opt-in for host-resident tensors: the same call handed to libpiquant_cpu.so (piquant_hip_set_host_path)
-                hctx.set_host_path("cpu")
+            def host_rotation(hctx):
                 # eight tensors of the caller's in rotation (1.1 GB: DRAM, not the sockets' 512 MB of L3), all allocated and filled by this thread
                 hxs = [xs0_host] + [xs0_host.copy() for _ in range(7)]
                 houts = [np.zeros(n, dtype=np.uint8) for _ in range(8)]
@@ -747,13 +1012,41 @@ def main():
                         hctx.quantize_ptr(hx.ctypes.data, DataType.F32, ho.ctypes.data, DataType.UINT8, n, scale, zp, RoundMode.NEAREST)
                     if rot:
                         best = min(best, (time.perf_counter() - t0) / len(hxs))
-                extras["host_pointers_cpu_companion"] = {"GiB/s": round(gib_per_step / best, 2), "ms_per_call": round(best * 1e3, 3),
-                                                         "note": "same call with piquant_hip_set_host_path(ctx, CPU): libpiquant_cpu.so, one worker per physical core, unpinned; eight "
-                                                                 "tensors in rotation (1.1 GB) that this thread allocated and filled -- nothing first-touched per worker: what an "
-                                                                 "unprepared caller gets; best mean per call over whole rotations"}
-                del hxs, houts
+                return best, houts[0]
+
+            try:   # what an UNCHANGED caller of the reference gets: a fresh context, nothing set
+                hctx = piquant.Context()
+                served_by = hctx.host_path_in_effect()
+                best, hq = host_rotation(hctx)
+                extras["host_pointers_default"] = {"GiB/s": round(gib_per_step / best, 2), "ms_per_call": round(best * 1e3, 3), "served_by": served_by,
+                                                   "bit_equal_to_the_device_path": None,
+                                                   "note": "pageable host in/out through piquant_quantize with a default context (PIQUANT_HIP_HOST_PATH_AUTO): 'cpu' = handed whole to "
+                                                           "libpiquant_cpu.so (AVX-512, one worker per physical core, unpinned; eight tensors in rotation = 1.1 GB that this thread "
+                                                           "allocated and filled, nothing first-touched per worker: what an unprepared caller gets), 'stage' = no companion / no AVX-512: "
+                                                           "PCIe staging; best mean per call over whole rotations"}
+                # the bytes, against the HIP kernel on the same tensor (outside any timed region)
+                dx = torch.from_numpy(xs0_host).to(dev)      # xs[0] itself has been an accumulator of the ADD measurement above
+                dq = piquant.torch.quantize(dx, scale=scale, zero_point=zp, dtype=torch.uint8)
+                torch.cuda.synchronize()
+                extras["host_pointers_default"]["bit_equal_to_the_device_path"] = bool(np.array_equal(hq, dq.cpu().numpy()))
+                del dx, dq
+                ctx.set_stream(stream.cuda_stream)
+                ctx.set_blocking(False)
             except Exception as exc:
-                extras["host_pointers_cpu_companion"] = {"error": repr(exc)}
+                extras["host_pointers_default"] = {"error": repr(exc)}
+            try:   # asked for: every element computed by the GPU
+                hctx = piquant.Context()
+                hctx.set_host_path("stage")
+                hout = np.empty(n, dtype=np.uint8)
+                hctx.quantize_ptr(xs0_host.ctypes.data, DataType.F32, hout.ctypes.data, DataType.UINT8, n, scale, zp, RoundMode.NEAREST)
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    hctx.quantize_ptr(xs0_host.ctypes.data, DataType.F32, hout.ctypes.data, DataType.UINT8, n, scale, zp, RoundMode.NEAREST)
+                th = (time.perf_counter() - t0) / 3
+                extras["host_pointers_pcie_inclusive"] = {"GiB/s": round(gib_per_step / th, 2), "ms_per_call": round(th * 1e3, 3),
+                                                          "note": "same call with piquant_hip_set_host_path(ctx, STAGE): pageable host in/out, chunked H2D -> HIP kernel -> D2H on two streams"}
+            except Exception as exc:
+                extras["host_pointers_pcie_inclusive"] = {"error": repr(exc)}
         for rec_ in extras.values():        # every side measurement that has an algorithmic rate also carries its fraction of the HBM peak
             if isinstance(rec_, dict) and "GB/s" in rec_:
                 rec_["roofline_frac"] = round(rec_["GB/s"] / HBM_PEAK_GBS, 4)

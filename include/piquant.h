@@ -9,7 +9,10 @@
  *
  * Pointer contract (extension of the reference, which knows host memory only):
  *   - device pointers (hipMalloc / PyTorch-ROCm tensor.data_ptr()) are processed in place, in HBM;
- *   - host pointers are staged through device scratch over PCIe -- there is no CPU compute path.
+ *   - pageable host pointers (the reference's only kind) are served where they live: the call is forwarded whole to the companion
+ *     libpiquant_cpu.so (the same arithmetic in AVX-512 on the host cores) when that library is present, and staged through device scratch
+ *     over PCIe to the HIP kernels otherwise or when asked (piquant_hip.h, piquant_hip_set_host_path).  libpiquant.so itself contains no CPU
+ *     arithmetic, and a context still needs a HIP device.
  * numel always counts logical elements; a packed buffer holds ceil(numel * bits / 8) bytes with the
  * lower-indexed element in the lower bits (reference src/kernels/quantize.inl:36-50).
  *

@@ -30,21 +30,30 @@ PIQUANT_EXPORT void piquant_hip_set_blocking(piquant_context_t* ctx, int blockin
 
 /* How a blocking call waits for the GPU: 0 = hipStreamSynchronize; 1 = the command processor writes the call's sequence number
  * into a pinned host word behind the kernel (hipStreamWriteValue32) and the host spins on it; 2 = the same word written by a
- * one-thread kernel.  All three return after the work has completed; they differ in latency only.  The
- * environment variable PIQUANT_HIP_BLOCKING_WAIT = sync | write32 | kernel sets it at context creation. */
+ * one-thread kernel; 3 = the work kernel is launched with a stop event (its dispatch packet's own completion signal) that the host polls
+ * with hipEventQuery -- nothing is enqueued behind it (piquant_quantize / piquant_dequantize on device buffers; other calls wait as 2).
+ * All four return after the work has completed; they differ in latency only.  The
+ * environment variable PIQUANT_HIP_BLOCKING_WAIT = sync | write32 | kernel | event sets it at context creation. */
 PIQUANT_EXPORT void piquant_hip_set_blocking_wait(piquant_context_t* ctx, int mode);
 
-/* What serves calls whose buffers are pageable HOST memory (the reference's own calling convention).
- *   PIQUANT_HIP_HOST_PATH_STAGE (0, default): chunks of 2^24 elements cross PCIe into device scratch, the HIP kernels process them, the
- *       results cross back -- every element is still computed by the GPU, at ~40 GiB/s of fp32 input (PCIe bound).
- *   PIQUANT_HIP_HOST_PATH_CPU (1): the call is handed to libpiquant_cpu.so (include/piquant_cpu.h; loaded from the directory of this
- *       library on first use, abort if it is missing): the same arithmetic in AVX-512 on the host cores, at host-memory bandwidth.
- *       Only calls whose input AND output are pageable host memory take it; device and pinned pointers always run the HIP kernels, and so
- *       do reference-layout mode and the per-element stochastic extension, which the companion does not implement.
- * The environment variable PIQUANT_HIP_HOST_PATH = stage | cpu sets it at context creation.  Nothing is ever switched silently. */
+/* What serves calls whose buffers are pageable HOST memory (the reference's own calling convention, src/capi.cpp:28-54).
+ *   PIQUANT_HIP_HOST_PATH_AUTO (2, default): host tensors stay on the host -- the call is handed to libpiquant_cpu.so when that library loads
+ *       and the host has AVX-512 (the same arithmetic on the host cores, at host-memory bandwidth: what the reference does with such a
+ *       call); otherwise, and for everything the companion does not implement (below), PIQUANT_HIP_HOST_PATH_STAGE.  Which of the two a
+ *       context resolved to: piquant_hip_host_path_in_effect.
+ *   PIQUANT_HIP_HOST_PATH_STAGE (0): chunks of 2^24 elements cross PCIe into device scratch, the HIP kernels process them, the
+ *       results cross back -- every element is computed by the GPU, at ~40 GiB/s of fp32 input (PCIe bound).
+ *   PIQUANT_HIP_HOST_PATH_CPU (1): always libpiquant_cpu.so (include/piquant_cpu.h; loaded from the directory of this library on first
+ *       use, ABORT if it is missing; its scalar form on hosts without AVX-512).
+ * Only calls whose input AND output are pageable host memory go to the companion; device, pinned and managed pointers always run the HIP
+ * kernels, and so do reference-layout mode and the per-element stochastic extension, which the companion does not implement (staged).
+ * The environment variable PIQUANT_HIP_HOST_PATH = auto | stage | cpu sets it at context creation. */
 #define PIQUANT_HIP_HOST_PATH_STAGE 0
 #define PIQUANT_HIP_HOST_PATH_CPU 1
+#define PIQUANT_HIP_HOST_PATH_AUTO 2
 PIQUANT_EXPORT void piquant_hip_set_host_path(piquant_context_t* ctx, int path);
+/* STAGE or CPU: what pageable host buffers of this context get right now (AUTO resolved) */
+PIQUANT_EXPORT int piquant_hip_host_path_in_effect(piquant_context_t* ctx);
 
 /* Pointer classification.  By default every buffer is classified with hipPointerGetAttributes (device / pinned: used in
  * place; pageable host: staged over PCIe).  A binding that already knows its buffers are device memory (PyTorch device

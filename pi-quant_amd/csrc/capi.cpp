@@ -2,8 +2,9 @@
 // buffers, and the quantization-parameter epilogue -- piquant_quantize / piquant_dequantize / piquant_compute_quant_params_* and their
 // device-record and sharded twins of piquant_hip.h.  It replaces the reference's src/piquant.cpp:277-381 and src/capi.cpp:15-104.
 //
-// There is no CPU compute path in this library: every element is processed by a HIP kernel -- unless the caller asks, per context, for
-// pageable host buffers to be served by the companion libpiquant_cpu.so (piquant_hip_set_host_path); such calls are forwarded whole.
+// Every element that lives in device (or pinned / managed) memory is processed by a HIP kernel; there is no CPU arithmetic in this library.
+// Calls whose buffers are pageable HOST memory -- the reference's own calling convention -- are forwarded whole to the companion
+// libpiquant_cpu.so when it is present (piquant_hip_set_host_path: AUTO, the default), and staged over PCIe to the same HIP kernels otherwise.
 #include "context.hpp"
 
 using namespace pq;
@@ -95,12 +96,15 @@ static void quantize_impl(piquant_context_t* ctx, const void* in, piquant_dtype_
         q.in = rin.dev;
         q.out = rout.dev;
         q.numel = static_cast<int64_t>(numel);
-        launch_quantize(q, ctx->stream, ctx->num_cu);
+        {
+            StopEventScope completion(ctx);
+            launch_quantize(q, ctx->stream, ctx->num_cu);
+        }
         if (ctx->blocking) wait_stream(ctx);
         return;
     }
-    if (ctx->host_path == PIQUANT_HIP_HOST_PATH_CPU && rin.pageable && rout.pageable && !q.ref_layout && q.round_mode != RM_STOCH_ELEM) {
-        // the caller's opt-in: host tensors stay on the host (the threshold drawn above is the call's, as in the reference)
+    if (rin.pageable && rout.pageable && !q.ref_layout && q.round_mode != RM_STOCH_ELEM && host_calls_go_to_cpu(ctx)) {
+        // host tensors stay on the host, as in the reference (the default when the companion is there; the threshold drawn above is the call's)
         cpu_companion().quantize(cpu_context_of(ctx), in, dtype_in, out, dtype_out, numel, scale, zero_point, mode == PIQUANT_STOCHASTIC ? 1 : 0, q.threshold);
         return;
     }
@@ -178,11 +182,14 @@ static void dequantize_impl(piquant_context_t* ctx, const void* in, piquant_dtyp
         d.in = rin.dev;
         d.out = rout.dev;
         d.numel = static_cast<int64_t>(numel);
-        launch_dequantize(d, ctx->stream, ctx->num_cu);
+        {
+            StopEventScope completion(ctx);
+            launch_dequantize(d, ctx->stream, ctx->num_cu);
+        }
         if (ctx->blocking) wait_stream(ctx);
         return;
     }
-    if (ctx->host_path == PIQUANT_HIP_HOST_PATH_CPU && rin.pageable && rout.pageable && !d.ref_layout) {
+    if (rin.pageable && rout.pageable && !d.ref_layout && host_calls_go_to_cpu(ctx)) {
         cpu_companion().dequantize(cpu_context_of(ctx), in, dtype_in, out, dtype_out, numel, scale, zero_point, d.op == OP_ADD ? 1 : 0);
         return;
     }
@@ -347,8 +354,8 @@ static void compute_params(piquant_context_t* ctx, const void* x, piquant_dtype_
         std::lock_guard<std::mutex> lock(ctx->mu);
         DeviceGuard guard(ctx->device);
         bool have = false;
-        if (ctx->host_path == PIQUANT_HIP_HOST_PATH_CPU && !ctx->assume_device && resolve(x).pageable) {
-            // the caller's opt-in (piquant_hip_set_host_path): a host tensor is scanned where it lives; same epilogue below
+        if (!ctx->assume_device && resolve(x).pageable && host_calls_go_to_cpu(ctx)) {
+            // a host tensor is scanned where it lives (piquant_hip_set_host_path; the default when the companion is there); same epilogue below
             float lo_h, hi_h;
             cpu_companion().minmax(cpu_context_of(ctx), x, dt, n, &lo_h, &hi_h);
             keys[0] = float_to_key(lo_h);

@@ -5,20 +5,9 @@
 
 using namespace pq;
 
-extern "C" {
-
-void piquant_hip_dequantize_sum(piquant_context_t* ctx, const void* const* inputs, const piquant_hip_params_t* const* device_params, size_t count,
-                                piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out, size_t numel, piquant_reduce_op_t op) {
-    if (!ctx) panic("piquant_hip_dequantize_sum: context is NULL");
-    const dtype_row& dti = dtype_of(dtype_in);
-    const dtype_row& dto = dtype_of(dtype_out);
-    if (!dti.quant) panic("dequantize: input dtype (%s) must be a quantized type", dti.name);
-    if (dto.quant) panic("dequantize: output dtype (%s) must be a dequantized type", dto.name);
-    if (op != PIQUANT_REDUCE_OP_SET && op != PIQUANT_REDUCE_OP_ADD) panic("dequantize: invalid reduce op %d", static_cast<int>(op));
-    if (count == 0 || numel == 0) return;
-    if (!inputs || !device_params || !out) panic("dequantize_sum: NULL argument");
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    DeviceGuard guard(ctx->device);
+// out (op)= sum of the dequantized inputs, stream-ordered; caller holds ctx->mu and the device guard, and waits if the context is blocking
+static void dequantize_sum_locked(piquant_context_t* ctx, const void* const* inputs, const piquant_hip_params_t* const* device_params, size_t count,
+                                  piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out, size_t numel, piquant_reduce_op_t op) {
     const Resolved rout = ctx->resolve_ptr(out);
     if (rout.pageable) panic("piquant_hip_dequantize_sum needs device (or pinned) buffers");
     // more inputs than one launch takes: the first launch carries the caller's op, the following ones accumulate
@@ -39,6 +28,23 @@ void piquant_hip_dequantize_sum(piquant_context_t* ctx, const void* const* input
         d.op = (first == 0 && op == PIQUANT_REDUCE_OP_SET) ? OP_SET : OP_ADD;
         launch_dequantize_sum(d, ctx->stream, ctx->num_cu);
     }
+}
+
+extern "C" {
+
+void piquant_hip_dequantize_sum(piquant_context_t* ctx, const void* const* inputs, const piquant_hip_params_t* const* device_params, size_t count,
+                                piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out, size_t numel, piquant_reduce_op_t op) {
+    if (!ctx) panic("piquant_hip_dequantize_sum: context is NULL");
+    const dtype_row& dti = dtype_of(dtype_in);
+    const dtype_row& dto = dtype_of(dtype_out);
+    if (!dti.quant) panic("dequantize: input dtype (%s) must be a quantized type", dti.name);
+    if (dto.quant) panic("dequantize: output dtype (%s) must be a dequantized type", dto.name);
+    if (op != PIQUANT_REDUCE_OP_SET && op != PIQUANT_REDUCE_OP_ADD) panic("dequantize: invalid reduce op %d", static_cast<int>(op));
+    if (count == 0 || numel == 0) return;
+    if (!inputs || !device_params || !out) panic("dequantize_sum: NULL argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    dequantize_sum_locked(ctx, inputs, device_params, count, dtype_in, out, dtype_out, numel, op);
     if (ctx->blocking) wait_stream(ctx);
 }
 
@@ -274,59 +280,44 @@ void piquant_hip_reduce_quantize_dynamic(piquant_context_t* ctx, void* acc, piqu
         return;
     }
     if (!acc || !out || !inputs || !input_params) panic("piquant_hip_reduce_quantize_dynamic: NULL argument");
+    // ONE critical section for the whole call: the per-call stochastic threshold is drawn once and handed down in the launch descriptor to
+    // whichever path runs (a fused attempt that does not qualify and the two-step path behind it must quantize with the SAME draw, or the bytes
+    // -- and every later draw of a seeded context -- would depend on whether fusion was tried); no shared context state is touched for it.
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    const Resolved rp = resolve(device_params), racc = ctx->resolve_ptr(acc), rout = ctx->resolve_ptr(out);
+    if (rp.pageable || racc.pageable || rout.pageable) panic("piquant_hip_reduce_quantize_dynamic needs device (or pinned) buffers");
+    QuantLaunch q {};
+    q.dt_in = dtype_acc;
+    q.dt_out = dtype_out;
+    fill_round_mode(ctx, q, mode);
     bool fused = false;
-    bool drew = false;      // a per-call stochastic threshold was drawn for the fused attempt: the two-step path below must use the SAME one,
-    float drawn = 0.0f;     // or the bytes (and every later draw of a seeded context) would depend on whether fusion was tried
-    {
-        std::lock_guard<std::mutex> lock(ctx->mu);
-        DeviceGuard guard(ctx->device);
-        const Resolved rp = resolve(device_params), racc = ctx->resolve_ptr(acc), rout = ctx->resolve_ptr(out);
-        if (rp.pageable || racc.pageable || rout.pageable) panic("piquant_hip_reduce_quantize_dynamic needs device (or pinned) buffers");
-        if (ctx->fusion && !ctx->reference_layout && count <= static_cast<size_t>(kDequantSumMaxInputs)) {
-            QuantLaunch q {};
-            q.in = racc.dev;
-            q.out = rout.dev;
-            q.numel = static_cast<int64_t>(numel);
-            q.dt_in = dtype_acc;
-            q.dt_out = dtype_out;
-            fill_round_mode(ctx, q, mode);
-            if (q.round_mode == RM_STOCH_CALL) {
-                drew = true;
-                drawn = q.threshold;
-            }
-            DequantSumLaunch terms {};
-            terms.count = static_cast<int>(count);
-            terms.dt_in = dtype_out;
-            for (size_t i = 0; i < count; ++i) {
-                if (!inputs[i] || !input_params[i]) panic("piquant_hip_reduce_quantize_dynamic: NULL input %zu", i);
-                const Resolved ri = ctx->resolve_ptr(inputs[i]), rq = resolve(input_params[i]);
-                if (ri.pageable || rq.pageable) panic("piquant_hip_reduce_quantize_dynamic needs device (or pinned) buffers");
-                terms.in[i] = ri.dev;
-                terms.params[i] = rq.dev;
-            }
-            {
-                order_context_state(ctx);
-                FusedLaunchOrder order(ctx->device, ctx->stream);
-                q.barrier_timeout_us = ctx->barrier_timeout_us;
-                fused = launch_fused_reduce_quantize(q, terms, ctx->d_fused, rp.dev, ctx->stream, ctx->num_cu);
-            }
-            if (fused && ctx->blocking) wait_stream(ctx);
+    if (ctx->fusion && !ctx->reference_layout && count <= static_cast<size_t>(kDequantSumMaxInputs)) {
+        QuantLaunch f = q;
+        f.in = racc.dev;
+        f.out = rout.dev;
+        f.numel = static_cast<int64_t>(numel);
+        DequantSumLaunch terms {};
+        terms.count = static_cast<int>(count);
+        terms.dt_in = dtype_out;
+        for (size_t i = 0; i < count; ++i) {
+            if (!inputs[i] || !input_params[i]) panic("piquant_hip_reduce_quantize_dynamic: NULL input %zu", i);
+            const Resolved ri = ctx->resolve_ptr(inputs[i]), rq = resolve(input_params[i]);
+            if (ri.pageable || rq.pageable) panic("piquant_hip_reduce_quantize_dynamic needs device (or pinned) buffers");
+            terms.in[i] = ri.dev;
+            terms.params[i] = rq.dev;
         }
+        order_context_state(ctx);
+        FusedLaunchOrder order(ctx->device, ctx->stream);
+        f.barrier_timeout_us = ctx->barrier_timeout_us;
+        fused = launch_fused_reduce_quantize(f, terms, ctx->d_fused, rp.dev, ctx->stream, ctx->num_cu);
     }
-    if (fused) return;
-    // the same result in two steps (and with `acc` updated on the way): one-pass sum into acc, then parameters + quantize
-    float saved = -1.0f;
-    if (drew) {
-        std::lock_guard<std::mutex> lock(ctx->mu);
-        saved = ctx->fixed_threshold;
-        ctx->fixed_threshold = drawn;
+    if (!fused) {
+        // the same result in two steps (and with `acc` updated on the way): one-pass sum into acc, then parameters + quantize with q's round mode
+        dequantize_sum_locked(ctx, inputs, input_params, count, dtype_out, acc, dtype_acc, numel, PIQUANT_REDUCE_OP_ADD);
+        quantize_dynamic_one(ctx, q, racc.dev, rout.dev, out, numel, rp.dev);
     }
-    piquant_hip_dequantize_sum(ctx, inputs, input_params, count, dtype_out, acc, dtype_acc, numel, PIQUANT_REDUCE_OP_ADD);
-    piquant_hip_quantize_dynamic(ctx, acc, dtype_acc, out, dtype_out, numel, device_params, mode);
-    if (drew) {
-        std::lock_guard<std::mutex> lock(ctx->mu);
-        ctx->fixed_threshold = saved;
-    }
+    if (ctx->blocking) wait_stream(ctx);
 }
 
 }  // extern "C"

@@ -57,10 +57,31 @@ namespace {
 constexpr int kDefaultBlockingWait = 2;   // WAIT_KERNEL: 30.4 us per blocking fp32->uint8 call at numel 27 264 000 against 31.7 (WAIT_WRITE32) and 34.8 (WAIT_SYNC), profiles/r02_blocking_wait_ab.json
 }  // namespace
 
+StopEventScope::StopEventScope(piquant_context_t* ctx) {
+    tl_stop_event = nullptr;
+    tl_stop_attached = false;
+    if (!ctx->blocking || ctx->wait_mode != WAIT_EVENT) return;
+    if (!ctx->done_event && hipEventCreateWithFlags(&ctx->done_event, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->done_event = nullptr;
+        return;
+    }
+    tl_stop_event = ctx->done_event;
+}
+
 void wait_stream(piquant_context_t* ctx) {
     hipStream_t stream = ctx->stream;
     // a captured launch does not run until the graph is replayed: waiting for it here would never end
     if (stream_is_capturing(stream)) panic("a blocking call cannot be captured into a hipGraph: make the context stream-ordered first (piquant_hip_set_blocking(ctx, 0))");
+    if (ctx->wait_mode == WAIT_EVENT && tl_stop_attached && ctx->done_event) {
+        tl_stop_attached = false;
+        for (;;) {
+            const hipError_t q = hipEventQuery(ctx->done_event);
+            if (q == hipSuccess) return;
+            if (q != hipErrorNotReady) PQ_HIP(q);
+            __builtin_ia32_pause();
+        }
+    }
     if (ctx->wait_mode == WAIT_SYNC || !ctx->done_dev) {
         PQ_HIP(hipStreamSynchronize(stream));
         return;
@@ -175,31 +196,71 @@ void order_context_state(piquant_context_t* ctx) {
     ctx->capture_stream = s;
 }
 
-const CpuCompanion& cpu_companion() {
-    static const CpuCompanion c = [] {
+namespace {
+struct CompanionSlot {
+    CpuCompanion c {};
+    bool ok = false;
+    std::string path, error;
+};
+
+const CompanionSlot& companion_slot() {
+    static const CompanionSlot slot = [] {
+        CompanionSlot r;
         Dl_info info {};
-        std::string path = "libpiquant_cpu.so";
+        r.path = "libpiquant_cpu.so";
         if (dladdr(reinterpret_cast<const void*>(&piquant_hip_set_host_path), &info) && info.dli_fname) {
             const std::string self(info.dli_fname);
             const size_t slash = self.rfind('/');
-            if (slash != std::string::npos) path = self.substr(0, slash + 1) + path;
+            if (slash != std::string::npos) r.path = self.substr(0, slash + 1) + r.path;
         }
-        void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
-        if (!h) panic("host path 'cpu' needs %s next to libpiquant.so: %s", path.c_str(), dlerror());
-        CpuCompanion r {};
+        void* h = dlopen(r.path.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!h) {
+            const char* why = dlerror();
+            r.error = why ? why : "dlopen failed";
+            return r;
+        }
+        bool complete = true;
         auto sym = [&](const char* name) {
             void* p = dlsym(h, name);
-            if (!p) panic("%s lacks %s", path.c_str(), name);
+            if (!p) {
+                complete = false;
+                r.error = std::string("missing symbol ") + name;
+            }
             return p;
         };
-        r.context_create = reinterpret_cast<decltype(r.context_create)>(sym("piquant_cpu_context_create"));
-        r.context_destroy = reinterpret_cast<decltype(r.context_destroy)>(sym("piquant_cpu_context_destroy"));
-        r.quantize = reinterpret_cast<decltype(r.quantize)>(sym("piquant_cpu_quantize"));
-        r.dequantize = reinterpret_cast<decltype(r.dequantize)>(sym("piquant_cpu_dequantize"));
-        r.minmax = reinterpret_cast<decltype(r.minmax)>(sym("piquant_cpu_minmax"));
+        r.c.context_create = reinterpret_cast<decltype(r.c.context_create)>(sym("piquant_cpu_context_create"));
+        r.c.context_destroy = reinterpret_cast<decltype(r.c.context_destroy)>(sym("piquant_cpu_context_destroy"));
+        r.c.quantize = reinterpret_cast<decltype(r.c.quantize)>(sym("piquant_cpu_quantize"));
+        r.c.dequantize = reinterpret_cast<decltype(r.c.dequantize)>(sym("piquant_cpu_dequantize"));
+        r.c.minmax = reinterpret_cast<decltype(r.c.minmax)>(sym("piquant_cpu_minmax"));
+        r.c.has_avx512 = reinterpret_cast<decltype(r.c.has_avx512)>(sym("piquant_cpu_has_avx512"));
+        r.ok = complete;
         return r;
     }();
-    return c;
+    return slot;
+}
+}  // namespace
+
+const CpuCompanion* try_cpu_companion() {
+    const CompanionSlot& s = companion_slot();
+    return s.ok ? &s.c : nullptr;
+}
+
+const CpuCompanion& cpu_companion() {
+    const CompanionSlot& s = companion_slot();
+    if (!s.ok) panic("host path 'cpu' needs %s next to libpiquant.so: %s", s.path.c_str(), s.error.c_str());
+    return s.c;
+}
+
+// AUTO: the companion when it is there and vectorised (its scalar form on a host without AVX-512 loses to PCIe staging), else staging.
+bool host_calls_go_to_cpu(piquant_context_t* ctx) {
+    if (ctx->host_path == PIQUANT_HIP_HOST_PATH_CPU) return true;
+    if (ctx->host_path == PIQUANT_HIP_HOST_PATH_STAGE) return false;
+    if (ctx->host_path_resolved < 0) {
+        const CpuCompanion* c = try_cpu_companion();
+        ctx->host_path_resolved = (c && c->has_avx512() != 0) ? PIQUANT_HIP_HOST_PATH_CPU : PIQUANT_HIP_HOST_PATH_STAGE;
+    }
+    return ctx->host_path_resolved == PIQUANT_HIP_HOST_PATH_CPU;
 }
 
 void* cpu_context_of(piquant_context_t* ctx) {
@@ -240,6 +301,9 @@ static void leave_stream(piquant_context_t* ctx, hipStream_t next) {
     hipStream_t old = ctx->stream;
     if (old == next) return;
     DeviceGuard guard(ctx->device);
+    // the capturing stream that last used the scan / barrier state (order_context_state): the owner may end that capture and destroy the
+    // stream once it is replaced here; a later capture must not query or record on the stale (or recycled) handle
+    if (ctx->capture_stream == old) ctx->capture_stream = nullptr;
     if (ctx->scan_stream && ctx->scan_stream != next) {
         // no host wait here (a caller who scans on one stream and quantizes on another must not be stalled by switching): an event behind the
         // scan, which the next scan -- the only thing that shares the state buffer -- makes its stream wait for
@@ -291,13 +355,14 @@ piquant_context_t* piquant_context_create(size_t num_threads) {
     ctx->wait_mode = kDefaultBlockingWait;
     if (const char* env = std::getenv("PIQUANT_HIP_BLOCKING_WAIT")) {
         const std::string m(env);
-        ctx->wait_mode = m == "write32" ? WAIT_WRITE32 : (m == "kernel" ? WAIT_KERNEL : WAIT_SYNC);
+        ctx->wait_mode = m == "write32" ? WAIT_WRITE32 : (m == "kernel" ? WAIT_KERNEL : (m == "event" ? WAIT_EVENT : WAIT_SYNC));
     }
     PQ_HIP(hipDeviceSynchronize());   // the arming memsets ran on the null stream; scans may run on any stream
     if (const char* env = std::getenv("PIQUANT_HIP_HOST_PATH")) {
         const std::string m(env);
         if (m == "cpu") ctx->host_path = PIQUANT_HIP_HOST_PATH_CPU;
-        else if (m != "stage" && !m.empty()) panic("PIQUANT_HIP_HOST_PATH=%s: expected stage or cpu", env);
+        else if (m == "stage") ctx->host_path = PIQUANT_HIP_HOST_PATH_STAGE;
+        else if (m != "auto" && !m.empty()) panic("PIQUANT_HIP_HOST_PATH=%s: expected auto, stage or cpu", env);
     }
     if (const char* env = std::getenv("PIQUANT_HIP_FUSION")) ctx->fusion = !(env[0] == '0' && env[1] == '\0');
     if (const char* env = std::getenv("PIQUANT_HIP_BARRIER_TIMEOUT_US")) ctx->barrier_timeout_us = static_cast<uint32_t>(std::strtoul(env, nullptr, 10));
@@ -330,6 +395,7 @@ void piquant_context_destroy(piquant_context_t* ctx) {
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     }
     if (ctx->capture_edge) (void)hipEventDestroy(ctx->capture_edge);
+    if (ctx->done_event) (void)hipEventDestroy(ctx->done_event);
     if (ctx->scan_left) (void)hipEventDestroy(ctx->scan_left);
     if (ctx->cpu_ctx) pq::cpu_companion().context_destroy(ctx->cpu_ctx);
     delete ctx;
@@ -337,10 +403,18 @@ void piquant_context_destroy(piquant_context_t* ctx) {
 
 void piquant_hip_set_host_path(piquant_context_t* ctx, int path) {
     if (!ctx) panic("piquant_hip_set_host_path: context is NULL");
-    if (path != PIQUANT_HIP_HOST_PATH_STAGE && path != PIQUANT_HIP_HOST_PATH_CPU) panic("piquant_hip_set_host_path: invalid path %d", path);
+    if (path != PIQUANT_HIP_HOST_PATH_STAGE && path != PIQUANT_HIP_HOST_PATH_CPU && path != PIQUANT_HIP_HOST_PATH_AUTO)
+        panic("piquant_hip_set_host_path: invalid path %d", path);
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (path == PIQUANT_HIP_HOST_PATH_CPU) (void)pq::cpu_companion();   // fail now, not at the first host call
     ctx->host_path = path;
+    ctx->host_path_resolved = -1;
+}
+
+int piquant_hip_host_path_in_effect(piquant_context_t* ctx) {
+    if (!ctx) panic("piquant_hip_host_path_in_effect: context is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    return pq::host_calls_go_to_cpu(ctx) ? PIQUANT_HIP_HOST_PATH_CPU : PIQUANT_HIP_HOST_PATH_STAGE;
 }
 
 void piquant_hip_set_fusion(piquant_context_t* ctx, int enabled) {
@@ -391,7 +465,7 @@ void piquant_hip_set_blocking(piquant_context_t* ctx, int blocking) {
 
 void piquant_hip_set_blocking_wait(piquant_context_t* ctx, int mode) {
     if (!ctx) panic("piquant_hip_set_blocking_wait: context is NULL");
-    if (mode < WAIT_SYNC || mode > WAIT_KERNEL) panic("piquant_hip_set_blocking_wait: invalid mode %d", mode);
+    if (mode < WAIT_SYNC || mode > WAIT_EVENT) panic("piquant_hip_set_blocking_wait: invalid mode %d", mode);
     std::lock_guard<std::mutex> lock(ctx->mu);
     ctx->wait_mode = mode;
 }

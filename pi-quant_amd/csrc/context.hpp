@@ -8,6 +8,7 @@
 #include "device_math.hpp"
 #include "dequant_kernels.hpp"   // OP_* enum only (host side)
 #include "launch.hpp"
+#include "stop_event.hpp"
 
 #include <hip/hip_runtime_api.h>
 
@@ -87,13 +88,15 @@ struct piquant_context_t {
     uint32_t* done = nullptr;              // pinned, host-coherent completion word of blocking calls ...
     void* done_dev = nullptr;              // ... and its device-visible address
     uint32_t done_seq = 0;
+    hipEvent_t done_event = nullptr;       // WAIT_EVENT: stop event of the call's work kernel (created on first use)
 
     // device scratch for host-pointer calls, grown on demand
     void* stage_in[2] = {nullptr, nullptr};
     void* stage_out[2] = {nullptr, nullptr};
     size_t stage_in_cap = 0, stage_out_cap = 0;
 
-    int host_path = PIQUANT_HIP_HOST_PATH_STAGE;   // piquant_hip_set_host_path: who serves pageable host buffers
+    int host_path = PIQUANT_HIP_HOST_PATH_AUTO;    // piquant_hip_set_host_path: who serves pageable host buffers
+    int host_path_resolved = -1;           // AUTO resolved to STAGE or CPU on first use (-1 = not yet)
     void* cpu_ctx = nullptr;               // piquant_cpu_context_t of the companion library, created on first use
 
     std::mt19937_64 rng;
@@ -139,10 +142,20 @@ constexpr size_t kStageChunkElems = size_t{1} << 24;
 //   WAIT_KERNEL   the same word written by a one-thread kernel launched behind the work (system-scope store).
 // Measured A/B at numel 27 264 000 (fp32 -> uint8, 21.9 us kernel): profiles/r02_blocking_wait_ab.json.  (Polling hipStreamQuery or
 // busy-polling an event recorded after the kernel were measured in round 1: 36.7 / 34.9 vs 34.4 us for hipStreamSynchronize.)
-enum : int { WAIT_SYNC = 0, WAIT_WRITE32 = 1, WAIT_KERNEL = 2 };
+//   WAIT_EVENT    the work kernel itself is launched with a stop event (hipExtLaunchKernelGGL): its dispatch packet's completion signal
+//                 is polled with hipEventQuery -- nothing is enqueued behind the kernel at all (stop_event.hpp).  Calls whose launcher
+//                 does not attach the event (fused / batched / scan launches) wait as WAIT_KERNEL does.
+enum : int { WAIT_SYNC = 0, WAIT_WRITE32 = 1, WAIT_KERNEL = 2, WAIT_EVENT = 3 };
 
 bool stream_is_capturing(hipStream_t s);
 void wait_stream(piquant_context_t* ctx);   // completion wait of a blocking call; caller holds ctx->mu
+
+// Arms the context's completion event as the stop event of the launch the caller is about to make when the context is blocking in
+// WAIT_EVENT mode (and disarms it at scope exit); wait_stream() then polls that event if the launcher attached it.
+struct StopEventScope {
+    explicit StopEventScope(piquant_context_t* ctx);
+    ~StopEventScope() { tl_stop_event = nullptr; }
+};
 
 struct FusedOrder;
 
@@ -174,16 +187,20 @@ void order_context_state(piquant_context_t* ctx);
 // A stream the caller is about to stop using (piquant_hip_set_stream / reset_stream): nothing may keep its handle.
 void detach_fused_stream(int device, hipStream_t stream);
 
-// Entry points of libpiquant_cpu.so (include/piquant_cpu.h), resolved on first use from the directory this library was loaded from; aborts
-// when the companion is missing -- a context asked for the CPU host path must not quietly get something else.
+// Entry points of libpiquant_cpu.so (include/piquant_cpu.h), resolved on first use from the directory this library was loaded from.
+// cpu_companion() aborts when the companion is missing -- a context explicitly asked for the CPU host path must not quietly get something else;
+// the AUTO default asks with try_cpu_companion() and stages when there is none.
 struct CpuCompanion {
     void* (*context_create)(size_t);
     void (*context_destroy)(void*);
     void (*quantize)(void*, const void*, int, void*, int, size_t, float, int64_t, int, float);
     void (*dequantize)(void*, const void*, int, void*, int, size_t, float, int64_t, int);
     void (*minmax)(void*, const void*, int, size_t, float*, float*);
+    int (*has_avx512)();
 };
 const CpuCompanion& cpu_companion();
+const CpuCompanion* try_cpu_companion();        // nullptr when libpiquant_cpu.so does not load (AUTO then stages); never aborts
+bool host_calls_go_to_cpu(piquant_context_t* ctx);   // the context's host path with AUTO resolved; caller holds ctx->mu
 void* cpu_context_of(piquant_context_t* ctx);   // the context's companion context (created on first use); caller holds ctx->mu
 
 // round-mode fields of a launch: NEAREST, one threshold per call (src/piquant.cpp:197-201) or the per-element extension

@@ -61,7 +61,7 @@ PQ_AVX512 void quantize_avx512(const void* in, uint8_t* out, size_t e0, size_t e
         partial(n);
         left -= n;
     }
-    const bool stream = (e1 - i) / PACK >= (size_t {1} << 18);   // large outputs bypass the caches (as the reference's do, :78-81)
+    const bool stream = a.stream;   // large outputs bypass the caches (as the reference's do, :78-81): the call's decision, the same for all its chunks
     for (; i + 16 * PACK <= e1; i += 16 * PACK) {               // 16 output bytes per iteration
         __m128i v;
         if (BITS == 8) v = chunk(i, 0xffff);
@@ -113,7 +113,7 @@ PQ_AVX512 void dequantize_avx512(const uint8_t* in, void* out, size_t e0, size_t
     const __m512i zp = _mm512_set1_epi32(a.zp32);
     float* of = static_cast<float*>(out);
     uint16_t* ob = static_cast<uint16_t*>(out);
-    const bool stream = !ADD && (e1 - e0) * (DT_OUT == DT_F32 ? 4 : 2) >= (size_t {1} << 20);
+    const bool stream = !ADD && a.stream;
     auto chunk = [&](size_t i, __mmask16 m, bool nt) {
         const __m512i q = unpack16<BITS>(in, i, m);
         __m512 f;

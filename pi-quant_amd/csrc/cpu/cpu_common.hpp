@@ -23,6 +23,7 @@ struct QuantArgs {
     int32_t zp32;      // zero point narrowed the way the reference's fast paths narrow it (quantize.inl:111)
     int64_t zp64;
     float threshold;
+    bool stream;       // non-temporal stores: decided ONCE per call from the whole call's output size (piquant_cpu.cpp), not per 64 Ki-element chunk
 };
 
 enum : int { STEP_FAST = 0, STEP_I64 = 1, STEP_STOCH = 2 };
@@ -32,6 +33,7 @@ struct DequantArgs {
     float bias;        // -(float)zp32 * scale (kernels_specialized.inl:1204, 1325)
     int32_t zp32;
     int64_t zp64;
+    bool stream;       // as in QuantArgs (SET only: ADD reads the lines it writes)
 };
 
 enum : int { DQ_SUBMUL = 0, DQ_FMA = 1, DQ_I64 = 2 };

@@ -192,6 +192,18 @@ struct alignas(64) Share {
     std::atomic<size_t> next {0};
     size_t end = 0;
 };
+// Non-temporal stores for a call whose OUTPUT is at least this large (the reference streams every output past the caches,
+// kernels_specialized.inl:78-81; below the last-level cache's reach a consumer that reads the result next wants it cached).
+// PIQUANT_CPU_NT_STORES = 0 / 1 forces them off / on for any size (A/B: tools/diag_cpu_nt_stores.py).
+constexpr size_t kStreamOutputBytes = size_t {4} << 20;
+inline bool streaming_stores(size_t output_bytes) {
+    static const int forced = [] {
+        const char* e = std::getenv("PIQUANT_CPU_NT_STORES");
+        return e == nullptr || *e == '\0' ? -1 : (*e == '0' ? 0 : 1);
+    }();
+    return forced >= 0 ? forced != 0 : output_bytes >= kStreamOutputBytes;
+}
+
 constexpr size_t kChunkElems = 65536;   // 256 KiB of fp32; a multiple of every pack size
 
 struct piquant_cpu_context_t {
@@ -298,6 +310,7 @@ void piquant_cpu_quantize(piquant_cpu_context_t* ctx, const void* in, int dtype_
     a.zp32 = static_cast<int32_t>(static_cast<uint32_t>(static_cast<uint64_t>(zero_point)));
     a.threshold = threshold;
     const size_t pack = 8 / bits_of(dtype_out);
+    a.stream = streaming_stores(numel / pack);
     std::lock_guard<std::mutex> lk(ctx->call);
     parallel_chunks(ctx, numel, pack, [&](size_t b, size_t e, size_t) { fn(in, static_cast<uint8_t*>(out), b, e, a); });
 }
@@ -313,6 +326,7 @@ void piquant_cpu_dequantize(piquant_cpu_context_t* ctx, const void* in, int dtyp
     a.zp32 = static_cast<int32_t>(static_cast<uint32_t>(static_cast<uint64_t>(zero_point)));
     a.bias = -static_cast<float>(a.zp32) * scale;
     const size_t pack = 8 / bits_of(dtype_in);
+    a.stream = reduce_op == 0 && streaming_stores(numel * (dtype_out == DT_F32 ? 4 : 2));
     std::lock_guard<std::mutex> lk(ctx->call);
     parallel_chunks(ctx, numel, pack, [&](size_t b, size_t e, size_t) { fn(static_cast<const uint8_t*>(in), out, b, e, a); });
 }

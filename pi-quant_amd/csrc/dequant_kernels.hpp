@@ -246,13 +246,13 @@ template <int BITS, int DT_OUT, int OP, int U, bool STAGE, int NT, int BLOCK, bo
 inline void launch_dequantize_kernel(unsigned grid, hipStream_t stream, const uint8_t* in, void* out, int64_t numel, int64_t n_tiles, const DequantParams& p, int head) {
     if constexpr (BITS < 8 && !COPY_ONLY) {
         if ((head >> 16) != 0) {   // the body starts inside a packed byte
-            hipLaunchKernelGGL((dequantize_kernel<BITS, DT_OUT, OP, U, STAGE, NT, BLOCK, false, true>), dim3(grid), dim3(BLOCK), 0, stream, in, out, numel, n_tiles, p.scale,
-                               head, p.dyn, p.zp32, grid, p);
+            PQ_LAUNCH((dequantize_kernel<BITS, DT_OUT, OP, U, STAGE, NT, BLOCK, false, true>), dim3(grid), dim3(BLOCK), 0, stream, in, out, numel, n_tiles, p.scale,
+                      head, p.dyn, p.zp32, grid, p);
             return;
         }
     }
-    hipLaunchKernelGGL((dequantize_kernel<BITS, DT_OUT, OP, U, STAGE, NT, BLOCK, COPY_ONLY>), dim3(grid), dim3(BLOCK), 0, stream, in, out, numel, n_tiles, p.scale, head,
-                       p.dyn, p.zp32, grid, p);
+    PQ_LAUNCH((dequantize_kernel<BITS, DT_OUT, OP, U, STAGE, NT, BLOCK, COPY_ONLY>), dim3(grid), dim3(BLOCK), 0, stream, in, out, numel, n_tiles, p.scale, head,
+              p.dyn, p.zp32, grid, p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

@@ -51,7 +51,7 @@ void quantize_t(const QuantLaunch& q, const QuantParams& p, hipStream_t stream, 
     if (reinterpret_cast<uintptr_t>(q.in) % ESIZE != 0 || head >= q.numel || (q.ref_layout && (q.ref_head != 0 || q.ref_threads > 1 || head != 0))) {
         const int64_t nbytes = (q.numel + PACK - 1) / PACK;
         const unsigned grid = capped_grid((nbytes + kScalarBlock - 1) / kScalarBlock, 16, num_cu);
-        hipLaunchKernelGGL((quantize_scalar_kernel<DT_IN, BITS, MODE>), dim3(grid), dim3(kScalarBlock), 0, stream, q.in, out, q.numel, p);
+        PQ_LAUNCH((quantize_scalar_kernel<DT_IN, BITS, MODE>), dim3(grid), dim3(kScalarBlock), 0, stream, q.in, out, q.numel, p);
         return;
     }
     QuantParams body = p;
@@ -106,7 +106,7 @@ void dequantize_t(const DequantLaunch& d, const DequantParams& p, hipStream_t st
     // lie inside the tensor (partitions of a T-thread context) or the tiles would not start at element 0
     if (oa % ESIZE != 0 || head >= d.numel || (d.ref_layout && (d.ref_threads > 1 || head != 0))) {
         const unsigned grid = capped_grid((d.numel + kScalarBlock - 1) / kScalarBlock, 16, num_cu);
-        hipLaunchKernelGGL((dequantize_scalar_kernel<BITS, DT_OUT, OP>), dim3(grid), dim3(kScalarBlock), 0, stream, in, d.out, d.numel, p);
+        PQ_LAUNCH((dequantize_scalar_kernel<BITS, DT_OUT, OP>), dim3(grid), dim3(kScalarBlock), 0, stream, in, d.out, d.numel, p);
         return;
     }
     DequantParams body = p;

@@ -18,6 +18,7 @@
 #pragma once
 
 #include "device_math.hpp"
+#include "stop_event.hpp"
 
 namespace pq {
 
@@ -505,12 +506,19 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
         if (DT_IN == DT_BF16 && (reinterpret_cast<uintptr_t>(in) & 2u) != 0) {
             // A bf16 tensor that starts on an odd element (x[1:]): 16-byte loads that are not even dword-aligned are split by the memory
             // pipeline (measured: 16.9 us instead of 12.6 for bf16 -> uint4 at numel 27 264 000).  Kernel-uniform detour: load the vector
-            // from 2 bytes earlier (dword-aligned; the two bytes belong to the same allocation -- no allocation starts at 2 mod 4) plus
-            // the dword that holds its last element, and shift the five dwords into place (4 x v_alignbit_b32).
+            // from 2 bytes earlier (dword-aligned) plus the dword that holds its last element, and shift the five dwords into place
+            // (4 x v_alignbit_b32).  The two vectors whose detour would touch bytes outside the tensor -- the first one when nothing was peeled
+            // in front of the body (2 bytes before element 0), the one that ends exactly at the tensor's end (2 bytes behind it) -- take the
+            // ordinary misaligned load instead: same page or not, sub-allocated or registered host memory, nothing outside [in, in + numel) is read.
             const uint8_t* base = static_cast<const uint8_t*>(in) - 2;
 #pragma unroll
             for (int k = 0; k < U; ++k) {
-                const uint8_t* a = base + (v0 + k * 64 + lane) * 16;
+                const int64_t vec = v0 + k * 64 + lane;
+                if ((vec == 0 && head == 0) || (vec + 1) * EPV >= numel) {
+                    raw[k] = ld<NT_LD>(in16 + vec);
+                    continue;
+                }
+                const uint8_t* a = base + vec * 16;
                 const u32x4 t = ld<NT_LD>(reinterpret_cast<const u32x4*>(a));
                 const uint32_t n = ld<NT_LD>(reinterpret_cast<const uint32_t*>(a + 16));
                 raw[k] = u32x4 {__builtin_amdgcn_alignbit(t[1], t[0], 16), __builtin_amdgcn_alignbit(t[2], t[1], 16), __builtin_amdgcn_alignbit(t[3], t[2], 16),
@@ -645,8 +653,8 @@ template <int DT_IN, int BITS, int MODE, int U, bool STAGE, int NT, int BLOCK, b
 inline void launch_quantize_kernel(unsigned grid, unsigned dyn_lds, hipStream_t stream, const void* in, uint8_t* out, int64_t numel, int64_t n_tiles, const QuantParams& p,
                                    int head) {
     const uint32_t flags = (p.zp64 >= 0 && p.zp64 <= (1 << BITS) - 1 ? 1u : 0u) | (static_cast<uint32_t>(head) << 16);   // head < 128 * 4 elements
-    hipLaunchKernelGGL((quantize_kernel<DT_IN, BITS, MODE, U, STAGE, NT, BLOCK, ALLOW_SHORT, VAR>), dim3(grid), dim3(BLOCK), dyn_lds, stream, in, out, numel, n_tiles,
-                       p.inv_scale, p.zp32, p.dyn, flags, grid, p);
+    PQ_LAUNCH((quantize_kernel<DT_IN, BITS, MODE, U, STAGE, NT, BLOCK, ALLOW_SHORT, VAR>), dim3(grid), dim3(BLOCK), dyn_lds, stream, in, out, numel, n_tiles,
+              p.inv_scale, p.zp32, p.dyn, flags, grid, p);
 }
 
 }  // namespace pq

@@ -196,9 +196,10 @@ class Context:
 
     def set_blocking_wait(self, mode: str) -> None:
         """How a blocking call waits for the GPU: 'sync' (hipStreamSynchronize), 'write32' (the command processor writes a pinned host
-        word behind the kernel, the host spins on it) or 'kernel' (a one-thread kernel writes it); include/piquant_hip.h."""
+        word behind the kernel, the host spins on it), 'kernel' (a one-thread kernel writes it) or 'event' (the work kernel carries a stop
+        event -- its own completion signal -- and the host polls hipEventQuery); include/piquant_hip.h."""
         self._record_policy('set_blocking_wait', mode)
-        C.piquant_hip_set_blocking_wait(self._ctx, {'sync': 0, 'write32': 1, 'kernel': 2}[mode])
+        C.piquant_hip_set_blocking_wait(self._ctx, {'sync': 0, 'write32': 1, 'kernel': 2, 'event': 3}[mode])
 
     def assume_device_pointers(self, assume: bool) -> None:
         """Skip the native pointer classification for the calls that follow (all buffers are device or pinned memory).
@@ -305,11 +306,16 @@ class Context:
         C.piquant_hip_dequantize_sum(self._ctx, arr_in, arr_p, n, dtype_in.value, ptr_out, dtype_out.value, numel, reduce_op.value)
 
     def set_host_path(self, path: str) -> None:
-        """Who serves calls on pageable HOST buffers: 'stage' (default: PCIe staging through the HIP kernels) or 'cpu' (the companion
-        libpiquant_cpu.so: the same arithmetic in AVX-512 on the host cores).  Device and pinned buffers always run the HIP kernels
-        (include/piquant_hip.h)."""
+        """Who serves calls on pageable HOST buffers: 'auto' (default: the companion libpiquant_cpu.so -- the same arithmetic in AVX-512 on the
+        host cores, as the reference does with host tensors -- when it is present and the host has AVX-512, PCIe staging otherwise), 'stage'
+        (always PCIe staging through the HIP kernels) or 'cpu' (always the companion; abort if it is missing).  Device and pinned buffers
+        always run the HIP kernels (include/piquant_hip.h)."""
         self._record_policy('set_host_path', path)
-        C.piquant_hip_set_host_path(self._ctx, {'stage': 0, 'cpu': 1}[path])
+        C.piquant_hip_set_host_path(self._ctx, {'stage': 0, 'cpu': 1, 'auto': 2}[path])
+
+    def host_path_in_effect(self) -> str:
+        """'stage' or 'cpu': what a call on pageable host buffers gets from this context right now ('auto' resolved)."""
+        return ('stage', 'cpu')[C.piquant_hip_host_path_in_effect(self._ctx)]
 
     def set_fusion(self, enabled: bool) -> None:
         """False: ``quantize_dynamic`` always runs the scan (with its parameter epilogue) and the quantize kernel as two launches (for A/B timing)."""

@@ -41,6 +41,7 @@ _DECLS = [
     ('piquant_hip_quantize_dynamic', None, [_vp, _vp, _int, _vp, _int, _sz, _vp, _int]),
     ('piquant_hip_set_fusion', None, [_vp, _int]),
     ('piquant_hip_set_host_path', None, [_vp, _int]),
+    ('piquant_hip_host_path_in_effect', _int, [_vp]),
     ('piquant_hip_set_barrier_timeout_us', None, [_vp, C.c_uint32]),
     ('piquant_hip_barrier_bailouts', C.c_uint64, [_vp]),
     ('piquant_hip_quantize_dynamic_batch', None, [_vp, C.POINTER(C.c_void_p), _int, C.POINTER(C.c_void_p), _int, C.POINTER(_sz), C.POINTER(C.c_void_p), _sz, _int]),

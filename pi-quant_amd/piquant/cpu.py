@@ -1,8 +1,8 @@
 """ctypes binding of libpiquant_cpu.so (include/piquant_cpu.h): the host-memory companion of the MI355X library.
 
-The same arithmetic as the HIP kernels on AVX-512 host cores, for buffers that live in host memory.  Not a fallback: `piquant.Context` never
-uses it unless told to (`Context.set_host_path("cpu")`), and device tensors always run the HIP kernels.  bench.py times it as the reproducible
-CPU baseline.
+The same arithmetic as the HIP kernels on AVX-512 host cores, for buffers that live in host memory -- where `piquant.Context` sends calls on
+pageable host buffers by default (`Context.set_host_path`: 'auto'); device tensors always run the HIP kernels, and a missing HIP extension is
+never papered over by this library.  bench.py times it as the reproducible CPU baseline.
 """
 import ctypes as C
 from pathlib import Path

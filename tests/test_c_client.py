@@ -46,12 +46,18 @@ def _fnv1a(b: bytes) -> int:
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("host_path", ["stage", "auto"])
 @pytest.mark.parametrize("client", ["c99", "cpp20"])
-def test_c_client_results_match_oracle(tmp_path, oracle_mod, client):
+def test_c_client_results_match_oracle(tmp_path, oracle_mod, client, host_path):
+    """An unchanged caller of the reference (host buffers, blocking calls): staged through the HIP kernels over PCIe (`stage`) and by the
+    library's default (`auto`: the companion libpiquant_cpu.so serves host tensors where they live) -- the same bytes both ways."""
+    import os
+
     O = oracle_mod
     n = 100_003
     exe = _build(tmp_path) if client == "c99" else _build_cpp(tmp_path)
-    out = subprocess.run([str(exe), str(n)], check=True, capture_output=True, text=True, timeout=300).stdout.split()
+    out = subprocess.run([str(exe), str(n)], check=True, capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, PIQUANT_HIP_HOST_PATH=host_path)).stdout.split()
     s = np.uint32(12345)
     x = np.empty(n, dtype=np.float32)
     with np.errstate(over="ignore"):

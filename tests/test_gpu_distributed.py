@@ -307,7 +307,8 @@ def test_bench_eight_ranks_sharing_the_gpu():
         port = s.getsockname()[1]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), str(root / "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5", "--backend", "gloo",
-                        "--share-gpu"], capture_output=True, text=True, timeout=1500, cwd=str(root))
+                        "--share-gpu"], capture_output=True, text=True, timeout=1500, cwd=str(root),
+                       env=dict(os.environ, PIQUANT_BENCH_EXTRAS_LIMIT_S="1200"))   # eight ranks on ONE GPU, collectives staged through the host: slow, and not the point
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -319,6 +320,10 @@ def test_bench_eight_ranks_sharing_the_gpu():
     assert c5["result_correct"] and c5["numel_per_gpu"] == 1 << 27 and c5["numel_total"] == 1 << 30 and "gloo (8 ranks)" in c5["note"]
     weak = d["extras"]["weak_scaling_own_tensor_per_gpu"]
     assert weak["scaling"] == "weak" and weak["numel_per_gpu"] == 27_264_000 and weak["GiB/s"] > 0
+    assert d["shard_bit_exact"] == [True] * 8 and d["ranks_seen"]["world_size"] == 8 and d["ranks_seen"]["launcher"] == "external"
+    assert d["n1_reference"]["bit_exact"] is True
+    ar = d["extras"]["all_reduce_109MB"]
+    assert ar["quantized_all_reduce_direct_u8"]["within_bound"] and ar["quantized_all_reduce_ring_u8"]["within_bound"]
 
 
 def test_bench_refuses_more_ranks_than_devices():
@@ -385,32 +390,63 @@ def test_quantize_shard_concatenation_is_the_whole_call(oracle_mod, world, qname
 # parameters right.
 # ---------------------------------------------------------------------------------------------------------------
 def test_bench_two_ranks_sharing_the_gpu():
+    """`python bench.py --gpus 2` with NO launcher around it (the shape of the driver's N = 1 command with another N): bench.py starts its own two
+    ranks, one JSON line comes out, and the line validates itself -- ranks seen by the process group, every rank's shard bit-exact against the
+    checker, the N = 1 point of the same run, both all-reduce schedules and the 8-byte MIN all-reduce in the extras."""
     import json
+    import os
     import subprocess
     import sys
     from pathlib import Path
 
     root = Path(__file__).resolve().parent.parent
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), str(root / "bench.py"), "--gpus", "2", "--steps", "50", "--warmup", "5", "--backend", "gloo",
-                        "--share-gpu"], capture_output=True, text=True, timeout=600, cwd=str(root))
-    assert r.returncode == 0, r.stderr[-2000:]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "20", "--warmup", "5"],
+                       capture_output=True, text=True, timeout=900, cwd=str(root), env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     # the headline is the north-star workload: ONE 27 264 000-element tensor split over the ranks (reference src/piquant.cpp:145-157)
-    assert d["n_gpus"] == 2 and d["steps"] == 50 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["numel_total"] == 27_264_000 and d["config"]["numel_per_gpu"] == 13_632_000
     assert d["roofline"]["algorithmic_bytes_per_launch"] == 5 * 13_632_000
     # value counts the whole tensor once per step, not once per rank
-    assert abs(d["value"] - 27_264_000 * 4 / 2**30 * 50 / (d["ms_per_step"] * 50e-3)) / d["value"] < 1e-3
+    assert abs(d["value"] - 27_264_000 * 4 / 2**30 * 20 / (d["ms_per_step"] * 20e-3)) / d["value"] < 1e-3
+    # self-validation
+    assert d["shard_bit_exact"] == [True, True] and d["self_check"]["all_bit_exact"] is True
+    assert d["self_check"]["shards"] == [[0, 13_632_000], [13_632_000, 27_264_000]]
+    seen = d["ranks_seen"]
+    assert seen["world_size"] == 2 and seen["backend"] == "gloo" and len(seen["devices"]) == 2 and seen["distinct_devices"] == 1   # --share-gpu
+    assert "own" in seen["launcher"]
+    n1 = d["n1_reference"]
+    assert n1["GiB/s"] > 0 and n1["bit_exact"] is True and 0 < n1["roofline_frac"] < 1
     c5 = d["extras"]["config5_sharded_compute_quant_params"]
     assert c5["result_correct"] and c5["numel_per_gpu"] == (1 << 30) // 2 and "gloo" in c5["note"]
+    assert c5["ms_per_call_without_collective"] > 0 and "collective_adds_ms" in c5
     weak = d["extras"]["weak_scaling_own_tensor_per_gpu"]
     assert weak["scaling"] == "weak" and weak["numel_per_gpu"] == 27_264_000 and weak["GiB/s"] > 0
+    ar = d["extras"]["all_reduce_109MB"]
+    assert ar["ranks"] == 2 and ar["all_reduce_fp32"]["ms"] > 0 and ar["min_all_reduce_8_bytes"]["us_per_call"] > 0
+    for algo in ("direct", "ring"):
+        rec = ar[f"quantized_all_reduce_{algo}_u8"]
+        assert rec["ms"] > 0 and rec["within_bound"] is True and rec["ranks_bit_identical"] is True, rec
+
+
+def test_bench_own_launch_refuses_more_ranks_than_devices():
+    """the same loud refusal when bench.py launches its own ranks: no hang in RCCL, no traceback -- a message and a non-zero exit code"""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1"], capture_output=True, text=True,
+                       timeout=300, cwd=str(root), env=env)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "visible device" in r.stderr, r.stderr[-2000:]
 
 
 def test_bench_headline_survives_side_measurements_that_overrun():

@@ -400,8 +400,13 @@ def test_misaligned_full_size_slice_of_a_tensor(ctx, O, big_x):
     assert same_floats(back, O.dequantize(want, 4, 0, x.size, scale, zp, 0))
 
 
-def test_host_pointers_are_staged_through_the_gpu(ctx, O):
-    """The reference's callers pass host memory; the drop-in stages it over PCIe in 2^24-element chunks."""
+def test_host_pointers_are_staged_through_the_gpu(O):
+    """The reference's callers pass host memory; asked to (`stage`), the drop-in takes it over PCIe in 2^24-element chunks to the HIP kernels."""
+    import piquant
+
+    ctx = piquant.Context()
+    ctx.set_host_path("stage")
+    assert ctx.host_path_in_effect() == "stage"
     rng = np.random.default_rng(77)
     n = (1 << 24) + 12_345     # two chunks
     x = rng.uniform(-1, 1, n).astype(np.float32)
@@ -419,18 +424,22 @@ def test_host_pointers_are_staged_through_the_gpu(ctx, O):
 
 
 def test_host_pointers_on_the_cpu_companion_when_asked(O):
-    """piquant_hip_set_host_path(ctx, CPU): calls on pageable host buffers are handed to libpiquant_cpu.so (AVX-512 on the host cores)
-    instead of crossing PCIe twice; same bytes as the oracle and as the staged GPU path.  Device buffers of the same context still run the
-    HIP kernels.  Nothing switches by itself: the default context stages."""
+    """Host tensors stay on the host by default (`auto`, SURVEY 8b "host pointers -> CPU path"): calls on pageable host buffers are handed to
+    libpiquant_cpu.so (AVX-512 on the host cores) instead of crossing PCIe twice; same bytes as the oracle and as the staged GPU path, also when
+    asked for explicitly (`cpu`).  Device buffers of the same contexts still run the HIP kernels; reference-layout mode is staged."""
     import piquant
+    import piquant.cpu
     import torch
 
     rng = np.random.default_rng(78)
     n = 3_000_001
     x = rng.uniform(-1, 1, n).astype(np.float32)
-    staged, cpu_ctx = piquant.Context(), piquant.Context()
+    staged, cpu_ctx, default_ctx = piquant.Context(), piquant.Context(), piquant.Context()
+    staged.set_host_path("stage")
     cpu_ctx.set_host_path("cpu")
-    for c in (staged, cpu_ctx):
+    assert staged.host_path_in_effect() == "stage" and cpu_ctx.host_path_in_effect() == "cpu"
+    assert default_ctx.host_path_in_effect() == ("cpu" if piquant.cpu.has_avx512() else "stage")
+    for c in (staged, cpu_ctx, default_ctx):
         got = gpu_quantize(c, x, 0, 4, 0.0078431377, 127, 0, host=True)
         want = O.quantize(x, 0, 4, 0.0078431377, 127)
         assert np.array_equal(got, want)

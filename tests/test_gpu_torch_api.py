@@ -69,17 +69,21 @@ def test_quantize_roundtrip(dtype_in, dtype_quantized):
     assert torch.allclose(dequantized_pi, inp, atol=scale * 0.5 + 1e-3)
 
 
-def test_cpu_tensors_round_trip_through_the_gpu():
-    """A reference user passing CPU tensors keeps working: same call, host pointers staged over PCIe."""
+@pytest.mark.parametrize("host_path", ["auto", "stage"])
+def test_cpu_tensors_round_trip(host_path):
+    """A reference user passing CPU tensors keeps working: same call; the host tensors are served where they live by default (the companion
+    library) or staged over PCIe through the HIP kernels when the context says so."""
     import piquant
 
+    ctx = piquant.Context()
+    ctx.set_host_path(host_path)
     x = torch.empty(257, 33).uniform_(-1, 1, generator=gen)
-    scale, zp = piquant.torch.compute_quant_params(x, dtype=torch.quint8)
-    q = piquant.torch.quantize(x, scale=scale, zero_point=zp, dtype=torch.quint8)
+    scale, zp = piquant.torch.compute_quant_params(x, dtype=torch.quint8, ctx=ctx)
+    q = piquant.torch.quantize(x, scale=scale, zero_point=zp, dtype=torch.quint8, ctx=ctx)
     assert q.dtype == torch.quint8 and not q.is_cuda and q.shape == x.shape
     ref = torch.quantize_per_tensor(x, scale=scale, zero_point=zp, dtype=torch.quint8)
     assert torch.equal(q.int_repr(), ref.int_repr()) or (q.int_repr().int() - ref.int_repr().int()).abs().max() <= 1
-    back = piquant.torch.dequantize(q, scale=scale, zero_point=zp, dtype=torch.float32)
+    back = piquant.torch.dequantize(q, scale=scale, zero_point=zp, dtype=torch.float32, ctx=ctx)
     assert torch.allclose(back, x, atol=scale * 0.5 + 1e-6)
 
 
