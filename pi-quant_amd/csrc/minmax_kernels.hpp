@@ -65,6 +65,79 @@ __device__ __forceinline__ int32_t wave_min_i32(int32_t v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// ---- Raw-word fold (round 4) -------------------------------------------------------------------------------------------------
+// min/max of IEEE floats without touching a float: read as integers, the patterns of non-negative floats ascend as SIGNED and as
+// unsigned integers, those of negative floats sit above every non-negative one as UNSIGNED integers and ascend with their magnitude.  Three
+// running integers per lane therefore hold everything:
+//     a = max as signed ints    -> the largest non-negative float, once one has been seen (else a stays negative);
+//     b = max as unsigned ints  -> the most negative float, once a negative one has been seen (else b < sign bit);
+//     c = min as unsigned ints  -> the smallest non-negative float if there is one, else the negative float of smallest magnitude.
+//     min = any negative ? b : c          max = any non-negative ? a : c
+// -0.0 counts as negative and orders below +0.0, exactly like the int32 keys the results travel in (float_to_key).
+// bf16: the same on both 16-bit halves of a dword at once (v_pk_max_i16 / v_pk_max_u16 / v_pk_min_u16: three instructions per TWO
+// elements, where unpack + canonicalise + v_min_f32 + v_max_f32 are four and a half per ONE); fp32: v_max3_i32 / v_max3_u32 / v_min3_u32,
+// three instructions per two elements against three per one.
+// NaNs: a positive NaN pattern is the largest signed value there is, a negative one the largest unsigned value: one of them in the data
+// ends up in a or b and is SEEN there (a above +inf's pattern, b above -inf's) -- c cannot hide one, it only becomes a NaN when there
+// is nothing else of that sign either, and then a or b shows it.  The scan kernel treats that as "this block has to look properly" and
+// folds its share again the float way (quieted, v_min/v_max skip NaNs): tensors with NaNs cost their blocks a second pass, everybody
+// else never executes a float instruction in the loop.
+typedef int16_t i16x2 __attribute__((ext_vector_type(2)));
+
+template <int DT_IN>
+struct RawFold;
+
+template <>
+struct RawFold<DT_F32> {
+    int32_t a = INT32_MIN;
+    uint32_t b = 0u, c = 0xffffffffu;
+    __device__ __forceinline__ void fold(const u32x4& r) {
+        a = max(max(a, static_cast<int32_t>(r[0])), static_cast<int32_t>(r[1]));
+        a = max(max(a, static_cast<int32_t>(r[2])), static_cast<int32_t>(r[3]));
+        b = max(max(b, r[0]), r[1]);
+        b = max(max(b, r[2]), r[3]);
+        c = min(min(c, r[0]), r[1]);
+        c = min(min(c, r[2]), r[3]);
+    }
+    // -> this lane's {min, max} as floats (identities when the lane saw nothing), true if it saw a NaN
+    __device__ __forceinline__ bool finish(float& lo, float& hi) const {
+        const bool any_neg = b >= 0x80000000u, any_nonneg = a >= 0;
+        lo = __uint_as_float(any_neg ? b : c);
+        hi = __uint_as_float(any_nonneg ? static_cast<uint32_t>(a) : c);
+        if (!any_neg && !any_nonneg) {
+            lo = 3.402823466e+38f;
+            hi = -3.402823466e+38f;
+        }
+        return a > 0x7f800000 || b > 0xff800000u;
+    }
+};
+
+template <>
+struct RawFold<DT_BF16> {
+    uint32_t a = 0x80008000u, b = 0u, c = 0xffffffffu;   // packed pairs of the fp32 form's three integers
+    __device__ __forceinline__ void fold(const u32x4& r) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t w = r[e];   // a copy, not r[e] itself: __builtin_bit_cast of an ext-vector ELEMENT lvalue reads element 0 whatever e is (clang 22)
+            a = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, a), __builtin_bit_cast(i16x2, w)));
+            b = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, b), __builtin_bit_cast(u16x2, w)));
+            c = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, c), __builtin_bit_cast(u16x2, w)));
+        }
+    }
+    __device__ __forceinline__ bool finish(float& lo, float& hi) const {
+        const int32_t a1 = max(static_cast<int32_t>(static_cast<int16_t>(a & 0xffffu)), static_cast<int32_t>(static_cast<int16_t>(a >> 16)));
+        const uint32_t b1 = max(b & 0xffffu, b >> 16), c1 = min(c & 0xffffu, c >> 16);
+        const bool any_neg = b1 >= 0x8000u, any_nonneg = a1 >= 0;
+        lo = __uint_as_float((any_neg ? b1 : c1) << 16);
+        hi = __uint_as_float((any_nonneg ? static_cast<uint32_t>(a1) : c1) << 16);
+        if (!any_neg && !any_nonneg) {
+            lo = 3.402823466e+38f;
+            hi = -3.402823466e+38f;
+        }
+        return a1 > 0x7f80 || b1 > 0xff80u;
+    }
+};
+
 constexpr int kMinmaxSlots = 64;          // key pairs per slot buffer
 constexpr int kMinmaxSlotStride = 32;     // int32 per slot: one 128-byte line each -- [0] key(min), [1] key(-max), [2] arrivals
 constexpr int kMinmaxSlotInts = kMinmaxSlots * kMinmaxSlotStride;
@@ -321,42 +394,14 @@ __device__ __forceinline__ void minmax_block_end_gather(float lo, float hi, cons
     }
 }
 
-// `head`: leading elements in FRONT of `in` (fewer than a vector; block 0 folds them one by one): the launcher moves `in` up to the next
-// 16-byte boundary, so that a scan of a tensor that is only element-aligned (x[1:]) still runs on aligned vector loads -- which elements
-// share a vector is of no consequence to a min/max.
-// Everything arrives as scalars -- 13 dwords, preloaded in SGPRs with the wave (Makefile, -amdgpu-kernarg-preload-count; an aggregate would
-// end the preloaded prefix): the epilogue's fields, the head and the grid size (gridDim.x read from the dispatch packet is an s_load too).
-// Until round 3 the epilogue struct, the head and gridDim were s_loaded at the kernel's first instructions and WAITED for before the
-// first global load: one scalar-cache round trip in front of a scan whose 2 048 waves all start at the same instant.
-template <int DT_IN, int U, bool NT, int BLOCK, bool GATHER = false>
-__global__ void __launch_bounds__(BLOCK) minmax_kernel(const void* __restrict__ in, int64_t numel, int32_t* state, void* ep_dst, int ep_action, int ep_bits, uint32_t ep_seq,
-                                                        int head, uint32_t grid) {
-    const MinmaxEpilogue ep {ep_action, ep_bits, ep_seq, ep_dst};
-    constexpr int EPV = InVec<DT_IN>::EPV;
-    constexpr int WAVES = BLOCK / 64;
-    const u32x4* __restrict__ in16 = static_cast<const u32x4*>(in);
-    const int64_t n_vec = numel / EPV;
-    const int64_t tid = static_cast<int64_t>(blockIdx.x) * BLOCK + threadIdx.x;
-    const int64_t nthreads = static_cast<int64_t>(grid) * BLOCK;
-
-    float lo = 3.402823466e+38f, hi = -3.402823466e+38f;     // identities of the reference (:1422-1423)
-
-    auto fold = [&](const u32x4& raw) {
-        float f[EPV];
-        InVec<DT_IN>::unpack(raw, f);
-#pragma unroll
-        for (int e = 0; e < EPV; ++e) {
-            const float x = quieted(f[e]);   // a signaling NaN would poison the fold (device_math.hpp)
-            lo = __builtin_fminf(lo, x);
-            hi = __builtin_fmaxf(hi, x);
-        }
-    };
+// One thread's share of the vectors -- v = tid, tid + nthreads, ... -- through `fold`, with a rolling window of U loads per lane: as soon as
+// a vector has been folded its register is refilled with the vector one round ahead, so every lane keeps U loads in flight from its first
+// instruction to its last round.  (Issuing U loads, waiting for all of them and folding them before the next U -- round 1's loop -- lets a
+// wave's loads in flight drop to zero once per round; with only eight waves per CU nothing else fills the gap.)
+template <int U, bool NT, class Fold>
+__device__ __forceinline__ void minmax_scan_share(const u32x4* __restrict__ in16, int64_t n_vec, int64_t tid, int64_t nthreads, Fold&& fold) {
     int64_t v = tid;
     const int64_t round = static_cast<int64_t>(U) * nthreads;
-    // A rolling window of U loads per lane: as soon as a vector has been folded its register is refilled with the vector one round
-    // ahead, so every lane keeps U loads in flight from its first instruction to its last round.  (Issuing U loads, waiting for all of
-    // them and folding them before the next U -- round 1's loop -- lets a wave's loads in flight drop to zero once per round; with only
-    // eight waves per CU nothing else fills the gap.)
     if (v + static_cast<int64_t>(U - 1) * nthreads < n_vec) {
         u32x4 raw[U];
 #pragma unroll
@@ -374,16 +419,66 @@ __global__ void __launch_bounds__(BLOCK) minmax_kernel(const void* __restrict__ 
         v += round;
     }
     for (; v < n_vec; v += nthreads) fold(ld<NT>(in16 + v));
-    // ragged scalar tail (numel % EPV elements)
-    for (int64_t i = n_vec * EPV + tid; i < numel; i += nthreads) {
-        const float x = quieted(InVec<DT_IN>::load_scalar(in, i));
-        lo = __builtin_fminf(lo, x);
-        hi = __builtin_fmaxf(hi, x);
-    }
-    if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < head) {   // the elements in front of the first aligned vector
-        const float x = quieted(InVec<DT_IN>::load_scalar(in, static_cast<int64_t>(threadIdx.x) - head));
-        lo = __builtin_fminf(lo, x);
-        hi = __builtin_fmaxf(hi, x);
+}
+
+// `head`: leading elements in FRONT of `in` (fewer than a vector; block 0 folds them one by one): the launcher moves `in` up to the next
+// 16-byte boundary, so that a scan of a tensor that is only element-aligned (x[1:]) still runs on aligned vector loads -- which elements
+// share a vector is of no consequence to a min/max.
+// Everything arrives as scalars -- 13 dwords, preloaded in SGPRs with the wave (Makefile, -amdgpu-kernarg-preload-count; an aggregate would
+// end the preloaded prefix): the epilogue's fields, the head and the grid size (gridDim.x read from the dispatch packet is an s_load too).
+// Until round 3 the epilogue struct, the head and gridDim were s_loaded at the kernel's first instructions and WAITED for before the
+// first global load: one scalar-cache round trip in front of a scan whose 2 048 waves all start at the same instant.
+// RAW: the vectors are folded as integers (RawFold above); a wave that meets a NaN pattern folds its share again the float way.
+// POLL (gather end only): the grid carries ONE block more than scans -- the last one, which does nothing but sweep the other blocks' result
+// words from the moment it starts; without it the highest scanning block sweeps after its own share, i.e. the sweep's first loads are issued
+// when the slowest block is done, not before.
+template <int DT_IN, int U, bool NT, int BLOCK, bool GATHER = false, bool RAW = false, bool POLL = false>
+__global__ void __launch_bounds__(BLOCK) minmax_kernel(const void* __restrict__ in, int64_t numel, int32_t* state, void* ep_dst, int ep_action, int ep_bits, uint32_t ep_seq,
+                                                        int head, uint32_t grid) {
+    static_assert(!POLL || GATHER, "the polling block belongs to the gather end");
+    const MinmaxEpilogue ep {ep_action, ep_bits, ep_seq, ep_dst};
+    constexpr int EPV = InVec<DT_IN>::EPV;
+    constexpr int WAVES = BLOCK / 64;
+    const u32x4* __restrict__ in16 = static_cast<const u32x4*>(in);
+    const int64_t n_vec = numel / EPV;
+    const int64_t tid = static_cast<int64_t>(blockIdx.x) * BLOCK + threadIdx.x;
+    const int64_t nthreads = static_cast<int64_t>(grid - (POLL ? 1u : 0u)) * BLOCK;
+
+    float lo = 3.402823466e+38f, hi = -3.402823466e+38f;     // identities of the reference (:1422-1423)
+
+    if (!POLL || blockIdx.x + 1 != grid) {
+        auto fold = [&](const u32x4& raw) {
+            float f[EPV];
+            InVec<DT_IN>::unpack(raw, f);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                const float x = quieted(f[e]);   // a signaling NaN would poison the fold (device_math.hpp)
+                lo = __builtin_fminf(lo, x);
+                hi = __builtin_fmaxf(hi, x);
+            }
+        };
+        if constexpr (RAW) {
+            RawFold<DT_IN> words;
+            minmax_scan_share<U, NT>(in16, n_vec, tid, nthreads, [&](const u32x4& raw) { words.fold(raw); });
+            if (__any(words.finish(lo, hi) ? 1 : 0)) {   // a NaN somewhere in this wave's share: look again, properly
+                lo = 3.402823466e+38f;
+                hi = -3.402823466e+38f;
+                minmax_scan_share<U, NT>(in16, n_vec, tid, nthreads, fold);
+            }
+        } else {
+            minmax_scan_share<U, NT>(in16, n_vec, tid, nthreads, fold);
+        }
+        // ragged scalar tail (numel % EPV elements)
+        for (int64_t i = n_vec * EPV + tid; i < numel; i += nthreads) {
+            const float x = quieted(InVec<DT_IN>::load_scalar(in, i));
+            lo = __builtin_fminf(lo, x);
+            hi = __builtin_fmaxf(hi, x);
+        }
+        if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < head) {   // the elements in front of the first aligned vector
+            const float x = quieted(InVec<DT_IN>::load_scalar(in, static_cast<int64_t>(threadIdx.x) - head));
+            lo = __builtin_fminf(lo, x);
+            hi = __builtin_fmaxf(hi, x);
+        }
     }
 
     lo = wave_min(lo);
@@ -399,10 +494,12 @@ __global__ void __launch_bounds__(BLOCK) minmax_kernel(const void* __restrict__ 
     else minmax_block_end<WAVES>(lo, hi, s_lo, s_hi, state, ep, grid);
 }
 
-// Host side of the argument convention above.
-template <int DT_IN, int U, bool NT, int BLOCK, bool GATHER = false>
+// Host side of the argument convention above.  `grid` = scanning blocks; POLL adds the sweeping block on top.
+template <int DT_IN, int U, bool NT, int BLOCK, bool GATHER = false, bool RAW = false, bool POLL = false>
 inline void launch_minmax_kernel(unsigned grid, hipStream_t stream, const void* in, int64_t numel, int32_t* state, const MinmaxEpilogue& ep, int head = 0) {
-    hipLaunchKernelGGL((minmax_kernel<DT_IN, U, NT, BLOCK, GATHER>), dim3(grid), dim3(BLOCK), 0, stream, in, numel, state, ep.dst, ep.action, ep.bits, ep.seq, head, grid);
+    const unsigned launched = grid + (POLL ? 1u : 0u);
+    hipLaunchKernelGGL((minmax_kernel<DT_IN, U, NT, BLOCK, GATHER, RAW, POLL>), dim3(launched), dim3(BLOCK), 0, stream, in, numel, state, ep.dst, ep.action, ep.bits, ep.seq, head,
+                       launched);
 }
 
 // Same scan for buffers that are not even element-aligned.

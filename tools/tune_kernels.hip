@@ -333,25 +333,80 @@ static void run_requant(const Bufs& b, int64_t numel, int num_cu, double bytes_p
 
 static std::vector<int> g_mm_caps = {1, 2, 4, 8, 16, 32};
 
-template <int DT_IN, int U, bool NT, int BLOCK, bool GATHER = false>
+template <int DT_IN, int U, bool NT, int BLOCK, bool GATHER = false, bool RAW = false, bool POLL = false>
 static void run_minmax(const Bufs& b, int64_t numel, int num_cu, int32_t* keys) {
     for (int cap : g_mm_caps) {
         // cap 0: one round of U loads per block, as many blocks as that takes (the hardware's dispatcher balances the load)
         const int64_t per_block = static_cast<int64_t>(BLOCK) * U * InVec<DT_IN>::EPV;
         const unsigned grid = cap == 0 ? static_cast<unsigned>((numel + per_block - 1) / per_block) : static_cast<unsigned>(cap * num_cu);
-        if (GATHER && grid > static_cast<unsigned>(kMinmaxGatherMax)) continue;
+        if (GATHER && grid + (POLL ? 1u : 0u) > static_cast<unsigned>(kMinmaxGatherMax)) continue;
         const double us = time_us([&](int i) {
             // production protocol: the finishing block folds the per-block results into a key pair and re-arms the state inside the launch
-            launch_minmax_kernel<DT_IN, U, NT, BLOCK, GATHER>(grid, g_stream, b.in[i % SETS], numel, keys,
+            launch_minmax_kernel<DT_IN, U, NT, BLOCK, GATHER, RAW, POLL>(grid, g_stream, b.in[i % SETS], numel, keys,
                                MinmaxEpilogue {EP_KEYS_SET, 0, 0u, keys + kMinmaxScanStateInts});
         });
         char name[160];
-        std::snprintf(name, sizeof name, "in=%s U=%d nt=%d block=%d end=%s cap=%d grid=%u", DT_IN == DT_F32 ? "f32" : "bf16", U, NT ? 1 : 0, BLOCK,
-                      GATHER ? "gather" : "slots", cap, grid);
+        std::snprintf(name, sizeof name, "in=%s U=%d nt=%d block=%d end=%s fold=%s cap=%d grid=%u", DT_IN == DT_F32 ? "f32" : "bf16", U, NT ? 1 : 0, BLOCK,
+                      GATHER ? (POLL ? "gather+poller" : "gather") : "slots", RAW ? "raw" : "float", cap, grid);
         report("minmax", name, us, (DT_IN == DT_F32 ? 4.0 : 2.0) * numel);
     }
 }
 
+// keys of one scan of `in` with the given variant (synchronous)
+template <int DT_IN, int U, bool NT, int BLOCK, bool GATHER, bool RAW, bool POLL>
+static void minmax_once(const void* in, int64_t numel, unsigned grid, int32_t* keys, int32_t (&out)[2]) {
+    launch_minmax_kernel<DT_IN, U, NT, BLOCK, GATHER, RAW, POLL>(grid, g_stream, in, numel, keys, MinmaxEpilogue {EP_KEYS_SET, 0, 0u, keys + kMinmaxScanStateInts});
+    CK(hipStreamSynchronize(g_stream));
+    CK(hipMemcpy(out, keys + kMinmaxScanStateInts, sizeof out, hipMemcpyDeviceToHost));
+}
+
+// every round-4 variant of the scan against the round-3 kernel on the same data: clean data, then the same buffer with NaNs of both signs
+// (quiet and signaling) and both infinities planted in it
+template <int DT_IN>
+static void check_minmax_variants(void* buf, int64_t numel, int num_cu, int32_t* keys) {
+    constexpr int ES = DT_IN == DT_F32 ? 4 : 2;
+    for (int planted = 0; planted < 3; ++planted) {
+        if (planted == 1) {   // NaNs only: the extremes must stay those of the numbers
+            const uint32_t pats32[4] = {0x7fc00000u, 0xffc00001u, 0x7f800001u, 0xffbfffffu};
+            const uint16_t pats16[4] = {0x7fc0u, 0xffc1u, 0x7f81u, 0xffbfu};
+            for (int k = 0; k < 4; ++k)
+                CK(hipMemcpy(static_cast<char*>(buf) + (static_cast<int64_t>(k) * (numel / 5) + 12345 + k) * ES, DT_IN == DT_F32 ? static_cast<const void*>(&pats32[k]) : static_cast<const void*>(&pats16[k]), ES,
+                             hipMemcpyHostToDevice));
+        }
+        if (planted == 2) {   // and the infinities
+            const uint32_t inf32[2] = {0x7f800000u, 0xff800000u};
+            const uint16_t inf16[2] = {0x7f80u, 0xff80u};
+            for (int k = 0; k < 2; ++k)
+                CK(hipMemcpy(static_cast<char*>(buf) + (static_cast<int64_t>(k) * (numel / 3) + 777 + k) * ES, DT_IN == DT_F32 ? static_cast<const void*>(&inf32[k]) : static_cast<const void*>(&inf16[k]), ES,
+                             hipMemcpyHostToDevice));
+        }
+        int32_t ref[2], got[2];
+        minmax_once<DT_IN, 4, true, 512, true, false, false>(buf, numel, num_cu, keys, ref);
+        bool ok = true;
+#define CHECK(U_, BLK, RAW_, POLL_, GRID)                                                     \
+    minmax_once<DT_IN, U_, true, BLK, true, RAW_, POLL_>(buf, numel, GRID, keys, got);         \
+    ok = ok && got[0] == ref[0] && got[1] == ref[1];
+        CHECK(4, 512, true, false, num_cu)
+        CHECK(4, 512, false, true, num_cu)
+        CHECK(4, 512, true, true, num_cu)
+        CHECK(8, 512, true, true, num_cu)
+        CHECK(4, 256, true, true, 2 * num_cu)
+        CHECK(4, 256, true, false, 2 * num_cu)
+        // odd sizes: ragged tail, a grid larger than the work
+        minmax_once<DT_IN, 4, true, 512, true, false, false>(buf, 1000003, num_cu, keys, ref);
+        CHECK(4, 512, true, true, num_cu)
+        minmax_once<DT_IN, 4, true, 512, true, false, false>(buf, 1000003, num_cu, keys, ref);
+        minmax_once<DT_IN, 4, true, 512, true, true, true>(buf, 1000003, num_cu, keys, got);
+        ok = ok && got[0] == ref[0] && got[1] == ref[1];
+#undef CHECK
+        std::printf("check,minmax variants == round-3 kernel in=%s planted=%s keys=%08x %08x,%d,0,0,0\n", DT_IN == DT_F32 ? "f32" : "bf16",
+                    planted == 0 ? "nothing" : (planted == 1 ? "NaNs" : "NaNs+infinities"), static_cast<unsigned>(ref[0]), static_cast<unsigned>(ref[1]), ok ? 1 : 0);
+        if (!ok) {
+            std::fprintf(stderr, "minmax variant mismatch\n");
+            std::exit(3);
+        }
+    }
+}
 
 // fused compute_quant_params + quantize (one launch, tensor resident on chip) against the two-launch path
 struct FusedBufs {
@@ -1238,6 +1293,63 @@ int main(int argc, char** argv) {
         run_minmax<DT_F32, 4, true, 512>(b, numel, num_cu, keys);
         run_minmax<DT_BF16, 4, true, 256>(b, 2 * numel, num_cu, keys);
         run_minmax<DT_BF16, 8, true, 256>(b, 2 * numel, num_cu, keys);
+    }
+
+    if (only == "mm4") {
+        // Round 4: the scan's fold on raw words (RawFold) and a block that only sweeps (POLL), against round 3's kernel and a read-only sweep
+        // with no arithmetic and no end protocol; interleaved passes, one timed batch each.  fp32 at `numel`, then bf16 at `numel` (U(-1,1) data).
+        void* scratch = nullptr;
+        CK(hipMalloc(&scratch, numel * 4 + 4096));
+        CK(hipMemcpy(scratch, b.in[0], numel * 4, hipMemcpyDeviceToDevice));
+        check_minmax_variants<DT_F32>(scratch, numel, num_cu, keys);
+        g_rounds = 1;
+        auto ceiling = [&](int64_t nvec, double bytes, const char* what) {
+            for (int cap : {2, 4}) {
+                const double us = time_us([&](int i) {
+                    hipLaunchKernelGGL((read_only_kernel<true>), dim3(cap * num_cu), dim3(256), 0, g_stream, static_cast<const u32x4*>(b.in[i % SETS]),
+                                       static_cast<uint32_t*>(b.out[i % SETS]), nvec);
+                });
+                report("minmax", std::string("read-only sweep, no arithmetic, no end (") + what + ") cap=" + std::to_string(cap), us, bytes);
+            }
+        };
+        for (int pass = 0; pass < 5; ++pass) {
+            ceiling(numel / 4, 4.0 * numel, "f32");
+            g_mm_caps = {1};
+            run_minmax<DT_F32, 4, true, 512, true, false, false>(b, numel, num_cu, keys);
+            run_minmax<DT_F32, 4, true, 512, true, true, false>(b, numel, num_cu, keys);
+            run_minmax<DT_F32, 4, true, 512, true, false, true>(b, numel, num_cu, keys);
+            run_minmax<DT_F32, 4, true, 512, true, true, true>(b, numel, num_cu, keys);
+            run_minmax<DT_F32, 8, true, 512, true, true, true>(b, numel, num_cu, keys);
+            run_minmax<DT_F32, 2, true, 1024, true, true, true>(b, numel, num_cu, keys);
+            g_mm_caps = {2};
+            run_minmax<DT_F32, 4, true, 256, true, true, true>(b, numel, num_cu, keys);
+            run_minmax<DT_F32, 8, true, 256, true, true, true>(b, numel, num_cu, keys);
+            g_mm_caps = {4};
+            run_minmax<DT_F32, 4, true, 256, true, true, true>(b, numel, num_cu, keys);
+        }
+        for (int s_ = 0; s_ < SETS; ++s_)
+            hipLaunchKernelGGL(fill_uniform_bf16, dim3(4096), dim3(256), 0, g_stream, static_cast<uint16_t*>(b.in[s_]), 2 * numel, 0x9e3779b9u * (s_ + 1));
+        CK(hipStreamSynchronize(g_stream));
+        CK(hipMemcpy(scratch, b.in[0], numel * 2, hipMemcpyDeviceToDevice));
+        check_minmax_variants<DT_BF16>(scratch, numel, num_cu, keys);
+        for (int pass = 0; pass < 5; ++pass) {
+            ceiling(numel / 8, 2.0 * numel, "bf16");
+            g_mm_caps = {1};
+            run_minmax<DT_BF16, 4, true, 512, true, false, false>(b, numel, num_cu, keys);
+            run_minmax<DT_BF16, 4, true, 512, true, true, false>(b, numel, num_cu, keys);
+            run_minmax<DT_BF16, 4, true, 512, true, false, true>(b, numel, num_cu, keys);
+            run_minmax<DT_BF16, 4, true, 512, true, true, true>(b, numel, num_cu, keys);
+            run_minmax<DT_BF16, 8, true, 512, true, true, true>(b, numel, num_cu, keys);
+            run_minmax<DT_BF16, 2, true, 512, true, true, true>(b, numel, num_cu, keys);
+            run_minmax<DT_BF16, 2, true, 1024, true, true, true>(b, numel, num_cu, keys);
+            g_mm_caps = {2};
+            run_minmax<DT_BF16, 4, true, 256, true, true, true>(b, numel, num_cu, keys);
+            run_minmax<DT_BF16, 2, true, 256, true, true, true>(b, numel, num_cu, keys);
+            g_mm_caps = {4};
+            run_minmax<DT_BF16, 2, true, 256, true, true, true>(b, numel, num_cu, keys);
+        }
+        g_rounds = 3;
+        return 0;
     }
 
     if (only == "pair") {
