@@ -991,7 +991,14 @@ def main():
             ctx.set_blocking(False)
             keys = torch.empty(2, dtype=torch.int32, device=dev)
             _, e = time_loop(lambda i: ctx.minmax_keys_ptr(ptr_in[i % nsets], DataType.F32, n, keys.data_ptr(), True), reps, stream)
-            extras["minmax_f32"] = {"GB/s": gbs(4, e, reps), "avg_launch_us": round(e / reps * 1e6, 3), "note": "piquant_hip_minmax_keys: one launch, the last block folds the slots into the key pair"}
+            extras["minmax_f32"] = {"GB/s": gbs(4, e, reps), "avg_launch_us": round(e / reps * 1e6, 3),
+                                    "note": "piquant_hip_minmax_keys: one launch, the highest block sweeps the per-block result words into the key pair (a read-only sweep of the same "
+                                            "bytes with no arithmetic and no end: 16.6-18.3 us; the scan's loop alone 17.1, + block reduction 17.7, profiles/r04_tune_mm8_summary.txt)"}
+            xb16 = [x.to(torch.bfloat16) for x in xs]
+            _, e = time_loop(lambda i: ctx.minmax_keys_ptr(xb16[i % nsets].data_ptr(), DataType.BF16, n, keys.data_ptr(), True), reps, stream)
+            extras["minmax_bf16"] = {"GB/s": gbs(2, e, reps), "avg_launch_us": round(e / reps * 1e6, 3), "buffer_sets": nsets,
+                                     "note": "the same scan over bf16 (54.5 MB per launch: half the bytes behind the same fixed ramp and end)"}
+            del xb16
             t0 = time.perf_counter()
             for i in range(50):
                 piquant.torch.compute_quant_params(xs[i % nsets], dtype=torch.quint8)

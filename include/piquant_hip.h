@@ -212,6 +212,17 @@ PIQUANT_EXPORT void piquant_hip_compute_quant_params_dist(piquant_context_t* ctx
                                                           size_t n_local, piquant_dtype_t target_quant_dtype, void* nccl_comm,
                                                           float* out_scale, int64_t* out_zero_point);
 
+/* Flags for peer-to-peer schedules between GPUs (or between processes on one GPU): sequence numbers in device memory that a peer
+ * writes and the owner polls -- what lets a quantize kernel store its bytes straight into a peer's receive buffer (an address obtained from
+ * hipIpcOpenMemHandle or a peer-accessible allocation) instead of local write -> collective -> local read (piquant.distributed,
+ * quantized_all_reduce(transport='p2p'); the use-case of reference README.md:29).  Both calls are stream-ordered on the context's stream:
+ *   piquant_hip_signal_flags  stores `value` into every flags[i] (system-scope release) once everything enqueued before it has completed;
+ *   piquant_hip_wait_flags    holds the stream until every flags[i] (an array in THIS device's memory) has reached `value` (serial-number
+ *                             compare, so a 32-bit counter may wrap); a peer that never arrives fails the launch after timeout_us (0 = 30 s)
+ *                             instead of hanging the device.  Not capturable into a hipGraph. */
+PIQUANT_EXPORT void piquant_hip_signal_flags(piquant_context_t* ctx, uint32_t* const* flags, size_t count, uint32_t value);
+PIQUANT_EXPORT void piquant_hip_wait_flags(piquant_context_t* ctx, const uint32_t* flags, size_t count, uint32_t value, uint32_t timeout_us);
+
 /* Host helpers: key <-> float, and the (min,max) -> (scale, zero_point) epilogue in double precision
  * (reference src/piquant.cpp:213-220, 245-258).  keys[0] encodes min, keys[1] encodes -max. */
 PIQUANT_EXPORT void piquant_hip_decode_minmax_keys(const int32_t keys[2], float* out_min, float* out_max);

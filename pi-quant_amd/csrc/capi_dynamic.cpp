@@ -320,4 +320,25 @@ void piquant_hip_reduce_quantize_dynamic(piquant_context_t* ctx, void* acc, piqu
     if (ctx->blocking) wait_stream(ctx);
 }
 
+void piquant_hip_signal_flags(piquant_context_t* ctx, uint32_t* const* flags, size_t count, uint32_t value) {
+    if (!ctx) panic("piquant_hip_signal_flags: context is NULL");
+    if (count == 0) return;
+    if (!flags) panic("piquant_hip_signal_flags: NULL flag list");
+    for (size_t i = 0; i < count; ++i)
+        if (!flags[i]) panic("piquant_hip_signal_flags: NULL flag %zu", i);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    launch_signal_flags(flags, static_cast<int>(count), value, ctx->stream);
+}
+
+void piquant_hip_wait_flags(piquant_context_t* ctx, const uint32_t* flags, size_t count, uint32_t value, uint32_t timeout_us) {
+    if (!ctx) panic("piquant_hip_wait_flags: context is NULL");
+    if (count == 0) return;
+    if (!flags) panic("piquant_hip_wait_flags: NULL flag array");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    if (stream_is_capturing(ctx->stream)) panic("piquant_hip_wait_flags cannot be captured into a hipGraph: the value waited for changes with every exchange");
+    launch_wait_flags(flags, static_cast<int>(count), value, timeout_us, ctx->stream);
+}
+
 }  // extern "C"

@@ -601,6 +601,54 @@ __global__ void __launch_bounds__(64) publish_seq_kernel(uint32_t* word, uint32_
     if (threadIdx.x == 0) __hip_atomic_store(word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Flags of the peer-to-peer schedules (piquant_hip_signal_flags / piquant_hip_wait_flags): sequence numbers in memory that other devices -- or
+// other processes on this device -- write and this one polls.  Signal: everything enqueued on the stream before this kernel has completed
+// and been released at system scope by then (a kernel's end is a system-scope release on this runtime); the stores are system-scope
+// releases on top.  Wait: one wave, lane i polls flag i with system-scope loads (they bypass this device's caches) and sleeps in between;
+// the kernels behind it on the stream start with the acquire of any kernel start.
+struct FlagList {
+    uint32_t* ptr[kFlagListMax];
+};
+
+__global__ void __launch_bounds__(64) signal_flags_kernel(FlagList flags, int count, uint32_t value) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if (static_cast<int>(threadIdx.x) < count) __hip_atomic_store(flags.ptr[threadIdx.x], value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void __launch_bounds__(64) wait_flags_kernel(const uint32_t* flags, int count, uint32_t value, uint64_t timeout_ticks, uint32_t* timed_out) {
+    const uint64_t t_begin = wall_clock64();
+    for (int base = 0; base < count; base += 64) {
+        const int i = base + static_cast<int>(threadIdx.x);
+        for (;;) {
+            bool behind = false;
+            if (i < count) behind = static_cast<int32_t>(__hip_atomic_load(flags + i, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0;
+            if (!__any(behind ? 1 : 0)) break;
+            __builtin_amdgcn_s_sleep(16);
+            if (wall_clock64() - t_begin > timeout_ticks) {   // a peer that never arrives: fail the launch loudly instead of hanging the device
+                if (threadIdx.x == 0 && timed_out != nullptr) __hip_atomic_store(timed_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __builtin_trap();
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+}
+
+void launch_signal_flags(uint32_t* const* flags, int count, uint32_t value, hipStream_t stream) {
+    for (int first = 0; first < count; first += kFlagListMax) {
+        FlagList list {};
+        const int n = std::min(kFlagListMax, count - first);
+        for (int i = 0; i < n; ++i) list.ptr[i] = flags[first + i];
+        hipLaunchKernelGGL(signal_flags_kernel, dim3(1), dim3(64), 0, stream, list, n, value);
+    }
+    PQ_HIP(hipGetLastError());
+}
+
+void launch_wait_flags(const uint32_t* flags, int count, uint32_t value, uint32_t timeout_us, hipStream_t stream) {
+    const uint64_t ticks = static_cast<uint64_t>(timeout_us == 0 ? 30000000u : timeout_us) * 100ull;   // wall_clock64 ticks at 100 MHz
+    hipLaunchKernelGGL(wait_flags_kernel, dim3(1), dim3(64), 0, stream, flags, count, value, ticks, static_cast<uint32_t*>(nullptr));
+    PQ_HIP(hipGetLastError());
+}
+
 void launch_publish_seq(uint32_t* host_visible_word, uint32_t seq, hipStream_t stream) {
     hipLaunchKernelGGL(publish_seq_kernel, dim3(1), dim3(64), 0, stream, host_visible_word, seq);
     PQ_HIP(hipGetLastError());

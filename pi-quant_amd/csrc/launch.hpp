@@ -146,6 +146,10 @@ bool launch_fused_reduce_quantize(const QuantLaunch& q, const DequantSumLaunch& 
                                   int num_cu);
 // one-thread kernel: system-scope store of `seq` into a host-visible word, behind everything enqueued on `stream` so far
 void launch_publish_seq(uint32_t* host_visible_word, uint32_t seq, hipStream_t stream);
+// peer-to-peer schedules: `value` into every flags[i] (addresses other devices / processes poll), and the wait for every flags[i] to reach it
+constexpr int kFlagListMax = 32;
+void launch_signal_flags(uint32_t* const* flags, int count, uint32_t value, hipStream_t stream);
+void launch_wait_flags(const uint32_t* flags, int count, uint32_t value, uint32_t timeout_us, hipStream_t stream);
 size_t fused_state_bytes();
 void init_fused_state(void* state, hipStream_t stream);
 // blocks of fused launches on `state` that left their grid barrier early so far (synchronises `stream`)

@@ -398,27 +398,46 @@ __device__ __forceinline__ void minmax_block_end_gather(float lo, float hi, cons
 // a vector has been folded its register is refilled with the vector one round ahead, so every lane keeps U loads in flight from its first
 // instruction to its last round.  (Issuing U loads, waiting for all of them and folding them before the next U -- round 1's loop -- lets a
 // wave's loads in flight drop to zero once per round; with only eight waves per CU nothing else fills the gap.)
+// Every thread runs the SAME number of rounds, ceil(n_vec / (U nthreads)), and the addresses of the last round are clamped to the tensor's
+// last vector: folding a vector twice changes no minimum and no maximum, so the ragged end needs neither predication nor a loop of its
+// own -- and its loads are issued a round ahead like all the others.  Until round 4 the vectors left over after the last FULL round were
+// loaded one at a time behind it, each waiting out a whole memory round trip with nothing else in flight: at numel 27 264 000 a bf16 scan
+// (26.0009 vectors per thread) paid two such trips, ~2 us of a 12.5 us kernel, the fp32 scan (52.0018) one in its block 0
+// (profiles/r04_tune_mm5.csv: 2.4 and 1.2 us above a read-only sweep).
 template <int U, bool NT, class Fold>
 __device__ __forceinline__ void minmax_scan_share(const u32x4* __restrict__ in16, int64_t n_vec, int64_t tid, int64_t nthreads, Fold&& fold) {
-    int64_t v = tid;
+    if (n_vec <= 0) return;
     const int64_t round = static_cast<int64_t>(U) * nthreads;
-    if (v + static_cast<int64_t>(U - 1) * nthreads < n_vec) {
-        u32x4 raw[U];
+    const int64_t rounds = (n_vec + round - 1) / round;
+    const int64_t last = n_vec - 1;
+    u32x4 raw[U];
+    if (rounds == 1) {
 #pragma unroll
-        for (int k = 0; k < U; ++k) raw[k] = ld<NT>(in16 + v + k * nthreads);
-        while (v + round + static_cast<int64_t>(U - 1) * nthreads < n_vec) {   // the next round is a full one too
+        for (int k = 0; k < U; ++k) {
+            const int64_t i = tid + k * nthreads;
+            raw[k] = ld<NT>(in16 + (i < last ? i : last));
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < U; ++k) raw[k] = ld<NT>(in16 + tid + k * nthreads);
+        int64_t v = tid + round;
+        for (int64_t r = 2; r < rounds; ++r) {   // refills with rounds 1 .. rounds - 2: whole rounds, no clamp
 #pragma unroll
             for (int k = 0; k < U; ++k) {
                 fold(raw[k]);
-                raw[k] = ld<NT>(in16 + v + round + k * nthreads);
+                raw[k] = ld<NT>(in16 + v + k * nthreads);
             }
             v += round;
         }
 #pragma unroll
-        for (int k = 0; k < U; ++k) fold(raw[k]);
-        v += round;
+        for (int k = 0; k < U; ++k) {            // refill with the last round: clamped
+            fold(raw[k]);
+            const int64_t i = v + k * nthreads;
+            raw[k] = ld<NT>(in16 + (i < last ? i : last));
+        }
     }
-    for (; v < n_vec; v += nthreads) fold(ld<NT>(in16 + v));
+#pragma unroll
+    for (int k = 0; k < U; ++k) fold(raw[k]);
 }
 
 // `head`: leading elements in FRONT of `in` (fewer than a vector; block 0 folds them one by one): the launcher moves `in` up to the next

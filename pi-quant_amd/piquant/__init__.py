@@ -305,6 +305,18 @@ class Context:
         arr_p = (_C.c_void_p * n)(*params_ptrs)
         C.piquant_hip_dequantize_sum(self._ctx, arr_in, arr_p, n, dtype_in.value, ptr_out, dtype_out.value, numel, reduce_op.value)
 
+    def signal_flags_ptr(self, flag_ptrs, value: int) -> None:
+        """Stream-ordered: store ``value`` into every flag address (peers' memory) once the work enqueued so far has completed
+        (include/piquant_hip.h, piquant_hip_signal_flags)."""
+        n = len(flag_ptrs)
+        if n:
+            C.piquant_hip_signal_flags(self._ctx, (_C.c_void_p * n)(*flag_ptrs), n, value & 0xFFFFFFFF)
+
+    def wait_flags_ptr(self, flags_ptr: int, count: int, value: int, timeout_us: int = 0) -> None:
+        """Stream-ordered: hold the stream until ``count`` uint32 flags at ``flags_ptr`` (this device's memory) have reached ``value``."""
+        if count:
+            C.piquant_hip_wait_flags(self._ctx, flags_ptr, count, value & 0xFFFFFFFF, timeout_us)
+
     def set_host_path(self, path: str) -> None:
         """Who serves calls on pageable HOST buffers: 'auto' (default: the companion libpiquant_cpu.so -- the same arithmetic in AVX-512 on the
         host cores, as the reference does with host tensors -- when it is present and the host has AVX-512, PCIe staging otherwise), 'stage'

@@ -266,6 +266,88 @@ def _all_gather(mine: torch.Tensor, everyone: torch.Tensor, group) -> None:
     everyone.copy_(torch.cat(parts))
 
 
+# -----------------------------------------------------------------------------------------------------------------
+# Peer-to-peer transport of the mesh schedule: the encode kernels store straight into the peers' receive buffers.
+# -----------------------------------------------------------------------------------------------------------------
+class _PeerMesh:
+    """Buffers of ``quantized_all_reduce_direct(transport='p2p')``, one allocation per rank, every rank's mapped into every other rank's
+    address space (IPC handles exchanged once per (group, device, slot size) through the process group; on one node every GPU reaches every
+    other over its own xGMI link, and several processes on one GPU -- the tests -- share it the same way):
+
+        recv[2][world][slot]   chunk j of peer i lands in recv[parity][i] of rank j -- written by PEER i's encode kernel, no copy
+        mine[2][slot]          the owner's finished chunk -- READ by every peer's decode kernel, no all-gather
+        arrived[world]         uint32 sequence numbers: arrived[i] = s  <=>  peer i's chunk of exchange s is in recv[s & 1][i]
+        finished[world]        finished[i] = s  <=>  owner i's mine[s & 1] holds its finished chunk of exchange s
+
+    Two parities suffice: a rank enters exchange s + 1 only behind its own decode of exchange s, a peer passes its wait of exchange s + 1
+    only after that rank's encode of s + 1 -- so when anybody writes parity (s + 2) & 1 = s & 1 again, every reader of exchange s is done.
+    """
+
+    _cache = {}
+
+    def __init__(self, group, device: torch.device, slot: int, world: int, rank: int):
+        from torch.multiprocessing.reductions import reduce_tensor
+
+        self.world, self.rank, self.slot, self.device = world, rank, slot, device
+        self.off_mine = 2 * world * slot
+        self.off_arrived = self.off_mine + 2 * slot
+        self.off_finished = self.off_arrived + 4 * world
+        total = -(-(self.off_finished + 4 * world) // 256) * 256
+        self.buf = torch.zeros(total, dtype=torch.uint8, device=device)
+        torch.cuda.synchronize(device)
+        fn, args = reduce_tensor(self.buf)
+        everyone = [None] * world
+        dist.all_gather_object(everyone, (fn, args), group=group)
+        self.peers = []
+        for j, (f, a) in enumerate(everyone):
+            if j == rank:
+                self.peers.append(self.buf)
+                continue
+            t = f(*a)                    # hipIpcOpenMemHandle through PyTorch's CUDA-IPC machinery: a uint8 view of rank j's allocation
+            if t.device != device:       # another GPU: this device needs peer access to it for raw-pointer kernels
+                _enable_peer_access(device, t.device)
+                probe = torch.empty(16, dtype=torch.uint8, device=device)
+                probe.copy_(t[:16])      # a runtime-managed copy first: a mapping that does not work fails HERE, with an exception
+            self.peers.append(t)
+        torch.cuda.synchronize(device)
+        dist.barrier(group=group)        # nobody signals into a buffer somebody has not finished zeroing / mapping
+        self.seq = 0
+
+    @classmethod
+    def get(cls, group, device, slot, world, rank):
+        key = (id(group) if group is not None else 0, device.index, slot, world)
+        m = cls._cache.get(key)
+        if m is None:
+            m = cls._cache[key] = cls(group, device, slot, world, rank)
+        return m
+
+    # views into rank j's allocation
+    def recv_slot(self, j: int, parity: int, i: int, nbytes: int) -> torch.Tensor:
+        o = (parity * self.world + i) * self.slot
+        return self.peers[j][o: o + nbytes]
+
+    def mine(self, j: int, parity: int, nbytes: int) -> torch.Tensor:
+        o = self.off_mine + parity * self.slot
+        return self.peers[j][o: o + nbytes]
+
+    def flag_ptr(self, j: int, which: str, i: int) -> int:
+        return self.peers[j].data_ptr() + (self.off_arrived if which == 'arrived' else self.off_finished) + 4 * i
+
+
+def _enable_peer_access(device: torch.device, peer: torch.device) -> None:
+    """hipDeviceEnablePeerAccess(peer) on `device` (idempotent); raises when the two GPUs cannot reach each other."""
+    import ctypes
+
+    hip = ctypes.CDLL('libamdhip64.so')
+    can = ctypes.c_int(0)
+    if hip.hipDeviceCanAccessPeer(ctypes.byref(can), device.index, peer.index) != 0 or not can.value:
+        raise RuntimeError(f"transport='p2p': {device} cannot access {peer} (hipDeviceCanAccessPeer)")
+    with torch.cuda.device(device):
+        rc = hip.hipDeviceEnablePeerAccess(peer.index, 0)
+    if rc not in (0, 704):   # hipSuccess, hipErrorPeerAccessAlreadyEnabled
+        raise RuntimeError(f"transport='p2p': hipDeviceEnablePeerAccess({peer.index}) on {device} -> {rc}")
+
+
 def ring_chunks(numel: int, world_size: int, packed_bits: int = 8, align: int = 4096):
     """Chunk boundaries of the ring: `world_size` contiguous chunks; interior boundaries are multiples of `align` elements
     (whole packed bytes and 16-byte vectors on both sides of every kernel); the last chunk keeps the ragged end."""
@@ -285,10 +367,14 @@ def quantized_all_reduce(
     group: Optional[dist.ProcessGroup] = None,
     ctx: Optional[Context] = None,
     algorithm: str = 'direct',
+    transport: str = 'collective',
     _ops=None,
     _single_rank_collectives: bool = False,
 ) -> torch.Tensor:
     """In-place SUM all-reduce of a contiguous float32/bfloat16 tensor whose wire format is quantized.
+
+    ``transport='p2p'`` (``algorithm='direct'`` only, one node): no collective at all -- the encode kernels store into the peers' receive
+    buffers over xGMI and flags order the steps (``quantized_all_reduce_direct``).
 
     (``_single_rank_collectives`` is a test hook: with a one-rank group the function normally returns at once; with the hook it
     runs the whole schedule -- encode, the group's collectives with the rank as its own only peer, decode -- so that the RCCL
@@ -312,9 +398,13 @@ def quantized_all_reduce(
         raise ValueError('quantized_all_reduce needs a contiguous float32 or bfloat16 tensor')
     if algorithm not in ('ring', 'direct'):
         raise ValueError(f"algorithm must be 'ring' or 'direct', got {algorithm!r}")
+    if transport not in ('collective', 'p2p'):
+        raise ValueError(f"transport must be 'collective' or 'p2p', got {transport!r}")
     if algorithm == 'direct':
-        return quantized_all_reduce_direct(tensor, quant_dtype=quant_dtype, round_mode=round_mode, group=group, ctx=ctx, _ops=_ops,
+        return quantized_all_reduce_direct(tensor, quant_dtype=quant_dtype, round_mode=round_mode, group=group, ctx=ctx, transport=transport, _ops=_ops,
                                            _single_rank_collectives=_single_rank_collectives)
+    if transport != 'collective':
+        raise ValueError("transport='p2p' is the mesh schedule's (algorithm='direct'); the ring forwards through its neighbours")
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if world == 1 and not _single_rank_collectives:
@@ -375,6 +465,7 @@ def quantized_all_reduce_direct(
     round_mode: str = 'nearest',
     group: Optional[dist.ProcessGroup] = None,
     ctx: Optional[Context] = None,
+    transport: str = 'collective',
     _ops=None,
     _single_rank_collectives: bool = False,
 ) -> torch.Tensor:
@@ -392,6 +483,13 @@ def quantized_all_reduce_direct(
 
     Every value is quantized exactly twice whatever the world size (a ring: up to G times), the wire carries the same
     2(G-1)/G x packed bytes per element, and the two collectives are what RCCL implements natively over the mesh.
+
+    ``transport='p2p'``: the same four steps and the same bytes with NO collective.  Step 1's kernel stores chunk j straight into rank j's
+    receive buffer (an address of rank j's memory mapped here once, ``_PeerMesh``) and a flag store behind it says so; step 3 waits for its
+    G-1 flags on the stream; step 4 leaves the finished chunk in the owner's own buffer, and every rank's decode kernel READS the G finished
+    chunks from their owners.  Against the collective transport that is one HBM write and one read of the wire bytes less per phase on every
+    rank, no staging copy inside RCCL and no RCCL launch: 4 kernel launches + 2 flag stores + 2 flag waits per all-reduce.  One node only
+    (IPC-mapped device memory); results are bit-identical to the collective transport (tests/test_gpu_distributed.py).
     """
     if not (tensor.is_contiguous() and tensor.dtype in (torch.float32, torch.bfloat16)):
         raise ValueError('quantized_all_reduce needs a contiguous float32 or bfloat16 tensor')
@@ -405,6 +503,12 @@ def quantized_all_reduce_direct(
     chunks = ring_chunks(flat.numel(), world, qdt.bit_size)
     slot = _HEADER_BYTES + max(qdt.packed_nbytes(e - b) for b, e in chunks)
     slot = -(-slot // 16) * 16                       # every slot starts on a 16-byte boundary (vector kernels on both sides)
+    if transport == 'p2p':
+        if world == 1:
+            raise ValueError("transport='p2p' needs peers (a one-rank group has none)")
+        return _all_reduce_direct_p2p(tensor, flat, chunks, slot, quant_dtype, qdt, round_mode, group, ctx, ops, world, rank)
+    if transport != 'collective':
+        raise ValueError(f"transport must be 'collective' or 'p2p', got {transport!r}")
     send = torch.zeros(world * slot, dtype=torch.uint8, device=tensor.device)
     recv = torch.empty(world * slot, dtype=torch.uint8, device=tensor.device)
 
@@ -429,4 +533,61 @@ def quantized_all_reduce_direct(
     recv = gathered
     full = [j for j in range(world) if chunks[j][1] > chunks[j][0]]
     ops.decode_batch([recv[j * slot: j * slot + wire_len(j)] for j in full], [flat[chunks[j][0]:chunks[j][1]] for j in full], quant_dtype, 'set')
+    return tensor
+
+
+def _all_reduce_direct_p2p(tensor, flat, chunks, slot, quant_dtype, qdt, round_mode, group, ctx, ops, world, rank):
+    """The mesh schedule over peer-mapped buffers (``quantized_all_reduce_direct``, ``transport='p2p'``).  The calls go through the context's
+    raw-pointer entry points: the peers' buffers are addresses of THEIR devices' memory, which the tensor-level wrappers (one device per
+    call, by design) would refuse."""
+    from . import ReduceOp, RoundMode
+
+    if not tensor.is_cuda:
+        raise RuntimeError("transport='p2p' moves device memory between GPUs: the tensor must live on one")
+    slot = -(-slot // 65536) * 65536    # tensors of similar size share one mesh (a mesh costs an IPC exchange and a barrier)
+    mesh = _PeerMesh.get(group, tensor.device, slot, world, rank)
+    cx = _ctx_for(tensor, ctx)          # the tensor's device, PyTorch's current stream, stream-ordered
+    fdt = torch_to_piquant_dtype(tensor.dtype)
+    rmode = RoundMode.NEAREST if round_mode == 'nearest' else RoundMode.STOCHASTIC
+    mesh.seq += 1
+    seq, par = mesh.seq, mesh.seq & 1
+    esize = tensor.element_size()
+    base = flat.data_ptr()
+
+    def chunk_ptr(j):
+        return base + chunks[j][0] * esize
+
+    def chunk_len(j):
+        return chunks[j][1] - chunks[j][0]
+
+    def recv_ptr(j, i):                 # recv[par][i] of rank j: 16-byte header (the parameter record), then the packed bytes
+        return mesh.peers[j].data_ptr() + (par * world + i) * slot
+
+    def mine_ptr(j):
+        return mesh.peers[j].data_ptr() + mesh.off_mine + par * slot
+
+    def wait_all_but_mine(offset):
+        flags = mesh.buf.data_ptr() + offset
+        if rank > 0:
+            cx.wait_flags_ptr(flags, rank, seq)
+        if rank + 1 < world:
+            cx.wait_flags_ptr(flags + 4 * (rank + 1), world - rank - 1, seq)
+
+    peers = [j for j in range(world) if j != rank]
+    # ---- 1. every peer's chunk, quantized straight into that peer's recv[par][rank]; then the flags ----
+    full = [j for j in peers if chunk_len(j) > 0]
+    cx.quantize_dynamic_batch_ptr([chunk_ptr(j) for j in full], fdt, [recv_ptr(j, rank) + _HEADER_BYTES for j in full], qdt, [chunk_len(j) for j in full],
+                                  [recv_ptr(j, rank) for j in full], rmode, _device_ptrs=True)
+    cx.signal_flags_ptr([mesh.flag_ptr(j, 'arrived', rank) for j in peers], seq)
+    # ---- 2./3. wait for the G-1 chunks of MY range, add them to my own values, quantize the finished chunk into mine[par] ----
+    wait_all_but_mine(mesh.off_arrived)
+    if chunk_len(rank) > 0:
+        cx.reduce_quantize_dynamic_ptr(chunk_ptr(rank), fdt, [recv_ptr(rank, i) + _HEADER_BYTES for i in peers], [recv_ptr(rank, i) for i in peers],
+                                       mine_ptr(rank) + _HEADER_BYTES, qdt, chunk_len(rank), mine_ptr(rank), rmode, _device_ptrs=True)
+    cx.signal_flags_ptr([mesh.flag_ptr(j, 'finished', rank) for j in peers], seq)
+    # ---- 4. every finished chunk, read from its owner (the own one from this rank's buffer: all ranks decode the same bytes) ----
+    wait_all_but_mine(mesh.off_finished)
+    everyone = [j for j in range(world) if chunk_len(j) > 0]
+    cx.dequantize_dp_batch_ptr([mine_ptr(j) + _HEADER_BYTES for j in everyone], qdt, [chunk_ptr(j) for j in everyone], fdt, [chunk_len(j) for j in everyone],
+                               [mine_ptr(j) for j in everyone], ReduceOp.SET, _device_ptrs=True)
     return tensor

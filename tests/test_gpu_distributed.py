@@ -116,7 +116,7 @@ def test_keys_fold_like_an_all_reduce(pg, oracle_mod):
 # gloo staged through host memory (RCCL refuses two ranks on one device); the schedule and every kernel are the real
 # ones, so each rank must reproduce the oracle simulation bit for bit.
 # ---------------------------------------------------------------------------------------------------------------
-def _ring_gpu_worker(rank, world, port, numel, qname, out_q, algorithm="ring"):
+def _ring_gpu_worker(rank, world, port, numel, qname, out_q, algorithm="ring", transport="collective", repeats=1):
     import sys
     from pathlib import Path
 
@@ -133,10 +133,13 @@ def _ring_gpu_worker(rank, world, port, numel, qname, out_q, algorithm="ring"):
         import piquant.distributed as D
 
         torch.cuda.set_device(0)
-        x = torch.from_numpy(np.random.default_rng(100 + rank).uniform(-1, 1, numel).astype(np.float32)).cuda()
-        D.quantized_all_reduce(x, quant_dtype=getattr(torch, qname), algorithm=algorithm)
+        outs = []
+        for rep in range(repeats):      # rep > 0: fresh data through the same buffers (the p2p transport alternates two parities of them)
+            x = torch.from_numpy(np.random.default_rng(100 + rank + 1000 * rep).uniform(-1, 1, numel).astype(np.float32)).cuda()
+            D.quantized_all_reduce(x, quant_dtype=getattr(torch, qname), algorithm=algorithm, transport=transport)
+            outs.append(x)
         torch.cuda.synchronize()
-        out_q.put((rank, x.cpu().numpy()))
+        out_q.put((rank, outs[0].cpu().numpy() if repeats == 1 else [o.cpu().numpy() for o in outs]))
     finally:
         dist.destroy_process_group()
 
@@ -172,6 +175,42 @@ def test_quantized_all_reduce_with_hip_kernels(oracle_mod, world, numel, qname, 
         assert np.array_equal(results[r], want[r]), r
     exact = np.sum(xs, axis=0)
     assert np.abs(results[0] - exact).max() <= world * (2.0 * world / ((1 << bits) - 1)) * 0.5 + 1e-5
+
+
+@pytest.mark.parametrize("world,numel,qname", [(2, 1_000_003, "uint8"), (3, 300_000, "quint4x2")])
+def test_quantized_all_reduce_p2p_transport_equals_the_collective_one(oracle_mod, world, numel, qname):
+    """transport='p2p': the encode kernels store straight into the peers' receive buffers (IPC-mapped device memory; here 2-3 processes on
+    the one GPU map each other's allocations), flags order the steps, the decode kernels read the finished chunks from their owners -- no
+    collective.  Three all-reduces in a row through the same buffers (both parities, and a parity reused): every rank, every time, byte
+    for byte what the oracle simulation of the mesh schedule gives -- which is what the collective transport is held to above."""
+    import sys
+
+    import torch.multiprocessing as mp
+
+    sys.path.insert(0, os.path.dirname(__file__))
+    import piquant.distributed as D
+    from ring_sim import simulate_direct
+
+    O = oracle_mod
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    reps = 3
+    procs = [ctx.Process(target=_ring_gpu_worker, args=(r, world, port, numel, qname, q, "direct", "p2p", reps)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    qd, bits = {"uint8": (O.UINT8, 8), "quint4x2": (O.UINT4, 4)}[qname]
+    for rep in range(reps):
+        xs = [np.random.default_rng(100 + r + 1000 * rep).uniform(-1, 1, numel).astype(np.float32) for r in range(world)]
+        want = simulate_direct(O, xs, qd, D.ring_chunks(numel, world, bits))
+        for r in range(world):
+            assert np.array_equal(results[r][rep], want[r]), (rep, r)
 
 
 def test_native_rccl_all_reduce_entry_point(oracle_mod):

@@ -36,7 +36,7 @@ for rot in range(6):
     if rot:
         best = min(best, (time.perf_counter() - t0) / 8)
 res["dequantize_u8_f32_set_ms"] = round(best * 1e3, 4)
-res["threads"] = ctx.num_threads()
+res["threads"] = ctx.num_threads() if callable(ctx.num_threads) else ctx.num_threads
 print(json.dumps(res))
 ''' % str(ROOT / "pi-quant_amd")
 

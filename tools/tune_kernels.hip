@@ -380,12 +380,18 @@ static void check_minmax_variants(void* buf, int64_t numel, int num_cu, int32_t*
                 CK(hipMemcpy(static_cast<char*>(buf) + (static_cast<int64_t>(k) * (numel / 3) + 777 + k) * ES, DT_IN == DT_F32 ? static_cast<const void*>(&inf32[k]) : static_cast<const void*>(&inf16[k]), ES,
                              hipMemcpyHostToDevice));
         }
+        CK(hipDeviceSynchronize());
         int32_t ref[2], got[2];
         minmax_once<DT_IN, 4, true, 512, true, false, false>(buf, numel, num_cu, keys, ref);
         bool ok = true;
-#define CHECK(U_, BLK, RAW_, POLL_, GRID)                                                     \
-    minmax_once<DT_IN, U_, true, BLK, true, RAW_, POLL_>(buf, numel, GRID, keys, got);         \
-    ok = ok && got[0] == ref[0] && got[1] == ref[1];
+#define CHECK(U_, BLK, RAW_, POLL_, GRID)                                                                                                          \
+    minmax_once<DT_IN, U_, true, BLK, true, RAW_, POLL_>(buf, numel, GRID, keys, got);                                                              \
+    if (got[0] != ref[0] || got[1] != ref[1]) {                                                                                                     \
+        ok = false;                                                                                                                                 \
+        std::printf("check,MISMATCH in=%s planted=%d U=%d block=%d raw=%d poll=%d grid=%u got=%08x %08x want=%08x %08x,0,0,0,0\n",                  \
+                    DT_IN == DT_F32 ? "f32" : "bf16", planted, U_, BLK, int(RAW_), int(POLL_), unsigned(GRID), unsigned(got[0]), unsigned(got[1]), \
+                    unsigned(ref[0]), unsigned(ref[1]));                                                                                            \
+    }
         CHECK(4, 512, true, false, num_cu)
         CHECK(4, 512, false, true, num_cu)
         CHECK(4, 512, true, true, num_cu)
@@ -394,10 +400,12 @@ static void check_minmax_variants(void* buf, int64_t numel, int num_cu, int32_t*
         CHECK(4, 256, true, false, 2 * num_cu)
         // odd sizes: ragged tail, a grid larger than the work
         minmax_once<DT_IN, 4, true, 512, true, false, false>(buf, 1000003, num_cu, keys, ref);
-        CHECK(4, 512, true, true, num_cu)
-        minmax_once<DT_IN, 4, true, 512, true, false, false>(buf, 1000003, num_cu, keys, ref);
         minmax_once<DT_IN, 4, true, 512, true, true, true>(buf, 1000003, num_cu, keys, got);
-        ok = ok && got[0] == ref[0] && got[1] == ref[1];
+        if (got[0] != ref[0] || got[1] != ref[1]) {
+            ok = false;
+            std::printf("check,MISMATCH odd size in=%s planted=%d got=%08x %08x want=%08x %08x,0,0,0,0\n", DT_IN == DT_F32 ? "f32" : "bf16", planted, unsigned(got[0]),
+                        unsigned(got[1]), unsigned(ref[0]), unsigned(ref[1]));
+        }
 #undef CHECK
         std::printf("check,minmax variants == round-3 kernel in=%s planted=%s keys=%08x %08x,%d,0,0,0\n", DT_IN == DT_F32 ? "f32" : "bf16",
                     planted == 0 ? "nothing" : (planted == 1 ? "NaNs" : "NaNs+infinities"), static_cast<unsigned>(ref[0]), static_cast<unsigned>(ref[1]), ok ? 1 : 0);
@@ -406,6 +414,68 @@ static void check_minmax_variants(void* buf, int64_t numel, int num_cu, int32_t*
             std::exit(3);
         }
     }
+}
+
+// Decomposition of the scan's cost above a read-only sweep (mode mm8): the production loop and fold with the end cut off at LEVEL
+//   0 = nothing (a lane that found a magic value stores it: the loads cannot be dropped)   1 = + wave reduction (DPP), LDS fold across the waves,
+//   one plain store per block   2 = that store as the device-scope atomic store of the gather end (no sweep: nobody reads the words)
+template <int DT_IN, int U, bool NT, int BLOCK, int LEVEL>
+__global__ void __launch_bounds__(BLOCK) scan_noend_kernel(const void* __restrict__ in, int64_t numel, unsigned long long* words, uint32_t grid) {
+    constexpr int EPV = InVec<DT_IN>::EPV;
+    constexpr int WAVES = BLOCK / 64;
+    const u32x4* __restrict__ in16 = static_cast<const u32x4*>(in);
+    const int64_t n_vec = numel / EPV;
+    const int64_t tid = static_cast<int64_t>(blockIdx.x) * BLOCK + threadIdx.x;
+    const int64_t nthreads = static_cast<int64_t>(grid) * BLOCK;
+    float lo = 3.402823466e+38f, hi = -3.402823466e+38f;
+    minmax_scan_share<U, NT>(in16, n_vec, tid, nthreads, [&](const u32x4& raw) {
+        float f[EPV];
+        InVec<DT_IN>::unpack(raw, f);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+            const float x = quieted(f[e]);
+            lo = __builtin_fminf(lo, x);
+            hi = __builtin_fmaxf(hi, x);
+        }
+    });
+    if constexpr (LEVEL == 0) {
+        if (lo == 1234.5f && hi == 1234.5f) words[0] = 1;
+        return;
+    } else {
+        lo = wave_min(lo);
+        hi = wave_max(hi);
+        __shared__ float s_lo[WAVES], s_hi[WAVES];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) {
+            s_lo[wave] = lo;
+            s_hi[wave] = hi;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) {
+                lo = __builtin_fminf(lo, s_lo[w]);
+                hi = __builtin_fmaxf(hi, s_hi[w]);
+            }
+            const unsigned long long mine = static_cast<unsigned long long>(static_cast<uint32_t>(float_to_key(lo))) |
+                                            (static_cast<unsigned long long>(static_cast<uint32_t>(float_to_key(-hi))) << 32);
+            if constexpr (LEVEL == 1) words[blockIdx.x] = mine;
+            else __hip_atomic_store(words + blockIdx.x, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+template <int DT_IN, int U, bool NT, int BLOCK, int LEVEL>
+static void run_scan_noend(const Bufs& b, int64_t numel, int num_cu, int cap, int32_t* keys) {
+    const unsigned grid = static_cast<unsigned>(cap * num_cu);
+    unsigned long long* words = reinterpret_cast<unsigned long long*>(keys + kMinmaxStateInts);
+    const double us = time_us([&](int i) {
+        hipLaunchKernelGGL((scan_noend_kernel<DT_IN, U, NT, BLOCK, LEVEL>), dim3(grid), dim3(BLOCK), 0, g_stream, b.in[i % SETS], numel, words, grid);
+    });
+    char name[160];
+    std::snprintf(name, sizeof name, "in=%s U=%d block=%d cap=%d grid=%u end cut at level %d (%s)", DT_IN == DT_F32 ? "f32" : "bf16", U, BLOCK, cap, grid, LEVEL,
+                  LEVEL == 0 ? "loop only" : (LEVEL == 1 ? "+ block reduction + plain store" : "+ device-scope store; no sweep"));
+    report("scan_noend", name, us, (DT_IN == DT_F32 ? 4.0 : 2.0) * numel);
 }
 
 // fused compute_quant_params + quantize (one launch, tensor resident on chip) against the two-launch path
@@ -1295,12 +1365,13 @@ int main(int argc, char** argv) {
         run_minmax<DT_BF16, 8, true, 256>(b, 2 * numel, num_cu, keys);
     }
 
-    if (only == "mm4") {
+    if (only == "mm5") {
         // Round 4: the scan's fold on raw words (RawFold) and a block that only sweeps (POLL), against round 3's kernel and a read-only sweep
         // with no arithmetic and no end protocol; interleaved passes, one timed batch each.  fp32 at `numel`, then bf16 at `numel` (U(-1,1) data).
         void* scratch = nullptr;
         CK(hipMalloc(&scratch, numel * 4 + 4096));
         CK(hipMemcpy(scratch, b.in[0], numel * 4, hipMemcpyDeviceToDevice));
+        CK(hipDeviceSynchronize());   // a device-to-device hipMemcpy may return before the copy has run
         check_minmax_variants<DT_F32>(scratch, numel, num_cu, keys);
         g_rounds = 1;
         auto ceiling = [&](int64_t nvec, double bytes, const char* what) {
@@ -1309,7 +1380,7 @@ int main(int argc, char** argv) {
                     hipLaunchKernelGGL((read_only_kernel<true>), dim3(cap * num_cu), dim3(256), 0, g_stream, static_cast<const u32x4*>(b.in[i % SETS]),
                                        static_cast<uint32_t*>(b.out[i % SETS]), nvec);
                 });
-                report("minmax", std::string("read-only sweep, no arithmetic, no end (") + what + ") cap=" + std::to_string(cap), us, bytes);
+                report("minmax", std::string("read-only sweep; no arithmetic; no end (") + what + ") cap=" + std::to_string(cap), us, bytes);
             }
         };
         for (int pass = 0; pass < 5; ++pass) {
@@ -1331,6 +1402,7 @@ int main(int argc, char** argv) {
             hipLaunchKernelGGL(fill_uniform_bf16, dim3(4096), dim3(256), 0, g_stream, static_cast<uint16_t*>(b.in[s_]), 2 * numel, 0x9e3779b9u * (s_ + 1));
         CK(hipStreamSynchronize(g_stream));
         CK(hipMemcpy(scratch, b.in[0], numel * 2, hipMemcpyDeviceToDevice));
+        CK(hipDeviceSynchronize());
         check_minmax_variants<DT_BF16>(scratch, numel, num_cu, keys);
         for (int pass = 0; pass < 5; ++pass) {
             ceiling(numel / 8, 2.0 * numel, "bf16");
@@ -1347,6 +1419,149 @@ int main(int argc, char** argv) {
             run_minmax<DT_BF16, 2, true, 256, true, true, true>(b, numel, num_cu, keys);
             g_mm_caps = {4};
             run_minmax<DT_BF16, 2, true, 256, true, true, true>(b, numel, num_cu, keys);
+        }
+        g_rounds = 3;
+        return 0;
+    }
+
+    if (only == "mm6") {
+        // Round 4, after the scan's ragged end moved into its rolling window (uniform rounds, clamped last round): geometry re-sweep with the
+        // raw-word fold and the sweeping-only block, fp32 then bf16 at `numel`; interleaved passes, one timed batch each.
+        void* scratch = nullptr;
+        CK(hipMalloc(&scratch, numel * 4 + 4096));
+        g_rounds = 1;
+        auto ceiling = [&](int64_t nvec, double bytes, const char* what) {
+            for (int cap : {4, 8}) {
+                const double us = time_us([&](int i) {
+                    hipLaunchKernelGGL((read_only_kernel<true>), dim3(cap * num_cu), dim3(256), 0, g_stream, static_cast<const u32x4*>(b.in[i % SETS]),
+                                       static_cast<uint32_t*>(b.out[i % SETS]), nvec);
+                });
+                report("minmax", std::string("read-only sweep; no arithmetic; no end (") + what + ") cap=" + std::to_string(cap), us, bytes);
+            }
+        };
+#define SWEEP(DT)                                                                   \
+    g_mm_caps = {1};                                                                \
+    run_minmax<DT, 4, true, 512, true, false, false>(b, numel, num_cu, keys);       \
+    run_minmax<DT, 4, true, 512, true, true, false>(b, numel, num_cu, keys);        \
+    run_minmax<DT, 4, true, 512, true, false, true>(b, numel, num_cu, keys);        \
+    run_minmax<DT, 4, true, 512, true, true, true>(b, numel, num_cu, keys);         \
+    run_minmax<DT, 2, true, 512, true, true, true>(b, numel, num_cu, keys);         \
+    run_minmax<DT, 8, true, 512, true, true, true>(b, numel, num_cu, keys);         \
+    run_minmax<DT, 2, true, 1024, true, true, true>(b, numel, num_cu, keys);        \
+    run_minmax<DT, 4, true, 1024, true, true, true>(b, numel, num_cu, keys);        \
+    g_mm_caps = {2};                                                                \
+    run_minmax<DT, 4, true, 256, true, true, true>(b, numel, num_cu, keys);         \
+    run_minmax<DT, 2, true, 256, true, true, true>(b, numel, num_cu, keys);         \
+    run_minmax<DT, 2, true, 512, true, true, true>(b, numel, num_cu, keys);         \
+    run_minmax<DT, 1, true, 512, true, true, true>(b, numel, num_cu, keys);         \
+    g_mm_caps = {4};                                                                \
+    run_minmax<DT, 4, true, 256, true, true, true>(b, numel, num_cu, keys);         \
+    run_minmax<DT, 2, true, 256, true, true, true>(b, numel, num_cu, keys);         \
+    run_minmax<DT, 1, true, 256, true, true, true>(b, numel, num_cu, keys);         \
+    run_minmax<DT, 2, true, 256, true, false, false>(b, numel, num_cu, keys);       \
+    g_mm_caps = {8};                                                                \
+    run_minmax<DT, 1, true, 256, true, true, true>(b, numel, num_cu, keys);         \
+    run_minmax<DT, 2, true, 128, true, true, true>(b, numel, num_cu, keys);
+        CK(hipMemcpy(scratch, b.in[0], numel * 4, hipMemcpyDeviceToDevice));
+        CK(hipDeviceSynchronize());
+        check_minmax_variants<DT_F32>(scratch, numel, num_cu, keys);
+        for (int pass = 0; pass < 4; ++pass) {
+            ceiling(numel / 4, 4.0 * numel, "f32");
+            SWEEP(DT_F32)
+        }
+        for (int s_ = 0; s_ < SETS; ++s_)
+            hipLaunchKernelGGL(fill_uniform_bf16, dim3(4096), dim3(256), 0, g_stream, static_cast<uint16_t*>(b.in[s_]), 2 * numel, 0x9e3779b9u * (s_ + 1));
+        CK(hipStreamSynchronize(g_stream));
+        CK(hipMemcpy(scratch, b.in[0], numel * 2, hipMemcpyDeviceToDevice));
+        CK(hipDeviceSynchronize());
+        check_minmax_variants<DT_BF16>(scratch, numel, num_cu, keys);
+        for (int pass = 0; pass < 4; ++pass) {
+            ceiling(numel / 8, 2.0 * numel, "bf16");
+            SWEEP(DT_BF16)
+        }
+#undef SWEEP
+        g_rounds = 3;
+        return 0;
+    }
+
+    if (only == "mm7") {
+        // Round 4: a read-only grid-stride sweep with ONE load in flight per wave runs at 16.6 us (fp32) / 8.8 us (bf16) with 32 waves per CU and
+        // at 18.3 / 9.9 with 16 (mm6): occupancy, not loads in flight per lane, is what the read stream wants.  The scan at high occupancy:
+        g_rounds = 1;
+        auto ceiling = [&](int64_t nvec, double bytes, const char* what) {
+            for (int cap : {4, 8}) {
+                const double us = time_us([&](int i) {
+                    hipLaunchKernelGGL((read_only_kernel<true>), dim3(cap * num_cu), dim3(256), 0, g_stream, static_cast<const u32x4*>(b.in[i % SETS]),
+                                       static_cast<uint32_t*>(b.out[i % SETS]), nvec);
+                });
+                report("minmax", std::string("read-only sweep; no arithmetic; no end (") + what + ") cap=" + std::to_string(cap), us, bytes);
+            }
+        };
+#define SWEEP(DT)                                                                   \
+    g_mm_caps = {1};                                                                \
+    run_minmax<DT, 4, true, 512, true, false, false>(b, numel, num_cu, keys);       \
+    g_mm_caps = {8};                                                                \
+    run_minmax<DT, 1, true, 256, true, false, false>(b, numel, num_cu, keys);       \
+    run_minmax<DT, 1, true, 256, true, true, false>(b, numel, num_cu, keys);        \
+    run_minmax<DT, 2, true, 256, true, false, false>(b, numel, num_cu, keys);       \
+    run_minmax<DT, 1, true, 256, false, false, false>(b, numel, num_cu, keys);      \
+    g_mm_caps = {6};                                                                \
+    run_minmax<DT, 1, true, 256, true, false, false>(b, numel, num_cu, keys);       \
+    run_minmax<DT, 2, true, 256, true, false, false>(b, numel, num_cu, keys);       \
+    g_mm_caps = {4};                                                                \
+    run_minmax<DT, 1, true, 512, true, false, false>(b, numel, num_cu, keys);       \
+    run_minmax<DT, 2, true, 512, true, false, false>(b, numel, num_cu, keys);       \
+    run_minmax<DT, 1, true, 512, true, false, true>(b, numel, num_cu, keys);        \
+    g_mm_caps = {3};                                                                \
+    run_minmax<DT, 2, true, 512, true, false, false>(b, numel, num_cu, keys);       \
+    g_mm_caps = {2};                                                                \
+    run_minmax<DT, 1, true, 1024, true, false, false>(b, numel, num_cu, keys);      \
+    run_minmax<DT, 2, true, 1024, true, false, false>(b, numel, num_cu, keys);      \
+    run_minmax<DT, 1, true, 1024, true, true, true>(b, numel, num_cu, keys);        \
+    g_mm_caps = {16};                                                               \
+    run_minmax<DT, 1, true, 128, false, false, false>(b, numel, num_cu, keys);      \
+    g_mm_caps = {8};                                                                \
+    run_minmax<DT, 2, true, 128, true, false, false>(b, numel, num_cu, keys);
+        for (int pass = 0; pass < 4; ++pass) {
+            ceiling(numel / 4, 4.0 * numel, "f32");
+            SWEEP(DT_F32)
+        }
+        for (int s_ = 0; s_ < SETS; ++s_)
+            hipLaunchKernelGGL(fill_uniform_bf16, dim3(4096), dim3(256), 0, g_stream, static_cast<uint16_t*>(b.in[s_]), 2 * numel, 0x9e3779b9u * (s_ + 1));
+        CK(hipStreamSynchronize(g_stream));
+        for (int pass = 0; pass < 4; ++pass) {
+            ceiling(numel / 8, 2.0 * numel, "bf16");
+            SWEEP(DT_BF16)
+        }
+#undef SWEEP
+        g_rounds = 3;
+        return 0;
+    }
+
+    if (only == "mm8") {
+        g_rounds = 1;
+        for (int pass = 0; pass < 4; ++pass) {
+            for (int cap : {4, 8}) {
+                const double us = time_us([&](int i) {
+                    hipLaunchKernelGGL((read_only_kernel<true>), dim3(cap * num_cu), dim3(256), 0, g_stream, static_cast<const u32x4*>(b.in[i % SETS]),
+                                       static_cast<uint32_t*>(b.out[i % SETS]), numel / 4);
+                });
+                report("minmax", std::string("read-only sweep; no arithmetic; no end (f32) cap=") + std::to_string(cap), us, 4.0 * numel);
+            }
+#define LEVELS(U_, BLK, CAP)                                                         \
+    run_scan_noend<DT_F32, U_, true, BLK, 0>(b, numel, num_cu, CAP, keys);          \
+    run_scan_noend<DT_F32, U_, true, BLK, 1>(b, numel, num_cu, CAP, keys);          \
+    run_scan_noend<DT_F32, U_, true, BLK, 2>(b, numel, num_cu, CAP, keys);          \
+    g_mm_caps = {CAP};                                                              \
+    run_minmax<DT_F32, U_, true, BLK, true, false, false>(b, numel, num_cu, keys);
+            LEVELS(1, 256, 8)
+            LEVELS(1, 256, 4)
+            LEVELS(2, 256, 4)
+            LEVELS(4, 512, 1)
+            LEVELS(2, 512, 2)
+            LEVELS(1, 512, 4)
+            LEVELS(4, 256, 2)
+#undef LEVELS
         }
         g_rounds = 3;
         return 0;
