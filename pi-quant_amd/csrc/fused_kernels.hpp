@@ -235,16 +235,15 @@ fused_params_quantize_kernel(const void* in0, uint8_t* out0, int64_t numel0, Par
     // The generation word is needed at the barrier, not before: its load is issued first and nothing looks at it until phase 1 is over.
     // (Until round 3 block 0's re-arming of the idle slot buffer stood here and used it at once -- which put an `s_waitcnt vmcnt(0)`, one
     // full device-scope memory round trip, in front of every block's first data load.)
-    // A scalar-cache load is enough: the word was last written by the PREVIOUS launch, which has completed, the scalar cache is
-    // invalidated at every kernel start (hipGraph replays included: every graph kernel node is a dispatch with its acquire), and this launch
-    // changes it only after every block has arrived -- hence started, hence read it.
-    // A vector load here, atomic or not, is followed at once by a v_readfirstlane of its result (the value is wave-uniform and the compiler
-    // wants it in an SGPR) and therefore by `s_waitcnt vmcnt(0)`; an s_load's wait lands where the value is first used.  The load is
-    // written as the instruction itself: block 0 of this same launch stores the word (atomically) later, so a plain C++ load would
-    // formally race with it and could legally be re-issued by the compiler after that store; an asm volatile statement is executed exactly
-    // once, here.  Its wait is the second statement, placed in front of the first use (gen_word()).
-    uint32_t gen_raw;
-    asm volatile("s_load_dword %0, %1, 0x0" : "=s"(gen_raw) : "s"(&st->generation) : "memory");
+    // It is a device-scope atomic load again (round 2's form): the word is written by the previous launch's block 0 with a device-scope
+    // store, and a later launch may run on an XCD whose scalar cache or L2 still holds the value from two launches ago -- rounds 3's plain
+    // load through the scalar cache relied on every dispatch invalidating both, and a hipGraph with two fused nodes of one context on
+    // dependent branches showed (round 4, once in a few runs of tests/test_gpu_parity.py::test_one_context_on_two_forked_streams_inside_one_capture)
+    // that it may not: the second node read the stale parity, folded into the buffer being re-armed and lost an extreme.  What made the
+    // atomic form slow -- the compiler moves the wave-uniform result into an SGPR (v_readfirstlane) right behind the load, and with it an
+    // `s_waitcnt vmcnt(0)` in front of every block's first data load -- is avoided by keeping the value in its VGPR, opaque to the
+    // compiler, until its first use behind phase 1 (gen_word below): the load is the oldest in flight and has long returned by then.
+    uint32_t gen_v = __hip_atomic_load(&st->generation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // ---- phase 1: load everything once; rounds [0, R_REG) stay in registers, [R_REG, R_REG + R_LDS) in LDS -------------
     float lo = 3.402823466e+38f, hi = -3.402823466e+38f;
@@ -302,8 +301,8 @@ fused_params_quantize_kernel(const void* in0, uint8_t* out0, int64_t numel0, Par
             }
         }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(gen_raw));   // the s_load above, issued a whole phase ago: every use of the word is behind this line
-    const uint32_t gen = gen_raw;
+    asm volatile("" : "+v"(gen_v));   // first use of the generation word loaded a whole phase ago: the load's wait lands here, not at the load
+    const uint32_t gen = __builtin_amdgcn_readfirstlane(gen_v);
     if (block == 0) {   // re-arm the buffer the NEXT launch will use: the previous launch read it, and that launch has completed
         if constexpr (AG) {
             if (tid < kFusedMaxBlocks) st->gathered[(gen & 1) ^ 1][tid] = kFusedNotArrived;
