@@ -301,9 +301,13 @@ static void leave_stream(piquant_context_t* ctx, hipStream_t next) {
     hipStream_t old = ctx->stream;
     if (old == next) return;
     DeviceGuard guard(ctx->device);
-    // the capturing stream that last used the scan / barrier state (order_context_state): the owner may end that capture and destroy the
-    // stream once it is replaced here; a later capture must not query or record on the stale (or recycled) handle
-    if (ctx->capture_stream == old) ctx->capture_stream = nullptr;
+    // The capturing stream that last used the scan / barrier state (order_context_state).  While `old` is still capturing it is alive, and the
+    // handle is exactly what the next captured launch on a sibling stream needs to become its graph successor (a binding switches streams
+    // for every call: main -> side inside one capture must keep the edge -- dropping the handle unconditionally here made the two fused
+    // nodes of tests/test_gpu_parity.py::test_one_context_on_two_forked_streams_inside_one_capture run side by side).  Once its capture
+    // has ended the owner may destroy it as soon as it is replaced here, and a later capture must not query or record on the stale (or
+    // recycled) handle: then it is forgotten.
+    if (ctx->capture_stream == old && !stream_is_capturing(old)) ctx->capture_stream = nullptr;
     if (ctx->scan_stream && ctx->scan_stream != next) {
         // no host wait here (a caller who scans on one stream and quantizes on another must not be stalled by switching): an event behind the
         // scan, which the next scan -- the only thing that shares the state buffer -- makes its stream wait for

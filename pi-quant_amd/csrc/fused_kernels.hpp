@@ -236,13 +236,13 @@ fused_params_quantize_kernel(const void* in0, uint8_t* out0, int64_t numel0, Par
     // (Until round 3 block 0's re-arming of the idle slot buffer stood here and used it at once -- which put an `s_waitcnt vmcnt(0)`, one
     // full device-scope memory round trip, in front of every block's first data load.)
     // It is a device-scope atomic load again (round 2's form): the word is written by the previous launch's block 0 with a device-scope
-    // store, and a later launch may run on an XCD whose scalar cache or L2 still holds the value from two launches ago -- rounds 3's plain
-    // load through the scalar cache relied on every dispatch invalidating both, and a hipGraph with two fused nodes of one context on
-    // dependent branches showed (round 4, once in a few runs of tests/test_gpu_parity.py::test_one_context_on_two_forked_streams_inside_one_capture)
-    // that it may not: the second node read the stale parity, folded into the buffer being re-armed and lost an extreme.  What made the
-    // atomic form slow -- the compiler moves the wave-uniform result into an SGPR (v_readfirstlane) right behind the load, and with it an
-    // `s_waitcnt vmcnt(0)` in front of every block's first data load -- is avoided by keeping the value in its VGPR, opaque to the
-    // compiler, until its first use behind phase 1 (gen_word below): the load is the oldest in flight and has long returned by then.
+    // store, and a later launch may run on an XCD whose scalar cache or L2 still holds the value from two launches ago -- round 3's plain
+    // load through the scalar cache relied on every dispatch (every node of a replayed hipGraph included) invalidating both, and block 0's
+    // later store to the same word made it a data race on paper (round-3 advisor).  What made the atomic form slow -- the compiler moves the
+    // wave-uniform result into an SGPR (v_readfirstlane) right behind the load, and with it an `s_waitcnt vmcnt(0)` in front of every
+    // block's first data load -- is avoided by keeping the value in its VGPR, opaque to the compiler, until its first use behind phase 1:
+    // the load is the oldest in flight and has long returned by then (one `global_load_dword ... sc1` in front of the 27 data loads, no
+    // wait before the first of them: checked in the ISA).
     uint32_t gen_v = __hip_atomic_load(&st->generation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // ---- phase 1: load everything once; rounds [0, R_REG) stay in registers, [R_REG, R_REG + R_LDS) in LDS -------------

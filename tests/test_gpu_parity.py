@@ -905,6 +905,53 @@ def test_one_context_on_two_forked_streams_inside_one_capture(O):
         assert c.barrier_bailouts() == 0 if hasattr(c, "barrier_bailouts") else True
 
 
+def test_fused_nodes_of_one_context_replayed_many_times_keep_their_generation(O):
+    """Round-3 advisor finding: the fused kernel picks one of two barrier buffers by the parity of a generation word that the previous fused
+    launch of the context bumped.  Fused nodes of one context in one hipGraph, each a successor of the one before (a forked side stream
+    included: round 4 broke that edge for a day by forgetting the capturing stream whenever the binding switched streams, and the two nodes
+    ran side by side), are the hard case -- nothing but the dispatch's own acquire stands between the bump and the read -- so the graph is
+    replayed a few hundred times with the extremes of both tensors moved around on every replay; a node that read a stale parity, or shared
+    the barrier state with its sibling, loses a block's extremes: wrong parameters, caught here."""
+    import piquant
+    import torch
+
+    n = 3_000_000
+    c = piquant.Context()
+    xa, xb = torch.empty(n, device="cuda").uniform_(-1, 1), torch.empty(n, device="cuda").uniform_(-1, 1)
+    qa, qb = torch.zeros(n, dtype=torch.uint8, device="cuda"), torch.zeros(n, dtype=torch.uint8, device="cuda")
+    ra, rb = torch.zeros(16, dtype=torch.uint8, device="cuda"), torch.zeros(16, dtype=torch.uint8, device="cuda")
+    main, side = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(main):
+        piquant.torch.quantize_dynamic(xa, dtype=torch.uint8, ctx=c, out=qa, params=ra)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(main):
+        with torch.cuda.graph(g, stream=main):
+            side.wait_stream(main)
+            piquant.torch.quantize_dynamic(xa, dtype=torch.uint8, ctx=c, out=qa, params=ra)
+            with torch.cuda.stream(side):
+                piquant.torch.quantize_dynamic(xb, dtype=torch.uint8, ctx=c, out=qb, params=rb)
+            main.wait_stream(side)
+            piquant.torch.quantize_dynamic(xb, dtype=torch.uint8, ctx=c, out=qb, params=rb)      # a third node: parity flips between replays too
+    rng = np.random.default_rng(5)
+    for it in range(300):
+        # the extremes are single planted elements whose place and value change per replay: the block that holds them changes too
+        ia, ib = int(rng.integers(0, n)), int(rng.integers(0, n))
+        ja, jb = int(rng.integers(0, n)), int(rng.integers(0, n))
+        va, vb = float(rng.uniform(2, 50)), float(rng.uniform(2, 50))
+        xa[ia], xa[ja] = va, -va * 0.5
+        xb[ib], xb[jb] = vb * 0.25, -vb
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        if ia != ja:
+            assert piquant.torch.params_to_host(ra) == piquant.quant_params_from_minmax(float(np.float32(-va * 0.5)), float(np.float32(va)), piquant.DataType.UINT8), it
+        if ib != jb:
+            assert piquant.torch.params_to_host(rb) == piquant.quant_params_from_minmax(float(np.float32(-vb)), float(np.float32(vb * 0.25)), piquant.DataType.UINT8), it
+        xa[ia], xa[ja], xb[ib], xb[jb] = 0.5, -0.5, 0.5, -0.5      # back inside (-1, 1)
+    assert c.barrier_bailouts() == 0
+
+
 def test_stream_can_be_destroyed_after_it_has_been_replaced(ctx, O):
     """A caller's stream handed to set_stream may be destroyed once the context has moved to another stream: no scan or fused launch that
     follows may touch the old handle (round-2 advisor finding: the fused-launch order and the scan kept it)."""

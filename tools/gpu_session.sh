@@ -36,7 +36,7 @@ for spec in $PHASES; do
                python -c "import json; d=json.load(open('$OUT/dtype_matrix.json')); [print(r['op'], r['in'], r['out'], r['mode'], r['us'], r['frac_of_peak']) for r in d['rows']]" ;;
     fit)       timeout 900 python tools/fit_fixed_cost.py > $OUT/fixed_cost_fit.json 2> $OUT/fixed_cost_fit.err; say "fit rc=$?" ;;
     soak)      timeout $(( ${SOAK_SECONDS:-600} + 400 )) python tools/parity_soak.py --seconds ${SOAK_SECONDS:-600} --seed ${SOAK_SEED:-404} > $OUT/parity_soak.json 2> $OUT/parity_soak.err; say "soak rc=$?"; cut -c1-1500 $OUT/parity_soak.json ;;
-    refstyle)  timeout 900 python tools/reference_style_benchmarks.py --out $OUT/reference_style.json --png $OUT/quant_benchmark.png > $OUT/reference_style.log 2>&1; say "refstyle rc=$?"; tail -15 $OUT/reference_style.log ;;
+    refstyle)  timeout 900 python tools/reference_style_benchmarks.py --plot $OUT/quant_benchmark.png > $OUT/reference_style.json 2> $OUT/reference_style.err; say "refstyle rc=$?"; cut -c1-1500 $OUT/reference_style.json; tail -3 $OUT/reference_style.err ;;
     cpunt)     timeout 900 python tools/diag_cpu_nt_stores.py > $OUT/cpu_nt_stores.json 2> $OUT/cpu_nt_stores.err; say "cpunt rc=$?"; cat $OUT/cpu_nt_stores.json ;;
     arcost)    timeout 900 python tools/all_reduce_compute_cost.py > $OUT/allreduce_cost.json 2> $OUT/allreduce_cost.err; say "arcost rc=$?"; cut -c1-2000 $OUT/allreduce_cost.json ;;
     pmc)       bash tools/pmc_all_kernels.sh 2>&1 | tail -160 ;;
