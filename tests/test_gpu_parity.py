@@ -940,14 +940,14 @@ def test_fused_nodes_of_one_context_replayed_many_times_keep_their_generation(O)
         ja, jb = int(rng.integers(0, n)), int(rng.integers(0, n))
         va, vb = float(rng.uniform(2, 50)), float(rng.uniform(2, 50))
         xa[ia], xa[ja] = va, -va * 0.5
-        xb[ib], xb[jb] = vb * 0.25, -vb
+        xb[ib], xb[jb] = vb * 0.75, -vb
         torch.cuda.synchronize()
         g.replay()
         torch.cuda.synchronize()
         if ia != ja:
             assert piquant.torch.params_to_host(ra) == piquant.quant_params_from_minmax(float(np.float32(-va * 0.5)), float(np.float32(va)), piquant.DataType.UINT8), it
         if ib != jb:
-            assert piquant.torch.params_to_host(rb) == piquant.quant_params_from_minmax(float(np.float32(-vb)), float(np.float32(vb * 0.25)), piquant.DataType.UINT8), it
+            assert piquant.torch.params_to_host(rb) == piquant.quant_params_from_minmax(float(np.float32(-vb)), float(np.float32(vb * 0.75)), piquant.DataType.UINT8), it
         xa[ia], xa[ja], xb[ib], xb[jb] = 0.5, -0.5, 0.5, -0.5      # back inside (-1, 1)
     assert c.barrier_bailouts() == 0
 
