@@ -347,6 +347,21 @@ def all_reduce_extras(args, pqd, dev, rank, world, n_total):
                                                         "ranks_bit_identical": int(lo[0]) == int(hi[0])}
         except Exception as exc:
             out[f"quantized_all_reduce_{algo}_u8"] = {"error": repr(exc)}
+    # The mesh schedule over peer-mapped buffers (no collective).  Bit-identical to the collective transport in the tests, but it has never run
+    # between two GPUs: a peer mapping that faults there would take the process -- and on rank 0 the whole line -- with it, so it is measured
+    # on request only.
+    if os.environ.get("PIQUANT_BENCH_P2P") == "1":
+        try:
+            t = timed(lambda c: pqd.quantized_all_reduce(c, quant_dtype=torch.uint8, algorithm="direct", transport="p2p"))
+            res = copies[-1]
+            err = float((res - exact).abs().max())
+            out["quantized_all_reduce_direct_u8_p2p"] = {"ms": round(t * 1e3, 4), "algbw_GB/s": round(n_total * 4 / t / 1e9, 1),
+                                                          "speedup_vs_fp32": round(out["all_reduce_fp32"]["ms"] / (t * 1e3), 3),
+                                                          "max_abs_err_vs_fp32_sum": round(err, 6), "within_bound": err <= (world * (2.0 / 255) + 2.0 * world / 255) * 0.5 + 1e-5}
+        except Exception as exc:
+            out["quantized_all_reduce_direct_u8_p2p"] = {"error": repr(exc)}
+    else:
+        out["quantized_all_reduce_direct_u8_p2p"] = "not run: set PIQUANT_BENCH_P2P=1 (peer-mapped buffers, never exercised between two GPUs)"
     del copies, exact
     # the path's only collective: 2 x int32 MIN
     keys = torch.zeros(2, dtype=torch.int32, device=dev)

@@ -78,7 +78,7 @@ def _load_native_module() -> C.CDLL:
         import torch  # noqa: F401
     except ImportError:
         pass
-    assert sys.platform.startswith('linux'), f'Unsupported platform: {sys.platform} (MI355X / ROCm is Linux-only)'
+    assert sys.platform.startswith('linux'), f'libpiquant.so for MI355X / ROCm exists for Linux only, this is {sys.platform}'
     lib_path = library_path()
     if not lib_path.exists():
         raise ImportError(

@@ -75,7 +75,7 @@ def quantize_shard(
     from .torch import packed_bytes, quantize
 
     if dtype not in _QUANT_TYPES:
-        raise ValueError(f'Unsupported quantized dtype: {dtype}')
+        raise ValueError(f'{dtype} is not a quantized dtype')
     if not tensor.is_contiguous():
         raise ValueError('quantize_shard needs a contiguous tensor: a shard is a range of the flat element order')
     qdt = torch_to_piquant_dtype(dtype)
@@ -120,7 +120,7 @@ def dequantize_shard(
     from .torch import dequantize, packed_bytes
 
     if quant_dtype not in _QUANT_TYPES:
-        raise ValueError(f'Unsupported quantized dtype: {quant_dtype}')
+        raise ValueError(f'{quant_dtype} is not a quantized dtype')
     qdt = torch_to_piquant_dtype(quant_dtype)
     raw = packed if packed.dtype == torch.uint8 else packed_bytes(packed)
     if not raw.is_contiguous() or raw.numel() < qdt.packed_nbytes(numel):
@@ -160,7 +160,7 @@ def compute_quant_params(
 ) -> Tuple[float, int]:
     """Quantization parameters of the tensor whose shards are spread over ``group`` (identical on every rank)."""
     if dtype not in _QUANT_TYPES:
-        raise ValueError(f'Unsupported quantized dtype: {dtype}')
+        raise ValueError(f'{dtype} is not a quantized dtype')
     keys = _scan(local_shard, ctx)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=group)   # the path's only collective: 8 bytes

@@ -51,7 +51,7 @@ _REDUCE_OP_CODES: dict[str, int] = {k: v.value for k, v in _REDUCE_OPS.items()}
 
 def torch_to_piquant_dtype(dtype: torch.dtype) -> DataType:
     if dtype not in _TORCH_DTYPE_MAP:
-        raise ValueError(f'Unsupported quant_dtype: {dtype}')
+        raise ValueError(f'{dtype} has no piquant counterpart (float32, bfloat16, uint8 / quint8, quint4x2, quint2x4 do)')
     return _TORCH_DTYPE_MAP[dtype]
 
 
@@ -60,7 +60,7 @@ def piquant_to_torch_dtype(dtype: DataType) -> torch.dtype:
     for torch_dtype, piquant_dtype in _TORCH_DTYPE_MAP.items():
         if piquant_dtype == dtype:
             return torch_dtype
-    raise ValueError(f'Unsupported quantized dtype: {dtype}')
+    raise ValueError(f'no torch dtype is mapped to {dtype}')
 
 
 def packed_bytes(tensor: torch.Tensor) -> torch.Tensor:
@@ -162,7 +162,7 @@ def _numel_of(shape) -> int:
 
 def compute_quant_params(tensor: torch.Tensor, *, dtype: torch.dtype, ctx: Optional[Context] = None) -> Tuple[float, int]:
     """(scale, zero_point) from the tensor's min/max (reference ``torch.py:53-67``)."""
-    assert dtype in _QUANT_TYPES, f'Unsupported quantized dtype: {dtype}. Must be one of {list(_QUANT_TYPES)}'
+    assert dtype in _QUANT_TYPES, f'dtype={dtype} is not a quantized type; choose from {[str(t) for t in _QUANT_TYPES]}'
     if not tensor.is_contiguous():
         tensor = tensor.contiguous()
     ctx = _ctx_for(tensor, ctx)
@@ -183,7 +183,7 @@ def quantize(
     out: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
     """Reference ``torch.py:70-99``; the result lives on ``tensor.device``."""
-    assert dtype in _QUANT_TYPES, f'Unsupported quantized dtype: {dtype}. Must be one of {list(_QUANT_TYPES)}'
+    assert dtype in _QUANT_TYPES, f'dtype={dtype} is not a quantized type; choose from {[str(t) for t in _QUANT_TYPES]}'
     if _native is not None and tensor.is_cuda and tensor.dtype in _DEQUANT_TYPES:
         return _native.quantize(_native_handle(tensor, ctx), tensor, scale, zero_point, dtype, _ROUND_MODE_CODES[round_mode], out)
     if not tensor.is_contiguous():
@@ -223,7 +223,7 @@ def dequantize(
 ) -> torch.Tensor:
     """Reference ``torch.py:102-129``.  ``out=`` (same shape, ``dtype``) is the accumulator for ``reduce_op='add'``."""
     if dtype not in _DEQUANT_TYPES:
-        raise ValueError(f'Unsupported dequantized dtype: {dtype}. Must be one of {list(_DEQUANT_TYPES)}')
+        raise ValueError(f'dtype={dtype} is not a float type to dequantize into; choose from {[str(t) for t in _DEQUANT_TYPES]}')
     if _native is not None and tensor.is_cuda and quant_dtype is None and shape is None and tensor.dtype in _QUANT_TYPES:
         if out is None and reduce_op == 'add':
             raise ValueError("reduce_op='add' accumulates into out=; pass the accumulator tensor")
@@ -268,7 +268,7 @@ def quantize_dequantize(
 ) -> torch.Tensor:
     """out (op)= dequantize(quantize(tensor)) in one pass over HBM -- the reference's C++-only
     ``context::quantize_dequantize_fused`` (``include/piquant.hpp:276-285``); ``out`` may be ``tensor`` (in place)."""
-    _require(quant_dtype in _QUANT_TYPES, f'Unsupported quantized dtype: {quant_dtype}')
+    _require(quant_dtype in _QUANT_TYPES, f'{quant_dtype} is not a quantized dtype')
     _check_float_input(tensor)
     if not tensor.is_contiguous():
         tensor = tensor.contiguous()
@@ -301,7 +301,7 @@ def params_to_host(params: torch.Tensor) -> Tuple[float, int]:
 def compute_quant_params_device(tensor: torch.Tensor, *, dtype: torch.dtype, ctx: Optional[Context] = None,
                                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Like ``compute_quant_params`` but asynchronous: the result is a 16-byte uint8 device tensor (the parameter record)."""
-    _require(dtype in _QUANT_TYPES, f'Unsupported quantized dtype: {dtype}')
+    _require(dtype in _QUANT_TYPES, f'{dtype} is not a quantized dtype')
     _check_float_input(tensor)
     if not tensor.is_contiguous():
         tensor = tensor.contiguous()
@@ -319,7 +319,7 @@ def quantize_dynamic(tensor: torch.Tensor, *, dtype: torch.dtype, round_mode: st
     """``compute_quant_params`` + ``quantize`` in one asynchronous call, parameters computed and kept on the device.  Returns
     (quantized, parameter record).  A tensor that fits on the chip (up to ~113 MB on an MI355X) is read from HBM once, by a single
     kernel that keeps it in registers / LDS between the min/max pass and the quantization; larger ones take two launches (scan with the parameter epilogue, then quantize)."""
-    _require(dtype in _QUANT_TYPES, f'Unsupported quantized dtype: {dtype}')
+    _require(dtype in _QUANT_TYPES, f'{dtype} is not a quantized dtype')
     _check_float_input(tensor)
     if not tensor.is_contiguous():
         tensor = tensor.contiguous()
@@ -340,7 +340,7 @@ def dequantize_dynamic(tensor: torch.Tensor, params: torch.Tensor, *, dtype: tor
                        ctx: Optional[Context] = None, out: Optional[torch.Tensor] = None, quant_dtype: Optional[torch.dtype] = None,
                        shape=None) -> torch.Tensor:
     """``dequantize`` with (scale, zero_point) read from a device parameter record."""
-    _require(dtype in _DEQUANT_TYPES, f'Unsupported dequantized dtype: {dtype}')
+    _require(dtype in _DEQUANT_TYPES, f'{dtype} is not a float dtype to dequantize into')
     _require(isinstance(tensor, torch.Tensor) and tensor.is_cuda, 'dequantize_dynamic needs a ROCm device tensor')
     if not tensor.is_contiguous():
         tensor = tensor.contiguous()
@@ -365,7 +365,7 @@ def dequantize_sum(tensors, params, *, dtype: torch.dtype, reduce_op: str = 'set
     """out (op)= sum_i dequantize(tensors[i]) with (scale, zero_point) of input i read from the device record ``params[i]``: one pass
     over the accumulator instead of ``len(tensors)``; the result equals ``dequantize_dynamic`` applied in order (first with
     ``reduce_op``, the rest with 'add') bit for bit.  The reduction step of ``piquant.distributed.quantized_all_reduce``."""
-    _require(dtype in _DEQUANT_TYPES, f'Unsupported dequantized dtype: {dtype}')
+    _require(dtype in _DEQUANT_TYPES, f'{dtype} is not a float dtype to dequantize into')
     _require(len(tensors) == len(params) and len(tensors) > 0, 'dequantize_sum needs as many parameter records as tensors, and at least one')
     first = tensors[0]
     _require(isinstance(first, torch.Tensor) and first.is_cuda, 'dequantize_sum needs ROCm device tensors')
@@ -389,7 +389,7 @@ def dequantize_sum(tensors, params, *, dtype: torch.dtype, reduce_op: str = 'set
 def quantize_dynamic_batch(tensors, *, dtype: torch.dtype, round_mode: str = 'nearest', ctx: Optional[Context] = None, outs=None, params=None):
     """``quantize_dynamic`` for a list of independent tensors of one float dtype: each gets its own (scale, zero_point) and record,
     up to 16 of them are processed by ONE kernel launch.  Returns (list of quantized tensors, list of parameter records)."""
-    _require(dtype in _QUANT_TYPES, f'Unsupported quantized dtype: {dtype}')
+    _require(dtype in _QUANT_TYPES, f'{dtype} is not a quantized dtype')
     _require(len(tensors) > 0, 'quantize_dynamic_batch needs at least one tensor')
     fdt = tensors[0].dtype
     for i, t in enumerate(tensors):
@@ -416,7 +416,7 @@ def dequantize_dynamic_batch(tensors, params, *, dtype: torch.dtype, reduce_op: 
                              quant_dtype: Optional[torch.dtype] = None, shapes=None):
     """``dequantize_dynamic`` for a list of independent quantized tensors (raw uint8 buffers with ``quant_dtype=`` and ``shapes=``, or
     quantized torch tensors) in one launch per 16; ``outs`` are required for ``reduce_op='add'``."""
-    _require(dtype in _DEQUANT_TYPES, f'Unsupported dequantized dtype: {dtype}')
+    _require(dtype in _DEQUANT_TYPES, f'{dtype} is not a float dtype to dequantize into')
     _require(len(tensors) == len(params) and len(tensors) > 0, 'dequantize_dynamic_batch needs as many parameter records as tensors, and at least one')
     _require(all(isinstance(t, torch.Tensor) and t.is_cuda for t in tensors), 'dequantize_dynamic_batch needs ROCm device tensors')
     metas = [_quant_meta(t, quant_dtype, None if shapes is None else shapes[i]) for i, t in enumerate(tensors)]
@@ -445,7 +445,7 @@ def reduce_quantize_dynamic(acc: torch.Tensor, tensors, params, *, dtype: torch.
     """(quantize(acc + sum_i dequantize(tensors[i])), record): the owner's step of a mesh all-reduce as one call -- one kernel launch
     that never writes the sum to memory when it stays on chip.  ``tensors`` are raw uint8 buffers of packed ``dtype`` values with
     ``acc.numel()`` elements each, ``params`` their device records.  The contents of ``acc`` afterwards are unspecified."""
-    _require(dtype in _QUANT_TYPES, f'Unsupported quantized dtype: {dtype}')
+    _require(dtype in _QUANT_TYPES, f'{dtype} is not a quantized dtype')
     _check_float_input(acc, 'acc')
     _require(acc.is_contiguous(), 'acc must be contiguous')
     _require(len(tensors) == len(params), 'reduce_quantize_dynamic needs as many parameter records as tensors')
