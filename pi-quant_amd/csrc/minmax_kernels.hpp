@@ -398,12 +398,36 @@ __device__ __forceinline__ void minmax_block_end_gather(float lo, float hi, cons
 // a vector has been folded its register is refilled with the vector one round ahead, so every lane keeps U loads in flight from its first
 // instruction to its last round.  (Issuing U loads, waiting for all of them and folding them before the next U -- round 1's loop -- lets a
 // wave's loads in flight drop to zero once per round; with only eight waves per CU nothing else fills the gap.)
-// Every thread runs the SAME number of rounds, ceil(n_vec / (U nthreads)), and the addresses of the last round are clamped to the tensor's
-// last vector: folding a vector twice changes no minimum and no maximum, so the ragged end needs neither predication nor a loop of its
-// own -- and its loads are issued a round ahead like all the others.  Until round 4 the vectors left over after the last FULL round were
-// loaded one at a time behind it, each waiting out a whole memory round trip with nothing else in flight: at numel 27 264 000 a bf16 scan
-// (26.0009 vectors per thread) paid two such trips, ~2 us of a 12.5 us kernel, the fp32 scan (52.0018) one in its block 0
-// (profiles/r04_tune_mm5.csv: 2.4 and 1.2 us above a read-only sweep).
+// Every thread runs the SAME number of rounds: the whole ones, then ONE ragged round whose addresses are clamped to the tensor's last
+// vector per lane (folding a vector twice changes no minimum and no maximum) and whose slots are skipped per wave when the whole wave is
+// past the end -- so the ragged end needs no loop of its own, and its loads are issued a round ahead like all the others.  Until round 4
+// the vectors left over after the last FULL round were loaded one at a time behind it, each waiting out a whole memory round trip with
+// nothing else in flight: at numel 27 264 000 a bf16 scan (26.0009 vectors per thread) paid two such trips, the fp32 scan (52.0018) one,
+// in its block 0 only.  Interleaved A/B of the three forms (profiles/r04_scan_tail_ab.csv): bf16 12.20 -> 11.94 us, fp32 19.44 -> 19.52.
+#if defined(PQ_SCAN_TAIL) && PQ_SCAN_TAIL == 0   // tune harness A/B only: round 3's loop (leftover vectors loaded one at a time behind the window)
+template <int U, bool NT, class Fold>
+__device__ __forceinline__ void minmax_scan_share(const u32x4* __restrict__ in16, int64_t n_vec, int64_t tid, int64_t nthreads, Fold&& fold) {
+    int64_t v = tid;
+    const int64_t round = static_cast<int64_t>(U) * nthreads;
+    if (v + static_cast<int64_t>(U - 1) * nthreads < n_vec) {
+        u32x4 raw[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) raw[k] = ld<NT>(in16 + v + k * nthreads);
+        while (v + round + static_cast<int64_t>(U - 1) * nthreads < n_vec) {
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                fold(raw[k]);
+                raw[k] = ld<NT>(in16 + v + round + k * nthreads);
+            }
+            v += round;
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) fold(raw[k]);
+        v += round;
+    }
+    for (; v < n_vec; v += nthreads) fold(ld<NT>(in16 + v));
+}
+#elif defined(PQ_SCAN_TAIL) && PQ_SCAN_TAIL == 1   // tune harness A/B only: uniform rounds, every slot of the last round loaded (clamped)
 template <int U, bool NT, class Fold>
 __device__ __forceinline__ void minmax_scan_share(const u32x4* __restrict__ in16, int64_t n_vec, int64_t tid, int64_t nthreads, Fold&& fold) {
     if (n_vec <= 0) return;
@@ -421,7 +445,7 @@ __device__ __forceinline__ void minmax_scan_share(const u32x4* __restrict__ in16
 #pragma unroll
         for (int k = 0; k < U; ++k) raw[k] = ld<NT>(in16 + tid + k * nthreads);
         int64_t v = tid + round;
-        for (int64_t r = 2; r < rounds; ++r) {   // refills with rounds 1 .. rounds - 2: whole rounds, no clamp
+        for (int64_t r = 2; r < rounds; ++r) {
 #pragma unroll
             for (int k = 0; k < U; ++k) {
                 fold(raw[k]);
@@ -430,7 +454,7 @@ __device__ __forceinline__ void minmax_scan_share(const u32x4* __restrict__ in16
             v += round;
         }
 #pragma unroll
-        for (int k = 0; k < U; ++k) {            // refill with the last round: clamped
+        for (int k = 0; k < U; ++k) {
             fold(raw[k]);
             const int64_t i = v + k * nthreads;
             raw[k] = ld<NT>(in16 + (i < last ? i : last));
@@ -439,6 +463,50 @@ __device__ __forceinline__ void minmax_scan_share(const u32x4* __restrict__ in16
 #pragma unroll
     for (int k = 0; k < U; ++k) fold(raw[k]);
 }
+#else
+template <int U, bool NT, class Fold>
+__device__ __forceinline__ void minmax_scan_share(const u32x4* __restrict__ in16, int64_t n_vec, int64_t tid, int64_t nthreads, Fold&& fold) {
+    if (n_vec <= 0) return;
+    const int64_t round = static_cast<int64_t>(U) * nthreads;
+    const int64_t last = n_vec - 1;
+    // index of this wave's lane 0 (wave-uniform, in SGPRs): a slot of the last round whose lane 0 is already past the end holds nothing
+    // for the whole wave and is skipped (loading it clamped instead would have 2 048 waves re-read the tensor's last 16 bytes at the same moment)
+    const int64_t wave_first = (static_cast<int64_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(tid >> 32))) << 32) |
+                               static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(tid)));
+    u32x4 raw[U];
+    bool live[U];
+    int64_t start = 0;        // first vector of the round that is loaded next; rounds below it are in raw[] or folded (no division anywhere:
+    bool held = false;        // a 64-bit quotient is ~80 instructions in front of every wave's first load)
+    if (round <= n_vec) {     // round 0 is a whole one
+#pragma unroll
+        for (int k = 0; k < U; ++k) raw[k] = ld<NT>(in16 + tid + k * nthreads);
+        held = true;
+        start = round;
+        while (start + round <= n_vec) {         // the round at `start` is whole too: fold a vector, refill its register, no clamp
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                fold(raw[k]);
+                raw[k] = ld<NT>(in16 + start + tid + k * nthreads);
+            }
+            start += round;
+        }
+    }
+    // the round at `start` is the ragged one (empty when the tensor is a whole number of rounds): its loads go out while the last whole
+    // round is folded, clamped per lane, skipped per wave
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+        if (held) fold(raw[k]);
+        live[k] = wave_first + start + k * nthreads <= last;
+        if (live[k]) {
+            const int64_t i = start + tid + k * nthreads;
+            raw[k] = ld<NT>(in16 + (i < last ? i : last));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k)
+        if (live[k]) fold(raw[k]);
+}
+#endif
 
 // `head`: leading elements in FRONT of `in` (fewer than a vector; block 0 folds them one by one): the launcher moves `in` up to the next
 // 16-byte boundary, so that a scan of a tensor that is only element-aligned (x[1:]) still runs on aligned vector loads -- which elements

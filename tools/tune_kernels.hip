@@ -1567,6 +1567,18 @@ int main(int argc, char** argv) {
         return 0;
     }
 
+    if (only == "mm9") {
+        // the production scan only (both dtypes), for A/B of BUILDS of this harness (-DPQ_SCAN_TAIL=0|1|2): interleave the binaries in the shell
+        g_rounds = 1;
+        g_mm_caps = {1};
+        for (int pass = 0; pass < 3; ++pass) run_minmax<DT_F32, 4, true, 512, true, false, false>(b, numel, num_cu, keys);
+        for (int s_ = 0; s_ < SETS; ++s_)
+            hipLaunchKernelGGL(fill_uniform_bf16, dim3(4096), dim3(256), 0, g_stream, static_cast<uint16_t*>(b.in[s_]), 2 * numel, 0x9e3779b9u * (s_ + 1));
+        CK(hipStreamSynchronize(g_stream));
+        for (int pass = 0; pass < 3; ++pass) run_minmax<DT_BF16, 4, true, 512, true, false, false>(b, numel, num_cu, keys);
+        return 0;
+    }
+
     if (only == "pair") {
         // The reference's own two-call sequence -- compute_quant_params(x), then quantize(x) -- on the same tensor, cold rotation otherwise:
         // can the scan leave x in the 256 MiB Infinity Cache for the quantize pass (109 MB at the headline size)?  Load policy of the scan
