@@ -1,7 +1,7 @@
 // A torch-free C++ process driving the REST of the additive C entry points of libpiquant.so (include/piquant_hip.h) on device buffers
 // and its own stream; tests/hip_client.cpp covers quantize_dynamic, the batched form, dequantize_dp and dequantize_sum.  Here:
 // minmax_keys + decode + params_from_minmax, compute_quant_params_device + quantize_dp, quantize_dequantize (requant), the stochastic
-// controls (pinned threshold, per-element counter hash), dequantize_dp_batch, reduce_quantize_dynamic, the three blocking-wait modes,
+// controls (pinned threshold, per-element counter hash), dequantize_dp_batch, reduce_quantize_dynamic, the four blocking-wait modes,
 // the barrier timeout + hand-over counter, reference-layout mode (1 and 3 reference threads), fusion off, the stochastic seed,
 // assume_device_pointers, reset_stream, piquant_hip_device / _version.  (piquant_hip_compute_quant_params_dist needs an RCCL communicator:
 // tests/test_gpu_distributed.py drives it through ctypes.)  Prints one line of values and
@@ -100,8 +100,8 @@ int main(int argc, char** argv) {
     piquant_hip_set_stochastic_threshold(ctx, -1.0f);
     // [6] blocking calls, one per wait mode: the three outputs must be the same bytes
     piquant_hip_set_blocking(ctx, 1);
-    uint64_t h_wait[3];
-    for (int mode = 0; mode < 3; ++mode) {
+    uint64_t h_wait[4];
+    for (int mode = 0; mode < 4; ++mode) {   // 0 sync, 1 write32, 2 kernel, 3 the work kernel's own stop event
         piquant_hip_set_blocking_wait(ctx, mode);
         CK(hipMemsetAsync(d_q, 0, n, stream));
         piquant_quantize(ctx, d_x, PIQUANT_DTYPE_F32, d_q, PIQUANT_DTYPE_UINT8, n, 1.0f / 127.0f, 128, PIQUANT_NEAREST);
@@ -109,7 +109,7 @@ int main(int argc, char** argv) {
         h_wait[mode] = fnv1a(q.data(), n);
     }
     piquant_hip_set_blocking(ctx, 0);
-    std::printf("%016llx %d ", static_cast<unsigned long long>(h_wait[0]), h_wait[0] == h_wait[1] && h_wait[1] == h_wait[2] ? 1 : 0);
+    std::printf("%016llx %d ", static_cast<unsigned long long>(h_wait[0]), h_wait[0] == h_wait[1] && h_wait[1] == h_wait[2] && h_wait[2] == h_wait[3] ? 1 : 0);
     // [8..10] one-launch params + quantize with a 1 us barrier limit (blocks hand their shares over), then the normal launch: same bytes
     piquant_hip_set_barrier_timeout_us(ctx, 1);
     piquant_hip_quantize_dynamic(ctx, d_x, PIQUANT_DTYPE_F32, d_q2, PIQUANT_DTYPE_UINT8, n, d_rec + 1, PIQUANT_NEAREST);
@@ -176,6 +176,35 @@ int main(int argc, char** argv) {
     piquant_quantize(ctx, d_x, PIQUANT_DTYPE_F32, d_q, PIQUANT_DTYPE_UINT8, n, 1.0f / 127.0f, 128, PIQUANT_NEAREST);
     CK(hipMemcpy(q.data(), d_q, n, hipMemcpyDeviceToHost));
     std::printf("%d ", fnv1a(q.data(), n) == h_wait[0] ? 1 : 0);
+    // [20] the flag calls of the peer-to-peer schedules, one process being its own peer: three flags in device memory, a stream-ordered store of
+    // sequence number 7 into each behind a quantize, a stream-ordered wait for 7 on the array, a second quantize behind the wait; then the
+    // serial-number compare (waiting for 5 when the flags hold 7 returns at once).  [21] what host buffers of a default context get.
+    piquant_hip_set_blocking(ctx, 0);
+    piquant_hip_set_stream(ctx, stream);
+    uint32_t* d_flags;
+    CK(hipMalloc(reinterpret_cast<void**>(&d_flags), 3 * sizeof(uint32_t)));
+    CK(hipMemsetAsync(d_flags, 0, 3 * sizeof(uint32_t), stream));
+    CK(hipMemsetAsync(d_q, 0, n, stream));
+    piquant_quantize(ctx, d_x, PIQUANT_DTYPE_F32, d_q2, PIQUANT_DTYPE_UINT8, n, 1.0f / 127.0f, 128, PIQUANT_NEAREST);
+    uint32_t* flag_list[3] = {d_flags + 0, d_flags + 1, d_flags + 2};
+    piquant_hip_signal_flags(ctx, flag_list, 3, 7u);
+    piquant_hip_wait_flags(ctx, d_flags, 3, 7u, 5000000u);
+    piquant_quantize(ctx, d_x, PIQUANT_DTYPE_F32, d_q, PIQUANT_DTYPE_UINT8, n, 1.0f / 127.0f, 128, PIQUANT_NEAREST);
+    piquant_hip_wait_flags(ctx, d_flags, 3, 5u, 5000000u);
+    CK(hipStreamSynchronize(stream));
+    uint32_t h_flags[3];
+    CK(hipMemcpy(h_flags, d_flags, sizeof h_flags, hipMemcpyDeviceToHost));
+    std::printf("%d ", h_flags[0] == 7u && h_flags[1] == 7u && h_flags[2] == 7u && pull_q(d_q, n) == h_wait[0] ? 1 : 0);
+    {
+        piquant_context_t* fresh = piquant_context_create(0);
+        const int dflt = piquant_hip_host_path_in_effect(fresh);
+        piquant_hip_set_host_path(fresh, PIQUANT_HIP_HOST_PATH_STAGE);
+        const int staged = piquant_hip_host_path_in_effect(fresh);
+        piquant_hip_set_host_path(fresh, PIQUANT_HIP_HOST_PATH_AUTO);
+        std::printf("%d ", (dflt == PIQUANT_HIP_HOST_PATH_STAGE || dflt == PIQUANT_HIP_HOST_PATH_CPU) && staged == PIQUANT_HIP_HOST_PATH_STAGE &&
+                               piquant_hip_host_path_in_effect(fresh) == dflt ? 1 : 0);
+        piquant_context_destroy(fresh);
+    }
     CK(hipMemcpy(rec, d_rec, sizeof rec, hipMemcpyDeviceToHost));
     std::printf("%.9g %lld %.9g %lld %d %s\n", static_cast<double>(rec[1].scale), static_cast<long long>(rec[1].zero_point), static_cast<double>(rec[2].scale),
                 static_cast<long long>(rec[2].zero_point), piquant_hip_device(ctx), std::strstr(piquant_hip_version(), "gfx950") ? "gfx950" : "?");

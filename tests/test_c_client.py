@@ -1,6 +1,7 @@
 """The C99 header is valid C and a plain C program (gcc, host buffers, no HIP headers) drives the library exactly as a
 user of the reference's C API would.  Compile checks run on CPU; the run itself needs the GPU."""
 import subprocess
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -160,7 +161,7 @@ def test_hip_client_ext_rest_of_the_extension_surface_matches_oracle(tmp_path, o
     assert int(out[4], 16) == _fnv1a(O.quantize(x, O.F32, O.UINT8, float(sc), zp, O.STOCHASTIC, 0.25).tobytes())
     assert int(out[5], 16) == _fnv1a(O.quantize_per_element(x, O.F32, O.UINT8, float(sc), zp, 0x1234567890abcdef, 77).tobytes())
     q_near = O.quantize(x, O.F32, O.UINT8, float(sc), zp)
-    assert int(out[6], 16) == _fnv1a(q_near.tobytes()) and out[7] == "1"       # three wait modes, same bytes
+    assert int(out[6], 16) == _fnv1a(q_near.tobytes()) and out[7] == "1"       # four wait modes, same bytes
     s8, z8 = O.compute_quant_params(x, O.F32, O.UINT8)
     q8 = O.quantize(x, O.F32, O.UINT8, s8, z8)
     assert int(out[8], 16) == _fnv1a(q8.tobytes()) and out[9] == "1"           # the 1 us barrier limit changes nothing but the time
@@ -177,5 +178,46 @@ def test_hip_client_ext_rest_of_the_extension_surface_matches_oracle(tmp_path, o
     base = (-wbuf.ctypes.data) % 16                                            # hipMalloc'ed output: aligned, no head
     assert int(out[15], 16) == _fnv1a(O.quantize(x, O.F32, O.UINT8, float(sc), zp, form=O.FORM_REFERENCE, threads=3, out=wbuf[base: base + n]).tobytes())
     assert out[16:20] == ["1", "1", "1", "1"]                                  # fusion off, reseeding, assume_device_pointers, reset_stream
-    assert (np.float32(float(out[20])), int(out[21]), np.float32(float(out[22])), int(out[23])) == (np.float32(s8), z8, np.float32(ss), zs)
-    assert int(out[24]) == 0 and out[25] == "gfx950"
+    assert out[20:22] == ["1", "1"]                                            # signal_flags / wait_flags on the stream; host_path_in_effect
+    assert (np.float32(float(out[22])), int(out[23]), np.float32(float(out[24])), int(out[25])) == (np.float32(s8), z8, np.float32(ss), zs)
+    assert int(out[26]) == 0 and out[27] == "gfx950"
+
+
+@pytest.mark.gpu
+def test_default_host_path_without_the_companion_library_stages(tmp_path, oracle_mod):
+    """PIQUANT_HIP_HOST_PATH_AUTO on an installation that has only libpiquant.so (no libpiquant_cpu.so next to it): host buffers are staged
+    through the GPU -- same bytes, nothing aborts -- while an explicit request for the companion still fails loudly."""
+    import shutil
+
+    O = oracle_mod
+    alone = tmp_path / "alone"
+    alone.mkdir()
+    shutil.copy(LIBDIR / "libpiquant.so", alone / "libpiquant.so")
+    code = f"""
+import ctypes, sys
+import numpy as np
+import torch                      # one HIP runtime per process: the one PyTorch bundles
+L = ctypes.CDLL({str(alone / "libpiquant.so")!r})
+L.piquant_context_create.restype = ctypes.c_void_p
+L.piquant_context_create.argtypes = [ctypes.c_size_t]
+L.piquant_hip_host_path_in_effect.argtypes = [ctypes.c_void_p]
+L.piquant_hip_set_host_path.argtypes = [ctypes.c_void_p, ctypes.c_int]
+L.piquant_quantize.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_float, ctypes.c_int64, ctypes.c_int]
+ctx = L.piquant_context_create(0)
+print("in_effect", L.piquant_hip_host_path_in_effect(ctx))
+x = np.random.default_rng(3).uniform(-1, 1, 200_003).astype(np.float32)
+q = np.zeros(x.size, dtype=np.uint8)
+L.piquant_quantize(ctx, x.ctypes.data, 0, q.ctypes.data, 4, x.size, 0.0078431377, 127, 0)
+print("sum", int(q.astype(np.int64).sum()), "first", int(q[0]))
+sys.stdout.flush()
+if len(sys.argv) > 1:
+    L.piquant_hip_set_host_path(ctx, 1)      # asks for the companion: must abort with a message
+    print("not reached")
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    x = np.random.default_rng(3).uniform(-1, 1, 200_003).astype(np.float32)
+    want = O.quantize(x, O.F32, O.UINT8, 0.0078431377, 127)
+    assert "in_effect 0" in r.stdout and f"sum {int(want.astype(np.int64).sum())} first {int(want[0])}" in r.stdout, r.stdout
+    r = subprocess.run([sys.executable, "-c", code, "insist"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "not reached" not in r.stdout and "libpiquant_cpu.so" in r.stderr, r.stderr[-1000:]
