@@ -258,3 +258,48 @@ def test_quantized_all_reduce_schedule(oracle_mod, world, numel, qname, algorith
     qmax = (1 << bits) - 1
     bound = world * (2.0 * world / qmax) * 0.5 + 1e-5
     assert np.abs(results[0] - exact).max() <= bound
+
+
+def _transport_args_worker(rank, world, port, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle as O
+        import piquant.distributed as D
+        from ring_sim import OracleOps
+
+        seen = []
+        x = torch.zeros(1000)
+        for kwargs in (dict(transport="rdma"), dict(algorithm="ring", transport="p2p"), dict(algorithm="direct", transport="p2p")):
+            try:
+                D.quantized_all_reduce(x.clone(), quant_dtype=torch.uint8, _ops=OracleOps(O), **kwargs)
+                seen.append("no error")
+            except (ValueError, RuntimeError) as exc:
+                seen.append(type(exc).__name__ + ": " + str(exc))
+        out_q.put((rank, seen))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_all_reduce_transport_argument_is_checked_before_anything_moves():
+    """transport= of quantized_all_reduce: an unknown name, the ring with the peer-to-peer transport (it has no peers to store into, only
+    neighbours), and peer-to-peer on host tensors (it maps DEVICE memory between ranks) are refused on every rank alike, so no rank is left
+    waiting in a collective the others never entered."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(__file__))
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_transport_args_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        a, b, c = results[r]
+        assert a.startswith("ValueError") and "transport" in a
+        assert b.startswith("ValueError") and "ring" in b
+        assert c.startswith("RuntimeError") and "device memory" in c
