@@ -246,6 +246,11 @@ def cpu_baseline(x_host: np.ndarray, scale: float, zp: int, budget_s: float, nse
     rb = _RefBackend()
     ref = _cpu_rotation(rb, x_host, scale, zp, budget_s * 0.6, nsets, counts, order)
     ref["sample"] = f"{rb.what}; {protocol}; best at {ref['cores']} threads"
+    if ncpu > physical and str(ncpu) in ref["GiB/s_by_threads"]:
+        ref["beyond_the_physical_cores"] = (f"{ncpu} threads = both hardware threads of every core: {ref['GiB/s_by_threads'][str(ncpu)]} GiB/s against "
+                                            f"{ref['GiB/s_by_threads'][str(physical)]} on the {physical} physical cores -- a static range split ends with its slowest worker, SMT siblings share a "
+                                            "core's load/store pipes, and the stand-in pool wakes its sleepers through a condition variable (milliseconds for 255 of them); the reference's "
+                                            "own pool is not vendored, so the physical-core count is the last point that says something about its kernels")
     ref["GiB/s_named"] = {named[t]: ref["GiB/s_by_threads"][str(t)] for t in counts if t in named}
     ref["port"] = port
     return ref
