@@ -315,9 +315,17 @@ class _PeerMesh:
 
     @classmethod
     def get(cls, group, device, slot, world, rank):
-        key = (id(group) if group is not None else 0, device.index, slot, world)
+        """The group's mesh on this device, grown when a tensor needs larger slots than it has (every rank sees the same sizes in the same order,
+        so every rank grows at the same call).  Growing is a collective (IPC exchange + barrier) behind a device synchronisation: this rank's
+        last decode -- the last reader of the peers' old buffers -- has finished before the barrier lets anybody drop them."""
+        key = (id(group) if group is not None else 0, device.index, world)
         m = cls._cache.get(key)
-        if m is None:
+        if m is None or m.slot < slot:
+            if m is not None:
+                torch.cuda.synchronize(device)
+                dist.barrier(group=group)
+                del cls._cache[key]
+                m = None
             m = cls._cache[key] = cls(group, device, slot, world, rank)
         return m
 
@@ -544,8 +552,9 @@ def _all_reduce_direct_p2p(tensor, flat, chunks, slot, quant_dtype, qdt, round_m
 
     if not tensor.is_cuda:
         raise RuntimeError("transport='p2p' moves device memory between GPUs: the tensor must live on one")
-    slot = -(-slot // 65536) * 65536    # tensors of similar size share one mesh (a mesh costs an IPC exchange and a barrier)
+    slot = -(-slot // 65536) * 65536    # coarse sizes: a mesh is grown (an IPC exchange and a barrier) only when a tensor needs more than any before it
     mesh = _PeerMesh.get(group, tensor.device, slot, world, rank)
+    slot = mesh.slot                    # the mesh's own slot size lays the buffers out (>= what this tensor needs)
     cx = _ctx_for(tensor, ctx)          # the tensor's device, PyTorch's current stream, stream-ordered
     fdt = torch_to_piquant_dtype(tensor.dtype)
     rmode = RoundMode.NEAREST if round_mode == 'nearest' else RoundMode.STOCHASTIC

@@ -116,7 +116,7 @@ def test_keys_fold_like_an_all_reduce(pg, oracle_mod):
 # gloo staged through host memory (RCCL refuses two ranks on one device); the schedule and every kernel are the real
 # ones, so each rank must reproduce the oracle simulation bit for bit.
 # ---------------------------------------------------------------------------------------------------------------
-def _ring_gpu_worker(rank, world, port, numel, qname, out_q, algorithm="ring", transport="collective", repeats=1):
+def _ring_gpu_worker(rank, world, port, numel, qname, out_q, algorithm="ring", transport="collective", repeats=1, numels=None):
     import sys
     from pathlib import Path
 
@@ -135,7 +135,8 @@ def _ring_gpu_worker(rank, world, port, numel, qname, out_q, algorithm="ring", t
         torch.cuda.set_device(0)
         outs = []
         for rep in range(repeats):      # rep > 0: fresh data through the same buffers (the p2p transport alternates two parities of them)
-            x = torch.from_numpy(np.random.default_rng(100 + rank + 1000 * rep).uniform(-1, 1, numel).astype(np.float32)).cuda()
+            n_rep = numels[rep] if numels else numel
+            x = torch.from_numpy(np.random.default_rng(100 + rank + 1000 * rep).uniform(-1, 1, n_rep).astype(np.float32)).cuda()
             D.quantized_all_reduce(x, quant_dtype=getattr(torch, qname), algorithm=algorithm, transport=transport)
             outs.append(x)
         torch.cuda.synchronize()
@@ -209,6 +210,38 @@ def test_quantized_all_reduce_p2p_transport_equals_the_collective_one(oracle_mod
     for rep in range(reps):
         xs = [np.random.default_rng(100 + r + 1000 * rep).uniform(-1, 1, numel).astype(np.float32) for r in range(world)]
         want = simulate_direct(O, xs, qd, D.ring_chunks(numel, world, bits))
+        for r in range(world):
+            assert np.array_equal(results[r][rep], want[r]), (rep, r)
+
+
+def test_quantized_all_reduce_p2p_mesh_grows_with_the_tensors(oracle_mod):
+    """One mesh per group and device, grown when a tensor needs larger slots: small, large (the mesh is rebuilt -- a collective every rank enters
+    at the same call), small again (served by the large mesh's layout), larger still; every result is the oracle simulation's."""
+    import sys
+
+    import torch.multiprocessing as mp
+
+    sys.path.insert(0, os.path.dirname(__file__))
+    import piquant.distributed as D
+    from ring_sim import simulate_direct
+
+    O = oracle_mod
+    world, numels = 2, [40_000, 900_001, 5_000, 2_000_000, 900_001]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ring_gpu_worker, args=(r, world, port, 0, "uint8", q, "direct", "p2p", len(numels), numels)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rep, n in enumerate(numels):
+        xs = [np.random.default_rng(100 + r + 1000 * rep).uniform(-1, 1, n).astype(np.float32) for r in range(world)]
+        want = simulate_direct(O, xs, O.UINT8, D.ring_chunks(n, world, 8))
         for r in range(world):
             assert np.array_equal(results[r][rep], want[r]), (rep, r)
 
