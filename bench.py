@@ -360,6 +360,7 @@ def all_reduce_extras(args, pqd, dev, rank, world, n_total):
             t = timed(lambda c: pqd.quantized_all_reduce(c, quant_dtype=torch.uint8, algorithm="direct", transport="p2p"))
             res = copies[-1]
             err = float((res - exact).abs().max())
+            pqd.release_peer_meshes()
             out["quantized_all_reduce_direct_u8_p2p"] = {"ms": round(t * 1e3, 4), "algbw_GB/s": round(n_total * 4 / t / 1e9, 1),
                                                           "speedup_vs_fp32": round(out["all_reduce_fp32"]["ms"] / (t * 1e3), 3),
                                                           "max_abs_err_vs_fp32_sum": round(err, 6), "within_bound": err <= (world * (2.0 / 255) + 2.0 * world / 255) * 0.5 + 1e-5}

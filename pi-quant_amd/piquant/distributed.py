@@ -322,12 +322,22 @@ class _PeerMesh:
         m = cls._cache.get(key)
         if m is None or m.slot < slot:
             if m is not None:
-                torch.cuda.synchronize(device)
-                dist.barrier(group=group)
-                del cls._cache[key]
-                m = None
+                cls._cache.pop(key).release(group)
             m = cls._cache[key] = cls(group, device, slot, world, rank)
         return m
+
+    def release(self, group) -> None:
+        """Collective: every rank lets go of the peers' buffers before anybody frees its own (PyTorch's CUDA-IPC bookkeeping warns when a
+        producer goes away while a consumer still holds its memory)."""
+        import gc
+
+        torch.cuda.synchronize(self.device)
+        dist.barrier(group=group)
+        self.peers = []
+        gc.collect()
+        torch.cuda.ipc_collect()
+        dist.barrier(group=group)
+        self.buf = None
 
     # views into rank j's allocation
     def recv_slot(self, j: int, parity: int, i: int, nbytes: int) -> torch.Tensor:
@@ -340,6 +350,14 @@ class _PeerMesh:
 
     def flag_ptr(self, j: int, which: str, i: int) -> int:
         return self.peers[j].data_ptr() + (self.off_arrived if which == 'arrived' else self.off_finished) + 4 * i
+
+
+def release_peer_meshes(group: Optional[dist.ProcessGroup] = None) -> None:
+    """Drops the peer-mapped buffers of ``transport='p2p'`` for ``group`` (a collective: every rank calls it, e.g. before
+    ``destroy_process_group``).  The next p2p all-reduce builds them again."""
+    gid = id(group) if group is not None else 0
+    for key in [k for k in _PeerMesh._cache if k[0] == gid]:
+        _PeerMesh._cache.pop(key).release(group)
 
 
 def _enable_peer_access(device: torch.device, peer: torch.device) -> None:

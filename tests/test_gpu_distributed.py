@@ -140,6 +140,8 @@ def _ring_gpu_worker(rank, world, port, numel, qname, out_q, algorithm="ring", t
             D.quantized_all_reduce(x, quant_dtype=getattr(torch, qname), algorithm=algorithm, transport=transport)
             outs.append(x)
         torch.cuda.synchronize()
+        if transport == "p2p":
+            D.release_peer_meshes()
         out_q.put((rank, outs[0].cpu().numpy() if repeats == 1 else [o.cpu().numpy() for o in outs]))
     finally:
         dist.destroy_process_group()
