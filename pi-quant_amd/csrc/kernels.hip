@@ -615,7 +615,7 @@ __global__ void __launch_bounds__(64) signal_flags_kernel(FlagList flags, int co
     if (static_cast<int>(threadIdx.x) < count) __hip_atomic_store(flags.ptr[threadIdx.x], value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-__global__ void __launch_bounds__(64) wait_flags_kernel(const uint32_t* flags, int count, uint32_t value, uint64_t timeout_ticks, uint32_t* timed_out) {
+__global__ void __launch_bounds__(64) wait_flags_kernel(const uint32_t* flags, int count, uint32_t value, uint64_t timeout_ticks) {
     const uint64_t t_begin = wall_clock64();
     for (int base = 0; base < count; base += 64) {
         const int i = base + static_cast<int>(threadIdx.x);
@@ -624,10 +624,7 @@ __global__ void __launch_bounds__(64) wait_flags_kernel(const uint32_t* flags, i
             if (i < count) behind = static_cast<int32_t>(__hip_atomic_load(flags + i, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0;
             if (!__any(behind ? 1 : 0)) break;
             __builtin_amdgcn_s_sleep(16);
-            if (wall_clock64() - t_begin > timeout_ticks) {   // a peer that never arrives: fail the launch loudly instead of hanging the device
-                if (threadIdx.x == 0 && timed_out != nullptr) __hip_atomic_store(timed_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __builtin_trap();
-            }
+            if (wall_clock64() - t_begin > timeout_ticks) __builtin_trap();   // a peer that never arrives: fail the launch loudly instead of hanging the device
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
@@ -645,7 +642,7 @@ void launch_signal_flags(uint32_t* const* flags, int count, uint32_t value, hipS
 
 void launch_wait_flags(const uint32_t* flags, int count, uint32_t value, uint32_t timeout_us, hipStream_t stream) {
     const uint64_t ticks = static_cast<uint64_t>(timeout_us == 0 ? 30000000u : timeout_us) * 100ull;   // wall_clock64 ticks at 100 MHz
-    hipLaunchKernelGGL(wait_flags_kernel, dim3(1), dim3(64), 0, stream, flags, count, value, ticks, static_cast<uint32_t*>(nullptr));
+    hipLaunchKernelGGL(wait_flags_kernel, dim3(1), dim3(64), 0, stream, flags, count, value, ticks);
     PQ_HIP(hipGetLastError());
 }
 

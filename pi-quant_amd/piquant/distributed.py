@@ -318,12 +318,17 @@ class _PeerMesh:
         """The group's mesh on this device, grown when a tensor needs larger slots than it has (every rank sees the same sizes in the same order,
         so every rank grows at the same call).  Growing is a collective (IPC exchange + barrier) behind a device synchronisation: this rank's
         last decode -- the last reader of the peers' old buffers -- has finished before the barrier lets anybody drop them."""
-        key = (id(group) if group is not None else 0, device.index, world)
+        owner = group if group is not None else dist.group.WORLD
+        key = (id(owner), device.index, world)
         m = cls._cache.get(key)
+        if m is not None and m.owner is not owner:      # an id recycled by a later process group: those peers are gone
+            cls._cache.pop(key)
+            m = None
         if m is None or m.slot < slot:
             if m is not None:
                 cls._cache.pop(key).release(group)
             m = cls._cache[key] = cls(group, device, slot, world, rank)
+            m.owner = owner
         return m
 
     def release(self, group) -> None:
@@ -355,8 +360,8 @@ class _PeerMesh:
 def release_peer_meshes(group: Optional[dist.ProcessGroup] = None) -> None:
     """Drops the peer-mapped buffers of ``transport='p2p'`` for ``group`` (a collective: every rank calls it, e.g. before
     ``destroy_process_group``).  The next p2p all-reduce builds them again."""
-    gid = id(group) if group is not None else 0
-    for key in [k for k in _PeerMesh._cache if k[0] == gid]:
+    owner = group if group is not None else dist.group.WORLD
+    for key in [k for k, m in _PeerMesh._cache.items() if m.owner is owner]:
         _PeerMesh._cache.pop(key).release(group)
 
 
