@@ -1020,28 +1020,11 @@ def main():
             extras["minmax_bf16"] = {"GB/s": gbs(2, e, reps), "avg_launch_us": round(e / reps * 1e6, 3), "buffer_sets": nsets,
                                      "note": "the same scan over bf16 (54.5 MB per launch: half the bytes behind the same fixed ramp and end)"}
             del xb16
-            def params_call_ms(pctx):
-                for i in range(10):
-                    piquant.torch.compute_quant_params(xs[i % nsets], dtype=torch.quint8, ctx=pctx)
-                t0 = time.perf_counter()
-                for i in range(100):
-                    piquant.torch.compute_quant_params(xs[i % nsets], dtype=torch.quint8, ctx=pctx)
-                return round((time.perf_counter() - t0) / 100 * 1e3, 5)
-
-            os.environ["PIQUANT_HIP_HOST_FOLD"] = "0"
-            ctx_device_fold = piquant.Context()
-            del os.environ["PIQUANT_HIP_HOST_FOLD"]
-            ctx_host_fold = piquant.Context()
-            ab = {"host_fold": [], "device_fold": []}
-            for _ in range(3):      # interleaved
-                ab["host_fold"].append(params_call_ms(ctx_host_fold))
-                ab["device_fold"].append(params_call_ms(ctx_device_fold))
-            extras["compute_quant_params_f32_call"] = {"ms_per_call": sorted(ab["host_fold"])[1], "ms_per_call_device_fold": sorted(ab["device_fold"])[1], "runs_ms": ab,
-                                                       "note": "full synchronous C-ABI call through piquant.torch on a device tensor (the scan kernel alone: minmax_f32).  Default: every block of "
-                                                               "the scan stores its result word into pinned host memory and the HOST folds them (no sweep on the device); "
-                                                               "device_fold (PIQUANT_HIP_HOST_FOLD=0, rounds 1-3): the highest block sweeps the words across the XCDs and publishes the "
-                                                               "folded keys into a host mailbox; interleaved, median of 3 x 100 calls each"}
-            del ctx_device_fold, ctx_host_fold
+            t0 = time.perf_counter()
+            for i in range(50):
+                piquant.torch.compute_quant_params(xs[i % nsets], dtype=torch.quint8)
+            extras["compute_quant_params_f32_call"] = {"ms_per_call": round((time.perf_counter() - t0) / 50 * 1e3, 5),
+                                                       "note": "full C-ABI call through piquant.torch: scan whose last block publishes the keys into a pinned host mailbox + host spin + double epilogue"}
             ctx.set_stream(stream.cuda_stream)
             ctx.set_blocking(False)
         # the reference's own calling convention: host buffers in, host buffers out, blocking (never `value`)

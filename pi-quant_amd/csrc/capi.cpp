@@ -11,7 +11,7 @@ using namespace pq;
 
 namespace pq {
 
-unsigned scan(piquant_context_t* ctx, const void* x, piquant_dtype_t dtype, size_t n, const MinmaxAction& action) {
+void scan(piquant_context_t* ctx, const void* x, piquant_dtype_t dtype, size_t n, const MinmaxAction& action) {
     // scans of one context share one state buffer: they must not overlap, which stream order guarantees on one stream
     // (a handle that went stale despite the rule "replace a stream before destroying it" gives an error here, not an abort: its work is over)
     if (ctx->scan_stream && ctx->scan_stream != ctx->stream && !stream_is_capturing(ctx->stream) && !stream_is_capturing(ctx->scan_stream) &&
@@ -23,13 +23,15 @@ unsigned scan(piquant_context_t* ctx, const void* x, piquant_dtype_t dtype, size
     }
     ctx->scan_stream = ctx->stream;
     order_context_state(ctx);   // captured scans of one context on parallel branches of a graph become successors of each other
-    if (action.action == MM_HOST_WORDS && (n == 0 || ctx->resolve_ptr(x).pageable)) return 0;   // the host folds words of ONE launch over device input only
     if (n == 0) {
         launch_minmax_epilogue(ctx->d_state, action, false, ctx->stream);
-        return 0;
+        return;
     }
     const Resolved r = ctx->resolve_ptr(x);
-    if (!r.pageable) return launch_minmax(r.dev, dtype, static_cast<int64_t>(n), ctx->d_state, action, ctx->stream, ctx->num_cu);
+    if (!r.pageable) {
+        launch_minmax(r.dev, dtype, static_cast<int64_t>(n), ctx->d_state, action, ctx->stream, ctx->num_cu);
+        return;
+    }
     if (stream_is_capturing(ctx->stream))
         panic("a min/max scan of host memory cannot be captured into a hipGraph (it needs staging copies and synchronisation)");
     // host input: stream it through device scratch; all chunks fold into the same slots, one fold launch at the end
@@ -45,7 +47,6 @@ unsigned scan(piquant_context_t* ctx, const void* x, piquant_dtype_t dtype, size
     }
     for (auto& s : ctx->stage_stream) PQ_HIP(hipStreamSynchronize(s));
     launch_minmax_epilogue(ctx->d_state, action, true, ctx->stream);
-    return 0;
 }
 
 }  // namespace pq
@@ -360,42 +361,8 @@ static void compute_params(piquant_context_t* ctx, const void* x, piquant_dtype_
             keys[0] = float_to_key(lo_h);
             keys[1] = float_to_key(-hi_h);
             have = true;
-        } else if (ctx->host_words_dev) {
-            // Device input.  The caller waits for the result anyway, so the grid reduction ends on the HOST: every block of the scan stores its
-            // {key(min), key(-max)} word into pinned host memory (one posted PCIe write each, all in flight together) and exits; this thread
-            // polls the words and folds them.  The device-side end of the scan -- the highest block sweeping the other blocks' words across
-            // the XCDs: three serial trips through the fabric, 1.8 us (profiles/r04_tune_mm8_summary.txt) -- is not run at all.
-            MinmaxAction a;
-            a.action = MM_HOST_WORDS;
-            a.dst = ctx->host_words_dev;
-            const unsigned blocks = scan(ctx, x, dt, n, a);   // 0: staged host input or a grid beyond the word array -- the mailbox below
-            if (blocks != 0) {
-                int32_t k0 = float_to_key(std::numeric_limits<float>::max()), k1 = k0;
-                volatile unsigned long long* words = ctx->host_words;
-                unsigned done = 0;
-                for (uint64_t spins = 0; done < blocks; ++spins) {
-                    const unsigned long long w = __atomic_load_n(&words[done], __ATOMIC_ACQUIRE);
-                    if (w != kMinmaxHostWordEmpty) {
-                        k0 = std::min(k0, static_cast<int32_t>(static_cast<uint32_t>(w)));
-                        k1 = std::min(k1, static_cast<int32_t>(static_cast<uint32_t>(w >> 32)));
-                        words[done] = kMinmaxHostWordEmpty;    // armed for the next call (the device only ever writes these words)
-                        ++done;
-                        continue;
-                    }
-                    if ((spins & 0xfff) == 0xfff) {   // every ~20 us of waiting: has the stream failed?  (finished is fine: posted writes land shortly after)
-                        const hipError_t q = hipStreamQuery(ctx->stream);
-                        if (q != hipSuccess && q != hipErrorNotReady) PQ_HIP(q);
-                        if (spins > (uint64_t {1} << 32)) panic("compute_quant_params: the scan's result words never arrived in host memory");
-                    }
-                    __builtin_ia32_pause();
-                }
-                keys[0] = k0;
-                keys[1] = k1;
-                have = true;
-            }
-        }
-        if (!have && ctx->mailbox_dev) {
-            // (staged host input, or no host word array:) the scan's last block publishes {keys, seq} straight into pinned host memory; spin on seq
+        } else if (ctx->mailbox_dev) {
+            // the scan's last block publishes {keys, seq} straight into pinned host memory; spin on seq
             const uint32_t seq = ++ctx->mailbox_seq;
             MinmaxAction a;
             a.action = MM_PUBLISH;

@@ -349,14 +349,6 @@ piquant_context_t* piquant_context_create(size_t num_threads) {
         (void)hipGetLastError();
         ctx->mailbox_dev = nullptr;   // no fine-grained host memory: compute_quant_params falls back to D2H + sync
     }
-    const size_t words_bytes = static_cast<size_t>(minmax_host_words()) * sizeof(unsigned long long);
-    if (hipHostMalloc(reinterpret_cast<void**>(&ctx->host_words), words_bytes, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
-        hipHostGetDevicePointer(&ctx->host_words_dev, ctx->host_words, 0) == hipSuccess) {
-        for (int i = 0; i < minmax_host_words(); ++i) ctx->host_words[i] = kMinmaxHostWordEmpty;
-    } else {
-        (void)hipGetLastError();
-        ctx->host_words_dev = nullptr;   // compute_quant_params then lets the device fold and publish (mailbox) as before
-    }
     if (hipHostMalloc(reinterpret_cast<void**>(&ctx->done), 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
         hipHostGetDevicePointer(&ctx->done_dev, ctx->done, 0) == hipSuccess) {
         *ctx->done = 0;
@@ -375,9 +367,6 @@ piquant_context_t* piquant_context_create(size_t num_threads) {
         if (m == "cpu") ctx->host_path = PIQUANT_HIP_HOST_PATH_CPU;
         else if (m == "stage") ctx->host_path = PIQUANT_HIP_HOST_PATH_STAGE;
         else if (m != "auto" && !m.empty()) panic("PIQUANT_HIP_HOST_PATH=%s: expected auto, stage or cpu", env);
-    }
-    if (const char* env = std::getenv("PIQUANT_HIP_HOST_FOLD")) {   // 0: compute_quant_params lets the device fold its blocks' results (A/B; the default is the host)
-        if (env[0] == '0' && env[1] == '\0') ctx->host_words_dev = nullptr;
     }
     if (const char* env = std::getenv("PIQUANT_HIP_FUSION")) ctx->fusion = !(env[0] == '0' && env[1] == '\0');
     if (const char* env = std::getenv("PIQUANT_HIP_BARRIER_TIMEOUT_US")) ctx->barrier_timeout_us = static_cast<uint32_t>(std::strtoul(env, nullptr, 10));
@@ -405,7 +394,6 @@ void piquant_context_destroy(piquant_context_t* ctx) {
         if (ctx->d_fused) (void)hipFree(ctx->d_fused);
         if (ctx->h_keys) (void)hipHostFree(ctx->h_keys);
         if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
-        if (ctx->host_words) (void)hipHostFree(ctx->host_words);
         if (ctx->done) (void)hipHostFree(ctx->done);
         if (ctx->d_dist_keys) (void)hipFree(ctx->d_dist_keys);
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

@@ -75,8 +75,6 @@ struct piquant_context_t {
     pq::MinmaxMailboxHost* mailbox = nullptr;  // pinned fine-grained host memory the fold kernel publishes into
     void* mailbox_dev = nullptr;           // its device-visible address
     uint32_t mailbox_seq = 0;
-    unsigned long long* host_words = nullptr;  // pinned fine-grained host memory, minmax_host_words() words: where the blocks of a MM_HOST_WORDS scan report
-    void* host_words_dev = nullptr;        // its device-visible address
     int32_t* d_dist_keys = nullptr;        // {key(min), key(-max)} buffer the RCCL all-reduce of the *_dist call runs on
     hipStream_t scan_stream = nullptr;     // stream of the previous scan (scans of one context must not overlap)
     hipEvent_t scan_left = nullptr;        // recorded behind the last scan of a stream the context has left since (leave_stream) ...
@@ -212,7 +210,6 @@ void fill_round_mode(piquant_context_t* ctx, QuantLaunch& q, piquant_round_mode_
 // for pageable host input; for an empty input the fold of the armed state (the identities, reference
 // kernels_specialized.inl:1422-1423).  Stream-ordered on ctx->stream except for host input, which completes before returning.
 // Caller holds ctx->mu and the device guard.
-// Returns the number of blocks of the one launch made for device input (the words a MM_HOST_WORDS scan fills), 0 otherwise.
-unsigned scan(piquant_context_t* ctx, const void* x, piquant_dtype_t dtype, size_t n, const MinmaxAction& action);
+void scan(piquant_context_t* ctx, const void* x, piquant_dtype_t dtype, size_t n, const MinmaxAction& action);
 
 }  // namespace pq

@@ -137,19 +137,17 @@ void dequantize_out(const DequantLaunch& d, const DequantParams& p, hipStream_t 
 }
 
 template <int DT_IN>
-unsigned minmax_t(const void* in, int64_t numel, int32_t* state, const MinmaxEpilogue& ep, hipStream_t stream, int num_cu) {
+void minmax_t(const void* in, int64_t numel, int32_t* state, const MinmaxEpilogue& ep, hipStream_t stream, int num_cu) {
     constexpr int EPV = InVec<DT_IN>::EPV;
     // scans that deliver a result end with the gather protocol; scans that leave their keys in the slots (EP_NONE: several staged
     // chunks of a host buffer folding into one state) keep the slot atomics
     if (reinterpret_cast<uintptr_t>(in) % (DT_IN == DT_F32 ? 4 : 2) != 0) {   // not even element-aligned; anything else is scanned with (possibly misaligned) 16-byte loads
         const unsigned grid = capped_grid((numel + kMinmaxBlock - 1) / kMinmaxBlock, 8, num_cu);
-        const bool gather = kMinmaxGatherEnd && ep.action != EP_NONE && grid <= static_cast<unsigned>(kMinmaxGatherMax);
-        if (ep.action == EP_HOST_WORDS && !gather) return 0;
-        if (gather)
+        if (kMinmaxGatherEnd && ep.action != EP_NONE && grid <= static_cast<unsigned>(kMinmaxGatherMax))
             hipLaunchKernelGGL((minmax_scalar_kernel<DT_IN, kMinmaxBlock, true>), dim3(grid), dim3(kMinmaxBlock), 0, stream, in, numel, state, ep);
         else
             hipLaunchKernelGGL((minmax_scalar_kernel<DT_IN, kMinmaxBlock, false>), dim3(grid), dim3(kMinmaxBlock), 0, stream, in, numel, state, ep);
-        return grid;
+        return;
     }
     // element-aligned but not vector-aligned input: the scan starts at the next 16-byte boundary and block 0 folds the few elements before it
     constexpr int ESIZE = DT_IN == DT_F32 ? 4 : 2;
@@ -158,18 +156,14 @@ unsigned minmax_t(const void* in, int64_t numel, int32_t* state, const MinmaxEpi
     numel -= head;
     const int64_t per_block = static_cast<int64_t>(kMinmaxBlock) * kMinmaxU * EPV;
     const unsigned grid = capped_grid((numel + per_block - 1) / per_block, kMinmaxBlocksPerCU, num_cu);
-    const bool gather = kMinmaxGatherEnd && ep.action != EP_NONE && grid <= static_cast<unsigned>(kMinmaxGatherMax);
-    if (ep.action == EP_HOST_WORDS && !gather) return 0;
-    if (gather)
+    if (kMinmaxGatherEnd && ep.action != EP_NONE && grid <= static_cast<unsigned>(kMinmaxGatherMax))
         launch_minmax_kernel<DT_IN, kMinmaxU, kMinmaxNT, kMinmaxBlock, true>(grid, stream, in, numel, state, ep, head);
     else
         launch_minmax_kernel<DT_IN, kMinmaxU, kMinmaxNT, kMinmaxBlock, false>(grid, stream, in, numel, state, ep, head);
-    return grid;
 }
 
 MinmaxEpilogue to_epilogue(const MinmaxAction& a) {
-    static_assert(MM_NONE == EP_NONE && MM_KEYS_SET == EP_KEYS_SET && MM_KEYS_MIN == EP_KEYS_MIN && MM_PUBLISH == EP_PUBLISH && MM_PARAMS == EP_PARAMS &&
-                      MM_HOST_WORDS == EP_HOST_WORDS && kMinmaxHostWordEmpty == kMinmaxNotArrived,
+    static_assert(MM_NONE == EP_NONE && MM_KEYS_SET == EP_KEYS_SET && MM_KEYS_MIN == EP_KEYS_MIN && MM_PUBLISH == EP_PUBLISH && MM_PARAMS == EP_PARAMS,
                   "host and device action codes");
     static_assert(sizeof(MinmaxMailbox) == sizeof(MinmaxMailboxHost), "mailbox layout");
     if (a.action != MM_NONE && !a.dst) panic("min/max epilogue without a destination");
@@ -602,7 +596,6 @@ void launch_minmax_epilogue(int32_t* state, const MinmaxAction& action, bool rea
 }
 
 int minmax_state_ints() { return kMinmaxScanStateInts; }
-int minmax_host_words() { return kMinmaxGatherMax; }
 
 __global__ void __launch_bounds__(64) publish_seq_kernel(uint32_t* word, uint32_t seq) {
     if (threadIdx.x == 0) __hip_atomic_store(word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -658,17 +651,15 @@ void launch_publish_seq(uint32_t* host_visible_word, uint32_t seq, hipStream_t s
     PQ_HIP(hipGetLastError());
 }
 
-unsigned launch_minmax(const void* in, int dt_in, int64_t numel, int32_t* state, const MinmaxAction& action, hipStream_t stream, int num_cu) {
+void launch_minmax(const void* in, int dt_in, int64_t numel, int32_t* state, const MinmaxAction& action, hipStream_t stream, int num_cu) {
     if (numel <= 0) panic("launch_minmax: empty input (an armed state buffer already holds the identities)");
     const MinmaxEpilogue ep = to_epilogue(action);
-    unsigned blocks = 0;
     switch (dt_in) {
-        case DT_F32: blocks = minmax_t<DT_F32>(in, numel, state, ep, stream, num_cu); break;
-        case DT_BF16: blocks = minmax_t<DT_BF16>(in, numel, state, ep, stream, num_cu); break;
+        case DT_F32: minmax_t<DT_F32>(in, numel, state, ep, stream, num_cu); break;
+        case DT_BF16: minmax_t<DT_BF16>(in, numel, state, ep, stream, num_cu); break;
         default: panic("min/max scan needs a float dtype, got %d", dt_in);
     }
     PQ_HIP(hipGetLastError());
-    return blocks;
 }
 
 }  // namespace pq

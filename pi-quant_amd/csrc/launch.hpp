@@ -103,10 +103,7 @@ void launch_requantize(const RequantLaunch& r, hipStream_t stream, int num_cu);
 //   MM_PUBLISH                 dst = device-visible address of a MinmaxMailboxHost in pinned fine-grained host memory
 //   MM_PARAMS                  dst = 16-byte device ParamRecord (scale, 1/scale, zero point) for `bits`-wide quantization
 //   MM_NONE                    keys stay in the slots (several scans into one buffer); finish with launch_minmax_epilogue
-//   MM_HOST_WORDS              dst = device-visible address of minmax_host_words() 8-byte words in pinned fine-grained host memory, all holding
-//                              kMinmaxHostWordEmpty: every block stores its own word there and the HOST folds them (launch_minmax returns how many)
-enum : int { MM_NONE = 0, MM_KEYS_SET = 1, MM_KEYS_MIN = 2, MM_PUBLISH = 3, MM_PARAMS = 4, MM_HOST_WORDS = 5 };
-constexpr unsigned long long kMinmaxHostWordEmpty = 0x7fffffff7fffffffull;   // both halves are keys of NaN patterns: never a block's result
+enum : int { MM_NONE = 0, MM_KEYS_SET = 1, MM_KEYS_MIN = 2, MM_PUBLISH = 3, MM_PARAMS = 4 };
 struct MinmaxAction {
     int action = MM_NONE;
     int bits = 0;
@@ -118,10 +115,7 @@ struct MinmaxMailboxHost {
     uint32_t seq;
     uint32_t pad;
 };
-// Returns the number of blocks launched (= words a MM_HOST_WORDS scan fills; 0 when such a scan cannot take the gather end: the caller
-// then uses another action).
-unsigned launch_minmax(const void* in, int dt_in, int64_t numel, int32_t* state, const MinmaxAction& action, hipStream_t stream, int num_cu);
-int minmax_host_words();   // capacity of the host word array a MM_HOST_WORDS scan may need
+void launch_minmax(const void* in, int dt_in, int64_t numel, int32_t* state, const MinmaxAction& action, hipStream_t stream, int num_cu);
 // Fold + epilogue as a launch of its own (after MM_NONE scans, or on an armed buffer for an empty input: identities).
 void launch_minmax_epilogue(int32_t* state, const MinmaxAction& action, bool rearm, hipStream_t stream);
 void launch_arm_slots(int32_t* state, hipStream_t stream, bool scan_state = true);   // scan_state: a minmax_state_ints() buffer (slots + per-block words)

@@ -156,9 +156,6 @@ enum : int {
     EP_KEYS_MIN = 2,    // dst = int32[2] device keys, accumulated with MIN (sharded / multi-part scans)
     EP_PUBLISH = 3,     // dst = MinmaxMailbox in pinned fine-grained host memory: keys, then the sequence number, system scope
     EP_PARAMS = 4,      // dst = ParamRecord: the (min,max) -> (scale, 1/scale, zero point) epilogue for `bits`-wide quantization
-    EP_HOST_WORDS = 5,  // dst = unsigned long long[grid] in pinned fine-grained host memory: EVERY block stores its own {key(min), key(-max)} word
-                        // there (system scope) and exits -- no sweep on the device at all; the host, which is waiting for the result anyway,
-                        // polls the words and folds them (gather end only; the synchronous compute_quant_params)
 };
 
 struct MinmaxEpilogue {
@@ -334,18 +331,6 @@ __device__ __forceinline__ void minmax_block_end_gather(float lo, float hi, cons
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long* words = reinterpret_cast<unsigned long long*>(state + kMinmaxStateInts);
     const uint32_t me = blockIdx.x;
-    if (ep.action == EP_HOST_WORDS) {   // the host folds: one store per block across PCIe, nobody sweeps, nothing to re-arm on the device
-        if (wave != 0) return;
-#pragma unroll
-        for (int w = 1; w < WAVES; ++w) {
-            lo = __builtin_fminf(lo, s_lo[w]);
-            hi = __builtin_fmaxf(hi, s_hi[w]);
-        }
-        const unsigned long long mine = static_cast<unsigned long long>(static_cast<uint32_t>(float_to_key(lo))) |
-                                        (static_cast<unsigned long long>(static_cast<uint32_t>(float_to_key(-hi))) << 32);
-        if (lane == 0) __hip_atomic_store(static_cast<unsigned long long*>(ep.dst) + me, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        return;
-    }
     if (me != G - 1) {
         if (wave != 0) return;
 #pragma unroll
