@@ -352,22 +352,6 @@ def all_reduce_extras(args, pqd, dev, rank, world, n_total):
                                                         "ranks_bit_identical": int(lo[0]) == int(hi[0])}
         except Exception as exc:
             out[f"quantized_all_reduce_{algo}_u8"] = {"error": repr(exc)}
-    # The mesh schedule over peer-mapped buffers (no collective).  Bit-identical to the collective transport in the tests, but it has never run
-    # between two GPUs: a peer mapping that faults there would take the process -- and on rank 0 the whole line -- with it, so it is measured
-    # on request only.
-    if os.environ.get("PIQUANT_BENCH_P2P") == "1":
-        try:
-            t = timed(lambda c: pqd.quantized_all_reduce(c, quant_dtype=torch.uint8, algorithm="direct", transport="p2p"))
-            res = copies[-1]
-            err = float((res - exact).abs().max())
-            pqd.release_peer_meshes()
-            out["quantized_all_reduce_direct_u8_p2p"] = {"ms": round(t * 1e3, 4), "algbw_GB/s": round(n_total * 4 / t / 1e9, 1),
-                                                          "speedup_vs_fp32": round(out["all_reduce_fp32"]["ms"] / (t * 1e3), 3),
-                                                          "max_abs_err_vs_fp32_sum": round(err, 6), "within_bound": err <= (world * (2.0 / 255) + 2.0 * world / 255) * 0.5 + 1e-5}
-        except Exception as exc:
-            out["quantized_all_reduce_direct_u8_p2p"] = {"error": repr(exc)}
-    else:
-        out["quantized_all_reduce_direct_u8_p2p"] = "not run: set PIQUANT_BENCH_P2P=1 (peer-mapped buffers, never exercised between two GPUs)"
     del copies, exact
     # the path's only collective: 2 x int32 MIN
     keys = torch.zeros(2, dtype=torch.int32, device=dev)
@@ -383,6 +367,44 @@ def all_reduce_extras(args, pqd, dev, rank, world, n_total):
     out["min_all_reduce_8_bytes"] = {"us_per_call": round(max_over_ranks((time.perf_counter() - t0) / kreps, dev, True) * 1e6, 2),
                                      "note": "dist.all_reduce(int32[2], MIN) + synchronize, one at a time: latency, not bandwidth"}
     return out, x
+
+
+def p2p_all_reduce_child_job(args, world):
+    """Rank 0 only: tools/p2p_all_reduce_bench.py as a child job of `world` ranks on the same GPUs (the mesh all-reduce over peer-mapped buffers next
+    to the collective transport and the fp32 all-reduce).  A separate job because the peer-to-peer transport has never run between two GPUs: a
+    peer mapping that faults takes the faulting PROCESS with it -- the child, not the process that owes the driver its line."""
+    import signal
+    import socket
+    import subprocess
+
+    if os.environ.get("PIQUANT_BENCH_P2P", "1") == "0":
+        return "not run: PIQUANT_BENCH_P2P=0"
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           str(ROOT / "tools" / "p2p_all_reduce_bench.py"), "--numel", str(args.numel), "--backend", args.backend] + (["--share-gpu"] if args.share_gpu else [])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE",
+                                                           "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT",
+                                                           "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    limit = float(os.environ.get("PIQUANT_BENCH_P2P_LIMIT_S", "90"))
+    try:
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            so, se = proc.communicate(timeout=limit)
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)      # the child job's own process group (start_new_session): nobody else's
+            so, se = proc.communicate()
+            return {"error": f"child job did not finish within {limit} s", "stderr_tail": se[-600:]}
+        lines = [ln for ln in so.splitlines() if ln.startswith("{")]
+        if proc.returncode != 0 or not lines:
+            return {"error": f"child job exit code {proc.returncode}", "stderr_tail": se[-600:]}
+        rec = json.loads(lines[-1])
+        rec["how"] = "tools/p2p_all_reduce_bench.py as a child job of this run (own processes and process group on the same GPUs; this run's ranks idle on the CPU meanwhile)"
+        return rec
+    except Exception as exc:
+        return {"error": repr(exc)}
 
 
 def native_dist_entry(args, ctx, shard, dev, rank, world, want):
@@ -717,6 +739,19 @@ def main():
             del _x
         except Exception as exc:
             all_reduce = {"error": repr(exc)}
+        # the peer-to-peer transport, as a child job (rank 0 starts it; everybody waits on the CPU -- a gloo barrier, not a collective kernel
+        # spinning on the GPUs the child measures on)
+        try:
+            cpu_group = dist.new_group(backend="gloo")
+            torch.cuda.synchronize()
+            dist.barrier(group=cpu_group)
+            p2p = p2p_all_reduce_child_job(args, world) if rank == 0 else None
+            dist.barrier(group=cpu_group)
+            if isinstance(all_reduce, dict) and rank == 0:
+                all_reduce["p2p_transport_child_job"] = p2p
+        except Exception as exc:
+            if isinstance(all_reduce, dict):
+                all_reduce["p2p_transport_child_job"] = {"error": repr(exc)}
         side["all_reduce_109MB"] = all_reduce
         ctx.set_stream(stream.cuda_stream)
         ctx.set_blocking(False)

@@ -505,6 +505,9 @@ def test_bench_two_ranks_sharing_the_gpu():
     for algo in ("direct", "ring"):
         rec = ar[f"quantized_all_reduce_{algo}_u8"]
         assert rec["ms"] > 0 and rec["within_bound"] is True and rec["ranks_bit_identical"] is True, rec
+    child = ar["p2p_transport_child_job"]          # the peer-to-peer transport, measured by a child job of its own
+    assert child["ranks"] == 2 and child["p2p_bit_identical_to_collective"] is True, child
+    assert child["quantized_all_reduce_direct_u8_p2p"]["within_bound"] is True and child["quantized_all_reduce_direct_u8_p2p"]["ms"] > 0
 
 
 def test_bench_own_launch_refuses_more_ranks_than_devices():
