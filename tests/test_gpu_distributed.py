@@ -398,6 +398,7 @@ def test_bench_eight_ranks_sharing_the_gpu():
     assert d["n1_reference"]["bit_exact"] is True
     ar = d["extras"]["all_reduce_109MB"]
     assert ar["quantized_all_reduce_direct_u8"]["within_bound"] and ar["quantized_all_reduce_ring_u8"]["within_bound"]
+    assert ar["p2p_transport_child_job"]["ranks"] == 8 and ar["p2p_transport_child_job"]["p2p_bit_identical_to_collective"] is True
 
 
 def test_bench_refuses_more_ranks_than_devices():
