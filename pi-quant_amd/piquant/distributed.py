@@ -366,17 +366,12 @@ def release_peer_meshes(group: Optional[dist.ProcessGroup] = None) -> None:
 
 
 def _enable_peer_access(device: torch.device, peer: torch.device) -> None:
-    """hipDeviceEnablePeerAccess(peer) on `device` (idempotent); raises when the two GPUs cannot reach each other."""
-    import ctypes
-
-    hip = ctypes.CDLL('libamdhip64.so')
-    can = ctypes.c_int(0)
-    if hip.hipDeviceCanAccessPeer(ctypes.byref(can), device.index, peer.index) != 0 or not can.value:
-        raise RuntimeError(f"transport='p2p': {device} cannot access {peer} (hipDeviceCanAccessPeer)")
-    with torch.cuda.device(device):
-        rc = hip.hipDeviceEnablePeerAccess(peer.index, 0)
-    if rc not in (0, 704):   # hipSuccess, hipErrorPeerAccessAlreadyEnabled
-        raise RuntimeError(f"transport='p2p': hipDeviceEnablePeerAccess({peer.index}) on {device} -> {rc}")
+    """Peer access from `device` to `peer`, enabled in the HIP runtime THIS process computes with: PyTorch enables it (once, both ways) the first
+    time it copies between the two devices, and the probe copy that follows this call in `_PeerMesh` is such a copy.  (Calling
+    hipDeviceEnablePeerAccess through a library handle of our own could reach a second copy of the runtime -- PyTorch-ROCm wheels bundle
+    theirs -- and enable nothing where it matters.)  Raises when the two GPUs cannot reach each other at all."""
+    if not torch.cuda.can_device_access_peer(device.index, peer.index):
+        raise RuntimeError(f"transport='p2p': {device} cannot access {peer} (no peer access between these two GPUs)")
 
 
 def ring_chunks(numel: int, world_size: int, packed_bits: int = 8, align: int = 4096):
