@@ -223,6 +223,19 @@ PIQUANT_EXPORT void piquant_hip_compute_quant_params_dist(piquant_context_t* ctx
 PIQUANT_EXPORT void piquant_hip_signal_flags(piquant_context_t* ctx, uint32_t* const* flags, size_t count, uint32_t value);
 PIQUANT_EXPORT void piquant_hip_wait_flags(piquant_context_t* ctx, const uint32_t* flags, size_t count, uint32_t value, uint32_t timeout_us);
 
+/* compute_quant_params of a sharded tensor WITHOUT a collective library, for GPUs of one node: the MIN all-reduce of the ranks' {key(min),
+ * key(-max)} pairs (the path's only exchange, 8 bytes) done by ONE one-wave kernel over peer-mapped mailboxes -- lane j stores this rank's
+ * pair into its slot of rank j's mailbox (an xGMI store) and polls slot j of the own mailbox until rank j's pair is there; the folded pair goes
+ * to out_keys (device or pinned host memory).  A collective of this size is all latency: the launch and protocol of an all-reduce against
+ * one store and one poll per peer.  Stream-ordered on the context's stream.
+ *   device_keys  this rank's int32[2] pair in device memory (piquant_hip_minmax_keys);
+ *   my_slots     `count` 8-byte words in THIS device's memory, all holding 0x7fffffff7fffffff when first used (the kernel empties what it
+ *                reads); a caller alternates between TWO such mailboxes from one exchange to the next (see piquant.distributed);
+ *   peer_slots   peer_slots[j] = the address of slot [this rank] in rank j's mailbox of the same parity (peer-mapped; j = this rank: own).
+ * A peer that never arrives fails the launch after timeout_us (0 = 30 s).  Not capturable into a hipGraph.  count <= 64. */
+PIQUANT_EXPORT void piquant_hip_exchange_minmax_keys(piquant_context_t* ctx, const int32_t* device_keys, uint64_t* const* peer_slots, uint64_t* my_slots,
+                                                     size_t count, int32_t* out_keys, uint32_t timeout_us);
+
 /* Host helpers: key <-> float, and the (min,max) -> (scale, zero_point) epilogue in double precision
  * (reference src/piquant.cpp:213-220, 245-258).  keys[0] encodes min, keys[1] encodes -max. */
 PIQUANT_EXPORT void piquant_hip_decode_minmax_keys(const int32_t keys[2], float* out_min, float* out_max);

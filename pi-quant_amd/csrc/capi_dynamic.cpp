@@ -341,4 +341,19 @@ void piquant_hip_wait_flags(piquant_context_t* ctx, const uint32_t* flags, size_
     launch_wait_flags(flags, static_cast<int>(count), value, timeout_us, ctx->stream);
 }
 
+void piquant_hip_exchange_minmax_keys(piquant_context_t* ctx, const int32_t* device_keys, uint64_t* const* peer_slots, uint64_t* my_slots, size_t count,
+                                      int32_t* out_keys, uint32_t timeout_us) {
+    if (!ctx) panic("piquant_hip_exchange_minmax_keys: context is NULL");
+    if (!device_keys || !peer_slots || !my_slots || !out_keys) panic("piquant_hip_exchange_minmax_keys: NULL argument");
+    if (count < 1 || count > static_cast<size_t>(kKeyExchangeMaxRanks)) panic("piquant_hip_exchange_minmax_keys: %zu ranks (1..%d supported)", count, kKeyExchangeMaxRanks);
+    for (size_t i = 0; i < count; ++i)
+        if (!peer_slots[i]) panic("piquant_hip_exchange_minmax_keys: NULL slot of rank %zu", i);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    if (stream_is_capturing(ctx->stream)) panic("piquant_hip_exchange_minmax_keys cannot be captured into a hipGraph: the mailbox parity changes with every exchange");
+    static_assert(sizeof(uint64_t) == sizeof(unsigned long long), "mailbox words");
+    launch_exchange_keys(device_keys, reinterpret_cast<unsigned long long* const*>(peer_slots), reinterpret_cast<unsigned long long*>(my_slots), static_cast<int>(count),
+                         out_keys, timeout_us, ctx->stream);
+}
+
 }  // extern "C"

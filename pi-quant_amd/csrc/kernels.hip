@@ -630,6 +630,50 @@ __global__ void __launch_bounds__(64) wait_flags_kernel(const uint32_t* flags, i
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 }
 
+// MIN all-reduce of one {key(min), key(-max)} word per rank over peer-mapped mailboxes, no collective library (piquant_hip_exchange_minmax_keys).
+// One wave; lane j (j < count) stores this rank's word into ITS slot of rank j's mailbox (a peer address; j == this rank: the own mailbox) and
+// then polls slot j of the OWN mailbox until rank j's word is there.  Words are valid key pairs or kKeyWordEmpty (both halves keys of NaN
+// patterns: never a scan's result); a slot is emptied again by its reader, and consecutive exchanges alternate between two mailboxes
+// (parity), so a fast peer's next word can never land in a slot that has not been read and emptied yet: it can start exchange s + 2, which
+// reuses the parity of s, only after everybody's word of s + 1 -- sent behind the sender's exchange s, emptying included -- has reached it.
+struct KeyPeers {
+    unsigned long long* slot[kKeyExchangeMaxRanks];
+};
+
+__global__ void __launch_bounds__(64) exchange_keys_kernel(const int32_t* my_keys, KeyPeers peers, unsigned long long* mine, int count, int32_t* out_keys,
+                                                            uint64_t timeout_ticks) {
+    const int lane = threadIdx.x;
+    const unsigned long long word = static_cast<unsigned long long>(static_cast<uint32_t>(my_keys[0])) | (static_cast<unsigned long long>(static_cast<uint32_t>(my_keys[1])) << 32);
+    unsigned long long got = word;   // lanes beyond the group fold this rank's own word again: harmless for a minimum
+    if (lane < count) {
+        __hip_atomic_store(peers.slot[lane], word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint64_t t_begin = wall_clock64();
+        for (;;) {
+            got = __hip_atomic_load(mine + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (got != kKeyWordEmpty) break;
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t_begin > timeout_ticks) __builtin_trap();   // a peer that never arrives: fail the launch loudly instead of hanging the device
+        }
+        __hip_atomic_store(mine + lane, kKeyWordEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // read: empty again, for the exchange after next
+    }
+    const int32_t k0 = wave_min_i32(static_cast<int32_t>(static_cast<uint32_t>(got)));
+    const int32_t k1 = wave_min_i32(static_cast<int32_t>(static_cast<uint32_t>(got >> 32)));
+    if (lane == 0) {
+        __hip_atomic_store(out_keys + 0, k0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(out_keys + 1, k1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+void launch_exchange_keys(const int32_t* my_keys, unsigned long long* const* peer_slots, unsigned long long* my_slots, int count, int32_t* out_keys, uint32_t timeout_us,
+                          hipStream_t stream) {
+    if (count < 1 || count > kKeyExchangeMaxRanks) panic("key exchange over %d ranks (1..%d supported)", count, kKeyExchangeMaxRanks);
+    KeyPeers peers {};
+    for (int i = 0; i < count; ++i) peers.slot[i] = peer_slots[i];
+    const uint64_t ticks = static_cast<uint64_t>(timeout_us == 0 ? 30000000u : timeout_us) * 100ull;
+    hipLaunchKernelGGL(exchange_keys_kernel, dim3(1), dim3(64), 0, stream, my_keys, peers, my_slots, count, out_keys, ticks);
+    PQ_HIP(hipGetLastError());
+}
+
 void launch_signal_flags(uint32_t* const* flags, int count, uint32_t value, hipStream_t stream) {
     for (int first = 0; first < count; first += kFlagListMax) {
         FlagList list {};

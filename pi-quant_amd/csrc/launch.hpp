@@ -150,6 +150,11 @@ void launch_publish_seq(uint32_t* host_visible_word, uint32_t seq, hipStream_t s
 constexpr int kFlagListMax = 32;
 void launch_signal_flags(uint32_t* const* flags, int count, uint32_t value, hipStream_t stream);
 void launch_wait_flags(const uint32_t* flags, int count, uint32_t value, uint32_t timeout_us, hipStream_t stream);
+// MIN all-reduce of one {key(min), key(-max)} word per rank through peer-mapped mailboxes (kernels.hip, exchange_keys_kernel)
+constexpr int kKeyExchangeMaxRanks = 64;
+constexpr unsigned long long kKeyWordEmpty = 0x7fffffff7fffffffull;
+void launch_exchange_keys(const int32_t* my_keys, unsigned long long* const* peer_slots, unsigned long long* my_slots, int count, int32_t* out_keys, uint32_t timeout_us,
+                          hipStream_t stream);
 size_t fused_state_bytes();
 void init_fused_state(void* state, hipStream_t stream);
 // blocks of fused launches on `state` that left their grid barrier early so far (synchronises `stream`)

@@ -317,6 +317,12 @@ class Context:
         if count:
             C.piquant_hip_wait_flags(self._ctx, flags_ptr, count, value & 0xFFFFFFFF, timeout_us)
 
+    def exchange_minmax_keys_ptr(self, keys_ptr: int, peer_slot_ptrs, my_slots_ptr: int, out_keys_ptr: int, timeout_us: int = 0) -> None:
+        """Stream-ordered MIN all-reduce of this rank's int32[2] key pair over peer-mapped mailboxes (include/piquant_hip.h,
+        piquant_hip_exchange_minmax_keys); ``peer_slot_ptrs[j]`` is this rank's slot in rank j's mailbox."""
+        n = len(peer_slot_ptrs)
+        C.piquant_hip_exchange_minmax_keys(self._ctx, keys_ptr, (_C.c_void_p * n)(*peer_slot_ptrs), my_slots_ptr, n, out_keys_ptr, timeout_us)
+
     def set_host_path(self, path: str) -> None:
         """Who serves calls on pageable HOST buffers: 'auto' (default: the companion libpiquant_cpu.so -- the same arithmetic in AVX-512 on the
         host cores, as the reference does with host tensors -- when it is present and the host has AVX-512, PCIe staging otherwise), 'stage'

@@ -156,17 +156,90 @@ def compute_quant_params(
     dtype: torch.dtype,
     group: Optional[dist.ProcessGroup] = None,
     ctx: Optional[Context] = None,
+    transport: str = 'collective',
     _scan=local_minmax_keys,
 ) -> Tuple[float, int]:
-    """Quantization parameters of the tensor whose shards are spread over ``group`` (identical on every rank)."""
+    """Quantization parameters of the tensor whose shards are spread over ``group`` (identical on every rank).
+
+    ``transport='collective'``: the local keys, ONE 8-byte ``all_reduce(MIN)`` (RCCL over xGMI), the epilogue.  ``transport='p2p'`` (GPUs of
+    one node): the same MIN over peer-mapped mailboxes by one one-wave kernel behind the scan -- a store to and a poll for every peer instead
+    of a collective's launch and protocol (``piquant_hip_exchange_minmax_keys``); same keys, hence the same parameters."""
     if dtype not in _QUANT_TYPES:
         raise ValueError(f'{dtype} is not a quantized dtype')
+    if transport not in ('collective', 'p2p'):
+        raise ValueError(f"transport must be 'collective' or 'p2p', got {transport!r}")
     keys = _scan(local_shard, ctx)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    if world > 1 and transport == 'p2p':
+        if not keys.is_cuda:
+            raise RuntimeError("transport='p2p' exchanges device memory between GPUs: the shard must live on one")
+        keys = _KeyMesh.get(group, keys.device, world, dist.get_rank(group)).exchange(keys, _ctx_for(local_shard, ctx))
+    elif world > 1:
         dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=group)   # the path's only collective: 8 bytes
     k = keys.cpu()
     r_min, r_max = decode_minmax_keys(int(k[0]), int(k[1]))
     return quant_params_from_minmax(r_min, r_max, torch_to_piquant_dtype(dtype))
+
+
+class _KeyMesh:
+    """Mailboxes of ``compute_quant_params(transport='p2p')``: per rank two arrays (parities) of ``world`` 8-byte words, every rank's mapped into
+    every other rank's address space once (the machinery of ``_PeerMesh`` below).  Word j of rank r's mailbox is where rank j stores its key
+    pair for r; a word is emptied by its reader; exchanges alternate between the parities (``include/piquant_hip.h``)."""
+
+    _EMPTY = 0x7fffffff7fffffff
+    _cache = {}
+
+    def __init__(self, group, device: torch.device, world: int, rank: int):
+        from torch.multiprocessing.reductions import reduce_tensor
+
+        self.world, self.rank, self.device = world, rank, device
+        self.buf = torch.full((2 * world,), self._EMPTY, dtype=torch.int64, device=device)
+        self.out = torch.empty(2, dtype=torch.int32, device=device)
+        torch.cuda.synchronize(device)
+        fn, args = reduce_tensor(self.buf)
+        everyone = [None] * world
+        dist.all_gather_object(everyone, (fn, args), group=group)
+        self.peers = []
+        for j, (f, a) in enumerate(everyone):
+            if j == rank:
+                self.peers.append(self.buf)
+                continue
+            t = f(*a)
+            if t.device != device:
+                _enable_peer_access(device, t.device)
+                torch.empty(2, dtype=torch.int64, device=device).copy_(t[:2])      # a runtime-managed copy first (see _PeerMesh)
+            self.peers.append(t)
+        torch.cuda.synchronize(device)
+        dist.barrier(group=group)
+        self.seq = 0
+
+    @classmethod
+    def get(cls, group, device, world, rank):
+        owner = group if group is not None else dist.group.WORLD
+        key = (id(owner), device.index, world)
+        m = cls._cache.get(key)
+        if m is None or m.owner is not owner:
+            m = cls._cache[key] = cls(group, device, world, rank)
+            m.owner = owner
+        return m
+
+    def exchange(self, keys: torch.Tensor, ctx: Context) -> torch.Tensor:
+        self.seq += 1
+        par = self.seq & 1
+        slots = [self.peers[j].data_ptr() + 8 * (par * self.world + self.rank) for j in range(self.world)]
+        ctx.exchange_minmax_keys_ptr(keys.data_ptr(), slots, self.buf.data_ptr() + 8 * par * self.world, self.out.data_ptr())
+        return self.out
+
+    def release(self, group) -> None:
+        import gc
+
+        torch.cuda.synchronize(self.device)
+        dist.barrier(group=group)
+        self.peers = []
+        gc.collect()
+        torch.cuda.ipc_collect()
+        dist.barrier(group=group)
+        self.buf = None
 
 
 # -----------------------------------------------------------------------------------------------------------------
@@ -361,8 +434,9 @@ def release_peer_meshes(group: Optional[dist.ProcessGroup] = None) -> None:
     """Drops the peer-mapped buffers of ``transport='p2p'`` for ``group`` (a collective: every rank calls it, e.g. before
     ``destroy_process_group``).  The next p2p all-reduce builds them again."""
     owner = group if group is not None else dist.group.WORLD
-    for key in [k for k, m in _PeerMesh._cache.items() if m.owner is owner]:
-        _PeerMesh._cache.pop(key).release(group)
+    for cache in (_PeerMesh._cache, _KeyMesh._cache):
+        for key in [k for k, m in cache.items() if m.owner is owner]:
+            cache.pop(key).release(group)
 
 
 def _enable_peer_access(device: torch.device, peer: torch.device) -> None:

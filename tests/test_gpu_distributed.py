@@ -248,6 +248,62 @@ def test_quantized_all_reduce_p2p_mesh_grows_with_the_tensors(oracle_mod):
             assert np.array_equal(results[r][rep], want[r]), (rep, r)
 
 
+def _p2p_params_worker(rank, world, port, numel, reps, out_q):
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    for p in (str(root), str(root / "pi-quant_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import piquant.distributed as D
+
+        torch.cuda.set_device(0)
+        got = []
+        for rep in range(reps):
+            whole = np.random.default_rng(500 + rep).normal(size=numel).astype(np.float32) * (1.0 + rep)
+            b, e = D.shard_range(numel, rank, world, 8)
+            shard = torch.from_numpy(whole[b:e]).cuda()
+            got.append((D.compute_quant_params(shard, dtype=torch.quint8, transport="p2p"), D.compute_quant_params(shard, dtype=torch.quint4x2, transport="p2p"),
+                        D.compute_quant_params(shard, dtype=torch.quint8)))     # the collective transport (gloo here) beside it
+        torch.cuda.synchronize()
+        D.release_peer_meshes()
+        out_q.put((rank, got))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_params_over_peer_mapped_mailboxes(oracle_mod, world):
+    """compute_quant_params(transport='p2p'): the 8-byte MIN all-reduce done by one one-wave kernel per rank over peer-mapped mailboxes (here
+    the mailboxes of 2-3 processes on the one GPU) instead of a collective.  Seven exchanges in a row -- both mailbox parities, each reused
+    several times -- with the extremes moving between the shards: every rank, every time, the parameters of the whole tensor."""
+    import torch.multiprocessing as mp
+
+    O = oracle_mod
+    numel, reps = 1_000_003, 7
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_p2p_params_worker, args=(r, world, port, numel, reps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rep in range(reps):
+        whole = np.random.default_rng(500 + rep).normal(size=numel).astype(np.float32) * np.float32(1.0 + rep)
+        want8, want4 = O.compute_quant_params(whole, O.F32, O.UINT8), O.compute_quant_params(whole, O.F32, O.UINT4)
+        for r in range(world):
+            assert results[r][rep] == (want8, want4, want8), (rep, r)
+
+
 def test_native_rccl_all_reduce_entry_point(oracle_mod):
     """piquant_hip_compute_quant_params_dist: the C-level sharded call that runs ncclAllReduce itself (RCCL resolved from the
     copy already loaded in the process).  One rank here -- the box has one GPU -- which still drives the whole path: scan,
