@@ -89,6 +89,39 @@ def main():
         out[f"quantized_all_reduce_direct_u8_{name}"] = {"ms": round(t * 1e3, 4), "algbw_GB/s": round(n * 4 / t / 1e9, 1), "speedup_vs_fp32": round(t_fp32 / t, 3),
                                                          "max_abs_err_vs_fp32_sum": round(err, 6), "within_bound": err <= bound}
     out["p2p_bit_identical_to_collective"] = bool(torch.equal(results["collective"].view(torch.int32), results["p2p"].view(torch.int32)))
+    del copies, results, exact
+    # BASELINE configs[4] (compute_quant_params of a 2^30-element tensor over the ranks): the same call with its 8-byte MIN all-reduce done by the
+    # backend's collective and by the one-wave mailbox kernel
+    total = 1 << 30
+    b5, e5 = pqd.shard_range(total, rank, world, 8)
+    g5 = torch.Generator(device=dev)
+    g5.manual_seed(77 + rank)
+    shard = torch.empty(e5 - b5, dtype=torch.float32, device=dev).uniform_(-1.0, 1.0, generator=g5)
+    if rank == 0:
+        shard[12345] = -7.5
+    if rank == world - 1:
+        shard[-6] = 9.25
+    cfg5 = {"numel_total": total, "numel_per_gpu": e5 - b5}
+    for name in ("collective", "p2p"):
+        for _ in range(3):
+            got = pqd.compute_quant_params(shard, dtype=torch.quint8, transport=name)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            got = pqd.compute_quant_params(shard, dtype=torch.quint8, transport=name)
+        t = torch.tensor([(time.perf_counter() - t0) / 20], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX) if args.backend != "nccl" else None
+        if args.backend == "nccl":
+            td = t.to(dev)
+            dist.all_reduce(td, op=dist.ReduceOp.MAX)
+            t = td.cpu()
+        cfg5[f"ms_per_call_{name}"] = round(float(t[0]) * 1e3, 5)
+        cfg5[f"result_{name}"] = list(got)
+    import piquant
+
+    cfg5["both_correct"] = tuple(cfg5["result_collective"]) == tuple(cfg5["result_p2p"]) == piquant.quant_params_from_minmax(-7.5, 9.25, piquant.DataType.UINT8)
+    out["config5_compute_quant_params_2p30"] = cfg5
     pqd.release_peer_meshes()
     if rank == 0:
         print(json.dumps(out), flush=True)
