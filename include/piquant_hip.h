@@ -212,6 +212,19 @@ PIQUANT_EXPORT void piquant_hip_compute_quant_params_dist(piquant_context_t* ctx
                                                           size_t n_local, piquant_dtype_t target_quant_dtype, void* nccl_comm,
                                                           float* out_scale, int64_t* out_zero_point);
 
+/* Device memory that other GPUs of the node -- or other processes on this GPU -- may map into their address space (HIP IPC), the ground the
+ * peer-to-peer schedules below stand on.  piquant_hip_peer_alloc allocates `bytes` (a multiple of 4) on the context's device, fills them with
+ * fill_word, and writes the allocation's 64-byte IPC handle to out_ipc_handle -- to be carried to the peers by whatever the caller has (a
+ * torch.distributed all_gather, MPI, a socket).  fine_grained != 0 gives memory that stays coherent with other agents WHILE kernels run: flags
+ * and mailboxes that another GPU writes and a kernel of this one polls; payload buffers that are consumed by a LATER launch may be ordinary
+ * (coarse-grained) memory, which is faster.  piquant_hip_peer_open maps a peer's allocation for this context's device (peer access is enabled
+ * on the way) and returns the local address; close before the owner frees.  Abort with a message on any HIP error, as everywhere. */
+#define PIQUANT_HIP_IPC_HANDLE_BYTES 64
+PIQUANT_EXPORT void* piquant_hip_peer_alloc(piquant_context_t* ctx, size_t bytes, int fine_grained, uint32_t fill_word, void* out_ipc_handle);
+PIQUANT_EXPORT void* piquant_hip_peer_open(piquant_context_t* ctx, const void* ipc_handle);
+PIQUANT_EXPORT void piquant_hip_peer_close(piquant_context_t* ctx, void* mapped);
+PIQUANT_EXPORT void piquant_hip_peer_free(piquant_context_t* ctx, void* allocated);
+
 /* Flags for peer-to-peer schedules between GPUs (or between processes on one GPU): sequence numbers in device memory that a peer
  * writes and the owner polls -- what lets a quantize kernel store its bytes straight into a peer's receive buffer (an address obtained from
  * hipIpcOpenMemHandle or a peer-accessible allocation) instead of local write -> collective -> local read (piquant.distributed,

@@ -3,6 +3,8 @@
 // fits on the chip), its batched form and the reduce variant.
 #include "context.hpp"
 
+#include <cstring>
+
 using namespace pq;
 
 // out (op)= sum of the dequantized inputs, stream-ordered; caller holds ctx->mu and the device guard, and waits if the context is blocking
@@ -339,6 +341,54 @@ void piquant_hip_wait_flags(piquant_context_t* ctx, const uint32_t* flags, size_
     DeviceGuard guard(ctx->device);
     if (stream_is_capturing(ctx->stream)) panic("piquant_hip_wait_flags cannot be captured into a hipGraph: the value waited for changes with every exchange");
     launch_wait_flags(flags, static_cast<int>(count), value, timeout_us, ctx->stream);
+}
+
+void* piquant_hip_peer_alloc(piquant_context_t* ctx, size_t bytes, int fine_grained, uint32_t fill_word, void* out_ipc_handle) {
+    if (!ctx) panic("piquant_hip_peer_alloc: context is NULL");
+    if (bytes == 0 || bytes % 4 != 0) panic("piquant_hip_peer_alloc: %zu bytes (a positive multiple of 4 is needed)", bytes);
+    if (!out_ipc_handle) panic("piquant_hip_peer_alloc: NULL handle buffer");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    void* p = nullptr;
+    // fine-grained: words ANOTHER device writes while a kernel of this one polls them (flags, mailboxes) -- coarse-grained device memory
+    // is only coherent with other agents at kernel boundaries
+    if (fine_grained) PQ_HIP(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained));
+    else PQ_HIP(hipMalloc(&p, bytes));
+    PQ_HIP(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p), static_cast<int>(fill_word), bytes / 4));
+    PQ_HIP(hipDeviceSynchronize());
+    static_assert(sizeof(hipIpcMemHandle_t) == PIQUANT_HIP_IPC_HANDLE_BYTES, "IPC handle size");
+    hipIpcMemHandle_t h;
+    PQ_HIP(hipIpcGetMemHandle(&h, p));
+    std::memcpy(out_ipc_handle, &h, sizeof h);
+    return p;
+}
+
+void* piquant_hip_peer_open(piquant_context_t* ctx, const void* ipc_handle) {
+    if (!ctx) panic("piquant_hip_peer_open: context is NULL");
+    if (!ipc_handle) panic("piquant_hip_peer_open: NULL handle");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, ipc_handle, sizeof h);
+    void* p = nullptr;
+    PQ_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));   // maps the peer's allocation for THIS device (peer access enabled on the way)
+    return p;
+}
+
+void piquant_hip_peer_close(piquant_context_t* ctx, void* mapped) {
+    if (!ctx) panic("piquant_hip_peer_close: context is NULL");
+    if (!mapped) return;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    PQ_HIP(hipIpcCloseMemHandle(mapped));
+}
+
+void piquant_hip_peer_free(piquant_context_t* ctx, void* allocated) {
+    if (!ctx) panic("piquant_hip_peer_free: context is NULL");
+    if (!allocated) return;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    PQ_HIP(hipFree(allocated));
 }
 
 void piquant_hip_exchange_minmax_keys(piquant_context_t* ctx, const int32_t* device_keys, uint64_t* const* peer_slots, uint64_t* my_slots, size_t count,

@@ -305,6 +305,23 @@ class Context:
         arr_p = (_C.c_void_p * n)(*params_ptrs)
         C.piquant_hip_dequantize_sum(self._ctx, arr_in, arr_p, n, dtype_in.value, ptr_out, dtype_out.value, numel, reduce_op.value)
 
+    def peer_alloc(self, nbytes: int, fine_grained: bool, fill_word: int = 0):
+        """-> (device address, 64-byte IPC handle) of a fresh allocation other GPUs / processes of the node may map (include/piquant_hip.h)."""
+        handle = _C.create_string_buffer(64)
+        ptr = C.piquant_hip_peer_alloc(self._ctx, nbytes, 1 if fine_grained else 0, fill_word & 0xFFFFFFFF, handle)
+        return int(ptr), bytes(handle.raw)
+
+    def peer_open(self, handle: bytes) -> int:
+        """Local address of a peer's allocation (its 64-byte IPC handle from ``peer_alloc`` on the peer)."""
+        assert len(handle) == 64
+        return int(C.piquant_hip_peer_open(self._ctx, _C.create_string_buffer(handle, 64)))
+
+    def peer_close(self, ptr: int) -> None:
+        C.piquant_hip_peer_close(self._ctx, ptr)
+
+    def peer_free(self, ptr: int) -> None:
+        C.piquant_hip_peer_free(self._ctx, ptr)
+
     def signal_flags_ptr(self, flag_ptrs, value: int) -> None:
         """Stream-ordered: store ``value`` into every flag address (peers' memory) once the work enqueued so far has completed
         (include/piquant_hip.h, piquant_hip_signal_flags)."""

@@ -51,6 +51,10 @@ _DECLS = [
     ('piquant_hip_dequantize_dp', None, [_vp, _vp, _int, _vp, _int, _sz, _vp, _int]),
     ('piquant_hip_compute_quant_params_dist', None, [_vp, _vp, _int, _sz, _int, _vp, C.POINTER(_f32), C.POINTER(_i64)]),
     ('piquant_hip_minmax_keys', None, [_vp, _vp, _int, _sz, _vp, _int]),
+    ('piquant_hip_peer_alloc', _vp, [_vp, _sz, _int, C.c_uint32, _vp]),
+    ('piquant_hip_peer_open', _vp, [_vp, _vp]),
+    ('piquant_hip_peer_close', None, [_vp, _vp]),
+    ('piquant_hip_peer_free', None, [_vp, _vp]),
     ('piquant_hip_signal_flags', None, [_vp, C.POINTER(C.c_void_p), _sz, C.c_uint32]),
     ('piquant_hip_wait_flags', None, [_vp, _vp, _sz, C.c_uint32, C.c_uint32]),
     ('piquant_hip_exchange_minmax_keys', None, [_vp, _vp, C.POINTER(C.c_void_p), _vp, _sz, _vp, C.c_uint32]),

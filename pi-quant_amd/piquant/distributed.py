@@ -181,34 +181,43 @@ def compute_quant_params(
     return quant_params_from_minmax(r_min, r_max, torch_to_piquant_dtype(dtype))
 
 
-class _KeyMesh:
-    """Mailboxes of ``compute_quant_params(transport='p2p')``: per rank two arrays (parities) of ``world`` 8-byte words, every rank's mapped into
-    every other rank's address space once (the machinery of ``_PeerMesh`` below).  Word j of rank r's mailbox is where rank j stores its key
-    pair for r; a word is emptied by its reader; exchanges alternate between the parities (``include/piquant_hip.h``)."""
+class _PeerMapped:
+    """One allocation per rank that every other rank of the group maps into its own address space (HIP IPC through the library's
+    ``piquant_hip_peer_*`` calls; the 64-byte handles travel over the process group).  ``ptrs[j]`` is the local address of rank j's
+    allocation (``ptrs[rank]`` the own one).  On one node every GPU reaches every other over its own xGMI link; several processes on one GPU
+    -- the tests -- share memory the same way."""
 
-    _EMPTY = 0x7fffffff7fffffff
+    def __init__(self, ctx: Context, group, nbytes: int, world: int, rank: int, fine_grained: bool, fill_word: int = 0):
+        self.ctx, self.rank = ctx, rank
+        self.own, handle = ctx.peer_alloc(nbytes, fine_grained, fill_word)
+        handles = [None] * world
+        dist.all_gather_object(handles, handle, group=group)
+        self.ptrs = [self.own if j == rank else ctx.peer_open(h) for j, h in enumerate(handles)]
+
+    def release(self, group) -> None:
+        """Collective: everybody unmaps before anybody frees."""
+        dist.barrier(group=group)
+        for j, p in enumerate(self.ptrs):
+            if j != self.rank:
+                self.ctx.peer_close(p)
+        self.ptrs = []
+        dist.barrier(group=group)
+        self.ctx.peer_free(self.own)
+        self.own = 0
+
+
+class _KeyMesh:
+    """Mailboxes of ``compute_quant_params(transport='p2p')``: per rank two arrays (parities) of ``world`` 8-byte words in FINE-GRAINED device
+    memory (another GPU writes them while a kernel of this one polls).  Word j of rank r's mailbox is where rank j stores its key pair for r;
+    a word is emptied by its reader; exchanges alternate between the parities (``include/piquant_hip.h``)."""
+
     _cache = {}
 
     def __init__(self, group, device: torch.device, world: int, rank: int):
-        from torch.multiprocessing.reductions import reduce_tensor
-
         self.world, self.rank, self.device = world, rank, device
-        self.buf = torch.full((2 * world,), self._EMPTY, dtype=torch.int64, device=device)
+        self.ctx = Context.get(device.index)
+        self.mem = _PeerMapped(self.ctx, group, 16 * world, world, rank, fine_grained=True, fill_word=0x7fffffff)   # every word = two keys of NaN patterns: empty
         self.out = torch.empty(2, dtype=torch.int32, device=device)
-        torch.cuda.synchronize(device)
-        fn, args = reduce_tensor(self.buf)
-        everyone = [None] * world
-        dist.all_gather_object(everyone, (fn, args), group=group)
-        self.peers = []
-        for j, (f, a) in enumerate(everyone):
-            if j == rank:
-                self.peers.append(self.buf)
-                continue
-            t = f(*a)
-            if t.device != device:
-                _enable_peer_access(device, t.device)
-                torch.empty(2, dtype=torch.int64, device=device).copy_(t[:2])      # a runtime-managed copy first (see _PeerMesh)
-            self.peers.append(t)
         torch.cuda.synchronize(device)
         dist.barrier(group=group)
         self.seq = 0
@@ -226,20 +235,13 @@ class _KeyMesh:
     def exchange(self, keys: torch.Tensor, ctx: Context) -> torch.Tensor:
         self.seq += 1
         par = self.seq & 1
-        slots = [self.peers[j].data_ptr() + 8 * (par * self.world + self.rank) for j in range(self.world)]
-        ctx.exchange_minmax_keys_ptr(keys.data_ptr(), slots, self.buf.data_ptr() + 8 * par * self.world, self.out.data_ptr())
+        slots = [self.mem.ptrs[j] + 8 * (par * self.world + self.rank) for j in range(self.world)]
+        ctx.exchange_minmax_keys_ptr(keys.data_ptr(), slots, self.mem.own + 8 * par * self.world, self.out.data_ptr())
         return self.out
 
     def release(self, group) -> None:
-        import gc
-
         torch.cuda.synchronize(self.device)
-        dist.barrier(group=group)
-        self.peers = []
-        gc.collect()
-        torch.cuda.ipc_collect()
-        dist.barrier(group=group)
-        self.buf = None
+        self.mem.release(group)
 
 
 # -----------------------------------------------------------------------------------------------------------------
@@ -343,54 +345,40 @@ def _all_gather(mine: torch.Tensor, everyone: torch.Tensor, group) -> None:
 # Peer-to-peer transport of the mesh schedule: the encode kernels store straight into the peers' receive buffers.
 # -----------------------------------------------------------------------------------------------------------------
 class _PeerMesh:
-    """Buffers of ``quantized_all_reduce_direct(transport='p2p')``, one allocation per rank, every rank's mapped into every other rank's
-    address space (IPC handles exchanged once per (group, device, slot size) through the process group; on one node every GPU reaches every
-    other over its own xGMI link, and several processes on one GPU -- the tests -- share it the same way):
+    """Buffers of ``quantized_all_reduce_direct(transport='p2p')``, per rank one payload allocation and one small flag allocation, both mapped
+    by every other rank (``_PeerMapped``):
 
         recv[2][world][slot]   chunk j of peer i lands in recv[parity][i] of rank j -- written by PEER i's encode kernel, no copy
         mine[2][slot]          the owner's finished chunk -- READ by every peer's decode kernel, no all-gather
         arrived[world]         uint32 sequence numbers: arrived[i] = s  <=>  peer i's chunk of exchange s is in recv[s & 1][i]
         finished[world]        finished[i] = s  <=>  owner i's mine[s & 1] holds its finished chunk of exchange s
 
-    Two parities suffice: a rank enters exchange s + 1 only behind its own decode of exchange s, a peer passes its wait of exchange s + 1
-    only after that rank's encode of s + 1 -- so when anybody writes parity (s + 2) & 1 = s & 1 again, every reader of exchange s is done.
+    The payload is ordinary device memory: it is produced by one launch and consumed by a LATER one on the other side (the flag wait sits
+    between them), and kernel boundaries are where ordinary device memory becomes coherent between GPUs.  The flags are polled by a running
+    kernel while another GPU writes them: fine-grained memory.  Two parities suffice: a rank enters exchange s + 1 only behind its own decode
+    of exchange s, a peer passes its wait of exchange s + 1 only after that rank's encode of s + 1 -- so when anybody writes parity
+    (s + 2) & 1 = s & 1 again, every reader of exchange s is done.
     """
 
     _cache = {}
 
     def __init__(self, group, device: torch.device, slot: int, world: int, rank: int):
-        from torch.multiprocessing.reductions import reduce_tensor
-
         self.world, self.rank, self.slot, self.device = world, rank, slot, device
+        self.ctx = Context.get(device.index)
         self.off_mine = 2 * world * slot
-        self.off_arrived = self.off_mine + 2 * slot
-        self.off_finished = self.off_arrived + 4 * world
-        total = -(-(self.off_finished + 4 * world) // 256) * 256
-        self.buf = torch.zeros(total, dtype=torch.uint8, device=device)
+        payload = -(-(self.off_mine + 2 * slot) // 256) * 256
+        self.data = _PeerMapped(self.ctx, group, payload, world, rank, fine_grained=False)
+        self.flags = _PeerMapped(self.ctx, group, 8 * world, world, rank, fine_grained=True)     # arrived[world] then finished[world], all 0
+        self.off_arrived, self.off_finished = 0, 4 * world
         torch.cuda.synchronize(device)
-        fn, args = reduce_tensor(self.buf)
-        everyone = [None] * world
-        dist.all_gather_object(everyone, (fn, args), group=group)
-        self.peers = []
-        for j, (f, a) in enumerate(everyone):
-            if j == rank:
-                self.peers.append(self.buf)
-                continue
-            t = f(*a)                    # hipIpcOpenMemHandle through PyTorch's CUDA-IPC machinery: a uint8 view of rank j's allocation
-            if t.device != device:       # another GPU: this device needs peer access to it for raw-pointer kernels
-                _enable_peer_access(device, t.device)
-                probe = torch.empty(16, dtype=torch.uint8, device=device)
-                probe.copy_(t[:16])      # a runtime-managed copy first: a mapping that does not work fails HERE, with an exception
-            self.peers.append(t)
-        torch.cuda.synchronize(device)
-        dist.barrier(group=group)        # nobody signals into a buffer somebody has not finished zeroing / mapping
+        dist.barrier(group=group)        # nobody signals into memory somebody has not finished mapping
         self.seq = 0
 
     @classmethod
     def get(cls, group, device, slot, world, rank):
         """The group's mesh on this device, grown when a tensor needs larger slots than it has (every rank sees the same sizes in the same order,
-        so every rank grows at the same call).  Growing is a collective (IPC exchange + barrier) behind a device synchronisation: this rank's
-        last decode -- the last reader of the peers' old buffers -- has finished before the barrier lets anybody drop them."""
+        so every rank grows at the same call).  Growing is a collective behind a device synchronisation: this rank's last decode -- the last
+        reader of the peers' old buffers -- has finished before the barriers inside release() let anybody unmap or free them."""
         owner = group if group is not None else dist.group.WORLD
         key = (id(owner), device.index, world)
         m = cls._cache.get(key)
@@ -405,29 +393,12 @@ class _PeerMesh:
         return m
 
     def release(self, group) -> None:
-        """Collective: every rank lets go of the peers' buffers before anybody frees its own (PyTorch's CUDA-IPC bookkeeping warns when a
-        producer goes away while a consumer still holds its memory)."""
-        import gc
-
         torch.cuda.synchronize(self.device)
-        dist.barrier(group=group)
-        self.peers = []
-        gc.collect()
-        torch.cuda.ipc_collect()
-        dist.barrier(group=group)
-        self.buf = None
-
-    # views into rank j's allocation
-    def recv_slot(self, j: int, parity: int, i: int, nbytes: int) -> torch.Tensor:
-        o = (parity * self.world + i) * self.slot
-        return self.peers[j][o: o + nbytes]
-
-    def mine(self, j: int, parity: int, nbytes: int) -> torch.Tensor:
-        o = self.off_mine + parity * self.slot
-        return self.peers[j][o: o + nbytes]
+        self.data.release(group)
+        self.flags.release(group)
 
     def flag_ptr(self, j: int, which: str, i: int) -> int:
-        return self.peers[j].data_ptr() + (self.off_arrived if which == 'arrived' else self.off_finished) + 4 * i
+        return self.flags.ptrs[j] + (self.off_arrived if which == 'arrived' else self.off_finished) + 4 * i
 
 
 def release_peer_meshes(group: Optional[dist.ProcessGroup] = None) -> None:
@@ -437,15 +408,6 @@ def release_peer_meshes(group: Optional[dist.ProcessGroup] = None) -> None:
     for cache in (_PeerMesh._cache, _KeyMesh._cache):
         for key in [k for k, m in cache.items() if m.owner is owner]:
             cache.pop(key).release(group)
-
-
-def _enable_peer_access(device: torch.device, peer: torch.device) -> None:
-    """Peer access from `device` to `peer`, enabled in the HIP runtime THIS process computes with: PyTorch enables it (once, both ways) the first
-    time it copies between the two devices, and the probe copy that follows this call in `_PeerMesh` is such a copy.  (Calling
-    hipDeviceEnablePeerAccess through a library handle of our own could reach a second copy of the runtime -- PyTorch-ROCm wheels bundle
-    theirs -- and enable nothing where it matters.)  Raises when the two GPUs cannot reach each other at all."""
-    if not torch.cuda.can_device_access_peer(device.index, peer.index):
-        raise RuntimeError(f"transport='p2p': {device} cannot access {peer} (no peer access between these two GPUs)")
 
 
 def ring_chunks(numel: int, world_size: int, packed_bits: int = 8, align: int = 4096):
@@ -585,7 +547,7 @@ def quantized_all_reduce_direct(
     2(G-1)/G x packed bytes per element, and the two collectives are what RCCL implements natively over the mesh.
 
     ``transport='p2p'``: the same four steps and the same bytes with NO collective.  Step 1's kernel stores chunk j straight into rank j's
-    receive buffer (an address of rank j's memory mapped here once, ``_PeerMesh``) and a flag store behind it says so; step 3 waits for its
+    receive buffer (an address of rank j's memory mapped here once: HIP IPC, ``_PeerMesh``) and a flag store behind it says so; step 3 waits for its
     G-1 flags on the stream; step 4 leaves the finished chunk in the owner's own buffer, and every rank's decode kernel READS the G finished
     chunks from their owners.  Against the collective transport that is one HBM write and one read of the wire bytes less per phase on every
     rank, no staging copy inside RCCL and no RCCL launch: 4 kernel launches + 2 flag stores + 2 flag waits per all-reduce.  One node only
@@ -662,13 +624,13 @@ def _all_reduce_direct_p2p(tensor, flat, chunks, slot, quant_dtype, qdt, round_m
         return chunks[j][1] - chunks[j][0]
 
     def recv_ptr(j, i):                 # recv[par][i] of rank j: 16-byte header (the parameter record), then the packed bytes
-        return mesh.peers[j].data_ptr() + (par * world + i) * slot
+        return mesh.data.ptrs[j] + (par * world + i) * slot
 
     def mine_ptr(j):
-        return mesh.peers[j].data_ptr() + mesh.off_mine + par * slot
+        return mesh.data.ptrs[j] + mesh.off_mine + par * slot
 
     def wait_all_but_mine(offset):
-        flags = mesh.buf.data_ptr() + offset
+        flags = mesh.flags.own + offset
         if rank > 0:
             cx.wait_flags_ptr(flags, rank, seq)
         if rank + 1 < world:
