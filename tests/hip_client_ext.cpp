@@ -181,9 +181,11 @@ int main(int argc, char** argv) {
     // serial-number compare (waiting for 5 when the flags hold 7 returns at once).  [21] what host buffers of a default context get.
     piquant_hip_set_blocking(ctx, 0);
     piquant_hip_set_stream(ctx, stream);
-    uint32_t* d_flags;
-    CK(hipMalloc(reinterpret_cast<void**>(&d_flags), 3 * sizeof(uint32_t)));
-    CK(hipMemsetAsync(d_flags, 0, 3 * sizeof(uint32_t), stream));
+    unsigned char ipc_handle[PIQUANT_HIP_IPC_HANDLE_BYTES] = {0};
+    uint32_t* d_flags = static_cast<uint32_t*>(piquant_hip_peer_alloc(ctx, 3 * sizeof(uint32_t), /*fine_grained=*/1, /*fill_word=*/0u, ipc_handle));   // what a peer would map
+    bool handle_set = false;
+    for (unsigned char b : ipc_handle) handle_set = handle_set || b != 0;
+    if (!d_flags || !handle_set) return 3;
     CK(hipMemsetAsync(d_q, 0, n, stream));
     piquant_quantize(ctx, d_x, PIQUANT_DTYPE_F32, d_q2, PIQUANT_DTYPE_UINT8, n, 1.0f / 127.0f, 128, PIQUANT_NEAREST);
     uint32_t* flag_list[3] = {d_flags + 0, d_flags + 1, d_flags + 2};
@@ -195,6 +197,7 @@ int main(int argc, char** argv) {
     uint32_t h_flags[3];
     CK(hipMemcpy(h_flags, d_flags, sizeof h_flags, hipMemcpyDeviceToHost));
     std::printf("%d ", h_flags[0] == 7u && h_flags[1] == 7u && h_flags[2] == 7u && pull_q(d_q, n) == h_wait[0] ? 1 : 0);
+    piquant_hip_peer_free(ctx, d_flags);
     {
         piquant_context_t* fresh = piquant_context_create(0);
         const int dflt = piquant_hip_host_path_in_effect(fresh);
