@@ -235,10 +235,6 @@ PIQUANT_EXPORT void piquant_hip_peer_free(piquant_context_t* ctx, void* allocate
  *                             instead of hanging the device.  Not capturable into a hipGraph. */
 PIQUANT_EXPORT void piquant_hip_signal_flags(piquant_context_t* ctx, uint32_t* const* flags, size_t count, uint32_t value);
 PIQUANT_EXPORT void piquant_hip_wait_flags(piquant_context_t* ctx, const uint32_t* flags, size_t count, uint32_t value, uint32_t timeout_us);
-/* Both in one launch: signal the n_signal (<= 32) peer flags, then wait for wait_flags[0 .. wait_count) -- all but wait_flags[skip_index]
- * (this rank's own entry; -1: none) -- to reach `value`. */
-PIQUANT_EXPORT void piquant_hip_signal_wait_flags(piquant_context_t* ctx, uint32_t* const* signal_flags, size_t n_signal, const uint32_t* wait_flags,
-                                                  size_t wait_count, int skip_index, uint32_t value, uint32_t timeout_us);
 
 /* compute_quant_params of a sharded tensor WITHOUT a collective library, for GPUs of one node: the MIN all-reduce of the ranks' {key(min),
  * key(-max)} pairs (the path's only exchange, 8 bytes) done by ONE one-wave kernel over peer-mapped mailboxes -- lane j stores this rank's

@@ -343,19 +343,6 @@ void piquant_hip_wait_flags(piquant_context_t* ctx, const uint32_t* flags, size_
     launch_wait_flags(flags, static_cast<int>(count), value, timeout_us, ctx->stream);
 }
 
-void piquant_hip_signal_wait_flags(piquant_context_t* ctx, uint32_t* const* signal_flags, size_t n_signal, const uint32_t* wait_flags, size_t wait_count, int skip_index,
-                                   uint32_t value, uint32_t timeout_us) {
-    if (!ctx) panic("piquant_hip_signal_wait_flags: context is NULL");
-    if (n_signal > static_cast<size_t>(kFlagListMax)) panic("piquant_hip_signal_wait_flags: %zu flags to signal (at most %d)", n_signal, kFlagListMax);
-    if ((n_signal != 0 && !signal_flags) || (wait_count != 0 && !wait_flags)) panic("piquant_hip_signal_wait_flags: NULL flag list");
-    for (size_t i = 0; i < n_signal; ++i)
-        if (!signal_flags[i]) panic("piquant_hip_signal_wait_flags: NULL flag %zu", i);
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    DeviceGuard guard(ctx->device);
-    if (stream_is_capturing(ctx->stream)) panic("piquant_hip_signal_wait_flags cannot be captured into a hipGraph: the value waited for changes with every exchange");
-    launch_signal_wait_flags(signal_flags, static_cast<int>(n_signal), wait_flags, static_cast<int>(wait_count), skip_index, value, timeout_us, ctx->stream);
-}
-
 void* piquant_hip_peer_alloc(piquant_context_t* ctx, size_t bytes, int fine_grained, uint32_t fill_word, void* out_ipc_handle) {
     if (!ctx) panic("piquant_hip_peer_alloc: context is NULL");
     if (bytes == 0 || bytes % 4 != 0) panic("piquant_hip_peer_alloc: %zu bytes (a positive multiple of 4 is needed)", bytes);

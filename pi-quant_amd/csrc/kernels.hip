@@ -674,34 +674,6 @@ void launch_exchange_keys(const int32_t* my_keys, unsigned long long* const* pee
     PQ_HIP(hipGetLastError());
 }
 
-// Both halves of a hand-over in ONE launch: store `value` into the peers' flags (everything enqueued before this kernel has completed), then
-// poll the own flags -- all but `skip`, this rank's own entry -- until they have reached it.  Two launches less per step of a schedule.
-__global__ void __launch_bounds__(64) signal_wait_flags_kernel(FlagList signal, int n_signal, const uint32_t* flags, int count, int skip, uint32_t value, uint64_t timeout_ticks) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    if (static_cast<int>(threadIdx.x) < n_signal) __hip_atomic_store(signal.ptr[threadIdx.x], value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    const uint64_t t_begin = wall_clock64();
-    for (int base = 0; base < count; base += 64) {
-        const int i = base + static_cast<int>(threadIdx.x);
-        for (;;) {
-            bool behind = false;
-            if (i < count && i != skip) behind = static_cast<int32_t>(__hip_atomic_load(flags + i, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0;
-            if (!__any(behind ? 1 : 0)) break;
-            __builtin_amdgcn_s_sleep(16);
-            if (wall_clock64() - t_begin > timeout_ticks) __builtin_trap();
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-}
-
-void launch_signal_wait_flags(uint32_t* const* signal, int n_signal, const uint32_t* flags, int count, int skip, uint32_t value, uint32_t timeout_us, hipStream_t stream) {
-    if (n_signal > kFlagListMax) panic("signal_wait_flags: %d flags to signal (at most %d in one launch)", n_signal, kFlagListMax);
-    FlagList list {};
-    for (int i = 0; i < n_signal; ++i) list.ptr[i] = signal[i];
-    const uint64_t ticks = static_cast<uint64_t>(timeout_us == 0 ? 30000000u : timeout_us) * 100ull;
-    hipLaunchKernelGGL(signal_wait_flags_kernel, dim3(1), dim3(64), 0, stream, list, n_signal, flags, count, skip, value, ticks);
-    PQ_HIP(hipGetLastError());
-}
-
 void launch_signal_flags(uint32_t* const* flags, int count, uint32_t value, hipStream_t stream) {
     for (int first = 0; first < count; first += kFlagListMax) {
         FlagList list {};

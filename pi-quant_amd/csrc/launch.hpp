@@ -150,7 +150,6 @@ void launch_publish_seq(uint32_t* host_visible_word, uint32_t seq, hipStream_t s
 constexpr int kFlagListMax = 32;
 void launch_signal_flags(uint32_t* const* flags, int count, uint32_t value, hipStream_t stream);
 void launch_wait_flags(const uint32_t* flags, int count, uint32_t value, uint32_t timeout_us, hipStream_t stream);
-void launch_signal_wait_flags(uint32_t* const* signal, int n_signal, const uint32_t* flags, int count, int skip, uint32_t value, uint32_t timeout_us, hipStream_t stream);
 // MIN all-reduce of one {key(min), key(-max)} word per rank through peer-mapped mailboxes (kernels.hip, exchange_keys_kernel)
 constexpr int kKeyExchangeMaxRanks = 64;
 constexpr unsigned long long kKeyWordEmpty = 0x7fffffff7fffffffull;

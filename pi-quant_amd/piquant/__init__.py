@@ -334,11 +334,6 @@ class Context:
         if count:
             C.piquant_hip_wait_flags(self._ctx, flags_ptr, count, value & 0xFFFFFFFF, timeout_us)
 
-    def signal_wait_flags_ptr(self, signal_ptrs, wait_ptr: int, wait_count: int, skip_index: int, value: int, timeout_us: int = 0) -> None:
-        """``signal_flags_ptr`` and ``wait_flags_ptr`` as ONE stream-ordered launch (``skip_index``: the own entry of the waited array, -1 for none)."""
-        n = len(signal_ptrs)
-        C.piquant_hip_signal_wait_flags(self._ctx, (_C.c_void_p * max(n, 1))(*signal_ptrs), n, wait_ptr, wait_count, skip_index, value & 0xFFFFFFFF, timeout_us)
-
     def exchange_minmax_keys_ptr(self, keys_ptr: int, peer_slot_ptrs, my_slots_ptr: int, out_keys_ptr: int, timeout_us: int = 0) -> None:
         """Stream-ordered MIN all-reduce of this rank's int32[2] key pair over peer-mapped mailboxes (include/piquant_hip.h,
         piquant_hip_exchange_minmax_keys); ``peer_slot_ptrs[j]`` is this rank's slot in rank j's mailbox."""

@@ -629,29 +629,27 @@ def _all_reduce_direct_p2p(tensor, flat, chunks, slot, quant_dtype, qdt, round_m
     def mine_ptr(j):
         return mesh.data.ptrs[j] + mesh.off_mine + par * slot
 
-    def hand_over(which, offset):       # tell every peer, then wait for every peer: one launch (world <= 33; larger groups take the two calls)
-        targets = [mesh.flag_ptr(j, which, rank) for j in peers]
-        if len(targets) <= 32:
-            cx.signal_wait_flags_ptr(targets, mesh.flags.own + offset, world, rank, seq)
-            return
-        cx.signal_flags_ptr(targets, seq)
+    def wait_all_but_mine(offset):
+        flags = mesh.flags.own + offset
         if rank > 0:
-            cx.wait_flags_ptr(mesh.flags.own + offset, rank, seq)
+            cx.wait_flags_ptr(flags, rank, seq)
         if rank + 1 < world:
-            cx.wait_flags_ptr(mesh.flags.own + offset + 4 * (rank + 1), world - rank - 1, seq)
+            cx.wait_flags_ptr(flags + 4 * (rank + 1), world - rank - 1, seq)
 
     peers = [j for j in range(world) if j != rank]
     # ---- 1. every peer's chunk, quantized straight into that peer's recv[par][rank]; then the flags ----
     full = [j for j in peers if chunk_len(j) > 0]
     cx.quantize_dynamic_batch_ptr([chunk_ptr(j) for j in full], fdt, [recv_ptr(j, rank) + _HEADER_BYTES for j in full], qdt, [chunk_len(j) for j in full],
                                   [recv_ptr(j, rank) for j in full], rmode, _device_ptrs=True)
+    cx.signal_flags_ptr([mesh.flag_ptr(j, 'arrived', rank) for j in peers], seq)
     # ---- 2./3. wait for the G-1 chunks of MY range, add them to my own values, quantize the finished chunk into mine[par] ----
-    hand_over('arrived', mesh.off_arrived)
+    wait_all_but_mine(mesh.off_arrived)
     if chunk_len(rank) > 0:
         cx.reduce_quantize_dynamic_ptr(chunk_ptr(rank), fdt, [recv_ptr(rank, i) + _HEADER_BYTES for i in peers], [recv_ptr(rank, i) for i in peers],
                                        mine_ptr(rank) + _HEADER_BYTES, qdt, chunk_len(rank), mine_ptr(rank), rmode, _device_ptrs=True)
+    cx.signal_flags_ptr([mesh.flag_ptr(j, 'finished', rank) for j in peers], seq)
     # ---- 4. every finished chunk, read from its owner (the own one from this rank's buffer: all ranks decode the same bytes) ----
-    hand_over('finished', mesh.off_finished)
+    wait_all_but_mine(mesh.off_finished)
     everyone = [j for j in range(world) if chunk_len(j) > 0]
     cx.dequantize_dp_batch_ptr([mine_ptr(j) + _HEADER_BYTES for j in everyone], qdt, [chunk_ptr(j) for j in everyone], fdt, [chunk_len(j) for j in everyone],
                                [mine_ptr(j) for j in everyone], ReduceOp.SET, _device_ptrs=True)
