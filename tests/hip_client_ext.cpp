@@ -3,7 +3,8 @@
 // minmax_keys + decode + params_from_minmax, compute_quant_params_device + quantize_dp, quantize_dequantize (requant), the stochastic
 // controls (pinned threshold, per-element counter hash), dequantize_dp_batch, reduce_quantize_dynamic, the four blocking-wait modes,
 // the barrier timeout + hand-over counter, reference-layout mode (1 and 3 reference threads), fusion off, the stochastic seed,
-// assume_device_pointers, reset_stream, piquant_hip_device / _version.  (piquant_hip_compute_quant_params_dist needs an RCCL communicator:
+// assume_device_pointers, reset_stream, the flag store / wait calls on a peer allocation (piquant_hip_peer_alloc), host_path_in_effect,
+// piquant_hip_device / _version.  (piquant_hip_compute_quant_params_dist needs an RCCL communicator:
 // tests/test_gpu_distributed.py drives it through ctypes.)  Prints one line of values and
 // FNV-1a checksums that tests/test_c_client.py compares with the oracle.
 //   g++ -std=c++20 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude tests/hip_client_ext.cpp -L<libdir> -lpiquant -L/opt/rocm/lib -lamdhip64
