@@ -158,7 +158,10 @@ PIQUANT_EXPORT void piquant_hip_set_fusion(piquant_context_t* ctx, int enabled);
  * share over and exits, freeing its CU.  The barrier still opens when the last block has arrived; the blocks resident then also
  * quantize the shares that were handed over, from HBM.  Results are identical; only the time differs.  0 restores the default.
  * piquant_hip_barrier_bailouts returns how many blocks ever left a barrier of this context early (0 in normal operation;
- * synchronises the context's stream). */
+ * synchronises the context's stream).  PIQUANT_HIP_BARRIER_HAND_OVER_ALWAYS as the limit is for tests of that path: every block
+ * of a launch except the last one of each tensor hands its share over without waiting at all, whatever the GPU's scheduling does
+ * (bailouts grows by blocks - 1 per tensor per launch; same bytes, same record). */
+#define PIQUANT_HIP_BARRIER_HAND_OVER_ALWAYS 0xffffffffu
 PIQUANT_EXPORT void piquant_hip_set_barrier_timeout_us(piquant_context_t* ctx, uint32_t microseconds);
 PIQUANT_EXPORT uint64_t piquant_hip_barrier_bailouts(piquant_context_t* ctx);
 

@@ -429,7 +429,8 @@ void piquant_hip_set_fusion(piquant_context_t* ctx, int enabled) {
 
 void piquant_hip_set_barrier_timeout_us(piquant_context_t* ctx, uint32_t microseconds) {
     if (!ctx) panic("piquant_hip_set_barrier_timeout_us: context is NULL");
-    if (microseconds > 40000000u) panic("piquant_hip_set_barrier_timeout_us: %u us is beyond the 40 s the tick counter holds", microseconds);
+    if (microseconds > 40000000u && microseconds != PIQUANT_HIP_BARRIER_HAND_OVER_ALWAYS)
+        panic("piquant_hip_set_barrier_timeout_us: %u us is beyond the 40 s the tick counter holds", microseconds);
     std::lock_guard<std::mutex> lock(ctx->mu);
     ctx->barrier_timeout_us = microseconds;
 }

@@ -57,6 +57,11 @@ namespace pq {
 
 constexpr int kFusedMaxBlocks = 256;                                   // blocks of one sub-grid (one per CU)
 constexpr unsigned long long kFusedNotArrived = 0x7fffffff7fffffffull;   // both halves are keys of NaN patterns: never a block's {key(min), key(-max)}
+// bail_ticks value that makes the hand-over path DETERMINISTIC (tests; piquant_hip_set_barrier_timeout_us(ctx, PIQUANT_HIP_BARRIER_HAND_OVER_ALWAYS)):
+// every block of a sub-grid but the last one marks its share as orphaned BEFORE it arrives at the barrier and exits right behind its arrival; the
+// last block waits as usual and adopts all of them.  The same marks, adoption loop and block-0 duties as a wait that ran out -- without depending
+// on how far apart the blocks happen to arrive.
+constexpr uint32_t kFusedBailAlways = 0xffffffffu;
 
 struct FusedState {
     uint32_t arrived;                 // counter barrier: blocks that have folded their keys into `slots`
@@ -359,6 +364,7 @@ fused_params_quantize_kernel(const void* in0, uint8_t* out0, int64_t numel0, Par
         }
         const uint32_t bail_raw = LEAD ? bail_ticks_arg : groups.bail_ticks;
         const uint32_t bail_ticks = bail_raw != 0 ? bail_raw : 100000u;   // 100 MHz ticks: 1 ms
+        const bool hand_over_always = AG && bail_raw == kFusedBailAlways && block + 1u != static_cast<uint32_t>(G);   // wave-uniform (kFusedBailAlways)
         const uint64_t t_arrive = wall_clock64();
         const uint32_t my_word = block >> 5, my_bit = 1u << (block & 31);
         bool leave = false;
@@ -386,6 +392,15 @@ fused_params_quantize_kernel(const void* in0, uint8_t* out0, int64_t numel0, Par
             unsigned long long* slots64 = st->gathered[gen & 1];
             const unsigned long long mine = static_cast<unsigned long long>(static_cast<uint32_t>(float_to_key(lo))) |
                                             (static_cast<unsigned long long>(static_cast<uint32_t>(float_to_key(-hi))) << 32);
+            if (hand_over_always) {
+                // the mark is PERFORMED (its old value has come back) before the arrival below is issued: whoever sees the barrier open sees the mark
+                uint32_t old = 0;
+                if (lane == 0) old = __hip_atomic_fetch_or(&st->orphans[my_word], my_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                old = __builtin_amdgcn_readfirstlane(old);
+                asm volatile("" : "+s"(old) : : "memory");
+                if (lane == 0) __hip_atomic_fetch_add(&st->bailouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                leave = true;
+            }
             if (lane == 0) __hip_atomic_store(slots64 + block, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long ident = static_cast<unsigned long long>(static_cast<uint32_t>(float_to_key(3.402823466e+38f))) * 0x100000001ull;
             unsigned long long seen[LPL];
@@ -405,7 +420,7 @@ fused_params_quantize_kernel(const void* in0, uint8_t* out0, int64_t numel0, Par
                 }
                 return __any(missing ? 1 : 0) != 0;
             };
-            while (sweep()) {
+            while (!hand_over_always && sweep()) {
                 __builtin_amdgcn_s_sleep(4);
                 if (wall_clock64() - t_arrive > bail_ticks) {
                     if (give_up(sweep)) {

@@ -294,6 +294,9 @@ static int fused_blocks_per_group(int64_t max_numel, int dt_in, int count, int n
     return static_cast<int>(std::min<int64_t>(cap, std::max<int64_t>((n_vec + per - 1) / per, 1)));
 }
 
+// 100 MHz wall clock ticks; 0 = the kernel's default (1 ms); the hand-over-always value (tests) passes through unchanged
+static uint32_t fused_bail_ticks(uint32_t timeout_us) { return timeout_us == kFusedBailAlways ? kFusedBailAlways : timeout_us * 100u; }
+
 bool fused_launch_applies(const QuantLaunch& q, int num_cu) {
     if (q.numel <= 0 || q.ref_layout || !aligned16(q.in) || !aligned16(q.out)) return false;
     if (q.dt_in != DT_F32 && q.dt_in != DT_BF16) panic("invalid quantization types: %d -> %d", q.dt_in, q.dt_out);
@@ -317,7 +320,7 @@ bool launch_fused_params_quantize_batch(const QuantLaunch& q, const FusedBatch& 
     g.count = b.count;
     g.blocks_per_group = fused_blocks_per_group(max_numel, q.dt_in, b.count, num_cu);
     if (g.blocks_per_group == 0) return false;
-    g.bail_ticks = q.barrier_timeout_us * 100u;   // 100 MHz wall clock; 0 = the kernel's default (1 ms)
+    g.bail_ticks = fused_bail_ticks(q.barrier_timeout_us);
     QuantParams p {};
     p.threshold = q.threshold;
     p.seed_lo = static_cast<uint32_t>(q.seed);
@@ -354,7 +357,7 @@ bool launch_fused_reduce_quantize(const QuantLaunch& q, const DequantSumLaunch& 
     g.params[0] = static_cast<ParamRecord*>(device_param_record);
     g.count = 1;
     g.blocks_per_group = bpg;
-    g.bail_ticks = q.barrier_timeout_us * 100u;
+    g.bail_ticks = fused_bail_ticks(q.barrier_timeout_us);
     QuantParams p {};
     p.threshold = q.threshold;
     p.seed_lo = static_cast<uint32_t>(q.seed);

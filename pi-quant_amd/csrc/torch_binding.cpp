@@ -26,7 +26,7 @@ piquant_dtype_t code_of(at::ScalarType t) {
         case at::kQUInt8: return PIQUANT_DTYPE_UINT8;
         case at::kQUInt4x2: return PIQUANT_DTYPE_UINT4;
         case at::kQUInt2x4: return PIQUANT_DTYPE_UINT2;
-        default: TORCH_CHECK(false, "no piquant counterpart for torch dtype ", t);
+        default: TORCH_CHECK(false, "Unsupported quant_dtype: ", t, " (no piquant counterpart)");
     }
 }
 
@@ -53,7 +53,7 @@ at::Tensor quantize(int64_t handle, const at::Tensor& tensor, double scale, int6
     TORCH_CHECK(tensor.is_cuda(), "the native path takes device tensors");
     TORCH_CHECK(is_float_type(tensor.scalar_type()), "quantize needs a float32 or bfloat16 tensor, got ", tensor.scalar_type());
     const piquant_dtype_t dt_out = code_of(dtype);
-    TORCH_CHECK(!is_float_type(dtype), "dtype= must be a quantized type, got ", dtype);
+    TORCH_CHECK(!is_float_type(dtype), "Unsupported quantized dtype: ", dtype, " (dtype= must be uint8 / quint8, quint4x2 or quint2x4)");
     const at::Tensor x = tensor.is_contiguous() ? tensor : tensor.contiguous();
     at::Tensor out;
     if (out_opt.has_value()) {
@@ -80,8 +80,9 @@ at::Tensor quantize(int64_t handle, const at::Tensor& tensor, double scale, int6
 at::Tensor dequantize(int64_t handle, const at::Tensor& tensor, double scale, int64_t zero_point, at::ScalarType dtype, int64_t reduce_op,
                       const c10::optional<at::Tensor>& out_opt) {
     TORCH_CHECK(tensor.is_cuda(), "the native path takes device tensors");
-    TORCH_CHECK(is_float_type(dtype), "dtype= must be float32 or bfloat16 to dequantize into, got ", dtype);
-    TORCH_CHECK(!is_float_type(tensor.scalar_type()), "quantize needs a float32 or bfloat16 tensor, got ", tensor.scalar_type());
+    TORCH_CHECK(is_float_type(dtype), "Unsupported dequantized dtype: ", dtype, " (dtype= must be float32 or bfloat16)");
+    TORCH_CHECK(!is_float_type(tensor.scalar_type()), "Unsupported quantized dtype: ", tensor.scalar_type(),
+                " (dequantize needs a uint8 / quint8, quint4x2 or quint2x4 tensor)");
     const at::Tensor q = tensor.is_contiguous() ? tensor : tensor.contiguous();
     at::Tensor out;
     if (out_opt.has_value()) {

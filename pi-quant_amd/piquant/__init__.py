@@ -357,6 +357,10 @@ class Context:
         self._record_policy('set_fusion', enabled)
         C.piquant_hip_set_fusion(self._ctx, 1 if enabled else 0)
 
+    #: ``set_barrier_timeout_us(Context.HAND_OVER_ALWAYS)``: every block but the last of each tensor hands its share over without waiting
+    #: (PIQUANT_HIP_BARRIER_HAND_OVER_ALWAYS; the deterministic form of the hand-over path, for tests)
+    HAND_OVER_ALWAYS = 0xffffffff
+
     def set_barrier_timeout_us(self, microseconds: int) -> None:
         """Longest wait of a block at the fused kernel's grid barrier before it hands its share over and frees its CU
         (include/piquant_hip.h); 0 = default (1 ms)."""

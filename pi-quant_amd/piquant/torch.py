@@ -51,7 +51,7 @@ _REDUCE_OP_CODES: dict[str, int] = {k: v.value for k, v in _REDUCE_OPS.items()}
 
 def torch_to_piquant_dtype(dtype: torch.dtype) -> DataType:
     if dtype not in _TORCH_DTYPE_MAP:
-        raise ValueError(f'{dtype} has no piquant counterpart (float32, bfloat16, uint8 / quint8, quint4x2, quint2x4 do)')
+        raise ValueError(f'Unsupported quant_dtype: {dtype} (float32, bfloat16, uint8 / quint8, quint4x2 and quint2x4 have a piquant counterpart)')
     return _TORCH_DTYPE_MAP[dtype]
 
 
@@ -60,7 +60,7 @@ def piquant_to_torch_dtype(dtype: DataType) -> torch.dtype:
     for torch_dtype, piquant_dtype in _TORCH_DTYPE_MAP.items():
         if piquant_dtype == dtype:
             return torch_dtype
-    raise ValueError(f'no torch dtype is mapped to {dtype}')
+    raise ValueError(f'Unsupported quantized dtype: {dtype} (no torch dtype is mapped to it)')
 
 
 def packed_bytes(tensor: torch.Tensor) -> torch.Tensor:
@@ -162,7 +162,7 @@ def _numel_of(shape) -> int:
 
 def compute_quant_params(tensor: torch.Tensor, *, dtype: torch.dtype, ctx: Optional[Context] = None) -> Tuple[float, int]:
     """(scale, zero_point) from the tensor's min/max (reference ``torch.py:53-67``)."""
-    assert dtype in _QUANT_TYPES, f'dtype={dtype} is not a quantized type; choose from {[str(t) for t in _QUANT_TYPES]}'
+    assert dtype in _QUANT_TYPES, f'Unsupported quantized dtype: {dtype}; choose from {[str(t) for t in _QUANT_TYPES]}'
     if not tensor.is_contiguous():
         tensor = tensor.contiguous()
     ctx = _ctx_for(tensor, ctx)
@@ -183,7 +183,7 @@ def quantize(
     out: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
     """Reference ``torch.py:70-99``; the result lives on ``tensor.device``."""
-    assert dtype in _QUANT_TYPES, f'dtype={dtype} is not a quantized type; choose from {[str(t) for t in _QUANT_TYPES]}'
+    assert dtype in _QUANT_TYPES, f'Unsupported quantized dtype: {dtype}; choose from {[str(t) for t in _QUANT_TYPES]}'
     if _native is not None and tensor.is_cuda and tensor.dtype in _DEQUANT_TYPES:
         return _native.quantize(_native_handle(tensor, ctx), tensor, scale, zero_point, dtype, _ROUND_MODE_CODES[round_mode], out)
     if not tensor.is_contiguous():
@@ -223,7 +223,7 @@ def dequantize(
 ) -> torch.Tensor:
     """Reference ``torch.py:102-129``.  ``out=`` (same shape, ``dtype``) is the accumulator for ``reduce_op='add'``."""
     if dtype not in _DEQUANT_TYPES:
-        raise ValueError(f'dtype={dtype} is not a float type to dequantize into; choose from {[str(t) for t in _DEQUANT_TYPES]}')
+        raise ValueError(f'Unsupported dequantized dtype: {dtype}; choose from {[str(t) for t in _DEQUANT_TYPES]}')
     if _native is not None and tensor.is_cuda and quant_dtype is None and shape is None and tensor.dtype in _QUANT_TYPES:
         if out is None and reduce_op == 'add':
             raise ValueError("reduce_op='add' accumulates into out=; pass the accumulator tensor")

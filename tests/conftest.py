@@ -35,7 +35,21 @@ def golden_dir():
     return GOLDEN
 
 
+# Order of GPU test files under `-x`: what pins results against the oracle first (BASELINE configs, goldens and the dtype matrix, the reference's
+# own suites, the epilogue, the C clients), then the Python surface and the sharded paths, and the scheduling / property tests (grid-barrier
+# hand-overs, processes sharing the GPU) last.  Round 4's driver run stopped at a scheduling-dependent counter assertion in a file that
+# sorted in front of the whole parity suite; nothing of that kind may stand in front of an oracle comparison again.
+_GPU_FILE_ORDER = ["test_gpu_00_baseline_configs.py", "test_gpu_parity.py", "test_gpu_reference_suites.py", "test_gpu_epilogue.py", "test_c_client.py",
+                   "test_gpu_torch_api.py", "test_gpu_distributed.py", "test_gpu_barrier.py"]
+
+
+def _file_rank(item):
+    name = Path(str(item.fspath)).name
+    return _GPU_FILE_ORDER.index(name) if name in _GPU_FILE_ORDER else len(_GPU_FILE_ORDER) - 1   # unknown files: in front of the barrier tests
+
+
 def pytest_collection_modifyitems(config, items):
+    items.sort(key=_file_rank)   # stable: the order inside a file is kept
     # Fail loudly rather than silently skip: a gpu test collected on a box without a GPU is an error.
     if os.environ.get("PIQUANT_ALLOW_GPU_SKIP") == "1":
         import torch

@@ -111,8 +111,8 @@ int main(int argc, char** argv) {
     }
     piquant_hip_set_blocking(ctx, 0);
     std::printf("%016llx %d ", static_cast<unsigned long long>(h_wait[0]), h_wait[0] == h_wait[1] && h_wait[1] == h_wait[2] && h_wait[2] == h_wait[3] ? 1 : 0);
-    // [8..10] one-launch params + quantize with a 1 us barrier limit (blocks hand their shares over), then the normal launch: same bytes
-    piquant_hip_set_barrier_timeout_us(ctx, 1);
+    // [8..10] one-launch params + quantize with every block but the last handing its share over, then the normal launch: same bytes
+    piquant_hip_set_barrier_timeout_us(ctx, PIQUANT_HIP_BARRIER_HAND_OVER_ALWAYS);
     piquant_hip_quantize_dynamic(ctx, d_x, PIQUANT_DTYPE_F32, d_q2, PIQUANT_DTYPE_UINT8, n, d_rec + 1, PIQUANT_NEAREST);
     const uint64_t h_bail = pull_q(d_q2, n);
     const unsigned long long bailouts = piquant_hip_barrier_bailouts(ctx);

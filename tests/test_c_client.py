@@ -164,8 +164,8 @@ def test_hip_client_ext_rest_of_the_extension_surface_matches_oracle(tmp_path, o
     assert int(out[6], 16) == _fnv1a(q_near.tobytes()) and out[7] == "1"       # four wait modes, same bytes
     s8, z8 = O.compute_quant_params(x, O.F32, O.UINT8)
     q8 = O.quantize(x, O.F32, O.UINT8, s8, z8)
-    assert int(out[8], 16) == _fnv1a(q8.tobytes()) and out[9] == "1"           # the 1 us barrier limit changes nothing but the time
-    assert int(out[10]) >= 0
+    assert int(out[8], 16) == _fnv1a(q8.tobytes()) and out[9] == "1"           # handing every share over changes nothing but the time
+    assert int(out[10]) >= 1                                                   # ... and it happened (deterministic: PIQUANT_HIP_BARRIER_HAND_OVER_ALWAYS)
     total = O.dequantize(q8, O.UINT8, O.F32, n, s8, z8, O.ADD, out=x.copy())
     total = O.dequantize(q8, O.UINT8, O.F32, n, s8, z8, O.ADD, out=total)
     ss, zs = O.compute_quant_params(total, O.F32, O.UINT8)

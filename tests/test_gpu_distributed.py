@@ -338,89 +338,6 @@ def test_native_rccl_all_reduce_entry_point(oracle_mod):
         rccl.ncclCommDestroy(comm)
 
 
-def test_config5_in_its_own_shape_2_pow_30_over_8_shards(oracle_mod):
-    """BASELINE configs[4] as BASELINE names it: numel 2^30 fp32 generated on the device, the global extremes planted in shards 0 and 7, eight
-    local scans of 2^27 elements (what each of 8 GPUs does), MIN fold of the eight key pairs (what the 8-byte all-reduce computes) == the
-    whole-tensor scan == the oracle's epilogue on the planted extremes; then the native sharded entry point on a one-rank RCCL communicator
-    for one 2^27 shard.  Each scan is timed with HIP events on its stream: this geometry first ran on hardware here, not in the day-one 8-GPU run."""
-    import ctypes
-
-    import piquant
-    import piquant.distributed as D
-
-    O = oracle_mod
-    total, world = 1 << 30, 8
-    g = torch.Generator(device="cuda")
-    g.manual_seed(77)
-    x = torch.empty(total, dtype=torch.float32, device="cuda").uniform_(-1.0, 1.0, generator=g)
-    x[12345] = -7.5                      # shard 0
-    x[total - 6] = 9.25                  # shard 7
-    want = O.quant_params_from_minmax(-7.5, 9.25, O.UINT8)
-    ctx = piquant.Context()
-    stream = torch.cuda.current_stream()
-    ctx.set_stream(stream.cuda_stream)
-    ctx.set_blocking(False)
-    parts, fracs = [], []
-    for r in range(world):
-        b, e = D.shard_range(total, r, world, 8)
-        assert e - b == 1 << 27
-        shard = x[b:e]
-        keys = torch.empty(2, dtype=torch.int32, device="cuda")
-        for _ in range(2):
-            ctx.minmax_keys_ptr(shard.data_ptr(), piquant.DataType.F32, e - b, keys.data_ptr(), init=True)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for _ in range(5):
-            ctx.minmax_keys_ptr(shard.data_ptr(), piquant.DataType.F32, e - b, keys.data_ptr(), init=True)
-        e1.record(stream)
-        torch.cuda.synchronize()
-        fracs.append(4.0 * (e - b) / (e0.elapsed_time(e1) * 1e-3 / 5) / 8e12)
-        parts.append(keys.clone())
-        lo, hi = piquant.decode_minmax_keys(int(keys[0]), int(keys[1]))
-        assert lo == (-7.5 if r == 0 else lo) and hi == (9.25 if r == world - 1 else hi)
-        assert (r == 0 or lo >= -1.0) and (r == world - 1 or hi <= 1.0)
-    folded = torch.stack(parts).min(dim=0).values.cpu()
-    whole = torch.empty(2, dtype=torch.int32, device="cuda")
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ctx.minmax_keys_ptr(x.data_ptr(), piquant.DataType.F32, total, whole.data_ptr(), init=True)
-    e0.record(stream)
-    for _ in range(3):
-        ctx.minmax_keys_ptr(x.data_ptr(), piquant.DataType.F32, total, whole.data_ptr(), init=True)
-    e1.record(stream)
-    torch.cuda.synchronize()
-    frac_whole = 4.0 * total / (e0.elapsed_time(e1) * 1e-3 / 3) / 8e12
-    assert torch.equal(folded, whole.cpu())
-    lo, hi = piquant.decode_minmax_keys(int(folded[0]), int(folded[1]))
-    assert (lo, hi) == (-7.5, 9.25)
-    assert piquant.quant_params_from_minmax(lo, hi, piquant.DataType.UINT8) == want
-    assert piquant.torch.compute_quant_params(x, dtype=torch.quint8) == want       # the synchronous C-ABI call on the whole tensor
-    print(f"config 5 scans: 2^27-element shards at {min(fracs):.3f}-{max(fracs):.3f} of 8 TB/s, 2^30 elements at {frac_whole:.3f}")
-    # 2^27 elements = 537 MB: 76 us of streaming + the scan's ~4.5 us end; measured 0.82-0.84 (shards) and 0.85-0.86 (whole)
-    assert min(fracs) >= 0.78 and frac_whole >= 0.80, (fracs, frac_whole)
-
-    # the native entry point (ncclAllReduce inside the call) for one shard on a one-rank communicator
-    rccl = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
-
-    class UniqueId(ctypes.Structure):
-        _fields_ = [("internal", ctypes.c_char * 128)]
-
-    rccl.ncclGetUniqueId.argtypes = [ctypes.POINTER(UniqueId)]
-    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
-    rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
-    uid = UniqueId()
-    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
-    comm = ctypes.c_void_p()
-    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
-    try:
-        ctx2 = piquant.Context()
-        b, e = D.shard_range(total, 7, world, 8)
-        got = ctx2.compute_quant_params_dist_ptr(x[b:e].data_ptr(), piquant.DataType.F32, e - b, piquant.DataType.UINT8, comm.value)
-        lo7, hi7 = piquant.decode_minmax_keys(int(parts[7][0]), int(parts[7][1]))
-        assert got == piquant.quant_params_from_minmax(lo7, hi7, piquant.DataType.UINT8)
-    finally:
-        rccl.ncclCommDestroy(comm)
-
-
 @pytest.mark.slow
 def test_bench_eight_ranks_sharing_the_gpu():
     """The command the driver will run on an 8-GPU node, with the eight ranks sharing this box's GPU over gloo (RCCL refuses two ranks on one
