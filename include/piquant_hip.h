@@ -234,8 +234,9 @@ PIQUANT_EXPORT void piquant_hip_peer_free(piquant_context_t* ctx, void* allocate
  * quantized_all_reduce(transport='p2p'); the use-case of reference README.md:29).  Both calls are stream-ordered on the context's stream:
  *   piquant_hip_signal_flags  stores `value` into every flags[i] (system-scope release) once everything enqueued before it has completed;
  *   piquant_hip_wait_flags    holds the stream until every flags[i] (an array in THIS device's memory) has reached `value` (serial-number
- *                             compare, so a 32-bit counter may wrap); a peer that never arrives fails the launch after timeout_us (0 = 30 s)
- *                             instead of hanging the device.  Not capturable into a hipGraph. */
+ *                             compare, so a 32-bit counter may wrap); a peer that has not arrived after timeout_us (0 = 10 minutes, what
+ *                             torch.distributed gives a collective; at most ~71 minutes) is REPORTED, see piquant_hip_peer_timeout.  Not
+ *                             capturable into a hipGraph. */
 PIQUANT_EXPORT void piquant_hip_signal_flags(piquant_context_t* ctx, uint32_t* const* flags, size_t count, uint32_t value);
 PIQUANT_EXPORT void piquant_hip_wait_flags(piquant_context_t* ctx, const uint32_t* flags, size_t count, uint32_t value, uint32_t timeout_us);
 
@@ -248,9 +249,18 @@ PIQUANT_EXPORT void piquant_hip_wait_flags(piquant_context_t* ctx, const uint32_
  *   my_slots     `count` 8-byte words in THIS device's memory, all holding 0x7fffffff7fffffff when first used (the kernel empties what it
  *                reads); a caller alternates between TWO such mailboxes from one exchange to the next (see piquant.distributed);
  *   peer_slots   peer_slots[j] = the address of slot [this rank] in rank j's mailbox of the same parity (peer-mapped; j = this rank: own).
- * A peer that never arrives fails the launch after timeout_us (0 = 30 s).  Not capturable into a hipGraph.  count <= 64. */
+ * A peer that has not arrived after timeout_us (0 = 10 minutes) is reported (piquant_hip_peer_timeout).  Not capturable into a hipGraph.  count <= 64. */
 PIQUANT_EXPORT void piquant_hip_exchange_minmax_keys(piquant_context_t* ctx, const int32_t* device_keys, uint64_t* const* peer_slots, uint64_t* my_slots,
                                                      size_t count, int32_t* out_keys, uint32_t timeout_us);
+
+/* A wait of the two calls above that ran out does NOT fault the GPU queue (round 4 trapped, which killed this process and, through the mapped
+ * memory, its peers): the waiting wave writes what it was missing into a pinned record of the context, the stream goes on -- whatever was enqueued
+ * behind the wait consumes stale bytes -- and the host finds out here.  Returns 0 (nothing happened), 1 (piquant_hip_wait_flags: flag *out_rank of
+ * the array waited on read *out_seen instead of *out_expected) or 2 (piquant_hip_exchange_minmax_keys: rank *out_rank never delivered its pair),
+ * and clears the record.  Reads host memory only; synchronise the stream first to be sure the wait in question is over.  A record nobody fetched
+ * makes the context's NEXT peer-to-peer call abort with a message naming the rank, so a host that never asks still fails loudly, one call late.
+ * piquant.distributed asks after every exchange it synchronises on and before every new one, and raises RuntimeError. */
+PIQUANT_EXPORT int piquant_hip_peer_timeout(piquant_context_t* ctx, uint32_t* out_rank, uint32_t* out_expected, uint32_t* out_seen);
 
 /* Host helpers: key <-> float, and the (min,max) -> (scale, zero_point) epilogue in double precision
  * (reference src/piquant.cpp:213-220, 245-258).  keys[0] encodes min, keys[1] encodes -max. */

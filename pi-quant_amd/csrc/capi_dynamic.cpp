@@ -330,6 +330,7 @@ void piquant_hip_signal_flags(piquant_context_t* ctx, uint32_t* const* flags, si
         if (!flags[i]) panic("piquant_hip_signal_flags: NULL flag %zu", i);
     std::lock_guard<std::mutex> lock(ctx->mu);
     DeviceGuard guard(ctx->device);
+    peer_timeout_pending(ctx, "piquant_hip_signal_flags");
     launch_signal_flags(flags, static_cast<int>(count), value, ctx->stream);
 }
 
@@ -340,7 +341,8 @@ void piquant_hip_wait_flags(piquant_context_t* ctx, const uint32_t* flags, size_
     std::lock_guard<std::mutex> lock(ctx->mu);
     DeviceGuard guard(ctx->device);
     if (stream_is_capturing(ctx->stream)) panic("piquant_hip_wait_flags cannot be captured into a hipGraph: the value waited for changes with every exchange");
-    launch_wait_flags(flags, static_cast<int>(count), value, timeout_us, ctx->stream);
+    peer_timeout_pending(ctx, "piquant_hip_wait_flags");
+    launch_wait_flags(flags, static_cast<int>(count), value, timeout_us, peer_timeout_record_dev(ctx), ctx->stream);
 }
 
 void* piquant_hip_peer_alloc(piquant_context_t* ctx, size_t bytes, int fine_grained, uint32_t fill_word, void* out_ipc_handle) {
@@ -402,8 +404,23 @@ void piquant_hip_exchange_minmax_keys(piquant_context_t* ctx, const int32_t* dev
     DeviceGuard guard(ctx->device);
     if (stream_is_capturing(ctx->stream)) panic("piquant_hip_exchange_minmax_keys cannot be captured into a hipGraph: the mailbox parity changes with every exchange");
     static_assert(sizeof(uint64_t) == sizeof(unsigned long long), "mailbox words");
+    peer_timeout_pending(ctx, "piquant_hip_exchange_minmax_keys");
     launch_exchange_keys(device_keys, reinterpret_cast<unsigned long long* const*>(peer_slots), reinterpret_cast<unsigned long long*>(my_slots), static_cast<int>(count),
-                         out_keys, timeout_us, ctx->stream);
+                         out_keys, timeout_us, peer_timeout_record_dev(ctx), ctx->stream);
+}
+
+int piquant_hip_peer_timeout(piquant_context_t* ctx, uint32_t* out_rank, uint32_t* out_expected, uint32_t* out_seen) {
+    if (!ctx) panic("piquant_hip_peer_timeout: context is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!ctx->done_dev) return 0;
+    volatile uint32_t* rec = ctx->done + kPeerTimeoutRecordWord;
+    const uint32_t kind = __atomic_load_n(rec + 0, __ATOMIC_ACQUIRE);
+    if (kind == kPeerTimeoutNone) return 0;
+    if (out_rank) *out_rank = rec[1];
+    if (out_expected) *out_expected = rec[2];
+    if (out_seen) *out_seen = rec[3];
+    __atomic_store_n(rec + 0, static_cast<uint32_t>(kPeerTimeoutNone), __ATOMIC_RELEASE);   // reported: cleared
+    return static_cast<int>(kind);
 }
 
 }  // extern "C"

@@ -351,7 +351,7 @@ piquant_context_t* piquant_context_create(size_t num_threads) {
     }
     if (hipHostMalloc(reinterpret_cast<void**>(&ctx->done), 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
         hipHostGetDevicePointer(&ctx->done_dev, ctx->done, 0) == hipSuccess) {
-        *ctx->done = 0;
+        for (int i = 0; i < 16; ++i) ctx->done[i] = 0;   // word 0: completion sequence number; words 4..7: the peer-timeout record
     } else {
         (void)hipGetLastError();
         ctx->done_dev = nullptr;
@@ -426,6 +426,26 @@ void piquant_hip_set_fusion(piquant_context_t* ctx, int enabled) {
     std::lock_guard<std::mutex> lock(ctx->mu);
     ctx->fusion = enabled != 0;
 }
+
+}  // extern "C"
+
+namespace pq {
+
+void peer_timeout_pending(piquant_context_t* ctx, const char* who) {
+    if (!ctx->done_dev) return;
+    volatile uint32_t* rec = ctx->done + kPeerTimeoutRecordWord;
+    const uint32_t kind = __atomic_load_n(rec + 0, __ATOMIC_ACQUIRE);
+    if (kind == kPeerTimeoutNone) return;
+    if (kind == kPeerTimeoutFlags)
+        panic("%s: an earlier piquant_hip_wait_flags on this context gave up -- rank %u never signalled exchange %u (its flag read %u); everything enqueued "
+              "behind that wait worked on stale bytes", who, rec[1], rec[2], rec[3]);
+    panic("%s: an earlier piquant_hip_exchange_minmax_keys on this context gave up -- rank %u never delivered its key pair; the folded keys of that exchange are void",
+          who, rec[1]);
+}
+
+}  // namespace pq
+
+extern "C" {
 
 void piquant_hip_set_barrier_timeout_us(piquant_context_t* ctx, uint32_t microseconds) {
     if (!ctx) panic("piquant_hip_set_barrier_timeout_us: context is NULL");

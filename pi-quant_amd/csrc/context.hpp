@@ -175,6 +175,16 @@ class FusedLaunchOrder {
 
 float draw_threshold(piquant_context_t* ctx);
 
+// Peer-to-peer waits that ran out (kernels.hip, report_peer_timeout) leave {kind, rank, expected, seen} in words 4..7 of the context's pinned
+// completion block.  peer_timeout_record_dev: the device address the kernels write to (nullptr without host-coherent memory: they trap instead).
+// peer_timeout_pending: called at the head of every peer-to-peer entry point -- a record nobody has fetched with piquant_hip_peer_timeout by
+// then aborts with a message that names the missing rank (a C host that does not ask still fails loudly, one call late).  Caller holds ctx->mu.
+constexpr int kPeerTimeoutRecordWord = 4;
+inline uint32_t* peer_timeout_record_dev(piquant_context_t* ctx) {
+    return ctx->done_dev ? static_cast<uint32_t*>(ctx->done_dev) + kPeerTimeoutRecordWord : nullptr;
+}
+void peer_timeout_pending(piquant_context_t* ctx, const char* who);
+
 // The scan state (d_state) and the fused kernel's barrier state (d_fused) are per CONTEXT.  Outside capture, launches that use them are
 // serialised by stream order plus the synchronise-on-stream-change in scan() and FusedLaunchOrder.  Inside capture those are skipped (a
 // capturing stream cannot be synchronised), so two captured launches of one context on parallel branches of one graph -- two side streams

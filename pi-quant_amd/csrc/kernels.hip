@@ -618,16 +618,37 @@ __global__ void __launch_bounds__(64) signal_flags_kernel(FlagList flags, int co
     if (static_cast<int>(threadIdx.x) < count) __hip_atomic_store(flags.ptr[threadIdx.x], value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-__global__ void __launch_bounds__(64) wait_flags_kernel(const uint32_t* flags, int count, uint32_t value, uint64_t timeout_ticks) {
+// A peer that never arrives (both kernels below): no trap -- a fault on the queue takes this process down and, with it, its peers' mapped memory.  The
+// wave that gave up writes {index of the first missing rank, the value waited for, the value seen} and then the kind (system-scope release) into
+// the context's pinned, host-coherent record and lets the stream go on (what follows consumes stale bytes); the host finds the record at its next
+// peer-to-peer call or status query and turns it into a message that names the rank (context.cpp, peer_timeout_pending).  Only a context without
+// host-coherent memory (record == nullptr) still traps.
+__device__ __forceinline__ void report_peer_timeout(uint32_t* record, uint32_t kind, uint32_t index, uint32_t expected, uint32_t seen) {
+    if (record == nullptr) __builtin_trap();
+    __hip_atomic_store(record + 1, index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(record + 2, expected, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(record + 3, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(record + 0, kind, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void __launch_bounds__(64) wait_flags_kernel(const uint32_t* flags, int count, uint32_t value, uint64_t timeout_ticks, uint32_t* timeout_record) {
     const uint64_t t_begin = wall_clock64();
     for (int base = 0; base < count; base += 64) {
         const int i = base + static_cast<int>(threadIdx.x);
         for (;;) {
             bool behind = false;
-            if (i < count) behind = static_cast<int32_t>(__hip_atomic_load(flags + i, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0;
-            if (!__any(behind ? 1 : 0)) break;
+            uint32_t seen = 0;
+            if (i < count) {
+                seen = __hip_atomic_load(flags + i, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                behind = static_cast<int32_t>(seen - value) < 0;
+            }
+            const unsigned long long missing = __ballot(behind ? 1 : 0);
+            if (missing == 0) break;
             __builtin_amdgcn_s_sleep(16);
-            if (wall_clock64() - t_begin > timeout_ticks) __builtin_trap();   // a peer that never arrives: fail the launch loudly instead of hanging the device
+            if (wall_clock64() - t_begin > timeout_ticks) {
+                if (static_cast<int>(threadIdx.x) == __builtin_ctzll(missing)) report_peer_timeout(timeout_record, kPeerTimeoutFlags, static_cast<uint32_t>(i), value, seen);
+                return;
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
@@ -644,7 +665,7 @@ struct KeyPeers {
 };
 
 __global__ void __launch_bounds__(64) exchange_keys_kernel(const int32_t* my_keys, KeyPeers peers, unsigned long long* mine, int count, int32_t* out_keys,
-                                                            uint64_t timeout_ticks) {
+                                                            uint64_t timeout_ticks, uint32_t* timeout_record) {
     const int lane = threadIdx.x;
     const unsigned long long word = static_cast<unsigned long long>(static_cast<uint32_t>(my_keys[0])) | (static_cast<unsigned long long>(static_cast<uint32_t>(my_keys[1])) << 32);
     unsigned long long got = word;   // lanes beyond the group fold this rank's own word again: harmless for a minimum
@@ -655,7 +676,11 @@ __global__ void __launch_bounds__(64) exchange_keys_kernel(const int32_t* my_key
             got = __hip_atomic_load(mine + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
             if (got != kKeyWordEmpty) break;
             __builtin_amdgcn_s_sleep(8);
-            if (wall_clock64() - t_begin > timeout_ticks) __builtin_trap();   // a peer that never arrives: fail the launch loudly instead of hanging the device
+            if (wall_clock64() - t_begin > timeout_ticks) {   // rank `lane` never arrived: report it, fold the own word in its place (the result is void)
+                report_peer_timeout(timeout_record, kPeerTimeoutKeys, static_cast<uint32_t>(lane), 0u, 0u);
+                got = word;
+                break;
+            }
         }
         __hip_atomic_store(mine + lane, kKeyWordEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // read: empty again, for the exchange after next
     }
@@ -667,13 +692,16 @@ __global__ void __launch_bounds__(64) exchange_keys_kernel(const int32_t* my_key
     }
 }
 
+// 0 = the default, ten minutes: what torch.distributed gives an NCCL collective before it calls a rank missing (a rank may be minutes late for honest
+// reasons: a checkpoint write, an evaluation pass on rank 0, a first-call compile)
+static uint64_t peer_timeout_ticks(uint32_t timeout_us) { return static_cast<uint64_t>(timeout_us == 0 ? kPeerTimeoutDefaultUs : timeout_us) * 100ull; }   // 100 MHz wall clock
+
 void launch_exchange_keys(const int32_t* my_keys, unsigned long long* const* peer_slots, unsigned long long* my_slots, int count, int32_t* out_keys, uint32_t timeout_us,
-                          hipStream_t stream) {
+                          uint32_t* timeout_record, hipStream_t stream) {
     if (count < 1 || count > kKeyExchangeMaxRanks) panic("key exchange over %d ranks (1..%d supported)", count, kKeyExchangeMaxRanks);
     KeyPeers peers {};
     for (int i = 0; i < count; ++i) peers.slot[i] = peer_slots[i];
-    const uint64_t ticks = static_cast<uint64_t>(timeout_us == 0 ? 30000000u : timeout_us) * 100ull;
-    hipLaunchKernelGGL(exchange_keys_kernel, dim3(1), dim3(64), 0, stream, my_keys, peers, my_slots, count, out_keys, ticks);
+    hipLaunchKernelGGL(exchange_keys_kernel, dim3(1), dim3(64), 0, stream, my_keys, peers, my_slots, count, out_keys, peer_timeout_ticks(timeout_us), timeout_record);
     PQ_HIP(hipGetLastError());
 }
 
@@ -687,9 +715,8 @@ void launch_signal_flags(uint32_t* const* flags, int count, uint32_t value, hipS
     PQ_HIP(hipGetLastError());
 }
 
-void launch_wait_flags(const uint32_t* flags, int count, uint32_t value, uint32_t timeout_us, hipStream_t stream) {
-    const uint64_t ticks = static_cast<uint64_t>(timeout_us == 0 ? 30000000u : timeout_us) * 100ull;   // wall_clock64 ticks at 100 MHz
-    hipLaunchKernelGGL(wait_flags_kernel, dim3(1), dim3(64), 0, stream, flags, count, value, ticks);
+void launch_wait_flags(const uint32_t* flags, int count, uint32_t value, uint32_t timeout_us, uint32_t* timeout_record, hipStream_t stream) {
+    hipLaunchKernelGGL(wait_flags_kernel, dim3(1), dim3(64), 0, stream, flags, count, value, peer_timeout_ticks(timeout_us), timeout_record);
     PQ_HIP(hipGetLastError());
 }
 

@@ -149,12 +149,16 @@ void launch_publish_seq(uint32_t* host_visible_word, uint32_t seq, hipStream_t s
 // peer-to-peer schedules: `value` into every flags[i] (addresses other devices / processes poll), and the wait for every flags[i] to reach it
 constexpr int kFlagListMax = 32;
 void launch_signal_flags(uint32_t* const* flags, int count, uint32_t value, hipStream_t stream);
-void launch_wait_flags(const uint32_t* flags, int count, uint32_t value, uint32_t timeout_us, hipStream_t stream);
+// A peer that does not arrive within the limit is REPORTED, not trapped on: {kind, index of the missing rank, value waited for, value seen} in
+// `timeout_record` (4 pinned host-coherent words; nullptr: trap) and the stream goes on (kernels.hip, report_peer_timeout)
+constexpr uint32_t kPeerTimeoutDefaultUs = 600000000u;   // 10 minutes
+enum : uint32_t { kPeerTimeoutNone = 0, kPeerTimeoutFlags = 1, kPeerTimeoutKeys = 2 };
+void launch_wait_flags(const uint32_t* flags, int count, uint32_t value, uint32_t timeout_us, uint32_t* timeout_record, hipStream_t stream);
 // MIN all-reduce of one {key(min), key(-max)} word per rank through peer-mapped mailboxes (kernels.hip, exchange_keys_kernel)
 constexpr int kKeyExchangeMaxRanks = 64;
 constexpr unsigned long long kKeyWordEmpty = 0x7fffffff7fffffffull;
 void launch_exchange_keys(const int32_t* my_keys, unsigned long long* const* peer_slots, unsigned long long* my_slots, int count, int32_t* out_keys, uint32_t timeout_us,
-                          hipStream_t stream);
+                          uint32_t* timeout_record, hipStream_t stream);
 size_t fused_state_bytes();
 void init_fused_state(void* state, hipStream_t stream);
 // blocks of fused launches on `state` that left their grid barrier early so far (synchronises `stream`)

@@ -340,6 +340,15 @@ class Context:
         n = len(peer_slot_ptrs)
         C.piquant_hip_exchange_minmax_keys(self._ctx, keys_ptr, (_C.c_void_p * n)(*peer_slot_ptrs), my_slots_ptr, n, out_keys_ptr, timeout_us)
 
+    def peer_timeout(self):
+        """None, or ``(kind, rank, expected, seen)`` of a peer-to-peer wait of this context that ran out since the last query (``kind``:
+        'flags' = ``wait_flags_ptr``, 'keys' = ``exchange_minmax_keys_ptr``); clears the record (include/piquant_hip.h, piquant_hip_peer_timeout)."""
+        rank, expected, seen = _C.c_uint32(0), _C.c_uint32(0), _C.c_uint32(0)
+        kind = C.piquant_hip_peer_timeout(self._ctx, _C.byref(rank), _C.byref(expected), _C.byref(seen))
+        if kind == 0:
+            return None
+        return ('flags' if kind == 1 else 'keys', int(rank.value), int(expected.value), int(seen.value))
+
     def set_host_path(self, path: str) -> None:
         """Who serves calls on pageable HOST buffers: 'auto' (default: the companion libpiquant_cpu.so -- the same arithmetic in AVX-512 on the
         host cores, as the reference does with host tensors -- when it is present and the host has AVX-512, PCIe staging otherwise), 'stage'

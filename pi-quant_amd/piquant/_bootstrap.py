@@ -58,6 +58,7 @@ _DECLS = [
     ('piquant_hip_signal_flags', None, [_vp, C.POINTER(C.c_void_p), _sz, C.c_uint32]),
     ('piquant_hip_wait_flags', None, [_vp, _vp, _sz, C.c_uint32, C.c_uint32]),
     ('piquant_hip_exchange_minmax_keys', None, [_vp, _vp, C.POINTER(C.c_void_p), _vp, _sz, _vp, C.c_uint32]),
+    ('piquant_hip_peer_timeout', _int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ('piquant_hip_decode_minmax_keys', None, [C.POINTER(C.c_int32), C.POINTER(_f32), C.POINTER(_f32)]),
     ('piquant_hip_quant_params_from_minmax', None, [_f32, _f32, _int, C.POINTER(_f32), C.POINTER(_i64)]),
     ('piquant_hip_device', _int, [_vp]),

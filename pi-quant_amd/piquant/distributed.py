@@ -19,6 +19,61 @@ from . import Context, DataType, decode_minmax_keys, quant_params_from_minmax
 from .torch import _QUANT_TYPES, _ctx_for, torch_to_piquant_dtype
 
 
+_P2P_MAX_TIMEOUT_S = 4294.0   # the C ABI carries microseconds in 32 bits
+
+
+def _p2p_timeout_us(timeout: Optional[float]) -> int:
+    """``timeout`` (seconds) of the peer-to-peer transports as the C ABI's microseconds.  None: ``PIQUANT_P2P_TIMEOUT_S`` from the environment,
+    else the library's default (0 -> 10 minutes, what torch.distributed gives a collective before it calls a rank missing).  A rank may be
+    minutes late for honest reasons -- a checkpoint write, an evaluation pass on rank 0, a first-call compile."""
+    import os
+
+    if timeout is None:
+        env = os.environ.get('PIQUANT_P2P_TIMEOUT_S')
+        if not env:
+            return 0
+        timeout = float(env)
+    if not 0.0 < timeout <= _P2P_MAX_TIMEOUT_S:
+        raise ValueError(f'timeout={timeout} s is outside (0, {_P2P_MAX_TIMEOUT_S:.0f}] s')
+    return max(1, int(timeout * 1e6))
+
+
+def _raise_peer_timeout(ctx: Context, what: str) -> None:
+    """RuntimeError if a peer-to-peer wait of ``ctx`` ran out since the last look (the GPU queue is NOT faulted by such a wait: the kernel reports
+    and the stream goes on, ``piquant_hip_peer_timeout``)."""
+    t = ctx.peer_timeout()
+    if t is None:
+        return
+    kind, rank, expected, seen = t
+    if kind == 'flags':
+        raise RuntimeError(f"{what}: rank {rank} did not arrive within the timeout (its flag read {seen}, exchange {expected} was waited for); the tensors of that "
+                           f"all-reduce hold stale bytes.  Raise timeout= / PIQUANT_P2P_TIMEOUT_S if ranks may be that far apart.")
+    raise RuntimeError(f"{what}: rank {rank} did not deliver its min/max keys within the timeout; the parameters of that call are void.  "
+                       f"Raise timeout= / PIQUANT_P2P_TIMEOUT_S if ranks may be that far apart.")
+
+
+class _StreamOrder:
+    """The buffers and sequence numbers of a cached mesh are ONE resource: its two-parity argument ("a rank enters exchange s + 1 only behind its own
+    decode of s") holds for exchanges issued in stream order.  Exchanges from different streams (a comm side stream, a DDP hook, two threads) are put
+    in that order here: an event behind every exchange, waited for by the next one when it comes from another stream."""
+
+    def __init__(self):
+        self._last_stream = None
+        self._event = None
+
+    def enter(self, device: torch.device) -> None:
+        cur = torch.cuda.current_stream(device)
+        if self._last_stream is not None and self._last_stream != cur.cuda_stream:
+            cur.wait_event(self._event)
+
+    def leave(self, device: torch.device) -> None:
+        cur = torch.cuda.current_stream(device)
+        if self._event is None:
+            self._event = torch.cuda.Event()
+        self._event.record(cur)
+        self._last_stream = cur.cuda_stream
+
+
 def shard_range(numel: int, rank: int, world_size: int, packed_bits: int = 8, align: int = 1) -> Tuple[int, int]:
     """[begin, end) of ``rank``'s shard: the reference's range split (``src/piquant.cpp:145-157``) -- boundaries are
     aligned down to a whole packed byte (2 elements for uint4, 4 for uint2); the last rank keeps the ragged end.
@@ -157,13 +212,16 @@ def compute_quant_params(
     group: Optional[dist.ProcessGroup] = None,
     ctx: Optional[Context] = None,
     transport: str = 'collective',
+    timeout: Optional[float] = None,
     _scan=local_minmax_keys,
 ) -> Tuple[float, int]:
     """Quantization parameters of the tensor whose shards are spread over ``group`` (identical on every rank).
 
     ``transport='collective'``: the local keys, ONE 8-byte ``all_reduce(MIN)`` (RCCL over xGMI), the epilogue.  ``transport='p2p'`` (GPUs of
     one node): the same MIN over peer-mapped mailboxes by one one-wave kernel behind the scan -- a store to and a poll for every peer instead
-    of a collective's launch and protocol (``piquant_hip_exchange_minmax_keys``); same keys, hence the same parameters."""
+    of a collective's launch and protocol (``piquant_hip_exchange_minmax_keys``); same keys, hence the same parameters.  At most 64 ranks.
+    ``timeout`` (seconds, p2p only; default ``PIQUANT_P2P_TIMEOUT_S`` or 10 minutes): how long a rank waits for its peers before the call raises
+    RuntimeError naming the missing rank."""
     if dtype not in _QUANT_TYPES:
         raise ValueError(f'{dtype} is not a quantized dtype')
     if transport not in ('collective', 'p2p'):
@@ -171,14 +229,66 @@ def compute_quant_params(
     keys = _scan(local_shard, ctx)
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     if world > 1 and transport == 'p2p':
+        if world > _KEY_MESH_MAX_RANKS:
+            raise ValueError(f"transport='p2p' exchanges the keys in one wave: at most {_KEY_MESH_MAX_RANKS} ranks, the group has {world}")
         if not keys.is_cuda:
             raise RuntimeError("transport='p2p' exchanges device memory between GPUs: the shard must live on one")
-        keys = _KeyMesh.get(group, keys.device, world, dist.get_rank(group)).exchange(keys, _ctx_for(local_shard, ctx))
+        cx = _ctx_for(local_shard, ctx)
+        mesh = _KeyMesh.get(group, keys.device, world, dist.get_rank(group))
+        keys = mesh.exchange(keys, cx, _p2p_timeout_us(timeout))
+        k = keys.cpu()                    # synchronises: the exchange is over, one way or the other
+        try:
+            _raise_peer_timeout(cx, "compute_quant_params(transport='p2p')")
+        except RuntimeError:
+            mesh.poisoned = True          # the late rank's word will land in a slot nobody empties any more
+            raise
     elif world > 1:
         dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=group)   # the path's only collective: 8 bytes
     k = keys.cpu()
     r_min, r_max = decode_minmax_keys(int(k[0]), int(k[1]))
     return quant_params_from_minmax(r_min, r_max, torch_to_piquant_dtype(dtype))
+
+
+def _device_identity(index: int) -> str:
+    props = torch.cuda.get_device_properties(index)
+    uuid = getattr(props, 'uuid', None)
+    return str(uuid) if uuid is not None else f'{props.name}#{index}'
+
+
+def _check_peers_reachable(group, device: torch.device, world: int, rank: int) -> None:
+    """Collective.  Before anything is mapped: every rank must sit on the same host, and every GPU of the group must be able to address every other
+    one (``hipDeviceCanAccessPeer``).  If a pair cannot, EVERY rank raises the same RuntimeError naming the pairs -- a refusal before the first
+    IPC handle is opened instead of a fault inside a kernel.  (``PIQUANT_P2P_PRETEND_UNREACHABLE="i-j"`` declares a pair of ranks unreachable:
+    the refusal can be tested on a box where everything is reachable.)  A peer's GPU that this process cannot see at all (per-rank
+    HIP_VISIBLE_DEVICES) cannot be asked about; the mapping itself then decides."""
+    import os
+    import socket
+
+    me = (socket.gethostname(), _device_identity(device.index))
+    everyone = [None] * world
+    dist.all_gather_object(everyone, me, group=group)
+    hosts = {h for h, _ in everyone}
+    if len(hosts) > 1:
+        raise RuntimeError(f"transport='p2p' maps device memory between the GPUs of ONE node; the group spans {sorted(hosts)}")
+    visible = {_device_identity(i): i for i in range(torch.cuda.device_count())}
+    pretend = set()
+    for pair in filter(None, os.environ.get('PIQUANT_P2P_PRETEND_UNREACHABLE', '').split(',')):
+        a, b = (int(v) for v in pair.split('-'))
+        pretend.add((min(a, b), max(a, b)))
+    mine = []
+    for j, (_, ident) in enumerate(everyone):
+        if j == rank:
+            continue
+        if (min(rank, j), max(rank, j)) in pretend:
+            mine.append((rank, j))
+        elif ident != me[1] and ident in visible and not torch.cuda.can_device_access_peer(device.index, visible[ident]):
+            mine.append((rank, j))
+    unreachable = [None] * world
+    dist.all_gather_object(unreachable, mine, group=group)
+    pairs = sorted({(min(a, b), max(a, b)) for per_rank in unreachable for a, b in per_rank})
+    if pairs:
+        raise RuntimeError(f"transport='p2p' refused: the GPUs of ranks {pairs} cannot address each other's memory (hipDeviceCanAccessPeer); "
+                           f"use transport='collective'")
 
 
 class _PeerMapped:
@@ -205,6 +315,20 @@ class _PeerMapped:
         self.ctx.peer_free(self.own)
         self.own = 0
 
+    def discard(self) -> None:
+        """NOT collective: the peers are gone (their process group was destroyed); unmap what was mapped, free what was allocated."""
+        torch.cuda.synchronize()
+        for j, p in enumerate(self.ptrs):
+            if j != self.rank:
+                self.ctx.peer_close(p)
+        self.ptrs = []
+        if self.own:
+            self.ctx.peer_free(self.own)
+            self.own = 0
+
+
+_KEY_MESH_MAX_RANKS = 64   # include/piquant_hip.h, piquant_hip_exchange_minmax_keys: one lane per rank
+
 
 class _KeyMesh:
     """Mailboxes of ``compute_quant_params(transport='p2p')``: per rank two arrays (parities) of ``world`` 8-byte words in FINE-GRAINED device
@@ -216,27 +340,39 @@ class _KeyMesh:
     def __init__(self, group, device: torch.device, world: int, rank: int):
         self.world, self.rank, self.device = world, rank, device
         self.ctx = Context.get(device.index)
+        _check_peers_reachable(group, device, world, rank)
         self.mem = _PeerMapped(self.ctx, group, 16 * world, world, rank, fine_grained=True, fill_word=0x7fffffff)   # every word = two keys of NaN patterns: empty
         self.out = torch.empty(2, dtype=torch.int32, device=device)
         torch.cuda.synchronize(device)
         dist.barrier(group=group)
         self.seq = 0
+        self.order = _StreamOrder()
+        self.poisoned = False            # an exchange of this mesh gave up: a late word may sit in a mailbox slot for ever
 
     @classmethod
     def get(cls, group, device, world, rank):
         owner = group if group is not None else dist.group.WORLD
         key = (id(owner), device.index, world)
         m = cls._cache.get(key)
-        if m is None or m.owner is not owner:
+        if m is not None and m.owner is not owner:      # an id recycled by a later process group: those peers are gone
+            cls._cache.pop(key).mem.discard()
+            m = None
+        if m is None:
             m = cls._cache[key] = cls(group, device, world, rank)
             m.owner = owner
         return m
 
-    def exchange(self, keys: torch.Tensor, ctx: Context) -> torch.Tensor:
+    def exchange(self, keys: torch.Tensor, ctx: Context, timeout_us: int = 0) -> torch.Tensor:
+        if self.poisoned:
+            raise RuntimeError("compute_quant_params(transport='p2p'): an earlier exchange of this group gave up on a late rank, whose keys may still sit in a "
+                               "mailbox; every rank must call piquant.distributed.release_peer_meshes(group) before the group uses transport='p2p' again")
+        _raise_peer_timeout(ctx, "an earlier compute_quant_params(transport='p2p')")
+        self.order.enter(self.device)
         self.seq += 1
         par = self.seq & 1
         slots = [self.mem.ptrs[j] + 8 * (par * self.world + self.rank) for j in range(self.world)]
-        ctx.exchange_minmax_keys_ptr(keys.data_ptr(), slots, self.mem.own + 8 * par * self.world, self.out.data_ptr())
+        ctx.exchange_minmax_keys_ptr(keys.data_ptr(), slots, self.mem.own + 8 * par * self.world, self.out.data_ptr(), timeout_us)
+        self.order.leave(self.device)
         return self.out
 
     def release(self, group) -> None:
@@ -367,12 +503,14 @@ class _PeerMesh:
         self.ctx = Context.get(device.index)
         self.off_mine = 2 * world * slot
         payload = -(-(self.off_mine + 2 * slot) // 256) * 256
+        _check_peers_reachable(group, device, world, rank)
         self.data = _PeerMapped(self.ctx, group, payload, world, rank, fine_grained=False)
         self.flags = _PeerMapped(self.ctx, group, 8 * world, world, rank, fine_grained=True)     # arrived[world] then finished[world], all 0
         self.off_arrived, self.off_finished = 0, 4 * world
         torch.cuda.synchronize(device)
         dist.barrier(group=group)        # nobody signals into memory somebody has not finished mapping
         self.seq = 0
+        self.order = _StreamOrder()
 
     @classmethod
     def get(cls, group, device, slot, world, rank):
@@ -383,7 +521,9 @@ class _PeerMesh:
         key = (id(owner), device.index, world)
         m = cls._cache.get(key)
         if m is not None and m.owner is not owner:      # an id recycled by a later process group: those peers are gone
-            cls._cache.pop(key)
+            m = cls._cache.pop(key)
+            m.data.discard()
+            m.flags.discard()
             m = None
         if m is None or m.slot < slot:
             if m is not None:
@@ -430,13 +570,16 @@ def quantized_all_reduce(
     ctx: Optional[Context] = None,
     algorithm: str = 'direct',
     transport: str = 'collective',
+    timeout: Optional[float] = None,
     _ops=None,
     _single_rank_collectives: bool = False,
 ) -> torch.Tensor:
     """In-place SUM all-reduce of a contiguous float32/bfloat16 tensor whose wire format is quantized.
 
-    ``transport='p2p'`` (``algorithm='direct'`` only, one node): no collective at all -- the encode kernels store into the peers' receive
-    buffers over xGMI and flags order the steps (``quantized_all_reduce_direct``).
+    ``transport='p2p'`` (``algorithm='direct'`` only, one node; EXPERIMENTAL until it has run between two GPUs): no collective at all -- the
+    encode kernels store into the peers' receive buffers over xGMI and flags order the steps (``quantized_all_reduce_direct``).  ``timeout``
+    (seconds; default ``PIQUANT_P2P_TIMEOUT_S`` or 10 minutes) bounds every wait for a peer; a rank that is later than that does not fault the
+    GPU: the NEXT p2p call on the device (or ``check_peer_timeouts``) raises RuntimeError naming it.
 
     (``_single_rank_collectives`` is a test hook: with a one-rank group the function normally returns at once; with the hook it
     runs the whole schedule -- encode, the group's collectives with the rank as its own only peer, decode -- so that the RCCL
@@ -463,8 +606,8 @@ def quantized_all_reduce(
     if transport not in ('collective', 'p2p'):
         raise ValueError(f"transport must be 'collective' or 'p2p', got {transport!r}")
     if algorithm == 'direct':
-        return quantized_all_reduce_direct(tensor, quant_dtype=quant_dtype, round_mode=round_mode, group=group, ctx=ctx, transport=transport, _ops=_ops,
-                                           _single_rank_collectives=_single_rank_collectives)
+        return quantized_all_reduce_direct(tensor, quant_dtype=quant_dtype, round_mode=round_mode, group=group, ctx=ctx, transport=transport, timeout=timeout,
+                                           _ops=_ops, _single_rank_collectives=_single_rank_collectives)
     if transport != 'collective':
         raise ValueError("transport='p2p' is the mesh schedule's (algorithm='direct'); the ring forwards through its neighbours")
     world = dist.get_world_size(group)
@@ -528,6 +671,7 @@ def quantized_all_reduce_direct(
     group: Optional[dist.ProcessGroup] = None,
     ctx: Optional[Context] = None,
     transport: str = 'collective',
+    timeout: Optional[float] = None,
     _ops=None,
     _single_rank_collectives: bool = False,
 ) -> torch.Tensor:
@@ -568,7 +712,7 @@ def quantized_all_reduce_direct(
     if transport == 'p2p':
         if world == 1:
             raise ValueError("transport='p2p' needs peers (a one-rank group has none)")
-        return _all_reduce_direct_p2p(tensor, flat, chunks, slot, quant_dtype, qdt, round_mode, group, ctx, ops, world, rank)
+        return _all_reduce_direct_p2p(tensor, flat, chunks, slot, quant_dtype, qdt, round_mode, group, ctx, ops, world, rank, _p2p_timeout_us(timeout))
     if transport != 'collective':
         raise ValueError(f"transport must be 'collective' or 'p2p', got {transport!r}")
     send = torch.zeros(world * slot, dtype=torch.uint8, device=tensor.device)
@@ -598,7 +742,7 @@ def quantized_all_reduce_direct(
     return tensor
 
 
-def _all_reduce_direct_p2p(tensor, flat, chunks, slot, quant_dtype, qdt, round_mode, group, ctx, ops, world, rank):
+def _all_reduce_direct_p2p(tensor, flat, chunks, slot, quant_dtype, qdt, round_mode, group, ctx, ops, world, rank, timeout_us=0):
     """The mesh schedule over peer-mapped buffers (``quantized_all_reduce_direct``, ``transport='p2p'``).  The calls go through the context's
     raw-pointer entry points: the peers' buffers are addresses of THEIR devices' memory, which the tensor-level wrappers (one device per
     call, by design) would refuse."""
@@ -610,6 +754,8 @@ def _all_reduce_direct_p2p(tensor, flat, chunks, slot, quant_dtype, qdt, round_m
     mesh = _PeerMesh.get(group, tensor.device, slot, world, rank)
     slot = mesh.slot                    # the mesh's own slot size lays the buffers out (>= what this tensor needs)
     cx = _ctx_for(tensor, ctx)          # the tensor's device, PyTorch's current stream, stream-ordered
+    _raise_peer_timeout(cx, "an earlier quantized_all_reduce(transport='p2p')")
+    mesh.order.enter(tensor.device)     # behind the mesh's previous exchange, whatever stream that ran on
     fdt = torch_to_piquant_dtype(tensor.dtype)
     rmode = RoundMode.NEAREST if round_mode == 'nearest' else RoundMode.STOCHASTIC
     mesh.seq += 1
@@ -629,28 +775,34 @@ def _all_reduce_direct_p2p(tensor, flat, chunks, slot, quant_dtype, qdt, round_m
     def mine_ptr(j):
         return mesh.data.ptrs[j] + mesh.off_mine + par * slot
 
-    def wait_all_but_mine(offset):
-        flags = mesh.flags.own + offset
-        if rank > 0:
-            cx.wait_flags_ptr(flags, rank, seq)
-        if rank + 1 < world:
-            cx.wait_flags_ptr(flags + 4 * (rank + 1), world - rank - 1, seq)
+    def wait_for_everybody(offset):     # ONE wait over all `world` flags (the own one is signalled with the peers'): flag index == rank, which is what a timeout reports
+        cx.wait_flags_ptr(mesh.flags.own + offset, world, seq, timeout_us)
 
     peers = [j for j in range(world) if j != rank]
+    everybody = list(range(world))
     # ---- 1. every peer's chunk, quantized straight into that peer's recv[par][rank]; then the flags ----
     full = [j for j in peers if chunk_len(j) > 0]
     cx.quantize_dynamic_batch_ptr([chunk_ptr(j) for j in full], fdt, [recv_ptr(j, rank) + _HEADER_BYTES for j in full], qdt, [chunk_len(j) for j in full],
                                   [recv_ptr(j, rank) for j in full], rmode, _device_ptrs=True)
-    cx.signal_flags_ptr([mesh.flag_ptr(j, 'arrived', rank) for j in peers], seq)
+    cx.signal_flags_ptr([mesh.flag_ptr(j, 'arrived', rank) for j in everybody], seq)
     # ---- 2./3. wait for the G-1 chunks of MY range, add them to my own values, quantize the finished chunk into mine[par] ----
-    wait_all_but_mine(mesh.off_arrived)
+    wait_for_everybody(mesh.off_arrived)
     if chunk_len(rank) > 0:
         cx.reduce_quantize_dynamic_ptr(chunk_ptr(rank), fdt, [recv_ptr(rank, i) + _HEADER_BYTES for i in peers], [recv_ptr(rank, i) for i in peers],
                                        mine_ptr(rank) + _HEADER_BYTES, qdt, chunk_len(rank), mine_ptr(rank), rmode, _device_ptrs=True)
-    cx.signal_flags_ptr([mesh.flag_ptr(j, 'finished', rank) for j in peers], seq)
+    cx.signal_flags_ptr([mesh.flag_ptr(j, 'finished', rank) for j in everybody], seq)
     # ---- 4. every finished chunk, read from its owner (the own one from this rank's buffer: all ranks decode the same bytes) ----
-    wait_all_but_mine(mesh.off_finished)
+    wait_for_everybody(mesh.off_finished)
     everyone = [j for j in range(world) if chunk_len(j) > 0]
     cx.dequantize_dp_batch_ptr([mine_ptr(j) + _HEADER_BYTES for j in everyone], qdt, [chunk_ptr(j) for j in everyone], fdt, [chunk_len(j) for j in everyone],
                                [mine_ptr(j) for j in everyone], ReduceOp.SET, _device_ptrs=True)
+    mesh.order.leave(tensor.device)
     return tensor
+
+
+def check_peer_timeouts(device: Optional[torch.device] = None, ctx: Optional[Context] = None) -> None:
+    """Synchronises the device and raises RuntimeError if a wait of a ``transport='p2p'`` call issued on it ran out (the asynchronous all-reduce
+    cannot raise by itself: a late rank is found at the next p2p call, or here)."""
+    device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    torch.cuda.synchronize(device)
+    _raise_peer_timeout(ctx if ctx is not None else Context.get(device.index), "quantized_all_reduce / compute_quant_params (transport='p2p')")

@@ -303,3 +303,21 @@ def test_all_reduce_transport_argument_is_checked_before_anything_moves():
         assert a.startswith("ValueError") and "transport" in a
         assert b.startswith("ValueError") and "ring" in b
         assert c.startswith("RuntimeError") and "device memory" in c
+
+
+def test_p2p_arguments_are_refused_in_python_not_by_an_abort(monkeypatch):
+    """Round-4 advisor: a group of more than 64 ranks reached panic() inside piquant_hip_exchange_minmax_keys (abort); timeouts were not arguments
+    at all.  Both are ValueErrors now, raised before anything touches a device."""
+    import piquant.distributed as D
+
+    monkeypatch.setattr(D.dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(D.dist, "get_world_size", lambda group=None: 65)
+    fake_scan = lambda t, c: torch.zeros(2, dtype=torch.int32)   # noqa: E731
+    with pytest.raises(ValueError, match="at most 64 ranks"):
+        D.compute_quant_params(torch.zeros(8), dtype=torch.quint8, transport="p2p", _scan=fake_scan)
+    for bad in (0.0, -1.0, 5000.0):
+        with pytest.raises(ValueError, match="timeout"):
+            D._p2p_timeout_us(bad)
+    assert D._p2p_timeout_us(None) == 0 and D._p2p_timeout_us(1.5) == 1_500_000
+    monkeypatch.setenv("PIQUANT_P2P_TIMEOUT_S", "90")
+    assert D._p2p_timeout_us(None) == 90_000_000 and D._p2p_timeout_us(2) == 2_000_000

@@ -38,6 +38,16 @@ def main():
         dist.init_process_group(args.backend)
     import piquant.distributed as pqd
 
+    # Startup self-test: can every GPU of the job address every other one?  If not, say so in the JSON line and leave with rc 0 -- before a
+    # single IPC handle is opened, let alone a kernel pointed at a peer's memory.
+    try:
+        pqd._check_peers_reachable(None, dev, world, rank)
+    except RuntimeError as exc:
+        if rank == 0:
+            print(json.dumps({"refused": str(exc), "ranks": world}), flush=True)
+        dist.destroy_process_group()
+        return
+
     n, warm, reps = args.numel, 3, args.reps
     g = torch.Generator(device=dev)
     g.manual_seed(9000 + rank)
