@@ -95,6 +95,14 @@ struct piquant_context_t {
     void* stage_out[2] = {nullptr, nullptr};
     size_t stage_in_cap = 0, stage_out_cap = 0;
 
+    // EXPERIMENT (round 5, PIQUANT_HIP_SPLIT_CALL=1 in the environment at context creation; off by default): a quantize call on device buffers of at
+    // least kSplitCallMinElems elements is issued as TWO launches, the upper half on an internal side stream between a fork and a join event
+    // (capi.cpp, quantize_impl).  Measured and left off -- the two cross-queue events cost 17 us: profiles/r05_split_call_ab.csv.
+    bool split_call = false;
+    bool independent_calls = false;        // piquant_hip_set_independent_calls: quantize / dequantize launches go out without the barrier bit
+    hipStream_t split_stream = nullptr;
+    hipEvent_t split_fork = nullptr, split_join = nullptr;
+
     int host_path = PIQUANT_HIP_HOST_PATH_AUTO;    // piquant_hip_set_host_path: who serves pageable host buffers
     int host_path_resolved = -1;           // AUTO resolved to STAGE or CPU on first use (-1 = not yet)
     void* cpu_ctx = nullptr;               // piquant_cpu_context_t of the companion library, created on first use
@@ -174,6 +182,13 @@ class FusedLaunchOrder {
 };
 
 float draw_threshold(piquant_context_t* ctx);
+
+// Arms stop_event.hpp's tl_any_order for the launch the caller is about to make when the context's calls were declared independent
+// (piquant_hip_set_independent_calls) and the call is stream-ordered outside a hipGraph capture; disarms at scope exit.
+struct IndependentCallScope {
+    explicit IndependentCallScope(piquant_context_t* ctx) { tl_any_order = ctx->independent_calls && !ctx->blocking && !stream_is_capturing(ctx->stream); }
+    ~IndependentCallScope() { tl_any_order = false; }
+};
 
 // Peer-to-peer waits that ran out (kernels.hip, report_peer_timeout) leave {kind, rank, expected, seen} in words 4..7 of the context's pinned
 // completion block.  peer_timeout_record_dev: the device address the kernels write to (nullptr without host-coherent memory: they trap instead).

@@ -366,6 +366,13 @@ class Context:
         self._record_policy('set_fusion', enabled)
         C.piquant_hip_set_fusion(self._ctx, 1 if enabled else 0)
 
+    def set_independent_calls(self, enabled: bool) -> None:
+        """Opt-in: the caller promises that every stream-ordered quantize / dequantize call on this context depends on nothing still in flight on
+        the stream (tensor after tensor of a gradient bucket); the launches then go out without the barrier bit and a call's ramp runs under the
+        previous one's drain -- 22.9 -> 21.6 us per fp32 -> uint8 call at numel 27 264 000 (include/piquant_hip.h, piquant_hip_set_independent_calls)."""
+        self._record_policy('set_independent_calls', enabled)
+        C.piquant_hip_set_independent_calls(self._ctx, 1 if enabled else 0)
+
     #: ``set_barrier_timeout_us(Context.HAND_OVER_ALWAYS)``: every block but the last of each tensor hands its share over without waiting
     #: (PIQUANT_HIP_BARRIER_HAND_OVER_ALWAYS; the deterministic form of the hand-over path, for tests)
     HAND_OVER_ALWAYS = 0xffffffff

@@ -40,6 +40,7 @@ _DECLS = [
     ('piquant_hip_quantize_dp', None, [_vp, _vp, _int, _vp, _int, _sz, _vp, _int]),
     ('piquant_hip_quantize_dynamic', None, [_vp, _vp, _int, _vp, _int, _sz, _vp, _int]),
     ('piquant_hip_set_fusion', None, [_vp, _int]),
+    ('piquant_hip_set_independent_calls', None, [_vp, _int]),
     ('piquant_hip_set_host_path', None, [_vp, _int]),
     ('piquant_hip_host_path_in_effect', _int, [_vp]),
     ('piquant_hip_set_barrier_timeout_us', None, [_vp, C.c_uint32]),

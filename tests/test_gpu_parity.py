@@ -1524,3 +1524,41 @@ def test_reduce_quantize_dynamic_equals_sum_then_quantize(O):
                         checked += 1
     ctx.set_stochastic_threshold(None)
     assert checked > 60
+
+
+def test_independent_calls_mode_same_bytes_and_later_work_waits(ctx, O):
+    """piquant_hip_set_independent_calls (round 5): quantize / dequantize launches without the barrier bit of their dispatch packets -- consecutive
+    calls overlap at their edges.  The caller's promise (no call depends on work still in flight) holds here: distinct tensors.  Every call's bytes
+    equal the oracle's, work enqueued BEHIND the calls (a torch reduction over all outputs, a device-to-host copy) sees all of them complete, and
+    with the mode off again a dependent chain (quantize -> dequantize of the same buffer) is ordered as always."""
+    import piquant
+    import torch
+
+    c = piquant.Context()
+    rng = np.random.default_rng(2025)
+    xs = [rng.uniform(-2, 2, n).astype(np.float32) for n in (3_000_001, 27_264_000 // 4, 4096, 1_000_003, 5_000_000, 77)]
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        xd = [torch.from_numpy(x).cuda() for x in xs]
+        qd = [torch.zeros(x.size, dtype=torch.uint8, device="cuda") for x in xs]
+        q4 = [torch.zeros((x.size + 1) // 2, dtype=torch.uint8, device="cuda") for x in xs]
+        back = [torch.zeros(x.size, dtype=torch.float32, device="cuda") for x in xs]
+        torch.cuda.synchronize()          # the inputs are complete: nothing the calls below depend on is in flight
+        c.set_independent_calls(True)
+        for rep in range(3):
+            for x, q, p4 in zip(xd, qd, q4):
+                piquant.torch.quantize(x, scale=0.0157, zero_point=128, dtype=torch.uint8, ctx=c, out=q)
+                piquant.torch.quantize(x, scale=0.27, zero_point=7, dtype=torch.quint4x2, ctx=c, out=p4)
+        total = sum(int(q.sum(dtype=torch.int64)) for q in qd)      # torch kernels behind the any-order launches: they wait for all of them
+        c.set_independent_calls(False)
+        for q, b in zip(qd, back):        # dependent on the quantize calls above: issued with the mode off, ordered as always
+            piquant.torch.dequantize(q, scale=0.0157, zero_point=128, dtype=torch.float32, ctx=c, out=b)
+    torch.cuda.synchronize()
+    want_total = 0
+    for x, q, p4, b in zip(xs, qd, q4, back):
+        want = O.quantize(x, 0, 4, 0.0157, 128)
+        assert np.array_equal(q.cpu().numpy(), want)
+        assert np.array_equal(p4.cpu().numpy(), O.quantize(x, 0, 3, 0.27, 7))
+        assert same_floats(b.cpu().numpy(), O.dequantize(want, 4, 0, x.size, 0.0157, 128))
+        want_total += int(want.astype(np.int64).sum())
+    assert total == want_total
