@@ -321,12 +321,64 @@ __device__ __forceinline__ void quantize_vec_bounded(const u32x4& raw, float inv
     }
 }
 
+// The stochastic short step as ceil(RU(|r| - tau)) (quantize_vec_bounded_stochastic below: three instructions per element for the +-1
+// adjustment and the truncation instead of five and a half).  false: rounds 2-4's form, for the tune harness' A/B.  profiles/r05_stochastic_ceil_step_ab.json
+#ifndef PQ_STOCH_CEIL_STEP
+#define PQ_STOCH_CEIL_STEP 1
+#endif
+constexpr bool kStochCeilStep = PQ_STOCH_CEIL_STEP != 0;
+
+// out[e] = RU(|r[e]| - t[e]): the subtraction rounded TOWARDS +INFINITY, whatever the wave's rounding mode is set to.  gfx9 has no per-instruction
+// rounding control: the mode is two bits of the wave's MODE register, so the subtractions of one vector sit between two s_setreg_imm32_b32
+// inside ONE asm statement -- nothing the compiler schedules can land between them and be rounded the wrong way (a v_pk_mul_f32 of the next
+// vector rounded up would change bytes).  Only the fp32 rounding field (MODE[1:0]) is written; the kernel's mode is round-to-nearest-even
+// (0), which is what the second s_setreg restores.  UNIFORM: one threshold for all elements (t[0]).
+template <int N, bool UNIFORM>
+__device__ __forceinline__ void sub_abs_round_up(const float (&r)[N], const float (&t)[N], float (&out)[N]) {
+    static_assert(N == 4 || N == 8, "one 16-byte vector of fp32 or bf16");
+#define PQ_RU_ON "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 1\n"
+#define PQ_RU_OFF "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+    if constexpr (N == 4 && UNIFORM) {
+        asm volatile(PQ_RU_ON "v_sub_f32_e64 %0, |%4|, %8\nv_sub_f32_e64 %1, |%5|, %8\nv_sub_f32_e64 %2, |%6|, %8\nv_sub_f32_e64 %3, |%7|, %8\n" PQ_RU_OFF
+                     : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3])
+                     : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(t[0]));
+    } else if constexpr (N == 4) {
+        asm volatile(PQ_RU_ON "v_sub_f32_e64 %0, |%4|, %8\nv_sub_f32_e64 %1, |%5|, %9\nv_sub_f32_e64 %2, |%6|, %10\nv_sub_f32_e64 %3, |%7|, %11\n" PQ_RU_OFF
+                     : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3])
+                     : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]));
+    } else if constexpr (UNIFORM) {
+        asm volatile(PQ_RU_ON "v_sub_f32_e64 %0, |%8|, %16\nv_sub_f32_e64 %1, |%9|, %16\nv_sub_f32_e64 %2, |%10|, %16\nv_sub_f32_e64 %3, |%11|, %16\n"
+                     "v_sub_f32_e64 %4, |%12|, %16\nv_sub_f32_e64 %5, |%13|, %16\nv_sub_f32_e64 %6, |%14|, %16\nv_sub_f32_e64 %7, |%15|, %16\n" PQ_RU_OFF
+                     : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(out[4]), "=&v"(out[5]), "=&v"(out[6]), "=&v"(out[7])
+                     : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]), "v"(r[6]), "v"(r[7]), "v"(t[0]));
+    } else {
+        asm volatile(PQ_RU_ON "v_sub_f32_e64 %0, |%8|, %16\nv_sub_f32_e64 %1, |%9|, %17\nv_sub_f32_e64 %2, |%10|, %18\nv_sub_f32_e64 %3, |%11|, %19\n"
+                     "v_sub_f32_e64 %4, |%12|, %20\nv_sub_f32_e64 %5, |%13|, %21\nv_sub_f32_e64 %6, |%14|, %22\nv_sub_f32_e64 %7, |%15|, %23\n" PQ_RU_OFF
+                     : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(out[4]), "=&v"(out[5]), "=&v"(out[6]), "=&v"(out[7])
+                     : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]), "v"(r[6]), "v"(r[7]), "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]), "v"(t[4]),
+                       "v"(t[5]), "v"(t[6]), "v"(t[7]));
+    }
+#undef PQ_RU_ON
+#undef PQ_RU_OFF
+}
+
 // The stochastic step (quantize.inl:8-19) under the same range condition: r = x * inv, tr = trunc(r), adj = +-1 towards the sign of r
 // when the call's (or the element's) threshold is below |r - tr|, and tr + adj -- an integer-valued float below 2^31 -- then takes
 // the float-domain clamp of the nearest step instead of the reference's int64 add and clamp: the same integers, for the same reason
 // (trunc and the clamp commute on integers; beyond 2^24 the sum with the zero point may round but is far outside [0, QMAX]; a NaN
 // gives adj = 0, tr = NaN and ends at 0, where the reference's INT64_MIN + zp is clamped to).  copysign(1, r) stands
 // for "if r < 0, adj = -adj": the two differ only for r = -0.0, where |r - tr| = 0 is never above a threshold and adj is 0 anyway.
+//
+// CEIL form (round 5, kStochCeilStep): the same integer in three instructions per element instead of five and a half.  With a = |r| and
+// 0 <= tau < 1 (the host guarantees it for a call's threshold, the hash for an element's), in real numbers
+//     floor(a) + [a - floor(a) > tau]  ==  ceil(a - tau)
+// (a - tau = floor(a) + (frac - tau) with 0 < frac - tau < 1 when the fraction is above the threshold, floor(a) - (tau - frac) with
+// 0 <= tau - frac < 1 when it is not), and |tr + adj| is the left side.  In fp32 the difference a - tau is not exact, but rounded TOWARDS
+// +INFINITY it is the smallest float >= the real difference v, and ceil(v) -- an integer below 2^31, representable -- is a float >= v too: so
+// RU(v) <= ceil(v), hence ceil(RU(v)) == ceil(v), exactly.  (At and above 2^24 every a is an integer: v lies in (a - 1, a], RU(v) = a.)
+// v_sub_f32 with the wave in round-up mode (sub_abs_round_up), v_ceil_f32, and v_bfi_b32 puts the sign of r back: compare, select, signed one
+// and the two additions are gone.  tau == fraction exactly gives v = floor(a): no step, as the reference's strict `<`; a = 0 gives -0 -> 0.
+// Tiles with a NaN never come here (the short step's range test), so |NaN| - tau needs no thought.
 template <int DT_IN, int BITS, int MODE, int PACK = PACK_SATURATED>
 __device__ __forceinline__ void quantize_vec_bounded_stochastic(const u32x4& raw, const QuantParams& p, const ElementKeys& keys, uint64_t e0,
                                                                 const BoundedStep& b, uint32_t (&w)[(InVec<DT_IN>::EPV * BITS / 8) > 4 ? 2 : 1]) {
@@ -336,22 +388,38 @@ __device__ __forceinline__ void quantize_vec_bounded_stochastic(const u32x4& raw
     float v[EPV];
     InVec<DT_IN>::unpack(raw, v);
     float s[EPV];
+    if constexpr (kStochCeilStep) {
+        float r[EPV], tau[EPV], a[EPV];
 #pragma unroll
-    for (int e = 0; e < EPV; e += 2) {
-        const f32x2 x = {v[e], v[e + 1]};
-        const f32x2 r = x * p.inv_scale;
-        const f32x2 tr = {__builtin_truncf(r[0]), __builtin_truncf(r[1])};
-        const f32x2 d = r - tr;
-        float t0 = p.threshold, t1 = p.threshold;
-        if constexpr (MODE == RM_STOCH_ELEM) {
-            t0 = element_threshold(keys, p.index_base + e0 + e);
-            t1 = element_threshold(keys, p.index_base + e0 + e + 1);
+        for (int e = 0; e < EPV; e += 2) {
+            const f32x2 x = {v[e], v[e + 1]};
+            const f32x2 prod = x * p.inv_scale;
+            r[e] = prod[0];
+            r[e + 1] = prod[1];
         }
-        const f32x2 adj = {t0 < __builtin_fabsf(d[0]) ? __builtin_copysignf(1.0f, r[0]) : 0.0f,
-                           t1 < __builtin_fabsf(d[1]) ? __builtin_copysignf(1.0f, r[1]) : 0.0f};
-        const f32x2 sum = tr + adj;
-        s[e] = sum[0];
-        s[e + 1] = sum[1];
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) tau[e] = MODE == RM_STOCH_ELEM ? element_threshold(keys, p.index_base + e0 + e) : p.threshold;
+        sub_abs_round_up<EPV, MODE == RM_STOCH_CALL>(r, tau, a);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) s[e] = __builtin_copysignf(__builtin_ceilf(a[e]), r[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPV; e += 2) {
+            const f32x2 x = {v[e], v[e + 1]};
+            const f32x2 r = x * p.inv_scale;
+            const f32x2 tr = {__builtin_truncf(r[0]), __builtin_truncf(r[1])};
+            const f32x2 d = r - tr;
+            float t0 = p.threshold, t1 = p.threshold;
+            if constexpr (MODE == RM_STOCH_ELEM) {
+                t0 = element_threshold(keys, p.index_base + e0 + e);
+                t1 = element_threshold(keys, p.index_base + e0 + e + 1);
+            }
+            const f32x2 adj = {t0 < __builtin_fabsf(d[0]) ? __builtin_copysignf(1.0f, r[0]) : 0.0f,
+                               t1 < __builtin_fabsf(d[1]) ? __builtin_copysignf(1.0f, r[1]) : 0.0f};
+            const f32x2 sum = tr + adj;
+            s[e] = sum[0];
+            s[e + 1] = sum[1];
+        }
     }
     if constexpr (PACK != PACK_HORNER || BITS == 8) {
         constexpr float K = SatScale<BITS>::K, R = 1.0f / static_cast<float>((1 << BITS) - 1);

@@ -56,6 +56,7 @@ constexpr bool kQuantShortStep = true;
 //   bf16 -> uint4 nearest 12.56 -> 12.53, stochastic 13.48 -> 13.33; bf16 -> uint2 nearest 11.56 (Horner form) -> 11.45, stochastic 12.95 -> 12.48;
 //   fp32 -> uint2 19.64 -> 19.57 / 19.92 -> 19.73; 8-bit outputs gain nothing (one v_perm per four elements against nothing) and keep the saturating pack.
 // Tile geometry re-swept on that step (U 2/4/8 x 64..512 threads, profiles/r03_tune_bf16_geometry_final.csv): every table entry above is still the best or within 0.05 us of it.
+// (the stochastic short step's form -- ceil(RU(|r| - tau)), round 5 -- is switched in quant_kernels.hpp, kStochCeilStep: the kernels' header does not see this file)
 constexpr int kQuantVariant = 7;                              // 8-bit outputs
 constexpr int kQuantVariantSubByte = 7 | 8;                   // 4- and 2-bit outputs: QV_NORM_PACK on top
 

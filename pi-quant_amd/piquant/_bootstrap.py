@@ -9,6 +9,7 @@ There is deliberately no fallback: if the HIP library is missing the import fail
 from __future__ import annotations
 
 import ctypes as C
+import os
 import sys
 from pathlib import Path
 
@@ -73,7 +74,10 @@ PIQUANT_DTYPE_F32, PIQUANT_DTYPE_BF16, PIQUANT_DTYPE_UINT2, PIQUANT_DTYPE_UINT4,
 
 
 def library_path() -> Path:
-    return Path(__file__).resolve().parent / _LIB_NAME
+    """libpiquant.so next to this package (where the reference's loader looks too).  PIQUANT_HIP_LIBRARY names another build of the same library:
+    interleaved A/B runs of two builds (tools/, profiles/*_ab.*), nothing else."""
+    override = os.environ.get('PIQUANT_HIP_LIBRARY')
+    return Path(override) if override else Path(__file__).resolve().parent / _LIB_NAME
 
 
 def _load_native_module() -> C.CDLL:
