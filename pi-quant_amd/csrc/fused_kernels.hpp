@@ -248,12 +248,7 @@ fused_params_quantize_kernel(const void* in0, uint8_t* out0, int64_t numel0, Par
     // block's first data load -- is avoided by keeping the value in its VGPR, opaque to the compiler, until its first use behind phase 1:
     // the load is the oldest in flight and has long returned by then (one `global_load_dword ... sc1` in front of the 27 data loads, no
     // wait before the first of them: checked in the ISA).
-#ifdef PQ_FUSED_GEN_SCALAR   // tune harness A/B only: round 3's load through the scalar cache (s_load_dword), not coherent across XCDs
-    uint32_t gen_v;
-    asm volatile("s_load_dword %0, %1, 0x0" : "=s"(gen_v) : "s"(&st->generation) : "memory");
-#else
     uint32_t gen_v = __hip_atomic_load(&st->generation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
 
     // ---- phase 1: load everything once; rounds [0, R_REG) stay in registers, [R_REG, R_REG + R_LDS) in LDS -------------
     float lo = 3.402823466e+38f, hi = -3.402823466e+38f;
@@ -311,13 +306,8 @@ fused_params_quantize_kernel(const void* in0, uint8_t* out0, int64_t numel0, Par
             }
         }
     }
-#ifdef PQ_FUSED_GEN_SCALAR
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(gen_v));
-    const uint32_t gen = gen_v;
-#else
     asm volatile("" : "+v"(gen_v));   // first use of the generation word loaded a whole phase ago: the load's wait lands here, not at the load
     const uint32_t gen = __builtin_amdgcn_readfirstlane(gen_v);
-#endif
     if (block == 0) {   // re-arm the buffer the NEXT launch will use: the previous launch read it, and that launch has completed
         if constexpr (AG) {
             if (tid < kFusedMaxBlocks) st->gathered[(gen & 1) ^ 1][tid] = kFusedNotArrived;

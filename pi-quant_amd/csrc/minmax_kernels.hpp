@@ -65,79 +65,6 @@ __device__ __forceinline__ int32_t wave_min_i32(int32_t v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
-// ---- Raw-word fold (round 4) -------------------------------------------------------------------------------------------------
-// min/max of IEEE floats without touching a float: read as integers, the patterns of non-negative floats ascend as SIGNED and as
-// unsigned integers, those of negative floats sit above every non-negative one as UNSIGNED integers and ascend with their magnitude.  Three
-// running integers per lane therefore hold everything:
-//     a = max as signed ints    -> the largest non-negative float, once one has been seen (else a stays negative);
-//     b = max as unsigned ints  -> the most negative float, once a negative one has been seen (else b < sign bit);
-//     c = min as unsigned ints  -> the smallest non-negative float if there is one, else the negative float of smallest magnitude.
-//     min = any negative ? b : c          max = any non-negative ? a : c
-// -0.0 counts as negative and orders below +0.0, exactly like the int32 keys the results travel in (float_to_key).
-// bf16: the same on both 16-bit halves of a dword at once (v_pk_max_i16 / v_pk_max_u16 / v_pk_min_u16: three instructions per TWO
-// elements, where unpack + canonicalise + v_min_f32 + v_max_f32 are four and a half per ONE); fp32: v_max3_i32 / v_max3_u32 / v_min3_u32,
-// three instructions per two elements against three per one.
-// NaNs: a positive NaN pattern is the largest signed value there is, a negative one the largest unsigned value: one of them in the data
-// ends up in a or b and is SEEN there (a above +inf's pattern, b above -inf's) -- c cannot hide one, it only becomes a NaN when there
-// is nothing else of that sign either, and then a or b shows it.  The scan kernel treats that as "this block has to look properly" and
-// folds its share again the float way (quieted, v_min/v_max skip NaNs): tensors with NaNs cost their blocks a second pass, everybody
-// else never executes a float instruction in the loop.
-typedef int16_t i16x2 __attribute__((ext_vector_type(2)));
-
-template <int DT_IN>
-struct RawFold;
-
-template <>
-struct RawFold<DT_F32> {
-    int32_t a = INT32_MIN;
-    uint32_t b = 0u, c = 0xffffffffu;
-    __device__ __forceinline__ void fold(const u32x4& r) {
-        a = max(max(a, static_cast<int32_t>(r[0])), static_cast<int32_t>(r[1]));
-        a = max(max(a, static_cast<int32_t>(r[2])), static_cast<int32_t>(r[3]));
-        b = max(max(b, r[0]), r[1]);
-        b = max(max(b, r[2]), r[3]);
-        c = min(min(c, r[0]), r[1]);
-        c = min(min(c, r[2]), r[3]);
-    }
-    // -> this lane's {min, max} as floats (identities when the lane saw nothing), true if it saw a NaN
-    __device__ __forceinline__ bool finish(float& lo, float& hi) const {
-        const bool any_neg = b >= 0x80000000u, any_nonneg = a >= 0;
-        lo = __uint_as_float(any_neg ? b : c);
-        hi = __uint_as_float(any_nonneg ? static_cast<uint32_t>(a) : c);
-        if (!any_neg && !any_nonneg) {
-            lo = 3.402823466e+38f;
-            hi = -3.402823466e+38f;
-        }
-        return a > 0x7f800000 || b > 0xff800000u;
-    }
-};
-
-template <>
-struct RawFold<DT_BF16> {
-    uint32_t a = 0x80008000u, b = 0u, c = 0xffffffffu;   // packed pairs of the fp32 form's three integers
-    __device__ __forceinline__ void fold(const u32x4& r) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const uint32_t w = r[e];   // a copy, not r[e] itself: __builtin_bit_cast of an ext-vector ELEMENT lvalue reads element 0 whatever e is (clang 22)
-            a = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, a), __builtin_bit_cast(i16x2, w)));
-            b = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, b), __builtin_bit_cast(u16x2, w)));
-            c = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, c), __builtin_bit_cast(u16x2, w)));
-        }
-    }
-    __device__ __forceinline__ bool finish(float& lo, float& hi) const {
-        const int32_t a1 = max(static_cast<int32_t>(static_cast<int16_t>(a & 0xffffu)), static_cast<int32_t>(static_cast<int16_t>(a >> 16)));
-        const uint32_t b1 = max(b & 0xffffu, b >> 16), c1 = min(c & 0xffffu, c >> 16);
-        const bool any_neg = b1 >= 0x8000u, any_nonneg = a1 >= 0;
-        lo = __uint_as_float((any_neg ? b1 : c1) << 16);
-        hi = __uint_as_float((any_nonneg ? static_cast<uint32_t>(a1) : c1) << 16);
-        if (!any_neg && !any_nonneg) {
-            lo = 3.402823466e+38f;
-            hi = -3.402823466e+38f;
-        }
-        return a1 > 0x7f80 || b1 > 0xff80u;
-    }
-};
-
 constexpr int kMinmaxSlots = 64;          // key pairs per slot buffer
 constexpr int kMinmaxSlotStride = 32;     // int32 per slot: one 128-byte line each -- [0] key(min), [1] key(-max), [2] arrivals
 constexpr int kMinmaxSlotInts = kMinmaxSlots * kMinmaxSlotStride;
@@ -404,66 +331,6 @@ __device__ __forceinline__ void minmax_block_end_gather(float lo, float hi, cons
 // the vectors left over after the last FULL round were loaded one at a time behind it, each waiting out a whole memory round trip with
 // nothing else in flight: at numel 27 264 000 a bf16 scan (26.0009 vectors per thread) paid two such trips, the fp32 scan (52.0018) one,
 // in its block 0 only.  Interleaved A/B of the three forms (profiles/r04_scan_tail_ab.csv): bf16 12.20 -> 11.94 us, fp32 19.44 -> 19.52.
-#if defined(PQ_SCAN_TAIL) && PQ_SCAN_TAIL == 0   // tune harness A/B only: round 3's loop (leftover vectors loaded one at a time behind the window)
-template <int U, bool NT, class Fold>
-__device__ __forceinline__ void minmax_scan_share(const u32x4* __restrict__ in16, int64_t n_vec, int64_t tid, int64_t nthreads, Fold&& fold) {
-    int64_t v = tid;
-    const int64_t round = static_cast<int64_t>(U) * nthreads;
-    if (v + static_cast<int64_t>(U - 1) * nthreads < n_vec) {
-        u32x4 raw[U];
-#pragma unroll
-        for (int k = 0; k < U; ++k) raw[k] = ld<NT>(in16 + v + k * nthreads);
-        while (v + round + static_cast<int64_t>(U - 1) * nthreads < n_vec) {
-#pragma unroll
-            for (int k = 0; k < U; ++k) {
-                fold(raw[k]);
-                raw[k] = ld<NT>(in16 + v + round + k * nthreads);
-            }
-            v += round;
-        }
-#pragma unroll
-        for (int k = 0; k < U; ++k) fold(raw[k]);
-        v += round;
-    }
-    for (; v < n_vec; v += nthreads) fold(ld<NT>(in16 + v));
-}
-#elif defined(PQ_SCAN_TAIL) && PQ_SCAN_TAIL == 1   // tune harness A/B only: uniform rounds, every slot of the last round loaded (clamped)
-template <int U, bool NT, class Fold>
-__device__ __forceinline__ void minmax_scan_share(const u32x4* __restrict__ in16, int64_t n_vec, int64_t tid, int64_t nthreads, Fold&& fold) {
-    if (n_vec <= 0) return;
-    const int64_t round = static_cast<int64_t>(U) * nthreads;
-    const int64_t rounds = (n_vec + round - 1) / round;
-    const int64_t last = n_vec - 1;
-    u32x4 raw[U];
-    if (rounds == 1) {
-#pragma unroll
-        for (int k = 0; k < U; ++k) {
-            const int64_t i = tid + k * nthreads;
-            raw[k] = ld<NT>(in16 + (i < last ? i : last));
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < U; ++k) raw[k] = ld<NT>(in16 + tid + k * nthreads);
-        int64_t v = tid + round;
-        for (int64_t r = 2; r < rounds; ++r) {
-#pragma unroll
-            for (int k = 0; k < U; ++k) {
-                fold(raw[k]);
-                raw[k] = ld<NT>(in16 + v + k * nthreads);
-            }
-            v += round;
-        }
-#pragma unroll
-        for (int k = 0; k < U; ++k) {
-            fold(raw[k]);
-            const int64_t i = v + k * nthreads;
-            raw[k] = ld<NT>(in16 + (i < last ? i : last));
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < U; ++k) fold(raw[k]);
-}
-#else
 template <int U, bool NT, class Fold>
 __device__ __forceinline__ void minmax_scan_share(const u32x4* __restrict__ in16, int64_t n_vec, int64_t tid, int64_t nthreads, Fold&& fold) {
     if (n_vec <= 0) return;
@@ -506,7 +373,6 @@ __device__ __forceinline__ void minmax_scan_share(const u32x4* __restrict__ in16
     for (int k = 0; k < U; ++k)
         if (live[k]) fold(raw[k]);
 }
-#endif
 
 // `head`: leading elements in FRONT of `in` (fewer than a vector; block 0 folds them one by one): the launcher moves `in` up to the next
 // 16-byte boundary, so that a scan of a tensor that is only element-aligned (x[1:]) still runs on aligned vector loads -- which elements
@@ -515,57 +381,41 @@ __device__ __forceinline__ void minmax_scan_share(const u32x4* __restrict__ in16
 // end the preloaded prefix): the epilogue's fields, the head and the grid size (gridDim.x read from the dispatch packet is an s_load too).
 // Until round 3 the epilogue struct, the head and gridDim were s_loaded at the kernel's first instructions and WAITED for before the
 // first global load: one scalar-cache round trip in front of a scan whose 2 048 waves all start at the same instant.
-// RAW: the vectors are folded as integers (RawFold above); a wave that meets a NaN pattern folds its share again the float way.
-// POLL (gather end only): the grid carries ONE block more than scans -- the last one, which does nothing but sweep the other blocks' result
-// words from the moment it starts; without it the highest scanning block sweeps after its own share, i.e. the sweep's first loads are issued
-// when the slowest block is done, not before.
-template <int DT_IN, int U, bool NT, int BLOCK, bool GATHER = false, bool RAW = false, bool POLL = false>
+// (Round 4 measured two more forms and dropped them -- folding the raw words as integers, and an extra block that only sweeps the result words from
+// its first instruction: profiles/EXPERIMENTS.md, r04_tune_mm5.csv / r04_tune_mm6.csv; the code went with round 5's clean-up.)
+template <int DT_IN, int U, bool NT, int BLOCK, bool GATHER = false>
 __global__ void __launch_bounds__(BLOCK) minmax_kernel(const void* __restrict__ in, int64_t numel, int32_t* state, void* ep_dst, int ep_action, int ep_bits, uint32_t ep_seq,
                                                         int head, uint32_t grid) {
-    static_assert(!POLL || GATHER, "the polling block belongs to the gather end");
     const MinmaxEpilogue ep {ep_action, ep_bits, ep_seq, ep_dst};
     constexpr int EPV = InVec<DT_IN>::EPV;
     constexpr int WAVES = BLOCK / 64;
     const u32x4* __restrict__ in16 = static_cast<const u32x4*>(in);
     const int64_t n_vec = numel / EPV;
     const int64_t tid = static_cast<int64_t>(blockIdx.x) * BLOCK + threadIdx.x;
-    const int64_t nthreads = static_cast<int64_t>(grid - (POLL ? 1u : 0u)) * BLOCK;
+    const int64_t nthreads = static_cast<int64_t>(grid) * BLOCK;
 
     float lo = 3.402823466e+38f, hi = -3.402823466e+38f;     // identities of the reference (:1422-1423)
 
-    if (!POLL || blockIdx.x + 1 != grid) {
-        auto fold = [&](const u32x4& raw) {
-            float f[EPV];
-            InVec<DT_IN>::unpack(raw, f);
+    minmax_scan_share<U, NT>(in16, n_vec, tid, nthreads, [&](const u32x4& raw) {
+        float f[EPV];
+        InVec<DT_IN>::unpack(raw, f);
 #pragma unroll
-            for (int e = 0; e < EPV; ++e) {
-                const float x = quieted(f[e]);   // a signaling NaN would poison the fold (device_math.hpp)
-                lo = __builtin_fminf(lo, x);
-                hi = __builtin_fmaxf(hi, x);
-            }
-        };
-        if constexpr (RAW) {
-            RawFold<DT_IN> words;
-            minmax_scan_share<U, NT>(in16, n_vec, tid, nthreads, [&](const u32x4& raw) { words.fold(raw); });
-            if (__any(words.finish(lo, hi) ? 1 : 0)) {   // a NaN somewhere in this wave's share: look again, properly
-                lo = 3.402823466e+38f;
-                hi = -3.402823466e+38f;
-                minmax_scan_share<U, NT>(in16, n_vec, tid, nthreads, fold);
-            }
-        } else {
-            minmax_scan_share<U, NT>(in16, n_vec, tid, nthreads, fold);
-        }
-        // ragged scalar tail (numel % EPV elements)
-        for (int64_t i = n_vec * EPV + tid; i < numel; i += nthreads) {
-            const float x = quieted(InVec<DT_IN>::load_scalar(in, i));
+        for (int e = 0; e < EPV; ++e) {
+            const float x = quieted(f[e]);   // a signaling NaN would poison the fold (device_math.hpp)
             lo = __builtin_fminf(lo, x);
             hi = __builtin_fmaxf(hi, x);
         }
-        if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < head) {   // the elements in front of the first aligned vector
-            const float x = quieted(InVec<DT_IN>::load_scalar(in, static_cast<int64_t>(threadIdx.x) - head));
-            lo = __builtin_fminf(lo, x);
-            hi = __builtin_fmaxf(hi, x);
-        }
+    });
+    // ragged scalar tail (numel % EPV elements)
+    for (int64_t i = n_vec * EPV + tid; i < numel; i += nthreads) {
+        const float x = quieted(InVec<DT_IN>::load_scalar(in, i));
+        lo = __builtin_fminf(lo, x);
+        hi = __builtin_fmaxf(hi, x);
+    }
+    if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < head) {   // the elements in front of the first aligned vector
+        const float x = quieted(InVec<DT_IN>::load_scalar(in, static_cast<int64_t>(threadIdx.x) - head));
+        lo = __builtin_fminf(lo, x);
+        hi = __builtin_fmaxf(hi, x);
     }
 
     lo = wave_min(lo);
@@ -581,12 +431,10 @@ __global__ void __launch_bounds__(BLOCK) minmax_kernel(const void* __restrict__ 
     else minmax_block_end<WAVES>(lo, hi, s_lo, s_hi, state, ep, grid);
 }
 
-// Host side of the argument convention above.  `grid` = scanning blocks; POLL adds the sweeping block on top.
-template <int DT_IN, int U, bool NT, int BLOCK, bool GATHER = false, bool RAW = false, bool POLL = false>
+// Host side of the argument convention above.
+template <int DT_IN, int U, bool NT, int BLOCK, bool GATHER = false>
 inline void launch_minmax_kernel(unsigned grid, hipStream_t stream, const void* in, int64_t numel, int32_t* state, const MinmaxEpilogue& ep, int head = 0) {
-    const unsigned launched = grid + (POLL ? 1u : 0u);
-    hipLaunchKernelGGL((minmax_kernel<DT_IN, U, NT, BLOCK, GATHER, RAW, POLL>), dim3(launched), dim3(BLOCK), 0, stream, in, numel, state, ep.dst, ep.action, ep.bits, ep.seq, head,
-                       launched);
+    hipLaunchKernelGGL((minmax_kernel<DT_IN, U, NT, BLOCK, GATHER>), dim3(grid), dim3(BLOCK), 0, stream, in, numel, state, ep.dst, ep.action, ep.bits, ep.seq, head, grid);
 }
 
 // Same scan for buffers that are not even element-aligned.

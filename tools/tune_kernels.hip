@@ -333,86 +333,22 @@ static void run_requant(const Bufs& b, int64_t numel, int num_cu, double bytes_p
 
 static std::vector<int> g_mm_caps = {1, 2, 4, 8, 16, 32};
 
-template <int DT_IN, int U, bool NT, int BLOCK, bool GATHER = false, bool RAW = false, bool POLL = false>
+template <int DT_IN, int U, bool NT, int BLOCK, bool GATHER = false>
 static void run_minmax(const Bufs& b, int64_t numel, int num_cu, int32_t* keys) {
     for (int cap : g_mm_caps) {
         // cap 0: one round of U loads per block, as many blocks as that takes (the hardware's dispatcher balances the load)
         const int64_t per_block = static_cast<int64_t>(BLOCK) * U * InVec<DT_IN>::EPV;
         const unsigned grid = cap == 0 ? static_cast<unsigned>((numel + per_block - 1) / per_block) : static_cast<unsigned>(cap * num_cu);
-        if (GATHER && grid + (POLL ? 1u : 0u) > static_cast<unsigned>(kMinmaxGatherMax)) continue;
+        if (GATHER && grid > static_cast<unsigned>(kMinmaxGatherMax)) continue;
         const double us = time_us([&](int i) {
             // production protocol: the finishing block folds the per-block results into a key pair and re-arms the state inside the launch
-            launch_minmax_kernel<DT_IN, U, NT, BLOCK, GATHER, RAW, POLL>(grid, g_stream, b.in[i % SETS], numel, keys,
+            launch_minmax_kernel<DT_IN, U, NT, BLOCK, GATHER>(grid, g_stream, b.in[i % SETS], numel, keys,
                                MinmaxEpilogue {EP_KEYS_SET, 0, 0u, keys + kMinmaxScanStateInts});
         });
         char name[160];
-        std::snprintf(name, sizeof name, "in=%s U=%d nt=%d block=%d end=%s fold=%s cap=%d grid=%u", DT_IN == DT_F32 ? "f32" : "bf16", U, NT ? 1 : 0, BLOCK,
-                      GATHER ? (POLL ? "gather+poller" : "gather") : "slots", RAW ? "raw" : "float", cap, grid);
+        std::snprintf(name, sizeof name, "in=%s U=%d nt=%d block=%d end=%s cap=%d grid=%u", DT_IN == DT_F32 ? "f32" : "bf16", U, NT ? 1 : 0, BLOCK,
+                      GATHER ? "gather" : "slots", cap, grid);
         report("minmax", name, us, (DT_IN == DT_F32 ? 4.0 : 2.0) * numel);
-    }
-}
-
-// keys of one scan of `in` with the given variant (synchronous)
-template <int DT_IN, int U, bool NT, int BLOCK, bool GATHER, bool RAW, bool POLL>
-static void minmax_once(const void* in, int64_t numel, unsigned grid, int32_t* keys, int32_t (&out)[2]) {
-    launch_minmax_kernel<DT_IN, U, NT, BLOCK, GATHER, RAW, POLL>(grid, g_stream, in, numel, keys, MinmaxEpilogue {EP_KEYS_SET, 0, 0u, keys + kMinmaxScanStateInts});
-    CK(hipStreamSynchronize(g_stream));
-    CK(hipMemcpy(out, keys + kMinmaxScanStateInts, sizeof out, hipMemcpyDeviceToHost));
-}
-
-// every round-4 variant of the scan against the round-3 kernel on the same data: clean data, then the same buffer with NaNs of both signs
-// (quiet and signaling) and both infinities planted in it
-template <int DT_IN>
-static void check_minmax_variants(void* buf, int64_t numel, int num_cu, int32_t* keys) {
-    constexpr int ES = DT_IN == DT_F32 ? 4 : 2;
-    for (int planted = 0; planted < 3; ++planted) {
-        if (planted == 1) {   // NaNs only: the extremes must stay those of the numbers
-            const uint32_t pats32[4] = {0x7fc00000u, 0xffc00001u, 0x7f800001u, 0xffbfffffu};
-            const uint16_t pats16[4] = {0x7fc0u, 0xffc1u, 0x7f81u, 0xffbfu};
-            for (int k = 0; k < 4; ++k)
-                CK(hipMemcpy(static_cast<char*>(buf) + (static_cast<int64_t>(k) * (numel / 5) + 12345 + k) * ES, DT_IN == DT_F32 ? static_cast<const void*>(&pats32[k]) : static_cast<const void*>(&pats16[k]), ES,
-                             hipMemcpyHostToDevice));
-        }
-        if (planted == 2) {   // and the infinities
-            const uint32_t inf32[2] = {0x7f800000u, 0xff800000u};
-            const uint16_t inf16[2] = {0x7f80u, 0xff80u};
-            for (int k = 0; k < 2; ++k)
-                CK(hipMemcpy(static_cast<char*>(buf) + (static_cast<int64_t>(k) * (numel / 3) + 777 + k) * ES, DT_IN == DT_F32 ? static_cast<const void*>(&inf32[k]) : static_cast<const void*>(&inf16[k]), ES,
-                             hipMemcpyHostToDevice));
-        }
-        CK(hipDeviceSynchronize());
-        int32_t ref[2], got[2];
-        minmax_once<DT_IN, 4, true, 512, true, false, false>(buf, numel, num_cu, keys, ref);
-        bool ok = true;
-#define CHECK(U_, BLK, RAW_, POLL_, GRID)                                                                                                          \
-    minmax_once<DT_IN, U_, true, BLK, true, RAW_, POLL_>(buf, numel, GRID, keys, got);                                                              \
-    if (got[0] != ref[0] || got[1] != ref[1]) {                                                                                                     \
-        ok = false;                                                                                                                                 \
-        std::printf("check,MISMATCH in=%s planted=%d U=%d block=%d raw=%d poll=%d grid=%u got=%08x %08x want=%08x %08x,0,0,0,0\n",                  \
-                    DT_IN == DT_F32 ? "f32" : "bf16", planted, U_, BLK, int(RAW_), int(POLL_), unsigned(GRID), unsigned(got[0]), unsigned(got[1]), \
-                    unsigned(ref[0]), unsigned(ref[1]));                                                                                            \
-    }
-        CHECK(4, 512, true, false, num_cu)
-        CHECK(4, 512, false, true, num_cu)
-        CHECK(4, 512, true, true, num_cu)
-        CHECK(8, 512, true, true, num_cu)
-        CHECK(4, 256, true, true, 2 * num_cu)
-        CHECK(4, 256, true, false, 2 * num_cu)
-        // odd sizes: ragged tail, a grid larger than the work
-        minmax_once<DT_IN, 4, true, 512, true, false, false>(buf, 1000003, num_cu, keys, ref);
-        minmax_once<DT_IN, 4, true, 512, true, true, true>(buf, 1000003, num_cu, keys, got);
-        if (got[0] != ref[0] || got[1] != ref[1]) {
-            ok = false;
-            std::printf("check,MISMATCH odd size in=%s planted=%d got=%08x %08x want=%08x %08x,0,0,0,0\n", DT_IN == DT_F32 ? "f32" : "bf16", planted, unsigned(got[0]),
-                        unsigned(got[1]), unsigned(ref[0]), unsigned(ref[1]));
-        }
-#undef CHECK
-        std::printf("check,minmax variants == round-3 kernel in=%s planted=%s keys=%08x %08x,%d,0,0,0\n", DT_IN == DT_F32 ? "f32" : "bf16",
-                    planted == 0 ? "nothing" : (planted == 1 ? "NaNs" : "NaNs+infinities"), static_cast<unsigned>(ref[0]), static_cast<unsigned>(ref[1]), ok ? 1 : 0);
-        if (!ok) {
-            std::fprintf(stderr, "minmax variant mismatch\n");
-            std::exit(3);
-        }
     }
 }
 
@@ -770,78 +706,6 @@ int main(int argc, char** argv) {
         }
         g_rounds = 3;
     }
-    if (only == "cap") {
-        // persistent grids for the streaming quantizers: at most `cap` blocks per CU striding over the tiles instead of one block per tile
-        g_rounds = 1;
-        g_num_cu = num_cu;
-        for (int pass = 0; pass < 5; ++pass) {
-            for (int cap : {0, 64, 32, 16, 8}) {
-                g_q3_cap = cap;
-                run_quant3<DT_F32, 8, RM_COPY, 2, true, 5, 128, 0>(b, numel, 5.0);
-                run_quant3<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 128, 7>(b, numel, 5.0);
-            }
-        }
-        for (int s_ = 0; s_ < SETS; ++s_)   // bf16 data of ordinary magnitude (random fp32 bits read as bf16 pairs hold NaNs: every tile would take the long step)
-            hipLaunchKernelGGL(fill_uniform_bf16, dim3(4096), dim3(256), 0, g_stream, static_cast<uint16_t*>(b.in[s_]), numel, 0x9e3779b9u * (s_ + 1));
-        CK(hipStreamSynchronize(g_stream));
-        for (int pass = 0; pass < 5; ++pass) {
-            for (int cap : {0, 64, 32, 16, 8}) {
-                g_q3_cap = cap;
-                run_quant3<DT_BF16, 4, RM_COPY, 2, true, 5, 64, 0>(b, numel, 2.5);
-                run_quant3<DT_BF16, 4, RM_NEAREST_FAST, 2, true, 5, 64, 7>(b, numel, 2.5);
-                run_quant3<DT_BF16, 4, RM_STOCH_CALL, 2, true, 5, 64, 7>(b, numel, 2.5);
-                run_quant3<DT_BF16, 2, RM_STOCH_CALL, 4, true, 5, 256, 7>(b, numel, 2.25);
-                run_quant3<DT_BF16, 8, RM_NEAREST_FAST, 2, true, 3, 64, 7>(b, numel, 3.0);
-            }
-        }
-        g_q3_cap = 0;
-        g_rounds = 3;
-    }
-    if (only == "cap2") {
-        // second look at the one place the persistent grid won: stochastic rounding on bf16 inputs (most arithmetic per byte)
-        g_rounds = 1;
-        g_num_cu = num_cu;
-        for (int s_ = 0; s_ < SETS; ++s_)
-            hipLaunchKernelGGL(fill_uniform_bf16, dim3(4096), dim3(256), 0, g_stream, static_cast<uint16_t*>(b.in[s_]), numel, 0x9e3779b9u * (s_ + 1));
-        CK(hipStreamSynchronize(g_stream));
-        for (int pass = 0; pass < 5; ++pass) {
-            for (int cap : {0, 4, 6, 8, 10, 12, 16}) {
-                g_q3_cap = cap;
-                run_quant3<DT_BF16, 2, RM_STOCH_CALL, 4, true, 5, 256, 7>(b, numel, 2.25);
-                run_quant3<DT_BF16, 4, RM_STOCH_CALL, 4, true, 5, 256, 7>(b, numel, 2.5);
-                run_quant3<DT_BF16, 8, RM_STOCH_CALL, 4, true, 5, 256, 7>(b, numel, 3.0);
-                run_quant3<DT_BF16, 2, RM_NEAREST_FAST, 4, true, 5, 256, 3>(b, numel, 2.25);
-                run_quant3<DT_BF16, 2, RM_STOCH_CALL, 2, true, 5, 256, 7>(b, numel, 2.25);
-            }
-            for (int cap : {0, 40, 48, 64, 80, 96, 128}) {
-                g_q3_cap = cap;
-                run_quant3<DT_BF16, 4, RM_STOCH_CALL, 2, true, 5, 64, 7>(b, numel, 2.5);
-                run_quant3<DT_BF16, 8, RM_STOCH_CALL, 2, true, 5, 64, 7>(b, numel, 3.0);
-                run_quant3<DT_BF16, 2, RM_NEAREST_FAST, 2, true, 5, 64, 3>(b, numel, 2.25);
-            }
-        }
-        g_q3_cap = 0;
-        g_rounds = 3;
-    }
-    if (only == "cap3") {
-        // the persistent grid of bf16 -> uint2 / uint4 stochastic at other sizes (run once per numel)
-        g_rounds = 1;
-        g_num_cu = num_cu;
-        for (int s_ = 0; s_ < SETS; ++s_)
-            hipLaunchKernelGGL(fill_uniform_bf16, dim3(4096), dim3(256), 0, g_stream, static_cast<uint16_t*>(b.in[s_]), numel, 0x9e3779b9u * (s_ + 1));
-        CK(hipStreamSynchronize(g_stream));
-        for (int pass = 0; pass < 5; ++pass) {
-            for (int cap : {0, 6, 8}) {
-                g_q3_cap = cap;
-                run_quant3<DT_BF16, 2, RM_STOCH_CALL, 4, true, 5, 256, 7>(b, numel, 2.25);
-                run_quant3<DT_BF16, 4, RM_STOCH_CALL, 4, true, 5, 256, 7>(b, numel, 2.5);
-            }
-            g_q3_cap = 0;
-            run_quant3<DT_BF16, 4, RM_STOCH_CALL, 2, true, 5, 64, 7>(b, numel, 2.5);
-        }
-        g_q3_cap = 0;
-        g_rounds = 3;
-    }
     if (only == "norm") {
         // pack_normalised (two elements per v_cvt_pknorm_u16_f32, var bit 3) against pack_saturated (var 7) and the Horner form (var 3), production tiles
         g_rounds = 1;
@@ -951,65 +815,6 @@ int main(int argc, char** argv) {
         g_mm_caps = {1, 2, 4, 8, 16, 32};
         g_rounds = 3;
     }
-    if (only == "finals") {
-        // interleaved A/B of the finalists: 6 passes over the list, one timed batch each (noise shows as spread)
-        g_rounds = 1;
-        const int64_t nt256 = numel / (4 * 4 * 64 * 4);
-        const QuantParams p = qparams();
-        for (int pass = 0; pass < 6; ++pass) {
-            g_caps = {0};
-            run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, 5, 256>(b, numel, num_cu, 5);
-            run_quant<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 64>(b, numel, num_cu, 5);
-            run_quant<DT_F32, 8, RM_NEAREST_FAST, 1, true, 5, 64>(b, numel, num_cu, 5);
-            run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, 5, 64>(b, numel, num_cu, 5);
-            run_quant<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 128>(b, numel, num_cu, 5);
-            run_quant<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 256>(b, numel, num_cu, 5);
-            run_quant<DT_F32, 8, RM_NEAREST_FAST, 1, true, 5, 256>(b, numel, num_cu, 5);
-            run_quant<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 1024>(b, numel, num_cu, 5);
-            run_quant<DT_F32, 8, RM_NEAREST_FAST, 2, false, 5, 64>(b, numel, num_cu, 5);
-            run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, false, 5, 64>(b, numel, num_cu, 5);
-            g_caps = {8};
-            run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, 5, 64>(b, numel, num_cu, 5);
-            const double us = time_us([&](int i) {
-                hipLaunchKernelGGL((quant_policy_kernel<1, 3, 256>), dim3(static_cast<unsigned>(nt256)), dim3(256), 0, g_stream,
-                                   static_cast<const u32x4*>(b.in[i % SETS]), static_cast<uint8_t*>(b.out[i % SETS]), nt256, p);
-            });
-            report("policy", "asm ld=nt st=sc0sc1 U=4 block=256 (waits for its loads)", us, 5.0 * numel);
-        }
-        g_caps = {0, 2, 4, 8, 16};
-        g_rounds = 3;
-    }
-    if (only == "shortab") {
-        // the short step on/off, per dtype pair and tile, cold at whatever numel is given (fp32 inputs are not VALU-limited: does the
-        // per-tile range test cost more than the shorter step saves?)
-        g_rounds = 1;
-        g_caps = {0};
-        const int64_t nt256 = numel / (4 * 4 * 64 * 4);
-        const QuantParams p = qparams();
-        for (int pass = 0; pass < 6; ++pass) {
-#define AB(DT, BITS, MODE, U_, BLK, N, BPE)                                    \
-    run_quant<DT, BITS, MODE, U_, true, 5, BLK, true>(b, N, num_cu, BPE);      \
-    run_quant<DT, BITS, MODE, U_, true, 5, BLK, false>(b, N, num_cu, BPE);
-            AB(DT_F32, 8, RM_NEAREST_FAST, 2, 128, numel, 5)
-            AB(DT_F32, 8, RM_NEAREST_FAST, 4, 256, numel, 5)
-            AB(DT_F32, 8, RM_NEAREST_FAST, 2, 64, numel, 5)
-            AB(DT_F32, 8, RM_STOCH_CALL, 2, 128, numel, 5)
-            AB(DT_F32, 4, RM_NEAREST_FAST, 2, 64, numel, 4.5)
-            AB(DT_F32, 2, RM_NEAREST_I64, 2, 64, numel, 4.25)
-            AB(DT_BF16, 8, RM_NEAREST_FAST, 2, 64, numel, 3)
-            AB(DT_BF16, 4, RM_NEAREST_FAST, 2, 64, numel, 2.5)
-            AB(DT_BF16, 4, RM_STOCH_CALL, 2, 64, numel, 2.5)
-            AB(DT_BF16, 2, RM_NEAREST_FAST, 4, 256, numel, 2.25)
-#undef AB
-            const double us = time_us([&](int i) {
-                hipLaunchKernelGGL((quant_policy_kernel<1, 3, 256>), dim3(static_cast<unsigned>(nt256)), dim3(256), 0, g_stream,
-                                   static_cast<const u32x4*>(b.in[i % SETS]), static_cast<uint8_t*>(b.out[i % SETS]), nt256, p);
-            });
-            report("policy", "asm ld=nt st=sc0sc1 U=4 block=256 (waits for its loads)", us, 5.0 * numel);
-        }
-        g_caps = {0, 2, 4, 8, 16};
-        g_rounds = 3;
-    }
     if (only == "rq") {
         g_rounds = 1;
         for (int pass = 0; pass < 4; ++pass) {
@@ -1027,111 +832,6 @@ int main(int argc, char** argv) {
 #undef R6
         }
         g_rounds = 3;
-    }
-    if (only == "occ") {
-        // occupancy throttle: dynamic LDS per block limits resident blocks per CU (160 KiB / request)
-        g_rounds = 1;
-        g_caps = {0};
-        for (int pass = 0; pass < 4; ++pass) {
-            for (unsigned lds : {0u, 9000u, 12000u, 19000u, 26000u, 39000u, 52000u, 79000u}) {
-                g_dyn_lds = lds;
-                run_quant<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 128>(b, numel, num_cu, 5);
-                run_quant<DT_F32, 8, RM_NEAREST_FAST, 4, true, 5, 128>(b, numel, num_cu, 5);
-                run_quant<DT_F32, 8, RM_NEAREST_FAST, 2, true, 5, 64>(b, numel, num_cu, 5);
-            }
-        }
-        g_dyn_lds = 0;
-        g_caps = {0, 2, 4, 8, 16};
-        g_rounds = 3;
-    }
-    if (only == "finals2") {
-        g_rounds = 1;
-        g_caps = {0};
-        for (int pass = 0; pass < 4; ++pass) {
-#define Q4(DT, BITS, MODE, N, BPE)                                                  \
-    run_quant<DT, BITS, MODE, 4, true, 5, 256>(b, N, num_cu, BPE);                  \
-    run_quant<DT, BITS, MODE, 2, true, 5, 128>(b, N, num_cu, BPE);                  \
-    run_quant<DT, BITS, MODE, 2, true, 5, 64>(b, N, num_cu, BPE);                   \
-    run_quant<DT, BITS, MODE, 4, true, 5, 64>(b, N, num_cu, BPE);                   \
-    run_quant<DT, BITS, MODE, 4, true, 5, 128>(b, N, num_cu, BPE);
-            Q4(DT_BF16, 4, RM_NEAREST_FAST, 2 * numel, 2.5)
-            Q4(DT_BF16, 8, RM_NEAREST_FAST, numel, 3)
-            Q4(DT_BF16, 2, RM_NEAREST_FAST, 2 * numel, 2.25)
-            Q4(DT_F32, 4, RM_NEAREST_FAST, numel, 4.5)
-            Q4(DT_F32, 2, RM_NEAREST_I64, numel, 4.25)
-            Q4(DT_F32, 8, RM_STOCH_CALL, numel, 5)
-#undef Q4
-#define D4(BITS, DT, OP, N, BPE)                                                    \
-    run_dequant<BITS, DT, OP, 4, true, 5, 256>(b, N, num_cu, BPE);                  \
-    run_dequant<BITS, DT, OP, 2, true, 5, 128>(b, N, num_cu, BPE);                  \
-    run_dequant<BITS, DT, OP, 2, true, 5, 64>(b, N, num_cu, BPE);                   \
-    run_dequant<BITS, DT, OP, 4, true, 5, 64>(b, N, num_cu, BPE);                   \
-    run_dequant<BITS, DT, OP, 4, true, 5, 128>(b, N, num_cu, BPE);
-            D4(8, DT_F32, OP_SET, numel, 5)
-            D4(8, DT_F32, OP_ADD, numel, 9)
-            D4(4, DT_BF16, OP_SET, 2 * numel, 2.5)
-            D4(4, DT_BF16, OP_ADD, 2 * numel, 4.5)
-            D4(8, DT_BF16, OP_SET, numel, 3)
-            D4(2, DT_BF16, OP_SET, 2 * numel, 2.25)
-            D4(4, DT_F32, OP_SET, numel, 4.5)
-#undef D4
-        }
-        g_caps = {0, 2, 4, 8, 16};
-        g_rounds = 3;
-    }
-    // (a "pf" section once compared persistent grids with software prefetch of the next tile: always slower than one small tile
-    // per block, profiles/r01_tune_experiments.csv; the kernel variant was removed from quant_kernels.hpp)
-    if (only == "exp") {
-        const QuantParams p = qparams();
-        // (1) fixed vs per-byte cost: production headline kernel at several sizes (all within the 109 MB input buffers)
-        for (double f : {0.0625, 0.125, 0.25, 0.5, 1.0}) {
-            const int64_t n = static_cast<int64_t>(numel * f) / 65536 * 65536;
-            using T = QuantTile<DT_F32, 8, 2, 1024>;
-            const int64_t nt = n / T::BLOCK_ELEMS;
-            const double us = time_us([&](int i) {
-                launch_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, 2, true, 3, 1024>(static_cast<unsigned>(nt), 0, g_stream, b.in[i % SETS], static_cast<uint8_t*>(b.out[i % SETS]), n, nt, p, 0);
-            });
-            report("size", "f32->u8 U=2 block=1024 numel=" + std::to_string(n), us, 5.0 * n);
-        }
-        // (2) two streams, alternate launches: does the next kernel's ramp hide the previous kernel's tail?
-        {
-            hipStream_t s2;
-            CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
-            using T = QuantTile<DT_F32, 8, 2, 1024>;
-            const int64_t nt = numel / T::BLOCK_ELEMS;
-            hipEvent_t e0, e1, j;
-            CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&j));
-            for (int round = 0; round < 3; ++round) {
-                CK(hipStreamSynchronize(g_stream)); CK(hipStreamSynchronize(s2));
-                CK(hipEventRecord(e0, g_stream));
-                CK(hipStreamWaitEvent(s2, e0, 0));
-                for (int i = 0; i < g_reps; ++i)
-                    launch_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, 2, true, 3, 1024>(static_cast<unsigned>(nt), 0, (i & 1) ? s2 : g_stream, b.in[i % SETS], static_cast<uint8_t*>(b.out[i % SETS]), numel, nt, p, 0);
-                CK(hipEventRecord(j, s2));
-                CK(hipStreamWaitEvent(g_stream, j, 0));
-                CK(hipEventRecord(e1, g_stream));
-                CK(hipEventSynchronize(e1));
-                float ms = 0;
-                CK(hipEventElapsedTime(&ms, e0, e1));
-                g_last_max = ms * 1e3 / g_reps;
-                report("overlap", "two streams alternating round=" + std::to_string(round), ms * 1e3 / g_reps, 5.0 * numel);
-            }
-        }
-        // (3) cache-policy bits on loads / stores
-        {
-            const int64_t nt256 = numel / (4 * 4 * 64 * 4);   // BLOCK 256: 4 waves * 4 vec * 64 lanes * 4 elems
-#define POLICY(LDP, STP)                                                                                                               \
-    {                                                                                                                                  \
-        const double us = time_us([&](int i) {                                                                                         \
-            hipLaunchKernelGGL((quant_policy_kernel<LDP, STP, 256>), dim3(static_cast<unsigned>(nt256)), dim3(256), 0, g_stream,       \
-                               static_cast<const u32x4*>(b.in[i % SETS]), static_cast<uint8_t*>(b.out[i % SETS]), nt256, p);           \
-        });                                                                                                                            \
-        report("policy", "ld=" #LDP " st=" #STP " (0 plain,1 nt,2 sc1,3 sc0sc1,4 sc0,5 sc1nt,6 sc0sc1nt)", us, 5.0 * numel);          \
-    }
-            POLICY(1, 1) POLICY(0, 0) POLICY(1, 0) POLICY(1, 2) POLICY(1, 3) POLICY(1, 4) POLICY(1, 5) POLICY(1, 6)
-            POLICY(2, 1) POLICY(3, 1) POLICY(4, 1) POLICY(5, 1) POLICY(6, 1) POLICY(5, 5) POLICY(6, 6) POLICY(2, 2) POLICY(3, 3)
-#undef POLICY
-        }
     }
 
     if (only == "all" || only == "qother") {
@@ -1175,186 +875,6 @@ int main(int argc, char** argv) {
         run_dequant<2, DT_BF16, OP_SET, 4, true, 5, 256>(b, 2 * numel, num_cu, 2.25);
         run_dequant<2, DT_F32, OP_SET, 4, true, 5, 256>(b, numel, num_cu, 4.25);
     }
-    if (only == "mm2") {
-        // interleaved A/B of the scan's end protocol at the production geometry and its neighbours
-        g_rounds = 1;
-        g_mm_caps = {1, 2, 4};
-        for (int pass = 0; pass < 5; ++pass) {
-            run_minmax<DT_F32, 4, true, 256, false>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 4, true, 256, true>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 8, true, 256, true>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 4, true, 512, true>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 8, true, 512, true>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 4, true, 1024, true>(b, numel, num_cu, keys);
-            run_minmax<DT_BF16, 4, true, 256, false>(b, numel, num_cu, keys);
-            run_minmax<DT_BF16, 4, true, 256, true>(b, numel, num_cu, keys);
-        }
-        g_mm_caps = {1, 2, 4, 8, 16, 32};
-        g_rounds = 3;
-    }
-    if (only == "mm4") {
-        // many small blocks (dynamic dispatch) against the persistent grids, gather end
-        g_rounds = 1;
-        g_mm_caps = {0, 1};
-        for (int pass = 0; pass < 4; ++pass) {
-            run_minmax<DT_F32, 4, true, 512, true>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 4, true, 256, true>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 8, true, 256, true>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 8, true, 512, true>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 16, true, 256, true>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 8, true, 1024, true>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 4, true, 1024, true>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 2, true, 1024, true>(b, numel, num_cu, keys);
-        }
-        g_mm_caps = {1, 2, 4, 8, 16, 32};
-        g_rounds = 3;
-    }
-    if (only == "mm3") {
-        // wider geometry sweep of the scan with the gather end: threads per block x loads in flight per lane x blocks per CU
-        g_rounds = 1;
-        g_mm_caps = {1, 2, 4, 8};
-        for (int pass = 0; pass < 4; ++pass) {
-            run_minmax<DT_F32, 4, true, 256, true>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 2, true, 256, true>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 4, true, 256, false>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 4, true, 512, true>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 8, true, 256, true>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 16, true, 256, true>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 16, true, 128, true>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 8, true, 128, true>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 2, true, 1024, true>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 2, true, 512, true>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 6, true, 512, true>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 4, false, 512, true>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 4, true, 768, true>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 4, true, 384, true>(b, numel, num_cu, keys);
-        }
-        g_mm_caps = {1, 2, 4, 8, 16, 32};
-        g_rounds = 3;
-    }
-    if (only == "dqp") {
-        // dequantize family under cold rotation: store policy (5 = write-through, 3 = non-temporal) x tile shape.  Run with numel = 27264000:
-        // the bf16 outputs hold numel (N1) or 2 * numel elements in the 109 MB buffers.
-        g_rounds = 1;
-        g_caps = {0};
-        for (int pass = 0; pass < 4; ++pass) {
-#define DQP(BITS, DT, OP, N, BPE)                                  \
-    run_dequant<BITS, DT, OP, 4, true, 5, 256>(b, N, num_cu, BPE); \
-    run_dequant<BITS, DT, OP, 4, true, 3, 256>(b, N, num_cu, BPE); \
-    run_dequant<BITS, DT, OP, 2, true, 5, 128>(b, N, num_cu, BPE); \
-    run_dequant<BITS, DT, OP, 2, true, 3, 128>(b, N, num_cu, BPE); \
-    run_dequant<BITS, DT, OP, 2, true, 5, 64>(b, N, num_cu, BPE);  \
-    run_dequant<BITS, DT, OP, 2, true, 3, 64>(b, N, num_cu, BPE);  \
-    run_dequant<BITS, DT, OP, 4, true, 3, 512>(b, N, num_cu, BPE);
-            DQP(4, DT_BF16, OP_SET, numel, 2.5)
-            DQP(4, DT_BF16, OP_SET, 2 * numel, 2.5)
-            DQP(4, DT_BF16, OP_ADD, numel, 4.5)
-            DQP(8, DT_F32, OP_SET, numel, 5)
-            DQP(8, DT_F32, OP_ADD, numel, 9)
-            DQP(8, DT_BF16, OP_SET, numel, 3)
-            DQP(4, DT_F32, OP_SET, numel, 4.5)
-            DQP(2, DT_BF16, OP_SET, numel, 2.25)
-            DQP(2, DT_F32, OP_SET, numel, 4.25)
-#undef DQP
-        }
-        g_caps = {0, 2, 4, 8, 16};
-        g_rounds = 3;
-    }
-    if (only == "dqa") {
-        // the ADD side of the dequantize pairs that the dqp sweep left out, cold rotation, numel = 27264000
-        g_rounds = 1;
-        g_caps = {0};
-        for (int pass = 0; pass < 4; ++pass) {
-#define DQA(BITS, DT, BPE)                                                \
-    run_dequant<BITS, DT, OP_ADD, 4, true, 5, 256>(b, numel, num_cu, BPE); \
-    run_dequant<BITS, DT, OP_ADD, 4, true, 3, 256>(b, numel, num_cu, BPE); \
-    run_dequant<BITS, DT, OP_ADD, 2, true, 5, 256>(b, numel, num_cu, BPE); \
-    run_dequant<BITS, DT, OP_ADD, 2, true, 5, 128>(b, numel, num_cu, BPE); \
-    run_dequant<BITS, DT, OP_ADD, 2, true, 3, 128>(b, numel, num_cu, BPE); \
-    run_dequant<BITS, DT, OP_ADD, 2, true, 5, 64>(b, numel, num_cu, BPE);  \
-    run_dequant<BITS, DT, OP_ADD, 2, true, 3, 64>(b, numel, num_cu, BPE);  \
-    run_dequant<BITS, DT, OP_ADD, 4, true, 5, 128>(b, numel, num_cu, BPE); \
-    run_dequant<BITS, DT, OP_ADD, 4, true, 3, 128>(b, numel, num_cu, BPE);
-            DQA(2, DT_BF16, 4.25)
-            DQA(2, DT_F32, 8.25)
-            DQA(8, DT_BF16, 5)
-            DQA(4, DT_F32, 8.5)
-#undef DQA
-        }
-        g_caps = {0, 2, 4, 8, 16};
-        g_rounds = 3;
-    }
-    if (only == "qp") {
-        // quantize family under cold rotation: store policy (5 = write-through, 3 = non-temporal, 1 = plain) at the production tiles; numel = 27264000
-        g_rounds = 1;
-        g_caps = {0};
-        for (int pass = 0; pass < 4; ++pass) {
-#define QP(DT, BITS, MODE, U_, BLK, N, BPE)                              \
-    run_quant<DT, BITS, MODE, U_, true, 5, BLK>(b, N, num_cu, BPE);      \
-    run_quant<DT, BITS, MODE, U_, true, 3, BLK>(b, N, num_cu, BPE);      \
-    run_quant<DT, BITS, MODE, U_, true, 1, BLK>(b, N, num_cu, BPE);
-            QP(DT_F32, 8, RM_NEAREST_FAST, 2, 128, numel, 5)
-            QP(DT_F32, 8, RM_STOCH_CALL, 2, 128, numel, 5)
-            QP(DT_F32, 4, RM_NEAREST_FAST, 2, 64, numel, 4.5)
-            QP(DT_F32, 2, RM_NEAREST_I64, 2, 64, numel, 4.25)
-            QP(DT_BF16, 8, RM_NEAREST_FAST, 2, 64, numel, 3)
-            QP(DT_BF16, 4, RM_NEAREST_FAST, 2, 64, numel, 2.5)
-            QP(DT_BF16, 4, RM_NEAREST_FAST, 2, 64, 2 * numel, 2.5)
-            QP(DT_BF16, 2, RM_NEAREST_FAST, 4, 256, numel, 2.25)
-#undef QP
-            run_requant<DT_F32, 8, OP_SET, 2, 5, 64>(b, numel, num_cu, 8);
-            run_requant<DT_F32, 8, OP_SET, 2, 3, 64>(b, numel, num_cu, 8);
-            run_requant<DT_F32, 8, OP_ADD, 2, 5, 64>(b, numel, num_cu, 12);
-            run_requant<DT_F32, 8, OP_ADD, 2, 3, 64>(b, numel, num_cu, 12);
-            run_requant<DT_BF16, 4, OP_SET, 2, 5, 64>(b, numel, num_cu, 4);
-            run_requant<DT_BF16, 4, OP_SET, 2, 3, 64>(b, numel, num_cu, 4);
-        }
-        g_caps = {0, 2, 4, 8, 16};
-        g_rounds = 3;
-    }
-    if (only == "bfq") {
-        // bf16 -> uint4 / uint2 nearest, tile shapes x store policy, really cold: pass N1/2 as numel (the bf16 view holds 2 * numel elements;
-        // the rotation is sized for 5 B per fp32 element of `numel`, i.e. 2.5 B per bf16 element of the view: > 330 MB of outputs)
-        g_rounds = 1;
-        g_caps = {0};
-        for (int pass = 0; pass < 4; ++pass) {
-#define BFQ(BITS, BPE)                                                                    \
-    run_quant<DT_BF16, BITS, RM_NEAREST_FAST, 2, true, 5, 64>(b, 2 * numel, num_cu, BPE);   \
-    run_quant<DT_BF16, BITS, RM_NEAREST_FAST, 2, true, 3, 64>(b, 2 * numel, num_cu, BPE);   \
-    run_quant<DT_BF16, BITS, RM_NEAREST_FAST, 1, true, 5, 64>(b, 2 * numel, num_cu, BPE);   \
-    run_quant<DT_BF16, BITS, RM_NEAREST_FAST, 2, true, 5, 128>(b, 2 * numel, num_cu, BPE);  \
-    run_quant<DT_BF16, BITS, RM_NEAREST_FAST, 1, true, 5, 128>(b, 2 * numel, num_cu, BPE);  \
-    run_quant<DT_BF16, BITS, RM_NEAREST_FAST, 4, true, 5, 128>(b, 2 * numel, num_cu, BPE);  \
-    run_quant<DT_BF16, BITS, RM_NEAREST_FAST, 2, true, 5, 256>(b, 2 * numel, num_cu, BPE);  \
-    run_quant<DT_BF16, BITS, RM_NEAREST_FAST, 4, true, 5, 256>(b, 2 * numel, num_cu, BPE);  \
-    run_quant<DT_BF16, BITS, RM_NEAREST_FAST, 4, true, 3, 256>(b, 2 * numel, num_cu, BPE);  \
-    run_quant<DT_BF16, BITS, RM_NEAREST_FAST, 1, true, 5, 256>(b, 2 * numel, num_cu, BPE);
-            BFQ(4, 2.5)      // (uint8 output of the 2 * numel view would need 2 * numel bytes: the output buffers hold numel)
-            BFQ(2, 2.25)
-#undef BFQ
-        }
-        g_caps = {0, 2, 4, 8, 16};
-        g_rounds = 3;
-    }
-    if (only == "q4") {
-        // bf16 -> uint4 at numel (pass N1/2 as numel: the bf16 view holds 2 * numel elements): tile shapes and persistent grids
-        g_rounds = 1;
-        for (int pass = 0; pass < 4; ++pass) {
-            g_caps = {0, 8, 16, 32};
-            run_quant<DT_BF16, 4, RM_NEAREST_FAST, 2, true, 5, 64>(b, 2 * numel, num_cu, 2.5);
-            run_quant<DT_BF16, 4, RM_NEAREST_FAST, 1, true, 5, 64>(b, 2 * numel, num_cu, 2.5);
-            run_quant<DT_BF16, 4, RM_NEAREST_FAST, 2, false, 5, 64>(b, 2 * numel, num_cu, 2.5);
-            run_quant<DT_BF16, 4, RM_NEAREST_FAST, 4, true, 5, 256>(b, 2 * numel, num_cu, 2.5);
-            run_quant<DT_BF16, 4, RM_NEAREST_FAST, 2, true, 5, 256>(b, 2 * numel, num_cu, 2.5);
-            run_quant<DT_BF16, 4, RM_NEAREST_FAST, 1, true, 5, 256>(b, 2 * numel, num_cu, 2.5);
-            run_quant<DT_BF16, 4, RM_NEAREST_FAST, 2, true, 5, 1024>(b, 2 * numel, num_cu, 2.5);
-            run_quant<DT_BF16, 4, RM_NEAREST_FAST, 1, true, 5, 1024>(b, 2 * numel, num_cu, 2.5);
-            run_quant<DT_BF16, 4, RM_NEAREST_FAST, 2, true, 3, 64>(b, 2 * numel, num_cu, 2.5);
-            run_quant<DT_BF16, 4, RM_NEAREST_FAST, 2, true, 1, 64>(b, 2 * numel, num_cu, 2.5);
-        }
-        g_caps = {0, 2, 4, 8, 16};
-        g_rounds = 3;
-    }
     if (only == "all" || only == "mm") {
         run_minmax<DT_F32, 2, true, 256>(b, numel, num_cu, keys);
         run_minmax<DT_F32, 4, true, 256>(b, numel, num_cu, keys);
@@ -1365,178 +885,8 @@ int main(int argc, char** argv) {
         run_minmax<DT_BF16, 8, true, 256>(b, 2 * numel, num_cu, keys);
     }
 
-    if (only == "mm5") {
-        // Round 4: the scan's fold on raw words (RawFold) and a block that only sweeps (POLL), against round 3's kernel and a read-only sweep
-        // with no arithmetic and no end protocol; interleaved passes, one timed batch each.  fp32 at `numel`, then bf16 at `numel` (U(-1,1) data).
-        void* scratch = nullptr;
-        CK(hipMalloc(&scratch, numel * 4 + 4096));
-        CK(hipMemcpy(scratch, b.in[0], numel * 4, hipMemcpyDeviceToDevice));
-        CK(hipDeviceSynchronize());   // a device-to-device hipMemcpy may return before the copy has run
-        check_minmax_variants<DT_F32>(scratch, numel, num_cu, keys);
-        g_rounds = 1;
-        auto ceiling = [&](int64_t nvec, double bytes, const char* what) {
-            for (int cap : {2, 4}) {
-                const double us = time_us([&](int i) {
-                    hipLaunchKernelGGL((read_only_kernel<true>), dim3(cap * num_cu), dim3(256), 0, g_stream, static_cast<const u32x4*>(b.in[i % SETS]),
-                                       static_cast<uint32_t*>(b.out[i % SETS]), nvec);
-                });
-                report("minmax", std::string("read-only sweep; no arithmetic; no end (") + what + ") cap=" + std::to_string(cap), us, bytes);
-            }
-        };
-        for (int pass = 0; pass < 5; ++pass) {
-            ceiling(numel / 4, 4.0 * numel, "f32");
-            g_mm_caps = {1};
-            run_minmax<DT_F32, 4, true, 512, true, false, false>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 4, true, 512, true, true, false>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 4, true, 512, true, false, true>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 4, true, 512, true, true, true>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 8, true, 512, true, true, true>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 2, true, 1024, true, true, true>(b, numel, num_cu, keys);
-            g_mm_caps = {2};
-            run_minmax<DT_F32, 4, true, 256, true, true, true>(b, numel, num_cu, keys);
-            run_minmax<DT_F32, 8, true, 256, true, true, true>(b, numel, num_cu, keys);
-            g_mm_caps = {4};
-            run_minmax<DT_F32, 4, true, 256, true, true, true>(b, numel, num_cu, keys);
-        }
-        for (int s_ = 0; s_ < SETS; ++s_)
-            hipLaunchKernelGGL(fill_uniform_bf16, dim3(4096), dim3(256), 0, g_stream, static_cast<uint16_t*>(b.in[s_]), 2 * numel, 0x9e3779b9u * (s_ + 1));
-        CK(hipStreamSynchronize(g_stream));
-        CK(hipMemcpy(scratch, b.in[0], numel * 2, hipMemcpyDeviceToDevice));
-        CK(hipDeviceSynchronize());
-        check_minmax_variants<DT_BF16>(scratch, numel, num_cu, keys);
-        for (int pass = 0; pass < 5; ++pass) {
-            ceiling(numel / 8, 2.0 * numel, "bf16");
-            g_mm_caps = {1};
-            run_minmax<DT_BF16, 4, true, 512, true, false, false>(b, numel, num_cu, keys);
-            run_minmax<DT_BF16, 4, true, 512, true, true, false>(b, numel, num_cu, keys);
-            run_minmax<DT_BF16, 4, true, 512, true, false, true>(b, numel, num_cu, keys);
-            run_minmax<DT_BF16, 4, true, 512, true, true, true>(b, numel, num_cu, keys);
-            run_minmax<DT_BF16, 8, true, 512, true, true, true>(b, numel, num_cu, keys);
-            run_minmax<DT_BF16, 2, true, 512, true, true, true>(b, numel, num_cu, keys);
-            run_minmax<DT_BF16, 2, true, 1024, true, true, true>(b, numel, num_cu, keys);
-            g_mm_caps = {2};
-            run_minmax<DT_BF16, 4, true, 256, true, true, true>(b, numel, num_cu, keys);
-            run_minmax<DT_BF16, 2, true, 256, true, true, true>(b, numel, num_cu, keys);
-            g_mm_caps = {4};
-            run_minmax<DT_BF16, 2, true, 256, true, true, true>(b, numel, num_cu, keys);
-        }
-        g_rounds = 3;
-        return 0;
-    }
 
-    if (only == "mm6") {
-        // Round 4, after the scan's ragged end moved into its rolling window (uniform rounds, clamped last round): geometry re-sweep with the
-        // raw-word fold and the sweeping-only block, fp32 then bf16 at `numel`; interleaved passes, one timed batch each.
-        void* scratch = nullptr;
-        CK(hipMalloc(&scratch, numel * 4 + 4096));
-        g_rounds = 1;
-        auto ceiling = [&](int64_t nvec, double bytes, const char* what) {
-            for (int cap : {4, 8}) {
-                const double us = time_us([&](int i) {
-                    hipLaunchKernelGGL((read_only_kernel<true>), dim3(cap * num_cu), dim3(256), 0, g_stream, static_cast<const u32x4*>(b.in[i % SETS]),
-                                       static_cast<uint32_t*>(b.out[i % SETS]), nvec);
-                });
-                report("minmax", std::string("read-only sweep; no arithmetic; no end (") + what + ") cap=" + std::to_string(cap), us, bytes);
-            }
-        };
-#define SWEEP(DT)                                                                   \
-    g_mm_caps = {1};                                                                \
-    run_minmax<DT, 4, true, 512, true, false, false>(b, numel, num_cu, keys);       \
-    run_minmax<DT, 4, true, 512, true, true, false>(b, numel, num_cu, keys);        \
-    run_minmax<DT, 4, true, 512, true, false, true>(b, numel, num_cu, keys);        \
-    run_minmax<DT, 4, true, 512, true, true, true>(b, numel, num_cu, keys);         \
-    run_minmax<DT, 2, true, 512, true, true, true>(b, numel, num_cu, keys);         \
-    run_minmax<DT, 8, true, 512, true, true, true>(b, numel, num_cu, keys);         \
-    run_minmax<DT, 2, true, 1024, true, true, true>(b, numel, num_cu, keys);        \
-    run_minmax<DT, 4, true, 1024, true, true, true>(b, numel, num_cu, keys);        \
-    g_mm_caps = {2};                                                                \
-    run_minmax<DT, 4, true, 256, true, true, true>(b, numel, num_cu, keys);         \
-    run_minmax<DT, 2, true, 256, true, true, true>(b, numel, num_cu, keys);         \
-    run_minmax<DT, 2, true, 512, true, true, true>(b, numel, num_cu, keys);         \
-    run_minmax<DT, 1, true, 512, true, true, true>(b, numel, num_cu, keys);         \
-    g_mm_caps = {4};                                                                \
-    run_minmax<DT, 4, true, 256, true, true, true>(b, numel, num_cu, keys);         \
-    run_minmax<DT, 2, true, 256, true, true, true>(b, numel, num_cu, keys);         \
-    run_minmax<DT, 1, true, 256, true, true, true>(b, numel, num_cu, keys);         \
-    run_minmax<DT, 2, true, 256, true, false, false>(b, numel, num_cu, keys);       \
-    g_mm_caps = {8};                                                                \
-    run_minmax<DT, 1, true, 256, true, true, true>(b, numel, num_cu, keys);         \
-    run_minmax<DT, 2, true, 128, true, true, true>(b, numel, num_cu, keys);
-        CK(hipMemcpy(scratch, b.in[0], numel * 4, hipMemcpyDeviceToDevice));
-        CK(hipDeviceSynchronize());
-        check_minmax_variants<DT_F32>(scratch, numel, num_cu, keys);
-        for (int pass = 0; pass < 4; ++pass) {
-            ceiling(numel / 4, 4.0 * numel, "f32");
-            SWEEP(DT_F32)
-        }
-        for (int s_ = 0; s_ < SETS; ++s_)
-            hipLaunchKernelGGL(fill_uniform_bf16, dim3(4096), dim3(256), 0, g_stream, static_cast<uint16_t*>(b.in[s_]), 2 * numel, 0x9e3779b9u * (s_ + 1));
-        CK(hipStreamSynchronize(g_stream));
-        CK(hipMemcpy(scratch, b.in[0], numel * 2, hipMemcpyDeviceToDevice));
-        CK(hipDeviceSynchronize());
-        check_minmax_variants<DT_BF16>(scratch, numel, num_cu, keys);
-        for (int pass = 0; pass < 4; ++pass) {
-            ceiling(numel / 8, 2.0 * numel, "bf16");
-            SWEEP(DT_BF16)
-        }
-#undef SWEEP
-        g_rounds = 3;
-        return 0;
-    }
 
-    if (only == "mm7") {
-        // Round 4: a read-only grid-stride sweep with ONE load in flight per wave runs at 16.6 us (fp32) / 8.8 us (bf16) with 32 waves per CU and
-        // at 18.3 / 9.9 with 16 (mm6): occupancy, not loads in flight per lane, is what the read stream wants.  The scan at high occupancy:
-        g_rounds = 1;
-        auto ceiling = [&](int64_t nvec, double bytes, const char* what) {
-            for (int cap : {4, 8}) {
-                const double us = time_us([&](int i) {
-                    hipLaunchKernelGGL((read_only_kernel<true>), dim3(cap * num_cu), dim3(256), 0, g_stream, static_cast<const u32x4*>(b.in[i % SETS]),
-                                       static_cast<uint32_t*>(b.out[i % SETS]), nvec);
-                });
-                report("minmax", std::string("read-only sweep; no arithmetic; no end (") + what + ") cap=" + std::to_string(cap), us, bytes);
-            }
-        };
-#define SWEEP(DT)                                                                   \
-    g_mm_caps = {1};                                                                \
-    run_minmax<DT, 4, true, 512, true, false, false>(b, numel, num_cu, keys);       \
-    g_mm_caps = {8};                                                                \
-    run_minmax<DT, 1, true, 256, true, false, false>(b, numel, num_cu, keys);       \
-    run_minmax<DT, 1, true, 256, true, true, false>(b, numel, num_cu, keys);        \
-    run_minmax<DT, 2, true, 256, true, false, false>(b, numel, num_cu, keys);       \
-    run_minmax<DT, 1, true, 256, false, false, false>(b, numel, num_cu, keys);      \
-    g_mm_caps = {6};                                                                \
-    run_minmax<DT, 1, true, 256, true, false, false>(b, numel, num_cu, keys);       \
-    run_minmax<DT, 2, true, 256, true, false, false>(b, numel, num_cu, keys);       \
-    g_mm_caps = {4};                                                                \
-    run_minmax<DT, 1, true, 512, true, false, false>(b, numel, num_cu, keys);       \
-    run_minmax<DT, 2, true, 512, true, false, false>(b, numel, num_cu, keys);       \
-    run_minmax<DT, 1, true, 512, true, false, true>(b, numel, num_cu, keys);        \
-    g_mm_caps = {3};                                                                \
-    run_minmax<DT, 2, true, 512, true, false, false>(b, numel, num_cu, keys);       \
-    g_mm_caps = {2};                                                                \
-    run_minmax<DT, 1, true, 1024, true, false, false>(b, numel, num_cu, keys);      \
-    run_minmax<DT, 2, true, 1024, true, false, false>(b, numel, num_cu, keys);      \
-    run_minmax<DT, 1, true, 1024, true, true, true>(b, numel, num_cu, keys);        \
-    g_mm_caps = {16};                                                               \
-    run_minmax<DT, 1, true, 128, false, false, false>(b, numel, num_cu, keys);      \
-    g_mm_caps = {8};                                                                \
-    run_minmax<DT, 2, true, 128, true, false, false>(b, numel, num_cu, keys);
-        for (int pass = 0; pass < 4; ++pass) {
-            ceiling(numel / 4, 4.0 * numel, "f32");
-            SWEEP(DT_F32)
-        }
-        for (int s_ = 0; s_ < SETS; ++s_)
-            hipLaunchKernelGGL(fill_uniform_bf16, dim3(4096), dim3(256), 0, g_stream, static_cast<uint16_t*>(b.in[s_]), 2 * numel, 0x9e3779b9u * (s_ + 1));
-        CK(hipStreamSynchronize(g_stream));
-        for (int pass = 0; pass < 4; ++pass) {
-            ceiling(numel / 8, 2.0 * numel, "bf16");
-            SWEEP(DT_BF16)
-        }
-#undef SWEEP
-        g_rounds = 3;
-        return 0;
-    }
 
     if (only == "mm8") {
         g_rounds = 1;
@@ -1553,7 +903,7 @@ int main(int argc, char** argv) {
     run_scan_noend<DT_F32, U_, true, BLK, 1>(b, numel, num_cu, CAP, keys);          \
     run_scan_noend<DT_F32, U_, true, BLK, 2>(b, numel, num_cu, CAP, keys);          \
     g_mm_caps = {CAP};                                                              \
-    run_minmax<DT_F32, U_, true, BLK, true, false, false>(b, numel, num_cu, keys);
+    run_minmax<DT_F32, U_, true, BLK, true>(b, numel, num_cu, keys);
             LEVELS(1, 256, 8)
             LEVELS(1, 256, 4)
             LEVELS(2, 256, 4)
@@ -1567,48 +917,7 @@ int main(int argc, char** argv) {
         return 0;
     }
 
-    if (only == "mm9") {
-        // the production scan only (both dtypes), for A/B of BUILDS of this harness (-DPQ_SCAN_TAIL=0|1|2): interleave the binaries in the shell
-        g_rounds = 1;
-        g_mm_caps = {1};
-        for (int pass = 0; pass < 3; ++pass) run_minmax<DT_F32, 4, true, 512, true, false, false>(b, numel, num_cu, keys);
-        for (int s_ = 0; s_ < SETS; ++s_)
-            hipLaunchKernelGGL(fill_uniform_bf16, dim3(4096), dim3(256), 0, g_stream, static_cast<uint16_t*>(b.in[s_]), 2 * numel, 0x9e3779b9u * (s_ + 1));
-        CK(hipStreamSynchronize(g_stream));
-        for (int pass = 0; pass < 3; ++pass) run_minmax<DT_BF16, 4, true, 512, true, false, false>(b, numel, num_cu, keys);
-        return 0;
-    }
 
-    if (only == "pair") {
-        // The reference's own two-call sequence -- compute_quant_params(x), then quantize(x) -- on the same tensor, cold rotation otherwise:
-        // can the scan leave x in the 256 MiB Infinity Cache for the quantize pass (109 MB at the headline size)?  Load policy of the scan
-        // (nt / plain) x load policy of the quantize (nt / plain); us per PAIR.
-        ParamRecord* rec = nullptr;
-        CK(hipMalloc(reinterpret_cast<void**>(&rec), 64));
-        QuantParams pd {};
-        pd.dyn = rec;
-        using T = QuantTile<DT_F32, 8, 2, 128>;
-        const int64_t n_tiles = numel / T::BLOCK_ELEMS;
-        const unsigned qgrid = static_cast<unsigned>(std::max<int64_t>(n_tiles, 1));
-        g_rounds = 1;
-        for (int pass = 0; pass < 5; ++pass) {
-#define PAIR(SCAN_NT, Q_NT, LABEL)                                                                                                                         \
-    {                                                                                                                                                      \
-        const double us = time_us([&](int i) {                                                                                                             \
-            launch_minmax_kernel<DT_F32, 4, SCAN_NT, 512, true>(num_cu, g_stream, static_cast<const void*>(b.in[i % SETS]),  \
-                               numel, keys, MinmaxEpilogue {EP_PARAMS, 8, 0u, rec});                                                                       \
-            launch_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, 2, true, mem_policy(Q_NT, ST_WT), 128>(qgrid, 0, g_stream, static_cast<const void*>(b.in[i % SETS]), static_cast<uint8_t*>(b.out[i % SETS]), numel, n_tiles, pd, 0);                        \
-        });                                                                                                                                                \
-        report("pair", LABEL, us, 9.0 * numel);                                                                                                            \
-    }
-            PAIR(true, true, "scan nt loads, quantize nt loads (production)")
-            PAIR(false, true, "scan plain loads, quantize nt loads")
-            PAIR(false, false, "scan plain loads, quantize plain loads")
-            PAIR(true, false, "scan nt loads, quantize plain loads")
-#undef PAIR
-        }
-        g_rounds = 3;
-    }
     if (only == "fused" || only == "fusedphases" || only == "fused3") {
         g_verbose_phases = only == "fusedphases";
         FusedBufs f {};
