@@ -179,13 +179,8 @@ __device__ __forceinline__ void minmax_finish(int32_t* state, int lane, const Mi
 __device__ __forceinline__ void minmax_action(int32_t k0, int32_t k1, const MinmaxEpilogue& ep) {
     if (ep.action == EP_KEYS_SET) {
         int32_t* keys = static_cast<int32_t*>(ep.dst);
-#ifdef PQ_SCAN_WT_RESULT   // A/B (round 5, tools/diag_scan_end.py): the result as ONE device-scope 8-byte store instead of two plain ones the end of the kernel writes back
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(keys), static_cast<unsigned long long>(static_cast<uint32_t>(k0)) | (static_cast<unsigned long long>(static_cast<uint32_t>(k1)) << 32),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
         keys[0] = k0;
         keys[1] = k1;
-#endif
     } else if (ep.action == EP_KEYS_MIN) {
         int32_t* keys = static_cast<int32_t*>(ep.dst);
         atomicMin(keys + 0, k0);
@@ -262,15 +257,8 @@ template <int WAVES>
 __device__ __forceinline__ void minmax_block_end_gather(float lo, float hi, const float* s_lo, const float* s_hi, int32_t* state, const MinmaxEpilogue& ep, uint32_t G) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long* words = reinterpret_cast<unsigned long long*>(state + kMinmaxStateInts);
-#ifdef PQ_SCAN_SWEEPER_FIRST   // A/B (round 5, tools/diag_scan_end.py): block 0 -- the first one dispatched -- sweeps instead of the last one
-    constexpr uint32_t OFF = 1;
-    const uint32_t me = blockIdx.x;
-    if (me != 0) {
-#else
-    constexpr uint32_t OFF = 0;
     const uint32_t me = blockIdx.x;
     if (me != G - 1) {
-#endif
         if (wave != 0) return;
 #pragma unroll
         for (int w = 1; w < WAVES; ++w) {
@@ -290,13 +278,13 @@ __device__ __forceinline__ void minmax_block_end_gather(float lo, float hi, cons
     for (uint32_t base = static_cast<uint32_t>(wave) * 64 * LPL; base + 1 < G; base += WAVES * 64 * LPL) {   // slots [0, G - 1)
         unsigned long long w[LPL];
 #pragma unroll
-        for (int j = 0; j < LPL; ++j) w[j] = base + j * 64 + lane + 1 < G ? kMinmaxNotArrived : ~0ull;   // slot base + j * 64 + lane + OFF exists
+        for (int j = 0; j < LPL; ++j) w[j] = base + j * 64 + lane + 1 < G ? kMinmaxNotArrived : ~0ull;
         for (;;) {
             bool missing = false;
 #pragma unroll
             for (int j = 0; j < LPL; ++j) {
                 if (w[j] == kMinmaxNotArrived) {
-                    w[j] = __hip_atomic_load(words + base + j * 64 + lane + OFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    w[j] = __hip_atomic_load(words + base + j * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     missing |= w[j] == kMinmaxNotArrived;
                 }
             }
@@ -309,7 +297,7 @@ __device__ __forceinline__ void minmax_block_end_gather(float lo, float hi, cons
 #pragma unroll
         for (int j = 0; j < LPL; ++j) {
             if (base + j * 64 + lane + 1 < G) {
-                __hip_atomic_store(words + base + j * 64 + lane + OFF, kMinmaxNotArrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // armed for the next scan
+                __hip_atomic_store(words + base + j * 64 + lane, kMinmaxNotArrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // armed for the next scan
                 k0 = min(k0, static_cast<int32_t>(static_cast<uint32_t>(w[j])));
                 k1 = min(k1, static_cast<int32_t>(static_cast<uint32_t>(w[j] >> 32)));
             }
