@@ -198,6 +198,24 @@ int main(int argc, char** argv) {
     uint32_t h_flags[3];
     CK(hipMemcpy(h_flags, d_flags, sizeof h_flags, hipMemcpyDeviceToHost));
     std::printf("%d ", h_flags[0] == 7u && h_flags[1] == 7u && h_flags[2] == 7u && pull_q(d_q, n) == h_wait[0] ? 1 : 0);
+    // [22] a wait that runs out is reported, not trapped on: flag 1 never reaches 9 -> piquant_hip_peer_timeout says {flags, rank 1, expected 9, seen 7},
+    // a second query says nothing happened, and the stream is as usable as before.  [23] independent calls: eight quantize launches without the
+    // barrier bit, the bytes of the last one and of an ordered call behind them
+    const uint32_t nine = 9u;
+    CK(hipMemcpy(d_flags, &nine, sizeof nine, hipMemcpyHostToDevice));    // rank 0 has arrived at exchange 9; ranks 1 and 2 still hold 7: the FIRST missing one is reported
+    piquant_hip_wait_flags(ctx, d_flags, 3, 9u, 20000u);
+    CK(hipStreamSynchronize(stream));
+    uint32_t t_rank = 99, t_expected = 0, t_seen = 0;
+    const int t_kind = piquant_hip_peer_timeout(ctx, &t_rank, &t_expected, &t_seen);
+    const int t_again = piquant_hip_peer_timeout(ctx, nullptr, nullptr, nullptr);
+    std::printf("%d ", t_kind == 1 && t_rank == 1u && t_expected == 9u && t_seen == 7u && t_again == 0 ? 1 : 0);
+    piquant_hip_set_independent_calls(ctx, 1);
+    for (int k = 0; k < 8; ++k)
+        piquant_quantize(ctx, d_x, PIQUANT_DTYPE_F32, k % 2 ? d_q : d_q2, PIQUANT_DTYPE_UINT8, n, 1.0f / 127.0f, 128, PIQUANT_NEAREST);
+    piquant_hip_set_independent_calls(ctx, 0);
+    const uint64_t h_indep = pull_q(d_q, n);
+    piquant_quantize(ctx, d_x, PIQUANT_DTYPE_F32, d_q3, PIQUANT_DTYPE_UINT8, n, 1.0f / 127.0f, 128, PIQUANT_NEAREST);
+    std::printf("%d ", h_indep == h_wait[0] && pull_q(d_q2, n) == h_wait[0] && pull_q(d_q3, n) == h_wait[0] ? 1 : 0);
     piquant_hip_peer_free(ctx, d_flags);
     {
         piquant_context_t* fresh = piquant_context_create(0);

@@ -140,7 +140,8 @@ def test_hip_client_ext_compiles_and_links(tmp_path):
 def test_hip_client_ext_rest_of_the_extension_surface_matches_oracle(tmp_path, oracle_mod):
     """26 additive exports, 4 of them tested at the C level.  This client drives the rest from a torch-free C++ process:
     minmax_keys / decode / params_from_minmax, compute_quant_params_device + quantize_dp, quantize_dequantize, the stochastic controls,
-    the blocking-wait modes, the barrier limit + hand-over counter, reduce_quantize_dynamic, dequantize_dp_batch, reference layout."""
+    the blocking-wait modes, the barrier limit + hand-over counter, reduce_quantize_dynamic, dequantize_dp_batch, reference layout, the flag calls with
+    a wait that runs out (piquant_hip_peer_timeout), independent calls."""
     O = oracle_mod
     n = 1_000_003
     exe = _build_hip_client_ext(tmp_path)
@@ -178,9 +179,10 @@ def test_hip_client_ext_rest_of_the_extension_surface_matches_oracle(tmp_path, o
     base = (-wbuf.ctypes.data) % 16                                            # hipMalloc'ed output: aligned, no head
     assert int(out[15], 16) == _fnv1a(O.quantize(x, O.F32, O.UINT8, float(sc), zp, form=O.FORM_REFERENCE, threads=3, out=wbuf[base: base + n]).tobytes())
     assert out[16:20] == ["1", "1", "1", "1"]                                  # fusion off, reseeding, assume_device_pointers, reset_stream
-    assert out[20:22] == ["1", "1"]                                            # signal_flags / wait_flags on the stream; host_path_in_effect
-    assert (np.float32(float(out[22])), int(out[23]), np.float32(float(out[24])), int(out[25])) == (np.float32(s8), z8, np.float32(ss), zs)
-    assert int(out[26]) == 0 and out[27] == "gfx950"
+    assert out[20:23] == ["1", "1", "1"]                                       # signal_flags / wait_flags on the stream; peer_timeout reports the late rank; independent calls
+    assert out[23] == "1"                                                      # host_path_in_effect
+    assert (np.float32(float(out[24])), int(out[25]), np.float32(float(out[26])), int(out[27])) == (np.float32(s8), z8, np.float32(ss), zs)
+    assert int(out[28]) == 0 and out[29] == "gfx950"
 
 
 @pytest.mark.gpu
