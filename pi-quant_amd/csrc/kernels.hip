@@ -29,10 +29,10 @@ inline unsigned capped_grid(int64_t want, int blocks_per_cu, int num_cu) {
     return static_cast<unsigned>(std::max<int64_t>(g, 1));
 }
 
-template <int DT_IN, int BITS, int MODE>
+template <int DT_IN, int BITS, int MODE, bool SMALL = false>
 void quantize_t(const QuantLaunch& q, const QuantParams& p, hipStream_t stream, int num_cu) {
     constexpr bool kStochastic = MODE == RM_STOCH_CALL || MODE == RM_STOCH_ELEM;
-    constexpr KernelTune t = kStochastic ? kQuantTuneStochastic[DT_IN][bits_index(BITS)] : kQuantTune[DT_IN][bits_index(BITS)];
+    constexpr KernelTune t = SMALL ? kQuantTuneSmallF32U8 : (kStochastic ? kQuantTuneStochastic[DT_IN][bits_index(BITS)] : kQuantTune[DT_IN][bits_index(BITS)]);
     using Tile = QuantTile<DT_IN, BITS, t.u, t.block>;
     uint8_t* out = static_cast<uint8_t*>(q.out);
     constexpr int PACK = 8 / BITS, ESIZE = DT_IN == DT_F32 ? 4 : 2;
@@ -72,9 +72,13 @@ void quantize_mode(const QuantLaunch& q, const QuantParams& p, hipStream_t strea
         case RM_NEAREST_I64:
             // f32 -> uint2 is the one nearest pair without a SIMD fast path in the reference (quantize.inl:105-127)
             if constexpr (DT_IN == DT_F32 && BITS == 2) quantize_t<DT_IN, BITS, RM_NEAREST_I64>(q, p, stream, num_cu);
+            else if (DT_IN == DT_F32 && BITS == 8 && q.numel < kQuantSmallNumel) quantize_t<DT_IN, BITS, RM_NEAREST_FAST, DT_IN == DT_F32 && BITS == 8>(q, p, stream, num_cu);
             else quantize_t<DT_IN, BITS, RM_NEAREST_FAST>(q, p, stream, num_cu);
             return;
-        case RM_STOCH_CALL: quantize_t<DT_IN, BITS, RM_STOCH_CALL>(q, p, stream, num_cu); return;
+        case RM_STOCH_CALL:
+            if (DT_IN == DT_F32 && BITS == 8 && q.numel < kQuantSmallNumel) quantize_t<DT_IN, BITS, RM_STOCH_CALL, DT_IN == DT_F32 && BITS == 8>(q, p, stream, num_cu);
+            else quantize_t<DT_IN, BITS, RM_STOCH_CALL>(q, p, stream, num_cu);
+            return;
         case RM_STOCH_ELEM: quantize_t<DT_IN, BITS, RM_STOCH_ELEM>(q, p, stream, num_cu); return;
         default: panic("invalid rounding mode %d", q.round_mode);
     }

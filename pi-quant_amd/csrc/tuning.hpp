@@ -28,6 +28,12 @@ constexpr KernelTune kQuantTune[2][3] = {
     {{2, true, kStream, 128, 0}, {2, true, kStream, 64, 0}, {2, true, kStream, 64, 0}},
     {{2, true, kStreamNT8, 64, 0}, {2, true, kStream, 64, 0}, {2, true, kStream, 64, 0}},
 };
+// fp32 -> uint8 below 16 M elements -- what one of 2, 4 or 8 GPUs gets of the headline tensor -- prefers ONE wave per block: interleaved sweep of eleven
+// geometries at seven sizes (tools/tune_kernels `small`, profiles/r05_tune_small_*.csv): 64-thread / U=2 tiles against the 128-thread tiles of the table
+// 9.71 vs 10.05 us at 10 M elements, 12.42 vs 12.75 at 13.6 M, 7.38 vs 7.50 at 6.8 M, 4.93 vs 4.86 at 3.4 M (a tie), 17.58 vs 17.51 at 20 M (a tie);
+// at 27.3 M and 54.5 M the 128-thread tile wins (22.78 vs 23.06, 43.8 vs 44.4).
+constexpr KernelTune kQuantTuneSmallF32U8 = {2, true, kStream, 64, 0};
+constexpr int64_t kQuantSmallNumel = int64_t {1} << 24;
 // Stochastic rounding does ~40 % more arithmetic per element than nearest, which moves one optimum: bf16 -> uint2 (eight elements per 16
 // bytes in, two bytes out) wants the 256-thread / U=4 tile back, 12.75 vs 13.15 us; every other pair keeps its nearest tile
 // (profiles/r03_tune_bf16_ceiling.csv).

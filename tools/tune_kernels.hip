@@ -745,6 +745,18 @@ int main(int argc, char** argv) {
         }
         g_rounds = 3;
     }
+    if (only == "small") {
+        // tile geometry of the headline pair at SHARD sizes (pass numel = 3 408 000 / 6 816 000 / 13 632 000: what one of 8 / 4 / 2 GPUs gets of
+        // the headline tensor): is the N1 optimum (128 threads, U = 2) still the optimum when a launch is half fixed cost?
+        g_rounds = 1;
+        for (int pass = 0; pass < 5; ++pass) {
+#define SMALL(U_, BLK) run_quant3<DT_F32, 8, RM_NEAREST_FAST, U_, true, 5, BLK, 7>(b, numel, 5.0);
+            SMALL(1, 64) SMALL(1, 128) SMALL(1, 256) SMALL(2, 64) SMALL(2, 128) SMALL(2, 256) SMALL(4, 64) SMALL(4, 128) SMALL(4, 256) SMALL(2, 512) SMALL(4, 512)
+#undef SMALL
+            run_quant3<DT_F32, 8, RM_COPY, 2, true, 5, 128, 7>(b, numel, 5.0);
+        }
+        g_rounds = 3;
+    }
     if (only == "geo") {
         // tile geometry of the bf16-input quantizers once more, on the final step (normalised pack): U x block
         g_rounds = 1;
