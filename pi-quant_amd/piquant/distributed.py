@@ -58,8 +58,11 @@ class _StreamOrder:
     in that order here: an event behind every exchange, waited for by the next one when it comes from another stream."""
 
     def __init__(self):
+        import threading
+
         self._last_stream = None
         self._event = None
+        self.lock = threading.Lock()      # the host side of an exchange (sequence number, parity, the launches) is one critical section per mesh
 
     def enter(self, device: torch.device) -> None:
         cur = torch.cuda.current_stream(device)
@@ -367,12 +370,13 @@ class _KeyMesh:
             raise RuntimeError("compute_quant_params(transport='p2p'): an earlier exchange of this group gave up on a late rank, whose keys may still sit in a "
                                "mailbox; every rank must call piquant.distributed.release_peer_meshes(group) before the group uses transport='p2p' again")
         _raise_peer_timeout(ctx, "an earlier compute_quant_params(transport='p2p')")
-        self.order.enter(self.device)
-        self.seq += 1
-        par = self.seq & 1
-        slots = [self.mem.ptrs[j] + 8 * (par * self.world + self.rank) for j in range(self.world)]
-        ctx.exchange_minmax_keys_ptr(keys.data_ptr(), slots, self.mem.own + 8 * par * self.world, self.out.data_ptr(), timeout_us)
-        self.order.leave(self.device)
+        with self.order.lock:
+            self.order.enter(self.device)
+            self.seq += 1
+            par = self.seq & 1
+            slots = [self.mem.ptrs[j] + 8 * (par * self.world + self.rank) for j in range(self.world)]
+            ctx.exchange_minmax_keys_ptr(keys.data_ptr(), slots, self.mem.own + 8 * par * self.world, self.out.data_ptr(), timeout_us)
+            self.order.leave(self.device)
         return self.out
 
     def release(self, group) -> None:
@@ -746,16 +750,23 @@ def _all_reduce_direct_p2p(tensor, flat, chunks, slot, quant_dtype, qdt, round_m
     """The mesh schedule over peer-mapped buffers (``quantized_all_reduce_direct``, ``transport='p2p'``).  The calls go through the context's
     raw-pointer entry points: the peers' buffers are addresses of THEIR devices' memory, which the tensor-level wrappers (one device per
     call, by design) would refuse."""
-    from . import ReduceOp, RoundMode
-
     if not tensor.is_cuda:
         raise RuntimeError("transport='p2p' moves device memory between GPUs: the tensor must live on one")
     slot = -(-slot // 65536) * 65536    # coarse sizes: a mesh is grown (an IPC exchange and a barrier) only when a tensor needs more than any before it
-    mesh = _PeerMesh.get(group, tensor.device, slot, world, rank)
-    slot = mesh.slot                    # the mesh's own slot size lays the buffers out (>= what this tensor needs)
+    mesh = _PeerMesh.get(group, tensor.device, slot, world, rank)      # its own slot size lays the buffers out (>= what this tensor needs)
     cx = _ctx_for(tensor, ctx)          # the tensor's device, PyTorch's current stream, stream-ordered
     _raise_peer_timeout(cx, "an earlier quantized_all_reduce(transport='p2p')")
-    mesh.order.enter(tensor.device)     # behind the mesh's previous exchange, whatever stream that ran on
+    with mesh.order.lock:               # one exchange of a mesh at a time on the host, whatever thread it comes from ...
+        mesh.order.enter(tensor.device)     # ... and behind the mesh's previous exchange on the device, whatever stream that ran on
+        _all_reduce_direct_p2p_locked(tensor, flat, chunks, mesh, cx, qdt, round_mode, world, rank, timeout_us)
+        mesh.order.leave(tensor.device)
+    return tensor
+
+
+def _all_reduce_direct_p2p_locked(tensor, flat, chunks, mesh, cx, qdt, round_mode, world, rank, timeout_us):
+    from . import ReduceOp, RoundMode
+
+    slot = mesh.slot
     fdt = torch_to_piquant_dtype(tensor.dtype)
     rmode = RoundMode.NEAREST if round_mode == 'nearest' else RoundMode.STOCHASTIC
     mesh.seq += 1
@@ -796,8 +807,6 @@ def _all_reduce_direct_p2p(tensor, flat, chunks, slot, quant_dtype, qdt, round_m
     everyone = [j for j in range(world) if chunk_len(j) > 0]
     cx.dequantize_dp_batch_ptr([mine_ptr(j) + _HEADER_BYTES for j in everyone], qdt, [chunk_ptr(j) for j in everyone], fdt, [chunk_len(j) for j in everyone],
                                [mine_ptr(j) for j in everyone], ReduceOp.SET, _device_ptrs=True)
-    mesh.order.leave(tensor.device)
-    return tensor
 
 
 def check_peer_timeouts(device: Optional[torch.device] = None, ctx: Optional[Context] = None) -> None:
