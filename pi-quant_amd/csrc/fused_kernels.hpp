@@ -150,16 +150,33 @@ __host__ __device__ inline int64_t fused_rounds(int64_t n_vec, int64_t G, int64_
     return (total + G - 1) / G;
 }
 
+// min/max of one vector folded into the thread's running pair: every element quieted (a signaling NaN would poison the fold, device_math.hpp), then
+// v_min3_f32 / v_max3_f32 over the running value and two elements at a time -- 2 instructions per element.  Written as asm because the compiler
+// cannot see across the guarded rounds that the running pair is never a signaling NaN and re-canonicalises it before every single v_min / v_max
+// (round 5: the fold was 7 instructions per element, and at 16 waves per CU that is 3-6 us of VALU time behind the last load).  No `valid`
+// argument: the addresses of all loads are clamped into the tensor, so a vector past a share's end is real data of the tensor seen twice, which
+// changes no minimum and no maximum.
+__device__ __forceinline__ float min3_f32(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float max3_f32(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 template <int DT_IN>
-__device__ __forceinline__ void minmax_vec(const u32x4& raw, bool valid, float& lo, float& hi) {
+__device__ __forceinline__ void minmax_vec(const u32x4& raw, float& lo, float& hi) {
     constexpr int EPV = InVec<DT_IN>::EPV;
     float f[EPV];
     InVec<DT_IN>::unpack(raw, f);
 #pragma unroll
-    for (int e = 0; e < EPV; ++e) {
-        const float x = quieted(f[e]);   // a signaling NaN would poison the fold (device_math.hpp)
-        lo = __builtin_fminf(lo, valid ? x : lo);
-        hi = __builtin_fmaxf(hi, valid ? x : hi);
+    for (int e = 0; e < EPV; e += 2) {
+        const float x0 = quieted(f[e]), x1 = quieted(f[e + 1]);
+        lo = min3_f32(lo, x0, x1);
+        hi = max3_f32(hi, x0, x1);
     }
 }
 
@@ -274,9 +291,9 @@ fused_params_quantize_kernel(const void* in0, uint8_t* out0, int64_t numel0, Par
 #pragma unroll
             for (int j = 0; j < LDS_BATCH; ++j) {
                 if (R_REG + j0 + j < rounds) {
-                    const int64_t v = v_first + (R_REG + j0 + j) * round_vecs;
+                    [[maybe_unused]] const int64_t v = v_first + (R_REG + j0 + j) * round_vecs;
                     if constexpr (RED_BITS != 0) add_reduce_terms<DT_IN, RED_BITS>(t[j], v < n_vec ? v : v_last, red);
-                    minmax_vec<DT_IN>(t[j], v < n_vec, lo, hi);
+                    minmax_vec<DT_IN>(t[j], lo, hi);
                     resident[(j0 + j) * BLOCK + tid] = t[j];
                 }
             }
@@ -292,19 +309,17 @@ fused_params_quantize_kernel(const void* in0, uint8_t* out0, int64_t numel0, Par
                 t[j] = ld<true>(in16 + (v < n_vec ? v : v_last));
             }
 #pragma unroll
-            for (int j = 0; j < STREAM_BATCH; ++j) {
-                const int64_t v = v_first + (k0 + j) * round_vecs;
-                minmax_vec<DT_IN>(t[j], k0 + j < rounds_total && v < n_vec, lo, hi);
-            }
+            for (int j = 0; j < STREAM_BATCH; ++j) minmax_vec<DT_IN>(t[j], lo, hi);   // slots past the share's end hold other real data of the tensor
         }
 #pragma unroll
         for (int k = 0; k < R_REG; ++k) {
             if (k < rounds) {
-                const int64_t v = v_first + k * round_vecs;
+                [[maybe_unused]] const int64_t v = v_first + k * round_vecs;
                 if constexpr (RED_BITS != 0) add_reduce_terms<DT_IN, RED_BITS>(r[k], v < n_vec ? v : v_last, red);
-                minmax_vec<DT_IN>(r[k], v < n_vec, lo, hi);
+                minmax_vec<DT_IN>(r[k], lo, hi);
             }
         }
+    
     }
     asm volatile("" : "+v"(gen_v));   // first use of the generation word loaded a whole phase ago: the load's wait lands here, not at the load
     const uint32_t gen = __builtin_amdgcn_readfirstlane(gen_v);

@@ -196,11 +196,7 @@ def native_dist_entry(args, ctx, shard, dev, rank, world, want):
 def n1_reference(B):
     """N > 1: the N = 1 point of the SAME run -- rank 0 alone quantizes the whole tensor with the headline's protocol (K steps per window, cold
     rotation of args.sets full-size sets) while the other ranks wait at the barrier behind it."""
-    args, ctx, stream, dev, rank, world, use_dist = B.args, B.ctx, B.stream, B.dev, B.rank, B.world, B.use_dist
-    n, n_total, nsets, scale, zp, gib_per_step = B.n, B.n_total, B.nsets, B.scale, B.zp, B.gib_per_step
-    xs, ptr_in, ptr_out, call_args, c_quantize, step, time_loop = B.xs, B.ptr_in, B.ptr_out, B.call_args, B.c_quantize, B.step, B.time_loop
-    import piquant
-    import piquant.distributed as pqd
+    args, ctx, stream, dev, rank, n_total, scale, zp, gib_per_step, c_quantize, time_loop = B.args, B.ctx, B.stream, B.dev, B.rank, B.n_total, B.scale, B.zp, B.gib_per_step, B.c_quantize, B.time_loop
     from piquant import DataType, RoundMode
     n1_ref = None
     try:
@@ -242,12 +238,8 @@ def n1_reference(B):
 
 def all_reduce_109mb(B):
     """N > 1: both schedules of the quantized all-reduce (collective transport) against the fp32 all-reduce of the same 109 MB tensor + the 8-byte MIN."""
-    args, ctx, stream, dev, rank, world, use_dist = B.args, B.ctx, B.stream, B.dev, B.rank, B.world, B.use_dist
-    n, n_total, nsets, scale, zp, gib_per_step = B.n, B.n_total, B.nsets, B.scale, B.zp, B.gib_per_step
-    xs, ptr_in, ptr_out, call_args, c_quantize, step, time_loop = B.xs, B.ptr_in, B.ptr_out, B.call_args, B.c_quantize, B.step, B.time_loop
-    import piquant
+    args, ctx, stream, dev, rank, world, n_total = B.args, B.ctx, B.stream, B.dev, B.rank, B.world, B.n_total
     import piquant.distributed as pqd
-    from piquant import DataType, RoundMode
     try:
         all_reduce, _x = all_reduce_extras(args, pqd, dev, rank, world, n_total)
         del _x
@@ -262,12 +254,7 @@ def all_reduce_109mb(B):
 def graph_replay(B):
     """The same K steps replayed from a hipGraph (every stream-ordered call of the library is capturable): what is left of a step when the host's
     per-launch work is taken out of it.  Runs on every rank (barriers)."""
-    args, ctx, stream, dev, rank, world, use_dist = B.args, B.ctx, B.stream, B.dev, B.rank, B.world, B.use_dist
-    n, n_total, nsets, scale, zp, gib_per_step = B.n, B.n_total, B.nsets, B.scale, B.zp, B.gib_per_step
-    xs, ptr_in, ptr_out, call_args, c_quantize, step, time_loop = B.xs, B.ptr_in, B.ptr_out, B.call_args, B.c_quantize, B.step, B.time_loop
-    import piquant
-    import piquant.distributed as pqd
-    from piquant import DataType, RoundMode
+    args, ctx, stream, dev, rank, use_dist, gib_per_step, step = B.args, B.ctx, B.stream, B.dev, B.rank, B.use_dist, B.gib_per_step, B.step
     graphed = None
     try:
         g, captured = None, 1
@@ -323,12 +310,8 @@ def graph_replay(B):
 def two_streams(B):
     """Independent calls issued alternately on two streams (a context each): the next tensor's ramp runs under this one's drain.  What a caller with
     many tensors and no order between them can have; never `value` (whose steps share ONE stream, as a plain caller's do)."""
-    args, ctx, stream, dev, rank, world, use_dist = B.args, B.ctx, B.stream, B.dev, B.rank, B.world, B.use_dist
-    n, n_total, nsets, scale, zp, gib_per_step = B.n, B.n_total, B.nsets, B.scale, B.zp, B.gib_per_step
-    xs, ptr_in, ptr_out, call_args, c_quantize, step, time_loop = B.xs, B.ptr_in, B.ptr_out, B.call_args, B.c_quantize, B.step, B.time_loop
+    args, stream, nsets, gib_per_step, call_args, c_quantize = B.args, B.stream, B.nsets, B.gib_per_step, B.call_args, B.c_quantize
     import piquant
-    import piquant.distributed as pqd
-    from piquant import DataType, RoundMode
     two_streams = None
     two_streams = None
     try:
@@ -410,11 +393,9 @@ def config5(B):
     """BASELINE configs[4]: compute_quant_params over a 2^30-element fp32 tensor sharded across the ranks -- every rank scans its shard in HBM,
     ONE 8-byte all_reduce(MIN) over RCCL/xGMI, identical double-precision epilogue everywhere.  Runs on every rank (it contains the collective)."""
     args, ctx, stream, dev, rank, world, use_dist = B.args, B.ctx, B.stream, B.dev, B.rank, B.world, B.use_dist
-    n, n_total, nsets, scale, zp, gib_per_step = B.n, B.n_total, B.nsets, B.scale, B.zp, B.gib_per_step
-    xs, ptr_in, ptr_out, call_args, c_quantize, step, time_loop = B.xs, B.ptr_in, B.ptr_out, B.call_args, B.c_quantize, B.step, B.time_loop
     import piquant
     import piquant.distributed as pqd
-    from piquant import DataType, RoundMode
+    from piquant import DataType
     rec5, native5 = None, None
     rec5 = None
     try:
@@ -479,11 +460,7 @@ def config5(B):
 
 def weak_scaling(B):
     """N > 1: every rank quantizes its OWN full-size tensor (the data-parallel gradient case), same protocol."""
-    args, ctx, stream, dev, rank, world, use_dist = B.args, B.ctx, B.stream, B.dev, B.rank, B.world, B.use_dist
-    n, n_total, nsets, scale, zp, gib_per_step = B.n, B.n_total, B.nsets, B.scale, B.zp, B.gib_per_step
-    xs, ptr_in, ptr_out, call_args, c_quantize, step, time_loop = B.xs, B.ptr_in, B.ptr_out, B.call_args, B.c_quantize, B.step, B.time_loop
-    import piquant
-    import piquant.distributed as pqd
+    args, ctx, stream, dev, rank, world, n_total, scale, zp, gib_per_step, c_quantize, time_loop = B.args, B.ctx, B.stream, B.dev, B.rank, B.world, B.n_total, B.scale, B.zp, B.gib_per_step, B.c_quantize, B.time_loop
     from piquant import DataType, RoundMode
     weak = None
     weak = None
@@ -549,11 +526,8 @@ def p2p_child(B):
 
 def single_gpu(B):
     """N = 1: the side measurements of the single-GPU line."""
-    args, ctx, stream, dev, rank, world, use_dist = B.args, B.ctx, B.stream, B.dev, B.rank, B.world, B.use_dist
-    n, n_total, nsets, scale, zp, gib_per_step = B.n, B.n_total, B.nsets, B.scale, B.zp, B.gib_per_step
-    xs, ptr_in, ptr_out, call_args, c_quantize, step, time_loop = B.xs, B.ptr_in, B.ptr_out, B.call_args, B.c_quantize, B.step, B.time_loop
+    ctx, stream, dev, n, nsets, scale, zp, gib_per_step, xs, ptr_in, ptr_out, call_args, c_quantize, step, time_loop = B.ctx, B.stream, B.dev, B.n, B.nsets, B.scale, B.zp, B.gib_per_step, B.xs, B.ptr_in, B.ptr_out, B.call_args, B.c_quantize, B.step, B.time_loop
     import piquant
-    import piquant.distributed as pqd
     from piquant import DataType, RoundMode
     xs0_host = B.xs0_host
     graphed = graph_replay(B)

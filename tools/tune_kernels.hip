@@ -434,6 +434,43 @@ static FusedGroups one_group(const void* in, void* out, int64_t numel, ParamReco
     return g;
 }
 
+// Phases of the production one-launch kernel for ANY dtype pair (round 5: where do bf16 inputs and sub-byte outputs spend their time?): average
+// time per launch over the cold rotation, then one stamped launch on a quiet device.  `numel` elements of DT_IN are read from the harness' fp32 buffers
+// (bf16: filled by fill_uniform_bf16 by the caller).
+template <int DT_IN, int BITS, int MODE>
+static void fused_phases_dt(const Bufs& b, const FusedBufs& f, int64_t numel, int num_cu) {
+    constexpr double BPE = (DT_IN == DT_F32 ? 4.0 : 2.0) + BITS / 8.0;
+    char name[160];
+    std::snprintf(name, sizeof name, "%s->u%d mode=%d fused (production geometry)", DT_IN == DT_F32 ? "f32" : "bf16", BITS, MODE);
+    QuantParams p {};
+    p.threshold = 0.37f;
+    auto launch = [&](int i) {
+        launch_fused_kernel(fused_params_quantize_kernel<DT_IN, BITS, MODE, kFusedRegRounds, kFusedLdsRounds, kFusedLdsRounds, kFusedBlock, ST_WT, false, 4, 0, true, true>, num_cu,
+                            kFusedBlock, g_stream, one_group(b.in[i % SETS], b.out[i % SETS], numel, f.rec, num_cu), p, f.st, FusedReduce {});
+    };
+    const double us = time_us(launch);
+    report("fused", name, us, BPE * numel);
+    CK(hipStreamSynchronize(g_stream));
+    launch_fused_kernel(fused_params_quantize_kernel<DT_IN, BITS, MODE, kFusedRegRounds, kFusedLdsRounds, kFusedLdsRounds, kFusedBlock, ST_WT, true, 4, 0, true, true>, num_cu, kFusedBlock,
+                        g_stream, one_group(b.in[3], b.out[3], numel, f.rec, num_cu), p, f.st, FusedReduce {});
+    CK(hipStreamSynchronize(g_stream));
+    std::vector<uint64_t> t(static_cast<size_t>(num_cu) * 8);
+    CK(hipMemcpy(t.data(), f.stamps, t.size() * 8, hipMemcpyDeviceToHost));
+    uint64_t t_begin = ~0ull;
+    for (int bb = 0; bb < num_cu; ++bb) t_begin = std::min(t_begin, t[bb * 8]);
+    auto stats = [&](const char* what, auto get) {
+        std::vector<double> v;
+        for (int bb = 0; bb < num_cu; ++bb) v.push_back(get(bb) * 0.01);
+        std::sort(v.begin(), v.end());
+        std::fprintf(stderr, "  %-44s %-28s min %6.2f  p10 %6.2f  median %6.2f  p90 %6.2f  max %6.2f us\n", name, what, v.front(), v[v.size() / 10], v[v.size() / 2], v[v.size() * 9 / 10], v.back());
+    };
+    stats("load + minmax", [&](int bb) { return static_cast<double>(t[bb * 8 + 1] - t[bb * 8]); });
+    stats("load end (since first start)", [&](int bb) { return static_cast<double>(t[bb * 8 + 1] - t_begin); });
+    stats("barrier wait + params", [&](int bb) { return static_cast<double>(t[bb * 8 + 2] - t[bb * 8 + 1]); });
+    stats("quantize + store issue", [&](int bb) { return static_cast<double>(t[bb * 8 + 4] - t[bb * 8 + 3]); });
+    stats("end (since first start)", [&](int bb) { return static_cast<double>(t[bb * 8 + 4] - t_begin); });
+}
+
 template <int R_REG, int R_LDS, int LDS_BATCH, int BLOCK, int STP = ST_WT, int SB = 4, bool AG = true, bool LEAD = true>
 static void run_fused(const Bufs& b, const FusedBufs& f, int64_t numel, int num_cu, int32_t* slots) {
     const int64_t n_vec = numel / 4;
@@ -930,7 +967,7 @@ int main(int argc, char** argv) {
     }
 
 
-    if (only == "fused" || only == "fusedphases" || only == "fused3") {
+    if (only == "fused" || only == "fusedphases" || only == "fused3" || only == "fuseddt") {
         g_verbose_phases = only == "fusedphases";
         FusedBufs f {};
         CK(hipMalloc(reinterpret_cast<void**>(&f.st), sizeof(FusedState)));
@@ -957,6 +994,25 @@ int main(int argc, char** argv) {
                 launch_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, 2, true, mem_policy(true, ST_WT), 128>(static_cast<unsigned>(std::max<int64_t>(n_tiles, 1)), 0, g_stream, static_cast<const void*>(b.in[i % SETS]), static_cast<uint8_t*>(b.out[i % SETS]), numel, n_tiles, pd, 0);
             });
             report("fused", "f32->u8 two launches (scan with parameter epilogue, quantize)", us, 9.0 * numel);
+        }
+        if (only == "fuseddt") {
+            // round 5: the phases of the one-launch kernel for the other dtype pairs (numel elements each; bf16 data for the bf16 rows)
+            for (int pass = 0; pass < 2; ++pass) {
+                fused_phases_dt<DT_F32, 8, RM_NEAREST_FAST>(b, f, numel, num_cu);
+                fused_phases_dt<DT_F32, 4, RM_NEAREST_FAST>(b, f, numel, num_cu);
+                fused_phases_dt<DT_F32, 2, RM_NEAREST_I64>(b, f, numel, num_cu);
+                fused_phases_dt<DT_F32, 8, RM_STOCH_CALL>(b, f, numel, num_cu);
+            }
+            for (int s_ = 0; s_ < SETS; ++s_)
+                hipLaunchKernelGGL(fill_uniform_bf16, dim3(4096), dim3(256), 0, g_stream, static_cast<uint16_t*>(b.in[s_]), numel, 0x9e3779b9u * (s_ + 1));
+            CK(hipStreamSynchronize(g_stream));
+            for (int pass = 0; pass < 2; ++pass) {
+                fused_phases_dt<DT_BF16, 8, RM_NEAREST_FAST>(b, f, numel, num_cu);
+                fused_phases_dt<DT_BF16, 4, RM_NEAREST_FAST>(b, f, numel, num_cu);
+                fused_phases_dt<DT_BF16, 2, RM_NEAREST_FAST>(b, f, numel, num_cu);
+                fused_phases_dt<DT_BF16, 4, RM_STOCH_CALL>(b, f, numel, num_cu);
+            }
+            return 0;
         }
         if (only == "fused3") {
             // round 3: tensor 0 and the grid shape as preloaded scalar arguments against the round-2 form (everything from the kernarg structs)
