@@ -373,6 +373,21 @@ class Context:
         self._record_policy('set_independent_calls', enabled)
         C.piquant_hip_set_independent_calls(self._ctx, 1 if enabled else 0)
 
+    def independent_calls(self):
+        """``with ctx.independent_calls(): ...`` -- the mode on for the calls inside the block (a gradient bucket quantized tensor after tensor), off again
+        behind it, so that whatever follows is ordered behind all of them as usual."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            self.set_independent_calls(True)
+            try:
+                yield self
+            finally:
+                self.set_independent_calls(False)
+
+        return scope()
+
     #: ``set_barrier_timeout_us(Context.HAND_OVER_ALWAYS)``: every block but the last of each tensor hands its share over without waiting
     #: (PIQUANT_HIP_BARRIER_HAND_OVER_ALWAYS; the deterministic form of the hand-over path, for tests)
     HAND_OVER_ALWAYS = 0xffffffff

@@ -1544,13 +1544,12 @@ def test_independent_calls_mode_same_bytes_and_later_work_waits(ctx, O):
         q4 = [torch.zeros((x.size + 1) // 2, dtype=torch.uint8, device="cuda") for x in xs]
         back = [torch.zeros(x.size, dtype=torch.float32, device="cuda") for x in xs]
         torch.cuda.synchronize()          # the inputs are complete: nothing the calls below depend on is in flight
-        c.set_independent_calls(True)
-        for rep in range(3):
-            for x, q, p4 in zip(xd, qd, q4):
-                piquant.torch.quantize(x, scale=0.0157, zero_point=128, dtype=torch.uint8, ctx=c, out=q)
-                piquant.torch.quantize(x, scale=0.27, zero_point=7, dtype=torch.quint4x2, ctx=c, out=p4)
-        total = sum(int(q.sum(dtype=torch.int64)) for q in qd)      # torch kernels behind the any-order launches: they wait for all of them
-        c.set_independent_calls(False)
+        with c.independent_calls():
+            for rep in range(3):
+                for x, q, p4 in zip(xd, qd, q4):
+                    piquant.torch.quantize(x, scale=0.0157, zero_point=128, dtype=torch.uint8, ctx=c, out=q)
+                    piquant.torch.quantize(x, scale=0.27, zero_point=7, dtype=torch.quint4x2, ctx=c, out=p4)
+            total = sum(int(q.sum(dtype=torch.int64)) for q in qd)      # torch kernels behind the any-order launches: they wait for all of them
         for q, b in zip(qd, back):        # dependent on the quantize calls above: issued with the mode off, ordered as always
             piquant.torch.dequantize(q, scale=0.0157, zero_point=128, dtype=torch.float32, ctx=c, out=b)
     torch.cuda.synchronize()
