@@ -394,51 +394,70 @@ _HEADER_BYTES = 16   # wire header per hop == the device parameter record {float
 class _DeviceOps:
     """Wire encode / decode on ROCm device tensors (HIP kernels through libpiquant.so).  The parameters are derived on
     the device straight into the buffer's header and read back from it by the receiver's dequantize kernel: a hop
-    needs no host synchronisation at all."""
+    needs no host synchronisation at all.
+
+    The calls go through the context's raw-pointer entry points (round 5): every buffer here is one this module laid out itself (16-byte header +
+    packed bytes, slots on 16-byte boundaries), and the tensor-level wrappers of ``piquant.torch`` -- two slices and a dozen attribute checks per
+    buffer -- cost 17 us of host time for a one-term ``reduce_encode`` and 42 us for a seven-term one, more than the kernels they launch
+    (profiles/EXPERIMENTS.md): an all-reduce of 109 MB was bound by its host."""
 
     def __init__(self, ctx: Optional[Context]):
         self.ctx = ctx
 
-    def encode(self, x: torch.Tensor, buf: torch.Tensor, qdtype: torch.dtype, round_mode: str) -> None:
-        from .torch import quantize_dynamic
+    def _cx(self, t: torch.Tensor) -> Context:
+        if not t.is_cuda:
+            raise RuntimeError('the wire kernels are HIP kernels: quantized_all_reduce needs ROCm device tensors (there is no CPU path)')
+        return _ctx_for(t, self.ctx)    # the tensor's device, PyTorch's current stream, stream-ordered
 
-        quantize_dynamic(x, dtype=qdtype, round_mode=round_mode, ctx=self.ctx, out=buf[_HEADER_BYTES:], params=buf[:_HEADER_BYTES])
+    @staticmethod
+    def _mode(round_mode: str):
+        from . import RoundMode
+
+        return RoundMode.NEAREST if round_mode == 'nearest' else RoundMode.STOCHASTIC
+
+    def encode(self, x: torch.Tensor, buf: torch.Tensor, qdtype: torch.dtype, round_mode: str) -> None:
+        p = buf.data_ptr()
+        self._cx(x).quantize_dynamic_ptr(x.data_ptr(), torch_to_piquant_dtype(x.dtype), p + _HEADER_BYTES, torch_to_piquant_dtype(qdtype), x.numel(), p,
+                                         self._mode(round_mode), _device_ptrs=True)
 
     def decode(self, buf: torch.Tensor, out: torch.Tensor, qdtype: torch.dtype, reduce_op: str) -> None:
-        from .torch import dequantize_dynamic
+        from . import ReduceOp
 
-        dequantize_dynamic(buf[_HEADER_BYTES:], buf[:_HEADER_BYTES], dtype=out.dtype, reduce_op=reduce_op, ctx=self.ctx, out=out,
-                           quant_dtype=qdtype, shape=out.shape)
+        p = buf.data_ptr()
+        self._cx(out).dequantize_dp_ptr(p + _HEADER_BYTES, torch_to_piquant_dtype(qdtype), out.data_ptr(), torch_to_piquant_dtype(out.dtype), out.numel(), p,
+                                        ReduceOp.ADD if reduce_op == 'add' else ReduceOp.SET, _device_ptrs=True)
 
     def encode_batch(self, xs, bufs, qdtype: torch.dtype, round_mode: str) -> None:
         """encode(xs[i], bufs[i]) for all i with one kernel launch per 16 chunks (each chunk its own parameters)."""
-        from .torch import quantize_dynamic_batch
-
         if xs:
-            quantize_dynamic_batch(list(xs), dtype=qdtype, round_mode=round_mode, ctx=self.ctx, outs=[b[_HEADER_BYTES:] for b in bufs],
-                                   params=[b[:_HEADER_BYTES] for b in bufs])
+            ps = [b.data_ptr() for b in bufs]
+            self._cx(xs[0]).quantize_dynamic_batch_ptr([x.data_ptr() for x in xs], torch_to_piquant_dtype(xs[0].dtype), [p + _HEADER_BYTES for p in ps],
+                                                       torch_to_piquant_dtype(qdtype), [x.numel() for x in xs], ps, self._mode(round_mode), _device_ptrs=True)
 
     def decode_batch(self, bufs, outs, qdtype: torch.dtype, reduce_op: str) -> None:
         """decode(bufs[i], outs[i]) for all i with one kernel launch per 16 chunks."""
-        from .torch import dequantize_dynamic_batch
+        from . import ReduceOp
 
         if bufs:
-            dequantize_dynamic_batch([b[_HEADER_BYTES:] for b in bufs], [b[:_HEADER_BYTES] for b in bufs], dtype=outs[0].dtype, reduce_op=reduce_op,
-                                     ctx=self.ctx, outs=list(outs), quant_dtype=qdtype, shapes=[o.shape for o in outs])
+            ps = [b.data_ptr() for b in bufs]
+            self._cx(outs[0]).dequantize_dp_batch_ptr([p + _HEADER_BYTES for p in ps], torch_to_piquant_dtype(qdtype), [o.data_ptr() for o in outs],
+                                                      torch_to_piquant_dtype(outs[0].dtype), [o.numel() for o in outs], ps,
+                                                      ReduceOp.ADD if reduce_op == 'add' else ReduceOp.SET, _device_ptrs=True)
 
     def reduce_encode(self, bufs, acc: torch.Tensor, buf: torch.Tensor, qdtype: torch.dtype, round_mode: str) -> None:
         """encode(acc + sum of the wire buffers) into ``buf`` as one call (``acc`` is scratch afterwards)."""
-        from .torch import reduce_quantize_dynamic
-
-        reduce_quantize_dynamic(acc, [b[_HEADER_BYTES:] for b in bufs], [b[:_HEADER_BYTES] for b in bufs], dtype=qdtype, round_mode=round_mode,
-                                ctx=self.ctx, out=buf[_HEADER_BYTES:], out_params=buf[:_HEADER_BYTES])
+        ps = [b.data_ptr() for b in bufs]
+        p = buf.data_ptr()
+        self._cx(acc).reduce_quantize_dynamic_ptr(acc.data_ptr(), torch_to_piquant_dtype(acc.dtype), [q + _HEADER_BYTES for q in ps], ps, p + _HEADER_BYTES,
+                                                  torch_to_piquant_dtype(qdtype), acc.numel(), p, self._mode(round_mode), _device_ptrs=True)
 
     def decode_sum(self, bufs, out: torch.Tensor, qdtype: torch.dtype) -> None:
         """out += sum of the wire buffers, one pass over ``out`` (same result as decode(..., 'add') buffer by buffer)."""
-        from .torch import dequantize_sum
+        from . import ReduceOp
 
-        dequantize_sum([b[_HEADER_BYTES:] for b in bufs], [b[:_HEADER_BYTES] for b in bufs], dtype=out.dtype, reduce_op='add', ctx=self.ctx,
-                       out=out, quant_dtype=qdtype, shape=out.shape)
+        ps = [b.data_ptr() for b in bufs]
+        self._cx(out).dequantize_sum_ptr([p + _HEADER_BYTES for p in ps], ps, torch_to_piquant_dtype(qdtype), out.data_ptr(), torch_to_piquant_dtype(out.dtype),
+                                         out.numel(), ReduceOp.ADD, _device_ptrs=True)
 
 
 def _exchange(send: torch.Tensor, recv: torch.Tensor, nxt: int, prv: int, group) -> None:
