@@ -256,6 +256,26 @@ __device__ __forceinline__ void pack_normalised(const float (&tn)[EPV], uint32_t
     }
 }
 
+#ifndef PQ_GENERIC_ROUND_DIRECTED
+#define PQ_GENERIC_ROUND_DIRECTED 1
+#endif
+constexpr bool kGenericRoundDirected = PQ_GENERIC_ROUND_DIRECTED != 0;   // fp32 -> uint2's std::round as floor(RD(|p| + 0.5)) (add_half_abs_round_down); 0: roundf, for the A/B
+
+// out[e] = RD(|r[e]| + 0.5): the sum rounded TOWARDS -INFINITY (the fp32 rounding field of the wave's MODE register around the additions, one asm
+// statement: see sub_abs_round_up below for why).  For the generic nearest step -- std::round, half away from zero (quantize.inl:21-26) -- which in
+// real numbers is sign(p) * floor(|p| + 0.5): the fp32 sum may round UP across an integer (0.49999997 + 0.5 -> 1.0, where std::round gives 0), but
+// rounded down it lies between floor(v) -- an integer below 2^31, representable -- and the real sum v, so floor(RD(v)) == floor(v) exactly.  Three
+// instructions per element (add, floor, sign) instead of roundf's six (trunc, subtract, compare, select, signed one, add).
+template <int N>
+__device__ __forceinline__ void add_half_abs_round_down(const float (&r)[N], float (&out)[N]) {
+    static_assert(N == 4, "the generic step exists for fp32 inputs only: four elements per vector");
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 2\n"
+                 "v_add_f32_e64 %0, |%4|, 0.5\nv_add_f32_e64 %1, |%5|, 0.5\nv_add_f32_e64 %2, |%6|, 0.5\nv_add_f32_e64 %3, |%7|, 0.5\n"
+                 "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+                 : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3])
+                 : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]));
+}
+
 // The nearest step for a call whose data range is known (device_math.hpp, BoundedStep): per element a packed multiply and add, the
 // copysign and a truncation give the integer-valued float t = q - zp, one packed fma moves it into the scaled domain and pack_saturated
 // clamps, converts and packs.  (SAT = false keeps round 2's form for the tune harness' A/B: v_med3_f32 + v_cvt_i32_f32 per element and
@@ -274,12 +294,28 @@ __device__ __forceinline__ void quantize_vec_bounded(const u32x4& raw, float inv
     if constexpr (PACK != PACK_HORNER || BITS == 8) {
         constexpr float K = SatScale<BITS>::K, R = 1.0f / static_cast<float>((1 << BITS) - 1);
         float tz[EPV];
+        [[maybe_unused]] float rounded[EPV];
+        if constexpr (GENERIC && kGenericRoundDirected) {   // std::round of all products as floor(RD(|p| + 0.5)) with the sign put back
+            float prods[EPV], sums[EPV];
+#pragma unroll
+            for (int e = 0; e < EPV; e += 2) {
+                const f32x2 x = {v[e], v[e + 1]};
+                const f32x2 prod = x * inv_scale;
+                prods[e] = prod[0];
+                prods[e + 1] = prod[1];
+            }
+            add_half_abs_round_down<EPV>(prods, sums);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) rounded[e] = __builtin_copysignf(__builtin_floorf(sums[e]), prods[e]);
+        }
 #pragma unroll
         for (int e = 0; e < EPV; e += 2) {
             const f32x2 x = {v[e], v[e + 1]};
             const f32x2 prod = x * inv_scale;
             f32x2 tr;
-            if constexpr (GENERIC) {
+            if constexpr (GENERIC && kGenericRoundDirected) {
+                tr = f32x2 {rounded[e], rounded[e + 1]};
+            } else if constexpr (GENERIC) {
                 tr = f32x2 {roundf(prod[0]), roundf(prod[1])};
             } else {
                 const f32x2 half = {__builtin_copysignf(0.5f, prod[0]), __builtin_copysignf(0.5f, prod[1])};
