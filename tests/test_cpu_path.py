@@ -154,3 +154,41 @@ def test_contract_violations_abort():
 
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(Path(__file__).resolve().parent.parent))
     assert r.returncode != 0 and "invalid quantization types" in r.stderr
+
+
+@pytest.mark.parametrize("vector", [True, False], ids=["avx512", "scalar"])
+def test_degenerate_scales_equal_the_oracle(O, cpu, vector):
+    """ANY float is a legal scale for the reference (it validates dtypes and sizes only, src/piquant.cpp:286-295): 0 and -0, +-inf, NaN, negative,
+    denormal scales and scales whose reciprocal is denormal, through every pair, rounding mode and store op, with non-finite values in the data and in
+    the accumulator.  (The oracle against the reference's own kernels on the same parameters: tests/test_oracle_vs_ref.py.)"""
+    if vector and not cpu.use_avx512(True):
+        pytest.skip("host without AVX-512")
+    cpu.use_avx512(vector)
+    scales = [0.0, -0.0, np.inf, -np.inf, np.nan, -0.05, -1.0, 1e-40, -1e-40, 3e38, -3e38, 1.1754944e-38, 3.4028235e38, 1e-45, 2.0 ** -126, 2.0 ** -127, 8.6e37]
+    rng = np.random.default_rng(12)
+    try:
+        ctx = cpu.CpuContext(3)
+        for n in (1, 65, 4099):
+            x = rng.uniform(-3, 3, n).astype(np.float32)
+            prev = rng.uniform(-5, 5, n).astype(np.float32)
+            if n > 20:
+                x[[1, 3, 5, 7, 9, 11, 13, 15, 17]] = [0.0, -0.0, np.nan, np.inf, -np.inf, 1e-40, -1e38, 3.3e38, -3.3e38]   # the last two: products of about +-1.1 with a DENORMAL 1/scale
+                prev[[2, 4, 6, 8]] = [np.nan, np.inf, -np.inf, 3e38]
+            for scale in scales:
+                for zp in (0, 3, 200, -7):
+                    for dt_in, xin in ((O.F32, x), (O.BF16, O.f32_to_bf16(x))):
+                        for dt_out in (O.UINT8, O.UINT4, O.UINT2):
+                            for rm, tau in ((0, 0.0), (1, 0.37)):
+                                out = np.empty(O.packed_numel(n, dt_out), np.uint8)
+                                ctx.quantize_ptr(xin.ctypes.data, dt_in, out.ctypes.data, dt_out, n, float(scale), zp, rm, tau)
+                                assert np.array_equal(out, O.quantize(xin, dt_in, dt_out, float(scale), zp, rm, tau, form=O.FORM_UNIFORM)), (n, scale, zp, dt_in, dt_out, rm)
+                    for dt_q in (O.UINT8, O.UINT4, O.UINT2):
+                        q = rng.integers(0, 256, O.packed_numel(n, dt_q)).astype(np.uint8)
+                        for dt_f, pv in ((O.F32, prev), (O.BF16, O.f32_to_bf16(prev))):
+                            for op in (0, 1):
+                                out = pv.copy()
+                                ctx.dequantize_ptr(q.ctypes.data, dt_q, out.ctypes.data, dt_f, n, float(scale), zp, op)
+                                assert _same_floats(out, O.dequantize(q, dt_q, dt_f, n, float(scale), zp, op, out=pv.copy())), (n, scale, zp, dt_q, dt_f, op)
+        ctx.close()
+    finally:
+        cpu.use_avx512(True)

@@ -1561,3 +1561,76 @@ def test_independent_calls_mode_same_bytes_and_later_work_waits(ctx, O):
         assert same_floats(b.cpu().numpy(), O.dequantize(want, 4, 0, x.size, 0.0157, 128))
         want_total += int(want.astype(np.int64).sum())
     assert total == want_total
+
+
+# ---------------------------------------------------------------------------------------------------
+# degenerate parameters: the reference validates dtypes and sizes only (src/piquant.cpp:286-295, 319-327) -- ANY float is a legal scale
+# ---------------------------------------------------------------------------------------------------
+# 0 and -0 (1/scale = +-inf: every product is +-inf or NaN), +-inf (1/scale = 0), NaN, negative scales, denormal scales (1/scale overflows to inf),
+# scales whose reciprocal is denormal (3e38, 8.6e37, FLT_MAX), the smallest normal, 2^-127 and the smallest denormal
+DEGENERATE_SCALES = [0.0, -0.0, np.inf, -np.inf, np.nan, -0.05, -1.0, 1e-40, -1e-40, 3e38, -3e38, 1.1754944e-38, 3.4028235e38, 1e-45, 2.0 ** -126, 2.0 ** -127, 8.6e37]
+
+
+@pytest.mark.parametrize("dt_in", [0, 1], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dt_out", [4, 3, 2], ids=["u8", "u4", "u2"])
+def test_quantize_with_degenerate_scales(ctx, O, dt_in, dt_out):
+    """Every such scale through every quantizer, both rounding modes, sizes that take the vector tiles and the ragged ends, data with zeros of both
+    signs, NaN, infinities, a denormal and a huge value: bytes equal the oracle's -- which equals the reference's own AVX-512 kernels on exactly
+    these parameters (tests/test_oracle_vs_ref.py::test_degenerate_scales_against_reference_kernels, where oracle/_ref is built)."""
+    rng = np.random.default_rng(4100 + 10 * dt_in + dt_out)
+    for n in (1, 65, 4099, 70_001):
+        x = rng.uniform(-3, 3, n).astype(np.float32)
+        if n > 20:
+            x[[1, 3, 5, 7, 9, 11, 13, 15, 17]] = [0.0, -0.0, np.nan, np.inf, -np.inf, 1e-40, -1e38, 3.3e38, -3.3e38]   # the last two: products of about +-1.1 with a DENORMAL 1/scale
+        xin = x if dt_in == 0 else O.f32_to_bf16(x)
+        for scale in DEGENERATE_SCALES:
+            for zp in (0, 3, 200, -7):
+                for rm, tau in ((0, 0.0), (1, 0.37)):
+                    ctx.set_stochastic_threshold(tau if rm else None)
+                    got = gpu_quantize(ctx, xin, dt_in, dt_out, float(scale), zp, rm)
+                    want = O.quantize(xin, dt_in, dt_out, float(scale), zp, rm, tau, form=O.FORM_UNIFORM)
+                    assert np.array_equal(got, want), (n, scale, zp, rm, np.nonzero(got != want)[0][:5], got[:8], want[:8])
+    ctx.set_stochastic_threshold(None)
+
+
+@pytest.mark.parametrize("dt_q", [4, 3, 2], ids=["u8", "u4", "u2"])
+@pytest.mark.parametrize("dt_f", [0, 1], ids=["f32", "bf16"])
+def test_dequantize_with_degenerate_scales_and_nonfinite_accumulators(ctx, O, dt_q, dt_f):
+    """The same scales through every dequantizer, SET and ADD, with NaN, +-inf and a value next to FLT_MAX sitting in the accumulator.  Float results
+    are compared bit for bit except that any NaN equals any NaN (payloads and signs of NaNs are outside the contract: the reference's own AVX-512F
+    body and its scalar tail already disagree about them -- 0x7fc1 against 0x7fc0 for the bf16 image of the default NaN, kernels_specialized.inl:14-33
+    against piquant.hpp:86-90)."""
+    rng = np.random.default_rng(4200 + 10 * dt_q + dt_f)
+    for n in (1, 65, 4099, 70_001):
+        q = rng.integers(0, 256, O.packed_numel(n, dt_q)).astype(np.uint8)
+        prev = rng.uniform(-5, 5, n).astype(np.float32)
+        if n > 20:
+            prev[[2, 4, 6, 8]] = [np.nan, np.inf, -np.inf, 3e38]
+        prev = prev if dt_f == 0 else O.f32_to_bf16(prev)
+        for scale in DEGENERATE_SCALES:
+            for zp in (0, 3, 200, -7):
+                for op in (0, 1):
+                    got = gpu_dequantize(ctx, q, dt_q, dt_f, n, float(scale), zp, op, prev=prev)
+                    want = O.dequantize(q, dt_q, dt_f, n, float(scale), zp, op, form=O.FORM_UNIFORM, out=prev.copy())
+                    assert same_floats(got, want), (n, scale, zp, op)
+
+
+@pytest.mark.parametrize("dt", [0, 1], ids=["f32", "bf16"])
+def test_requantize_with_degenerate_scales(ctx, O, dt):
+    rng = np.random.default_rng(4300 + dt)
+    n = 4099
+    x = rng.uniform(-3, 3, n).astype(np.float32)
+    x[[1, 3, 5, 7, 9, 11, 13, 15, 17]] = [0.0, -0.0, np.nan, np.inf, -np.inf, 1e-40, -1e38, 3.3e38, -3.3e38]   # the last two: products of about +-1.1 with a DENORMAL 1/scale
+    xin = x if dt == 0 else O.f32_to_bf16(x)
+    prev = rng.uniform(-5, 5, n).astype(np.float32)
+    prev = prev if dt == 0 else O.f32_to_bf16(prev)
+    for qd in (4, 3, 2):
+        for scale in DEGENERATE_SCALES:
+            for zp in (0, 3, -7):
+                for rm, tau in ((0, 0.0), (1, 0.37)):
+                    ctx.set_stochastic_threshold(tau if rm else None)
+                    for op in (0, 1):
+                        got = gpu_requantize(ctx, xin, dt, qd, float(scale), zp, rm, op, prev)
+                        want = O.requantize(xin, dt, qd, float(scale), zp, rm, tau, op, out=prev.copy())
+                        assert same_floats(got, want), (qd, scale, zp, rm, op)
+    ctx.set_stochastic_threshold(None)
