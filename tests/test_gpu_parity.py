@@ -1236,6 +1236,15 @@ def _dynamic_cases(rng, n):
     yield "far from zero", (np.float32(1e12) + rng.uniform(0, 1e6, n)).astype(np.float32)     # x/scale beyond 2^31: every step hits the x86 indefinite
     yield "all negative", rng.uniform(-6, -2, n).astype(np.float32)
     yield "huge range", (rng.normal(size=n) * 1e30).astype(np.float32)
+    # an infinity in the data: the reference's epilogue returns (inf, 0) -- inf passes its `scale >= 0` assertion (src/piquant.cpp:373) -- and
+    # quantizing with it is legal (1/scale = 0: every finite product is 0, inf * 0 is NaN -> the x86 indefinite -> 0)
+    for name, vals in (("plus inf", [np.inf]), ("minus inf", [-np.inf]), ("both inf", [np.inf, -np.inf])):
+        with_inf = base.copy()
+        with_inf[rng.choice(n, min(n, len(vals)), replace=False)] = vals[: min(n, len(vals))]
+        yield name, with_inf
+    full = base.copy()                                   # +-FLT_MAX: the range only fits in the epilogue's doubles; uint2's 1/scale is a denormal
+    full[rng.choice(n, min(n, 2), replace=False)] = [3.4028235e38, -3.4028235e38][: min(n, 2)]
+    yield "whole float range", full
 
 
 def test_fused_dynamic_quantize_matches_oracle_and_unfused_path(O):
@@ -1255,8 +1264,8 @@ def test_fused_dynamic_quantize_matches_oracle_and_unfused_path(O):
                     # the scan ignores NaNs (v_min/v_max return the other operand); the reference leaves them unspecified
                     finite = xin[~np.isnan(x)] if name == "nan" else xin
                     want_p = O.compute_quant_params(finite, dt_in, dt_out)
-                    if not (want_p[0] > 0) or np.isinf(want_p[0]):
-                        continue          # the reference aborts on such a scale; nothing to compare
+                    if np.isnan(want_p[0]) or want_p[0] < 0:
+                        continue          # the reference aborts on such a scale (src/piquant.cpp:373); nothing to compare
                     want = O.quantize(xin, dt_in, dt_out, want_p[0], want_p[1])
                     got, got_p = gpu_quantize_dynamic(fused, xin, dt_in, dt_out)
                     assert (np.float32(got_p[0]).tobytes(), got_p[1]) == (np.float32(want_p[0]).tobytes(), want_p[1]), (n, dt_in, dt_out, name)
