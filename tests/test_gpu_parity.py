@@ -691,6 +691,18 @@ def test_compute_quant_params_matches_oracle(ctx, O):
     # misaligned view
     base = torch.from_numpy(rng.normal(size=10_001).astype(np.float32)).cuda()
     assert piquant.torch.compute_quant_params(base[1:], dtype=torch.quint8) == O.compute_quant_params(base[1:].cpu().numpy(), 0, 4)
+    # extremes of the float range through the synchronous call: infinities (the reference returns (inf, 0): inf passes its `scale >= 0` assertion,
+    # src/piquant.cpp:373), +-FLT_MAX (the range only fits in the epilogue's doubles), denormals only, zeros of both signs only
+    for vals in ([np.inf], [-np.inf], [np.inf, -np.inf], [3.4028235e38, -3.4028235e38], [3.4028235e38], [-3.4028235e38]):
+        y = rng.normal(size=70_001).astype(np.float32)
+        y[rng.choice(y.size, len(vals), replace=False)] = vals
+        yb = O.f32_to_bf16(y)                       # FLT_MAX rounds to inf in bf16: one more infinity case
+        for tdt, odt in ((torch.quint8, 4), (torch.quint4x2, 3), (torch.quint2x4, 2)):
+            assert piquant.torch.compute_quant_params(torch.from_numpy(y).cuda(), dtype=tdt) == O.compute_quant_params(y, 0, odt), (vals, odt)
+            assert piquant.torch.compute_quant_params(torch.from_numpy(yb.view(np.int16)).cuda().view(torch.bfloat16), dtype=tdt) == O.compute_quant_params(yb, 1, odt), (vals, odt)
+    for y in ((rng.uniform(-1, 1, 5000) * 1e-41).astype(np.float32), np.where(rng.uniform(size=5000) < 0.5, np.float32(0.0), np.float32(-0.0)).astype(np.float32)):
+        for tdt, odt in ((torch.quint8, 4), (torch.quint4x2, 3), (torch.quint2x4, 2)):
+            assert piquant.torch.compute_quant_params(torch.from_numpy(y).cuda(), dtype=tdt) == O.compute_quant_params(y, 0, odt), odt
 
 
 def test_compute_quant_params_back_to_back(O):
@@ -1245,6 +1257,8 @@ def _dynamic_cases(rng, n):
     full = base.copy()                                   # +-FLT_MAX: the range only fits in the epilogue's doubles; uint2's 1/scale is a denormal
     full[rng.choice(n, min(n, 2), replace=False)] = [3.4028235e38, -3.4028235e38][: min(n, 2)]
     yield "whole float range", full
+    yield "denormals only", (rng.uniform(-1, 1, n) * 1e-41).astype(np.float32)      # a denormal scale: 1/scale overflows to inf, every product is +-inf or NaN
+    yield "tiny range", (np.float32(1e-30) * rng.uniform(-1, 1, n)).astype(np.float32)
 
 
 def test_fused_dynamic_quantize_matches_oracle_and_unfused_path(O):
