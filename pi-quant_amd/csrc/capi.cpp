@@ -96,31 +96,6 @@ static void quantize_impl(piquant_context_t* ctx, const void* in, piquant_dtype_
         q.in = rin.dev;
         q.out = rout.dev;
         q.numel = static_cast<int64_t>(numel);
-        constexpr size_t kSplitCallMinElems = size_t {1} << 23;
-        if (ctx->split_call && numel >= kSplitCallMinElems && !q.ref_layout) {
-            // EXPERIMENT (context.hpp, split_call): the upper half on a side stream between a fork and a join event, the lower half on the
-            // context's stream; the cut is a multiple of 2^13 elements (whole tiles, packed bytes and 16-byte vectors on both sides)
-            if (!ctx->split_stream) {
-                PQ_HIP(hipStreamCreateWithFlags(&ctx->split_stream, hipStreamNonBlocking));
-                PQ_HIP(hipEventCreateWithFlags(&ctx->split_fork, hipEventDisableTiming));
-                PQ_HIP(hipEventCreateWithFlags(&ctx->split_join, hipEventDisableTiming));
-            }
-            const size_t half = (numel / 2) & ~((size_t {1} << 13) - 1);
-            QuantLaunch hi = q;
-            hi.in = static_cast<const char*>(q.in) + span_bytes(half, dtype_in);
-            hi.out = static_cast<char*>(q.out) + span_bytes(half, dtype_out);
-            hi.numel = static_cast<int64_t>(numel - half);
-            hi.index_base = q.index_base + half;
-            q.numel = static_cast<int64_t>(half);
-            PQ_HIP(hipEventRecord(ctx->split_fork, ctx->stream));
-            PQ_HIP(hipStreamWaitEvent(ctx->split_stream, ctx->split_fork, 0));
-            launch_quantize(hi, ctx->split_stream, ctx->num_cu);
-            PQ_HIP(hipEventRecord(ctx->split_join, ctx->split_stream));
-            launch_quantize(q, ctx->stream, ctx->num_cu);
-            PQ_HIP(hipStreamWaitEvent(ctx->stream, ctx->split_join, 0));
-            if (ctx->blocking) wait_stream(ctx);
-            return;
-        }
         {
             StopEventScope completion(ctx);
             IndependentCallScope independent(ctx);

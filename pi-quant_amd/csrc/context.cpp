@@ -368,7 +368,6 @@ piquant_context_t* piquant_context_create(size_t num_threads) {
         else if (m == "stage") ctx->host_path = PIQUANT_HIP_HOST_PATH_STAGE;
         else if (m != "auto" && !m.empty()) panic("PIQUANT_HIP_HOST_PATH=%s: expected auto, stage or cpu", env);
     }
-    if (const char* env = std::getenv("PIQUANT_HIP_SPLIT_CALL")) ctx->split_call = env[0] == '1';
     if (const char* env = std::getenv("PIQUANT_HIP_FUSION")) ctx->fusion = !(env[0] == '0' && env[1] == '\0');
     if (const char* env = std::getenv("PIQUANT_HIP_BARRIER_TIMEOUT_US")) ctx->barrier_timeout_us = static_cast<uint32_t>(std::strtoul(env, nullptr, 10));
     std::random_device rd;
@@ -391,9 +390,6 @@ void piquant_context_destroy(piquant_context_t* ctx) {
             if (p) (void)hipFree(p);
         for (auto& p : ctx->stage_out)
             if (p) (void)hipFree(p);
-        if (ctx->split_stream) (void)hipStreamDestroy(ctx->split_stream);
-        if (ctx->split_fork) (void)hipEventDestroy(ctx->split_fork);
-        if (ctx->split_join) (void)hipEventDestroy(ctx->split_join);
         if (ctx->d_state) (void)hipFree(ctx->d_state);
         if (ctx->d_fused) (void)hipFree(ctx->d_fused);
         if (ctx->h_keys) (void)hipHostFree(ctx->h_keys);

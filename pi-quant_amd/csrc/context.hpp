@@ -95,13 +95,7 @@ struct piquant_context_t {
     void* stage_out[2] = {nullptr, nullptr};
     size_t stage_in_cap = 0, stage_out_cap = 0;
 
-    // EXPERIMENT (round 5, PIQUANT_HIP_SPLIT_CALL=1 in the environment at context creation; off by default): a quantize call on device buffers of at
-    // least kSplitCallMinElems elements is issued as TWO launches, the upper half on an internal side stream between a fork and a join event
-    // (capi.cpp, quantize_impl).  Measured and left off -- the two cross-queue events cost 17 us: profiles/r05_split_call_ab.csv.
-    bool split_call = false;
     bool independent_calls = false;        // piquant_hip_set_independent_calls: quantize / dequantize launches go out without the barrier bit
-    hipStream_t split_stream = nullptr;
-    hipEvent_t split_fork = nullptr, split_join = nullptr;
 
     int host_path = PIQUANT_HIP_HOST_PATH_AUTO;    // piquant_hip_set_host_path: who serves pageable host buffers
     int host_path_resolved = -1;           // AUTO resolved to STAGE or CPU on first use (-1 = not yet)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""A/B of ONE piquant_quantize call issued as one launch (production), as two launches on two streams between a fork and a join event
-(PIQUANT_HIP_SPLIT_CALL=1, csrc/capi.cpp) -- round-4 verdict item 2 -- and as one launch without the barrier bit of its dispatch packet
-(piquant_hip_set_independent_calls: the caller declares consecutive calls independent).  fp32 -> uint8 nearest at numel 27 264 000, 24 cold buffer sets, windows of
+"""A/B of ONE piquant_quantize call issued as one launch (production) and as one launch without the barrier bit of its dispatch packet
+(piquant_hip_set_independent_calls: the caller declares consecutive calls independent).  The third variant behind profiles/r05_split_call_ab.csv --
+the call as two launches on two streams between a fork and a join event, round-4 verdict item 2 -- lost (41 against 23.5 us per call) and its code
+left the library again; commit 5514ca7 has it (PIQUANT_HIP_SPLIT_CALL=1, csrc/capi.cpp).  fp32 -> uint8 nearest at numel 27 264 000, 24 cold buffer sets, windows of
 K stream-ordered calls through the C ABI, the two variants interleaved window by window; wall clock (first call -> completion) and HIP events.
 CSV on stdout."""
 import os
@@ -26,17 +27,16 @@ scale, zp = piquant.torch.compute_quant_params(xs[0], dtype=torch.quint8)
 stream = torch.cuda.Stream()
 
 
-def make(split):
-    os.environ["PIQUANT_HIP_SPLIT_CALL"] = "1" if split == 1 else "0"
+def make(independent):
     c = piquant.Context()
-    c.set_independent_calls(split == 2)
+    c.set_independent_calls(independent)
     c.set_stream(stream.cuda_stream)
     c.set_blocking(False)
     c.assume_device_pointers(True)
     return c
 
 
-ctxs = {"one_launch": make(0), "two_launches_fork_join": make(1), "one_launch_without_barrier_bit_caller_declares_independence": make(2)}
+ctxs = {"one_launch": make(False), "one_launch_without_barrier_bit_caller_declares_independence": make(True)}
 args = {k: [(c._ctx, xs[i].data_ptr(), DataType.F32.value, outs[i].data_ptr(), DataType.UINT8.value, N, scale, zp, RoundMode.NEAREST.value) for i in range(SETS)]
         for k, c in ctxs.items()}
 # same bytes
@@ -46,7 +46,7 @@ for k in ctxs:
     C_LIB.piquant_quantize(*args[k][0])
     torch.cuda.synchronize()
     got = outs[0].clone()
-    assert ref is None or torch.equal(ref, got), "split call changed the bytes"
+    assert ref is None or torch.equal(ref, got), "the any-order launch changed the bytes"
     ref = got
 res = {k: {"wall": [], "ev": []} for k in ctxs}
 with torch.cuda.stream(stream):
