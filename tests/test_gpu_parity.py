@@ -1657,3 +1657,41 @@ def test_requantize_with_degenerate_scales(ctx, O, dt):
                         want = O.requantize(xin, dt, qd, float(scale), zp, rm, tau, op, out=prev.copy())
                         assert same_floats(got, want), (qd, scale, zp, rm, op)
     ctx.set_stochastic_threshold(None)
+
+
+def test_reference_layout_with_degenerate_scales(ctx, O):
+    """The same degenerate scales in reference-layout mode: the scalar heads and tails of a one- and a three-thread reference context take the
+    reference's scalar formulas (std::round, the (q - zp) * scale form of the bf16 tails) on +-inf / NaN / denormal reciprocals too."""
+    rng = np.random.default_rng(4400)
+    try:
+        for threads in (1, 3):
+            ctx.set_reference_layout(True, threads=threads)
+            for n in (65, 4099):
+                x = rng.uniform(-3, 3, n).astype(np.float32)
+                x[[1, 3, 5, 7, 9, 11, 13, 15, 17]] = [0.0, -0.0, np.nan, np.inf, -np.inf, 1e-40, -1e38, 3.3e38, -3.3e38]
+                x[-3:] = [0.49999997, 3.3e38, np.nan]                           # in the last partition's scalar tail
+                for scale in DEGENERATE_SCALES:
+                    for zp in (3, -7):
+                        for dt_in, xin in ((O.F32, x), (O.BF16, O.f32_to_bf16(x))):
+                            for dt_out in (O.UINT8, O.UINT4, O.UINT2):
+                                for rm, tau in ((0, 0.0), (1, 0.37)):
+                                    ctx.set_stochastic_threshold(tau if rm else None)
+                                    nbytes = O.packed_numel(n, dt_out)
+                                    wbuf = np.zeros(nbytes + 32, dtype=np.uint8)
+                                    base = (-wbuf.ctypes.data) % 16
+                                    want = O.quantize(xin, dt_in, dt_out, float(scale), zp, rm, tau, form=O.FORM_REFERENCE, threads=threads, out=wbuf[base: base + nbytes])
+                                    got = gpu_quantize(ctx, xin, dt_in, dt_out, float(scale), zp, rm)
+                                    assert np.array_equal(got, want), (threads, n, scale, zp, dt_in, dt_out, rm, np.nonzero(got != want)[0][:5])
+                        for dt_q in (O.UINT8, O.UINT4, O.UINT2):
+                            q = rng.integers(0, 256, O.packed_numel(n, dt_q), dtype=np.uint8)
+                            for dt_f in (O.F32, O.BF16):
+                                prev = rng.uniform(-3, 3, n).astype(np.float32)
+                                prev[[2, 4, n - 1]] = [np.nan, np.inf, -np.inf]
+                                prev = prev if dt_f == O.F32 else O.f32_to_bf16(prev)
+                                for op in (0, 1):
+                                    want = O.dequantize(q, dt_q, dt_f, n, float(scale), zp, op, form=O.FORM_REFERENCE, threads=threads, out=prev.copy())
+                                    got = gpu_dequantize(ctx, q, dt_q, dt_f, n, float(scale), zp, op, prev=prev.copy())
+                                    assert same_floats(got, want), (threads, n, scale, zp, dt_q, dt_f, op)
+    finally:
+        ctx.set_reference_layout(False, threads=1)
+        ctx.set_stochastic_threshold(None)
