@@ -122,8 +122,14 @@ def p2p_all_reduce_child_job(args, world):
     import socket
     import subprocess
 
-    if os.environ.get("PIQUANT_BENCH_P2P", "1") == "0":
+    # PIQUANT_BENCH_P2P: "0" never, "1" always; unset = only where it cannot cost a LATER run -- a scaling sweep runs N = 1, 2, 4, 8 back to back on one
+    # node, and a transport that has never run between two GPUs gets its first contact behind the LAST of them (N >= 8), not between them
+    # (--share-gpu: the one-GPU test plumbing, where it has run many times)
+    want = os.environ.get("PIQUANT_BENCH_P2P", "auto")
+    if want == "0":
         return "not run: PIQUANT_BENCH_P2P=0"
+    if want != "1" and not (world >= 8 or args.share_gpu):
+        return f"not run at N = {world}: first contact of the peer-to-peer transport with real peers is kept behind the last run of a sweep (N >= 8); PIQUANT_BENCH_P2P=1 runs it anyway"
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
