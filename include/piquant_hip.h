@@ -56,7 +56,7 @@ PIQUANT_EXPORT void piquant_hip_set_host_path(piquant_context_t* ctx, int path);
 PIQUANT_EXPORT int piquant_hip_host_path_in_effect(piquant_context_t* ctx);
 
 /* Pointer classification.  By default every buffer is classified with hipPointerGetAttributes (device / pinned: used in
- * place; pageable host: staged over PCIe).  A binding that already knows its buffers are device memory (PyTorch device
+ * place; pageable host: the host path above -- companion library or staging over PCIe).  A binding that already knows its buffers are device memory (PyTorch device
  * tensors) sets assume != 0 to skip the two runtime queries per call -- they are a visible share of the ~10 us a small
  * call costs.  With assume set, passing a pageable host pointer is undefined behaviour. */
 PIQUANT_EXPORT void piquant_hip_assume_device_pointers(piquant_context_t* ctx, int assume);

@@ -3,8 +3,9 @@
 Same public names as the reference package (reference ``python/src/piquant/__init__.py:20-142``):
 ``RoundMode``, ``ReduceOp``, ``DataType``, ``Context`` with ``quantize_ptr`` / ``dequantize_ptr`` /
 ``compute_quant_params_ptr_float32`` / ``compute_quant_params_ptr_bfloat16``, and the ``piquant.torch``
-module.  Behind it every call lands in hand-written HIP kernels through the C ABI of ``libpiquant.so``.
-Pointers may be device pointers (PyTorch-ROCm ``tensor.data_ptr()``) or host pointers (staged over PCIe).
+module.  Behind it every call on device, pinned or managed memory lands in hand-written HIP kernels through the C ABI of ``libpiquant.so``.
+Pointers may be device pointers (PyTorch-ROCm ``tensor.data_ptr()``) or pageable host pointers (served by the companion library
+``libpiquant_cpu.so`` where they live -- the default -- or staged over PCIe to the same HIP kernels: ``piquant_hip_set_host_path``).
 """
 from __future__ import annotations
 

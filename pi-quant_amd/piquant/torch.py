@@ -6,7 +6,8 @@ Same functions and keyword arguments as the reference module (``python/src/piqua
 
 * tensors may live on a ROCm device; the output is allocated on ``tensor.device`` and the kernels are
   enqueued on the current PyTorch stream (ordinary PyTorch stream semantics, no host sync);
-* CPU tensors still work (their host pointers are staged through the GPU over PCIe);
+* CPU tensors still work: their host buffers are served where they live by the companion library ``libpiquant_cpu.so`` (the default since
+  round 4, synchronous on host threads) or, without it / with ``PIQUANT_HIP_HOST_PATH=stage``, staged through the GPU over PCIe;
 * ``out=`` lets ``reduce_op='add'`` accumulate into an existing tensor -- the reference allocates a fresh
   uninitialised output (``torch.py:117``), which makes ADD unusable through its tensor API;
 * ``ctx=None`` resolves to the default context of the tensor's device at call time (the reference evaluates

@@ -28,6 +28,10 @@ from helpers import gpu_dequantize, gpu_quantize, same_floats  # noqa: E402
 from test_gpu_parity import _fuzz_values, gpu_quantize_dynamic, gpu_requantize  # noqa: E402
 
 
+DEGENERATE_SCALES = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, -0.05, -1.0, 1e-40, -1e-40, 3e38, -3e38, 1.1754944e-38, 3.4028235e38, 1e-45, 2.0 ** -126, 2.0 ** -127,
+                              8.6e37], dtype=np.float32)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=600.0)
@@ -67,6 +71,8 @@ def main():
         wild = it % 2 == 0
         x = _fuzz_values(rng, n) if wild else rng.uniform(-3, 3, n).astype(np.float32)
         scale = float(np.float32(10.0 ** rng.uniform(-30, 30))) if wild else float(np.float32(rng.uniform(0.001, 0.1)))
+        if wild and it % 16 == 2:   # any float is a legal scale for the reference (src/piquant.cpp:286-295): zeros, infinities, NaN, negative, denormal, denormal reciprocal
+            scale = float(rng.choice(DEGENERATE_SCALES))
         zp = int(rng.integers(-2**63, 2**63 - 1)) if it % 5 == 0 else int(rng.integers(-300, 300))
         dt_f, dt_q = int(rng.integers(0, 2)), int(rng.integers(2, 5))
         xin = x if dt_f == 0 else O.f32_to_bf16(x)
@@ -114,6 +120,29 @@ def main():
         check(same_floats(got, want), "requantize", n=n, dt_f=dt_f, dt_q=dt_q, scale=scale, zp=zp, rm=rm, tau=tau, op=op, wild=wild, x=xin, prev=prev, got=got, want=want)
         kinds["requantize"] += 1
         elems += 3 * n
+
+        if it % 6 == 5 and n <= 50_000:
+            # reference-layout mode: the scalar heads / tails of a T-thread reference context (src/piquant.cpp:145-157) take the reference's scalar formulas
+            # at the reference's positions; the expected bytes are the oracle's REFERENCE form, the head placed by the output pointer's alignment
+            threads = int(rng.choice([1, 1, 2, 3, 7, 64]))
+            ctx.set_reference_layout(True, threads=threads)
+            try:
+                off = int(rng.integers(0, 16)) if (dt_f, dt_q) == (0, 4) else 0
+                nbytes = O.packed_numel(n, dt_q)
+                wbuf = np.zeros(nbytes + 48, dtype=np.uint8)
+                base = (-wbuf.ctypes.data) % 16
+                want = O.quantize(xin, dt_f, dt_q, scale, zp, rm, tau, form=O.FORM_REFERENCE, threads=threads, out=wbuf[base + off: base + off + nbytes]).copy()
+                got = gpu_quantize(ctx, xin, dt_f, dt_q, scale, zp, rm, offset_out=off)
+                check(np.array_equal(got, want), "reference_layout_quantize", n=n, dt_f=dt_f, dt_q=dt_q, scale=scale, zp=zp, rm=rm, tau=tau, threads=threads, off=off, x=xin,
+                      got=got, want=want)
+                want = O.dequantize(q, dt_q, dt_f, n, scale, zp, op, form=O.FORM_REFERENCE, threads=threads, out=prev.copy())
+                got = gpu_dequantize(ctx, q, dt_q, dt_f, n, scale, zp, op, prev=prev.copy())
+                check(same_floats(got, want), "reference_layout_dequantize", n=n, dt_f=dt_f, dt_q=dt_q, scale=scale, zp=zp, op=op, threads=threads, q=q, prev=prev, got=got,
+                      want=want)
+            finally:
+                ctx.set_reference_layout(False, threads=1)
+            kinds["reference_layout"] = kinds.get("reference_layout", 0) + 2
+            elems += 2 * n
 
         # min/max scan on whatever the data is (NaNs of both kinds are skipped, infinities count); numeric comparison: -0.0 == 0.0
         xd_buf = torch.empty(xin.nbytes + off_f, dtype=torch.uint8, device="cuda")
