@@ -9,6 +9,8 @@
 // behaviour (src/kernels/kernels_specialized.inl:753-758, 953-971, 1244-1284).
 #pragma once
 
+#include <type_traits>
+
 #include "quant_kernels.hpp"
 
 namespace pq {
@@ -21,7 +23,8 @@ struct DequantForm {
 };
 
 // `shift`: bits in front of element 0 inside in[0] (a body that starts in the middle of a packed byte, dequantize_kernel); 0 everywhere else
-template <int BITS, int DT_OUT, int OP>
+// KNOWN_TAIL: the caller has established that element i lies in a reference tail (the patch kernels below): no partition arithmetic
+template <int BITS, int DT_OUT, int OP, bool KNOWN_TAIL = false>
 __device__ __forceinline__ void dequant_store_scalar(const uint8_t* in, void* out, int64_t i, const DequantParams& p, int shift = 0) {
     constexpr int PACK = 8 / BITS;
     constexpr int FORM = DequantForm<BITS, DT_OUT>::value;
@@ -30,11 +33,15 @@ __device__ __forceinline__ void dequant_store_scalar(const uint8_t* in, void* ou
     if (p.ref_layout) {
         // Reference-layout mode: element g of the call sits in the reference's scalar tail when it is past the last whole
         // SIMD block (64 / 128 / 256 elements for uint8 / uint4 / uint2->bf16; groups of 4 for the generic uint2->f32).
-        const int64_t g = p.ref_index0 + i;
-        constexpr int64_t BLK = BITS == 8 ? 64 : (BITS == 4 ? 128 : (DT_OUT == DT_BF16 ? 256 : 4));
-        int64_t begin = 0, len = p.ref_total;        // the tail is the tail of the element's partition (a T-thread reference context)
-        if (p.ref_threads > 1) ref_partition_of(g, p.ref_total, p.ref_threads, PACK, begin, len);
-        if (g - begin >= (len / BLK) * BLK) {
+        bool tail = KNOWN_TAIL;
+        if constexpr (!KNOWN_TAIL) {
+            const int64_t g = p.ref_index0 + i;
+            constexpr int64_t BLK = BITS == 8 ? 64 : (BITS == 4 ? 128 : (DT_OUT == DT_BF16 ? 256 : 4));
+            int64_t begin = 0, len = p.ref_total;        // the tail is the tail of the element's partition (a T-thread reference context)
+            if (p.ref_threads > 1) ref_partition_of(g, p.ref_total, p.ref_threads, PACK, begin, len);
+            tail = g - begin >= (len / BLK) * BLK;
+        }
+        if (tail) {
             if constexpr (DT_OUT == DT_F32) {
                 if constexpr (BITS == 2) {   // dequantize.inl:72-86: the 1-3 element tail always stores, ADD is ignored
                     static_cast<float*>(out)[i] = dequant_one<FORM>(q, p);
@@ -71,6 +78,40 @@ __global__ void __launch_bounds__(256) dequantize_scalar_kernel(const uint8_t* i
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < numel; i += stride)
         dequant_store_scalar<BITS, DT_OUT, OP>(in, out, i, p);
+}
+
+// Reference-layout mode with tails INSIDE the tensor (partitions of a T-thread reference context; a body that does not start at element 0):
+// the vector kernel decodes the whole call with the SIMD-body formula and these kernels, one block per partition, give the partition's scalar
+// tail (at most 255 elements) the reference's tail formula.  SET: PATCH_DIRECT behind the vector kernel rewrites the tail in place.  ADD: the old
+// accumulator values are gone once the vector kernel has run, so PATCH_STASH runs FIRST -- it copies the tail's old values into `scratch` (256 slots
+// per partition) and applies the tail formula there -- and PATCH_UNSTASH behind the vector kernel copies the results into place.
+enum : int { PATCH_DIRECT = 0, PATCH_STASH = 1, PATCH_UNSTASH = 2 };
+constexpr int kRefTailSlots = 256;
+
+template <int BITS, int DT_OUT, int OP, int WHAT>
+__global__ void __launch_bounds__(256) dequantize_ref_patch_kernel(const uint8_t* in, void* out, void* scratch, int64_t numel, DequantParams p_arg) {
+    const DequantParams p = resolved(p_arg);
+    using elem_t = typename std::conditional<DT_OUT == DT_F32, float, uint16_t>::type;
+    constexpr int PACK = 8 / BITS;
+    constexpr int64_t BLK = BITS == 8 ? 64 : (BITS == 4 ? 128 : (DT_OUT == DT_BF16 ? 256 : 4));
+    static_assert(BLK <= kRefTailSlots, "a tail fits its slots");
+    int64_t begin = 0, len = p.ref_total;
+    if (p.ref_threads > 1) ref_partition_bounds(blockIdx.x, p.ref_total, p.ref_threads, PACK, begin, len);
+    const int64_t tail0 = begin + (len / BLK) * BLK;                      // global index of the tail's first element
+    const int64_t g = tail0 + threadIdx.x;
+    const int64_t i = g - p.ref_index0;                                   // element of THIS launch
+    if (g >= begin + len || i < 0 || i >= numel) return;
+    elem_t* o = static_cast<elem_t*>(out);
+    elem_t* slot = static_cast<elem_t*>(scratch) + static_cast<int64_t>(blockIdx.x) * kRefTailSlots + threadIdx.x;
+    if constexpr (WHAT == PATCH_DIRECT) {
+        dequant_store_scalar<BITS, DT_OUT, OP, true>(in, out, i, p);
+    } else if constexpr (WHAT == PATCH_STASH) {
+        *slot = o[i];
+        // dequant_store_scalar indexes its output with i: hand it the address at which element i IS this slot
+        dequant_store_scalar<BITS, DT_OUT, OP, true>(in, reinterpret_cast<void*>(reinterpret_cast<uintptr_t>(slot) - static_cast<uintptr_t>(i) * sizeof(elem_t)), i, p);
+    } else {
+        o[i] = *slot;
+    }
 }
 
 template <int BITS, int DT_OUT, int U, int BLOCK>

@@ -230,6 +230,16 @@ __device__ __forceinline__ void ref_partition_of(int64_t g, int64_t n, int64_t T
     len = first(t + 1) - begin;
 }
 
+// Partition t of a T-thread reference context over n elements (src/piquant.cpp:145-157): [begin, begin + len)
+__device__ __forceinline__ void ref_partition_bounds(int64_t t, int64_t n, int64_t T, int64_t pack, int64_t& begin, int64_t& len) {
+    auto first = [&](int64_t k) {
+        const int64_t b = n * k / T;
+        return k >= T ? n : (pack > 1 ? b - b % pack : b);
+    };
+    begin = first(t);
+    len = first(t + 1) - begin;
+}
+
 // true when global element g of a call lies in the reference's scalar head or tail (block = SIMD block of the kernel, pack = elements
 // per packed output byte): of the whole call for a one-thread context, of its partition otherwise
 __device__ __forceinline__ bool ref_scalar_position(const QuantParams& p, int64_t g, int64_t block, int64_t pack) {

@@ -29,6 +29,18 @@ inline unsigned capped_grid(int64_t want, int blocks_per_cu, int num_cu) {
     return static_cast<unsigned>(std::max<int64_t>(g, 1));
 }
 
+// A call that is several launches (reference-layout mode with partitions, below): only the FIRST may go out without the barrier bit of an
+// independent call (stop_event.hpp) -- the others depend on it -- and only the LAST carries a blocking call's stop event.
+struct LaunchSequence {
+    hipEvent_t stop = tl_stop_event;
+    bool any_order = tl_any_order;
+    void first() { tl_stop_event = nullptr; }
+    void middle() { tl_stop_event = nullptr; tl_any_order = false; }
+    void last() { tl_stop_event = stop; tl_any_order = false; }
+    ~LaunchSequence() { tl_stop_event = stop; tl_any_order = any_order; }
+};
+constexpr int kRefPatchMaxThreads = 1 << 20;   // partitions of a reference context the patch kernels are launched for (one block each); beyond: element by element
+
 template <int DT_IN, int BITS, int MODE, bool SMALL = false>
 void quantize_t(const QuantLaunch& q, const QuantParams& p, hipStream_t stream, int num_cu) {
     constexpr bool kStochastic = MODE == RM_STOCH_CALL || MODE == RM_STOCH_ELEM;
@@ -45,10 +57,15 @@ void quantize_t(const QuantLaunch& q, const QuantParams& p, hipStream_t stream, 
     // tiles (profiles/r03_tune_misaligned.csv).
     const int64_t head_bytes = static_cast<int64_t>((kStoreAlign - (reinterpret_cast<uintptr_t>(q.out) & (kStoreAlign - 1))) & (kStoreAlign - 1));
     const int64_t head = head_bytes * PACK;
-    // The guarded kernel remains for: inputs that are not even element-aligned, tensors that end inside the head, and reference-layout mode
-    // whenever scalar positions lie inside the tensor (a scalar head shifts every SIMD block, and the partitions of a T-thread reference
-    // context put heads and tails everywhere).
-    if (reinterpret_cast<uintptr_t>(q.in) % ESIZE != 0 || head >= q.numel || (q.ref_layout && (q.ref_head != 0 || q.ref_threads > 1 || head != 0))) {
+    // Reference-layout mode with scalar positions INSIDE the tensor (a scalar head shifts every SIMD block, and the partitions of a T-thread
+    // reference context put heads and tails everywhere): the vector kernel runs in the uniform form and a patch kernel behind it rewrites the
+    // heads and tails (quant_kernels.hpp, quantize_ref_patch_kernel).  Only the nearest fast step has a scalar form of its own; the other
+    // steps are the same formula at every position, layout or not.
+    const bool ref_inside = q.ref_layout && (q.ref_head != 0 || q.ref_threads > 1 || head != 0);
+    const bool ref_patch = ref_inside && MODE == RM_NEAREST_FAST;
+    // The guarded kernel remains for: inputs that are not even element-aligned, tensors that end inside the head, and reference contexts of
+    // more threads than the patch kernel is launched for.
+    if (reinterpret_cast<uintptr_t>(q.in) % ESIZE != 0 || head >= q.numel || (ref_patch && q.ref_threads > kRefPatchMaxThreads)) {
         const int64_t nbytes = (q.numel + PACK - 1) / PACK;
         const unsigned grid = capped_grid((nbytes + kScalarBlock - 1) / kScalarBlock, 16, num_cu);
         PQ_LAUNCH((quantize_scalar_kernel<DT_IN, BITS, MODE>), dim3(grid), dim3(kScalarBlock), 0, stream, q.in, out, q.numel, p);
@@ -57,12 +74,21 @@ void quantize_t(const QuantLaunch& q, const QuantParams& p, hipStream_t stream, 
     QuantParams body = p;
     body.index_base += static_cast<uint64_t>(head);
     body.ref_index0 += head;
+    if (ref_inside) body.ref_layout = 0;
     const int64_t numel = q.numel - head;
     const int64_t n_tiles = numel / Tile::BLOCK_ELEMS;
     const unsigned grid = capped_grid(n_tiles, t.blocks_per_cu, num_cu);
     constexpr int kVariant = BITS == 8 ? kQuantVariant : kQuantVariantSubByte;   // tuning.hpp
+    LaunchSequence seq;
+    if (ref_patch) seq.first();
     launch_quantize_kernel<DT_IN, BITS, MODE, t.u, t.stage, t.nt, t.block, kQuantShortStep, kVariant>(
         grid, 0, stream, static_cast<const void*>(static_cast<const uint8_t*>(q.in) + head * ESIZE), out + head_bytes, numel, n_tiles, body, static_cast<int>(head));
+    if constexpr (MODE == RM_NEAREST_FAST) {
+        if (ref_patch) {
+            seq.last();
+            PQ_LAUNCH((quantize_ref_patch_kernel<DT_IN, BITS>), dim3(static_cast<unsigned>(p.ref_threads)), dim3(256), 0, stream, q.in, out, q.numel, p);
+        }
+    }
 }
 
 template <int DT_IN, int BITS>
@@ -106,20 +132,56 @@ void dequantize_t(const DequantLaunch& d, const DequantParams& p, hipStream_t st
     const uintptr_t oa = reinterpret_cast<uintptr_t>(d.out);
     const int64_t head = static_cast<int64_t>((kStoreAlign - (oa & (kStoreAlign - 1))) & (kStoreAlign - 1)) / ESIZE;   // to a whole cache line (quantize_t)
     const int shift = static_cast<int>(head % PACK) * BITS;   // != 0: the body starts inside a packed byte and the kernel funnel-shifts its input (dequant_kernels.hpp)
-    // element-wise kernel: an output that is not element-aligned, a tensor that ends inside the head, and reference-layout mode when tails
-    // lie inside the tensor (partitions of a T-thread context) or the tiles would not start at element 0
-    if (oa % ESIZE != 0 || head >= d.numel || (d.ref_layout && (d.ref_threads > 1 || head != 0))) {
+    // Reference-layout mode when tails lie inside the tensor (partitions of a T-thread context) or the tiles would not start at element 0: the
+    // vector kernel runs in the uniform form and patch kernels give the tails the reference's tail formula (dequant_kernels.hpp,
+    // dequantize_ref_patch_kernel).  Only bf16 outputs and the uint2 -> fp32 ADD tail (which stores) have a tail form of their own.
+    const bool ref_inside = d.ref_layout && (d.ref_threads > 1 || head != 0);
+    const bool ref_patch = ref_inside && (DT_OUT == DT_BF16 || (BITS == 2 && OP == OP_ADD));
+    bool capturing = false;
+    if (ref_patch && OP == OP_ADD) {   // the ADD flow takes stream-ordered scratch memory: not inside a capture
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        capturing = hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone;
+        (void)hipGetLastError();
+    }
+    // element-wise kernel: an output that is not element-aligned, a tensor that ends inside the head, reference contexts of more threads than
+    // the patch kernels are launched for, the ADD flow inside a capture
+    if (oa % ESIZE != 0 || head >= d.numel || (ref_patch && (p.ref_threads > kRefPatchMaxThreads || capturing))) {
         const unsigned grid = capped_grid((d.numel + kScalarBlock - 1) / kScalarBlock, 16, num_cu);
         PQ_LAUNCH((dequantize_scalar_kernel<BITS, DT_OUT, OP>), dim3(grid), dim3(kScalarBlock), 0, stream, in, d.out, d.numel, p);
         return;
     }
     DequantParams body = p;
     body.ref_index0 += head;
+    if (ref_inside) body.ref_layout = 0;
     const int64_t numel = d.numel - head;
     const int64_t n_tiles = numel / Tile::BLOCK_ELEMS;
     const unsigned grid = capped_grid(n_tiles, t.blocks_per_cu, num_cu);
+    const dim3 parts(static_cast<unsigned>(p.ref_threads));
+    LaunchSequence seq;
+    void* scratch = nullptr;
+    if constexpr (DT_OUT == DT_BF16 || (BITS == 2 && OP == OP_ADD)) {
+        if (ref_patch && OP == OP_ADD) {     // the tails' old values are needed AFTER the vector kernel has overwritten them: stash first
+            PQ_HIP(hipMallocAsync(&scratch, static_cast<size_t>(p.ref_threads) * kRefTailSlots * ESIZE, stream));
+            seq.first();
+            PQ_LAUNCH((dequantize_ref_patch_kernel<BITS, DT_OUT, OP, PATCH_STASH>), parts, dim3(kRefTailSlots), 0, stream, in, d.out, scratch, d.numel, p);
+            seq.middle();
+        } else if (ref_patch) {
+            seq.first();
+        }
+    }
     launch_dequantize_kernel<BITS, DT_OUT, OP, t.u, t.stage, t.nt, t.block>(grid, stream, in + head / PACK, static_cast<void*>(static_cast<uint8_t*>(d.out) + head * ESIZE),
                                                                             numel, n_tiles, body, static_cast<int>(head) | (shift << 16));
+    if constexpr (DT_OUT == DT_BF16 || (BITS == 2 && OP == OP_ADD)) {
+        if (ref_patch) {
+            seq.last();
+            if (OP == OP_ADD) {
+                PQ_LAUNCH((dequantize_ref_patch_kernel<BITS, DT_OUT, OP, PATCH_UNSTASH>), parts, dim3(kRefTailSlots), 0, stream, in, d.out, scratch, d.numel, p);
+                PQ_HIP(hipFreeAsync(scratch, stream));
+            } else {
+                PQ_LAUNCH((dequantize_ref_patch_kernel<BITS, DT_OUT, OP, PATCH_DIRECT>), parts, dim3(kRefTailSlots), 0, stream, in, d.out, scratch, d.numel, p);
+            }
+        }
+    }
 }
 
 template <int BITS, int DT_OUT>

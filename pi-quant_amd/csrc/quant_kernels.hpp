@@ -124,6 +124,44 @@ __global__ void __launch_bounds__(256) quantize_scalar_kernel(const void* in, ui
                                               static_cast<int64_t>(gridDim.x) * blockDim.x);
 }
 
+// Reference-layout mode with scalar positions INSIDE the tensor (the partitions of a T-thread reference context, a scalar head in front of a
+// misaligned output): the vector kernel quantizes the whole call with the SIMD-body formula, and this kernel -- launched behind it, one block per
+// partition -- rewrites the partition's scalar head and tail (at most 15 + 63 elements, whole packed bytes) with the reference's scalar formula
+// through the guarded path.  The element-by-element kernel used to take such calls whole: 124-213 us at numel 27 264 000 against 23.
+template <int DT_IN, int BITS>
+__global__ void __launch_bounds__(256) quantize_ref_patch_kernel(const void* in, uint8_t* out, int64_t numel, QuantParams p_arg) {
+    const QuantParams p = resolved(p_arg);
+    constexpr int PACK = 8 / BITS;
+    constexpr int64_t BLK = BITS == 8 ? 64 : 16;
+    int64_t begin = 0, len = p.ref_total, head = p.ref_head;
+    if (p.ref_threads > 1) {
+        ref_partition_bounds(blockIdx.x, p.ref_total, p.ref_threads, PACK, begin, len);
+        head = 0;
+        if (p.ref_out_align >= 0) head = (16 - ((p.ref_out_align + begin) & 15)) & 15;
+    }
+    head = head < len ? head : len;
+    const int64_t body = ((len - head) / BLK) * BLK;
+    // global element ranges -> bytes of THIS launch (a chunk of a staged host call covers [ref_index0, ref_index0 + numel) of the call)
+    const int64_t ranges[2][2] = {{begin, begin + head}, {begin + head + body, begin + len}};
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        int64_t lo = ranges[r][0] - p.ref_index0, hi = ranges[r][1] - p.ref_index0;
+        lo = lo < 0 ? 0 : lo;
+        hi = hi > numel ? numel : hi;
+        // every element of these bytes is a scalar position by construction (both ends of a range are whole packed bytes, the tensor's ragged last
+        // byte aside): the reference's scalar formula without asking ref_scalar_position -- its 64-bit divisions per element were most of this kernel
+        for (int64_t b = lo / PACK + threadIdx.x; b < (hi + PACK - 1) / PACK; b += blockDim.x) {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int k = 0; k < PACK; ++k) {
+                const int64_t i = b * PACK + k;
+                if (i < numel) acc |= quant_nearest_tail32<(1 << BITS) - 1>(InVec<DT_IN>::load_scalar(in, i), p) << (k * BITS);
+            }
+            out[b] = static_cast<uint8_t>(acc);
+        }
+    }
+}
+
 // one 16-byte input vector -> WORDS packed 32-bit words (OB = EPV*BITS/8 bytes of output)
 template <int DT_IN, int BITS, int MODE>
 __device__ __forceinline__ void quantize_vec(const u32x4& raw, const QuantParams& p, const ElementKeys& keys, uint64_t e0,

@@ -1695,3 +1695,81 @@ def test_reference_layout_with_degenerate_scales(ctx, O):
     finally:
         ctx.set_reference_layout(False, threads=1)
         ctx.set_stochastic_threshold(None)
+
+
+def test_reference_layout_partitions_at_full_size(ctx, O):
+    """Round 5: reference-layout mode with scalar positions inside the tensor (partitions of a T-thread reference context, a misaligned output) no
+    longer takes the element-by-element kernels (124-213 us at numel 27 264 000): the vector kernels run in the uniform form and patch kernels rewrite
+    the partitions' heads and tails (quantize_ref_patch_kernel, dequantize_ref_patch_kernel).  255 and 3 partitions of the BASELINE tensor, salted with
+    the values on which the reference's formulas differ -- also exactly at the partition boundaries -- against the oracle's threaded reference form;
+    stream-ordered, blocking in every wait mode, and with the calls declared independent."""
+    import piquant
+    import torch
+
+    rng = np.random.default_rng(255)
+    n = N1
+    x = rng.uniform(-1.2, 1.2, n).astype(np.float32)
+    x[rng.choice(n, n // 50)] = np.float32(0.49999997)
+    x[rng.choice(n, n // 60)] = np.float32(-0.49999997)
+    x[rng.choice(n, n // 70)] = np.float32(8388609.0)
+    q8 = rng.integers(0, 256, n, dtype=np.uint8)
+    prev = rng.uniform(-3, 3, n).astype(np.float32)
+    try:
+        for threads in (255, 3):
+            edges = np.unique(np.clip(np.concatenate([(n * np.arange(1, threads) // threads)[:, None] + np.arange(-70, 20)[None, :]]).ravel(), 0, n - 1))
+            x[edges] = rng.choice(np.array([0.49999997, -0.49999997, 8388609.0, 0.3], np.float32), edges.size)
+            xb = O.f32_to_bf16(x)
+            ctx.set_reference_layout(True, threads=threads)
+            for dt_in, xin, dt_out, off in ((O.F32, x, O.UINT8, 0), (O.F32, x, O.UINT8, 5), (O.BF16, xb, O.UINT4, 0), (O.BF16, xb, O.UINT2, 0)):
+                nbytes = O.packed_numel(n, dt_out)
+                wbuf = np.zeros(nbytes + 32, dtype=np.uint8)
+                base = (-wbuf.ctypes.data) % 16
+                want = O.quantize(xin, dt_in, dt_out, 1.0, 1, form=O.FORM_REFERENCE, threads=threads, out=wbuf[base + off: base + off + nbytes])
+                got = gpu_quantize(ctx, xin, dt_in, dt_out, 1.0, 1, offset_out=off)
+                assert np.array_equal(got, want), (threads, dt_in, dt_out, off, np.nonzero(got != want)[0][:8])
+                if dt_in == O.F32 and threads == 255:      # (bf16 has no value on which the nearest formulas differ: 0.49999997 and 8388609 are not bf16 numbers;
+                    #  three partitions of 27 264 000 elements are whole SIMD blocks: no tails, and heads only in front of a misaligned output)
+                    assert not np.array_equal(want, O.quantize(xin, dt_in, dt_out, 1.0, 1, form=O.FORM_UNIFORM)), "the salt never met a scalar position"
+            for dt_q, dt_f, op in ((O.UINT4, O.BF16, 0), (O.UINT4, O.BF16, 1), (O.UINT8, O.BF16, 1), (O.UINT2, O.BF16, 1), (O.UINT2, O.F32, 1), (O.UINT8, O.F32, 1)):
+                q = q8[: O.packed_numel(n, dt_q)]
+                pv = prev if dt_f == O.F32 else O.f32_to_bf16(prev)
+                want = O.dequantize(q, dt_q, dt_f, n, 0.3, 2, op, form=O.FORM_REFERENCE, threads=threads, out=pv.copy())
+                got = gpu_dequantize(ctx, q, dt_q, dt_f, n, 0.3, 2, op, prev=pv.copy())
+                assert same_floats(got, want), (threads, dt_q, dt_f, op)
+        # the same call as a blocking call in every wait mode (the patch kernel carries the completion signal, not the vector kernel in front of it),
+        # and as an independent call (only the first launch of the sequence may go out of order)
+        ctx.set_reference_layout(True, threads=7)
+        m = 3_000_001
+        xs = x[:m].copy()
+        wbuf = np.zeros(m + 32, dtype=np.uint8)
+        base = (-wbuf.ctypes.data) % 16
+        want = O.quantize(xs, O.F32, O.UINT8, 1.0, 1, form=O.FORM_REFERENCE, threads=7, out=wbuf[base: base + m]).copy()
+        xd = torch.from_numpy(xs).cuda()
+        for mode in ('sync', 'write32', 'kernel', 'event'):
+            out = torch.zeros(m, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            ctx.reset_stream()
+            ctx.set_blocking(True)
+            ctx.set_blocking_wait(mode)
+            ctx.quantize_ptr(xd.data_ptr(), piquant.DataType.F32, out.data_ptr(), piquant.DataType.UINT8, m, 1.0, 1, piquant.RoundMode.NEAREST)
+            host = torch.empty(m, dtype=torch.uint8).pin_memory()
+            host.copy_(out, non_blocking=True)          # on another stream than the call's: correct only if the call really completed
+            torch.cuda.synchronize()
+            assert np.array_equal(host.numpy(), want), mode
+        ctx.set_blocking_wait('kernel')
+        ctx.set_blocking(False)
+        stream = torch.cuda.Stream()
+        ctx.set_stream(stream.cuda_stream)
+        with torch.cuda.stream(stream):
+            outs = [torch.zeros(m, dtype=torch.uint8, device="cuda") for _ in range(6)]
+            torch.cuda.synchronize()
+            with ctx.independent_calls():
+                for o in outs:
+                    ctx.quantize_ptr(xd.data_ptr(), piquant.DataType.F32, o.data_ptr(), piquant.DataType.UINT8, m, 1.0, 1, piquant.RoundMode.NEAREST)
+        torch.cuda.synchronize()
+        for o in outs:
+            assert np.array_equal(o.cpu().numpy(), want)
+    finally:
+        ctx.set_blocking_wait('kernel')
+        ctx.set_blocking(False)
+        ctx.set_reference_layout(False, threads=1)
