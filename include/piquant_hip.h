@@ -87,10 +87,14 @@ PIQUANT_EXPORT void piquant_hip_set_stochastic_per_element(piquant_context_t* ct
  * 1-3 element tail of uint2 -> f32 ADD stores instead of adding (dequantize.inl:72-86).  With this mode on, those
  * positions use the reference's scalar formulas, so every output byte equals what the reference's AVX-512 build writes
  * from a context with ONE pool thread.  A reference context with T pool threads splits the call into T partitions
- * (src/piquant.cpp:145-157), each with its own head and tail: piquant_hip_set_reference_threads(ctx, T) reproduces those positions
- * (default 1; only read in reference-layout mode).
- * Costs nothing on aligned bulk data with T = 1 (only the guarded tail path looks at it); a non-zero head, or T > 1, sends the whole
- * call through the guarded (slower) kernels.  For golden-file regression against reference output, not production. */
+ * (src/piquant.cpp:145-157), each with its own head and tail: those positions are reproduced for T = the num_threads this context was
+ * created with (the reference context it stands for), or whatever piquant_hip_set_reference_threads(ctx, T) says (only read in
+ * reference-layout mode).  PIQUANT_HIP_REFERENCE_LAYOUT=1 in the environment at context creation turns the mode on without a code change:
+ * an unchanged binding then gets, byte for byte, what the CPU library's context of the same num_threads writes.
+ * Costs nothing on aligned bulk data with T = 1 (only the guarded tail path looks at it).  A non-zero head, or T > 1: the vector kernels
+ * run as always and a patch kernel behind them rewrites the partitions' heads and tails -- one more dependent launch, 26 against 23 us
+ * for fp32 -> uint8 at numel 27 264 000 with T = 255 (round 5; the element-by-element kernels took such calls whole until then: 213 us).
+ * Position-dependent output is what sharding must not have: leave the mode off on contexts that serve shard calls (piquant.distributed). */
 PIQUANT_EXPORT void piquant_hip_set_reference_layout(piquant_context_t* ctx, int enabled);
 PIQUANT_EXPORT void piquant_hip_set_reference_threads(piquant_context_t* ctx, int threads);
 

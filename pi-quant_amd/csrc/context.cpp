@@ -324,13 +324,15 @@ static void leave_stream(piquant_context_t* ctx, hipStream_t next) {
 extern "C" {
 
 piquant_context_t* piquant_context_create(size_t num_threads) {
-    (void)num_threads;   // sized the reference's CPU pool (src/piquant.cpp:178-181); the GPU grid replaces it
+    // num_threads sized the reference's CPU pool (src/piquant.cpp:178-181); the GPU grid replaces it.  It is remembered for one thing: in
+    // reference-layout mode the partitions of THAT pool are what decides where the reference's scalar heads and tails sit.
     int count = 0;
     const hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)
         panic("piquant_context_create: no HIP device available (%s) -- this library has no CPU path",
               e == hipSuccess ? "device count 0" : hipGetErrorString(e));
     auto* ctx = new piquant_context_t;
+    ctx->reference_threads = static_cast<int>(std::min<size_t>(std::max<size_t>(num_threads, 1), 65536));
     PQ_HIP(hipGetDevice(&ctx->device));
     PQ_HIP(hipDeviceGetAttribute(&ctx->num_cu, hipDeviceAttributeMultiprocessorCount, ctx->device));
     PQ_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
@@ -368,6 +370,8 @@ piquant_context_t* piquant_context_create(size_t num_threads) {
         else if (m == "stage") ctx->host_path = PIQUANT_HIP_HOST_PATH_STAGE;
         else if (m != "auto" && !m.empty()) panic("PIQUANT_HIP_HOST_PATH=%s: expected auto, stage or cpu", env);
     }
+    // PIQUANT_HIP_REFERENCE_LAYOUT=1: an unchanged binding gets, byte for byte, what the CPU library's context of the same num_threads writes
+    if (const char* env = std::getenv("PIQUANT_HIP_REFERENCE_LAYOUT")) ctx->reference_layout = env[0] == '1' && env[1] == '\0';
     if (const char* env = std::getenv("PIQUANT_HIP_FUSION")) ctx->fusion = !(env[0] == '0' && env[1] == '\0');
     if (const char* env = std::getenv("PIQUANT_HIP_BARRIER_TIMEOUT_US")) ctx->barrier_timeout_us = static_cast<uint32_t>(std::strtoul(env, nullptr, 10));
     std::random_device rd;

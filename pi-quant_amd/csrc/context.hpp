@@ -105,7 +105,8 @@ struct piquant_context_t {
     float fixed_threshold = -1.0f;
     bool per_element = false;
     bool reference_layout = false;
-    int reference_threads = 1;             // piquant_hip_set_reference_threads: pool threads of the reference context reproduced in reference-layout mode
+    int reference_threads = 1;             // pool threads of the reference context reproduced in reference-layout mode: num_threads of piquant_context_create
+                                           // until piquant_hip_set_reference_threads says otherwise
     uint64_t elem_seed = 0, elem_base = 0;
     std::mutex mu;
 

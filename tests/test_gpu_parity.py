@@ -1773,3 +1773,32 @@ def test_reference_layout_partitions_at_full_size(ctx, O):
         ctx.set_blocking_wait('kernel')
         ctx.set_blocking(False)
         ctx.set_reference_layout(False, threads=1)
+
+
+def test_reference_layout_from_the_environment_takes_the_contexts_own_thread_count(O):
+    """PIQUANT_HIP_REFERENCE_LAYOUT=1 at context creation: an UNCHANGED binding -- piquant_context_create(num_threads) and the six calls, nothing else --
+    gets byte for byte what the reference's context of the same num_threads writes (its partitions' scalar heads and tails, src/piquant.cpp:145-157)."""
+    code = textwrap.dedent(f"""
+        import sys, numpy as np
+        sys.path.insert(0, {str(os.path.join(os.path.dirname(__file__), '..', 'pi-quant_amd'))!r}); sys.path.insert(0, {str(os.path.join(os.path.dirname(__file__), '..'))!r})
+        import torch, oracle as O
+        from piquant._bootstrap import C_LIB as C
+        rng = np.random.default_rng(31)
+        n = 1_000_003
+        x = rng.uniform(-1.2, 1.2, n).astype(np.float32)
+        x[rng.choice(n, n // 3)] = np.float32(0.49999997)
+        x[rng.choice(n, n // 5)] = np.float32(8388609.0)
+        xd = torch.from_numpy(x).cuda()
+        for threads in (1, 5, 31):
+            ctx = C.piquant_context_create(threads)
+            out = torch.zeros(n, dtype=torch.uint8, device='cuda')
+            C.piquant_quantize(ctx, xd.data_ptr(), 0, out.data_ptr(), 4, n, 1.0, 1, 0)        # blocking, as the reference's calls are
+            wbuf = np.zeros(n + 32, dtype=np.uint8); base = (-wbuf.ctypes.data) % 16
+            want = O.quantize(x, O.F32, O.UINT8, 1.0, 1, form=O.FORM_REFERENCE, threads=threads, out=wbuf[base: base + n])
+            assert np.array_equal(out.cpu().numpy(), want), threads
+            assert not np.array_equal(want, O.quantize(x, O.F32, O.UINT8, 1.0, 1, form=O.FORM_UNIFORM))
+            C.piquant_context_destroy(ctx)
+        print('layout ok')
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, PIQUANT_HIP_REFERENCE_LAYOUT="1"))
+    assert r.returncode == 0 and "layout ok" in r.stdout, r.stderr[-2000:]
