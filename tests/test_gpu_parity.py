@@ -1802,3 +1802,46 @@ def test_reference_layout_from_the_environment_takes_the_contexts_own_thread_cou
     """)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, PIQUANT_HIP_REFERENCE_LAYOUT="1"))
     assert r.returncode == 0 and "layout ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_reference_layout_partitions_across_staged_host_chunks(ctx, O):
+    """A host call longer than one staging chunk (2^24 elements) in reference-layout mode for a 7- and a 100-thread reference context: every chunk is its
+    own vector launch + patch launch over a WINDOW of the call, and a partition's head or tail may sit in either chunk (or straddle the cut) -- the
+    patch kernels clip their ranges to the window (quantize_ref_patch_kernel, dequantize_ref_patch_kernel).  fp32 -> uint8 with a misaligned host
+    output (heads), bf16 -> uint4, uint4 -> bf16 ADD."""
+    import piquant
+
+    rng = np.random.default_rng(79)
+    n = (1 << 24) + (1 << 22) + 1000 + 37
+    x = rng.uniform(-1.2, 1.2, n).astype(np.float32)
+    x[rng.choice(n, n // 40)] = np.float32(0.49999997)
+    x[rng.choice(n, n // 50)] = np.float32(8388609.0)
+    xb = O.f32_to_bf16(x)
+    q4 = rng.integers(0, 256, O.packed_numel(n, O.UINT4), dtype=np.uint8)
+    prev = O.f32_to_bf16(rng.uniform(-3, 3, n).astype(np.float32))
+    try:
+        ctx.reset_stream()
+        ctx.set_blocking(True)
+        ctx.set_host_path("stage")
+        for threads in (7, 100):
+            ctx.set_reference_layout(True, threads=threads)
+            for off in (0, 3):
+                buf = np.zeros(n + 32, dtype=np.uint8)
+                base = (-buf.ctypes.data) % 16
+                out = buf[base + off: base + off + n]
+                ctx.quantize_ptr(x.ctypes.data, piquant.DataType.F32, out.ctypes.data, piquant.DataType.UINT8, n, 1.0, 0, piquant.RoundMode.NEAREST)
+                wbuf = np.zeros(n + 32, dtype=np.uint8)
+                wbase = (-wbuf.ctypes.data) % 16
+                want = O.quantize(x, O.F32, O.UINT8, 1.0, 0, form=O.FORM_REFERENCE, threads=threads, out=wbuf[wbase + off: wbase + off + n])
+                assert np.array_equal(out, want), (threads, off, np.nonzero(out != want)[0][:8])
+                assert not np.array_equal(want, O.quantize(x, O.F32, O.UINT8, 1.0, 0, form=O.FORM_UNIFORM))
+            out4 = np.zeros(O.packed_numel(n, O.UINT4), dtype=np.uint8)
+            ctx.quantize_ptr(xb.ctypes.data, piquant.DataType.BF16, out4.ctypes.data, piquant.DataType.UINT4, n, 0.2, 7, piquant.RoundMode.NEAREST)
+            assert np.array_equal(out4, O.quantize(xb, O.BF16, O.UINT4, 0.2, 7, form=O.FORM_REFERENCE, threads=threads)), threads
+            acc = prev.copy()
+            ctx.dequantize_ptr(q4.ctypes.data, piquant.DataType.UINT4, acc.ctypes.data, piquant.DataType.BF16, n, 0.3, 2, piquant.ReduceOp.ADD)
+            assert same_floats(acc, O.dequantize(q4, O.UINT4, O.BF16, n, 0.3, 2, 1, form=O.FORM_REFERENCE, threads=threads, out=prev.copy())), threads
+    finally:
+        ctx.set_host_path("auto")
+        ctx.set_reference_layout(False, threads=1)
+        ctx.set_blocking(False)
