@@ -563,6 +563,23 @@ def single_gpu(B):
         w, e = time_loop(lambda i: c_quantize(*reuse_args[i % nsets]), 600, stream)
         extras["cold_inputs_one_output_buffer"] = {"GiB/s": round(gib_per_step * 600 / w, 1), "avg_launch_us": round(e / 600 * 1e6, 3), "GB/s": gbs_plain(5, e, 600),
                                                    "note": f"inputs rotate over the {nsets} cold sets, every launch writes the same 27 MB output buffer"}
+        # reference-layout mode (opt-in byte identity with a CPU reference context): one partition costs nothing, 255 partitions
+        # (the reference's Python default on this host: cpu_count - 1) one small dependent launch that rewrites their scalar heads and tails
+        try:
+            layout = {}
+            for threads in (1, 255):
+                ctx.set_reference_layout(True, threads=threads)
+                for i in range(nsets):
+                    step(i)
+                w, e = time_loop(step, 300, stream)
+                layout[f"{threads}_reference_threads"] = {"us_per_call": round(e / 300 * 1e6, 3), "roofline_frac": round(5 * n / (e / 300) / 1e9 / 8000.0, 4)}
+            extras["reference_layout_mode"] = dict(layout, note="the headline's calls with piquant_hip_set_reference_layout on: the output equals, byte for byte, what the "
+                                                   "reference's AVX-512 context of that many pool threads writes (the headline itself runs in the default, position-independent "
+                                                   "mode -- what sharding needs); round 5: vector kernel + per-partition patch kernel (213 us per call for 255 threads before)")
+        except Exception as exc:
+            extras["reference_layout_mode"] = {"error": repr(exc)}
+        finally:
+            ctx.set_reference_layout(False, threads=1)
         # reference semantics: every call waits for completion (blocking context); A/B of the three ways to wait (csrc/context.cpp wait_stream)
         ctx.set_blocking(True)
         ctx.assume_device_pointers(True)      # step() makes the raw C call: the context must know these are device pointers
