@@ -49,6 +49,15 @@ PIQUANT_CPU_EXPORT void piquant_cpu_quantize(piquant_cpu_context_t* ctx, const v
                                              int64_t zero_point, int round_mode, float threshold);
 PIQUANT_CPU_EXPORT void piquant_cpu_dequantize(piquant_cpu_context_t* ctx, const void* in, int dtype_in, void* out, int dtype_out, size_t numel, float scale,
                                                int64_t zero_point, int reduce_op);
+/* Reference-layout mode for host buffers (include/piquant_hip.h, piquant_hip_set_reference_layout): the same calls, and then the scalar heads and
+ * tails of the partitions of a reference context with `threads` pool threads (src/piquant.cpp:145-157) are rewritten with the reference's scalar
+ * formulas (std::round in the nearest fast paths' heads and tails; (q - zp) * scale and a second rounding for ADD in the bf16 tails; the uint2 ->
+ * fp32 ADD tail that stores): every output byte equals what the reference's AVX-512 context of that many threads writes.  Position-dependent by
+ * design; the plain calls above are not. */
+PIQUANT_CPU_EXPORT void piquant_cpu_quantize_reference_layout(piquant_cpu_context_t* ctx, const void* in, int dtype_in, void* out, int dtype_out, size_t numel,
+                                                              float scale, int64_t zero_point, int round_mode, float threshold, size_t threads);
+PIQUANT_CPU_EXPORT void piquant_cpu_dequantize_reference_layout(piquant_cpu_context_t* ctx, const void* in, int dtype_in, void* out, int dtype_out, size_t numel,
+                                                                float scale, int64_t zero_point, int reduce_op, size_t threads);
 /* min / max of x as fp32, NaNs ignored, identities +-FLT_MAX. */
 PIQUANT_CPU_EXPORT void piquant_cpu_minmax(piquant_cpu_context_t* ctx, const void* x, int dtype, size_t numel, float* out_min, float* out_max);
 PIQUANT_CPU_EXPORT void piquant_cpu_compute_quant_params(piquant_cpu_context_t* ctx, const void* x, int dtype, size_t numel, int target_quant_dtype,

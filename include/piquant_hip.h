@@ -46,7 +46,8 @@ PIQUANT_EXPORT void piquant_hip_set_blocking_wait(piquant_context_t* ctx, int mo
  *   PIQUANT_HIP_HOST_PATH_CPU (1): always libpiquant_cpu.so (include/piquant_cpu.h; loaded from the directory of this library on first
  *       use, ABORT if it is missing; its scalar form on hosts without AVX-512).
  * Only calls whose input AND output are pageable host memory go to the companion; device, pinned and managed pointers always run the HIP
- * kernels, and so do reference-layout mode and the per-element stochastic extension, which the companion does not implement (staged).
+ * kernels, and so does the per-element stochastic extension, which the companion does not implement (staged).  Reference-layout mode on host
+ * buffers is the companion's too since round 5 (piquant_cpu_*_reference_layout: the head of a partition placed by the CALLER's output pointer).
  * The environment variable PIQUANT_HIP_HOST_PATH = auto | stage | cpu sets it at context creation. */
 #define PIQUANT_HIP_HOST_PATH_STAGE 0
 #define PIQUANT_HIP_HOST_PATH_CPU 1

@@ -104,9 +104,14 @@ static void quantize_impl(piquant_context_t* ctx, const void* in, piquant_dtype_
         if (ctx->blocking) wait_stream(ctx);
         return;
     }
-    if (rin.pageable && rout.pageable && !q.ref_layout && q.round_mode != RM_STOCH_ELEM && host_calls_go_to_cpu(ctx)) {
+    if (rin.pageable && rout.pageable && q.round_mode != RM_STOCH_ELEM && host_calls_go_to_cpu(ctx) && (!q.ref_layout || cpu_companion().quantize_reference_layout)) {
         // host tensors stay on the host, as in the reference (the default when the companion is there; the threshold drawn above is the call's)
-        cpu_companion().quantize(cpu_context_of(ctx), in, dtype_in, out, dtype_out, numel, scale, zero_point, mode == PIQUANT_STOCHASTIC ? 1 : 0, q.threshold);
+        const int stochastic = mode == PIQUANT_STOCHASTIC ? 1 : 0;
+        if (q.ref_layout)   // the partitions' scalar heads and tails as the reference places them: the head by the caller's output pointer
+            cpu_companion().quantize_reference_layout(cpu_context_of(ctx), in, dtype_in, out, dtype_out, numel, scale, zero_point, stochastic, q.threshold,
+                                                      static_cast<size_t>(q.ref_threads > 1 ? q.ref_threads : 1));
+        else
+            cpu_companion().quantize(cpu_context_of(ctx), in, dtype_in, out, dtype_out, numel, scale, zero_point, stochastic, q.threshold);
         return;
     }
 
@@ -191,8 +196,12 @@ static void dequantize_impl(piquant_context_t* ctx, const void* in, piquant_dtyp
         if (ctx->blocking) wait_stream(ctx);
         return;
     }
-    if (rin.pageable && rout.pageable && !d.ref_layout && host_calls_go_to_cpu(ctx)) {
-        cpu_companion().dequantize(cpu_context_of(ctx), in, dtype_in, out, dtype_out, numel, scale, zero_point, d.op == OP_ADD ? 1 : 0);
+    if (rin.pageable && rout.pageable && host_calls_go_to_cpu(ctx) && (!d.ref_layout || cpu_companion().dequantize_reference_layout)) {
+        if (d.ref_layout)
+            cpu_companion().dequantize_reference_layout(cpu_context_of(ctx), in, dtype_in, out, dtype_out, numel, scale, zero_point, d.op == OP_ADD ? 1 : 0,
+                                                        static_cast<size_t>(d.ref_threads > 1 ? d.ref_threads : 1));
+        else
+            cpu_companion().dequantize(cpu_context_of(ctx), in, dtype_in, out, dtype_out, numel, scale, zero_point, d.op == OP_ADD ? 1 : 0);
         return;
     }
 

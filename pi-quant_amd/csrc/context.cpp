@@ -234,6 +234,8 @@ const CompanionSlot& companion_slot() {
         r.c.dequantize = reinterpret_cast<decltype(r.c.dequantize)>(sym("piquant_cpu_dequantize"));
         r.c.minmax = reinterpret_cast<decltype(r.c.minmax)>(sym("piquant_cpu_minmax"));
         r.c.has_avx512 = reinterpret_cast<decltype(r.c.has_avx512)>(sym("piquant_cpu_has_avx512"));
+        r.c.quantize_reference_layout = reinterpret_cast<decltype(r.c.quantize_reference_layout)>(dlsym(h, "piquant_cpu_quantize_reference_layout"));   // optional
+        r.c.dequantize_reference_layout = reinterpret_cast<decltype(r.c.dequantize_reference_layout)>(dlsym(h, "piquant_cpu_dequantize_reference_layout"));
         r.ok = complete;
         return r;
     }();

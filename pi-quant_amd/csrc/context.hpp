@@ -217,6 +217,9 @@ struct CpuCompanion {
     void (*dequantize)(void*, const void*, int, void*, int, size_t, float, int64_t, int);
     void (*minmax)(void*, const void*, int, size_t, float*, float*);
     int (*has_avx512)();
+    // reference-layout mode on host buffers; nullptr in a companion built before round 5 (such calls are then staged through the HIP kernels)
+    void (*quantize_reference_layout)(void*, const void*, int, void*, int, size_t, float, int64_t, int, float, size_t);
+    void (*dequantize_reference_layout)(void*, const void*, int, void*, int, size_t, float, int64_t, int, size_t);
 };
 const CpuCompanion& cpu_companion();
 const CpuCompanion* try_cpu_companion();        // nullptr when libpiquant_cpu.so does not load (AUTO then stages); never aborts

@@ -26,7 +26,7 @@ struct QuantArgs {
     bool stream;       // non-temporal stores: decided ONCE per call from the whole call's output size (piquant_cpu.cpp), not per 64 Ki-element chunk
 };
 
-enum : int { STEP_FAST = 0, STEP_I64 = 1, STEP_STOCH = 2 };
+enum : int { STEP_FAST = 0, STEP_I64 = 1, STEP_STOCH = 2, STEP_TAIL32 = 3 };   // TAIL32: the scalar head / tail of the reference's nearest fast paths (reference-layout mode only)
 
 struct DequantArgs {
     float scale;
@@ -108,6 +108,15 @@ inline uint32_t quant_nearest_i64(float x, const QuantArgs& a) {
     return static_cast<uint32_t>(std::min<int64_t>(std::max<int64_t>(q, 0), QMAX));
 }
 
+// The scalar head / tail step of the reference's nearest fast paths (kernels_specialized.inl:52-56, 178-182, 468-472, 711-716): std::round, then
+// int32 arithmetic.  Only reference-layout mode applies it, at the positions where the reference does.
+template <int QMAX>
+inline uint32_t quant_nearest_tail32(float x, const QuantArgs& a) {
+    const float r = std::round(x * a.inv_scale);
+    const int32_t q = static_cast<int32_t>(static_cast<uint32_t>(cvtt32(r)) + static_cast<uint32_t>(a.zp32));
+    return static_cast<uint32_t>(std::min(std::max(q, 0), QMAX));
+}
+
 // quantize.inl:8-19
 template <int QMAX>
 inline uint32_t quant_stochastic(float x, const QuantArgs& a) {
@@ -130,7 +139,8 @@ void quantize_scalar(const void* in, uint8_t* out, size_t e0, size_t e1, const Q
             const size_t i = b * PACK + k;
             if (i >= e1) break;
             const float x = load_float<DT_IN>(in, i);
-            const uint32_t q = STEP == STEP_FAST ? quant_nearest_fast<QMAX>(x, a) : (STEP == STEP_I64 ? quant_nearest_i64<QMAX>(x, a) : quant_stochastic<QMAX>(x, a));
+            const uint32_t q = STEP == STEP_FAST ? quant_nearest_fast<QMAX>(x, a)
+                               : (STEP == STEP_I64 ? quant_nearest_i64<QMAX>(x, a) : (STEP == STEP_TAIL32 ? quant_nearest_tail32<QMAX>(x, a) : quant_stochastic<QMAX>(x, a)));
             acc |= q << (k * BITS);
         }
         out[b] = static_cast<uint8_t>(acc);
@@ -157,6 +167,25 @@ void dequantize_scalar(const uint8_t* in, void* out, size_t e0, size_t e1, const
             uint16_t* o = static_cast<uint16_t*>(out);
             if (ADD) f = f + bf16_to_f32(o[i]);
             o[i] = f32_to_bf16(f);
+        }
+    }
+}
+
+// Reference-layout mode: elements [e0, e1) lie in a scalar tail of the reference's dequantize kernels.  bf16 outputs: (q - zp) * scale rounded to
+// bf16, ADD through bfp16_t::operator+= -- a second rounding (kernels_specialized.inl:977-981, 1290-1303, 1388-1415; include/piquant.hpp:97-103);
+// uint2 -> fp32: the generic tail STORES whatever the reduce op (dequantize.inl:72-86).  `old`: the accumulator's values of [e0, e1) from BEFORE
+// the uniform pass touched them (ADD only).
+template <int BITS, int DT_OUT, bool ADD>
+void dequantize_reference_tail(const uint8_t* in, void* out, size_t e0, size_t e1, const DequantArgs& a, const void* old) {
+    constexpr int PACK = 8 / BITS;
+    for (size_t i = e0; i < e1; ++i) {
+        const uint32_t q = (in[i / PACK] >> ((i % PACK) * BITS)) & ((1u << BITS) - 1u);
+        if (DT_OUT == DT_F32) {
+            static_cast<float*>(out)[i] = dequant_one<dequant_form<BITS, DT_OUT>()>(q, a);
+        } else {
+            const float dq = BITS == 2 ? (static_cast<float>(q) - static_cast<float>(a.zp32)) * a.scale : dequant_one<DQ_SUBMUL>(q, a);
+            const uint16_t d16 = f32_to_bf16(dq);
+            static_cast<uint16_t*>(out)[i] = ADD ? f32_to_bf16(bf16_to_f32(static_cast<const uint16_t*>(old)[i - e0]) + bf16_to_f32(d16)) : d16;
         }
     }
 }

@@ -331,6 +331,86 @@ void piquant_cpu_dequantize(piquant_cpu_context_t* ctx, const void* in, int dtyp
     parallel_chunks(ctx, numel, pack, [&](size_t b, size_t e, size_t) { fn(static_cast<const uint8_t*>(in), out, b, e, a); });
 }
 
+// Reference-layout mode (include/piquant_hip.h, piquant_hip_set_reference_layout) for host buffers: the output equals, byte for byte, what the
+// reference's AVX-512 context of `threads` pool threads writes.  The uniform pass above runs as always; then the scalar heads (fp32 -> uint8
+// nearest: until the partition's output is 16-byte aligned) and tails (the elements behind the partition's last whole SIMD block) of the
+// reference's partitions (src/piquant.cpp:145-157) -- a few dozen elements each -- are rewritten with the reference's scalar formulas on the
+// calling thread.  Only the nearest fast paths have a scalar form of their own; every other step is one formula at every position.
+void piquant_cpu_quantize_reference_layout(piquant_cpu_context_t* ctx, const void* in, int dtype_in, void* out, int dtype_out, size_t numel, float scale,
+                                           int64_t zero_point, int round_mode, float threshold, size_t threads) {
+    piquant_cpu_quantize(ctx, in, dtype_in, out, dtype_out, numel, scale, zero_point, round_mode, threshold);
+    if (numel == 0 || round_mode != 0 || (dtype_in == DT_F32 && dtype_out == DT_UINT2)) return;
+    QuantArgs a {};
+    a.inv_scale = 1.0f / scale;
+    a.zp64 = zero_point;
+    a.zp32 = static_cast<int32_t>(static_cast<uint32_t>(static_cast<uint64_t>(zero_point)));
+    const int bits = bits_of(dtype_out);
+    const size_t pack = 8 / bits, blk = bits == 8 ? 64 : 16, T = std::max<size_t>(threads, 1);
+    const bool has_head = dtype_in == DT_F32 && dtype_out == DT_UINT8;      // kernels_specialized.inl:52
+    QuantFn tail = nullptr;
+    if (dtype_in == DT_F32) tail = bits == 8 ? quantize_scalar<DT_F32, 8, STEP_TAIL32> : quantize_scalar<DT_F32, 4, STEP_TAIL32>;
+    else tail = bits == 8 ? quantize_scalar<DT_BF16, 8, STEP_TAIL32> : (bits == 4 ? quantize_scalar<DT_BF16, 4, STEP_TAIL32> : quantize_scalar<DT_BF16, 2, STEP_TAIL32>);
+    std::lock_guard<std::mutex> lk(ctx->call);
+    for (size_t t = 0; t < T; ++t) {
+        size_t b, e;
+        part_of(numel, t, T, pack, b, e);
+        const size_t len = e - b;
+        size_t head = has_head ? (16 - ((reinterpret_cast<uintptr_t>(out) + b) & 15)) & 15 : 0;
+        head = std::min(head, len);
+        const size_t body = ((len - head) / blk) * blk;
+        if (head) tail(in, static_cast<uint8_t*>(out), b, b + head, a);
+        if (b + head + body < e) tail(in, static_cast<uint8_t*>(out), b + head + body, e, a);
+    }
+}
+
+void piquant_cpu_dequantize_reference_layout(piquant_cpu_context_t* ctx, const void* in, int dtype_in, void* out, int dtype_out, size_t numel, float scale,
+                                             int64_t zero_point, int reduce_op, size_t threads) {
+    if (!is_quant(dtype_in) || !is_float(dtype_out) || (reduce_op != 0 && reduce_op != 1)) {
+        piquant_cpu_dequantize(ctx, in, dtype_in, out, dtype_out, numel, scale, zero_point, reduce_op);   // aborts with the usual message
+        return;
+    }
+    const int bits = bits_of(dtype_in);
+    const bool add = reduce_op == 1;
+    // tails with a form of their own: every bf16 output, and uint2 -> fp32 ADD (whose tail stores)
+    const bool own_tail = dtype_out == DT_BF16 || (bits == 2 && add);
+    if (numel == 0 || !own_tail) {
+        piquant_cpu_dequantize(ctx, in, dtype_in, out, dtype_out, numel, scale, zero_point, reduce_op);
+        return;
+    }
+    if (!in || !out) panic("piquant_cpu_dequantize: null buffer");
+    const size_t pack = 8 / bits, esize = float_size(dtype_out), T = std::max<size_t>(threads, 1);
+    const size_t blk = bits == 8 ? 64 : (bits == 4 ? 128 : (dtype_out == DT_BF16 ? 256 : 4));
+    std::vector<std::pair<size_t, size_t>> tails;
+    for (size_t t = 0; t < T; ++t) {
+        size_t b, e;
+        part_of(numel, t, T, pack, b, e);
+        const size_t t0 = b + ((e - b) / blk) * blk;
+        if (t0 < e) tails.emplace_back(t0, e);
+    }
+    // ADD: the tails' old values, before the uniform pass adds to them
+    std::vector<uint8_t> old;
+    if (add) {
+        old.resize(tails.size() * 256 * esize);
+        for (size_t k = 0; k < tails.size(); ++k)
+            std::memcpy(old.data() + k * 256 * esize, static_cast<const uint8_t*>(out) + tails[k].first * esize, (tails[k].second - tails[k].first) * esize);
+    }
+    piquant_cpu_dequantize(ctx, in, dtype_in, out, dtype_out, numel, scale, zero_point, reduce_op);
+    DequantArgs a {};
+    a.scale = scale;
+    a.zp64 = zero_point;
+    a.zp32 = static_cast<int32_t>(static_cast<uint32_t>(static_cast<uint64_t>(zero_point)));
+    a.bias = -static_cast<float>(a.zp32) * scale;
+    using TailFn = void (*)(const uint8_t*, void*, size_t, size_t, const DequantArgs&, const void*);
+    TailFn fn;
+    if (dtype_out == DT_F32) fn = dequantize_reference_tail<2, DT_F32, true>;
+    else if (bits == 8) fn = add ? dequantize_reference_tail<8, DT_BF16, true> : dequantize_reference_tail<8, DT_BF16, false>;
+    else if (bits == 4) fn = add ? dequantize_reference_tail<4, DT_BF16, true> : dequantize_reference_tail<4, DT_BF16, false>;
+    else fn = add ? dequantize_reference_tail<2, DT_BF16, true> : dequantize_reference_tail<2, DT_BF16, false>;
+    std::lock_guard<std::mutex> lk(ctx->call);
+    for (size_t k = 0; k < tails.size(); ++k)
+        fn(static_cast<const uint8_t*>(in), out, tails[k].first, tails[k].second, a, add ? old.data() + k * 256 * esize : nullptr);
+}
+
 void piquant_cpu_minmax(piquant_cpu_context_t* ctx, const void* x, int dtype, size_t numel, float* out_min, float* out_max) {
     if (!is_float(dtype)) panic("min/max scan needs a float dtype, got %d", dtype);
     float lo = FLT_MAX, hi = -FLT_MAX;                             // kernels_specialized.inl:1422-1423

@@ -30,6 +30,9 @@ def lib() -> C.CDLL:
         L.piquant_cpu_use_avx512.argtypes = [C.c_int]
         L.piquant_cpu_quantize.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.c_int64, C.c_int, C.c_float]
         L.piquant_cpu_dequantize.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.c_int64, C.c_int]
+        L.piquant_cpu_quantize_reference_layout.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.c_int64, C.c_int, C.c_float,
+                                                            C.c_size_t]
+        L.piquant_cpu_dequantize_reference_layout.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.c_int64, C.c_int, C.c_size_t]
         L.piquant_cpu_minmax.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.piquant_cpu_compute_quant_params.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int64)]
         L.piquant_cpu_partition_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]
@@ -68,11 +71,19 @@ class CpuContext:
         self._lib.piquant_cpu_set_affinity(self._ctx, arr, len(cpus))
 
     def quantize_ptr(self, ptr_in: int, dt_in: int, ptr_out: int, dt_out: int, numel: int, scale: float, zero_point: int, round_mode: int = 0,
-                     threshold: float = 0.0) -> None:
-        self._lib.piquant_cpu_quantize(self._ctx, ptr_in, dt_in, ptr_out, dt_out, numel, scale, zero_point, round_mode, threshold)
+                     threshold: float = 0.0, reference_threads: int = 0) -> None:
+        """reference_threads > 0: reference-layout mode -- the bytes of the reference's AVX-512 context of that many pool threads (include/piquant_cpu.h)"""
+        if reference_threads > 0:
+            self._lib.piquant_cpu_quantize_reference_layout(self._ctx, ptr_in, dt_in, ptr_out, dt_out, numel, scale, zero_point, round_mode, threshold, reference_threads)
+        else:
+            self._lib.piquant_cpu_quantize(self._ctx, ptr_in, dt_in, ptr_out, dt_out, numel, scale, zero_point, round_mode, threshold)
 
-    def dequantize_ptr(self, ptr_in: int, dt_in: int, ptr_out: int, dt_out: int, numel: int, scale: float, zero_point: int, reduce_op: int = 0) -> None:
-        self._lib.piquant_cpu_dequantize(self._ctx, ptr_in, dt_in, ptr_out, dt_out, numel, scale, zero_point, reduce_op)
+    def dequantize_ptr(self, ptr_in: int, dt_in: int, ptr_out: int, dt_out: int, numel: int, scale: float, zero_point: int, reduce_op: int = 0,
+                       reference_threads: int = 0) -> None:
+        if reference_threads > 0:
+            self._lib.piquant_cpu_dequantize_reference_layout(self._ctx, ptr_in, dt_in, ptr_out, dt_out, numel, scale, zero_point, reduce_op, reference_threads)
+        else:
+            self._lib.piquant_cpu_dequantize(self._ctx, ptr_in, dt_in, ptr_out, dt_out, numel, scale, zero_point, reduce_op)
 
     def minmax_ptr(self, ptr: int, dt: int, numel: int) -> Tuple[float, float]:
         lo, hi = C.c_float(), C.c_float()

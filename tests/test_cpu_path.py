@@ -192,3 +192,55 @@ def test_degenerate_scales_equal_the_oracle(O, cpu, vector):
         ctx.close()
     finally:
         cpu.use_avx512(True)
+
+
+@pytest.mark.parametrize("vector", [True, False], ids=["avx512", "scalar"])
+def test_reference_layout_equals_the_oracles_reference_form_and_the_reference_kernels(O, cpu, vector):
+    """piquant_cpu_*_reference_layout: the bytes of a reference context of T pool threads -- its partitions' scalar heads (fp32 -> uint8: from the
+    OUTPUT pointer's alignment) and tails take the reference's scalar formulas.  Against the oracle's threaded reference form on data salted with
+    the values on which the formulas differ, every pair / mode / op, pool sizes that differ from T; and, where oracle/_ref is built, against the
+    reference's own kernels run per partition."""
+    if vector and not cpu.use_avx512(True):
+        pytest.skip("host without AVX-512")
+    cpu.use_avx512(vector)
+    rng = np.random.default_rng(13)
+    R = O.Ref() if O.ref_available() else None
+    try:
+        for pool, threads in ((1, 1), (3, 1), (2, 3), (3, 7), (4, 64)):
+            ctx = cpu.CpuContext(pool)
+            for n in (1, 5, 64, 1000, 4099, 70_001):
+                x = rng.uniform(-1.2, 1.2, n).astype(np.float32)
+                x[rng.choice(n, max(1, n // 3))] = np.float32(0.49999997)
+                x[rng.choice(n, max(1, n // 5))] = np.float32(-0.49999997)
+                x[rng.choice(n, max(1, n // 7))] = np.float32(8388609.0)
+                differs = 0
+                for dt_in, xin in ((O.F32, x), (O.BF16, O.f32_to_bf16(x))):
+                    for dt_out in (O.UINT8, O.UINT4, O.UINT2):
+                        for rm, tau in ((0, 0.0), (1, 0.37)):
+                            for off in ((0, 5) if (dt_in, dt_out) == (O.F32, O.UINT8) else (0,)):
+                                nbytes = O.packed_numel(n, dt_out)
+                                buf, wbuf = np.full(nbytes + 48, 0xAA, dtype=np.uint8), np.zeros(nbytes + 48, dtype=np.uint8)
+                                base, wbase = (-buf.ctypes.data) % 16, (-wbuf.ctypes.data) % 16
+                                out = buf[base + off: base + off + nbytes]
+                                ctx.quantize_ptr(xin.ctypes.data, dt_in, out.ctypes.data, dt_out, n, 1.0, 1, rm, tau, reference_threads=threads)
+                                want = O.quantize(xin, dt_in, dt_out, 1.0, 1, rm, tau, form=O.FORM_REFERENCE, threads=threads, out=wbuf[wbase + off: wbase + off + nbytes])
+                                assert np.array_equal(out, want), (pool, threads, n, dt_in, dt_out, rm, off, np.nonzero(out != want)[0][:5])
+                                assert (buf[:base + off] == 0xAA).all() and (buf[base + off + nbytes:] == 0xAA).all()
+                                differs += int(not np.array_equal(want, O.quantize(xin, dt_in, dt_out, 1.0, 1, rm, tau)))
+                                if R is not None and vector and off == 0 and n >= 64:
+                                    assert np.array_equal(out, R.quantize(xin, dt_in, dt_out, 1.0, 1, rm, tau, isa=O.Ref.AVX512F, threads=threads)), (threads, n, dt_in, dt_out, rm)
+                if n >= 1000:
+                    assert differs > 0, "the salt never met a scalar position"
+                for dt_q in (O.UINT8, O.UINT4, O.UINT2):
+                    q = rng.integers(0, 256, O.packed_numel(n, dt_q), dtype=np.uint8)
+                    for dt_f in (O.F32, O.BF16):
+                        prev = rng.uniform(-3, 3, n).astype(np.float32)
+                        prev = prev if dt_f == O.F32 else O.f32_to_bf16(prev)
+                        for op in (0, 1):
+                            out = prev.copy()
+                            ctx.dequantize_ptr(q.ctypes.data, dt_q, out.ctypes.data, dt_f, n, 0.3, 2, op, reference_threads=threads)
+                            want = O.dequantize(q, dt_q, dt_f, n, 0.3, 2, op, form=O.FORM_REFERENCE, threads=threads, out=prev.copy())
+                            assert _same_floats(out, want), (pool, threads, n, dt_q, dt_f, op)
+            ctx.close()
+    finally:
+        cpu.use_avx512(True)

@@ -1188,12 +1188,13 @@ def test_reference_layout_head_and_host_chunks(ctx, O):
         x = rng.uniform(-1.2, 1.2, n).astype(np.float32)
         x[-37:] = np.float32(0.49999997)
         x[:20] = np.float32(0.49999997)
-        for off in (0, 3):
+        for off, path in ((0, "stage"), (3, "stage"), (0, "auto"), (3, "auto")):      # auto: the companion library serves reference-layout mode too (round 5)
             buf = np.zeros(n + 32, dtype=np.uint8)
             base = (-buf.ctypes.data) % 16
             out = buf[base + off: base + off + n]
             ctx.reset_stream()
             ctx.set_blocking(True)
+            ctx.set_host_path(path)
             ctx.quantize_ptr(x.ctypes.data, piquant.DataType.F32, out.ctypes.data, piquant.DataType.UINT8, n, 1.0, 0, piquant.RoundMode.NEAREST)
             wbuf = np.zeros(n + 32, dtype=np.uint8)
             wbase = (-wbuf.ctypes.data) % 16
@@ -1204,6 +1205,7 @@ def test_reference_layout_head_and_host_chunks(ctx, O):
             else:
                 assert out[0] == 0 and out[-1] == 1     # head of 13 scalar elements, and (n - 13) % 64 == 0: no tail
     finally:
+        ctx.set_host_path("auto")
         ctx.set_reference_layout(False)
     # with the mode off every position rounds it up, like the SIMD body
     got = gpu_quantize(ctx, np.full(37, 0.49999997, dtype=np.float32), O.F32, O.UINT8, 1.0, 0)
@@ -1797,6 +1799,19 @@ def test_reference_layout_from_the_environment_takes_the_contexts_own_thread_cou
             want = O.quantize(x, O.F32, O.UINT8, 1.0, 1, form=O.FORM_REFERENCE, threads=threads, out=wbuf[base: base + n])
             assert np.array_equal(out.cpu().numpy(), want), threads
             assert not np.array_equal(want, O.quantize(x, O.F32, O.UINT8, 1.0, 1, form=O.FORM_UNIFORM))
+            # host tensors, the reference's own calling convention: served by the companion library (or staged), same bytes; the head by the HOST pointer
+            hbuf = np.zeros(n + 32, dtype=np.uint8); hb = (-hbuf.ctypes.data) % 16
+            for off in (0, 7):
+                hout = hbuf[hb + off: hb + off + n]
+                C.piquant_quantize(ctx, x.ctypes.data, 0, hout.ctypes.data, 4, n, 1.0, 1, 0)
+                want = O.quantize(x, O.F32, O.UINT8, 1.0, 1, form=O.FORM_REFERENCE, threads=threads, out=wbuf[base + off: base + off + n])
+                assert np.array_equal(hout, want), (threads, off)
+            xb = O.f32_to_bf16(x); h4 = np.zeros((n + 1) // 2, dtype=np.uint8)
+            C.piquant_quantize(ctx, xb.ctypes.data, 1, h4.ctypes.data, 3, n, 0.2, 7, 0)
+            assert np.array_equal(h4, O.quantize(xb, O.BF16, O.UINT4, 0.2, 7, form=O.FORM_REFERENCE, threads=threads)), threads
+            acc = O.f32_to_bf16(rng.uniform(-3, 3, n).astype(np.float32)); want = O.dequantize(h4, O.UINT4, O.BF16, n, 0.3, 2, 1, form=O.FORM_REFERENCE, threads=threads, out=acc.copy())
+            C.piquant_dequantize(ctx, h4.ctypes.data, 3, acc.ctypes.data, 1, n, 0.3, 2, 1)
+            assert np.array_equal(acc, want), threads
             C.piquant_context_destroy(ctx)
         print('layout ok')
     """)
