@@ -1860,3 +1860,56 @@ def test_reference_layout_partitions_across_staged_host_chunks(ctx, O):
         ctx.set_host_path("auto")
         ctx.set_reference_layout(False, threads=1)
         ctx.set_blocking(False)
+
+
+def test_reference_layout_partitions_inside_a_hip_graph(O):
+    """Reference-layout mode for a 5-thread reference context captured into a hipGraph: quantize is two kernel nodes (vector + patch), dequantize SET to bf16
+    likewise, and dequantize ADD to bf16 -- whose fast flow takes stream-ordered scratch memory -- falls back to the element-by-element kernel inside a
+    capture.  Replayed on new data: the oracle's threaded reference form every time."""
+    import piquant
+    import torch
+
+    n, threads = 1_000_003, 5
+    x = torch.zeros(n, device="cuda")
+    q = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    q4 = torch.zeros((n + 1) // 2, dtype=torch.uint8, device="cuda")
+    y = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
+    acc = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
+    c = piquant.Context()
+    c.set_reference_layout(True, threads=threads)
+    s = torch.cuda.Stream()
+    c.set_stream(s.cuda_stream)
+    c.set_blocking(False)
+    F32, BF16, U8, U4 = piquant.DataType.F32, piquant.DataType.BF16, piquant.DataType.UINT8, piquant.DataType.UINT4
+
+    def calls():
+        c.quantize_ptr(x.data_ptr(), F32, q.data_ptr(), U8, n, 1.0, 1, piquant.RoundMode.NEAREST, _device_ptrs=True)
+        c.dequantize_ptr(q4.data_ptr(), U4, y.data_ptr(), BF16, n, 0.3, 2, piquant.ReduceOp.SET, _device_ptrs=True)
+        c.dequantize_ptr(q4.data_ptr(), U4, acc.data_ptr(), BF16, n, 0.3, 2, piquant.ReduceOp.ADD, _device_ptrs=True)
+
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        calls()                                   # warm-up outside capture (also: the ADD flow's memory pool exists)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            calls()
+    rng = np.random.default_rng(14)
+    for _ in range(3):
+        data = rng.uniform(-1.2, 1.2, n).astype(np.float32)
+        data[rng.choice(n, n // 3)] = np.float32(0.49999997)
+        packed = rng.integers(0, 256, (n + 1) // 2, dtype=np.uint8)
+        prev = O.f32_to_bf16(rng.uniform(-3, 3, n).astype(np.float32))
+        x.copy_(torch.from_numpy(data))
+        q4.copy_(torch.from_numpy(packed))
+        acc.copy_(torch.from_numpy(prev.view(np.int16)).view(torch.bfloat16))
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        wbuf = np.zeros(n + 32, dtype=np.uint8)
+        base = (-wbuf.ctypes.data) % 16
+        want = O.quantize(data, O.F32, O.UINT8, 1.0, 1, form=O.FORM_REFERENCE, threads=threads, out=wbuf[base: base + n])
+        assert np.array_equal(q.cpu().numpy(), want)
+        assert not np.array_equal(want, O.quantize(data, O.F32, O.UINT8, 1.0, 1))
+        assert same_floats(y.view(torch.int16).cpu().numpy().view(np.uint16), O.dequantize(packed, O.UINT4, O.BF16, n, 0.3, 2, 0, form=O.FORM_REFERENCE, threads=threads))
+        assert same_floats(acc.view(torch.int16).cpu().numpy().view(np.uint16),
+                           O.dequantize(packed, O.UINT4, O.BF16, n, 0.3, 2, 1, form=O.FORM_REFERENCE, threads=threads, out=prev.copy()))
