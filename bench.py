@@ -11,8 +11,10 @@ every N: the 256 MiB Infinity Cache holds none of it, outputs included), so the 
 
 This file: the timed region, `roofline`, the self-check against the checker, `cpu_baseline` (tools/bench_cpu_baseline.py, rank 0 at N = 1).
 Everything else -- graph replay, the other operators, configs 3-5, all-reduce schedules, weak scaling -- is tools/bench_extras.py, imported only
-when extras are on (the default) and unable to cost the line: for N > 1 a watchdog prints the headline with whatever has finished, and the
-peer-to-peer child job starts only AFTER the line is out.  `--no-extras` prints the bare headline in a few seconds.
+when extras are on and unable to cost the line.  N = 1: on by default.  N > 1 (round 6): the default is the line, its N = 1 reference point and
+config 5 (the one path with a collective) -- nothing that has never run between two GPUs stands near the first scaling run; `--extras` adds the
+rest (a watchdog prints the headline with whatever has finished, and the peer-to-peer child job starts only AFTER the line is out).
+`--no-extras` prints the bare headline in a few seconds.
 
 Launch: python bench.py [--gpus N]     (N > 1 without a launcher environment: bench.py starts its own N ranks through torch.distributed.run)
         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
@@ -53,6 +55,9 @@ def parse():
     ap.add_argument("--sets", type=int, default=24, help="distinct buffer sets rotated through at N=1 (24 x 136 MB = 3.3 GB); N>1 keeps the same bytes per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="the bare contract line: no side measurements, no CPU baseline")
+    ap.add_argument("--extras", action="store_true", default=os.environ.get("PIQUANT_BENCH_EXTRAS") == "1",
+                    help="N > 1: ALL side measurements (all-reduce schedules, hipGraph replay, weak scaling, the peer-to-peer child job); the default for N > 1 is the "
+                         "contract line, its N = 1 reference point and config 5 (sharded compute_quant_params with its 8-byte RCCL all-reduce) only")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline time budget")
     # test plumbing: the N > 1 control flow on a box with ONE GPU (all ranks on cuda:0, gloo instead of RCCL, which refuses two ranks on one device)
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)
@@ -186,7 +191,9 @@ def main():
     # host time per call instead of the 4.7 us of Context.quantize_ptr (enum lookups, asserts), which matters at N = 8, where a shard is a
     # 4.9 us kernel (profiles/r02_host_call_cost.json).  The context is stream-ordered, non-blocking and in device-pointer mode.
     ctx.assume_device_pointers(True)
-    c_quantize = C_LIB.piquant_quantize
+    # N = 1: the plain piquant_quantize -- its bytes are those of the reference context `ctx` stands for (cpu_count - 1 pool threads, the reference's
+    # Python default).  N > 1: a rank's call covers a SHARD of the tensor, and ranks are not pool threads: the position-independent twin.
+    c_quantize = C_LIB.piquant_quantize if world == 1 else C_LIB.piquant_hip_quantize_uniform
     call_args = [(ctx._ctx, ptr_in[k], DataType.F32.value, ptr_out[k], DataType.UINT8.value, n, scale, zp, RoundMode.NEAREST.value) for k in range(nsets)]
 
     def step(i):
@@ -242,7 +249,8 @@ def main():
                                                           f"{n_max} elements per GPU, no collective in the timed region") +
                         f", inputs resident in HBM, {nsets} rotating buffer sets ({nsets * ALGO_BYTES_PER_ELEM * n / 1e6:.0f} MB per GPU) to defeat the 256 MiB Infinity Cache",
             "numel_total": n_total, "numel_per_gpu": n_max, "round_mode": "nearest", "scale": scale, "zero_point": zp,
-            "api": "piquant_quantize (C ABI, libpiquant.so), stream-ordered, one call per GPU per step",
+            "api": ("piquant_quantize (C ABI, libpiquant.so; reference layout of a " + str(ctx._num_threads) + "-thread reference context, the default)" if world == 1 else
+                    "piquant_hip_quantize_uniform (C ABI, libpiquant.so; piquant_quantize in the position-independent form shards need)") + ", stream-ordered, one call per GPU per step",
             "parallelism": f"dp{world} (one shard of the tensor per GPU, no collective)", "prewarm_launches": PREWARM, "buffer_sets": nsets,
         },
         "roofline": {
@@ -316,7 +324,7 @@ def main():
             result["cpu_baseline"] = {"value": None, "unit": "GiB/s", "cores": 0, "kind": "port", "sample": f"failed: {exc!r}"}
     emit(result)
     # The peer-to-peer transport has never run between two GPUs: its child job starts only now, with the line already out (its record: stderr).
-    if world > 1 and not args.no_extras:
+    if world > 1 and args.extras and not args.no_extras:
         try:
             cpu_group = dist.new_group(backend="gloo")      # everybody waits on the CPU, not in a collective kernel spinning on the GPUs the child measures on
             torch.cuda.synchronize()

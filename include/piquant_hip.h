@@ -79,25 +79,27 @@ PIQUANT_EXPORT void piquant_hip_set_stochastic_seed(piquant_context_t* ctx, uint
 PIQUANT_EXPORT void piquant_hip_set_stochastic_per_element(piquant_context_t* ctx, int enabled, uint64_t seed,
                                                            uint64_t index_base);
 
-/* Reference-layout mode (off by default).  The kernels apply ONE formula to every element -- the one of the reference's
- * AVX-512 SIMD body -- which makes results independent of pointer alignment, length and sharding.  The reference's own
- * output also depends on WHERE an element sits: its scalar head (fp32 -> uint8 only: elements before the output pointer
- * is 16-byte aligned, kernels_specialized.inl:52) and scalar tails (the last numel mod 64 / 16 elements when quantizing,
- * mod 64 / 128 / 256 when dequantizing to bf16) use std::round and a second bf16 rounding, which differ from the body on
- * a few corner inputs (|x/scale| = 0.49999997, odd |x/scale| >= 2^23, bf16 ADD ties), and the
- * 1-3 element tail of uint2 -> f32 ADD stores instead of adding (dequantize.inl:72-86).  With this mode on, those
- * positions use the reference's scalar formulas, so every output byte equals what the reference's AVX-512 build writes
- * from a context with ONE pool thread.  A reference context with T pool threads splits the call into T partitions
- * (src/piquant.cpp:145-157), each with its own head and tail: those positions are reproduced for T = the num_threads this context was
- * created with (the reference context it stands for), or whatever piquant_hip_set_reference_threads(ctx, T) says (only read in
- * reference-layout mode).  PIQUANT_HIP_REFERENCE_LAYOUT=1 in the environment at context creation turns the mode on without a code change:
- * an unchanged binding then gets, byte for byte, what the CPU library's context of the same num_threads writes.
- * Costs nothing on aligned bulk data with T = 1 (only the guarded tail path looks at it).  A non-zero head, or T > 1: the vector kernels
- * run as always and a patch kernel behind them rewrites the partitions' heads and tails -- one more dependent launch, 26 against 23 us
- * for fp32 -> uint8 at numel 27 264 000 with T = 255 (round 5; the element-by-element kernels took such calls whole until then: 213 us).
- * Position-dependent output is what sharding must not have: leave the mode off on contexts that serve shard calls (piquant.distributed). */
+/* Reference layout (ON by default for piquant_quantize and piquant_dequantize since round 6).  The reference's output depends on WHERE an
+ * element sits: a reference context of T pool threads splits a call into T partitions (src/piquant.cpp:145-157), every partition runs one
+ * kernel call, and that call's scalar head (fp32 -> uint8 only: elements before the partition's output pointer is 16-byte aligned,
+ * kernels_specialized.inl:52) and scalar tail (what is left of the last SIMD block: numel mod 64 / 16 elements when quantizing, mod 64 / 128 /
+ * 256 when dequantizing to bf16) use std::round and a second bf16 rounding, which differ from the SIMD body on a few inputs (|x/scale| =
+ * 0.49999997, odd |x/scale| >= 2^23, bf16 ADD ties -- 22 of 10^6 ordinary elements with 3 threads), and the 1-3 element
+ * tail of uint2 -> f32 ADD stores instead of adding (dequantize.inl:72-86).  The two plain calls reproduce exactly that: every output byte
+ * equals what the reference's AVX-512 build writes from a context created with the same num_threads (T = the num_threads of
+ * piquant_context_create, or whatever piquant_hip_set_reference_threads says), for device, pinned and host buffers alike.  It costs nothing:
+ * a wave tile that a partition's head or tail reaches into handles those positions itself, in registers, before its one store.
+ *   piquant_hip_set_reference_layout(ctx, 0), or PIQUANT_HIP_REFERENCE_LAYOUT=0 in the environment at context creation, turns it off: the
+ *       SIMD-body formula at every element, independent of pointer alignment, length and thread count.
+ * Position-independent BY CONSTRUCTION, whatever the mode: piquant_hip_quantize_uniform / piquant_hip_dequantize_uniform (the plain calls in
+ * the SIMD-body form -- what a shard of a larger tensor must be computed with, piquant.distributed), the device-parameter twins (*_dp), the
+ * one-launch calls (piquant_hip_quantize_dynamic, its batch and reduce variants) and piquant_hip_dequantize_sum / _dp_batch. */
 PIQUANT_EXPORT void piquant_hip_set_reference_layout(piquant_context_t* ctx, int enabled);
 PIQUANT_EXPORT void piquant_hip_set_reference_threads(piquant_context_t* ctx, int threads);
+PIQUANT_EXPORT void piquant_hip_quantize_uniform(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out,
+                                                 size_t numel, float scale, int64_t zero_point, piquant_round_mode_t mode);
+PIQUANT_EXPORT void piquant_hip_dequantize_uniform(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out,
+                                                   size_t numel, float scale, int64_t zero_point, piquant_reduce_op_t op);
 
 /* Fused quantize -> dequantize: out[i] (op)= dequantize(quantize(in[i])) without materialising the quantized tensor;
  * dtype_in_out (F32 or BF16) is the type of BOTH buffers, quant_dtype (UINT2/4/8) the type passed through; `out` may

@@ -24,8 +24,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <condition_variable>
-#include <functional>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -100,6 +100,8 @@ namespace {
     // Optional pinning for timing runs (bench.py cpu_baseline): worker t of the pool runs on logical CPU g_pin[t].  On a two-socket
     // host an unpinned pool wanders between the sockets and the figure becomes a NUMA accident; with pinning, and with every buffer
     // partition first touched by the worker that will process it (ref_partition_copy below), each worker streams from its own node.
+    // Thread 0 is the caller: pinned when the pinning is installed and released when it is removed (ref_set_pinning), not per call --
+    // two affinity system calls and a possible migration per call were part of every timed call until round 6.
     std::vector<int> g_pin;
 
     void pin_this_thread(int index) {
@@ -110,72 +112,81 @@ namespace {
         (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
     }
 
-    // Persistent worker pool (the reference keeps its pool threads alive between calls too,
-    // src/piquant.cpp:178-181); created on first use with the requested size, re-created if the size changes.
+    // Persistent worker pool (the reference keeps its pool threads alive between calls too, src/piquant.cpp:178-181); created on first
+    // use with the requested size, re-created if the size changes.  Workers SPIN on a generation word between calls and go to sleep on a
+    // condition variable only after ~2 ms without work: back-to-back calls -- a timing loop, a training step -- are dispatched and joined
+    // through two cache lines, with no mutex, no futex wake and no std::function on the way.  (Rounds 1-5 woke 127 sleepers through one
+    // mutex per call: 0.1-0.3 ms of a 0.4 ms call at 128 threads, which is why the reference's kernels looked slower at 128 cores than at 64.)
     class Pool {
     public:
-        void run(int threads, const std::function<void(int)>& job) {
-            std::unique_lock<std::mutex> lk(m_);
-            if (static_cast<int>(workers_.size()) != threads - 1 || repin_) resize(lk, threads - 1);
-            job_ = &job;
-            pending_ = threads - 1;
-            ++generation_;
-            cv_start_.notify_all();
-            lk.unlock();
-            cpu_set_t saved;
-            const bool pinned = !g_pin.empty() && pthread_getaffinity_np(pthread_self(), sizeof saved, &saved) == 0;
-            if (pinned) pin_this_thread(0);
-            job(0);                                   // the caller is thread 0
-            if (pinned) (void)pthread_setaffinity_np(pthread_self(), sizeof saved, &saved);
-            lk.lock();
-            cv_done_.wait(lk, [&] { return pending_ == 0; });
-            job_ = nullptr;
+        using fn_t = void (*)(void* arg, int index);
+        void run(int threads, fn_t fn, void* arg) {
+            if (static_cast<int>(workers_.size()) != threads - 1 || repin_.load(std::memory_order_relaxed)) resize(threads - 1);
+            fn_ = fn;
+            arg_ = arg;
+            pending_.store(threads - 1, std::memory_order_relaxed);
+            generation_.fetch_add(1);                     // seq_cst with the sleepers' counter: one side always sees the other
+            if (sleepers_.load() != 0) {   // somebody gave up spinning: the slow wake
+                std::lock_guard<std::mutex> lk(m_);
+                cv_.notify_all();
+            }
+            fn(arg, 0);                                   // the caller is thread 0
+            while (pending_.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
         }
-        void repin() {
-            std::unique_lock<std::mutex> lk(m_);
-            repin_ = true;
-        }
-        ~Pool() {
-            std::unique_lock<std::mutex> lk(m_);
-            resize(lk, 0);
-        }
+        void repin() { repin_.store(true, std::memory_order_relaxed); }
+        ~Pool() { resize(0); }
     private:
-        void resize(std::unique_lock<std::mutex>& lk, int n) {
-            stop_ = true;
-            ++generation_;
-            cv_start_.notify_all();
-            lk.unlock();
+        static constexpr int kSpins = 1 << 16;            // ~2 ms of pause instructions
+        void resize(int n) {
+            stop_.store(true, std::memory_order_relaxed);
+            generation_.fetch_add(1, std::memory_order_release);
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                cv_.notify_all();
+            }
             for (auto& t : workers_) t.join();
-            lk.lock();
             workers_.clear();
-            stop_ = false;
-            repin_ = false;
-            for (int i = 0; i < n; ++i) workers_.emplace_back([this, i, gen = generation_]() mutable { loop(i + 1, gen); });
+            stop_.store(false, std::memory_order_relaxed);
+            repin_.store(false, std::memory_order_relaxed);
+            const unsigned long gen = generation_.load(std::memory_order_relaxed);
+            for (int i = 0; i < n; ++i) workers_.emplace_back([this, i, gen] { loop(i + 1, gen); });
         }
         void loop(int index, unsigned long seen) {
             pin_this_thread(index);
-            std::unique_lock<std::mutex> lk(m_);
             for (;;) {
-                cv_start_.wait(lk, [&] { return generation_ != seen; });
-                seen = generation_;
-                if (stop_) return;
-                const auto* job = job_;
-                lk.unlock();
-                (*job)(index);
-                lk.lock();
-                if (--pending_ == 0) cv_done_.notify_one();
+                int spins = 0;
+                while (generation_.load(std::memory_order_acquire) == seen) {
+                    if (++spins < kSpins) {
+                        __builtin_ia32_pause();
+                        continue;
+                    }
+                    std::unique_lock<std::mutex> lk(m_);
+                    sleepers_.fetch_add(1);
+                    cv_.wait(lk, [&] { return generation_.load() != seen; });
+                    sleepers_.fetch_sub(1);
+                }
+                seen = generation_.load(std::memory_order_acquire);
+                if (stop_.load(std::memory_order_relaxed)) return;
+                fn_(arg_, index);
+                pending_.fetch_sub(1, std::memory_order_release);
             }
         }
+        alignas(64) std::atomic<unsigned long> generation_ {0};
+        alignas(64) std::atomic<int> pending_ {0};
+        alignas(64) std::atomic<int> sleepers_ {0};
+        std::atomic<bool> stop_ {false}, repin_ {false};
+        fn_t fn_ = nullptr;
+        void* arg_ = nullptr;
         std::mutex m_;
-        std::condition_variable cv_start_, cv_done_;
+        std::condition_variable cv_;
         std::vector<std::thread> workers_;
-        const std::function<void(int)>* job_ = nullptr;
-        unsigned long generation_ = 0;
-        int pending_ = 0;
-        bool stop_ = false;
-        bool repin_ = false;
     };
     Pool g_pool;
+
+    template <typename Job>
+    void run_on_pool(int threads, Job& job) {
+        g_pool.run(threads, [](void* arg, int t) { (*static_cast<Job*>(arg))(t); }, &job);
+    }
 
     void run_mt(const kernel_registry& reg, const desc_t& d, int threads) {
         const auto bits_in = static_cast<std::int64_t>(piquant::dtype_info_of(d.dt_in).bit_size);
@@ -188,16 +199,25 @@ namespace {
             reg.quant_kernel(d.in + bits_in * b / 8, d.out + bits_out * b / 8, n, d);
         };
         if (threads <= 1) { job(0); return; }
-        g_pool.run(threads, job);
+        run_on_pool(threads, job);
     }
 }
 
 extern "C" {
 
-// cpus[t] = logical CPU of pool thread t (thread 0 is the caller, pinned only for the duration of a call); n == 0 removes the pinning.
+// cpus[t] = logical CPU of pool thread t (thread 0 is the CALLING thread: pinned here, until the pinning is removed); n == 0 removes the pinning.
 void ref_set_pinning(const int* cpus, int n) {
+    static cpu_set_t saved;
+    static bool have_saved = false;
     g_pin.assign(cpus, cpus + (n > 0 ? n : 0));
     g_pool.repin();
+    if (n > 0) {
+        if (!have_saved) have_saved = pthread_getaffinity_np(pthread_self(), sizeof saved, &saved) == 0;
+        pin_this_thread(0);
+    } else if (have_saved) {
+        (void)pthread_setaffinity_np(pthread_self(), sizeof saved, &saved);
+        have_saved = false;
+    }
 }
 
 // dst[i] = src[i] over `numel` elements of `elem_bytes` bytes, split over `threads` pool threads by the reference's partition rule:
@@ -210,7 +230,7 @@ void ref_partition_copy(const void* src, void* dst, long long numel, int elem_by
         std::memcpy(static_cast<char*>(dst) + b * elem_bytes, static_cast<const char*>(src) + b * elem_bytes, static_cast<std::size_t>(n) * elem_bytes);
     };
     if (threads <= 1) { job(0); return; }
-    g_pool.run(threads, job);
+    run_on_pool(threads, job);
 }
 
 int ref_isa_count(void) { return ISA_COUNT; }

@@ -53,8 +53,10 @@ void scan(piquant_context_t* ctx, const void* x, piquant_dtype_t dtype, size_t n
 
 extern "C" {
 
+// reference_layout: the plain piquant.h call (whose bytes are those of a reference context of the same num_threads, unless the context says otherwise);
+// false for the additive twins (device-resident parameters, the position-independent calls that shards are made of)
 static void quantize_impl(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out, size_t numel,
-                          float scale, int64_t zero_point, piquant_round_mode_t mode, const void* dyn_params) {
+                          float scale, int64_t zero_point, piquant_round_mode_t mode, const void* dyn_params, bool reference_layout) {
     if (!ctx) panic("piquant_quantize: context is NULL");
     const dtype_row& dti = dtype_of(dtype_in);
     const dtype_row& dto = dtype_of(dtype_out);
@@ -76,15 +78,13 @@ static void quantize_impl(piquant_context_t* ctx, const void* in, piquant_dtype_
     fill_round_mode(ctx, q, mode);
 
     q.ref_out_align = -1;
-    if (ctx->reference_layout) {
+    if (reference_layout && ctx->reference_layout) {
         q.ref_layout = true;
         q.ref_total = static_cast<int64_t>(numel);
         q.ref_threads = ctx->reference_threads;
-        // kernels_specialized.inl:52: fp32 -> uint8 peels scalar elements until the OUTPUT pointer (as the caller passed it) is 16-byte aligned
-        if (dtype_in == PIQUANT_DTYPE_F32 && dtype_out == PIQUANT_DTYPE_UINT8 && mode == PIQUANT_NEAREST) {
-            q.ref_head = static_cast<int>(std::min<size_t>(numel, (16u - (reinterpret_cast<uintptr_t>(out) & 15u)) & 15u));
+        // kernels_specialized.inl:52: fp32 -> uint8 peels scalar elements until the OUTPUT pointer (as the caller passed it; every partition's own) is 16-byte aligned
+        if (dtype_in == PIQUANT_DTYPE_F32 && dtype_out == PIQUANT_DTYPE_UINT8 && mode == PIQUANT_NEAREST)
             q.ref_out_align = static_cast<int>(reinterpret_cast<uintptr_t>(out) & 15u);
-        }
     }
     const Resolved rin = ctx->resolve_ptr(in), rout = ctx->resolve_ptr(out);
     if (dyn_params) {
@@ -98,7 +98,7 @@ static void quantize_impl(piquant_context_t* ctx, const void* in, piquant_dtype_
         q.numel = static_cast<int64_t>(numel);
         {
             StopEventScope completion(ctx);
-            IndependentCallScope independent(ctx);
+            IndependentCallScope independent(ctx, dyn_params != nullptr);
             launch_quantize(q, ctx->stream, ctx->num_cu);
         }
         if (ctx->blocking) wait_stream(ctx);
@@ -142,17 +142,22 @@ static void quantize_impl(piquant_context_t* ctx, const void* in, piquant_dtype_
 
 void piquant_quantize(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out,
                       size_t numel, float scale, int64_t zero_point, piquant_round_mode_t mode) {
-    quantize_impl(ctx, in, dtype_in, out, dtype_out, numel, scale, zero_point, mode, nullptr);
+    quantize_impl(ctx, in, dtype_in, out, dtype_out, numel, scale, zero_point, mode, nullptr, true);
+}
+
+void piquant_hip_quantize_uniform(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out, size_t numel,
+                                  float scale, int64_t zero_point, piquant_round_mode_t mode) {
+    quantize_impl(ctx, in, dtype_in, out, dtype_out, numel, scale, zero_point, mode, nullptr, false);
 }
 
 void piquant_hip_quantize_dp(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out, size_t numel,
                              const piquant_hip_params_t* device_params, piquant_round_mode_t mode) {
     if (!device_params) panic("piquant_hip_quantize_dp: NULL parameter record");
-    quantize_impl(ctx, in, dtype_in, out, dtype_out, numel, 1.0f, 0, mode, device_params);
+    quantize_impl(ctx, in, dtype_in, out, dtype_out, numel, 1.0f, 0, mode, device_params, false);
 }
 
 static void dequantize_impl(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out, size_t numel,
-                            float scale, int64_t zero_point, piquant_reduce_op_t op, const void* dyn_params) {
+                            float scale, int64_t zero_point, piquant_reduce_op_t op, const void* dyn_params, bool reference_layout) {
     if (!ctx) panic("piquant_dequantize: context is NULL");
     const dtype_row& dti = dtype_of(dtype_in);
     const dtype_row& dto = dtype_of(dtype_out);
@@ -175,7 +180,7 @@ static void dequantize_impl(piquant_context_t* ctx, const void* in, piquant_dtyp
     // fp32 product on the host exactly as the reference forms it (kernels_specialized.inl:1204,1325)
     d.bias = -static_cast<float>(static_cast<int32_t>(static_cast<uint32_t>(static_cast<uint64_t>(zero_point)))) * scale;
 
-    d.ref_layout = ctx->reference_layout;
+    d.ref_layout = reference_layout && ctx->reference_layout;
     d.ref_total = static_cast<int64_t>(numel);
     d.ref_threads = ctx->reference_threads;
     const Resolved rin = ctx->resolve_ptr(in), rout = ctx->resolve_ptr(out);
@@ -190,7 +195,7 @@ static void dequantize_impl(piquant_context_t* ctx, const void* in, piquant_dtyp
         d.numel = static_cast<int64_t>(numel);
         {
             StopEventScope completion(ctx);
-            IndependentCallScope independent(ctx);
+            IndependentCallScope independent(ctx, dyn_params != nullptr);
             launch_dequantize(d, ctx->stream, ctx->num_cu);
         }
         if (ctx->blocking) wait_stream(ctx);
@@ -233,13 +238,18 @@ static void dequantize_impl(piquant_context_t* ctx, const void* in, piquant_dtyp
 
 void piquant_dequantize(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out,
                         size_t numel, float scale, int64_t zero_point, piquant_reduce_op_t op) {
-    dequantize_impl(ctx, in, dtype_in, out, dtype_out, numel, scale, zero_point, op, nullptr);
+    dequantize_impl(ctx, in, dtype_in, out, dtype_out, numel, scale, zero_point, op, nullptr, true);
+}
+
+void piquant_hip_dequantize_uniform(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out, size_t numel,
+                                    float scale, int64_t zero_point, piquant_reduce_op_t op) {
+    dequantize_impl(ctx, in, dtype_in, out, dtype_out, numel, scale, zero_point, op, nullptr, false);
 }
 
 void piquant_hip_dequantize_dp(piquant_context_t* ctx, const void* in, piquant_dtype_t dtype_in, void* out, piquant_dtype_t dtype_out, size_t numel,
                                const piquant_hip_params_t* device_params, piquant_reduce_op_t op) {
     if (!device_params) panic("piquant_hip_dequantize_dp: NULL parameter record");
-    dequantize_impl(ctx, in, dtype_in, out, dtype_out, numel, 1.0f, 0, op, device_params);
+    dequantize_impl(ctx, in, dtype_in, out, dtype_out, numel, 1.0f, 0, op, device_params, false);
 }
 
 void piquant_hip_minmax_keys(piquant_context_t* ctx, const void* x, piquant_dtype_t dtype, size_t n, int32_t* device_keys, int init) {

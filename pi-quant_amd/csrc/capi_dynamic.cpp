@@ -146,16 +146,7 @@ static void quantize_dynamic_one(piquant_context_t* ctx, QuantLaunch q, const vo
     q.in = in_dev;
     q.out = out_dev;
     q.numel = static_cast<int64_t>(numel);
-    q.ref_out_align = -1;
-    if (ctx->reference_layout) {
-        q.ref_layout = true;
-        q.ref_total = q.numel;
-        q.ref_threads = ctx->reference_threads;
-        if (q.dt_in == PIQUANT_DTYPE_F32 && q.dt_out == PIQUANT_DTYPE_UINT8 && q.round_mode == RM_NEAREST_FAST) {
-            q.ref_head = static_cast<int>(std::min<size_t>(numel, (16u - (reinterpret_cast<uintptr_t>(out_as_passed) & 15u)) & 15u));
-            q.ref_out_align = static_cast<int>(reinterpret_cast<uintptr_t>(out_as_passed) & 15u);
-        }
-    }
+    q.ref_out_align = -1;   // the one-launch call is position-independent whatever the context's layout mode says (include/piquant_hip.h)
     // One launch with the tensor held on chip between the scan and the quantization when it fits; otherwise (or with fusion
     // switched off) the same result from two launches: the scan, whose last block writes the record, and a quantize that reads it.
     bool fused = false;
@@ -331,7 +322,7 @@ void piquant_hip_signal_flags(piquant_context_t* ctx, uint32_t* const* flags, si
     std::lock_guard<std::mutex> lock(ctx->mu);
     DeviceGuard guard(ctx->device);
     peer_timeout_pending(ctx, "piquant_hip_signal_flags");
-    launch_signal_flags(flags, static_cast<int>(count), value, ctx->stream);
+    launch_signal_flags(flags, static_cast<int>(count), value, peer_timeout_record_dev(ctx), ctx->stream);
 }
 
 void piquant_hip_wait_flags(piquant_context_t* ctx, const uint32_t* flags, size_t count, uint32_t value, uint32_t timeout_us) {

@@ -326,8 +326,8 @@ static void leave_stream(piquant_context_t* ctx, hipStream_t next) {
 extern "C" {
 
 piquant_context_t* piquant_context_create(size_t num_threads) {
-    // num_threads sized the reference's CPU pool (src/piquant.cpp:178-181); the GPU grid replaces it.  It is remembered for one thing: in
-    // reference-layout mode the partitions of THAT pool are what decides where the reference's scalar heads and tails sit.
+    // num_threads sized the reference's CPU pool (src/piquant.cpp:178-181); the GPU grid replaces it.  It is remembered for one thing: the
+    // partitions of THAT pool decide where the reference's scalar heads and tails sit, and the plain calls reproduce them (piquant_hip.h).
     int count = 0;
     const hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)
@@ -372,8 +372,8 @@ piquant_context_t* piquant_context_create(size_t num_threads) {
         else if (m == "stage") ctx->host_path = PIQUANT_HIP_HOST_PATH_STAGE;
         else if (m != "auto" && !m.empty()) panic("PIQUANT_HIP_HOST_PATH=%s: expected auto, stage or cpu", env);
     }
-    // PIQUANT_HIP_REFERENCE_LAYOUT=1: an unchanged binding gets, byte for byte, what the CPU library's context of the same num_threads writes
-    if (const char* env = std::getenv("PIQUANT_HIP_REFERENCE_LAYOUT")) ctx->reference_layout = env[0] == '1' && env[1] == '\0';
+    // the default: an unchanged binding gets, byte for byte, what the CPU library's context of the same num_threads writes; =0: position-independent output
+    if (const char* env = std::getenv("PIQUANT_HIP_REFERENCE_LAYOUT")) ctx->reference_layout = !(env[0] == '0' && env[1] == '\0');
     if (const char* env = std::getenv("PIQUANT_HIP_FUSION")) ctx->fusion = !(env[0] == '0' && env[1] == '\0');
     if (const char* env = std::getenv("PIQUANT_HIP_BARRIER_TIMEOUT_US")) ctx->barrier_timeout_us = static_cast<uint32_t>(std::strtoul(env, nullptr, 10));
     std::random_device rd;

@@ -104,9 +104,8 @@ struct piquant_context_t {
     std::mt19937_64 rng;
     float fixed_threshold = -1.0f;
     bool per_element = false;
-    bool reference_layout = false;
-    int reference_threads = 1;             // pool threads of the reference context reproduced in reference-layout mode: num_threads of piquant_context_create
-                                           // until piquant_hip_set_reference_threads says otherwise
+    bool reference_layout = true;          // piquant_quantize / piquant_dequantize write the bytes of a reference context of reference_threads pool threads
+    int reference_threads = 1;             // num_threads of piquant_context_create until piquant_hip_set_reference_threads says otherwise
     uint64_t elem_seed = 0, elem_base = 0;
     std::mutex mu;
 
@@ -180,8 +179,12 @@ float draw_threshold(piquant_context_t* ctx);
 
 // Arms stop_event.hpp's tl_any_order for the launch the caller is about to make when the context's calls were declared independent
 // (piquant_hip_set_independent_calls) and the call is stream-ordered outside a hipGraph capture; disarms at scope exit.
+// Never for a call with device-resident parameters: its record is written by whatever was enqueued just before it (the scan's epilogue, a
+// received wire header), which is exactly the producer an out-of-order launch would not wait for.
 struct IndependentCallScope {
-    explicit IndependentCallScope(piquant_context_t* ctx) { tl_any_order = ctx->independent_calls && !ctx->blocking && !stream_is_capturing(ctx->stream); }
+    explicit IndependentCallScope(piquant_context_t* ctx, bool device_params = false) {
+        tl_any_order = ctx->independent_calls && !device_params && !ctx->blocking && !stream_is_capturing(ctx->stream);
+    }
     ~IndependentCallScope() { tl_any_order = false; }
 };
 

@@ -22,40 +22,50 @@ struct DequantForm {
     static constexpr int value = DT_OUT == DT_F32 ? (BITS == 2 ? DQ_I64 : DQ_SUBMUL) : (BITS == 8 ? DQ_SUBMUL : DQ_FMA);
 };
 
+// SIMD block of the reference's AVX-512 dequantize kernels -- its scalar tail is what is left of the last one: 64 elements for uint8 inputs
+// (kernels_specialized.inl:741,941), 128 for uint4 (:1024,1231), 256 for uint2 -> bf16 (:1377); the generic uint2 -> fp32 works in groups of 4
+// (dequantize.inl:42-87).  HAS_FORM: the tail computes something else than the body -- the bf16 outputs ((q - zp) * scale instead of the fma form,
+// ADD rounded twice: :977-981, :1290-1303, :1388-1415) and the uint2 -> fp32 ADD tail, which stores (dequantize.inl:72-86).
+template <int BITS, int DT_OUT, int OP>
+struct DequantRefTail {
+    static constexpr int BLK = BITS == 8 ? 64 : (BITS == 4 ? 128 : (DT_OUT == DT_BF16 ? 256 : 4));
+    static constexpr bool HAS_FORM = DT_OUT == DT_BF16 || (BITS == 2 && OP == OP_ADD);
+};
+
+// element value q at a tail position of the reference layout -> the output word (fp32 bits, or bf16 bits in the low half); `old` = the output's
+// previous value in the same representation (read only for ADD)
+template <int BITS, int DT_OUT, int OP>
+__device__ __forceinline__ uint32_t dequant_ref_tail(uint32_t q, uint32_t old, const DequantParams& p) {
+    if constexpr (DT_OUT == DT_F32) {
+        return __float_as_uint(dequant_one<DequantForm<BITS, DT_OUT>::value>(q, p));   // uint2 -> fp32: the 1-3 element tail always stores, ADD is ignored
+    } else {
+        // (q - zp) * scale rounded to bf16; ADD goes through bfp16_t::operator+= (include/piquant.hpp:97-103) and rounds a second time
+        float dq;
+        if constexpr (BITS == 2) dq = __fmul_rn(__fsub_rn(static_cast<float>(q), static_cast<float>(p.zp32)), p.scale);
+        else dq = dequant_one<DQ_SUBMUL>(q, p);
+        const uint32_t d16 = f32_to_bf16_bits(dq);
+        return OP == OP_ADD ? f32_to_bf16_bits(__fadd_rn(bf16_bits_to_f32(old), bf16_bits_to_f32(d16))) : d16;
+    }
+}
+
 // `shift`: bits in front of element 0 inside in[0] (a body that starts in the middle of a packed byte, dequantize_kernel); 0 everywhere else
-// KNOWN_TAIL: the caller has established that element i lies in a reference tail (the patch kernels below): no partition arithmetic
-template <int BITS, int DT_OUT, int OP, bool KNOWN_TAIL = false>
+template <int BITS, int DT_OUT, int OP>
 __device__ __forceinline__ void dequant_store_scalar(const uint8_t* in, void* out, int64_t i, const DequantParams& p, int shift = 0) {
     constexpr int PACK = 8 / BITS;
     constexpr int FORM = DequantForm<BITS, DT_OUT>::value;
+    using Ref = DequantRefTail<BITS, DT_OUT, OP>;
     const int64_t bit = i * BITS + shift;
     const uint32_t q = (in[bit >> 3] >> (bit & 7)) & ((1u << BITS) - 1u);
-    if (p.ref_layout) {
-        // Reference-layout mode: element g of the call sits in the reference's scalar tail when it is past the last whole
-        // SIMD block (64 / 128 / 256 elements for uint8 / uint4 / uint2->bf16; groups of 4 for the generic uint2->f32).
-        bool tail = KNOWN_TAIL;
-        if constexpr (!KNOWN_TAIL) {
-            const int64_t g = p.ref_index0 + i;
-            constexpr int64_t BLK = BITS == 8 ? 64 : (BITS == 4 ? 128 : (DT_OUT == DT_BF16 ? 256 : 4));
-            int64_t begin = 0, len = p.ref_total;        // the tail is the tail of the element's partition (a T-thread reference context)
-            if (p.ref_threads > 1) ref_partition_of(g, p.ref_total, p.ref_threads, PACK, begin, len);
-            tail = g - begin >= (len / BLK) * BLK;
-        }
-        if (tail) {
-            if constexpr (DT_OUT == DT_F32) {
-                if constexpr (BITS == 2) {   // dequantize.inl:72-86: the 1-3 element tail always stores, ADD is ignored
-                    static_cast<float*>(out)[i] = dequant_one<FORM>(q, p);
-                    return;
+    if constexpr (Ref::HAS_FORM) {
+        if (p.ref.on) {   // reference layout: element g of the call sits in the scalar tail of its partition when it is past the partition's last whole SIMD block
+            const int64_t g = p.ref.index0 + i;
+            if (g >= ref_part<PACK, Ref::BLK>(p.ref, ref_partition_index<PACK>(p.ref, g)).body_end) {
+                if constexpr (DT_OUT == DT_F32) {
+                    static_cast<uint32_t*>(out)[i] = dequant_ref_tail<BITS, DT_OUT, OP>(q, 0u, p);
+                } else {
+                    uint16_t* o = static_cast<uint16_t*>(out);
+                    o[i] = static_cast<uint16_t>(dequant_ref_tail<BITS, DT_OUT, OP>(q, o[i], p));
                 }
-            } else {
-                // kernels_specialized.inl:977-981, 1290-1303, 1388-1415: (q - zp) * scale, rounded to bf16; ADD goes through
-                // bfp16_t::operator+= (include/piquant.hpp:97-103) and rounds a second time
-                float dq;
-                if constexpr (BITS == 2) dq = __fmul_rn(__fsub_rn(static_cast<float>(q), static_cast<float>(p.zp32)), p.scale);
-                else dq = dequant_one<DQ_SUBMUL>(q, p);
-                uint16_t* o = static_cast<uint16_t*>(out);
-                const uint32_t d16 = f32_to_bf16_bits(dq);
-                o[i] = static_cast<uint16_t>(OP == OP_ADD ? f32_to_bf16_bits(__fadd_rn(bf16_bits_to_f32(o[i]), bf16_bits_to_f32(d16))) : d16);
                 return;
             }
         }
@@ -80,39 +90,19 @@ __global__ void __launch_bounds__(256) dequantize_scalar_kernel(const uint8_t* i
         dequant_store_scalar<BITS, DT_OUT, OP>(in, out, i, p);
 }
 
-// Reference-layout mode with tails INSIDE the tensor (partitions of a T-thread reference context; a body that does not start at element 0):
-// the vector kernel decodes the whole call with the SIMD-body formula and these kernels, one block per partition, give the partition's scalar
-// tail (at most 255 elements) the reference's tail formula.  SET: PATCH_DIRECT behind the vector kernel rewrites the tail in place.  ADD: the old
-// accumulator values are gone once the vector kernel has run, so PATCH_STASH runs FIRST -- it copies the tail's old values into `scratch` (256 slots
-// per partition) and applies the tail formula there -- and PATCH_UNSTASH behind the vector kernel copies the results into place.
-enum : int { PATCH_DIRECT = 0, PATCH_STASH = 1, PATCH_UNSTASH = 2 };
-constexpr int kRefTailSlots = 256;
-
-template <int BITS, int DT_OUT, int OP, int WHAT>
-__global__ void __launch_bounds__(256) dequantize_ref_patch_kernel(const uint8_t* in, void* out, void* scratch, int64_t numel, DequantParams p_arg) {
-    const DequantParams p = resolved(p_arg);
-    using elem_t = typename std::conditional<DT_OUT == DT_F32, float, uint16_t>::type;
-    constexpr int PACK = 8 / BITS;
-    constexpr int64_t BLK = BITS == 8 ? 64 : (BITS == 4 ? 128 : (DT_OUT == DT_BF16 ? 256 : 4));
-    static_assert(BLK <= kRefTailSlots, "a tail fits its slots");
-    int64_t begin = 0, len = p.ref_total;
-    if (p.ref_threads > 1) ref_partition_bounds(blockIdx.x, p.ref_total, p.ref_threads, PACK, begin, len);
-    const int64_t tail0 = begin + (len / BLK) * BLK;                      // global index of the tail's first element
-    const int64_t g = tail0 + threadIdx.x;
-    const int64_t i = g - p.ref_index0;                                   // element of THIS launch
-    if (g >= begin + len || i < 0 || i >= numel) return;
-    elem_t* o = static_cast<elem_t*>(out);
-    elem_t* slot = static_cast<elem_t*>(scratch) + static_cast<int64_t>(blockIdx.x) * kRefTailSlots + threadIdx.x;
-    if constexpr (WHAT == PATCH_DIRECT) {
-        dequant_store_scalar<BITS, DT_OUT, OP, true>(in, out, i, p);
-    } else if constexpr (WHAT == PATCH_STASH) {
-        *slot = o[i];
-        // dequant_store_scalar indexes its output with i: hand it the address at which element i IS this slot
-        dequant_store_scalar<BITS, DT_OUT, OP, true>(in, reinterpret_cast<void*>(reinterpret_cast<uintptr_t>(slot) - static_cast<uintptr_t>(i) * sizeof(elem_t)), i, p);
-    } else {
-        o[i] = *slot;
-    }
-}
+// the kernarg segment of dequantize_kernel as the ABI lays it out, for load_ref_split (device_math.hpp)
+struct DequantKernargs {
+    const uint8_t* in;
+    void* out;
+    int64_t numel, n_tiles;
+    float scale;
+    int head;
+    const ParamRecord* dyn;
+    int32_t zp32;
+    uint32_t tile_stride;
+    DequantParams p;
+};
+constexpr uint32_t kDequantKernargRef = static_cast<uint32_t>(__builtin_offsetof(DequantKernargs, p) + __builtin_offsetof(DequantParams, ref));
 
 template <int BITS, int DT_OUT, int U, int BLOCK>
 struct DequantTile {
@@ -125,11 +115,9 @@ struct DequantTile {
     static constexpr int64_t BLOCK_ELEMS = static_cast<int64_t>(WAVES) * WAVE_VECS * EPV;
 };
 
-// COPY_ONLY (tune harness): no arithmetic -- every output word is the vector's packed input word -- i.e. this kernel's traffic, tile shape,
-// LDS staging and store policy alone: the ceiling the real kernel is measured against.
 // SHIFTED: the body starts inside a packed byte (`head` bits 16-18 = the bits in front of it); its own instantiation, so that the ordinary
 // kernels carry none of it (as a run-time branch it cost the 256-thread bf16-output kernels 0.4 us: 11.7 -> 12.1 us for uint4 -> bf16).
-template <int BITS, int DT_OUT, int OP, int U, bool STAGE, int NT, int BLOCK, bool COPY_ONLY = false, bool SHIFTED = false>
+template <int BITS, int DT_OUT, int OP, int U, bool STAGE, int NT, int BLOCK, bool SHIFTED = false>
 __global__ void __launch_bounds__(BLOCK)
 dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int64_t n_tiles, float scale, int head, const ParamRecord* dyn, int32_t zp32,
                   uint32_t tile_stride, DequantParams p_arg) {
@@ -138,6 +126,8 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
     // of elements before a cache line: the body then starts in the middle of a byte, and every vector's packed bits are funnel-shifted into
     // place -- one more LDS byte and one v_alignbit_b32 per vector instead of misaligned stores for the whole call, 31.0 -> ~21 us)
     const int shift = SHIFTED ? (head >> 16) & 7 : 0;
+    // bit 19: reference layout, for the pairs whose scalar tail computes something else than the SIMD body (DequantRefTail)
+    [[maybe_unused]] const bool ref_on = DequantRefTail<BITS, DT_OUT, OP>::HAS_FORM && (head & (1 << 19)) != 0;
     head &= 0xffff;
     // scale / dyn / zp32 repeat fields of p_arg, tile_stride is gridDim.x and head is the launcher's, as scalar arguments so that they arrive
     // preloaded in SGPRs (quantize_kernel explains); the bias is formed here as the host forms it (kernels_specialized.inl:1204)
@@ -159,7 +149,7 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
     __shared__ __attribute__((aligned(16))) uint8_t lds[STAGE ? T::WAVES * SLICE : 16];
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // in an SGPR (quantize_kernel)
     u32x4* out16 = static_cast<u32x4*>(out);
 
 
@@ -171,6 +161,22 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
         if constexpr (OP == OP_ADD) {
 #pragma unroll
             for (int k = 0; k < U; ++k) old[k] = ld<NT_LD>(out16 + v0 + k * 64 + lane);
+        }
+
+        // Reference layout, first look (device_math.hpp, ref_candidates): does the scalar tail of a reference partition reach into this wave tile?
+        [[maybe_unused]] int32_t ref_ta = 1, ref_tb = 0;
+        [[maybe_unused]] uint32_t ref_m[U] = {};
+        if constexpr (DequantRefTail<BITS, DT_OUT, OP>::HAS_FORM) {
+            if (ref_on) {
+                using Ref = DequantRefTail<BITS, DT_OUT, OP>;
+                const RefSplit ref = load_ref_split<kDequantKernargRef>();   // behind the tile's loads, on purpose
+                if (ref_first_look(ref, static_cast<uint64_t>(tile) * T::WAVES + static_cast<uint32_t>(wave))) {
+                    const int64_t g0 = ref.index0 + v0 * EPV;
+                    ref_candidates<8 / BITS, Ref::BLK>(ref, g0, g0 + static_cast<int64_t>(T::WAVE_VECS) * EPV, ref_ta, ref_tb);
+                    if (ref_ta <= ref_tb)   // wave-uniform, rare: which elements of this lane's vectors are tail positions
+                        ref_scalar_masks<8 / BITS, Ref::BLK, EPV, U>(ref, ref_ta, ref_tb, ref.index0 + (v0 + lane) * EPV, 64 * EPV, ref_m);
+                }
+            }
         }
 
         uint32_t w[U][WORDS];
@@ -236,12 +242,6 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
 
 #pragma unroll
         for (int k = 0; k < U; ++k) {
-            if constexpr (COPY_ONLY) {
-                u32x4 r = {w[k][0], w[k][WORDS - 1], w[k][0], w[k][WORDS - 1]};
-                if constexpr (OP == OP_ADD) r ^= old[k];
-                st<NT_ST>(out16 + v0 + k * 64 + lane, r);
-                continue;
-            }
             float f[EPV];
 #pragma unroll
             for (int e = 0; e < EPV; ++e) {
@@ -249,6 +249,28 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
                 f[e] = dequant_one<FORM>(q, p);
             }
             u32x4 r;
+            if constexpr (DequantRefTail<BITS, DT_OUT, OP>::HAS_FORM) {
+                if (ref_m[k] != 0) {   // a vector with tail positions of the reference layout: element by element, each with the formula of its position
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) {
+                        const uint32_t q = (w[k][(e * BITS) >> 5] >> ((e * BITS) & 31)) & ((1u << BITS) - 1u);
+                        uint32_t o = 0;
+                        if constexpr (OP == OP_ADD) o = DT_OUT == DT_F32 ? old[k][e] : (old[k][e >> 1] >> ((e & 1) * 16)) & 0xffffu;
+                        uint32_t bits;
+                        if (((ref_m[k] >> e) & 1u) != 0) {
+                            bits = dequant_ref_tail<BITS, DT_OUT, OP>(q, o, p);
+                        } else {
+                            float g = f[e];
+                            if constexpr (OP == OP_ADD) g = __fadd_rn(g, DT_OUT == DT_F32 ? __uint_as_float(o) : bf16_bits_to_f32(o));
+                            bits = DT_OUT == DT_F32 ? __float_as_uint(g) : f32_to_bf16_bits(g);
+                        }
+                        if constexpr (DT_OUT == DT_F32) r[e] = bits;
+                        else r[e >> 1] = (e & 1) != 0 ? (r[e >> 1] | (bits << 16)) : bits;
+                    }
+                    st<NT_ST>(out16 + v0 + k * 64 + lane, r);
+                    continue;
+                }
+            }
             if constexpr (DT_OUT == DT_F32) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -272,10 +294,15 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
     // ragged tail and head, element by element, dealt over the threads of the whole grid after the tiles (quant_kernels.hpp explains)
     if (n_tiles * T::BLOCK_ELEMS < numel || head > 0) {   // kernel-uniform
         const int64_t gtid = static_cast<int64_t>(blockIdx.x) * BLOCK + threadIdx.x, gthreads = static_cast<int64_t>(tile_stride) * BLOCK;
-        for (int64_t i = n_tiles * T::BLOCK_ELEMS + gtid; i < numel; i += gthreads) dequant_store_scalar<BITS, DT_OUT, OP>(in, out, i, p, shift);
+        DequantParams pg = p;
+        pg.ref = RefSplit {};
+        if constexpr (DequantRefTail<BITS, DT_OUT, OP>::HAS_FORM) {
+            if (ref_on) pg.ref = load_ref_split<kDequantKernargRef>();
+        }
+        for (int64_t i = n_tiles * T::BLOCK_ELEMS + gtid; i < numel; i += gthreads) dequant_store_scalar<BITS, DT_OUT, OP>(in, out, i, pg, shift);
         if (head > 0) {
-            DequantParams ph = p;
-            ph.ref_index0 -= head;
+            DequantParams ph = pg;
+            ph.ref.index0 -= head;
             const uint8_t* in0 = in - head / (8 / BITS);   // floor: with shift != 0 the body's first byte also holds the head's last elements
             void* out0 = static_cast<uint8_t*>(out) - static_cast<int64_t>(head) * (DT_OUT == DT_F32 ? 4 : 2);
             for (int64_t i = gtid; i < head; i += gthreads) dequant_store_scalar<BITS, DT_OUT, OP>(in0, out0, i, ph);
@@ -283,16 +310,17 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
     }
 }
 
-template <int BITS, int DT_OUT, int OP, int U, bool STAGE, int NT, int BLOCK, bool COPY_ONLY = false>
+template <int BITS, int DT_OUT, int OP, int U, bool STAGE, int NT, int BLOCK>
 inline void launch_dequantize_kernel(unsigned grid, hipStream_t stream, const uint8_t* in, void* out, int64_t numel, int64_t n_tiles, const DequantParams& p, int head) {
-    if constexpr (BITS < 8 && !COPY_ONLY) {
-        if ((head >> 16) != 0) {   // the body starts inside a packed byte
-            PQ_LAUNCH((dequantize_kernel<BITS, DT_OUT, OP, U, STAGE, NT, BLOCK, false, true>), dim3(grid), dim3(BLOCK), 0, stream, in, out, numel, n_tiles, p.scale,
+    if (p.ref.on) head |= 1 << 19;   // dequantize_kernel: bits 0-15 peeled elements, 16-18 shift, 19 reference layout
+    if constexpr (BITS < 8) {
+        if (((head >> 16) & 7) != 0) {   // the body starts inside a packed byte
+            PQ_LAUNCH((dequantize_kernel<BITS, DT_OUT, OP, U, STAGE, NT, BLOCK, true>), dim3(grid), dim3(BLOCK), 0, stream, in, out, numel, n_tiles, p.scale,
                       head, p.dyn, p.zp32, grid, p);
             return;
         }
     }
-    PQ_LAUNCH((dequantize_kernel<BITS, DT_OUT, OP, U, STAGE, NT, BLOCK, COPY_ONLY>), dim3(grid), dim3(BLOCK), 0, stream, in, out, numel, n_tiles, p.scale, head,
+    PQ_LAUNCH((dequantize_kernel<BITS, DT_OUT, OP, U, STAGE, NT, BLOCK>), dim3(grid), dim3(BLOCK), 0, stream, in, out, numel, n_tiles, p.scale, head,
               p.dyn, p.zp32, grid, p);
 }
 

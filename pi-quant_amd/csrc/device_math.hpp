@@ -18,9 +18,7 @@ enum : int { DT_F32 = 0, DT_BF16 = 1, DT_UINT2 = 2, DT_UINT4 = 3, DT_UINT8 = 4 }
 //   RM_NEAREST_I64  : the reference's generic scalar formula, std::round in int64 (only f32 -> uint2 has no fast path)
 //   RM_STOCH_CALL   : stochastic, one threshold per call (the reference's behaviour)
 //   RM_STOCH_ELEM   : stochastic, counter-hash threshold per element (extension)
-//   RM_COPY         : tune harness only -- no arithmetic at all (a vector's dwords are xor-ed into its packed word): the streaming kernel's
-//                     traffic, tile shape, LDS staging and store policy with nothing else, i.e. the ceiling its real modes are measured against
-enum : int { RM_NEAREST_FAST = 0, RM_NEAREST_I64 = 1, RM_STOCH_CALL = 2, RM_STOCH_ELEM = 3, RM_COPY = 4 };
+enum : int { RM_NEAREST_FAST = 0, RM_NEAREST_I64 = 1, RM_STOCH_CALL = 2, RM_STOCH_ELEM = 3 };
 
 // Quantization parameters living in DEVICE memory (16 bytes), written by params_from_slots_kernel and read by the
 // kernels when QuantParams::dyn / DequantParams::dyn is set: the "dynamic" path, where (scale, zero_point) never
@@ -29,6 +27,30 @@ struct ParamRecord {
     float scale;
     float inv_scale;      // 1.0f / scale, correctly rounded fp32 division (as the host computes it)
     int64_t zero_point;
+};
+
+// Reference layout (the default of the two plain piquant.h calls): WHERE the reference's AVX-512 build applies its scalar head / tail formulas
+// instead of the SIMD-body formula.  A reference context of T pool threads splits a call of n elements into partitions (src/piquant.cpp:145-157:
+// thread t covers [n t / T, n (t + 1) / T), both ends aligned down to a whole packed byte, the last thread keeps the ragged end), and every partition
+// runs one kernel call with its own scalar head (fp32 -> uint8 nearest only: until the partition's OUTPUT pointer is 16-byte aligned,
+// kernels_specialized.inl:52) and scalar tail (what is left of the last SIMD block).  Prepared on the host so that a boundary costs the device one 32-bit
+// division: n t / T == q t + (rem t) / T with n == q T + rem, and rem t < 2^32 because T <= 65536.  Positions are global (index0 = global index of this
+// launch's element 0), so that a staged host chunk keeps the layout of the whole call.
+struct RefSplit {
+    int64_t n;            // numel of the whole call
+    int64_t q;            // n / T
+    uint32_t rem;         // n % T
+    uint32_t T;           // pool threads of the reference context, 1 .. 65536
+    double rate;          // T / n: boundaries per element (the estimate in front of the exact arithmetic)
+    int64_t index0;
+    int32_t out_align;    // (output pointer as the caller passed it) & 15 for fp32 -> uint8 nearest, -1 for the pairs without a scalar head
+    int32_t on;
+    // The vector kernels' first look (ref_first_look below), prepared per launch for the kernel's wave tile: 0.64 fixed-point fractions of t = g T / n
+    uint64_t f0;          // frac of t at (first element of wave tile 0) - (margin below)
+    uint64_t d;           // frac of t per wave tile
+    uint64_t w;           // t-width of a wave tile with both margins
+    int32_t always;       // != 0: every wave tile takes the second look (partitions smaller than a tile, or a tensor beyond the fixed point's reach)
+    int32_t pad;
 };
 
 // Field order matters: the leading 14 dwords of a kernel's arguments arrive preloaded in SGPRs (Makefile, -amdgpu-kernarg-preload-count) --
@@ -43,15 +65,7 @@ struct QuantParams {
     uint32_t seed_lo;     // RM_STOCH_ELEM
     uint32_t seed_hi;
     uint64_t index_base;  // RM_STOCH_ELEM: global index of element 0 of this launch
-    // Opt-in "reference layout" (piquant_hip_set_reference_layout): reproduce WHERE the reference's AVX-512 build applies its
-    // scalar head/tail formula instead of the SIMD-body formula, for a context with one pool thread.  Positions are global
-    // (ref_index0 = global index of this launch's element 0) so that chunked host staging keeps the layout of the whole call.
-    int32_t ref_layout;
-    int32_t ref_head;         // leading elements processed by the scalar head loop (fp32 -> uint8 only, kernels_specialized.inl:52); ref_threads == 1
-    int64_t ref_total;        // numel of the whole call
-    int64_t ref_index0;
-    int32_t ref_threads;      // pool threads of the reference context being reproduced (>= 1): every partition has its own head and tail
-    int32_t ref_out_align;    // (output pointer as the caller passed it) & 15, or -1 when the pair has no scalar head: heads of the partitions
+    RefSplit ref;         // reference layout of the call (below); ref.on == 0: the SIMD-body formula at every position
 };
 
 struct DequantParams {
@@ -60,10 +74,7 @@ struct DequantParams {
     const ParamRecord* dyn;   // nullable, as in QuantParams (and placed for the same reason)
     int32_t zp32;
     int64_t zp64;
-    int32_t ref_layout;       // as in QuantParams (tail formulas of the bf16 kernels, the uint2 -> f32 tail)
-    int64_t ref_total;
-    int64_t ref_index0;
-    int32_t ref_threads;      // as in QuantParams
+    RefSplit ref;             // as in QuantParams (tail formulas of the bf16 kernels, the uint2 -> f32 tail)
 };
 
 // Kernel-entry resolution of the dynamic parameters (wave-uniform scalar loads; a no-op when dyn is null).
@@ -195,17 +206,9 @@ __device__ __forceinline__ void quant_nearest_fast2(float x0, float x1, const Qu
 // giving 0 -- which is what the reference's INT_MIN + zp clamps to.  Three instructions (v_med3_f32, v_cvt_i32_f32, add)
 // instead of six; used by the fused params+quantize kernel, which knows the data range before it quantizes.
 struct BoundedStep {
-    float lo, hi;    // float(-zp), float(QMAX - zp)
-    uint32_t zp_word;   // zp replicated into every BITS-wide field of a 32-bit word
-    float zp_scaled;    // float(zp) * (255 / QMAX): the zero point in the scaled domain of pack_saturated (quant_kernels.hpp)
+    float zp_float;     // float(zp): 8-bit outputs add it and saturate (pack_saturated_u8, quant_kernels.hpp)
     float zp_norm;      // (float(zp) + 0.3 QMAX / 65535) / QMAX: the zero point in the normalised domain of pack_normalised, a third of a 16-bit step up
 };
-
-// trunc(clamp(adj)) as a signed offset from the zero point, in [-zp, QMAX - zp].  v_med3_f32 returns min3 of its operands
-// when one of them is a NaN, and min ignores the NaN: med3(NaN, lo, hi) = lo, the value the fmax/fmin pair would give.
-__device__ __forceinline__ int32_t quant_nearest_bounded_offset(float adj, const BoundedStep& b) {
-    return static_cast<int32_t>(__builtin_amdgcn_fmed3f(adj, b.lo, b.hi));
-}
 
 // The scalar head/tail step of the reference's nearest fast paths (kernels_specialized.inl:52-56, 178-182, 468-472, 711-716):
 // std::round, then int32 arithmetic.  Used only in reference-layout mode.
@@ -215,47 +218,156 @@ __device__ __forceinline__ uint32_t quant_nearest_tail32(float x, const QuantPar
     return quant_nearest_finish<QMAX>(r, p);
 }
 
-// Partition of a T-thread reference context that holds global element g (src/piquant.cpp:145-157): thread t covers [n t / T, n (t + 1) / T),
-// both ends aligned down to `pack` elements (a whole packed byte), the last thread keeps the ragged end.
-__device__ __forceinline__ void ref_partition_of(int64_t g, int64_t n, int64_t T, int64_t pack, int64_t& begin, int64_t& len) {
-    auto first = [&](int64_t t) {
-        const int64_t b = n * t / T;
-        return t >= T ? n : (pack > 1 ? b - b % pack : b);
-    };
-    int64_t t = ((g + 1) * T + n - 1) / n - 1;        // largest t with n t / T <= g, before the alignment moves the ends down
-    t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
-    while (t > 0 && g < first(t)) --t;
-    while (t + 1 < T && g >= first(t + 1)) ++t;
-    begin = first(t);
-    len = first(t + 1) - begin;
+// first element of partition t (t == T: the end of the call); PACK = elements per packed byte of the quantized side
+template <int PACK>
+__device__ __forceinline__ int64_t ref_boundary(const RefSplit& s, int64_t t) {
+    if (t >= static_cast<int64_t>(s.T)) return s.n;
+    if (t <= 0) return 0;
+    const int64_t b = s.q * t + static_cast<int64_t>(s.rem * static_cast<uint32_t>(t) / s.T);
+    return PACK > 1 ? b & ~static_cast<int64_t>(PACK - 1) : b;
 }
 
-// Partition t of a T-thread reference context over n elements (src/piquant.cpp:145-157): [begin, begin + len)
-__device__ __forceinline__ void ref_partition_bounds(int64_t t, int64_t n, int64_t T, int64_t pack, int64_t& begin, int64_t& len) {
-    auto first = [&](int64_t k) {
-        const int64_t b = n * k / T;
-        return k >= T ? n : (pack > 1 ? b - b % pack : b);
-    };
-    begin = first(t);
-    len = first(t + 1) - begin;
-}
+// Partition t as the reference's kernel sees it: scalar positions are [begin, head_end) and [body_end, end), SIMD-body positions [head_end, body_end).
+// BLK = elements per SIMD block of the pair's AVX-512 kernel; a head exists only where out_align >= 0.
+struct RefPart {
+    int64_t begin, head_end, body_end, end;
+};
 
-// true when global element g of a call lies in the reference's scalar head or tail (block = SIMD block of the kernel, pack = elements
-// per packed output byte): of the whole call for a one-thread context, of its partition otherwise
-__device__ __forceinline__ bool ref_scalar_position(const QuantParams& p, int64_t g, int64_t block, int64_t pack) {
-    if (p.ref_threads <= 1) {
-        const int64_t body_end = p.ref_head + ((p.ref_total - p.ref_head) / block) * block;
-        return g < p.ref_head || g >= body_end;
-    }
-    int64_t begin, len;
-    ref_partition_of(g, p.ref_total, p.ref_threads, pack, begin, len);
+template <int PACK, int BLK>
+__device__ __forceinline__ RefPart ref_part(const RefSplit& s, int64_t t) {
+    static_assert((BLK & (BLK - 1)) == 0, "SIMD blocks are powers of two");
+    RefPart r;
+    r.begin = ref_boundary<PACK>(s, t);
+    r.end = ref_boundary<PACK>(s, t + 1);
+    const int64_t len = r.end - r.begin;
     int64_t head = 0;
-    if (p.ref_out_align >= 0) {   // fp32 -> uint8: the partition's output starts at out + begin bytes
-        head = (16 - ((p.ref_out_align + begin) & 15)) & 15;
+    if (s.out_align >= 0) {   // the partition's output starts at out + begin bytes (fp32 -> uint8: one byte per element)
+        head = (16 - ((s.out_align + r.begin) & 15)) & 15;
         head = head < len ? head : len;
     }
-    const int64_t local = g - begin;
-    return local < head || local >= head + ((len - head) / block) * block;
+    r.head_end = r.begin + head;
+    r.body_end = r.head_end + ((len - head) & ~static_cast<int64_t>(BLK - 1));
+    return r;
+}
+
+// index of the partition that holds global element g (0 <= g < n): the estimate g T / n in double is within one of it, the exact boundaries decide
+template <int PACK>
+__device__ __forceinline__ int64_t ref_partition_index(const RefSplit& s, int64_t g) {
+    int64_t t = static_cast<int64_t>(static_cast<double>(g) * s.rate);
+    const int64_t last = static_cast<int64_t>(s.T) - 1;
+    t = t < 0 ? 0 : (t > last ? last : t);
+    while (t > 0 && g < ref_boundary<PACK>(s, t)) --t;
+    while (t < last && g >= ref_boundary<PACK>(s, t + 1)) ++t;
+    return t;
+}
+
+// true when global element g lies in a scalar head or tail of its partition
+template <int PACK, int BLK>
+__device__ __forceinline__ bool ref_scalar_position(const RefSplit& s, int64_t g) {
+    const RefPart r = ref_part<PACK, BLK>(s, ref_partition_index<PACK>(s, g));
+    return g < r.head_end || g >= r.body_end;
+}
+
+// The vector kernels' look at a wave tile [g0, g1) of global elements, in two steps.
+// FIRST look, every tile, scalar ALU only: can the scalar window of any boundary t (0 .. T, both ends of the call included) -- the tail of
+// partition t - 1 and the head of partition t, at most BLK - 1 elements below and 15 above the boundary -- reach into the tile?  Boundary t lies in
+// (n t / T - PACK, n t / T], so the question is whether an integer lies in [x, x + w] with x = (g0 - margin) T / n: the fraction of x is a 64-bit
+// fixed-point number that advances by a constant per wave tile (f0 + tile * d, wrapping), and the answer is the carry of frac(x) + w.  One 64-bit
+// multiply-add and an add with carry on the scalar unit -- no vector instruction: this kernel has about 250 vector issue slots per wave tile, and a
+// first look in double precision (conversions, ceil, floor: quarter rate) cost 0.85 us on the 22.7 us headline launch.  The fractions are rounded
+// down, by less than tiles * 2^-64 in all -- the two elements of slack in the margins are worth at least 2^-36 for any tensor the host does not
+// flag `always`.
+// SECOND look, one tile in n / T / tile: the candidates [ta, tb] in double (exact by the same margins; relative rounding 2^-52), then the windows.
+__device__ __forceinline__ bool ref_first_look(const RefSplit& s, uint64_t wave_tile) {
+    const uint64_t f = s.f0 + wave_tile * s.d;
+    return s.always != 0 || f + s.w < f;
+}
+
+template <int PACK, int BLK>
+struct RefMargins {
+    static constexpr int below = 16 + PACK + 2, above = BLK + PACK + 2;   // elements: head reach + boundary alignment + slack; tail reach + alignment + slack
+};
+
+template <int PACK, int BLK>
+__device__ __forceinline__ void ref_candidates(const RefSplit& s, int64_t g0, int64_t g1, int32_t& ta, int32_t& tb) {
+    const double x0 = static_cast<double>(g0 - RefMargins<PACK, BLK>::below) * s.rate;
+    const double x1 = static_cast<double>(g1 + RefMargins<PACK, BLK>::above) * s.rate;
+    const double T = static_cast<double>(s.T);
+    ta = static_cast<int32_t>(__builtin_ceil(x0 < 0.0 ? 0.0 : x0));    // <= T + 1 <= 65537
+    tb = static_cast<int32_t>(__builtin_floor(x1 > T ? T : x1));
+}
+
+// The RefSplit of a streaming kernel's by-value parameter struct, fetched from the kernarg segment HERE and nowhere earlier.  Read as an ordinary
+// member, the compiler hoists the s_load to the kernel's entry (kernarg loads are speculatable) and the entry's first lgkmcnt wait -- in front of the
+// tile's global loads -- then waits for it: the price of a scalar load's latency on every launch, reference layout or not (quant_kernels.hpp has
+// the measurement for a trailing `head` argument: +0.4 us).  An asm statement stays where it is written: behind the tile's global loads, where its
+// latency disappears under theirs.  OFFSET = byte offset of the RefSplit inside the kernarg segment.
+typedef uint32_t ref_u32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t ref_u32x4 __attribute__((ext_vector_type(4)));
+template <uint32_t OFFSET>
+__device__ __forceinline__ RefSplit load_ref_split() {
+    static_assert(sizeof(RefSplit) == 80 && OFFSET % 4 == 0, "twenty dwords");
+    ref_u32x16 a;
+    ref_u32x4 b;
+    asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx4 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b)
+                 : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"(OFFSET), "n"(OFFSET + 64)
+                 : "memory");
+    auto u64 = [](uint32_t lo, uint32_t hi) { return lo | static_cast<uint64_t>(hi) << 32; };
+    RefSplit r;
+    r.n = static_cast<int64_t>(u64(a[0], a[1]));
+    r.q = static_cast<int64_t>(u64(a[2], a[3]));
+    r.rem = a[4];
+    r.T = a[5];
+    r.rate = __builtin_bit_cast(double, u64(a[6], a[7]));
+    r.index0 = static_cast<int64_t>(u64(a[8], a[9]));
+    r.out_align = static_cast<int32_t>(a[10]);
+    r.on = static_cast<int32_t>(a[11]);
+    r.f0 = u64(a[12], a[13]);
+    r.d = u64(a[14], a[15]);
+    r.w = u64(b[0], b[1]);
+    r.always = static_cast<int32_t>(b[2]);
+    r.pad = 0;
+    return r;
+}
+
+// scalar window around boundary t: [lo, hi) = tail of partition t - 1 followed by the head of partition t
+template <int PACK, int BLK>
+__device__ __forceinline__ void ref_window(const RefSplit& s, int64_t t, int64_t& lo, int64_t& hi) {
+    lo = hi = ref_boundary<PACK>(s, t);
+    if (t > 0) lo = ref_part<PACK, BLK>(s, t - 1).body_end;
+    if (t < static_cast<int64_t>(s.T)) hi = ref_part<PACK, BLK>(s, t).head_end;
+}
+
+// m[k] bit e: element e0 + k * stride + e (e < EPV) of the k-th vector a lane holds is a scalar position.  [ta, tb] from ref_candidates of the wave
+// tile that holds the vectors.  A handful of candidates are walked window by window (wave-uniform arithmetic, then two compares per vector); a tile
+// that spans many partitions (a reference context with more threads than the tensor has SIMD blocks) asks element by element instead.
+constexpr int kRefWindowWalk = 4;
+template <int PACK, int BLK, int EPV, int U>
+__device__ __forceinline__ void ref_scalar_masks(const RefSplit& s, int32_t ta, int32_t tb, int64_t e0, int64_t stride, uint32_t (&m)[U]) {
+#pragma unroll
+    for (int k = 0; k < U; ++k) m[k] = 0;
+    if (tb - ta < kRefWindowWalk) {
+        for (int32_t t = ta; t <= tb; ++t) {
+            int64_t lo, hi;
+            ref_window<PACK, BLK>(s, t, lo, hi);
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const int64_t a = lo - (e0 + k * stride), b = hi - (e0 + k * stride);   // elements [max(a, 0), min(b, EPV)) of the vector
+                if (b <= 0 || a >= EPV) continue;
+                const uint32_t from = a > 0 ? static_cast<uint32_t>(a) : 0u, to = b < EPV ? static_cast<uint32_t>(b) : static_cast<uint32_t>(EPV);
+                m[k] |= ((1u << to) - 1u) & ~((1u << from) - 1u);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < U; ++k)
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                const int64_t g = e0 + k * stride + e;
+                if (g < s.n && ref_scalar_position<PACK, BLK>(s, g)) m[k] |= 1u << e;
+            }
+    }
 }
 
 // v_min_f32 / v_max_f32 return the other operand when one is a QUIET NaN -- which is how every min/max fold of this library skips NaNs --
@@ -322,8 +434,7 @@ __device__ __forceinline__ float element_threshold(const ElementKeys& k, uint64_
 
 template <int MODE, int QMAX>
 __device__ __forceinline__ uint32_t quant_one(float x, const QuantParams& p, uint64_t elem_index) {
-    if constexpr (MODE == RM_COPY) return __float_as_uint(x) & static_cast<uint32_t>(QMAX);
-    else if constexpr (MODE == RM_NEAREST_FAST) return quant_nearest_fast<QMAX>(x, p);
+    if constexpr (MODE == RM_NEAREST_FAST) return quant_nearest_fast<QMAX>(x, p);
     else if constexpr (MODE == RM_NEAREST_I64) return quant_nearest_i64<QMAX>(x, p);
     else if constexpr (MODE == RM_STOCH_CALL) return quant_stochastic<QMAX>(x, p, p.threshold);
     else return quant_stochastic<QMAX>(x, p, element_threshold(p, p.index_base + elem_index));

@@ -530,7 +530,7 @@ fused_params_quantize_kernel(const void* in0, uint8_t* out0, int64_t numel0, Par
     // per-element RNG keys: all indices of this thread lie in [first, first + 2^32) -- the resident tensor is far smaller
     [[maybe_unused]] ElementKeys keys {};
     if constexpr (MODE == RM_STOCH_ELEM) keys = element_keys_for(p, p.index_base + static_cast<uint64_t>(v_first) * EPV);
-    const BoundedStep bstep = bounded_step_for<DT_IN, BITS>(p.zp32);
+    const BoundedStep bstep = bounded_step_for<BITS>(p.zp32);
     // A block whose whole share lies inside the tensor (all but the last one or two) needs no per-vector bounds check.
     const bool full_share = (first_round + rounds_total) * BLOCK <= n_vec;
     const bool short_step = bounded_ok;   // grid-uniform: the data range decides (every rounding mode has a short step)

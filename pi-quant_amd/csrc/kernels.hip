@@ -29,17 +29,41 @@ inline unsigned capped_grid(int64_t want, int blocks_per_cu, int num_cu) {
     return static_cast<unsigned>(std::max<int64_t>(g, 1));
 }
 
-// A call that is several launches (reference-layout mode with partitions, below): only the FIRST may go out without the barrier bit of an
-// independent call (stop_event.hpp) -- the others depend on it -- and only the LAST carries a blocking call's stop event.
-struct LaunchSequence {
-    hipEvent_t stop = tl_stop_event;
-    bool any_order = tl_any_order;
-    void first() { tl_stop_event = nullptr; }
-    void middle() { tl_stop_event = nullptr; tl_any_order = false; }
-    void last() { tl_stop_event = stop; tl_any_order = false; }
-    ~LaunchSequence() { tl_stop_event = stop; tl_any_order = any_order; }
-};
-constexpr int kRefPatchMaxThreads = 1 << 20;   // partitions of a reference context the patch kernels are launched for (one block each); beyond: element by element
+// host half of RefSplit (device_math.hpp): the partition rule of a `threads`-thread reference context over a call of `total` elements
+RefSplit ref_split(bool on, int64_t total, int threads, int64_t index0, int out_align) {
+    RefSplit r {};
+    if (!on || total <= 0) return r;
+    const int64_t T = std::min<int64_t>(std::max(threads, 1), 65536);
+    r.n = total;
+    r.q = total / T;
+    r.rem = static_cast<uint32_t>(total % T);
+    r.T = static_cast<uint32_t>(T);
+    r.rate = static_cast<double>(T) / static_cast<double>(total);
+    r.index0 = index0;
+    r.out_align = out_align;
+    r.on = 1;
+    return r;
+}
+
+// The first look of the vector kernels (device_math.hpp, ref_first_look) for a kernel whose wave tiles hold `wave_tile` elements: the fractions of
+// t = g T / n at wave tile 0 and per wave tile, and a tile's width with both margins, as 0.64 fixed-point numbers (rounded down, down, up).
+void ref_prepare_first_look(RefSplit& r, int64_t wave_tile, int pack, int blk) {
+    if (!r.on) return;
+    using u128 = unsigned __int128;
+    const int below = 16 + pack + 2, above = blk + pack + 2;   // RefMargins
+    const u128 n = static_cast<u128>(r.n), T = r.T;
+    const u128 width = static_cast<u128>(wave_tile + below + above) * T;   // a tile's width in partitions, times n
+    if (width >= n || r.n > (int64_t {1} << 36)) {   // partitions no larger than a tile, or more tiles than the fixed point's slack covers
+        r.always = 1;
+        return;
+    }
+    __int128 a = (static_cast<__int128>(r.index0) - below) % static_cast<__int128>(n);
+    if (a < 0) a += static_cast<__int128>(n);
+    r.f0 = static_cast<uint64_t>((((static_cast<u128>(a) * T) % n) << 64) / n);
+    r.d = static_cast<uint64_t>(((static_cast<u128>(wave_tile) * T) << 64) / n);   // wave_tile * T < width < n
+    r.w = static_cast<uint64_t>(((width << 64) + n - 1) / n);
+    r.always = 0;
+}
 
 template <int DT_IN, int BITS, int MODE, bool SMALL = false>
 void quantize_t(const QuantLaunch& q, const QuantParams& p, hipStream_t stream, int num_cu) {
@@ -57,15 +81,11 @@ void quantize_t(const QuantLaunch& q, const QuantParams& p, hipStream_t stream, 
     // tiles (profiles/r03_tune_misaligned.csv).
     const int64_t head_bytes = static_cast<int64_t>((kStoreAlign - (reinterpret_cast<uintptr_t>(q.out) & (kStoreAlign - 1))) & (kStoreAlign - 1));
     const int64_t head = head_bytes * PACK;
-    // Reference-layout mode with scalar positions INSIDE the tensor (a scalar head shifts every SIMD block, and the partitions of a T-thread
-    // reference context put heads and tails everywhere): the vector kernel runs in the uniform form and a patch kernel behind it rewrites the
-    // heads and tails (quant_kernels.hpp, quantize_ref_patch_kernel).  Only the nearest fast step has a scalar form of its own; the other
-    // steps are the same formula at every position, layout or not.
-    const bool ref_inside = q.ref_layout && (q.ref_head != 0 || q.ref_threads > 1 || head != 0);
-    const bool ref_patch = ref_inside && MODE == RM_NEAREST_FAST;
-    // The guarded kernel remains for: inputs that are not even element-aligned, tensors that end inside the head, and reference contexts of
-    // more threads than the patch kernel is launched for.
-    if (reinterpret_cast<uintptr_t>(q.in) % ESIZE != 0 || head >= q.numel || (ref_patch && q.ref_threads > kRefPatchMaxThreads)) {
+    // Reference layout needs nothing from the launcher: a wave tile that a scalar head or tail of a reference partition reaches into quantizes those
+    // positions with the reference's scalar formula itself, in registers, before its one store (quant_kernels.hpp; until round 6 a second,
+    // dependent launch rewrote them: 22.9 -> 26.1 us per call for a 255-thread reference context).
+    // The guarded kernel remains for inputs that are not even element-aligned and tensors that end inside the head.
+    if (reinterpret_cast<uintptr_t>(q.in) % ESIZE != 0 || head >= q.numel) {
         const int64_t nbytes = (q.numel + PACK - 1) / PACK;
         const unsigned grid = capped_grid((nbytes + kScalarBlock - 1) / kScalarBlock, 16, num_cu);
         PQ_LAUNCH((quantize_scalar_kernel<DT_IN, BITS, MODE>), dim3(grid), dim3(kScalarBlock), 0, stream, q.in, out, q.numel, p);
@@ -73,22 +93,13 @@ void quantize_t(const QuantLaunch& q, const QuantParams& p, hipStream_t stream, 
     }
     QuantParams body = p;
     body.index_base += static_cast<uint64_t>(head);
-    body.ref_index0 += head;
-    if (ref_inside) body.ref_layout = 0;
+    body.ref.index0 += head;
+    if (MODE == RM_NEAREST_FAST) ref_prepare_first_look(body.ref, Tile::BLOCK_ELEMS / Tile::WAVES, PACK, QuantRefBlock<BITS>::value);
     const int64_t numel = q.numel - head;
     const int64_t n_tiles = numel / Tile::BLOCK_ELEMS;
     const unsigned grid = capped_grid(n_tiles, t.blocks_per_cu, num_cu);
-    constexpr int kVariant = BITS == 8 ? kQuantVariant : kQuantVariantSubByte;   // tuning.hpp
-    LaunchSequence seq;
-    if (ref_patch) seq.first();
-    launch_quantize_kernel<DT_IN, BITS, MODE, t.u, t.stage, t.nt, t.block, kQuantShortStep, kVariant>(
+    launch_quantize_kernel<DT_IN, BITS, MODE, t.u, t.stage, t.nt, t.block>(
         grid, 0, stream, static_cast<const void*>(static_cast<const uint8_t*>(q.in) + head * ESIZE), out + head_bytes, numel, n_tiles, body, static_cast<int>(head));
-    if constexpr (MODE == RM_NEAREST_FAST) {
-        if (ref_patch) {
-            seq.last();
-            PQ_LAUNCH((quantize_ref_patch_kernel<DT_IN, BITS>), dim3(static_cast<unsigned>(p.ref_threads)), dim3(256), 0, stream, q.in, out, q.numel, p);
-        }
-    }
 }
 
 template <int DT_IN, int BITS>
@@ -132,56 +143,21 @@ void dequantize_t(const DequantLaunch& d, const DequantParams& p, hipStream_t st
     const uintptr_t oa = reinterpret_cast<uintptr_t>(d.out);
     const int64_t head = static_cast<int64_t>((kStoreAlign - (oa & (kStoreAlign - 1))) & (kStoreAlign - 1)) / ESIZE;   // to a whole cache line (quantize_t)
     const int shift = static_cast<int>(head % PACK) * BITS;   // != 0: the body starts inside a packed byte and the kernel funnel-shifts its input (dequant_kernels.hpp)
-    // Reference-layout mode when tails lie inside the tensor (partitions of a T-thread context) or the tiles would not start at element 0: the
-    // vector kernel runs in the uniform form and patch kernels give the tails the reference's tail formula (dequant_kernels.hpp,
-    // dequantize_ref_patch_kernel).  Only bf16 outputs and the uint2 -> fp32 ADD tail (which stores) have a tail form of their own.
-    const bool ref_inside = d.ref_layout && (d.ref_threads > 1 || head != 0);
-    const bool ref_patch = ref_inside && (DT_OUT == DT_BF16 || (BITS == 2 && OP == OP_ADD));
-    bool capturing = false;
-    if (ref_patch && OP == OP_ADD) {   // the ADD flow takes stream-ordered scratch memory: not inside a capture
-        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-        capturing = hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone;
-        (void)hipGetLastError();
-    }
-    // element-wise kernel: an output that is not element-aligned, a tensor that ends inside the head, reference contexts of more threads than
-    // the patch kernels are launched for, the ADD flow inside a capture
-    if (oa % ESIZE != 0 || head >= d.numel || (ref_patch && (p.ref_threads > kRefPatchMaxThreads || capturing))) {
+    // (reference layout: tails of reference partitions are decoded with the reference's tail formula by the wave tile they fall into, dequant_kernels.hpp)
+    // element-wise kernel: an output that is not element-aligned, a tensor that ends inside the head
+    if (oa % ESIZE != 0 || head >= d.numel) {
         const unsigned grid = capped_grid((d.numel + kScalarBlock - 1) / kScalarBlock, 16, num_cu);
         PQ_LAUNCH((dequantize_scalar_kernel<BITS, DT_OUT, OP>), dim3(grid), dim3(kScalarBlock), 0, stream, in, d.out, d.numel, p);
         return;
     }
     DequantParams body = p;
-    body.ref_index0 += head;
-    if (ref_inside) body.ref_layout = 0;
+    body.ref.index0 += head;
+    if (DequantRefTail<BITS, DT_OUT, OP>::HAS_FORM) ref_prepare_first_look(body.ref, Tile::BLOCK_ELEMS / Tile::WAVES, PACK, DequantRefTail<BITS, DT_OUT, OP>::BLK);
     const int64_t numel = d.numel - head;
     const int64_t n_tiles = numel / Tile::BLOCK_ELEMS;
     const unsigned grid = capped_grid(n_tiles, t.blocks_per_cu, num_cu);
-    const dim3 parts(static_cast<unsigned>(p.ref_threads));
-    LaunchSequence seq;
-    void* scratch = nullptr;
-    if constexpr (DT_OUT == DT_BF16 || (BITS == 2 && OP == OP_ADD)) {
-        if (ref_patch && OP == OP_ADD) {     // the tails' old values are needed AFTER the vector kernel has overwritten them: stash first
-            PQ_HIP(hipMallocAsync(&scratch, static_cast<size_t>(p.ref_threads) * kRefTailSlots * ESIZE, stream));
-            seq.first();
-            PQ_LAUNCH((dequantize_ref_patch_kernel<BITS, DT_OUT, OP, PATCH_STASH>), parts, dim3(kRefTailSlots), 0, stream, in, d.out, scratch, d.numel, p);
-            seq.middle();
-        } else if (ref_patch) {
-            seq.first();
-        }
-    }
     launch_dequantize_kernel<BITS, DT_OUT, OP, t.u, t.stage, t.nt, t.block>(grid, stream, in + head / PACK, static_cast<void*>(static_cast<uint8_t*>(d.out) + head * ESIZE),
                                                                             numel, n_tiles, body, static_cast<int>(head) | (shift << 16));
-    if constexpr (DT_OUT == DT_BF16 || (BITS == 2 && OP == OP_ADD)) {
-        if (ref_patch) {
-            seq.last();
-            if (OP == OP_ADD) {
-                PQ_LAUNCH((dequantize_ref_patch_kernel<BITS, DT_OUT, OP, PATCH_UNSTASH>), parts, dim3(kRefTailSlots), 0, stream, in, d.out, scratch, d.numel, p);
-                PQ_HIP(hipFreeAsync(scratch, stream));
-            } else {
-                PQ_LAUNCH((dequantize_ref_patch_kernel<BITS, DT_OUT, OP, PATCH_DIRECT>), parts, dim3(kRefTailSlots), 0, stream, in, d.out, scratch, d.numel, p);
-            }
-        }
-    }
 }
 
 template <int BITS, int DT_OUT>
@@ -249,12 +225,7 @@ void launch_quantize(const QuantLaunch& q, hipStream_t stream, int num_cu) {
     p.seed_hi = static_cast<uint32_t>(q.seed >> 32);
     p.index_base = q.index_base;
     p.dyn = static_cast<const ParamRecord*>(q.dyn_params);
-    p.ref_layout = q.ref_layout ? 1 : 0;
-    p.ref_head = q.ref_head;
-    p.ref_total = q.ref_total;
-    p.ref_index0 = q.ref_index0;
-    p.ref_threads = q.ref_threads > 1 ? q.ref_threads : 1;
-    p.ref_out_align = q.ref_out_align;
+    p.ref = ref_split(q.ref_layout, q.ref_total, q.ref_threads, q.ref_index0, q.ref_out_align);
     switch (q.dt_in) {
         case DT_F32: quantize_bits<DT_F32>(q, p, stream, num_cu); break;
         case DT_BF16: quantize_bits<DT_BF16>(q, p, stream, num_cu); break;
@@ -455,10 +426,7 @@ void launch_dequantize(const DequantLaunch& d, hipStream_t stream, int num_cu) {
     p.zp64 = d.zero_point;
     p.zp32 = static_cast<int32_t>(static_cast<uint32_t>(static_cast<uint64_t>(d.zero_point)));
     p.dyn = static_cast<const ParamRecord*>(d.dyn_params);
-    p.ref_layout = d.ref_layout ? 1 : 0;
-    p.ref_total = d.ref_total;
-    p.ref_index0 = d.ref_index0;
-    p.ref_threads = d.ref_threads > 1 ? d.ref_threads : 1;
+    p.ref = ref_split(d.ref_layout, d.ref_total, d.ref_threads, d.ref_index0, -1);
     switch (d.dt_in) {
         case DT_UINT8: dequantize_out<8>(d, p, stream, num_cu); break;
         case DT_UINT4: dequantize_out<4>(d, p, stream, num_cu); break;
@@ -679,7 +647,11 @@ struct FlagList {
     uint32_t* ptr[kFlagListMax];
 };
 
-__global__ void __launch_bounds__(64) signal_flags_kernel(FlagList flags, int count, uint32_t value) {
+// `timeout_record` (nullable): the context's peer-timeout record.  A wait of this context that gave up earlier on the stream (report_peer_timeout
+// below) leaves its kind there, and what ran behind that wait worked on stale bytes: nothing is signalled then -- the peers must not take this rank's
+// step for done; they run into their own timeouts and name this rank, and the host finds the record at its next peer-to-peer call.
+__global__ void __launch_bounds__(64) signal_flags_kernel(FlagList flags, int count, uint32_t value, const uint32_t* timeout_record) {
+    if (timeout_record != nullptr && __hip_atomic_load(timeout_record, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != kPeerTimeoutNone) return;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     if (static_cast<int>(threadIdx.x) < count) __hip_atomic_store(flags.ptr[threadIdx.x], value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -735,6 +707,7 @@ __global__ void __launch_bounds__(64) exchange_keys_kernel(const int32_t* my_key
     const int lane = threadIdx.x;
     const unsigned long long word = static_cast<unsigned long long>(static_cast<uint32_t>(my_keys[0])) | (static_cast<unsigned long long>(static_cast<uint32_t>(my_keys[1])) << 32);
     unsigned long long got = word;   // lanes beyond the group fold this rank's own word again: harmless for a minimum
+    bool gave_up = false;
     if (lane < count) {
         __hip_atomic_store(peers.slot[lane], word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         const uint64_t t_begin = wall_clock64();
@@ -742,14 +715,17 @@ __global__ void __launch_bounds__(64) exchange_keys_kernel(const int32_t* my_key
             got = __hip_atomic_load(mine + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
             if (got != kKeyWordEmpty) break;
             __builtin_amdgcn_s_sleep(8);
-            if (wall_clock64() - t_begin > timeout_ticks) {   // rank `lane` never arrived: report it, fold the own word in its place (the result is void)
-                report_peer_timeout(timeout_record, kPeerTimeoutKeys, static_cast<uint32_t>(lane), 0u, 0u);
+            if (wall_clock64() - t_begin > timeout_ticks) {   // rank `lane` never arrived: fold the own word in its place (the result is void) and report below
+                gave_up = true;
                 got = word;
                 break;
             }
         }
         __hip_atomic_store(mine + lane, kKeyWordEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // read: empty again, for the exchange after next
     }
+    // ONE reporter, the lowest missing rank (as wait_flags_kernel): several lanes writing the record's fields at once could interleave them
+    const unsigned long long late = __ballot(gave_up ? 1 : 0);
+    if (late != 0 && lane == __builtin_ctzll(late)) report_peer_timeout(timeout_record, kPeerTimeoutKeys, static_cast<uint32_t>(lane), 0u, 0u);
     const int32_t k0 = wave_min_i32(static_cast<int32_t>(static_cast<uint32_t>(got)));
     const int32_t k1 = wave_min_i32(static_cast<int32_t>(static_cast<uint32_t>(got >> 32)));
     if (lane == 0) {
@@ -771,12 +747,12 @@ void launch_exchange_keys(const int32_t* my_keys, unsigned long long* const* pee
     PQ_HIP(hipGetLastError());
 }
 
-void launch_signal_flags(uint32_t* const* flags, int count, uint32_t value, hipStream_t stream) {
+void launch_signal_flags(uint32_t* const* flags, int count, uint32_t value, const uint32_t* timeout_record, hipStream_t stream) {
     for (int first = 0; first < count; first += kFlagListMax) {
         FlagList list {};
         const int n = std::min(kFlagListMax, count - first);
         for (int i = 0; i < n; ++i) list.ptr[i] = flags[first + i];
-        hipLaunchKernelGGL(signal_flags_kernel, dim3(1), dim3(64), 0, stream, list, n, value);
+        hipLaunchKernelGGL(signal_flags_kernel, dim3(1), dim3(64), 0, stream, list, n, value, timeout_record);
     }
     PQ_HIP(hipGetLastError());
 }

@@ -20,7 +20,6 @@ struct QuantLaunch {
     uint64_t index_base;
     const void* dyn_params;   // nullable: 16-byte device ParamRecord overriding inv_scale / zero_point
     bool ref_layout;          // reference-layout mode (see QuantParams)
-    int ref_head;
     int64_t ref_total;
     int64_t ref_index0;
     int ref_threads;          // pool threads of the reference context being reproduced (0 / 1: one partition)
@@ -148,7 +147,7 @@ bool launch_fused_reduce_quantize(const QuantLaunch& q, const DequantSumLaunch& 
 void launch_publish_seq(uint32_t* host_visible_word, uint32_t seq, hipStream_t stream);
 // peer-to-peer schedules: `value` into every flags[i] (addresses other devices / processes poll), and the wait for every flags[i] to reach it
 constexpr int kFlagListMax = 32;
-void launch_signal_flags(uint32_t* const* flags, int count, uint32_t value, hipStream_t stream);
+void launch_signal_flags(uint32_t* const* flags, int count, uint32_t value, const uint32_t* timeout_record, hipStream_t stream);   // record set (a wait gave up): signals nothing
 // A peer that does not arrive within the limit is REPORTED, not trapped on: {kind, index of the missing rank, value waited for, value seen} in
 // `timeout_record` (4 pinned host-coherent words; nullptr: trap) and the stream goes on (kernels.hip, report_peer_timeout)
 constexpr uint32_t kPeerTimeoutDefaultUs = 600000000u;   // 10 minutes

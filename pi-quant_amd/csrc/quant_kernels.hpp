@@ -88,8 +88,16 @@ struct InVec {
     }
 };
 
-// Guarded path: one output byte per iteration, any alignment, any numel.  Used for the ragged tail of the
-// vector kernel and, through quantize_scalar_kernel, for misaligned buffers.
+// SIMD block of the reference's AVX-512 quantize kernels, i.e. what its scalar tail is the remainder of: 64 elements for 8-bit outputs
+// (kernels_specialized.inl:57,202), 16 for the packed ones (:334, :504, :669)
+template <int BITS>
+struct QuantRefBlock {
+    static constexpr int value = BITS == 8 ? 64 : 16;
+};
+
+// Guarded path: one output byte per iteration, any alignment, any numel.  Used for the ragged tail and the peeled head of the vector kernel and,
+// through quantize_scalar_kernel, for buffers that are not even element-aligned.  Reference layout: the elements of a packed byte share their
+// partition (boundaries are whole bytes), so the partition is looked up once per byte.
 template <int DT_IN, int BITS, int MODE>
 __device__ __forceinline__ void quantize_bytes_guarded(const void* in, uint8_t* out, int64_t numel, int64_t byte_begin,
                                                        int64_t byte_end, const QuantParams& p, int64_t tid,
@@ -97,6 +105,10 @@ __device__ __forceinline__ void quantize_bytes_guarded(const void* in, uint8_t* 
     constexpr int PACK = 8 / BITS;
     constexpr int QMAX = (1 << BITS) - 1;
     for (int64_t b = byte_begin + tid; b < byte_end; b += nthreads) {
+        [[maybe_unused]] RefPart part {};
+        if constexpr (MODE == RM_NEAREST_FAST) {
+            if (p.ref.on) part = ref_part<PACK, QuantRefBlock<BITS>::value>(p.ref, ref_partition_index<PACK>(p.ref, p.ref.index0 + b * PACK));
+        }
         uint32_t acc = 0;
 #pragma unroll
         for (int k = 0; k < PACK; ++k) {
@@ -104,10 +116,13 @@ __device__ __forceinline__ void quantize_bytes_guarded(const void* in, uint8_t* 
             if (i >= numel) continue;
             const float x = InVec<DT_IN>::load_scalar(in, i);
             uint32_t q;
-            if (MODE == RM_NEAREST_FAST && p.ref_layout && ref_scalar_position(p, p.ref_index0 + i, BITS == 8 ? 64 : 16, PACK))
-                q = quant_nearest_tail32<QMAX>(x, p);      // reference-layout mode: the reference's scalar head/tail formula here
-            else
-                q = quant_one<MODE, QMAX>(x, p, static_cast<uint64_t>(i));
+            bool scalar_form = false;
+            if constexpr (MODE == RM_NEAREST_FAST) {
+                const int64_t g = p.ref.index0 + i;
+                scalar_form = p.ref.on && (g < part.head_end || g >= part.body_end);
+            }
+            if (scalar_form) q = quant_nearest_tail32<QMAX>(x, p);      // the reference's scalar head / tail formula at this position
+            else q = quant_one<MODE, QMAX>(x, p, static_cast<uint64_t>(i));
             acc |= q << (k * BITS);
         }
         out[b] = static_cast<uint8_t>(acc);
@@ -122,44 +137,6 @@ __global__ void __launch_bounds__(256) quantize_scalar_kernel(const void* in, ui
     quantize_bytes_guarded<DT_IN, BITS, MODE>(in, out, numel, 0, nbytes, p,
                                               static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x,
                                               static_cast<int64_t>(gridDim.x) * blockDim.x);
-}
-
-// Reference-layout mode with scalar positions INSIDE the tensor (the partitions of a T-thread reference context, a scalar head in front of a
-// misaligned output): the vector kernel quantizes the whole call with the SIMD-body formula, and this kernel -- launched behind it, one block per
-// partition -- rewrites the partition's scalar head and tail (at most 15 + 63 elements, whole packed bytes) with the reference's scalar formula
-// through the guarded path.  The element-by-element kernel used to take such calls whole: 124-213 us at numel 27 264 000 against 23.
-template <int DT_IN, int BITS>
-__global__ void __launch_bounds__(256) quantize_ref_patch_kernel(const void* in, uint8_t* out, int64_t numel, QuantParams p_arg) {
-    const QuantParams p = resolved(p_arg);
-    constexpr int PACK = 8 / BITS;
-    constexpr int64_t BLK = BITS == 8 ? 64 : 16;
-    int64_t begin = 0, len = p.ref_total, head = p.ref_head;
-    if (p.ref_threads > 1) {
-        ref_partition_bounds(blockIdx.x, p.ref_total, p.ref_threads, PACK, begin, len);
-        head = 0;
-        if (p.ref_out_align >= 0) head = (16 - ((p.ref_out_align + begin) & 15)) & 15;
-    }
-    head = head < len ? head : len;
-    const int64_t body = ((len - head) / BLK) * BLK;
-    // global element ranges -> bytes of THIS launch (a chunk of a staged host call covers [ref_index0, ref_index0 + numel) of the call)
-    const int64_t ranges[2][2] = {{begin, begin + head}, {begin + head + body, begin + len}};
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        int64_t lo = ranges[r][0] - p.ref_index0, hi = ranges[r][1] - p.ref_index0;
-        lo = lo < 0 ? 0 : lo;
-        hi = hi > numel ? numel : hi;
-        // every element of these bytes is a scalar position by construction (both ends of a range are whole packed bytes, the tensor's ragged last
-        // byte aside): the reference's scalar formula without asking ref_scalar_position -- its 64-bit divisions per element were most of this kernel
-        for (int64_t b = lo / PACK + threadIdx.x; b < (hi + PACK - 1) / PACK; b += blockDim.x) {
-            uint32_t acc = 0;
-#pragma unroll
-            for (int k = 0; k < PACK; ++k) {
-                const int64_t i = b * PACK + k;
-                if (i < numel) acc |= quant_nearest_tail32<(1 << BITS) - 1>(InVec<DT_IN>::load_scalar(in, i), p) << (k * BITS);
-            }
-            out[b] = static_cast<uint8_t>(acc);
-        }
-    }
 }
 
 // one 16-byte input vector -> WORDS packed 32-bit words (OB = EPV*BITS/8 bytes of output)
@@ -193,59 +170,22 @@ __device__ __forceinline__ void quantize_vec(const u32x4& raw, const QuantParams
     }
 }
 
-// Clamp + convert + pack for every output width through ONE instruction per element.  gfx950's v_cvt_pk_u8_f32 converts a float to uint8 with
+// Clamp + convert + pack for 8-bit outputs through ONE instruction per element.  gfx950's v_cvt_pk_u8_f32 converts a float to uint8 with
 // saturation to [0, 255] (NaN -> 0) and inserts it into a chosen byte of a word.  It rounds to nearest even, so it is fed integer-valued floats
-// only (tools/probe_cvt_pk_u8.hip).  For 8-bit output that is the whole job:  clamp(t + zp, 0, 255) == sat_u8(float(t) + float(zp)).
-// For 4- and 2-bit output the value is scaled by K = 255 / QMAX (17 or 85) first:
-//     sat_u8((t + zp) * K)  ==  clamp(t + zp, 0, QMAX) * K          (0 * K = 0, QMAX * K = 255, everything between is exact)
-// and q * 17 = q | q << 4, q * 85 = q replicated into all four 2-bit fields: the byte holds the clamped value in EVERY field, and packing
-// is a byte shuffle (v_perm_b32) plus bit-field inserts that pick field k of element k -- 3 instructions per 8 nibbles, 7 per 8 two-bit fields,
-// instead of a v_med3_f32 + v_cvt_i32_f32 + v_lshl_add_u32 per element.  The scaled sum is ONE fma: exact while |t| < 2^16, and beyond that so
-// far outside [0, 255], with the right sign, that its rounding cannot matter.
-template <int BITS>
-struct SatScale {
-    static constexpr float K = BITS == 8 ? 1.0f : (BITS == 4 ? 17.0f : 85.0f);
-};
-
+// only (tools/probe_cvt_pk_u8.hip):  clamp(t + zp, 0, 255) == sat_u8(float(t) + float(zp)), and the sum is exact while |t| < 2^24 -- beyond that it
+// is so far outside [0, 255], with the right sign, that its rounding cannot matter.  (4- and 2-bit outputs went the same way in a scaled domain
+// until round 6 -- the fused kernel's form; they take pack_normalised below everywhere now: same bytes, three instructions fewer per vector.)
 __device__ __forceinline__ uint32_t bfi32(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }   // v_bfi_b32
 
-// tz[e] = (t_e + zp) * K as floats (integer-valued, or NaN / huge)  ->  the packed words of one input vector
-template <int BITS, int EPV>
-__device__ __forceinline__ void pack_saturated(const float (&tz)[EPV], uint32_t (&w)[(EPV * BITS / 8) > 4 ? 2 : 1]) {
-    uint32_t c[EPV / 4];   // four saturated bytes per word, element order
+// tz[e] = float(t_e + zp) (integer-valued, or NaN / huge)  ->  the packed words of one input vector
+template <int EPV>
+__device__ __forceinline__ void pack_saturated_u8(const float (&tz)[EPV], uint32_t (&w)[EPV / 4]) {
 #pragma unroll
     for (int j = 0; j < EPV / 4; ++j) {
         uint32_t acc = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_cvt_pk_u8_f32(tz[j * 4 + e], static_cast<uint32_t>(e), acc);
-        c[j] = acc;
-    }
-    if constexpr (BITS == 8) {
-#pragma unroll
-        for (int j = 0; j < EPV / 4; ++j) w[j] = c[j];
-    } else if constexpr (BITS == 4) {
-        // even elements keep their low nibble, odd elements their high one
-        if constexpr (EPV == 8) {
-            const uint32_t even = __builtin_amdgcn_perm(c[1], c[0], 0x06040200u);   // bytes {c0.b0, c0.b2, c1.b0, c1.b2}
-            const uint32_t odd = __builtin_amdgcn_perm(c[1], c[0], 0x07050301u);    //       {c0.b1, c0.b3, c1.b1, c1.b3}
-            w[0] = bfi32(0x0f0f0f0fu, even, odd);
-        } else {
-            const uint32_t even = __builtin_amdgcn_perm(0u, c[0], 0x0c0c0200u);
-            const uint32_t odd = __builtin_amdgcn_perm(0u, c[0], 0x0c0c0301u);
-            w[0] = bfi32(0x0f0f0f0fu, even, odd);
-        }
-    } else {
-        // a byte holds its element in all four 2-bit fields: {e0, e1} of a pair of bytes -> fields {0, 1, 0, 1}, then pairs -> {0, 1, 2, 3}
-        uint32_t u[EPV / 4];   // bytes 0 and 2 of u[j]: fields {e0, e1, e0, e1} and {e2, e3, e2, e3}
-#pragma unroll
-        for (int j = 0; j < EPV / 4; ++j) u[j] = bfi32(0x33333333u, c[j], c[j] >> 8);
-        if constexpr (EPV == 8) {
-            const uint32_t lo = __builtin_amdgcn_perm(u[1], u[0], 0x0c0c0400u);     // bytes {u0.b0, u1.b0}
-            const uint32_t hi = __builtin_amdgcn_perm(u[1], u[0], 0x0c0c0602u);     //       {u0.b2, u1.b2}
-            w[0] = bfi32(0x0f0f0f0fu, lo, hi);
-        } else {
-            w[0] = bfi32(0x0fu, u[0], u[0] >> 16) & 0xffu;
-        }
+        w[j] = acc;
     }
 }
 
@@ -260,7 +200,6 @@ __device__ __forceinline__ void pack_saturated(const float (&tz)[EPV], uint32_t 
 //                        takes low nibbles from the first and high nibbles from the second: 4 + 3 instructions (8 + 3 through v_cvt_pk_u8_f32)
 //   2 bits, 8 elements   A = P(e0,e4) B = P(e1,e5) C = P(e2,e6) D = P(e3,e7); bfi(0x3333.., A, B) and bfi(0x3333.., C, D) interleave fields, bfi(0x0f0f.., .., ..)
 //                        nibbles: the low half holds byte {e0,e1,e2,e3}, the high half {e4,e5,e6,e7}; one v_perm: 4 + 4 (8 + 7)
-//   8 bits               P(e0,e1) P(e2,e3) -> one v_perm per four elements: 2 + 1 (4)
 template <int BITS, int EPV>
 __device__ __forceinline__ void pack_normalised(const float (&tn)[EPV], uint32_t (&w)[(EPV * BITS / 8) > 4 ? 2 : 1]) {
     auto P = [](float a, float b) -> uint32_t {
@@ -269,10 +208,8 @@ __device__ __forceinline__ void pack_normalised(const float (&tn)[EPV], uint32_t
         return __builtin_bit_cast(uint32_t, r);
     };
     constexpr uint32_t LOW_BYTES = 0x06040200u;   // v_perm_b32(hi, lo): {lo.b0, lo.b2, hi.b0, hi.b2}
-    if constexpr (BITS == 8) {
-#pragma unroll
-        for (int j = 0; j < EPV / 4; ++j) w[j] = __builtin_amdgcn_perm(P(tn[4 * j + 2], tn[4 * j + 3]), P(tn[4 * j], tn[4 * j + 1]), LOW_BYTES);
-    } else if constexpr (BITS == 4) {
+    static_assert(BITS == 4 || BITS == 2, "8-bit outputs gain nothing from the normalised domain (one v_perm per four elements against nothing): pack_saturated_u8");
+    if constexpr (BITS == 4) {
         if constexpr (EPV == 8) {
             const uint32_t even = __builtin_amdgcn_perm(P(tn[4], tn[6]), P(tn[0], tn[2]), LOW_BYTES);
             const uint32_t odd = __builtin_amdgcn_perm(P(tn[5], tn[7]), P(tn[1], tn[3]), LOW_BYTES);
@@ -294,11 +231,6 @@ __device__ __forceinline__ void pack_normalised(const float (&tn)[EPV], uint32_t
     }
 }
 
-#ifndef PQ_GENERIC_ROUND_DIRECTED
-#define PQ_GENERIC_ROUND_DIRECTED 1
-#endif
-constexpr bool kGenericRoundDirected = PQ_GENERIC_ROUND_DIRECTED != 0;   // fp32 -> uint2's std::round as floor(RD(|p| + 0.5)) (add_half_abs_round_down); 0: roundf, for the A/B
-
 // out[e] = RD(|r[e]| + 0.5): the sum rounded TOWARDS -INFINITY (the fp32 rounding field of the wave's MODE register around the additions, one asm
 // statement: see sub_abs_round_up below for why).  For the generic nearest step -- std::round, half away from zero (quantize.inl:21-26) -- which in
 // real numbers is sign(p) * floor(|p| + 0.5): the fp32 sum may round UP across an integer (0.49999997 + 0.5 -> 1.0, where std::round gives 0), but
@@ -314,93 +246,65 @@ __device__ __forceinline__ void add_half_abs_round_down(const float (&r)[N], flo
                  : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]));
 }
 
+// tz[e] = the integer-valued float s[e] (= q - zp before the clamp) moved into the packing domain of the output width: + float(zp) for 8-bit outputs
+// (pack_saturated_u8), (s + zp) / QMAX a third of a 16-bit step up for the packed ones (pack_normalised; the one place a fused multiply-add is wanted)
+template <int BITS, int EPV>
+__device__ __forceinline__ void clamp_and_pack(const float (&s)[EPV], const BoundedStep& b, uint32_t (&w)[(EPV * BITS / 8) > 4 ? 2 : 1]) {
+#pragma clang fp contract(off)
+    constexpr float R = 1.0f / static_cast<float>((1 << BITS) - 1);
+    float tz[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; e += 2) {
+        const f32x2 pair = {s[e], s[e + 1]};
+        f32x2 sum;
+        if constexpr (BITS == 8) sum = pair + b.zp_float;
+        else sum = __builtin_elementwise_fma(pair, f32x2 {R, R}, f32x2 {b.zp_norm, b.zp_norm});
+        tz[e] = sum[0];
+        tz[e + 1] = sum[1];
+    }
+    if constexpr (BITS == 8) pack_saturated_u8<EPV>(tz, w);
+    else pack_normalised<BITS, EPV>(tz, w);
+}
+
 // The nearest step for a call whose data range is known (device_math.hpp, BoundedStep): per element a packed multiply and add, the
-// copysign and a truncation give the integer-valued float t = q - zp, one packed fma moves it into the scaled domain and pack_saturated
-// clamps, converts and packs.  (SAT = false keeps round 2's form for the tune harness' A/B: v_med3_f32 + v_cvt_i32_f32 per element and
-// Horner steps w = (w << BITS) + t, the zero point added to all fields of a word at once.)
+// copysign and a truncation give the integer-valued float t = q - zp, one packed add / fma moves it into the packing domain and one conversion per
+// element (or per two) clamps, converts and packs.
 // GENERIC selects the rounding of the reference's generic nearest step (std::round, quantize.inl:21-26 -- the only form fp32 ->
-// uint2 has) instead of the SIMD bodies' trunc(p + copysign(0.5, p)); under the same range condition its int64 arithmetic
-// gives the same integers as the clamp in the float domain, and a NaN again ends at 0.
-enum : int { PACK_HORNER = 0, PACK_SATURATED = 1, PACK_NORMALISED = 2 };
-template <int DT_IN, int BITS, bool GENERIC = false, int PACK = PACK_SATURATED>
+// uint2 has) instead of the SIMD bodies' trunc(p + copysign(0.5, p)): floor(RD(|p| + 0.5)) with the sign put back (add_half_abs_round_down); under
+// the same range condition its int64 arithmetic gives the same integers as the clamp in the float domain, and a NaN again ends at 0.
+template <int DT_IN, int BITS, bool GENERIC = false>
 __device__ __forceinline__ void quantize_vec_bounded(const u32x4& raw, float inv_scale, const BoundedStep& b,
                                                      uint32_t (&w)[(InVec<DT_IN>::EPV * BITS / 8) > 4 ? 2 : 1]) {
 #pragma clang fp contract(off)
-    constexpr int EPV = InVec<DT_IN>::EPV, WORDS = (EPV * BITS / 8) > 4 ? 2 : 1, EPW = EPV / WORDS;
+    constexpr int EPV = InVec<DT_IN>::EPV;
     float v[EPV];
     InVec<DT_IN>::unpack(raw, v);
-    if constexpr (PACK != PACK_HORNER || BITS == 8) {
-        constexpr float K = SatScale<BITS>::K, R = 1.0f / static_cast<float>((1 << BITS) - 1);
-        float tz[EPV];
-        [[maybe_unused]] float rounded[EPV];
-        if constexpr (GENERIC && kGenericRoundDirected) {   // std::round of all products as floor(RD(|p| + 0.5)) with the sign put back
-            float prods[EPV], sums[EPV];
-#pragma unroll
-            for (int e = 0; e < EPV; e += 2) {
-                const f32x2 x = {v[e], v[e + 1]};
-                const f32x2 prod = x * inv_scale;
-                prods[e] = prod[0];
-                prods[e + 1] = prod[1];
-            }
-            add_half_abs_round_down<EPV>(prods, sums);
-#pragma unroll
-            for (int e = 0; e < EPV; ++e) rounded[e] = __builtin_copysignf(__builtin_floorf(sums[e]), prods[e]);
-        }
+    float t[EPV];
+    if constexpr (GENERIC) {
+        float prods[EPV], sums[EPV];
 #pragma unroll
         for (int e = 0; e < EPV; e += 2) {
             const f32x2 x = {v[e], v[e + 1]};
             const f32x2 prod = x * inv_scale;
-            f32x2 tr;
-            if constexpr (GENERIC && kGenericRoundDirected) {
-                tr = f32x2 {rounded[e], rounded[e + 1]};
-            } else if constexpr (GENERIC) {
-                tr = f32x2 {roundf(prod[0]), roundf(prod[1])};
-            } else {
-                const f32x2 half = {__builtin_copysignf(0.5f, prod[0]), __builtin_copysignf(0.5f, prod[1])};
-                const f32x2 adj = prod + half;
-                tr = f32x2 {__builtin_truncf(adj[0]), __builtin_truncf(adj[1])};
-            }
-            f32x2 sum;
-            if constexpr (PACK == PACK_NORMALISED) sum = __builtin_elementwise_fma(tr, f32x2 {R, R}, f32x2 {b.zp_norm, b.zp_norm});
-            else if constexpr (BITS == 8) sum = tr + b.zp_scaled;
-            else sum = __builtin_elementwise_fma(tr, f32x2 {K, K}, f32x2 {b.zp_scaled, b.zp_scaled});   // the one place a fused multiply-add is wanted
-            tz[e] = sum[0];
-            tz[e + 1] = sum[1];
+            prods[e] = prod[0];
+            prods[e + 1] = prod[1];
         }
-        if constexpr (PACK == PACK_NORMALISED) pack_normalised<BITS, EPV>(tz, w);
-        else pack_saturated<BITS, EPV>(tz, w);
-        return;
-    }
-    int32_t t[EPV];
+        add_half_abs_round_down<EPV>(prods, sums);
 #pragma unroll
-    for (int e = 0; e < EPV; e += 2) {
-        const f32x2 x = {v[e], v[e + 1]};
-        const f32x2 prod = x * inv_scale;
-        f32x2 adj;
-        if constexpr (GENERIC) {
-            adj = f32x2 {roundf(prod[0]), roundf(prod[1])};
-        } else {
+        for (int e = 0; e < EPV; ++e) t[e] = __builtin_copysignf(__builtin_floorf(sums[e]), prods[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPV; e += 2) {
+            const f32x2 x = {v[e], v[e + 1]};
+            const f32x2 prod = x * inv_scale;
             const f32x2 half = {__builtin_copysignf(0.5f, prod[0]), __builtin_copysignf(0.5f, prod[1])};
-            adj = prod + half;
+            const f32x2 adj = prod + half;
+            t[e] = __builtin_truncf(adj[0]);
+            t[e + 1] = __builtin_truncf(adj[1]);
         }
-        t[e] = quant_nearest_bounded_offset(adj[0], b);
-        t[e + 1] = quant_nearest_bounded_offset(adj[1], b);
     }
-#pragma unroll
-    for (int j = 0; j < WORDS; ++j) {
-        uint32_t acc = static_cast<uint32_t>(t[j * EPW + EPW - 1]);
-#pragma unroll
-        for (int e = EPW - 2; e >= 0; --e) acc = (acc << BITS) + static_cast<uint32_t>(t[j * EPW + e]);
-        w[j] = acc + b.zp_word;
-    }
+    clamp_and_pack<BITS, EPV>(t, b, w);
 }
-
-// The stochastic short step as ceil(RU(|r| - tau)) (quantize_vec_bounded_stochastic below: three instructions per element for the +-1
-// adjustment and the truncation instead of five and a half).  false: rounds 2-4's form, for the tune harness' A/B.  profiles/r05_stochastic_ceil_step_ab.json
-#ifndef PQ_STOCH_CEIL_STEP
-#define PQ_STOCH_CEIL_STEP 1
-#endif
-constexpr bool kStochCeilStep = PQ_STOCH_CEIL_STEP != 0;
 
 // out[e] = RU(|r[e]| - t[e]): the subtraction rounded TOWARDS +INFINITY, whatever the wave's rounding mode is set to.  gfx9 has no per-instruction
 // rounding control: the mode is two bits of the wave's MODE register, so the subtractions of one vector sit between two s_setreg_imm32_b32
@@ -443,7 +347,7 @@ __device__ __forceinline__ void sub_abs_round_up(const float (&r)[N], const floa
 // gives adj = 0, tr = NaN and ends at 0, where the reference's INT64_MIN + zp is clamped to).  copysign(1, r) stands
 // for "if r < 0, adj = -adj": the two differ only for r = -0.0, where |r - tr| = 0 is never above a threshold and adj is 0 anyway.
 //
-// CEIL form (round 5, kStochCeilStep): the same integer in three instructions per element instead of five and a half.  With a = |r| and
+// CEIL form (round 5): the same integer in three instructions per element instead of the literal form's five and a half.  With a = |r| and
 // 0 <= tau < 1 (the host guarantees it for a call's threshold, the hash for an element's), in real numbers
 //     floor(a) + [a - floor(a) > tau]  ==  ceil(a - tau)
 // (a - tau = floor(a) + (frac - tau) with 0 < frac - tau < 1 when the fraction is above the threshold, floor(a) - (tau - frac) with
@@ -453,110 +357,56 @@ __device__ __forceinline__ void sub_abs_round_up(const float (&r)[N], const floa
 // v_sub_f32 with the wave in round-up mode (sub_abs_round_up), v_ceil_f32, and v_bfi_b32 puts the sign of r back: compare, select, signed one
 // and the two additions are gone.  tau == fraction exactly gives v = floor(a): no step, as the reference's strict `<`; a = 0 gives -0 -> 0.
 // Tiles with a NaN never come here (the short step's range test), so |NaN| - tau needs no thought.
-template <int DT_IN, int BITS, int MODE, int PACK = PACK_SATURATED>
+template <int DT_IN, int BITS, int MODE>
 __device__ __forceinline__ void quantize_vec_bounded_stochastic(const u32x4& raw, const QuantParams& p, const ElementKeys& keys, uint64_t e0,
                                                                 const BoundedStep& b, uint32_t (&w)[(InVec<DT_IN>::EPV * BITS / 8) > 4 ? 2 : 1]) {
 #pragma clang fp contract(off)
     static_assert(MODE == RM_STOCH_CALL || MODE == RM_STOCH_ELEM, "stochastic modes only");
-    constexpr int EPV = InVec<DT_IN>::EPV, WORDS = (EPV * BITS / 8) > 4 ? 2 : 1, EPW = EPV / WORDS;
+    constexpr int EPV = InVec<DT_IN>::EPV;
     float v[EPV];
     InVec<DT_IN>::unpack(raw, v);
-    float s[EPV];
-    if constexpr (kStochCeilStep) {
-        float r[EPV], tau[EPV], a[EPV];
+    float s[EPV], r[EPV], tau[EPV], a[EPV];
 #pragma unroll
-        for (int e = 0; e < EPV; e += 2) {
-            const f32x2 x = {v[e], v[e + 1]};
-            const f32x2 prod = x * p.inv_scale;
-            r[e] = prod[0];
-            r[e + 1] = prod[1];
-        }
-#pragma unroll
-        for (int e = 0; e < EPV; ++e) tau[e] = MODE == RM_STOCH_ELEM ? element_threshold(keys, p.index_base + e0 + e) : p.threshold;
-        sub_abs_round_up<EPV, MODE == RM_STOCH_CALL>(r, tau, a);
-#pragma unroll
-        for (int e = 0; e < EPV; ++e) s[e] = __builtin_copysignf(__builtin_ceilf(a[e]), r[e]);
-    } else {
-#pragma unroll
-        for (int e = 0; e < EPV; e += 2) {
-            const f32x2 x = {v[e], v[e + 1]};
-            const f32x2 r = x * p.inv_scale;
-            const f32x2 tr = {__builtin_truncf(r[0]), __builtin_truncf(r[1])};
-            const f32x2 d = r - tr;
-            float t0 = p.threshold, t1 = p.threshold;
-            if constexpr (MODE == RM_STOCH_ELEM) {
-                t0 = element_threshold(keys, p.index_base + e0 + e);
-                t1 = element_threshold(keys, p.index_base + e0 + e + 1);
-            }
-            const f32x2 adj = {t0 < __builtin_fabsf(d[0]) ? __builtin_copysignf(1.0f, r[0]) : 0.0f,
-                               t1 < __builtin_fabsf(d[1]) ? __builtin_copysignf(1.0f, r[1]) : 0.0f};
-            const f32x2 sum = tr + adj;
-            s[e] = sum[0];
-            s[e + 1] = sum[1];
-        }
+    for (int e = 0; e < EPV; e += 2) {
+        const f32x2 x = {v[e], v[e + 1]};
+        const f32x2 prod = x * p.inv_scale;
+        r[e] = prod[0];
+        r[e + 1] = prod[1];
     }
-    if constexpr (PACK != PACK_HORNER || BITS == 8) {
-        constexpr float K = SatScale<BITS>::K, R = 1.0f / static_cast<float>((1 << BITS) - 1);
-        float tz[EPV];
 #pragma unroll
-        for (int e = 0; e < EPV; e += 2) {
-            const f32x2 pair = {s[e], s[e + 1]};
-            f32x2 sum;
-            if constexpr (PACK == PACK_NORMALISED) sum = __builtin_elementwise_fma(pair, f32x2 {R, R}, f32x2 {b.zp_norm, b.zp_norm});
-            else if constexpr (BITS == 8) sum = pair + b.zp_scaled;
-            else sum = __builtin_elementwise_fma(pair, f32x2 {K, K}, f32x2 {b.zp_scaled, b.zp_scaled});
-            tz[e] = sum[0];
-            tz[e + 1] = sum[1];
-        }
-        if constexpr (PACK == PACK_NORMALISED) pack_normalised<BITS, EPV>(tz, w);
-        else pack_saturated<BITS, EPV>(tz, w);
-    } else {
+    for (int e = 0; e < EPV; ++e) tau[e] = MODE == RM_STOCH_ELEM ? element_threshold(keys, p.index_base + e0 + e) : p.threshold;
+    sub_abs_round_up<EPV, MODE == RM_STOCH_CALL>(r, tau, a);
 #pragma unroll
-        for (int j = 0; j < WORDS; ++j) {
-            uint32_t acc = static_cast<uint32_t>(quant_nearest_bounded_offset(s[j * EPW + EPW - 1], b));
-#pragma unroll
-            for (int e = EPW - 2; e >= 0; --e) acc = (acc << BITS) + static_cast<uint32_t>(quant_nearest_bounded_offset(s[j * EPW + e], b));
-            w[j] = acc + b.zp_word;
-        }
-    }
+    for (int e = 0; e < EPV; ++e) s[e] = __builtin_copysignf(__builtin_ceilf(a[e]), r[e]);
+    clamp_and_pack<BITS, EPV>(s, b, w);
 }
 
 // The short step of whatever rounding mode the kernel was built for.
-template <int DT_IN, int BITS, int MODE, int PACK = PACK_SATURATED>
+template <int DT_IN, int BITS, int MODE>
 __device__ __forceinline__ void quantize_vec_short(const u32x4& raw, const QuantParams& p, const ElementKeys& keys, uint64_t e0, const BoundedStep& b,
                                                    uint32_t (&w)[(InVec<DT_IN>::EPV * BITS / 8) > 4 ? 2 : 1]) {
-    if constexpr (MODE == RM_NEAREST_FAST || MODE == RM_NEAREST_I64) quantize_vec_bounded<DT_IN, BITS, MODE == RM_NEAREST_I64, PACK>(raw, p.inv_scale, b, w);
-    else quantize_vec_bounded_stochastic<DT_IN, BITS, MODE, PACK>(raw, p, keys, e0, b, w);
+    if constexpr (MODE == RM_NEAREST_FAST || MODE == RM_NEAREST_I64) quantize_vec_bounded<DT_IN, BITS, MODE == RM_NEAREST_I64>(raw, p.inv_scale, b, w);
+    else quantize_vec_bounded_stochastic<DT_IN, BITS, MODE>(raw, p, keys, e0, b, w);
 }
 
-// BoundedStep of a zero point that lies inside the quantized range (0 <= zp <= 2^BITS - 1): the clamp bounds as floats and the
-// zero point replicated into every field of a packed word.
-template <int DT_IN, int BITS>
+// BoundedStep of a zero point that lies inside the quantized range (0 <= zp <= 2^BITS - 1): the zero point in the two packing domains
+template <int BITS>
 __device__ __forceinline__ BoundedStep bounded_step_for(int32_t zp32) {
-    constexpr int EPV = InVec<DT_IN>::EPV;
-    constexpr int FIELDS = 32 / BITS < EPV ? 32 / BITS : EPV;    // fields of a packed word that one vector fills
-    uint32_t zp_word = 0;
-#pragma unroll
-    for (int i = 0; i < FIELDS; ++i) zp_word |= static_cast<uint32_t>(zp32) << (i * BITS);
     constexpr float QMAX = static_cast<float>((1 << BITS) - 1);
-    return BoundedStep {-static_cast<float>(zp32), static_cast<float>(((1 << BITS) - 1) - zp32), zp_word, static_cast<float>(zp32) * SatScale<BITS>::K,
-                        (static_cast<float>(zp32) + 0.3f * QMAX / 65535.0f) * (1.0f / QMAX)};
+    return BoundedStep {static_cast<float>(zp32), (static_cast<float>(zp32) + 0.3f * QMAX / 65535.0f) * (1.0f / QMAX)};
 }
 
-// Range test of the short step, one vector at a time: m = max(m, |elements|) and `nan` |= "a NaN is among them".  A tile with a NaN takes
+// Range test of the short step for fp32 inputs, one vector at a time: m = max(m, |elements|) and `nan` |= "a NaN is among them".  A tile with a NaN takes
 // the long step like one with an infinity or a huge value: v_max skips a quiet NaN but is POISONED by a signaling one (IEEE mode: the result
 // is a NaN, which the next v_max skips together with the maximum so far), so the maximum of a tile that holds NaNs cannot be trusted --
 // the parity soak found the case: a value beyond 10^9 * scale followed, in the same lane, by a signaling NaN, and the tile took the short
 // step.  One v_cmp_u_f32 per two elements tells.
-template <int DT_IN>
-__device__ __forceinline__ float vec_absmax(const u32x4& raw, float m, bool& nan) {
-    constexpr int EPV = InVec<DT_IN>::EPV;
-    float v[EPV];
-    InVec<DT_IN>::unpack(raw, v);
+__device__ __forceinline__ float vec_absmax_f32(const u32x4& raw, float m, bool& nan) {
 #pragma unroll
-    for (int e = 0; e < EPV; e += 2) {
-        m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[e]), __builtin_fabsf(v[e + 1])), m);
-        nan |= __builtin_isunordered(v[e], v[e + 1]);
+    for (int e = 0; e < 4; e += 2) {
+        const float a = __uint_as_float(raw[e]), b = __uint_as_float(raw[e + 1]);
+        m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)), m);
+        nan |= __builtin_isunordered(a, b);
     }
     return m;
 }
@@ -586,6 +436,19 @@ __device__ __forceinline__ void store_packed(uint8_t* dst, const uint32_t (&w)[O
     else st<POLICY>(reinterpret_cast<u32x2*>(dst), u32x2 {w[0], w[1]});
 }
 
+// the kernarg segment of quantize_kernel as the ABI lays it out (natural alignment, in order), for load_ref_split (device_math.hpp)
+struct QuantKernargs {
+    const void* in;
+    uint8_t* out;
+    int64_t numel, n_tiles;
+    float inv_scale;
+    int32_t zp32;
+    const ParamRecord* dyn;
+    uint32_t flags, tile_stride;
+    QuantParams p;
+};
+constexpr uint32_t kQuantKernargRef = static_cast<uint32_t>(__builtin_offsetof(QuantKernargs, p) + __builtin_offsetof(QuantParams, ref));
+
 template <int DT_IN, int BITS, int U, int BLOCK>
 struct QuantTile {
     static constexpr int EPV = InVec<DT_IN>::EPV;
@@ -597,15 +460,7 @@ struct QuantTile {
     static constexpr int64_t BLOCK_ELEMS = static_cast<int64_t>(WAVES) * WAVE_VECS * EPV;
 };
 
-// VAR: experiment switches of the tune harness (tools/tune_kernels.hip `bf16`); production = kQuantVariant (tuning.hpp).
-//   bit 0  bf16 inputs: range test of the short step on the raw words (vec_absmax_bits_bf16) instead of on unpacked floats
-//   bit 1  a cheaper first look before that test: the OR of the tile's raw words has the top exponent bit clear <=> every |x| < 2
-//   bit 2  4- and 2-bit outputs clamp, convert and pack through v_cvt_pk_u8_f32 in a scaled domain (pack_saturated)
-// (round 3 also tried marking block 0's head / tail work and the long step unlikely so that the hot path is laid out straight: no
-// difference, 12.69 vs 12.70 us for bf16 -> uint4, profiles/r03_tune_bf16_ceiling.csv `var=3` rows of the first session.)
-//   bit 3  ... two elements per conversion through v_cvt_pknorm_u16_f32 in a normalised domain instead (pack_normalised; wins over bit 2)
-enum : int { QV_RAW_RANGE_TEST = 1, QV_OR_PRETEST = 2, QV_SAT_PACK = 4, QV_NORM_PACK = 8 };
-template <int DT_IN, int BITS, int MODE, int U, bool STAGE, int NT, int BLOCK, bool ALLOW_SHORT = true, int VAR = 0>
+template <int DT_IN, int BITS, int MODE, int U, bool STAGE, int NT, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t numel, int64_t n_tiles, float inv_scale, int32_t zp32,
                 const ParamRecord* dyn, uint32_t flags, uint32_t tile_stride, QuantParams p_arg) {
@@ -618,6 +473,8 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
     // or of the dispatch packet.  (`head` travelled as a trailing argument for a day: the compiler hoists its s_load to the kernel's
     // first instruction and the next lgkmcnt wait -- in front of the first global loads -- waits for it: +0.4 us on every quantize launch.)
     const int head = static_cast<int>(flags >> 16);
+    // flags bit 1: reference layout (only the nearest fast step has a scalar form of its own; every other step is one formula at every position)
+    [[maybe_unused]] const bool ref_on = MODE == RM_NEAREST_FAST && (flags & 2u) != 0;
     p_arg.inv_scale = inv_scale;
     p_arg.zp32 = zp32;
     p_arg.dyn = dyn;
@@ -631,15 +488,14 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
     __shared__ __attribute__((aligned(16))) uint8_t lds[STAGE ? T::WAVES * T::WAVE_OUT_BYTES : 16];
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // in an SGPR: what depends on the wave only (tile addresses, the reference layout's first look) stays on the scalar unit
     const u32x4* __restrict__ in16 = static_cast<const u32x4*>(in);
-    constexpr bool SHORT_CAPABLE = ALLOW_SHORT && MODE != RM_COPY;   // every rounding mode has a short step (quantize_vec_short); the launcher decides who uses it
     // kernel-uniform; written so that only the device-resident-parameter path looks at a 64-bit zero point (the immediate one is not preloaded)
     uint32_t zp_in_range = flags & 1u;
     if (dyn != nullptr) zp_in_range = dyn->zero_point >= 0 && dyn->zero_point <= (1 << BITS) - 1 ? 1u : 0u;
-    [[maybe_unused]] const bool short_ok = SHORT_CAPABLE && zp_in_range != 0;
-    [[maybe_unused]] const BoundedStep bstep = bounded_step_for<DT_IN, BITS>(p.zp32);
-    [[maybe_unused]] const float abs_inv = __builtin_fabsf(p.inv_scale);
+    const bool short_ok = zp_in_range != 0;   // every rounding mode has a short step (quantize_vec_short)
+    const BoundedStep bstep = bounded_step_for<BITS>(p.zp32);
+    const float abs_inv = __builtin_fabsf(p.inv_scale);
 
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += tile_stride) {
         const int64_t v0 = (tile * T::WAVES + wave) * T::WAVE_VECS;   // first input vector of this wave tile
@@ -671,6 +527,20 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
             for (int k = 0; k < U; ++k) raw[k] = ld<NT_LD>(in16 + v0 + k * 64 + lane);
         }
 
+        // Reference layout, first look (device_math.hpp, ref_candidates): does a scalar head or tail of a reference partition reach into this wave
+        // tile?  Nearly never -- and then the tile is patched in registers below, before its one store: no second launch, no second write.
+        [[maybe_unused]] int32_t ref_ta = 1, ref_tb = 0;
+        [[maybe_unused]] RefSplit ref {};
+        if constexpr (MODE == RM_NEAREST_FAST) {
+            if (ref_on) {
+                ref = load_ref_split<kQuantKernargRef>();   // behind the tile's loads, on purpose
+                if (ref_first_look(ref, static_cast<uint64_t>(tile) * T::WAVES + static_cast<uint32_t>(wave))) {
+                    const int64_t g0 = ref.index0 + v0 * EPV;
+                    ref_candidates<8 / BITS, QuantRefBlock<BITS>::value>(ref, g0, g0 + static_cast<int64_t>(T::WAVE_VECS) * EPV, ref_ta, ref_tb);
+                }
+            }
+        }
+
         [[maybe_unused]] ElementKeys keys {};
         if constexpr (MODE == RM_STOCH_ELEM) keys = element_keys_for(p, p.index_base + static_cast<uint64_t>(v0 + lane) * EPV);
         // The short step (quantize_vec_short: about half the instructions per element for nearest, a third for stochastic) is exact whenever the zero point lies
@@ -678,33 +548,29 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
         // decided per wave tile from max|x| * |1/scale| (one v_max3 per two elements and one compare per lane).  Ordinary data always
         // takes it; a tile with a NaN, an infinity or a huge value takes the long step, with the same bytes either way.
         bool short_step = false;
-        if constexpr (SHORT_CAPABLE) {
-            if (short_ok) {
-                // First look: OR the tile's raw words (one v_or3_b32 per two dwords).  The top exponent bit of every element clear means
-                // every |x| < 2 -- zeros and denormals included, NaN and infinity excluded -- and then |x / scale| < 2 |1/scale| < 10^9 for any
-                // scale a quantizer sees (kernel-uniform condition).  Tensors of ordinary magnitude never get past this line; the exact
-                // test below runs for tiles that hold an element of magnitude 2 or more.
-                if constexpr ((VAR & QV_OR_PRETEST) != 0) {
-                    if (abs_inv < 5.0e8f) {
-                        uint32_t o = 0;
+        if (short_ok) {
+            // First look: OR the tile's raw words (one v_or3_b32 per two dwords).  The top exponent bit of every element clear means
+            // every |x| < 2 -- zeros and denormals included, NaN and infinity excluded -- and then |x / scale| < 2 |1/scale| < 10^9 for any
+            // scale a quantizer sees (kernel-uniform condition).  Tensors of ordinary magnitude never get past this line; the exact
+            // test below runs for tiles that hold an element of magnitude 2 or more.
+            if (abs_inv < 5.0e8f) {
+                uint32_t o = 0;
 #pragma unroll
-                        for (int k = 0; k < U; ++k) o |= raw[k][0] | raw[k][1] | raw[k][2] | raw[k][3];
-                        short_step = __all((o & (DT_IN == DT_F32 ? 0x40000000u : 0x40004000u)) == 0 ? 1 : 0) != 0;
-                    }
-                }
-                if (short_step) {
-                } else if constexpr (DT_IN == DT_BF16 && (VAR & QV_RAW_RANGE_TEST) != 0) {
-                    uint32_t m = 0;
+                for (int k = 0; k < U; ++k) o |= raw[k][0] | raw[k][1] | raw[k][2] | raw[k][3];
+                short_step = __all((o & (DT_IN == DT_F32 ? 0x40000000u : 0x40004000u)) == 0 ? 1 : 0) != 0;
+            }
+            if (short_step) {
+            } else if constexpr (DT_IN == DT_BF16) {
+                uint32_t m = 0;
 #pragma unroll
-                    for (int k = 0; k < U; ++k) m = vec_absmax_bits_bf16(raw[k], m);
-                    short_step = __all(__fmul_rn(absmax_bits_to_float(m), abs_inv) < 1.0e9f ? 1 : 0) != 0;   // false for a NaN maximum
-                } else {
-                    float amax = 0.0f;
-                    bool nan = false;
+                for (int k = 0; k < U; ++k) m = vec_absmax_bits_bf16(raw[k], m);
+                short_step = __all(__fmul_rn(absmax_bits_to_float(m), abs_inv) < 1.0e9f ? 1 : 0) != 0;   // false for a NaN maximum
+            } else {
+                float amax = 0.0f;
+                bool nan = false;
 #pragma unroll
-                    for (int k = 0; k < U; ++k) amax = vec_absmax<DT_IN>(raw[k], amax, nan);
-                    short_step = __all(!nan && __fmul_rn(amax, abs_inv) < 1.0e9f ? 1 : 0) != 0;
-                }
+                for (int k = 0; k < U; ++k) amax = vec_absmax_f32(raw[k], amax, nan);
+                short_step = __all(!nan && __fmul_rn(amax, abs_inv) < 1.0e9f ? 1 : 0) != 0;
             }
         }
         uint8_t* o = out + v0 * OB;                                    // output of this wave tile
@@ -745,26 +611,39 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
                 __builtin_amdgcn_wave_barrier();
             }
         };
-        if constexpr (MODE == RM_COPY) {   // tune harness: the kernel without its arithmetic
-            uint32_t w[U][WORDS];
+        // vectors that hold scalar positions of the reference layout are quantized again, element by element, with the formula of each position
+        auto patch = [&](uint32_t (&w)[U][WORDS]) {
+            if constexpr (MODE == RM_NEAREST_FAST) {
+                if (ref_ta > ref_tb) return;   // wave-uniform
+                constexpr int QMAX = (1 << BITS) - 1;
+                uint32_t m[U];
+                ref_scalar_masks<8 / BITS, QuantRefBlock<BITS>::value, EPV, U>(ref, ref_ta, ref_tb, ref.index0 + (v0 + lane) * EPV, 64 * EPV, m);
 #pragma unroll
-            for (int k = 0; k < U; ++k) {
-                w[k][0] = raw[k][0] ^ raw[k][1];
-                w[k][WORDS - 1] = raw[k][2] ^ raw[k][3];
-                if constexpr (WORDS == 1) w[k][0] = raw[k][0] ^ raw[k][1] ^ raw[k][2] ^ raw[k][3];
+                for (int k = 0; k < U; ++k) {
+                    if (m[k] == 0) continue;
+                    float v[EPV];
+                    InVec<DT_IN>::unpack(raw[k], v);
+#pragma unroll
+                    for (int j = 0; j < WORDS; ++j) w[k][j] = 0;
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) {
+                        const uint32_t q = ((m[k] >> e) & 1u) != 0 ? quant_nearest_tail32<QMAX>(v[e], p) : quant_nearest_fast<QMAX>(v[e], p);
+                        w[k][(e * BITS) >> 5] |= q << ((e * BITS) & 31);
+                    }
+                }
             }
-            put(w);
-        } else if (__builtin_expect(short_step, 1)) {
+        };
+        if (__builtin_expect(short_step, 1)) {
             uint32_t w[U][WORDS];
 #pragma unroll
-            for (int k = 0; k < U; ++k)
-                quantize_vec_short<DT_IN, BITS, MODE, (VAR & QV_NORM_PACK) != 0 ? PACK_NORMALISED : ((VAR & QV_SAT_PACK) != 0 ? PACK_SATURATED : PACK_HORNER)>(
-                    raw[k], p, keys, static_cast<uint64_t>(v0 + k * 64 + lane) * EPV, bstep, w[k]);
+            for (int k = 0; k < U; ++k) quantize_vec_short<DT_IN, BITS, MODE>(raw[k], p, keys, static_cast<uint64_t>(v0 + k * 64 + lane) * EPV, bstep, w[k]);
+            patch(w);
             put(w);
         } else {
             uint32_t w[U][WORDS];
 #pragma unroll
             for (int k = 0; k < U; ++k) quantize_vec<DT_IN, BITS, MODE>(raw[k], p, keys, static_cast<uint64_t>(v0 + k * 64 + lane) * EPV, w[k]);
+            patch(w);
             put(w);
         }
     }
@@ -779,11 +658,16 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
     const bool ragged = n_tiles * T::BLOCK_ELEMS < numel;
     if (ragged || head > 0) {   // kernel-uniform
         const int64_t gtid = static_cast<int64_t>(blockIdx.x) * BLOCK + threadIdx.x, gthreads = static_cast<int64_t>(tile_stride) * BLOCK;
-        if (ragged) quantize_bytes_guarded<DT_IN, BITS, MODE>(in, out, numel, n_tiles * T::BLOCK_ELEMS / PACK, (numel + PACK - 1) / PACK, p, gtid, gthreads);
+        QuantParams pg = p;
+        pg.ref = RefSplit {};
+        if constexpr (MODE == RM_NEAREST_FAST) {
+            if (ref_on) pg.ref = load_ref_split<kQuantKernargRef>();
+        }
+        if (ragged) quantize_bytes_guarded<DT_IN, BITS, MODE>(in, out, numel, n_tiles * T::BLOCK_ELEMS / PACK, (numel + PACK - 1) / PACK, pg, gtid, gthreads);
         if (head > 0) {
-            QuantParams ph = p;
+            QuantParams ph = pg;
             ph.index_base -= static_cast<uint64_t>(head);
-            ph.ref_index0 -= head;
+            ph.ref.index0 -= head;
             quantize_bytes_guarded<DT_IN, BITS, MODE>(static_cast<const uint8_t*>(in) - static_cast<int64_t>(head) * (DT_IN == DT_F32 ? 4 : 2), out - head / PACK,
                                                       head, 0, head / PACK, ph, gtid, gthreads);
         }
@@ -791,11 +675,11 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
 }
 
 // Host side of the argument convention above: one place that knows which fields travel as preloaded scalars.
-template <int DT_IN, int BITS, int MODE, int U, bool STAGE, int NT, int BLOCK, bool ALLOW_SHORT = true, int VAR = 0>
+template <int DT_IN, int BITS, int MODE, int U, bool STAGE, int NT, int BLOCK>
 inline void launch_quantize_kernel(unsigned grid, unsigned dyn_lds, hipStream_t stream, const void* in, uint8_t* out, int64_t numel, int64_t n_tiles, const QuantParams& p,
                                    int head) {
-    const uint32_t flags = (p.zp64 >= 0 && p.zp64 <= (1 << BITS) - 1 ? 1u : 0u) | (static_cast<uint32_t>(head) << 16);   // head < 128 * 4 elements
-    PQ_LAUNCH((quantize_kernel<DT_IN, BITS, MODE, U, STAGE, NT, BLOCK, ALLOW_SHORT, VAR>), dim3(grid), dim3(BLOCK), dyn_lds, stream, in, out, numel, n_tiles,
+    const uint32_t flags = (p.zp64 >= 0 && p.zp64 <= (1 << BITS) - 1 ? 1u : 0u) | (p.ref.on ? 2u : 0u) | (static_cast<uint32_t>(head) << 16);   // head < 128 * 4 elements
+    PQ_LAUNCH((quantize_kernel<DT_IN, BITS, MODE, U, STAGE, NT, BLOCK>), dim3(grid), dim3(BLOCK), dyn_lds, stream, in, out, numel, n_tiles,
               p.inv_scale, p.zp32, p.dyn, flags, grid, p);
 }
 

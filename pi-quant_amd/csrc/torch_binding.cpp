@@ -49,7 +49,7 @@ piquant_context_t* prepare(int64_t handle, const at::Tensor& t) {
 }
 
 at::Tensor quantize(int64_t handle, const at::Tensor& tensor, double scale, int64_t zero_point, at::ScalarType dtype, int64_t round_mode,
-                    const c10::optional<at::Tensor>& out_opt) {
+                    const c10::optional<at::Tensor>& out_opt, bool uniform) {
     TORCH_CHECK(tensor.is_cuda(), "the native path takes device tensors");
     TORCH_CHECK(is_float_type(tensor.scalar_type()), "quantize needs a float32 or bfloat16 tensor, got ", tensor.scalar_type());
     const piquant_dtype_t dt_out = code_of(dtype);
@@ -71,14 +71,14 @@ at::Tensor quantize(int64_t handle, const at::Tensor& tensor, double scale, int6
         out = at::empty(x.sizes(), x.options().dtype(dtype));   // reference torch.py:87, plus the device
     }
     piquant_context_t* ctx = prepare(handle, x);
-    piquant_quantize(ctx, x.data_ptr(), code_of(x.scalar_type()), out.data_ptr(), dt_out, static_cast<size_t>(x.numel()), static_cast<float>(scale),
-                     zero_point, static_cast<piquant_round_mode_t>(round_mode));
+    (uniform ? piquant_hip_quantize_uniform : piquant_quantize)(ctx, x.data_ptr(), code_of(x.scalar_type()), out.data_ptr(), dt_out, static_cast<size_t>(x.numel()),
+                                                                static_cast<float>(scale), zero_point, static_cast<piquant_round_mode_t>(round_mode));
     return out;
 }
 
 // `tensor` is a quantized tensor (quint8 / quint4x2 / quint2x4 / uint8); its own dtype and shape describe it
 at::Tensor dequantize(int64_t handle, const at::Tensor& tensor, double scale, int64_t zero_point, at::ScalarType dtype, int64_t reduce_op,
-                      const c10::optional<at::Tensor>& out_opt) {
+                      const c10::optional<at::Tensor>& out_opt, bool uniform) {
     TORCH_CHECK(tensor.is_cuda(), "the native path takes device tensors");
     TORCH_CHECK(is_float_type(dtype), "Unsupported dequantized dtype: ", dtype, " (dtype= must be float32 or bfloat16)");
     TORCH_CHECK(!is_float_type(tensor.scalar_type()), "Unsupported quantized dtype: ", tensor.scalar_type(),
@@ -94,8 +94,8 @@ at::Tensor dequantize(int64_t handle, const at::Tensor& tensor, double scale, in
         out = at::empty(q.sizes(), q.options().dtype(dtype));
     }
     piquant_context_t* ctx = prepare(handle, q);
-    piquant_dequantize(ctx, q.data_ptr(), code_of(q.scalar_type()), out.data_ptr(), code_of(dtype), static_cast<size_t>(q.numel()),
-                       static_cast<float>(scale), zero_point, static_cast<piquant_reduce_op_t>(reduce_op));
+    (uniform ? piquant_hip_dequantize_uniform : piquant_dequantize)(ctx, q.data_ptr(), code_of(q.scalar_type()), out.data_ptr(), code_of(dtype), static_cast<size_t>(q.numel()),
+                                                                    static_cast<float>(scale), zero_point, static_cast<piquant_reduce_op_t>(reduce_op));
     return out;
 }
 
@@ -104,7 +104,7 @@ at::Tensor dequantize(int64_t handle, const at::Tensor& tensor, double scale, in
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "native front end of piquant.torch for ROCm tensors (forwards to the C ABI of libpiquant.so)";
     m.def("quantize", &quantize, py::arg("handle"), py::arg("tensor"), py::arg("scale"), py::arg("zero_point"), py::arg("dtype"), py::arg("round_mode"),
-          py::arg("out") = py::none());
+          py::arg("out") = py::none(), py::arg("uniform") = false);
     m.def("dequantize", &dequantize, py::arg("handle"), py::arg("tensor"), py::arg("scale"), py::arg("zero_point"), py::arg("dtype"), py::arg("reduce_op"),
-          py::arg("out") = py::none());
+          py::arg("out") = py::none(), py::arg("uniform") = false);
 }

@@ -44,27 +44,16 @@ constexpr KernelTune kQuantTuneStochastic[2][3] = {
 // (bf16 -> uint2 had 256-thread / U=4 tiles until round 3: with real bf16 data -- the harness used to feed random bit patterns, NaNs in every
 // tile, which never took the short step -- 64-thread / U=2 tiles are faster for it too, 11.50 vs 11.81 us, profiles/r03_tune_bf16_ceiling.csv)
 
-// The per-tile short step of the streaming quantize kernels (quant_kernels.hpp, quantize_vec_short): on.  It halves the arithmetic; its range
-// test (max|x| over the tile, a wave-wide vote, a branch) makes a wave wait for all its loads before it computes, which costs the fp32 inputs
-// nothing measurable and is repaid on the bf16 inputs (twice the elements per byte).  A/B through the library, all 12 quantize operators at
-// numel 27 264 000, hipGraph replay over 24 cold sets (tools/dtype_matrix.py): on / off = bf16->uint8 15.0 / 15.5 us, bf16->uint4 13.1 / 13.5,
-// bf16->uint2 12.5 / 13.3, fp32->uint8 23.1 / 23.2, fp32->uint4 20.6 / 20.6, fp32->uint2 19.5 / 19.5.  (The tune harness' own A/B, mode `shortab`,
-// disagrees by +-0.4 us from run to run at this size -- it launches from the host over fewer sets -- and is not what this was decided on.)
-constexpr bool kQuantShortStep = true;
-// Switches of quantize_kernel's short step (quant_kernels.hpp, QV_*) as the library builds it, from the interleaved A/B against a copy kernel
-// with the same traffic, tile and store policy (tools/tune_kernels.hip `bf16`, profiles/r03_tune_bf16_ceiling.csv; numel 27 264 000, 40 cold sets;
-// copy / round 2's step / +raw-word range test / +OR first look / +saturating pack):
-//   bf16 -> uint4 nearest 12.05 / 12.87 / 12.66 / 12.63 / 12.57 us, stochastic 12.05 / 14.68 / 14.10 / 13.90 / 13.43
-//   bf16 -> uint8 nearest 14.16 / 14.81 / 14.63 / 14.61 / 14.62,    stochastic 14.16 / 15.25 / 15.27 / 15.13 / 15.11
-//   bf16 -> uint2 nearest 10.77 / 12.37 / 11.66 / 11.50 / 11.74 (64-thread tiles), stochastic 10.95 / 13.69 / 13.67 / 13.10 / 12.84 (256-thread tiles)
-// fp32 inputs sit on their copy ceiling either way (22.50 copy / 22.74 / 22.75 for fp32 -> uint8; profiles/r03_tune_f32_ceiling.csv).
-// Round 3, later: + two elements per conversion (QV_NORM_PACK, pack_normalised; profiles/r03_tune_normalised_pack.csv, same protocol, saturating pack -> this):
-//   bf16 -> uint4 nearest 12.56 -> 12.53, stochastic 13.48 -> 13.33; bf16 -> uint2 nearest 11.56 (Horner form) -> 11.45, stochastic 12.95 -> 12.48;
-//   fp32 -> uint2 19.64 -> 19.57 / 19.92 -> 19.73; 8-bit outputs gain nothing (one v_perm per four elements against nothing) and keep the saturating pack.
-// Tile geometry re-swept on that step (U 2/4/8 x 64..512 threads, profiles/r03_tune_bf16_geometry_final.csv): every table entry above is still the best or within 0.05 us of it.
-// (the stochastic short step's form -- ceil(RU(|r| - tau)), round 5 -- is switched in quant_kernels.hpp, kStochCeilStep: the kernels' header does not see this file)
-constexpr int kQuantVariant = 7;                              // 8-bit outputs
-constexpr int kQuantVariantSubByte = 7 | 8;                   // 4- and 2-bit outputs: QV_NORM_PACK on top
+// The per-tile short step of the streaming quantize kernels (quant_kernels.hpp, quantize_vec_short) is always built in.  It halves the arithmetic; its
+// range test (max|x| over the tile, a wave-wide vote, a branch) makes a wave wait for all its loads before it computes, which costs the fp32 inputs
+// nothing measurable and is repaid on the bf16 inputs (twice the elements per byte).  A/B through the library, all 12 quantize operators at numel
+// 27 264 000, hipGraph replay over 24 cold sets (round 2): on / off = bf16->uint8 15.0 / 15.5 us, bf16->uint4 13.1 / 13.5, bf16->uint2 12.5 / 13.3,
+// fp32->uint8 23.1 / 23.2, fp32->uint4 20.6 / 20.6, fp32->uint2 19.5 / 19.5.  Its ingredients, each from an interleaved A/B against a copy kernel with
+// the same traffic, tile and store policy (round 3, profiles/r03_tune_bf16_ceiling.csv, r03_tune_normalised_pack.csv; copy / round 2's step / + raw-word
+// range test for bf16 / + OR first look / + saturating pack / + two elements per conversion for the packed outputs):
+//   bf16 -> uint4 nearest 12.05 / 12.87 / 12.66 / 12.63 / 12.57 / 12.53 us, stochastic 12.05 / 14.68 / 14.10 / 13.90 / 13.43 / 13.33
+//   bf16 -> uint2 nearest 10.77 / 12.37 / 11.66 / 11.50 / 11.74 / 11.45;  fp32 inputs sit on their copy ceiling either way (22.50 / 22.74 / 22.75).
+// Round 6 removed the switches that selected the losing forms (they served the retired tune harness only); one form per output width is left.
 
 // dequantize, indexed [dt_out: f32,bf16][bits: 8,4,2]; SET and ADD separately -- ADD also streams the accumulator in, which moves the
 // optimum to small tiles.  bf16 entries re-measured after fp32 -> bf16 became one v_cvt_pk_bf16_f32 (profiles/r01_tune_finals_other_hw_bf16_cvt.csv,

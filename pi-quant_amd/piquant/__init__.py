@@ -70,8 +70,9 @@ class DataType(Enum):
 class Context:
     """Owns one native context, bound to the HIP device that is current at construction.
 
-    ``num_threads`` is accepted for source compatibility with the reference (it sized the CPU thread
-    pool there, ``__init__.py:65-70``) and ignored: the GPU grid does the partitioning.
+    ``num_threads`` sized the reference's CPU thread pool (``__init__.py:65-70``; default there and here: CPUs - 1).  The GPU grid does
+    the partitioning, but the number still means something: ``quantize_ptr`` / ``dequantize_ptr`` write, byte for byte, what a reference
+    context of that many pool threads writes -- its partitions' scalar heads and tails included (``set_reference_layout``).
     """
 
     # Default contexts are per (thread, device): a context carries the stream and the blocking / pointer modes of the call being
@@ -92,7 +93,11 @@ class Context:
                 Context._default_policy[name] = args
 
     def __init__(self, num_threads: Union[int, None] = None) -> None:
-        self._num_threads = 0 if num_threads is None else int(num_threads)
+        if num_threads is None:   # reference __init__.py:67-68
+            import multiprocessing
+
+            num_threads = max(multiprocessing.cpu_count() - 1, 1)
+        self._num_threads = int(num_threads)
         _require_device()   # a Python exception instead of the native abort when there is no GPU
         self._ctx = C.piquant_context_create(self._num_threads)
         assert self._ctx, 'piquant_context_create returned NULL'
@@ -133,22 +138,26 @@ class Context:
 
     # ---- reference surface (python/src/piquant/__init__.py:82-142) ---------------------------------
     def quantize_ptr(self, ptr_in: int, dtype_in: DataType, ptr_out: int, dtype_out: DataType, numel: int, scale: float,
-                     zero_point: int, round_mode: RoundMode, _device_ptrs: bool = False) -> None:
+                     zero_point: int, round_mode: RoundMode, _device_ptrs: bool = False, uniform: bool = False) -> None:
+        """``uniform=True`` (additive): the position-independent form -- the SIMD-body formula at every element, whatever the context's
+        layout mode: what a shard of a larger tensor is computed with (``piquant_hip_quantize_uniform``)."""
         assert dtype_in.is_dequantized, f'Input dtype must be a dequantized type, but is: {dtype_in}'
         assert dtype_out.is_quantized, f'Output dtype must be a quantized type, but is: {dtype_out}'
         assert numel == 0 or ptr_in != 0, 'Input arr pointer must not be NULL'
         assert numel == 0 or ptr_out != 0, 'Output arr pointer must not be NULL'
         self.assume_device_pointers(_device_ptrs)
-        C.piquant_quantize(self._ctx, ptr_in, dtype_in.value, ptr_out, dtype_out.value, numel, scale, zero_point, round_mode.value)
+        call = C.piquant_hip_quantize_uniform if uniform else C.piquant_quantize
+        call(self._ctx, ptr_in, dtype_in.value, ptr_out, dtype_out.value, numel, scale, zero_point, round_mode.value)
 
     def dequantize_ptr(self, ptr_in: int, dtype_in: DataType, ptr_out: int, dtype_out: DataType, numel: int, scale: float,
-                       zero_point: int, reduce_op: ReduceOp, _device_ptrs: bool = False) -> None:
+                       zero_point: int, reduce_op: ReduceOp, _device_ptrs: bool = False, uniform: bool = False) -> None:
         assert dtype_in.is_quantized, f'Input dtype must be a quantized type, but is: {dtype_in}'
         assert dtype_out.is_dequantized, f'Output dtype must be a dequantized type, but is: {dtype_out}'
         assert numel == 0 or ptr_in != 0, 'Input arr pointer must not be NULL'
         assert numel == 0 or ptr_out != 0, 'Output arr pointer must not be NULL'
         self.assume_device_pointers(_device_ptrs)
-        C.piquant_dequantize(self._ctx, ptr_in, dtype_in.value, ptr_out, dtype_out.value, numel, scale, zero_point, reduce_op.value)
+        call = C.piquant_hip_dequantize_uniform if uniform else C.piquant_dequantize
+        call(self._ctx, ptr_in, dtype_in.value, ptr_out, dtype_out.value, numel, scale, zero_point, reduce_op.value)
 
     def compute_quant_params_ptr_float32(self, ptr: int, target_quant_dtype: DataType, numel: int, _device_ptrs: bool = False) -> Tuple[float, int]:
         assert target_quant_dtype.is_quantized, f'Target dtype must be a quantized type, but is: {target_quant_dtype}'
@@ -224,12 +233,13 @@ class Context:
         self._record_policy('set_stochastic_per_element', enabled, seed, index_base)
         C.piquant_hip_set_stochastic_per_element(self._ctx, 1 if enabled else 0, seed & 0xFFFFFFFFFFFFFFFF, index_base)
 
-    def set_reference_layout(self, enabled: bool, threads: int = 1) -> None:
-        """Opt-in: reproduce the reference's scalar head/tail formulas at the positions where its AVX-512 build uses them
-        (include/piquant_hip.h), for a reference context with ``threads`` pool threads (each partition has its own head and tail);
-        off, every element takes the SIMD-body formula."""
+    def set_reference_layout(self, enabled: bool, threads: Optional[int] = None) -> None:
+        """On (the default): ``quantize_ptr`` / ``dequantize_ptr`` reproduce the reference's scalar head / tail formulas at the positions where
+        its AVX-512 build uses them (include/piquant_hip.h), for a reference context with ``threads`` pool threads (each partition has its
+        own head and tail; None: the ``num_threads`` this context was created with).  Off: every element takes the SIMD-body formula."""
+        threads = self._num_threads if threads is None else int(threads)
         self._record_policy('set_reference_layout', enabled, threads)
-        C.piquant_hip_set_reference_threads(self._ctx, int(threads))
+        C.piquant_hip_set_reference_threads(self._ctx, max(threads, 1))
         C.piquant_hip_set_reference_layout(self._ctx, 1 if enabled else 0)
 
     def quantize_dequantize_ptr(self, ptr_in: int, dtype_in_out: DataType, ptr_out: int, quant_dtype: DataType, numel: int, scale: float,

@@ -36,6 +36,8 @@ _DECLS = [
     ('piquant_hip_set_stochastic_per_element', None, [_vp, _int, C.c_uint64, C.c_uint64]),
     ('piquant_hip_set_reference_layout', None, [_vp, _int]),
     ('piquant_hip_set_reference_threads', None, [_vp, _int]),
+    ('piquant_hip_quantize_uniform', None, [_vp, _vp, _int, _vp, _int, _sz, _f32, _i64, _int]),
+    ('piquant_hip_dequantize_uniform', None, [_vp, _vp, _int, _vp, _int, _sz, _f32, _i64, _int]),
     ('piquant_hip_quantize_dequantize', None, [_vp, _vp, _int, _vp, _int, _sz, _f32, _i64, _int, _int]),
     ('piquant_hip_compute_quant_params_device', None, [_vp, _vp, _int, _sz, _int, _vp]),
     ('piquant_hip_quantize_dp', None, [_vp, _vp, _int, _vp, _int, _sz, _vp, _int]),

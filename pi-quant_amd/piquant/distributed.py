@@ -45,6 +45,13 @@ def _raise_peer_timeout(ctx: Context, what: str) -> None:
     if t is None:
         return
     kind, rank, expected, seen = t
+    # The buffers of the exchange that gave up are void from here on: the rank that was waited for may still store into them (its chunk into a receive
+    # buffer of a LATER exchange's parity, its key pair into a mailbox slot nobody empties), and this rank signalled nothing behind the wait that ran out
+    # (signal_flags_kernel), so its peers are about to give up on it in turn.  Every mesh of that kind on the device is poisoned until the group
+    # rebuilds them (release_peer_meshes, a collective).
+    for m in list((_PeerMesh if kind == 'flags' else _KeyMesh)._cache.values()):
+        if m.device.index == ctx.device:
+            m.poisoned = True
     if kind == 'flags':
         raise RuntimeError(f"{what}: rank {rank} did not arrive within the timeout (its flag read {seen}, exchange {expected} was waited for); the tensors of that "
                            f"all-reduce hold stale bytes.  Raise timeout= / PIQUANT_P2P_TIMEOUT_S if ranks may be that far apart.")
@@ -152,7 +159,7 @@ def quantize_shard(
         dst = whole.view(-1)[first: first + n_bytes]
     if end > begin:
         (_quantize or quantize)(flat[begin:end], scale=scale, zero_point=zero_point, dtype=dtype,
-                                round_mode=round_mode, ctx=ctx, out=dst)
+                                round_mode=round_mode, ctx=ctx, out=dst, uniform=True)
     return dst, (begin, end)
 
 
@@ -192,7 +199,7 @@ def dequantize_shard(
         first = begin * qdt.bit_size // 8
         src = raw.view(-1)[first: first + qdt.packed_nbytes(end - begin)]
         (_dequantize or dequantize)(src, scale=scale, zero_point=zero_point, dtype=out.dtype, reduce_op=reduce_op, ctx=ctx, out=dst,
-                                    quant_dtype=quant_dtype, shape=(end - begin,))
+                                    quant_dtype=quant_dtype, shape=(end - begin,), uniform=True)
     return dst, (begin, end)
 
 
@@ -534,6 +541,7 @@ class _PeerMesh:
         dist.barrier(group=group)        # nobody signals into memory somebody has not finished mapping
         self.seq = 0
         self.order = _StreamOrder()
+        self.poisoned = False            # a wait of an exchange on this device gave up (_raise_peer_timeout): late stores may land in these buffers
 
     @classmethod
     def get(cls, group, device, slot, world, rank):
@@ -602,7 +610,11 @@ def quantized_all_reduce(
     ``transport='p2p'`` (``algorithm='direct'`` only, one node; EXPERIMENTAL until it has run between two GPUs): no collective at all -- the
     encode kernels store into the peers' receive buffers over xGMI and flags order the steps (``quantized_all_reduce_direct``).  ``timeout``
     (seconds; default ``PIQUANT_P2P_TIMEOUT_S`` or 10 minutes) bounds every wait for a peer; a rank that is later than that does not fault the
-    GPU: the NEXT p2p call on the device (or ``check_peer_timeouts``) raises RuntimeError naming it.
+    GPU: the NEXT p2p call on the device (or ``check_peer_timeouts``) raises RuntimeError naming it.  The all-reduce is asynchronous, so a caller of
+    ``transport='p2p'`` MUST call ``check_peer_timeouts()`` (it synchronises) before it consumes the result -- e.g. at the step's synchronisation point,
+    in front of the optimizer step: behind a wait that ran out the tensor holds sums of stale bytes.  After such a failure the rank signals nothing
+    more (its peers give up on it in turn, so every rank learns of it) and the group's peer-mapped buffers stay refused until every rank has called
+    ``release_peer_meshes(group)``.
 
     (``_single_rank_collectives`` is a test hook: with a one-rank group the function normally returns at once; with the hook it
     runs the whole schedule -- encode, the group's collectives with the rank as its own only peer, decode -- so that the RCCL
@@ -775,6 +787,9 @@ def _all_reduce_direct_p2p(tensor, flat, chunks, slot, quant_dtype, qdt, round_m
     mesh = _PeerMesh.get(group, tensor.device, slot, world, rank)      # its own slot size lays the buffers out (>= what this tensor needs)
     cx = _ctx_for(tensor, ctx)          # the tensor's device, PyTorch's current stream, stream-ordered
     _raise_peer_timeout(cx, "an earlier quantized_all_reduce(transport='p2p')")
+    if mesh.poisoned:
+        raise RuntimeError("quantized_all_reduce(transport='p2p'): an earlier exchange of this group gave up on a late rank, whose stores may still land in the "
+                           "peer-mapped buffers; every rank must call piquant.distributed.release_peer_meshes(group) before the group uses transport='p2p' again")
     with mesh.order.lock:               # one exchange of a mesh at a time on the host, whatever thread it comes from ...
         mesh.order.enter(tensor.device)     # ... and behind the mesh's previous exchange on the device, whatever stream that ran on
         _all_reduce_direct_p2p_locked(tensor, flat, chunks, mesh, cx, qdt, round_mode, world, rank, timeout_us)

@@ -182,11 +182,14 @@ def quantize(
     round_mode: str = 'nearest',
     ctx: Optional[Context] = None,
     out: Optional[torch.Tensor] = None,
+    uniform: bool = False,
 ) -> torch.Tensor:
-    """Reference ``torch.py:70-99``; the result lives on ``tensor.device``."""
+    """Reference ``torch.py:70-99``; the result lives on ``tensor.device``.  The bytes are those of a reference context with the
+    context's ``num_threads`` (``Context.set_reference_layout``); ``uniform=True`` (additive) asks for the position-independent form
+    instead -- what shards of one logical tensor must be computed with (``piquant.distributed``)."""
     assert dtype in _QUANT_TYPES, f'Unsupported quantized dtype: {dtype}; choose from {[str(t) for t in _QUANT_TYPES]}'
     if _native is not None and tensor.is_cuda and tensor.dtype in _DEQUANT_TYPES:
-        return _native.quantize(_native_handle(tensor, ctx), tensor, scale, zero_point, dtype, _ROUND_MODE_CODES[round_mode], out)
+        return _native.quantize(_native_handle(tensor, ctx), tensor, scale, zero_point, dtype, _ROUND_MODE_CODES[round_mode], out, uniform)
     if not tensor.is_contiguous():
         tensor = tensor.contiguous()
     dtype_in = torch_to_piquant_dtype(tensor.dtype)
@@ -206,6 +209,7 @@ def quantize(
         zero_point=zero_point,
         round_mode=_ROUND_MODES[round_mode],
         _device_ptrs=tensor.is_cuda,
+        uniform=uniform,
     )
     return out
 
@@ -221,14 +225,15 @@ def dequantize(
     out: Optional[torch.Tensor] = None,
     quant_dtype: Optional[torch.dtype] = None,
     shape=None,
+    uniform: bool = False,
 ) -> torch.Tensor:
-    """Reference ``torch.py:102-129``.  ``out=`` (same shape, ``dtype``) is the accumulator for ``reduce_op='add'``."""
+    """Reference ``torch.py:102-129``.  ``out=`` (same shape, ``dtype``) is the accumulator for ``reduce_op='add'``; ``uniform``: see ``quantize``."""
     if dtype not in _DEQUANT_TYPES:
         raise ValueError(f'Unsupported dequantized dtype: {dtype}; choose from {[str(t) for t in _DEQUANT_TYPES]}')
     if _native is not None and tensor.is_cuda and quant_dtype is None and shape is None and tensor.dtype in _QUANT_TYPES:
         if out is None and reduce_op == 'add':
             raise ValueError("reduce_op='add' accumulates into out=; pass the accumulator tensor")
-        return _native.dequantize(_native_handle(tensor, ctx), tensor, scale, zero_point, dtype, _REDUCE_OP_CODES[reduce_op], out)
+        return _native.dequantize(_native_handle(tensor, ctx), tensor, scale, zero_point, dtype, _REDUCE_OP_CODES[reduce_op], out, uniform)
     if not tensor.is_contiguous():
         tensor = tensor.contiguous()
     dtype_in, logical_shape = _quant_meta(tensor, quant_dtype, shape)
@@ -252,6 +257,7 @@ def dequantize(
         zero_point=zero_point,
         reduce_op=_REDUCE_OPS[reduce_op],
         _device_ptrs=tensor.is_cuda,
+        uniform=uniform,
     )
     return out
 

@@ -39,7 +39,7 @@ def golden_dir():
 # own suites, the epilogue, the C clients), then the Python surface and the sharded paths, and the scheduling / property tests (grid-barrier
 # hand-overs, processes sharing the GPU) last.  Round 4's driver run stopped at a scheduling-dependent counter assertion in a file that
 # sorted in front of the whole parity suite; nothing of that kind may stand in front of an oracle comparison again.
-_GPU_FILE_ORDER = ["test_gpu_00_baseline_configs.py", "test_gpu_parity.py", "test_gpu_reference_suites.py", "test_gpu_epilogue.py", "test_c_client.py",
+_GPU_FILE_ORDER = ["test_gpu_00_baseline_configs.py", "test_gpu_01_default_is_reference_exact.py", "test_gpu_parity.py", "test_gpu_reference_suites.py", "test_gpu_epilogue.py", "test_c_client.py",
                    "test_gpu_torch_api.py", "test_gpu_distributed.py", "test_gpu_barrier.py"]
 
 

@@ -124,11 +124,11 @@ def test_quantize_and_dequantize_shard_cover_the_tensor(oracle_mod, world, qname
     scale, zp = O.compute_quant_params(x, O.F32, odt)
     want_q = O.quantize(x, O.F32, odt, scale, zp)
 
-    def q_op(t, *, scale, zero_point, dtype, round_mode, ctx, out):
+    def q_op(t, *, scale, zero_point, dtype, round_mode, ctx, out, uniform):
         out.copy_(torch.from_numpy(O.quantize(t.numpy(), O.F32, odt, scale, zero_point)))
         return out
 
-    def dq_op(src, *, scale, zero_point, dtype, reduce_op, ctx, out, quant_dtype, shape):
+    def dq_op(src, *, scale, zero_point, dtype, reduce_op, ctx, out, quant_dtype, shape, uniform):
         m = int(shape[0])
         prev = out.numpy().copy()
         got = O.dequantize(src.numpy(), odt, O.F32, m, scale, zero_point, O.ADD if reduce_op == 'add' else O.SET, out=prev)
@@ -169,7 +169,7 @@ def _shard_worker(rank, world, port, numel, out_q):
         x = np.random.default_rng(5).uniform(-2, 2, numel).astype(np.float32)     # every rank holds the same logical tensor
         scale, zp = O.compute_quant_params(x, O.F32, O.UINT4)
 
-        def q_op(t, *, scale, zero_point, dtype, round_mode, ctx, out):
+        def q_op(t, *, scale, zero_point, dtype, round_mode, ctx, out, uniform):
             out.copy_(torch.from_numpy(O.quantize(t.numpy(), O.F32, O.UINT4, scale, zero_point)))
             return out
 

@@ -418,20 +418,22 @@ def test_quantize_shard_concatenation_is_the_whole_call(oracle_mod, world, qname
     g.manual_seed(17)
     x = torch.empty(n, device="cuda").uniform_(-1, 1, generator=g).to(fdtype)
     scale, zp = piquant.torch.compute_quant_params(x, dtype=qdtype)
-    whole = piquant.torch.packed_bytes(piquant.torch.quantize(x, scale=scale, zero_point=zp, dtype=qdtype))
+    # (the whole calls in the position-independent form too: the plain call's bytes are those of a reference context of num_threads pool threads,
+    # whose tails double-round bf16 ADD and, for uint2 -> fp32 ADD, store -- ranks are not pool threads)
+    whole = piquant.torch.packed_bytes(piquant.torch.quantize(x, scale=scale, zero_point=zp, dtype=qdtype, uniform=True))
     buf = torch.full_like(whole, 0xAA)
     for r in range(world):
         dst, (b, e) = D.quantize_shard(x, scale=scale, zero_point=zp, dtype=qdtype, out=buf, rank=r, world_size=world)
         assert e > b and dst.numel() == piquant.torch.torch_to_piquant_dtype(qdtype).packed_nbytes(e - b)
     assert torch.equal(buf, whole)
-    full = piquant.torch.dequantize(whole, scale=scale, zero_point=zp, dtype=fdtype, quant_dtype=qdtype, shape=(n,))
+    full = piquant.torch.dequantize(whole, scale=scale, zero_point=zp, dtype=fdtype, quant_dtype=qdtype, shape=(n,), uniform=True)
     out = torch.full((n,), 7.0, device="cuda", dtype=fdtype)
     for r in range(world):
         D.dequantize_shard(buf, numel=n, scale=scale, zero_point=zp, quant_dtype=qdtype, out=out, rank=r, world_size=world)
     assert torch.equal(out.view(torch.int16 if fdtype == torch.bfloat16 else torch.int32), full.view(torch.int16 if fdtype == torch.bfloat16 else torch.int32))
     acc = torch.ones(n, device="cuda", dtype=fdtype)
     want = piquant.torch.dequantize(whole, scale=scale, zero_point=zp, dtype=fdtype, quant_dtype=qdtype, shape=(n,), reduce_op="add",
-                                    out=torch.ones(n, device="cuda", dtype=fdtype))
+                                    out=torch.ones(n, device="cuda", dtype=fdtype), uniform=True)
     for r in range(world):
         D.dequantize_shard(buf, numel=n, scale=scale, zero_point=zp, quant_dtype=qdtype, out=acc, reduce_op="add", rank=r, world_size=world)
     assert torch.equal(acc, want)
@@ -449,10 +451,39 @@ def test_quantize_shard_concatenation_is_the_whole_call(oracle_mod, world, qname
 # nothing; the run must finish, print exactly one JSON line, shard the headline tensor (strong scaling) and get the sharded
 # parameters right.
 # ---------------------------------------------------------------------------------------------------------------
+def test_bench_two_ranks_default_flags_print_the_line_within_a_minute():
+    """Round-5 verdict: the first scaling run must not be lost to a side measurement.  `bench.py --gpus 2` with DEFAULT flags is the contract line, its
+    N = 1 reference point and config 5 (the one path with a collective) -- no all-reduce schedules, no graph replay, no weak scaling, no
+    peer-to-peer child job -- and the line is on stdout within 60 s of the process start (two ranks sharing this box's one GPU)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import time
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PIQUANT_BENCH_EXTRAS")}
+    t0 = time.perf_counter()
+    p = subprocess.Popen([sys.executable, str(root / "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "20", "--warmup", "5"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=str(root), env=env)
+    line = p.stdout.readline()
+    t_line = time.perf_counter() - t0
+    _, err = p.communicate(timeout=300)
+    assert p.returncode == 0, err[-3000:]
+    d = json.loads(line)
+    assert t_line < 60.0, f"the contract line took {t_line:.1f} s"
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["shard_bit_exact"] == [True, True]
+    assert "piquant_hip_quantize_uniform" in d["config"]["api"]          # a rank's call covers a shard: the position-independent twin
+    assert d["n1_reference"]["bit_exact"] is True
+    assert set(d["extras"]) == {"config5_sharded_compute_quant_params"} and d["extras"]["config5_sharded_compute_quant_params"]["result_correct"]
+    assert "p2p_transport_child_job" not in err
+
+
 def test_bench_two_ranks_sharing_the_gpu():
-    """`python bench.py --gpus 2` with NO launcher around it (the shape of the driver's N = 1 command with another N): bench.py starts its own two
-    ranks, one JSON line comes out, and the line validates itself -- ranks seen by the process group, every rank's shard bit-exact against the
-    checker, the N = 1 point of the same run, both all-reduce schedules and the 8-byte MIN all-reduce in the extras."""
+    """`python bench.py --gpus 2 --extras` with NO launcher around it: bench.py starts its own two ranks, one JSON line comes out, and the line
+    validates itself -- ranks seen by the process group, every rank's shard bit-exact against the checker, the N = 1 point of the same run, both
+    all-reduce schedules and the 8-byte MIN all-reduce in the extras."""
     import json
     import os
     import subprocess
@@ -461,7 +492,7 @@ def test_bench_two_ranks_sharing_the_gpu():
 
     root = Path(__file__).resolve().parent.parent
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "20", "--warmup", "5"],
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "20", "--warmup", "5", "--extras"],
                        capture_output=True, text=True, timeout=900, cwd=str(root), env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -643,8 +674,9 @@ def _p2p_late_rank_worker(rank, world, port, out_q):
         D.check_peer_timeouts()
         report["late_but_in_time"] = y.cpu().numpy()
         dist.barrier()
-        # 2. rank 1 is 2 s late and the others give up after 0.3 s: nobody faults, the early ranks raise RuntimeError naming rank 1 (the late
-        #    rank itself finds everybody's flags set and completes)
+        # 2. rank 1 is 2 s late and the others give up after 0.3 s: nobody faults, the early ranks raise RuntimeError naming rank 1; a rank that gave up
+        #    signals nothing more, so the late rank -- which finds everybody's chunk there, but decodes sums made without its own -- never sees rank 0
+        #    finish and raises too, naming rank 0 (round 5: it completed silently with a wrong tensor)
         if rank == 1:
             time.sleep(2.0)
         z = x.clone()
@@ -656,6 +688,19 @@ def _p2p_late_rank_worker(rank, world, port, out_q):
             report["gave_up"] = str(exc)
         dist.barrier()
         torch.cuda.synchronize()
+        # ... and the group's buffers are refused until everybody has rebuilt them: a late store may still land in a later exchange's parity
+        try:
+            D.quantized_all_reduce(x.clone(), transport="p2p", timeout=30.0)
+            report["refused"] = None
+        except RuntimeError as exc:
+            report["refused"] = str(exc)
+        dist.barrier()
+        D.release_peer_meshes()
+        v = x.clone()
+        D.quantized_all_reduce(v, transport="p2p", timeout=30.0)
+        D.check_peer_timeouts()
+        report["after_release"] = v.cpu().numpy()
+        dist.barrier()
         # 3. compute_quant_params(transport='p2p') with a late rank beyond the limit raises from the call itself (it is synchronous)
         if rank == 1:
             time.sleep(1.5)
@@ -709,7 +754,10 @@ def test_p2p_transport_with_a_late_rank_raises_instead_of_faulting(oracle_mod):
         assert np.array_equal(results[r]["late_but_in_time"], want[r]), r
         assert results[r]["alive"] is True
     assert results[0]["gave_up"] is not None and "rank 1 did not arrive" in results[0]["gave_up"], results[0]["gave_up"]
-    assert results[1]["gave_up"] is None
+    assert results[1]["gave_up"] is not None and "rank 0 did not arrive" in results[1]["gave_up"], results[1]["gave_up"]
+    for r in range(world):
+        assert results[r]["refused"] is not None and "release_peer_meshes" in results[r]["refused"], results[r]["refused"]
+        assert np.array_equal(results[r]["after_release"], want[r]), r
     assert results[0]["params_gave_up"] is not None and "rank 1 did not deliver" in results[0]["params_gave_up"], results[0]["params_gave_up"]
 
 

@@ -204,6 +204,8 @@ def n1_reference(B):
     rotation of args.sets full-size sets) while the other ranks wait at the barrier behind it."""
     args, ctx, stream, dev, rank, n_total, scale, zp, gib_per_step, c_quantize, time_loop = B.args, B.ctx, B.stream, B.dev, B.rank, B.n_total, B.scale, B.zp, B.gib_per_step, B.c_quantize, B.time_loop
     from piquant import DataType, RoundMode
+    from piquant._bootstrap import C_LIB
+    c_quantize = C_LIB.piquant_quantize     # the whole tensor in one call: the plain call, as in the N = 1 line (the ranks' shard calls use the position-independent twin)
     n1_ref = None
     try:
         if rank == 0:
@@ -512,9 +514,11 @@ def _rearm(B):
 def multi_rank(B):
     """N > 1, every rank (collectives inside).  Results are put into B.side as they finish: what the watchdog's line carries."""
     B.result["n1_reference"] = n1_reference(B)        # in the line even if a later side measurement runs into the watchdog
-    for key, fn in (("independent_calls_one_stream", independent_calls), ("all_reduce_109MB", all_reduce_109mb), ("steps_replayed_from_a_hipgraph", graph_replay),
-                    ("config5_sharded_compute_quant_params", config5),
-                    ("weak_scaling_own_tensor_per_gpu", weak_scaling)):
+    todo = (("config5_sharded_compute_quant_params", config5),)      # the default for N > 1: the one path with a collective (bench.py --extras: all of them)
+    if B.args.extras:
+        todo = (("independent_calls_one_stream", independent_calls), ("all_reduce_109MB", all_reduce_109mb), ("steps_replayed_from_a_hipgraph", graph_replay)) + todo + \
+               (("weak_scaling_own_tensor_per_gpu", weak_scaling),)
+    for key, fn in todo:
         try:
             B.side[key] = fn(B)
         except Exception as exc:
@@ -563,23 +567,24 @@ def single_gpu(B):
         w, e = time_loop(lambda i: c_quantize(*reuse_args[i % nsets]), 600, stream)
         extras["cold_inputs_one_output_buffer"] = {"GiB/s": round(gib_per_step * 600 / w, 1), "avg_launch_us": round(e / 600 * 1e6, 3), "GB/s": gbs_plain(5, e, 600),
                                                    "note": f"inputs rotate over the {nsets} cold sets, every launch writes the same 27 MB output buffer"}
-        # reference-layout mode (opt-in byte identity with a CPU reference context): one partition costs nothing, 255 partitions
-        # (the reference's Python default on this host: cpu_count - 1) one small dependent launch that rewrites their scalar heads and tails
+        # Reference layout (the default of the plain calls since round 6: the bytes of a CPU reference context of num_threads pool threads),
+        # for one partition, for 255 (the reference's Python default on this host: cpu_count - 1) and switched off.  A wave tile that a partition's scalar head
+        # or tail reaches into handles those positions itself, inside the one vector launch (round 5: a second, dependent patch launch, 26 us at 255 threads).
         try:
             layout = {}
-            for threads in (1, 255):
-                ctx.set_reference_layout(True, threads=threads)
+            for key, on, threads in (("1_reference_threads", True, 1), ("255_reference_threads", True, 255), ("layout_off_position_independent", False, 1)):
+                ctx.set_reference_layout(on, threads=threads)
                 for i in range(nsets):
                     step(i)
                 w, e = time_loop(step, 300, stream)
-                layout[f"{threads}_reference_threads"] = {"us_per_call": round(e / 300 * 1e6, 3), "roofline_frac": round(5 * n / (e / 300) / 1e9 / 8000.0, 4)}
-            extras["reference_layout_mode"] = dict(layout, note="the headline's calls with piquant_hip_set_reference_layout on: the output equals, byte for byte, what the "
-                                                   "reference's AVX-512 context of that many pool threads writes (the headline itself runs in the default, position-independent "
-                                                   "mode -- what sharding needs); round 5: vector kernel + per-partition patch kernel (213 us per call for 255 threads before)")
+                layout[key] = {"us_per_call": round(e / 300 * 1e6, 3), "roofline_frac": round(5 * n / (e / 300) / 1e9 / 8000.0, 4)}
+            extras["reference_layout_mode"] = dict(layout, note="the headline's calls for three settings of the context: the output equals, byte for byte, what the reference's "
+                                                   "AVX-512 context of that many pool threads writes (the headline itself runs with the context's default: the layout of "
+                                                   f"num_threads = {ctx._num_threads} pool threads); round 6: handled inside the vector launch, no patch kernel")
         except Exception as exc:
             extras["reference_layout_mode"] = {"error": repr(exc)}
         finally:
-            ctx.set_reference_layout(False, threads=1)
+            ctx.set_reference_layout(True)      # the default again: the context's own num_threads
         # reference semantics: every call waits for completion (blocking context); A/B of the three ways to wait (csrc/context.cpp wait_stream)
         ctx.set_blocking(True)
         ctx.assume_device_pointers(True)      # step() makes the raw C call: the context must know these are device pointers
