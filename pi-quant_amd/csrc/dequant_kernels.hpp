@@ -294,6 +294,8 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
     // ragged tail and head, element by element, dealt over the threads of the whole grid after the tiles (quant_kernels.hpp explains)
     if (n_tiles * T::BLOCK_ELEMS < numel || head > 0) {   // kernel-uniform
         const int64_t gtid = static_cast<int64_t>(blockIdx.x) * BLOCK + threadIdx.x, gthreads = static_cast<int64_t>(tile_stride) * BLOCK;
+        const int64_t rag_elems = numel - n_tiles * T::BLOCK_ELEMS;   // a wave with nothing to do leaves before the scalar load below (quantize_kernel)
+        if (static_cast<int64_t>(blockIdx.x) * BLOCK + wave * 64 >= (rag_elems > head ? rag_elems : static_cast<int64_t>(head))) return;
         DequantParams pg = p;
         pg.ref = RefSplit {};
         if constexpr (DequantRefTail<BITS, DT_OUT, OP>::HAS_FORM) {

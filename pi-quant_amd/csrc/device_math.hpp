@@ -250,10 +250,13 @@ __device__ __forceinline__ RefPart ref_part(const RefSplit& s, int64_t t) {
     return r;
 }
 
-// index of the partition that holds global element g (0 <= g < n): the estimate g T / n in double is within one of it, the exact boundaries decide
+// index of the partition that holds global element g (0 <= g < n).  Without the alignment of the boundaries it is the largest t with n t / T <= g, i.e.
+// ceil((g + 1) T / n) - 1 (NOT floor(g T / n): a context with more threads than elements has empty partitions in front of the one that holds g, and
+// walking through them one division at a time took 30 us for a one-element tensor and 255 threads); the estimate in double is within one of it, the
+// exact boundaries -- aligned down to whole packed bytes, which can move g into the next partition or two -- decide.
 template <int PACK>
 __device__ __forceinline__ int64_t ref_partition_index(const RefSplit& s, int64_t g) {
-    int64_t t = static_cast<int64_t>(static_cast<double>(g) * s.rate);
+    int64_t t = static_cast<int64_t>(__builtin_ceil(static_cast<double>(g + 1) * s.rate)) - 1;
     const int64_t last = static_cast<int64_t>(s.T) - 1;
     t = t < 0 ? 0 : (t > last ? last : t);
     while (t > 0 && g < ref_boundary<PACK>(s, t)) --t;
@@ -295,6 +298,42 @@ __device__ __forceinline__ void ref_candidates(const RefSplit& s, int64_t g0, in
     const double T = static_cast<double>(s.T);
     ta = static_cast<int32_t>(__builtin_ceil(x0 < 0.0 ? 0.0 : x0));    // <= T + 1 <= 65537
     tb = static_cast<int32_t>(__builtin_floor(x1 > T ? T : x1));
+}
+
+// host half of RefSplit (device_math.hpp): the partition rule of a `threads`-thread reference context over a call of `total` elements
+inline RefSplit ref_split(bool on, int64_t total, int threads, int64_t index0, int out_align) {
+    RefSplit r {};
+    if (!on || total <= 0) return r;
+    const int64_t T = threads < 1 ? 1 : (threads > 65536 ? 65536 : threads);
+    r.n = total;
+    r.q = total / T;
+    r.rem = static_cast<uint32_t>(total % T);
+    r.T = static_cast<uint32_t>(T);
+    r.rate = static_cast<double>(T) / static_cast<double>(total);
+    r.index0 = index0;
+    r.out_align = out_align;
+    r.on = 1;
+    return r;
+}
+
+// The first look of the vector kernels (device_math.hpp, ref_first_look) for a kernel whose wave tiles hold `wave_tile` elements: the fractions of
+// t = g T / n at wave tile 0 and per wave tile, and a tile's width with both margins, as 0.64 fixed-point numbers (rounded down, down, up).
+inline void ref_prepare_first_look(RefSplit& r, int64_t wave_tile, int pack, int blk) {
+    if (!r.on) return;
+    using u128 = unsigned __int128;
+    const int below = 16 + pack + 2, above = blk + pack + 2;   // RefMargins
+    const u128 n = static_cast<u128>(r.n), T = r.T;
+    const u128 width = static_cast<u128>(wave_tile + below + above) * T;   // a tile's width in partitions, times n
+    if (width >= n || r.n > (int64_t {1} << 36)) {   // partitions no larger than a tile, or more tiles than the fixed point's slack covers
+        r.always = 1;
+        return;
+    }
+    __int128 a = (static_cast<__int128>(r.index0) - below) % static_cast<__int128>(n);
+    if (a < 0) a += static_cast<__int128>(n);
+    r.f0 = static_cast<uint64_t>((((static_cast<u128>(a) * T) % n) << 64) / n);
+    r.d = static_cast<uint64_t>(((static_cast<u128>(wave_tile) * T) << 64) / n);   // wave_tile * T < width < n
+    r.w = static_cast<uint64_t>(((width << 64) + n - 1) / n);
+    r.always = 0;
 }
 
 // The RefSplit of a streaming kernel's by-value parameter struct, fetched from the kernarg segment HERE and nowhere earlier.  Read as an ordinary

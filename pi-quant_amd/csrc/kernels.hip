@@ -29,42 +29,6 @@ inline unsigned capped_grid(int64_t want, int blocks_per_cu, int num_cu) {
     return static_cast<unsigned>(std::max<int64_t>(g, 1));
 }
 
-// host half of RefSplit (device_math.hpp): the partition rule of a `threads`-thread reference context over a call of `total` elements
-RefSplit ref_split(bool on, int64_t total, int threads, int64_t index0, int out_align) {
-    RefSplit r {};
-    if (!on || total <= 0) return r;
-    const int64_t T = std::min<int64_t>(std::max(threads, 1), 65536);
-    r.n = total;
-    r.q = total / T;
-    r.rem = static_cast<uint32_t>(total % T);
-    r.T = static_cast<uint32_t>(T);
-    r.rate = static_cast<double>(T) / static_cast<double>(total);
-    r.index0 = index0;
-    r.out_align = out_align;
-    r.on = 1;
-    return r;
-}
-
-// The first look of the vector kernels (device_math.hpp, ref_first_look) for a kernel whose wave tiles hold `wave_tile` elements: the fractions of
-// t = g T / n at wave tile 0 and per wave tile, and a tile's width with both margins, as 0.64 fixed-point numbers (rounded down, down, up).
-void ref_prepare_first_look(RefSplit& r, int64_t wave_tile, int pack, int blk) {
-    if (!r.on) return;
-    using u128 = unsigned __int128;
-    const int below = 16 + pack + 2, above = blk + pack + 2;   // RefMargins
-    const u128 n = static_cast<u128>(r.n), T = r.T;
-    const u128 width = static_cast<u128>(wave_tile + below + above) * T;   // a tile's width in partitions, times n
-    if (width >= n || r.n > (int64_t {1} << 36)) {   // partitions no larger than a tile, or more tiles than the fixed point's slack covers
-        r.always = 1;
-        return;
-    }
-    __int128 a = (static_cast<__int128>(r.index0) - below) % static_cast<__int128>(n);
-    if (a < 0) a += static_cast<__int128>(n);
-    r.f0 = static_cast<uint64_t>((((static_cast<u128>(a) * T) % n) << 64) / n);
-    r.d = static_cast<uint64_t>(((static_cast<u128>(wave_tile) * T) << 64) / n);   // wave_tile * T < width < n
-    r.w = static_cast<uint64_t>(((width << 64) + n - 1) / n);
-    r.always = 0;
-}
-
 template <int DT_IN, int BITS, int MODE, bool SMALL = false>
 void quantize_t(const QuantLaunch& q, const QuantParams& p, hipStream_t stream, int num_cu) {
     constexpr bool kStochastic = MODE == RM_STOCH_CALL || MODE == RM_STOCH_ELEM;
@@ -661,8 +625,11 @@ __global__ void __launch_bounds__(64) signal_flags_kernel(FlagList flags, int co
 // the context's pinned, host-coherent record and lets the stream go on (what follows consumes stale bytes); the host finds the record at its next
 // peer-to-peer call or status query and turns it into a message that names the rank (context.cpp, peer_timeout_pending).  Only a context without
 // host-coherent memory (record == nullptr) still traps.
+// The FIRST failure stays: a record the host has not fetched yet is not overwritten (behind a wait that gave up this rank signals nothing, so its own
+// later waits would run out on its OWN flag and name the wrong rank).
 __device__ __forceinline__ void report_peer_timeout(uint32_t* record, uint32_t kind, uint32_t index, uint32_t expected, uint32_t seen) {
     if (record == nullptr) __builtin_trap();
+    if (__hip_atomic_load(record + 0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != kPeerTimeoutNone) return;
     __hip_atomic_store(record + 1, index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(record + 2, expected, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(record + 3, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -670,6 +637,8 @@ __device__ __forceinline__ void report_peer_timeout(uint32_t* record, uint32_t k
 }
 
 __global__ void __launch_bounds__(64) wait_flags_kernel(const uint32_t* flags, int count, uint32_t value, uint64_t timeout_ticks, uint32_t* timeout_record) {
+    // an earlier wait of this context gave up and the host has not looked yet: the rest of that schedule is void anyway -- do not sit out another timeout
+    if (timeout_record != nullptr && __hip_atomic_load(timeout_record, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != kPeerTimeoutNone) return;
     const uint64_t t_begin = wall_clock64();
     for (int base = 0; base < count; base += 64) {
         const int i = base + static_cast<int>(threadIdx.x);

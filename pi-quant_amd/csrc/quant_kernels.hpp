@@ -543,36 +543,6 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
 
         [[maybe_unused]] ElementKeys keys {};
         if constexpr (MODE == RM_STOCH_ELEM) keys = element_keys_for(p, p.index_base + static_cast<uint64_t>(v0 + lane) * EPV);
-        // The short step (quantize_vec_short: about half the instructions per element for nearest, a third for stochastic) is exact whenever the zero point lies
-        // inside the quantized range and no element of the wave's tile reaches the range where x86's cvttps2dq turns indefinite --
-        // decided per wave tile from max|x| * |1/scale| (one v_max3 per two elements and one compare per lane).  Ordinary data always
-        // takes it; a tile with a NaN, an infinity or a huge value takes the long step, with the same bytes either way.
-        bool short_step = false;
-        if (short_ok) {
-            // First look: OR the tile's raw words (one v_or3_b32 per two dwords).  The top exponent bit of every element clear means
-            // every |x| < 2 -- zeros and denormals included, NaN and infinity excluded -- and then |x / scale| < 2 |1/scale| < 10^9 for any
-            // scale a quantizer sees (kernel-uniform condition).  Tensors of ordinary magnitude never get past this line; the exact
-            // test below runs for tiles that hold an element of magnitude 2 or more.
-            if (abs_inv < 5.0e8f) {
-                uint32_t o = 0;
-#pragma unroll
-                for (int k = 0; k < U; ++k) o |= raw[k][0] | raw[k][1] | raw[k][2] | raw[k][3];
-                short_step = __all((o & (DT_IN == DT_F32 ? 0x40000000u : 0x40004000u)) == 0 ? 1 : 0) != 0;
-            }
-            if (short_step) {
-            } else if constexpr (DT_IN == DT_BF16) {
-                uint32_t m = 0;
-#pragma unroll
-                for (int k = 0; k < U; ++k) m = vec_absmax_bits_bf16(raw[k], m);
-                short_step = __all(__fmul_rn(absmax_bits_to_float(m), abs_inv) < 1.0e9f ? 1 : 0) != 0;   // false for a NaN maximum
-            } else {
-                float amax = 0.0f;
-                bool nan = false;
-#pragma unroll
-                for (int k = 0; k < U; ++k) amax = vec_absmax_f32(raw[k], amax, nan);
-                short_step = __all(!nan && __fmul_rn(amax, abs_inv) < 1.0e9f ? 1 : 0) != 0;
-            }
-        }
         uint8_t* o = out + v0 * OB;                                    // output of this wave tile
         // stores of the tile's packed words; written once, called from both branches below so that the two quantization paths never
         // have to merge their results (a merge costs a register copy per word)
@@ -611,16 +581,20 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
                 __builtin_amdgcn_wave_barrier();
             }
         };
-        // vectors that hold scalar positions of the reference layout are quantized again, element by element, with the formula of each position
-        auto patch = [&](uint32_t (&w)[U][WORDS]) {
+        // A tile that scalar positions of the reference layout reach into is quantized on a path of its own -- the long step everywhere (same bytes as the
+        // short one), and element by element with the formula of each position in the vectors that hold such positions.  Its own path, not a patch of the
+        // other two's results: merely keeping the input vectors alive behind the short step for a patch that nearly never runs cost every launch 0.25 us
+        // (interleaved A/B of the kernel with and without the patch's code, profiles/r06_ab_kernel_variants.txt).
+        bool ref_tile = false;
+        if constexpr (MODE == RM_NEAREST_FAST) ref_tile = ref_ta <= ref_tb;   // wave-uniform
+        if (__builtin_expect(ref_tile, 0)) {
             if constexpr (MODE == RM_NEAREST_FAST) {
-                if (ref_ta > ref_tb) return;   // wave-uniform
                 constexpr int QMAX = (1 << BITS) - 1;
                 uint32_t m[U];
                 ref_scalar_masks<8 / BITS, QuantRefBlock<BITS>::value, EPV, U>(ref, ref_ta, ref_tb, ref.index0 + (v0 + lane) * EPV, 64 * EPV, m);
+                uint32_t w[U][WORDS];
 #pragma unroll
                 for (int k = 0; k < U; ++k) {
-                    if (m[k] == 0) continue;
                     float v[EPV];
                     InVec<DT_IN>::unpack(raw[k], v);
 #pragma unroll
@@ -631,20 +605,50 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
                         w[k][(e * BITS) >> 5] |= q << ((e * BITS) & 31);
                     }
                 }
+                put(w);
             }
-        };
-        if (__builtin_expect(short_step, 1)) {
-            uint32_t w[U][WORDS];
-#pragma unroll
-            for (int k = 0; k < U; ++k) quantize_vec_short<DT_IN, BITS, MODE>(raw[k], p, keys, static_cast<uint64_t>(v0 + k * 64 + lane) * EPV, bstep, w[k]);
-            patch(w);
-            put(w);
         } else {
-            uint32_t w[U][WORDS];
+            // The short step (quantize_vec_short: about half the instructions per element for nearest, a third for stochastic) is exact whenever the zero point lies
+            // inside the quantized range and no element of the wave's tile reaches the range where x86's cvttps2dq turns indefinite --
+            // decided per wave tile from max|x| * |1/scale| (one v_max3 per two elements and one compare per lane).  Ordinary data always
+            // takes it; a tile with a NaN, an infinity or a huge value takes the long step, with the same bytes either way.
+            bool short_step = false;
+            if (short_ok) {
+                // First look: OR the tile's raw words (one v_or3_b32 per two dwords).  The top exponent bit of every element clear means
+                // every |x| < 2 -- zeros and denormals included, NaN and infinity excluded -- and then |x / scale| < 2 |1/scale| < 10^9 for any
+                // scale a quantizer sees (kernel-uniform condition).  Tensors of ordinary magnitude never get past this line; the exact
+                // test below runs for tiles that hold an element of magnitude 2 or more.
+                if (abs_inv < 5.0e8f) {
+                    uint32_t o = 0;
+    #pragma unroll
+                    for (int k = 0; k < U; ++k) o |= raw[k][0] | raw[k][1] | raw[k][2] | raw[k][3];
+                    short_step = __all((o & (DT_IN == DT_F32 ? 0x40000000u : 0x40004000u)) == 0 ? 1 : 0) != 0;
+                }
+                if (short_step) {
+                } else if constexpr (DT_IN == DT_BF16) {
+                    uint32_t m = 0;
+    #pragma unroll
+                    for (int k = 0; k < U; ++k) m = vec_absmax_bits_bf16(raw[k], m);
+                    short_step = __all(__fmul_rn(absmax_bits_to_float(m), abs_inv) < 1.0e9f ? 1 : 0) != 0;   // false for a NaN maximum
+                } else {
+                    float amax = 0.0f;
+                    bool nan = false;
+    #pragma unroll
+                    for (int k = 0; k < U; ++k) amax = vec_absmax_f32(raw[k], amax, nan);
+                    short_step = __all(!nan && __fmul_rn(amax, abs_inv) < 1.0e9f ? 1 : 0) != 0;
+                }
+            }
+            if (__builtin_expect(short_step, 1)) {
+                uint32_t w[U][WORDS];
 #pragma unroll
-            for (int k = 0; k < U; ++k) quantize_vec<DT_IN, BITS, MODE>(raw[k], p, keys, static_cast<uint64_t>(v0 + k * 64 + lane) * EPV, w[k]);
-            patch(w);
-            put(w);
+                for (int k = 0; k < U; ++k) quantize_vec_short<DT_IN, BITS, MODE>(raw[k], p, keys, static_cast<uint64_t>(v0 + k * 64 + lane) * EPV, bstep, w[k]);
+                put(w);
+            } else {
+                uint32_t w[U][WORDS];
+#pragma unroll
+                for (int k = 0; k < U; ++k) quantize_vec<DT_IN, BITS, MODE>(raw[k], p, keys, static_cast<uint64_t>(v0 + k * 64 + lane) * EPV, w[k]);
+                put(w);
+            }
         }
     }
 
@@ -658,6 +662,10 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
     const bool ragged = n_tiles * T::BLOCK_ELEMS < numel;
     if (ragged || head > 0) {   // kernel-uniform
         const int64_t gtid = static_cast<int64_t>(blockIdx.x) * BLOCK + threadIdx.x, gthreads = static_cast<int64_t>(tile_stride) * BLOCK;
+        // a wave none of whose threads has a byte to do leaves here -- nearly all of them, and before the scalar load of the reference layout below: that load
+        // and its wait at the end of EVERY wave of a 26 000-block grid cost the launch 0.35 us (profiles/r06_ab_kernel_variants.txt, new3)
+        const int64_t rag_bytes = ragged ? (numel + PACK - 1) / PACK - n_tiles * T::BLOCK_ELEMS / PACK : 0, head_bytes = head / PACK;
+        if (static_cast<int64_t>(blockIdx.x) * BLOCK + wave * 64 >= (rag_bytes > head_bytes ? rag_bytes : head_bytes)) return;
         QuantParams pg = p;
         pg.ref = RefSplit {};
         if constexpr (MODE == RM_NEAREST_FAST) {

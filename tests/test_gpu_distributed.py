@@ -700,6 +700,8 @@ def _p2p_late_rank_worker(rank, world, port, out_q):
         D.quantized_all_reduce(v, transport="p2p", timeout=30.0)
         D.check_peer_timeouts()
         report["after_release"] = v.cpu().numpy()
+        assert D.compute_quant_params(x, dtype=torch.quint8, transport="p2p") == on_time     # (builds the key mesh again: a collective, everybody on time)
+        torch.cuda.synchronize()
         dist.barrier()
         # 3. compute_quant_params(transport='p2p') with a late rank beyond the limit raises from the call itself (it is synchronous)
         if rank == 1:
