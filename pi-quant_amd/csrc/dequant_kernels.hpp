@@ -9,6 +9,9 @@
 // behaviour (src/kernels/kernels_specialized.inl:753-758, 953-971, 1244-1284).
 #pragma once
 
+#include <cstdio>
+#include <cstdlib>
+
 #include <type_traits>
 
 #include "quant_kernels.hpp"
@@ -94,12 +97,13 @@ __global__ void __launch_bounds__(256) dequantize_scalar_kernel(const uint8_t* i
 struct DequantKernargs {
     const uint8_t* in;
     void* out;
-    int64_t numel, n_tiles;
+    int64_t numel;
+    uint64_t ref_m;
     float scale;
     int head;
     const ParamRecord* dyn;
     int32_t zp32;
-    uint32_t tile_stride;
+    uint32_t n_tiles;
     DequantParams p;
 };
 constexpr uint32_t kDequantKernargRef = static_cast<uint32_t>(__builtin_offsetof(DequantKernargs, p) + __builtin_offsetof(DequantParams, ref));
@@ -119,8 +123,11 @@ struct DequantTile {
 // kernels carry none of it (as a run-time branch it cost the 256-thread bf16-output kernels 0.4 us: 11.7 -> 12.1 us for uint4 -> bf16).
 template <int BITS, int DT_OUT, int OP, int U, bool STAGE, int NT, int BLOCK, bool SHIFTED = false>
 __global__ void __launch_bounds__(BLOCK)
-dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int64_t n_tiles, float scale, int head, const ParamRecord* dyn, int32_t zp32,
-                  uint32_t tile_stride, DequantParams p_arg) {
+dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, uint64_t look_m, float scale, int head, const ParamRecord* dyn, int32_t zp32,
+                  uint32_t tiles, DequantParams p_arg) {
+    // one tile per block: the grid is the tile count (quantize_kernel); look_m: the preloaded constant of the reference layout's first look, or 0
+    const int64_t n_tiles = tiles;
+    const uint32_t tile_stride = tiles > 0 ? tiles : 1u;
     // `head` carries two numbers: bits 0-15 the elements peeled in front of the body, bits 16-18 `shift` = the bits of in[0] that belong to
     // those peeled elements when their number is not a whole packed byte (a uint4 tensor decoded into a float slice that starts an odd number
     // of elements before a cache line: the body then starts in the middle of a byte, and every vector's packed bits are funnel-shifted into
@@ -153,31 +160,52 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
     u32x4* out16 = static_cast<u32x4*>(out);
 
 
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += tile_stride) {
+    if (const int64_t turn = blockIdx.x; turn < n_tiles) {
+        // Reference layout: the call's LAST tile holds the scalar tail of the last partition, i.e. it takes the slow path below -- and the block that is
+        // dispatched last is the one whose latency is the kernel's.  The tiles are dealt rotated by one: block 0 takes the last tile, everybody else the
+        // tile in front of its own (uint4 -> bf16 SET at numel 27 264 000 for a 255-thread context: 12.8 -> 11.9 us, profiles/r06_dtype_matrix_ab.txt).
+        const int64_t tile = !ref_on ? turn : (turn == 0 ? n_tiles - 1 : turn - 1);
         const int64_t v0 = (tile * T::WAVES + wave) * T::WAVE_VECS;     // first output vector of this wave tile
         const uint8_t* src = in + v0 * IB;
 
         u32x4 old[OP == OP_ADD ? U : 1];
-        if constexpr (OP == OP_ADD) {
+        // (the accumulator is loaded BEHIND the packed input -- load_old below: the input is the head of the chain load -> LDS -> unpack, and loads return in order)
+        auto load_old = [&]() {
+            if constexpr (OP == OP_ADD) {
 #pragma unroll
-            for (int k = 0; k < U; ++k) old[k] = ld<NT_LD>(out16 + v0 + k * 64 + lane);
-        }
+                for (int k = 0; k < U; ++k) old[k] = ld<NT_LD>(out16 + v0 + k * 64 + lane);
+            }
+        };
 
-        // Reference layout, first look (device_math.hpp, ref_candidates): does the scalar tail of a reference partition reach into this wave tile?
+        // Reference layout, first look (device_math.hpp, ref_candidates): does the scalar tail of a reference partition reach into this wave tile?  Called
+        // once ALL of the tile's global loads are on their way -- the accumulator's and the packed input's: its scalar load and wait in front of the input
+        // loads delayed them by a scalar-cache round trip in every wave, 1.4-1.7 us on the 12-22 us bf16-output launches (profiles/r06_dtype_matrix_ab.txt).
         [[maybe_unused]] int32_t ref_ta = 1, ref_tb = 0;
         [[maybe_unused]] uint32_t ref_m[U] = {};
-        if constexpr (DequantRefTail<BITS, DT_OUT, OP>::HAS_FORM) {
-            if (ref_on) {
-                using Ref = DequantRefTail<BITS, DT_OUT, OP>;
-                const RefSplit ref = load_ref_split<kDequantKernargRef>();   // behind the tile's loads, on purpose
-                if (ref_first_look(ref, static_cast<uint64_t>(tile) * T::WAVES + static_cast<uint32_t>(wave))) {
-                    const int64_t g0 = ref.index0 + v0 * EPV;
-                    ref_candidates<8 / BITS, Ref::BLK>(ref, g0, g0 + static_cast<int64_t>(T::WAVE_VECS) * EPV, ref_ta, ref_tb);
-                    if (ref_ta <= ref_tb)   // wave-uniform, rare: which elements of this lane's vectors are tail positions
-                        ref_scalar_masks<8 / BITS, Ref::BLK, EPV, U>(ref, ref_ta, ref_tb, ref.index0 + (v0 + lane) * EPV, 64 * EPV, ref_m);
+        auto ref_look = [&]() {
+            if constexpr (DequantRefTail<BITS, DT_OUT, OP>::HAS_FORM) {
+                if (ref_on) {
+                    using Ref = DequantRefTail<BITS, DT_OUT, OP>;
+                    using Margins = RefMargins<8 / BITS, Ref::BLK>;
+                    const uint64_t wave_tile = static_cast<uint64_t>(tile) * T::WAVES + static_cast<uint32_t>(wave);
+                    RefSplit ref {};
+                    bool look;
+                    if (look_m != 0) {
+                        look = ref_first_look_fast<Margins::below, Margins::above>(look_m, wave_tile, T::WAVE_VECS * EPV);
+                        if (look) ref = load_ref_split<kDequantKernargRef>();   // one tile in a hundred
+                    } else {
+                        ref = load_ref_split<kDequantKernargRef>();
+                        look = ref_first_look(ref, wave_tile);
+                    }
+                    if (look) {
+                        const int64_t g0 = ref.index0 + v0 * EPV;
+                        ref_candidates<8 / BITS, Ref::BLK>(ref, g0, g0 + static_cast<int64_t>(T::WAVE_VECS) * EPV, ref_ta, ref_tb);
+                        if (ref_ta <= ref_tb)   // wave-uniform, rare: which elements of this lane's vectors are tail positions
+                            ref_scalar_masks<8 / BITS, Ref::BLK, EPV, U>(ref, ref_ta, ref_tb, ref.index0 + (v0 + lane) * EPV, 64 * EPV, ref_m);
+                    }
                 }
             }
-        }
+        };
 
         uint32_t w[U][WORDS];
         if constexpr (!STAGE) {
@@ -199,21 +227,44 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
                     }
                 }
             }
+            load_old();
+            ref_look();
         } else {
             uint8_t* s = lds + wave * SLICE;
+            // the wave's packed input: global loads first, all of them, then the look at the reference layout, then into the wave's LDS slice
+            constexpr int N16 = T::LANE_IN_BYTES >= 16 ? T::LANE_IN_BYTES / 16 : 1;
+            [[maybe_unused]] u32x4 t16[N16];
+            [[maybe_unused]] u32x2 t8;
+            [[maybe_unused]] uint32_t t4 = 0;
+            [[maybe_unused]] uint16_t t2 = 0;
+            [[maybe_unused]] uint8_t t_last = 0;
             if constexpr (T::LANE_IN_BYTES >= 16) {
 #pragma unroll
-                for (int j = 0; j < T::LANE_IN_BYTES / 16; ++j)
-                    reinterpret_cast<u32x4*>(s)[j * 64 + lane] = ld<NT_LD>(reinterpret_cast<const u32x4*>(src) + j * 64 + lane);
+                for (int j = 0; j < N16; ++j) t16[j] = ld<NT_LD>(reinterpret_cast<const u32x4*>(src) + j * 64 + lane);
             } else if constexpr (T::LANE_IN_BYTES == 8) {
-                reinterpret_cast<u32x2*>(s)[lane] = ld<NT_LD>(reinterpret_cast<const u32x2*>(src) + lane);
+                t8 = ld<NT_LD>(reinterpret_cast<const u32x2*>(src) + lane);
             } else if constexpr (T::LANE_IN_BYTES == 4) {
-                reinterpret_cast<uint32_t*>(s)[lane] = ld<NT_LD>(reinterpret_cast<const uint32_t*>(src) + lane);
+                t4 = ld<NT_LD>(reinterpret_cast<const uint32_t*>(src) + lane);
             } else {
-                reinterpret_cast<uint16_t*>(s)[lane] = ld<NT_LD>(reinterpret_cast<const uint16_t*>(src) + lane);
+                t2 = ld<NT_LD>(reinterpret_cast<const uint16_t*>(src) + lane);
             }
             if constexpr (SHIFTED) {
-                if (lane == 0) s[T::WAVE_IN_BYTES] = ld<NT_LD>(src + T::WAVE_IN_BYTES);   // the byte the last vector's bits run into
+                if (lane == 0) t_last = ld<NT_LD>(src + T::WAVE_IN_BYTES);   // the byte the last vector's bits run into
+            }
+            load_old();
+            ref_look();
+            if constexpr (T::LANE_IN_BYTES >= 16) {
+#pragma unroll
+                for (int j = 0; j < N16; ++j) reinterpret_cast<u32x4*>(s)[j * 64 + lane] = t16[j];
+            } else if constexpr (T::LANE_IN_BYTES == 8) {
+                reinterpret_cast<u32x2*>(s)[lane] = t8;
+            } else if constexpr (T::LANE_IN_BYTES == 4) {
+                reinterpret_cast<uint32_t*>(s)[lane] = t4;
+            } else {
+                reinterpret_cast<uint16_t*>(s)[lane] = t2;
+            }
+            if constexpr (SHIFTED) {
+                if (lane == 0) s[T::WAVE_IN_BYTES] = t_last;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -240,17 +291,35 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
             __builtin_amdgcn_wave_barrier();
         }
 
-#pragma unroll
-        for (int k = 0; k < U; ++k) {
-            float f[EPV];
-#pragma unroll
-            for (int e = 0; e < EPV; ++e) {
-                const uint32_t q = (w[k][(e * BITS) >> 5] >> ((e * BITS) & 31)) & ((1u << BITS) - 1u);
-                f[e] = dequant_one<FORM>(q, p);
-            }
-            u32x4 r;
+        // A tile that tail positions of the reference layout reach into is decoded on a path of its own, element by element, each with the formula of its
+        // position (wave-uniform, rare; its own path so that the ordinary one carries nothing of it: quantize_kernel has the measurement).
+        bool ref_tile = false;
+        if constexpr (DequantRefTail<BITS, DT_OUT, OP>::HAS_FORM) ref_tile = ref_ta <= ref_tb;
+        if (__builtin_expect(ref_tile, 0)) {
             if constexpr (DequantRefTail<BITS, DT_OUT, OP>::HAS_FORM) {
-                if (ref_m[k] != 0) {   // a vector with tail positions of the reference layout: element by element, each with the formula of its position
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    u32x4 r;
+                    if (ref_m[k] == 0) {   // per lane; a tail is at most BLK - 1 elements: most vectors of the tile take the vector form
+                        float f[EPV];
+#pragma unroll
+                        for (int e = 0; e < EPV; ++e) f[e] = dequant_one<FORM>((w[k][(e * BITS) >> 5] >> ((e * BITS) & 31)) & ((1u << BITS) - 1u), p);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if constexpr (DT_OUT == DT_F32) {
+                                if constexpr (OP == OP_ADD) f[e] = __fadd_rn(f[e], __uint_as_float(old[k][e]));
+                                r[e] = __float_as_uint(f[e]);
+                            } else {
+                                if constexpr (OP == OP_ADD) {
+                                    f[2 * e] = __fadd_rn(f[2 * e], __uint_as_float(old[k][e] << 16));
+                                    f[2 * e + 1] = __fadd_rn(f[2 * e + 1], __uint_as_float(old[k][e] & 0xffff0000u));
+                                }
+                                r[e] = f32x2_to_bf16x2_bits(f[2 * e], f[2 * e + 1]);
+                            }
+                        }
+                        st<NT_ST>(out16 + v0 + k * 64 + lane, r);
+                        continue;
+                    }
 #pragma unroll
                     for (int e = 0; e < EPV; ++e) {
                         const uint32_t q = (w[k][(e * BITS) >> 5] >> ((e * BITS) & 31)) & ((1u << BITS) - 1u);
@@ -260,7 +329,7 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
                         if (((ref_m[k] >> e) & 1u) != 0) {
                             bits = dequant_ref_tail<BITS, DT_OUT, OP>(q, o, p);
                         } else {
-                            float g = f[e];
+                            float g = dequant_one<FORM>(q, p);
                             if constexpr (OP == OP_ADD) g = __fadd_rn(g, DT_OUT == DT_F32 ? __uint_as_float(o) : bf16_bits_to_f32(o));
                             bits = DT_OUT == DT_F32 ? __float_as_uint(g) : f32_to_bf16_bits(g);
                         }
@@ -268,26 +337,39 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
                         else r[e >> 1] = (e & 1) != 0 ? (r[e >> 1] | (bits << 16)) : bits;
                     }
                     st<NT_ST>(out16 + v0 + k * 64 + lane, r);
-                    continue;
                 }
             }
-            if constexpr (DT_OUT == DT_F32) {
+        } else {
+            // all of the tile's vectors first, then its stores back to back (U KiB of consecutive lines per wave in one burst: with the stores dealt between
+            // the vectors' arithmetic uint4 -> bf16 SET ran 12.8 instead of 11.7 us, profiles/r06_dtype_matrix_ab.txt)
+            u32x4 r[U];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if constexpr (OP == OP_ADD) f[e] = __fadd_rn(f[e], __uint_as_float(old[k][e]));
-                    r[e] = __float_as_uint(f[e]);
+            for (int k = 0; k < U; ++k) {
+                float f[EPV];
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                    const uint32_t q = (w[k][(e * BITS) >> 5] >> ((e * BITS) & 31)) & ((1u << BITS) - 1u);
+                    f[e] = dequant_one<FORM>(q, p);
                 }
-            } else {
+                if constexpr (DT_OUT == DT_F32) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if constexpr (OP == OP_ADD) {
-                        f[2 * e] = __fadd_rn(f[2 * e], __uint_as_float(old[k][e] << 16));
-                        f[2 * e + 1] = __fadd_rn(f[2 * e + 1], __uint_as_float(old[k][e] & 0xffff0000u));
+                    for (int e = 0; e < 4; ++e) {
+                        if constexpr (OP == OP_ADD) f[e] = __fadd_rn(f[e], __uint_as_float(old[k][e]));
+                        r[k][e] = __float_as_uint(f[e]);
                     }
-                    r[e] = f32x2_to_bf16x2_bits(f[2 * e], f[2 * e + 1]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if constexpr (OP == OP_ADD) {
+                            f[2 * e] = __fadd_rn(f[2 * e], __uint_as_float(old[k][e] << 16));
+                            f[2 * e + 1] = __fadd_rn(f[2 * e + 1], __uint_as_float(old[k][e] & 0xffff0000u));
+                        }
+                        r[k][e] = f32x2_to_bf16x2_bits(f[2 * e], f[2 * e + 1]);
+                    }
                 }
             }
-            st<NT_ST>(out16 + v0 + k * 64 + lane, r);
+#pragma unroll
+            for (int k = 0; k < U; ++k) st<NT_ST>(out16 + v0 + k * 64 + lane, r[k]);
         }
     }
 
@@ -313,17 +395,25 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, int6
 }
 
 template <int BITS, int DT_OUT, int OP, int U, bool STAGE, int NT, int BLOCK>
-inline void launch_dequantize_kernel(unsigned grid, hipStream_t stream, const uint8_t* in, void* out, int64_t numel, int64_t n_tiles, const DequantParams& p, int head) {
+inline void launch_dequantize_kernel(hipStream_t stream, const uint8_t* in, void* out, int64_t numel, int64_t n_tiles, const DequantParams& p, int head) {
+    using Tile = DequantTile<BITS, DT_OUT, U, BLOCK>;
+    using Ref = DequantRefTail<BITS, DT_OUT, OP>;
     if (p.ref.on) head |= 1 << 19;   // dequantize_kernel: bits 0-15 peeled elements, 16-18 shift, 19 reference layout
+    if (n_tiles > 0x7fffffff) {   // 2^41 elements: not on this device
+        fprintf(stderr, "dequantize: %lld tiles in one launch\n", static_cast<long long>(n_tiles));
+        abort();
+    }
+    const uint64_t ref_m = Ref::HAS_FORM ? ref_fast_look_constant(p.ref, Tile::BLOCK_ELEMS / Tile::WAVES, 8 / BITS, Ref::BLK) : 0;
+    const unsigned grid = n_tiles > 0 ? static_cast<unsigned>(n_tiles) : 1u;
+    const uint32_t tiles = static_cast<uint32_t>(n_tiles);
     if constexpr (BITS < 8) {
         if (((head >> 16) & 7) != 0) {   // the body starts inside a packed byte
-            PQ_LAUNCH((dequantize_kernel<BITS, DT_OUT, OP, U, STAGE, NT, BLOCK, true>), dim3(grid), dim3(BLOCK), 0, stream, in, out, numel, n_tiles, p.scale,
-                      head, p.dyn, p.zp32, grid, p);
+            PQ_LAUNCH((dequantize_kernel<BITS, DT_OUT, OP, U, STAGE, NT, BLOCK, true>), dim3(grid), dim3(BLOCK), 0, stream, in, out, numel, ref_m, p.scale, head, p.dyn, p.zp32,
+                      tiles, p);
             return;
         }
     }
-    PQ_LAUNCH((dequantize_kernel<BITS, DT_OUT, OP, U, STAGE, NT, BLOCK>), dim3(grid), dim3(BLOCK), 0, stream, in, out, numel, n_tiles, p.scale, head,
-              p.dyn, p.zp32, grid, p);
+    PQ_LAUNCH((dequantize_kernel<BITS, DT_OUT, OP, U, STAGE, NT, BLOCK>), dim3(grid), dim3(BLOCK), 0, stream, in, out, numel, ref_m, p.scale, head, p.dyn, p.zp32, tiles, p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

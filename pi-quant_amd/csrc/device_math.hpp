@@ -286,6 +286,20 @@ __device__ __forceinline__ bool ref_first_look(const RefSplit& s, uint64_t wave_
     return s.always != 0 || f + s.w < f;
 }
 
+// The first look WITHOUT the RefSplit -- from one preloaded 64-bit constant, for the common launch (the call's element 0 is the launch's element 0, i.e.
+// no peeled head and no staged chunk; at most 2^31 elements).  m = floor(2^64 T / n), so frac(x) of x = (tile * S - below) T / n is the low 64 bits of
+// (tile * S - below) * m, short by less than n * 2^-64 <= 2^-33 of a partition, and a tile's width is (S + below + above) * m; the two elements of slack
+// inside the margins are worth 2 m >= 2^34 T / n * 2^-33... in 64-bit fixed point: 2 m >= n whenever n <= 2^32 sqrt(T), which the host checks.  The
+// RefSplit itself -- 80 bytes of the kernarg segment, which lives in host memory -- is then fetched by the one tile in a hundred that passes the look:
+// fetched by EVERY wave it cost uint4 -> bf16 SET, whose waves have a single 16-byte load in flight to hide it behind, 0.7 us of 12
+// (profiles/r06_ab_kernel_variants.txt, dq4 ref1 against uniform).
+template <int BELOW, int ABOVE>
+__device__ __forceinline__ bool ref_first_look_fast(uint64_t m, uint64_t wave_tile, uint32_t wave_tile_elems) {
+    const uint64_t f = (wave_tile * wave_tile_elems - static_cast<uint64_t>(BELOW)) * m;
+    const uint64_t w = (static_cast<uint64_t>(wave_tile_elems) + BELOW + ABOVE) * m;
+    return f + w < f;
+}
+
 template <int PACK, int BLK>
 struct RefMargins {
     static constexpr int below = 16 + PACK + 2, above = BLK + PACK + 2;   // elements: head reach + boundary alignment + slack; tail reach + alignment + slack
@@ -334,6 +348,16 @@ inline void ref_prepare_first_look(RefSplit& r, int64_t wave_tile, int pack, int
     r.d = static_cast<uint64_t>(((static_cast<u128>(wave_tile) * T) << 64) / n);   // wave_tile * T < width < n
     r.w = static_cast<uint64_t>(((width << 64) + n - 1) / n);
     r.always = 0;
+}
+
+// m of ref_first_look_fast for a launch whose wave tiles hold `wave_tile` elements, or 0 when the launch must take the look that reads the RefSplit
+// (a launch that does not start at the call's element 0, partitions no larger than a tile, more than 2^31 elements)
+inline uint64_t ref_fast_look_constant(const RefSplit& r, int64_t wave_tile, int pack, int blk) {
+    if (!r.on || r.always || r.index0 != 0 || r.n > (int64_t {1} << 31)) return 0;
+    const unsigned __int128 m = ((static_cast<unsigned __int128>(r.T) << 64) / static_cast<unsigned __int128>(r.n));
+    const int width = static_cast<int>(wave_tile) + (16 + pack + 2) + (blk + pack + 2);
+    if (m == 0 || 2 * m < static_cast<unsigned __int128>(r.n) || (m * static_cast<unsigned>(width)) >> 64 != 0) return 0;
+    return static_cast<uint64_t>(m);
 }
 
 // The RefSplit of a streaming kernel's by-value parameter struct, fetched from the kernarg segment HERE and nowhere earlier.  Read as an ordinary
@@ -399,13 +423,21 @@ __device__ __forceinline__ void ref_scalar_masks(const RefSplit& s, int32_t ta, 
             }
         }
     } else {
+        // many small partitions: per vector, partition by partition (a vector of 4 or 8 elements lies in one partition or straddles a boundary or two) --
+        // one lookup per partition touched instead of one per element, which is what a small tensor under a 255-thread context pays in EVERY wave
 #pragma unroll
-        for (int k = 0; k < U; ++k)
-#pragma unroll
-            for (int e = 0; e < EPV; ++e) {
-                const int64_t g = e0 + k * stride + e;
-                if (g < s.n && ref_scalar_position<PACK, BLK>(s, g)) m[k] |= 1u << e;
+        for (int k = 0; k < U; ++k) {
+            const int64_t first = e0 + k * stride, stop = first + EPV < s.n ? first + EPV : s.n;
+            for (int64_t g = first; g < stop;) {
+                const RefPart part = ref_part<PACK, BLK>(s, ref_partition_index<PACK>(s, g));
+                const int64_t hi = part.end < stop ? part.end : stop;                       // elements [g, hi) of the vector lie in this partition
+                const int64_t h1 = part.head_end < hi ? part.head_end : hi;                  // scalar: [g, h1) and [max(g, body_end), hi)
+                const int64_t t0 = part.body_end > g ? part.body_end : g;
+                if (h1 > g) m[k] |= ((1u << (h1 - first)) - 1u) & ~((1u << (g - first)) - 1u);
+                if (hi > t0) m[k] |= ((1u << (hi - first)) - 1u) & ~((1u << (t0 - first)) - 1u);
+                g = hi > g ? hi : g + 1;
             }
+        }
     }
 }
 

@@ -60,10 +60,8 @@ void quantize_t(const QuantLaunch& q, const QuantParams& p, hipStream_t stream, 
     body.ref.index0 += head;
     if (MODE == RM_NEAREST_FAST) ref_prepare_first_look(body.ref, Tile::BLOCK_ELEMS / Tile::WAVES, PACK, QuantRefBlock<BITS>::value);
     const int64_t numel = q.numel - head;
-    const int64_t n_tiles = numel / Tile::BLOCK_ELEMS;
-    const unsigned grid = capped_grid(n_tiles, t.blocks_per_cu, num_cu);
-    launch_quantize_kernel<DT_IN, BITS, MODE, t.u, t.stage, t.nt, t.block>(
-        grid, 0, stream, static_cast<const void*>(static_cast<const uint8_t*>(q.in) + head * ESIZE), out + head_bytes, numel, n_tiles, body, static_cast<int>(head));
+    launch_quantize_kernel<DT_IN, BITS, MODE, t.u, t.stage, t.nt, t.block>(stream, static_cast<const void*>(static_cast<const uint8_t*>(q.in) + head * ESIZE), out + head_bytes,
+                                                                           numel, numel / Tile::BLOCK_ELEMS, body, static_cast<int>(head));
 }
 
 template <int DT_IN, int BITS>
@@ -118,10 +116,8 @@ void dequantize_t(const DequantLaunch& d, const DequantParams& p, hipStream_t st
     body.ref.index0 += head;
     if (DequantRefTail<BITS, DT_OUT, OP>::HAS_FORM) ref_prepare_first_look(body.ref, Tile::BLOCK_ELEMS / Tile::WAVES, PACK, DequantRefTail<BITS, DT_OUT, OP>::BLK);
     const int64_t numel = d.numel - head;
-    const int64_t n_tiles = numel / Tile::BLOCK_ELEMS;
-    const unsigned grid = capped_grid(n_tiles, t.blocks_per_cu, num_cu);
-    launch_dequantize_kernel<BITS, DT_OUT, OP, t.u, t.stage, t.nt, t.block>(grid, stream, in + head / PACK, static_cast<void*>(static_cast<uint8_t*>(d.out) + head * ESIZE),
-                                                                            numel, n_tiles, body, static_cast<int>(head) | (shift << 16));
+    launch_dequantize_kernel<BITS, DT_OUT, OP, t.u, t.stage, t.nt, t.block>(stream, in + head / PACK, static_cast<void*>(static_cast<uint8_t*>(d.out) + head * ESIZE), numel,
+                                                                            numel / Tile::BLOCK_ELEMS, body, static_cast<int>(head) | (shift << 16));
 }
 
 template <int BITS, int DT_OUT>

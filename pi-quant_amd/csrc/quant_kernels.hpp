@@ -17,6 +17,9 @@
 // the whole grid, so a call is always exactly one kernel (a second launch would cost ~1.5 us on a ~20 us kernel).
 #pragma once
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "device_math.hpp"
 #include "stop_event.hpp"
 
@@ -440,11 +443,12 @@ __device__ __forceinline__ void store_packed(uint8_t* dst, const uint32_t (&w)[O
 struct QuantKernargs {
     const void* in;
     uint8_t* out;
-    int64_t numel, n_tiles;
+    int64_t numel;
+    uint64_t ref_m;
     float inv_scale;
     int32_t zp32;
     const ParamRecord* dyn;
-    uint32_t flags, tile_stride;
+    uint32_t flags, n_tiles;
     QuantParams p;
 };
 constexpr uint32_t kQuantKernargRef = static_cast<uint32_t>(__builtin_offsetof(QuantKernargs, p) + __builtin_offsetof(QuantParams, ref));
@@ -462,8 +466,11 @@ struct QuantTile {
 
 template <int DT_IN, int BITS, int MODE, int U, bool STAGE, int NT, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
-quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t numel, int64_t n_tiles, float inv_scale, int32_t zp32,
-                const ParamRecord* dyn, uint32_t flags, uint32_t tile_stride, QuantParams p_arg) {
+quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t numel, uint64_t look_m, float inv_scale, int32_t zp32,
+                const ParamRecord* dyn, uint32_t flags, uint32_t tiles, QuantParams p_arg) {
+    // One tile per block: the grid IS the tile count (`tiles`; 0 when the tensor is smaller than a tile and the one block only does the guarded work).
+    const int64_t n_tiles = tiles;
+    const uint32_t tile_stride = tiles > 0 ? tiles : 1u;
     // `in` / `out` / `numel` / the positions in `p_arg` describe the BODY of the call: the launcher has peeled `head` leading elements (a whole
     // number of packed bytes) so that `out` is 16-byte aligned; block 0 quantizes them through the guarded path below, like the ragged tail.
     // The nine scalar arguments in front of p_arg are 14 dwords, and those arrive preloaded in SGPRs (Makefile: -amdgpu-kernarg-preload-count;
@@ -473,7 +480,8 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
     // or of the dispatch packet.  (`head` travelled as a trailing argument for a day: the compiler hoists its s_load to the kernel's
     // first instruction and the next lgkmcnt wait -- in front of the first global loads -- waits for it: +0.4 us on every quantize launch.)
     const int head = static_cast<int>(flags >> 16);
-    // flags bit 1: reference layout (only the nearest fast step has a scalar form of its own; every other step is one formula at every position)
+    // flags bit 1: reference layout (only the nearest fast step has a scalar form of its own; every other step is one formula at every position);
+    // look_m != 0: the first look needs nothing but this preloaded constant (device_math.hpp, ref_first_look_fast)
     [[maybe_unused]] const bool ref_on = MODE == RM_NEAREST_FAST && (flags & 2u) != 0;
     p_arg.inv_scale = inv_scale;
     p_arg.zp32 = zp32;
@@ -497,7 +505,11 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
     const BoundedStep bstep = bounded_step_for<BITS>(p.zp32);
     const float abs_inv = __builtin_fabsf(p.inv_scale);
 
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += tile_stride) {
+    if (const int64_t turn = blockIdx.x; turn < n_tiles) {
+        // Reference layout: the call's LAST tile holds the scalar tail of the last partition, i.e. it takes the slow path below -- and the block that is
+        // dispatched last is the one whose latency is the kernel's.  The tiles are dealt rotated by one: block 0 takes the last tile, everybody else the
+        // tile in front of its own (uint4 -> bf16 SET at numel 27 264 000 for a 255-thread context: 12.8 -> 11.9 us, profiles/r06_dtype_matrix_ab.txt).
+        const int64_t tile = !ref_on ? turn : (turn == 0 ? n_tiles - 1 : turn - 1);
         const int64_t v0 = (tile * T::WAVES + wave) * T::WAVE_VECS;   // first input vector of this wave tile
 
         u32x4 raw[U];
@@ -533,8 +545,17 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
         [[maybe_unused]] RefSplit ref {};
         if constexpr (MODE == RM_NEAREST_FAST) {
             if (ref_on) {
-                ref = load_ref_split<kQuantKernargRef>();   // behind the tile's loads, on purpose
-                if (ref_first_look(ref, static_cast<uint64_t>(tile) * T::WAVES + static_cast<uint32_t>(wave))) {
+                using Margins = RefMargins<8 / BITS, QuantRefBlock<BITS>::value>;
+                const uint64_t wave_tile = static_cast<uint64_t>(tile) * T::WAVES + static_cast<uint32_t>(wave);
+                bool look;
+                if (look_m != 0) {
+                    look = ref_first_look_fast<Margins::below, Margins::above>(look_m, wave_tile, T::WAVE_VECS * EPV);
+                    if (look) ref = load_ref_split<kQuantKernargRef>();   // one tile in a hundred
+                } else {
+                    ref = load_ref_split<kQuantKernargRef>();   // behind the tile's loads, on purpose
+                    look = ref_first_look(ref, wave_tile);
+                }
+                if (look) {
                     const int64_t g0 = ref.index0 + v0 * EPV;
                     ref_candidates<8 / BITS, QuantRefBlock<BITS>::value>(ref, g0, g0 + static_cast<int64_t>(T::WAVE_VECS) * EPV, ref_ta, ref_tb);
                 }
@@ -595,14 +616,20 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
                 uint32_t w[U][WORDS];
 #pragma unroll
                 for (int k = 0; k < U; ++k) {
+                    if (m[k] == 0) {   // per lane; a window is a few dozen elements: most vectors of the tile take the vector form
+                        quantize_vec<DT_IN, BITS, MODE>(raw[k], p, keys, static_cast<uint64_t>(v0 + k * 64 + lane) * EPV, w[k]);
+                        continue;
+                    }
                     float v[EPV];
                     InVec<DT_IN>::unpack(raw[k], v);
 #pragma unroll
                     for (int j = 0; j < WORDS; ++j) w[k][j] = 0;
 #pragma unroll
                     for (int e = 0; e < EPV; ++e) {
-                        const uint32_t q = ((m[k] >> e) & 1u) != 0 ? quant_nearest_tail32<QMAX>(v[e], p) : quant_nearest_fast<QMAX>(v[e], p);
-                        w[k][(e * BITS) >> 5] |= q << ((e * BITS) & 31);
+                        // one product, the rounding of the position's formula (std::round in a scalar head or tail, trunc(p + copysign(0.5, p)) in the SIMD body), one finish
+                        const float prod = __fmul_rn(v[e], p.inv_scale);
+                        const float r = ((m[k] >> e) & 1u) != 0 ? roundf(prod) : __fadd_rn(prod, __builtin_copysignf(0.5f, prod));
+                        w[k][(e * BITS) >> 5] |= quant_nearest_finish<QMAX>(r, p) << ((e * BITS) & 31);
                     }
                 }
                 put(w);
@@ -684,11 +711,17 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
 
 // Host side of the argument convention above: one place that knows which fields travel as preloaded scalars.
 template <int DT_IN, int BITS, int MODE, int U, bool STAGE, int NT, int BLOCK>
-inline void launch_quantize_kernel(unsigned grid, unsigned dyn_lds, hipStream_t stream, const void* in, uint8_t* out, int64_t numel, int64_t n_tiles, const QuantParams& p,
-                                   int head) {
+inline void launch_quantize_kernel(hipStream_t stream, const void* in, uint8_t* out, int64_t numel, int64_t n_tiles, const QuantParams& p, int head) {
+    using Tile = QuantTile<DT_IN, BITS, U, BLOCK>;
     const uint32_t flags = (p.zp64 >= 0 && p.zp64 <= (1 << BITS) - 1 ? 1u : 0u) | (p.ref.on ? 2u : 0u) | (static_cast<uint32_t>(head) << 16);   // head < 128 * 4 elements
-    PQ_LAUNCH((quantize_kernel<DT_IN, BITS, MODE, U, STAGE, NT, BLOCK>), dim3(grid), dim3(BLOCK), dyn_lds, stream, in, out, numel, n_tiles,
-              p.inv_scale, p.zp32, p.dyn, flags, grid, p);
+    if (n_tiles > 0x7fffffff) {   // 2^41 elements: not on this device
+        fprintf(stderr, "quantize: %lld tiles in one launch\n", static_cast<long long>(n_tiles));
+        abort();
+    }   // 2^41 elements: not on this device
+    const uint64_t ref_m = MODE == RM_NEAREST_FAST ? ref_fast_look_constant(p.ref, Tile::BLOCK_ELEMS / Tile::WAVES, 8 / BITS, QuantRefBlock<BITS>::value) : 0;
+    const unsigned grid = n_tiles > 0 ? static_cast<unsigned>(n_tiles) : 1u;
+    PQ_LAUNCH((quantize_kernel<DT_IN, BITS, MODE, U, STAGE, NT, BLOCK>), dim3(grid), dim3(BLOCK), 0, stream, in, out, numel, ref_m, p.inv_scale, p.zp32, p.dyn, flags,
+              static_cast<uint32_t>(n_tiles), p);
 }
 
 }  // namespace pq

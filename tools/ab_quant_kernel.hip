@@ -12,6 +12,13 @@
 
 using namespace pq;
 
+#ifndef AB_DT
+#define AB_DT DT_F32     // -DAB_DT=1: bf16 input
+#endif
+#ifndef AB_BITS
+#define AB_BITS 8
+#endif
+
 #define CK(x)                                                                        \
     do {                                                                             \
         hipError_t e_ = (x);                                                         \
@@ -27,7 +34,9 @@ __global__ void fill(float* x, int64_t n, uint32_t seed) {
         h ^= h >> 15;
         h *= 0x2c1b3c6du;
         h ^= h >> 12;
-        x[i] = static_cast<float>(static_cast<int32_t>(h)) * (1.0f / 2147483648.0f);
+        const float f = static_cast<float>(static_cast<int32_t>(h)) * (1.0f / 2147483648.0f);
+        if (AB_DT == DT_F32) x[i] = f;
+        else x[i] = __uint_as_float((__float_as_uint(f) & 0xffff0000u) | (__float_as_uint(f * 0.7f) >> 16));   // two bf16 values in (-1, 1) per word
     }
 }
 
@@ -49,23 +58,32 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    constexpr KernelTune t = kQuantTune[DT_F32][0];
-    using Tile = QuantTile<DT_F32, 8, t.u, t.block>;
+    constexpr int kBitsIndex = AB_BITS == 8 ? 0 : (AB_BITS == 4 ? 1 : 2);
+    constexpr KernelTune t = kQuantTune[AB_DT][kBitsIndex];
+    using Tile = QuantTile<AB_DT, AB_BITS, t.u, t.block>;
     const int64_t all_tiles = n / Tile::BLOCK_ELEMS;
-    const int modes = 3;
+    // modes: uniform, then the reference layout for 1 and 255 pool threads -- or for the thread counts given as further arguments
+    std::vector<int> threads = {0, 1, 255};
+    if (argc > 4) {
+        threads.assign(1, 0);
+        for (int i = 4; i < argc; ++i) threads.push_back(atoi(argv[i]));
+    }
+    const int modes = static_cast<int>(threads.size());
+    char name_buf[32];
     for (int round = 0; round < 3; ++round) {
         for (int mode = 0; mode < modes; ++mode) {
             QuantParams p {};
-            p.inv_scale = 127.5f;
-            p.zp64 = 128;
-            p.zp32 = 128;
+            p.inv_scale = 0.5f * ((1 << AB_BITS) - 1);
+            p.zp64 = 1 << (AB_BITS - 1);
+            p.zp32 = 1 << (AB_BITS - 1);
             const char* name = "uniform";
             int64_t n_tiles = all_tiles;
 #ifndef AB_R05
             if (mode > 0) {
-                p.ref = ref_split(true, n, mode == 1 ? 1 : 255, 0, 0);
-                ref_prepare_first_look(p.ref, Tile::BLOCK_ELEMS / Tile::WAVES, 1, 64);
-                name = mode == 1 ? "ref1" : "ref255";
+                p.ref = ref_split(true, n, threads[mode], 0, AB_DT == DT_F32 && AB_BITS == 8 ? 0 : -1);
+                ref_prepare_first_look(p.ref, Tile::BLOCK_ELEMS / Tile::WAVES, 8 / AB_BITS, AB_BITS == 8 ? 64 : 16);
+                snprintf(name_buf, sizeof name_buf, "ref%d", threads[mode]);
+                name = name_buf;
             }
 #else
             if (mode > 0) continue;
@@ -73,9 +91,9 @@ int main(int argc, char** argv) {
             auto launch = [&](int i) {
                 const int s = i % SETS;
 #ifndef AB_R05
-                launch_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, t.u, t.stage, t.nt, t.block>(static_cast<unsigned>(n_tiles), 0, st, in[s], out[s], n, n_tiles, p, 0);
+                launch_quantize_kernel<AB_DT, AB_BITS, RM_NEAREST_FAST, t.u, t.stage, t.nt, t.block>(st, in[s], out[s], n, n_tiles, p, 0);
 #else
-                launch_quantize_kernel<DT_F32, 8, RM_NEAREST_FAST, t.u, t.stage, t.nt, t.block, kQuantShortStep, kQuantVariant>(static_cast<unsigned>(n_tiles), 0, st, in[s], out[s], n,
+                launch_quantize_kernel<AB_DT, AB_BITS, RM_NEAREST_FAST, t.u, t.stage, t.nt, t.block, kQuantShortStep, (AB_BITS == 8 ? kQuantVariant : kQuantVariantSubByte)>(static_cast<unsigned>(n_tiles), 0, st, in[s], out[s], n,
                                                                                                                             n_tiles, p, 0);
 #endif
             };
