@@ -297,9 +297,10 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, uint
         if constexpr (DequantRefTail<BITS, DT_OUT, OP>::HAS_FORM) ref_tile = ref_ta <= ref_tb;
         if (__builtin_expect(ref_tile, 0)) {
             if constexpr (DequantRefTail<BITS, DT_OUT, OP>::HAS_FORM) {
+                u32x4 rr[U];   // as below: the tile's stores go out back to back, behind all of its arithmetic
 #pragma unroll
                 for (int k = 0; k < U; ++k) {
-                    u32x4 r;
+                    u32x4& r = rr[k];
                     if (ref_m[k] == 0) {   // per lane; a tail is at most BLK - 1 elements: most vectors of the tile take the vector form
                         float f[EPV];
 #pragma unroll
@@ -317,7 +318,6 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, uint
                                 r[e] = f32x2_to_bf16x2_bits(f[2 * e], f[2 * e + 1]);
                             }
                         }
-                        st<NT_ST>(out16 + v0 + k * 64 + lane, r);
                         continue;
                     }
 #pragma unroll
@@ -336,8 +336,9 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, uint
                         if constexpr (DT_OUT == DT_F32) r[e] = bits;
                         else r[e >> 1] = (e & 1) != 0 ? (r[e >> 1] | (bits << 16)) : bits;
                     }
-                    st<NT_ST>(out16 + v0 + k * 64 + lane, r);
                 }
+#pragma unroll
+                for (int k = 0; k < U; ++k) st<NT_ST>(out16 + v0 + k * 64 + lane, rr[k]);
             }
         } else {
             // all of the tile's vectors first, then its stores back to back (U KiB of consecutive lines per wave in one burst: with the stores dealt between
