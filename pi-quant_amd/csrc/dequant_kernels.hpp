@@ -161,10 +161,7 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, uint
 
 
     if (const int64_t turn = blockIdx.x; turn < n_tiles) {
-        // Reference layout: the call's LAST tile holds the scalar tail of the last partition, i.e. it takes the slow path below -- and the block that is
-        // dispatched last is the one whose latency is the kernel's.  The tiles are dealt rotated by one: block 0 takes the last tile, everybody else the
-        // tile in front of its own (uint4 -> bf16 SET at numel 27 264 000 for a 255-thread context: 12.8 -> 11.9 us, profiles/r06_dtype_matrix_ab.txt).
-        const int64_t tile = !ref_on ? turn : (turn == 0 ? n_tiles - 1 : turn - 1);
+        const int64_t tile = turn;
         const int64_t v0 = (tile * T::WAVES + wave) * T::WAVE_VECS;     // first output vector of this wave tile
         const uint8_t* src = in + v0 * IB;
 
