@@ -107,6 +107,7 @@ class Context:
         self._stream: object = 'own'
         self._blocking = True
         self._assume_device = False
+        self._native_managed = False     # piquant.torch's C++ front end drives this context too: the cache above cannot be trusted, always push
 
     @staticmethod
     def get(device_index: Optional[int] = None) -> 'Context':
@@ -179,7 +180,7 @@ class Context:
     def set_stream(self, hip_stream: int) -> None:
         """Enqueue on this hipStream_t, e.g. ``torch.cuda.current_stream().cuda_stream``.  0 is HIP's legacy default
         stream (PyTorch's default stream), not "no stream"; see ``reset_stream``."""
-        if self._stream != hip_stream:
+        if self._stream != hip_stream or self._native_managed:
             C.piquant_hip_set_stream(self._ctx, hip_stream or None)
             self._stream = hip_stream
 
@@ -194,13 +195,13 @@ class Context:
 
     def reset_stream(self) -> None:
         """Back to the context's private non-blocking stream (the state of a new context)."""
-        if self._stream != 'own':
+        if self._stream != 'own' or self._native_managed:
             C.piquant_hip_reset_stream(self._ctx)
             self._stream = 'own'
 
     def set_blocking(self, blocking: bool) -> None:
         """True (native default): calls return after completion, like the reference.  False: stream-ordered."""
-        if self._blocking != bool(blocking):
+        if self._blocking != bool(blocking) or self._native_managed:
             C.piquant_hip_set_blocking(self._ctx, 1 if blocking else 0)
             self._blocking = bool(blocking)
 
@@ -215,7 +216,7 @@ class Context:
         """Skip the native pointer classification for the calls that follow (all buffers are device or pinned memory).
         The ``*_ptr`` methods set it per call from their ``_device_ptrs`` argument (False unless the torch binding knows
         better), so raw-pointer users always get the classifying, host-pointer-safe behaviour."""
-        if self._assume_device != bool(assume):
+        if self._assume_device != bool(assume) or self._native_managed:
             C.piquant_hip_assume_device_pointers(self._ctx, 1 if assume else 0)
             self._assume_device = bool(assume)
 

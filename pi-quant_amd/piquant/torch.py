@@ -95,6 +95,19 @@ def _ctx_for(tensor: torch.Tensor, ctx: Optional[Context]) -> Context:
     return ctx
 
 
+def _resolve_default_handle(index: int) -> int:
+    """Called by the native front end once per (thread, device): the native handle of the thread's default context of that device.  The front end
+    pushes stream / non-blocking / device-pointer mode to the native context itself on every call, so the Python-side cache of pushed settings is
+    switched off for this context (``Context._native_managed``): a later ctypes call pushes what it needs whatever the cache says."""
+    ctx = Context._thread_defaults().get(index) or Context.get(index)
+    ctx._native_managed = True
+    return ctx._native_call()
+
+
+if _native is not None:
+    _native.set_default_resolver(_resolve_default_handle)
+
+
 def _native_handle(tensor: torch.Tensor, ctx: Optional[Context]) -> int:
     """Native context handle for a call through the C++ front end (default context of the tensor's device unless one is given)."""
     if ctx is None:
@@ -187,6 +200,8 @@ def quantize(
     """Reference ``torch.py:70-99``; the result lives on ``tensor.device``.  The bytes are those of a reference context with the
     context's ``num_threads`` (``Context.set_reference_layout``); ``uniform=True`` (additive) asks for the position-independent form
     instead -- what shards of one logical tensor must be computed with (``piquant.distributed``)."""
+    if _native is not None and ctx is None and tensor.is_cuda:      # the whole call in C++: checks, default context, output, stream, the C ABI call
+        return _native.quantize_default(tensor, scale, zero_point, dtype, round_mode, out, uniform)
     assert dtype in _QUANT_TYPES, f'Unsupported quantized dtype: {dtype}; choose from {[str(t) for t in _QUANT_TYPES]}'
     if _native is not None and tensor.is_cuda and tensor.dtype in _DEQUANT_TYPES:
         return _native.quantize(_native_handle(tensor, ctx), tensor, scale, zero_point, dtype, _ROUND_MODE_CODES[round_mode], out, uniform)
@@ -230,6 +245,8 @@ def dequantize(
     """Reference ``torch.py:102-129``.  ``out=`` (same shape, ``dtype``) is the accumulator for ``reduce_op='add'``; ``uniform``: see ``quantize``."""
     if dtype not in _DEQUANT_TYPES:
         raise ValueError(f'Unsupported dequantized dtype: {dtype}; choose from {[str(t) for t in _DEQUANT_TYPES]}')
+    if _native is not None and ctx is None and quant_dtype is None and shape is None and tensor.is_cuda and tensor.dtype in _QUANT_TYPES:
+        return _native.dequantize_default(tensor, scale, zero_point, dtype, reduce_op, out, uniform)
     if _native is not None and tensor.is_cuda and quant_dtype is None and shape is None and tensor.dtype in _QUANT_TYPES:
         if out is None and reduce_op == 'add':
             raise ValueError("reduce_op='add' accumulates into out=; pass the accumulator tensor")
