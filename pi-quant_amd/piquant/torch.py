@@ -279,6 +279,14 @@ def dequantize(
     return out
 
 
+# With the native front end built, the two functions above ARE its entry points: keyword arguments are parsed in C++, a device tensor with the default
+# context never enters a Python frame, and everything else comes back to the implementations above (kept under their own names for that).
+_quantize_py, _dequantize_py = quantize, dequantize
+if _native is not None:
+    _native.set_python_implementations(_quantize_py, _dequantize_py)
+    quantize, dequantize = _native.quantize_entry, _native.dequantize_entry
+
+
 def quantize_dequantize(
     tensor: torch.Tensor,
     *,

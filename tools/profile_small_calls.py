@@ -62,16 +62,19 @@ def main():
         rec["piquant.torch.dequantize"] = timed(lambda: piquant.torch.dequantize(q, scale=scale, zero_point=zp, dtype=torch.float32))
         rec["torch.dequantize"] = timed(lambda: torch.dequantize(tq))
         # pure device time of the kernels: the same launches replayed from a hipGraph (no host in the loop)
-        s = torch.cuda.Stream()
-        with torch.cuda.stream(s):
-            piquant.torch.quantize(x, scale=scale, zero_point=zp, dtype=torch.quint8, out=outq)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=s):
-                for _ in range(50):
-                    piquant.torch.quantize(x, scale=scale, zero_point=zp, dtype=torch.quint8, out=outq)
-            r = timed(g.replay, n=200)
-            rec["piquant kernel, graph of 50"] = {k: round(v / 50, 3) for k, v in r.items()}
+        for label, uniform in (("piquant kernel, graph of 50", False), ("piquant kernel (uniform), graph of 50", True)):
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                piquant.torch.quantize(x, scale=scale, zero_point=zp, dtype=torch.quint8, out=outq, uniform=uniform)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=s):
+                    for _ in range(50):
+                        piquant.torch.quantize(x, scale=scale, zero_point=zp, dtype=torch.quint8, out=outq, uniform=uniform)
+                r = timed(g.replay, n=200)
+                rec[label] = {k: round(v / 50, 3) for k, v in r.items()}
+        with torch.cuda.stream(torch.cuda.Stream()) as _:
+            pass
         out[f"numel={numel}"] = rec
     print(json.dumps(out))
 
