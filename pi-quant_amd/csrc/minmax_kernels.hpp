@@ -406,46 +406,14 @@ __global__ void __launch_bounds__(BLOCK) minmax_kernel(const void* __restrict__ 
             hi = __builtin_fmaxf(hi, x);
         }
     };
-    if constexpr (DT_IN == DT_BF16) {
-        // bf16: the extremes of a NaN-free share from three PACKED 16-bit integer folds of the raw words -- 1.5 instructions per element, no unpack,
-        // against 3.65 for the float fold (twice the elements per byte made the bf16 scan the instruction-heaviest kernel of the path, 759 VALU
-        // instructions per wave at numel 27 264 000 against the fp32 scan's 573 on twice the bytes).  A bf16 is sign-magnitude, so with s = the largest
-        // pattern as a SIGNED int16, u = the largest and m = the smallest as UNSIGNED:
-        //   maximum = s when s >= 0 (a non-negative value exists, and among those the order of the patterns is the order of the values), else m
-        //             (everything is negative: the smallest pattern has the smallest magnitude);
-        //   minimum = u when u >= 0x8000 (a negative value exists: negatives lie above all non-negatives as unsigned, larger magnitude higher), else m.
-        // A NaN is the one thing this cannot skip: positive NaN patterns (> 0x7f80) win s, negative ones (> 0xff80) win u -- which is also how they
-        // are seen.  A wave that meets one folds its share again with the float fold, which ignores NaNs (the reference leaves them unspecified).
-        // (Eight independent 16-bit lanes per fold -- four accumulator registers each, folded into one value at the end.  Written as a chain through ONE
-        // packed register -- acc = max(acc, dword e) for e = 0..3 with bit casts between uint32_t and a 2 x 16-bit vector -- hipcc 7.2 drops three of
-        // the four dwords: found by the golden min/max vectors, /tmp reproduction in profiles/EXPERIMENTS.md.)
-        typedef int16_t i16x8 __attribute__((ext_vector_type(8)));
-        typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
-        i16x8 smax8 = static_cast<int16_t>(-32768);
-        u16x8 umax8 = static_cast<uint16_t>(0), umin8 = static_cast<uint16_t>(0xffff);
-        minmax_scan_share<U, NT>(in16, n_vec, tid, nthreads, [&](const u32x4& raw) {
-            smax8 = __builtin_elementwise_max(smax8, __builtin_bit_cast(i16x8, raw));
-            umax8 = __builtin_elementwise_max(umax8, __builtin_bit_cast(u16x8, raw));
-            umin8 = __builtin_elementwise_min(umin8, __builtin_bit_cast(u16x8, raw));
-        });
-        int32_t s = -32768;
-        uint32_t u = 0u, m = 0xffffu;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            s = max(s, static_cast<int32_t>(smax8[e]));
-            u = max(u, static_cast<uint32_t>(umax8[e]));
-            m = min(m, static_cast<uint32_t>(umin8[e]));
-        }
-        const bool nan = s > 0x7f80 || u > 0xff80u;
-        if (__any(nan ? 1 : 0)) {
-            minmax_scan_share<U, NT>(in16, n_vec, tid, nthreads, fold_floats);
-        } else if (u >= m) {   // this lane folded at least one vector
-            hi = bf16_bits_to_f32(s >= 0 ? static_cast<uint32_t>(s) : m);
-            lo = bf16_bits_to_f32(u >= 0x8000u ? u : m);
-        }
-    } else {
-        minmax_scan_share<U, NT>(in16, n_vec, tid, nthreads, fold_floats);
-    }
+    // (bf16, round 6: three PACKED 16-bit integer folds of the raw words -- signed max, unsigned max, unsigned min of the sign-magnitude patterns, 13
+    // VALU instructions per 16-byte vector against the float fold's 27, a wave that meets a NaN pattern folding its share again with the float fold
+    // -- were built, passed the golden vectors and the NaN tests, and LOST: 12.7-13.0 us against 11.7-11.9 us for this float fold at numel
+    // 27 264 000, same box, interleaved (profiles/r06_tune_mmbf_ab.txt).  The scan waits for memory 78 % of its wave cycles and spends 13 % of them
+    // in the VALU: halving the arithmetic bought nothing, and twelve accumulator registers, a second copy of the scan for the NaN case and an
+    // 8-lane fold at the end cost a microsecond.  With U = 8 the packed form spilled to scratch, 32 us.  Also on file: hipcc 7.2 drops three of four
+    // dwords of a fold chained through ONE 2 x 16-bit register with bit casts to and from uint32_t -- profiles/EXPERIMENTS.md.)
+    minmax_scan_share<U, NT>(in16, n_vec, tid, nthreads, fold_floats);
     // ragged scalar tail (numel % EPV elements)
     for (int64_t i = n_vec * EPV + tid; i < numel; i += nthreads) {
         const float x = quieted(InVec<DT_IN>::load_scalar(in, i));

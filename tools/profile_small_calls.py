@@ -73,8 +73,6 @@ def main():
                         piquant.torch.quantize(x, scale=scale, zero_point=zp, dtype=torch.quint8, out=outq, uniform=uniform)
                 r = timed(g.replay, n=200)
                 rec[label] = {k: round(v / 50, 3) for k, v in r.items()}
-        with torch.cuda.stream(torch.cuda.Stream()) as _:
-            pass
         out[f"numel={numel}"] = rec
     print(json.dumps(out))
 
