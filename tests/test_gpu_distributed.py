@@ -351,7 +351,8 @@ def _p2p_child_record(stderr: str):
 
 @pytest.mark.slow
 def test_bench_eight_ranks_sharing_the_gpu():
-    """The command the driver will run on an 8-GPU node, with the eight ranks sharing this box's GPU over gloo (RCCL refuses two ranks on one
+    """The command the driver will run on an 8-GPU node plus --extras (the default prints the line with n1_reference and config 5 only -- what
+    test_bench_two_ranks_default_flags_print_the_line_within_a_minute covers), with the eight ranks sharing this box's GPU over gloo (RCCL refuses two ranks on one
     device): 192 buffer sets of 3 408 000 elements per rank allocate, every barrier is reached, ONE JSON line comes out, the shards and the
     config-5 shards have the sizes BASELINE implies.  The numbers mean nothing; the control flow must not be what kills the first real run."""
     import json
@@ -365,7 +366,7 @@ def test_bench_eight_ranks_sharing_the_gpu():
         port = s.getsockname()[1]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), str(root / "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5", "--backend", "gloo",
-                        "--share-gpu"], capture_output=True, text=True, timeout=1500, cwd=str(root),
+                        "--share-gpu", "--extras"], capture_output=True, text=True, timeout=1500, cwd=str(root),   # --extras: the driver's line + every side measurement
                        env=dict(os.environ, PIQUANT_BENCH_EXTRAS_LIMIT_S="1200"))   # eight ranks on ONE GPU, collectives staged through the host: slow, and not the point
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
