@@ -279,7 +279,12 @@ PIQUANT_EXPORT void piquant_hip_exchange_minmax_keys(piquant_context_t* ctx, con
  * the array waited on read *out_seen instead of *out_expected) or 2 (piquant_hip_exchange_minmax_keys: rank *out_rank never delivered its pair),
  * and clears the record.  Reads host memory only; synchronise the stream first to be sure the wait in question is over.  A record nobody fetched
  * makes the context's NEXT peer-to-peer call abort with a message naming the rank, so a host that never asks still fails loudly, one call late.
- * piquant.distributed asks after every exchange it synchronises on and before every new one, and raises RuntimeError. */
+ * While a record is pending (round 6): the FIRST failure is the one kept -- a later wait that also runs out does not overwrite it --, further
+ * waits on this context return at once instead of spinning out their own timeouts, and piquant_hip_signal_flags signals NOTHING: a rank that gave
+ * up does not tell its peers that its step is finished (they time out on it and name it, instead of consuming bytes it never wrote).  After a
+ * kind-2 timeout the mailboxes are in an unknown state (pairs may arrive late into either parity): free them and exchange handles again before
+ * the next exchange.  piquant.distributed asks after every exchange it synchronises on and before every new one, raises RuntimeError, and marks
+ * the peer mesh of that kind as poisoned: its next use is refused until piquant.distributed.release_peer_meshes() has let it be rebuilt. */
 PIQUANT_EXPORT int piquant_hip_peer_timeout(piquant_context_t* ctx, uint32_t* out_rank, uint32_t* out_expected, uint32_t* out_seen);
 
 /* Host helpers: key <-> float, and the (min,max) -> (scale, zero_point) epilogue in double precision

@@ -133,7 +133,7 @@ void piquant_hip_quantize_dequantize(piquant_context_t* ctx, const void* in, piq
 
 // compute_quant_params + quantize of ONE tensor on resolved device pointers; `q` carries dtypes and the round-mode fields.
 // Caller holds ctx->mu and the device guard.
-static void quantize_dynamic_one(piquant_context_t* ctx, QuantLaunch q, const void* in_dev, void* out_dev, const void* out_as_passed, size_t numel,
+static void quantize_dynamic_one(piquant_context_t* ctx, QuantLaunch q, const void* in_dev, void* out_dev, size_t numel,
                                  void* params_dev) {
     MinmaxAction params_action;
     params_action.action = MM_PARAMS;
@@ -187,11 +187,11 @@ void piquant_hip_quantize_dynamic(piquant_context_t* ctx, const void* in, piquan
     q.dt_out = dtype_out;
     fill_round_mode(ctx, q, mode);
     if (numel == 0) {
-        quantize_dynamic_one(ctx, q, nullptr, nullptr, nullptr, 0, rp.dev);
+        quantize_dynamic_one(ctx, q, nullptr, nullptr, 0, rp.dev);
     } else {
         const Resolved rin = ctx->resolve_ptr(in), rout = ctx->resolve_ptr(out);
         if (rin.pageable || rout.pageable) panic("piquant_hip_quantize_dynamic needs device (or pinned) buffers");
-        quantize_dynamic_one(ctx, q, rin.dev, rout.dev, out, numel, rp.dev);
+        quantize_dynamic_one(ctx, q, rin.dev, rout.dev, numel, rp.dev);
     }
     if (ctx->blocking) wait_stream(ctx);
 }
@@ -213,7 +213,6 @@ void piquant_hip_quantize_dynamic_batch(piquant_context_t* ctx, const void* cons
     struct Item {
         const void* in;
         void* out;
-        const void* out_as_passed;
         size_t numel;
         void* params;
     };
@@ -222,7 +221,7 @@ void piquant_hip_quantize_dynamic_batch(piquant_context_t* ctx, const void* cons
         if (!device_params[i]) panic("piquant_hip_quantize_dynamic_batch: NULL parameter record %zu", i);
         const Resolved rp = resolve(device_params[i]);
         if (rp.pageable) panic("piquant_hip_quantize_dynamic_batch: parameter records must live in device (or pinned) memory");
-        items[i] = {nullptr, nullptr, outputs[i], numels[i], rp.dev};
+        items[i] = {nullptr, nullptr, numels[i], rp.dev};
         if (numels[i] == 0) continue;
         if (!inputs[i] || !outputs[i]) panic("quantize: NULL buffer %zu", i);
         const Resolved rin = ctx->resolve_ptr(inputs[i]), rout = ctx->resolve_ptr(outputs[i]);
@@ -255,7 +254,7 @@ void piquant_hip_quantize_dynamic_batch(piquant_context_t* ctx, const void* cons
         }
         for (size_t k = i; k < j; ++k) {
             if (fused && items[k].numel != 0) continue;
-            quantize_dynamic_one(ctx, q, items[k].in, items[k].out, items[k].out_as_passed, items[k].numel, items[k].params);
+            quantize_dynamic_one(ctx, q, items[k].in, items[k].out, items[k].numel, items[k].params);
         }
         i = j;
     }
@@ -308,7 +307,7 @@ void piquant_hip_reduce_quantize_dynamic(piquant_context_t* ctx, void* acc, piqu
     if (!fused) {
         // the same result in two steps (and with `acc` updated on the way): one-pass sum into acc, then parameters + quantize with q's round mode
         dequantize_sum_locked(ctx, inputs, input_params, count, dtype_out, acc, dtype_acc, numel, PIQUANT_REDUCE_OP_ADD);
-        quantize_dynamic_one(ctx, q, racc.dev, rout.dev, out, numel, rp.dev);
+        quantize_dynamic_one(ctx, q, racc.dev, rout.dev, numel, rp.dev);
     }
     if (ctx->blocking) wait_stream(ctx);
 }
