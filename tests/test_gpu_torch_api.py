@@ -124,50 +124,103 @@ def test_non_contiguous_input_is_made_contiguous():
 
 
 def test_native_front_end_matches_the_ctypes_path():
-    """piquant.torch.quantize / dequantize go through csrc/torch_binding.cpp when it is built; the ctypes path must give the
-    same tensors (dtype, shape, device, bytes), including out=, ADD and non-contiguous input."""
+    """piquant.torch.quantize / dequantize ARE the entry points of csrc/torch_binding.cpp when it is built (CPython vectorcall functions); the Python
+    implementation behind them -- with the native allocation path and, with the module switched off, through ctypes -- must give the same tensors
+    (dtype, shape, device, bytes), including out=, ADD and non-contiguous input."""
     import piquant
     import piquant.torch as pt
 
     if pt._native is None:
         pytest.skip("native front end not built")
     native = pt._native
+    assert pt.quantize is native.quantize_entry and pt.dequantize is native.dequantize_entry
     g = torch.Generator(device="cuda").manual_seed(3)
     x = torch.empty(257, 129, device="cuda").uniform_(-2, 3, generator=g)
+    as_int = lambda t: t.view(torch.int16 if t.dtype == torch.bfloat16 else torch.int32)   # noqa: E731
+
+    def through(quantize, dequantize, src, scale, zp, qdt):
+        q = quantize(src, scale=scale, zero_point=zp, dtype=qdt)
+        d = dequantize(q, scale=scale, zero_point=zp, dtype=src.dtype)
+        acc = torch.ones_like(d)
+        r = dequantize(q, scale=scale, zero_point=zp, dtype=src.dtype, reduce_op="add", out=acc)
+        assert r is acc
+        return q, d, acc
+
     try:
         for src in (x, x.to(torch.bfloat16), x.t()):
             for qdt in (torch.quint8, torch.uint8, torch.quint4x2, torch.quint2x4):
                 scale, zp = pt.compute_quant_params(src.contiguous(), dtype=qdt)
                 pt._native = native
-                q_n = pt.quantize(src, scale=scale, zero_point=zp, dtype=qdt)
-                d_n = pt.dequantize(q_n, scale=scale, zero_point=zp, dtype=src.dtype)
-                acc_n = torch.ones_like(d_n)
-                pt.dequantize(q_n, scale=scale, zero_point=zp, dtype=src.dtype, reduce_op="add", out=acc_n)
+                q_e, d_e, acc_e = through(pt.quantize, pt.dequantize, src, scale, zp, qdt)            # the entry points
+                q_n, d_n, acc_n = through(pt._quantize_py, pt._dequantize_py, src, scale, zp, qdt)    # Python wrapper, native call
                 pt._native = None
-                q_c = pt.quantize(src, scale=scale, zero_point=zp, dtype=qdt)
-                d_c = pt.dequantize(q_c, scale=scale, zero_point=zp, dtype=src.dtype)
-                acc_c = torch.ones_like(d_c)
-                pt.dequantize(q_c, scale=scale, zero_point=zp, dtype=src.dtype, reduce_op="add", out=acc_c)
-                assert q_n.dtype == q_c.dtype == qdt and q_n.shape == q_c.shape == src.shape and q_n.device == src.device
-                assert torch.equal(pt.packed_bytes(q_n), pt.packed_bytes(q_c))
-                assert d_n.dtype == src.dtype and torch.equal(d_n.view(torch.int16 if src.dtype == torch.bfloat16 else torch.int32),
-                                                              d_c.view(torch.int16 if src.dtype == torch.bfloat16 else torch.int32))
-                assert torch.equal(acc_n, acc_c)
-        # mixing the two paths on one context: stream / blocking caches must stay coherent
+                q_c, d_c, acc_c = through(pt._quantize_py, pt._dequantize_py, src, scale, zp, qdt)    # Python wrapper, ctypes
+                for q, d, acc in ((q_e, d_e, acc_e), (q_n, d_n, acc_n)):
+                    assert q.dtype == q_c.dtype == qdt and q.shape == q_c.shape == src.shape and q.device == src.device
+                    assert torch.equal(pt.packed_bytes(q), pt.packed_bytes(q_c))
+                    assert d.dtype == src.dtype and torch.equal(as_int(d), as_int(d_c)) and torch.equal(acc, acc_c)
+        # mixing the paths on one context: stream / blocking caches must stay coherent
         pt._native = native
         s = torch.cuda.Stream()
         with torch.cuda.stream(s):
             a = pt.quantize(x, scale=0.02, zero_point=100, dtype=torch.quint8)
             pt._native = None
-            b = pt.quantize(x, scale=0.02, zero_point=100, dtype=torch.quint8)
+            b = pt._quantize_py(x, scale=0.02, zero_point=100, dtype=torch.quint8)
         pt._native = native
-        c = pt.quantize(x, scale=0.02, zero_point=100, dtype=torch.quint8)
+        c = pt._quantize_py(x, scale=0.02, zero_point=100, dtype=torch.quint8)
         torch.cuda.synchronize()
         assert torch.equal(pt.packed_bytes(a), pt.packed_bytes(b)) and torch.equal(pt.packed_bytes(a), pt.packed_bytes(c))
-        with pytest.raises(ValueError):
-            pt.dequantize(a, scale=0.02, zero_point=100, dtype=torch.float32, reduce_op="add")
     finally:
         pt._native = native
+
+
+def test_entry_points_take_what_the_python_implementation_takes_and_raise_what_it_raises():
+    """The vectorcall entry points serve the common call themselves and hand everything else, arguments untouched, to the Python implementation:
+    numpy and tensor scalars, ctx=, out= identity, uniform=, and every refusal with the exception type of the Python path."""
+    import numpy as np
+
+    import piquant
+    import piquant.torch as pt
+
+    if pt._native is None:
+        pytest.skip("native front end not built")
+    x = torch.linspace(-1, 1, 4099, device="cuda")
+    want = pt.packed_bytes(pt._quantize_py(x, scale=0.01, zero_point=100, dtype=torch.quint8))
+    for scale, zp in ((0.01, 100), (np.float32(0.01).item(), np.int64(100)), (np.float64(0.01), 100), (torch.tensor(0.01, dtype=torch.float64), torch.tensor(100))):
+        got = pt.quantize(x, scale=scale, zero_point=zp, dtype=torch.quint8)
+        assert got.dtype == torch.quint8 and torch.equal(pt.packed_bytes(got), want), (type(scale), type(zp))
+    assert torch.equal(pt.packed_bytes(pt.quantize(x, scale=1, zero_point=100, dtype=torch.quint8)),      # an int for scale
+                       pt.packed_bytes(pt._quantize_py(x, scale=1, zero_point=100, dtype=torch.quint8)))
+    out = torch.empty(x.shape, dtype=torch.quint8, device="cuda")
+    assert pt.quantize(x, scale=0.01, zero_point=100, dtype=torch.quint8, out=out) is out and torch.equal(pt.packed_bytes(out), want)
+    assert torch.equal(pt.packed_bytes(pt.quantize(x, scale=0.01, zero_point=100, dtype=torch.quint8, uniform=True)), want)   # ordinary data: same bytes
+    ctx = piquant.Context(num_threads=3)
+    assert torch.equal(pt.packed_bytes(pt.quantize(x, scale=0.01, zero_point=100, dtype=torch.quint8, ctx=ctx)), want)
+    assert torch.equal(pt.packed_bytes(pt.quantize(x, scale=0.01, zero_point=100, dtype=torch.quint8, round_mode="nearest", ctx=None, out=None)), want)
+    q = pt.quantize(x, scale=0.01, zero_point=100, dtype=torch.quint8)
+    d = pt.dequantize(q, scale=0.01, zero_point=100, dtype=torch.float32, reduce_op="set")
+    assert torch.equal(d, pt._dequantize_py(q, scale=0.01, zero_point=100, dtype=torch.float32))
+    raw = pt.packed_bytes(q)
+    assert torch.equal(pt.dequantize(raw, scale=0.01, zero_point=100, dtype=torch.float32, quant_dtype=torch.quint8, shape=x.shape), d)
+    # refusals: the same exception type from the entry point and from the Python implementation
+    cases = [
+        (pt.quantize, pt._quantize_py, (x,), dict(scale=0.01, zero_point=100, dtype=torch.float32)),                     # not a quantized dtype
+        (pt.quantize, pt._quantize_py, (x,), dict(scale=0.01, zero_point=100, dtype=torch.quint8, round_mode="up")),      # unknown mode name
+        (pt.quantize, pt._quantize_py, (x,), dict(scale=0.01, zero_point=100, dtype=torch.quint8, bogus=1)),              # unknown keyword
+        (pt.quantize, pt._quantize_py, (x,), dict(scale=0.01, dtype=torch.quint8)),                                      # missing keyword
+        (pt.quantize, pt._quantize_py, (x, 0.01), dict(zero_point=100, dtype=torch.quint8)),                             # positional scale
+        (pt.quantize, pt._quantize_py, (x.to(torch.int32),), dict(scale=0.01, zero_point=100, dtype=torch.quint8)),       # not a float tensor
+        (pt.dequantize, pt._dequantize_py, (q,), dict(scale=0.01, zero_point=100, dtype=torch.quint8)),                  # not a float dtype
+        (pt.dequantize, pt._dequantize_py, (q,), dict(scale=0.01, zero_point=100, dtype=torch.float32, reduce_op="add")),  # ADD without an accumulator
+        (pt.dequantize, pt._dequantize_py, (q,), dict(scale=0.01, zero_point=100, dtype=torch.float32, reduce_op="mul")),  # unknown operator name
+        (pt.dequantize, pt._dequantize_py, (q,), dict(scale=0.01, zero_point=100, dtype=torch.float32, out=torch.empty(3, device="cuda"))),   # out= of the wrong size
+    ]
+    for entry, py, args, kw in cases:
+        with pytest.raises(Exception) as e_py:
+            py(*args, **kw)
+        with pytest.raises(Exception) as e_entry:
+            entry(*args, **kw)
+        assert type(e_entry.value) is type(e_py.value), (kw, e_entry.value, e_py.value)
 
 
 def test_reference_style_benchmark_harness_runs(tmp_path):
