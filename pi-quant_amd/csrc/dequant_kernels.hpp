@@ -103,7 +103,7 @@ struct DequantKernargs {
     int head;
     const ParamRecord* dyn;
     int32_t zp32;
-    uint32_t n_tiles;
+    uint32_t look_w;
     DequantParams p;
 };
 constexpr uint32_t kDequantKernargRef = static_cast<uint32_t>(__builtin_offsetof(DequantKernargs, p) + __builtin_offsetof(DequantParams, ref));
@@ -124,8 +124,11 @@ struct DequantTile {
 template <int BITS, int DT_OUT, int OP, int U, bool STAGE, int NT, int BLOCK, bool SHIFTED = false>
 __global__ void __launch_bounds__(BLOCK)
 dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, uint64_t look_m, float scale, int head, const ParamRecord* dyn, int32_t zp32,
-                  uint32_t tiles, DequantParams p_arg) {
-    // one tile per block: the grid is the tile count (quantize_kernel); look_m: the preloaded constant of the reference layout's first look, or 0
+                  uint32_t look_w, DequantParams p_arg) {
+    // one tile per block: the grid is the tile count, numel / BLOCK_ELEMS -- a shift; the preloaded dword that used to carry it now carries look_w
+    // (quantize_kernel); look_m, look_w: the constants of the reference layout's first look (device_math.hpp, ref_first_look_fast), or 0
+    static_assert((DequantTile<BITS, DT_OUT, U, BLOCK>::BLOCK_ELEMS & (DequantTile<BITS, DT_OUT, U, BLOCK>::BLOCK_ELEMS - 1)) == 0, "a shift");
+    const uint32_t tiles = static_cast<uint32_t>(static_cast<uint64_t>(numel) / static_cast<uint64_t>(DequantTile<BITS, DT_OUT, U, BLOCK>::BLOCK_ELEMS));
     const int64_t n_tiles = tiles;
     const uint32_t tile_stride = tiles > 0 ? tiles : 1u;
     // `head` carries two numbers: bits 0-15 the elements peeled in front of the body, bits 16-18 `shift` = the bits of in[0] that belong to
@@ -152,6 +155,9 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, uint
     constexpr bool NT_LD = (NT & 1) != 0;   // see mem_policy()
     constexpr int NT_ST = NT >> 1;
 
+    // the reference layout's first look behind the staging of the input instead of behind the loads (ref_look below has the measurement)
+    constexpr bool LOOK_LATE = STAGE && OP == OP_SET && DT_OUT == DT_BF16 && BITS < 8;
+
     constexpr int SLICE = T::WAVE_IN_BYTES + (SHIFTED ? 16 : 0);   // + the byte behind a wave's slice
     __shared__ __attribute__((aligned(16))) uint8_t lds[STAGE ? T::WAVES * SLICE : 16];
 
@@ -160,8 +166,8 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, uint
     u32x4* out16 = static_cast<u32x4*>(out);
 
 
-    if (const int64_t turn = blockIdx.x; turn < n_tiles) {
-        const int64_t tile = turn;
+    if (blockIdx.x < tiles) {   // 32-bit on purpose: a 64-bit unsigned order compare is a vector instruction, and this one stands in front of the tile's loads
+        const int64_t tile = blockIdx.x;
         const int64_t v0 = (tile * T::WAVES + wave) * T::WAVE_VECS;     // first output vector of this wave tile
         const uint8_t* src = in + v0 * IB;
 
@@ -177,6 +183,12 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, uint
         // Reference layout, first look (device_math.hpp, ref_candidates): does the scalar tail of a reference partition reach into this wave tile?  Called
         // once ALL of the tile's global loads are on their way -- the accumulator's and the packed input's: its scalar load and wait in front of the input
         // loads delayed them by a scalar-cache round trip in every wave, 1.4-1.7 us on the 12-22 us bf16-output launches (profiles/r06_dtype_matrix_ab.txt).
+        // WHERE behind the loads is decided per kernel (LOOK_LATE below), by measurement (profiles/r06_ab_first_look.txt, numel 27 264 000, interleaved):
+        // between the loads and the wait for them, even a look of a dozen scalar instructions that is computed and never acted upon costs the two sub-byte
+        // -> bf16 SET kernels, whose waves have one load in flight and 150 instructions in all, 0.5 us of 10.7 (uint2) and 0.15 of 11.8 (uint4) in EVERY
+        // launch; behind the staging of the input it costs them nothing, and what a flagged tile does is then no longer hidden behind its load: for a
+        // 255-thread context uint2 -> bf16 11.42 -> 10.84 us, uint4 -> bf16 12.07 -> 12.09 (for 1 thread 11.93 -> 11.55).  The other kernels -- uint8 input,
+        // every ADD -- pay nothing for the early look and 0.1-0.2 us for the late one: they keep the early one.
         [[maybe_unused]] int32_t ref_ta = 1, ref_tb = 0;
         [[maybe_unused]] uint32_t ref_m[U] = {};
         auto ref_look = [&]() {
@@ -188,7 +200,7 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, uint
                     RefSplit ref {};
                     bool look;
                     if (look_m != 0) {
-                        look = ref_first_look_fast<Margins::below, Margins::above>(look_m, wave_tile, T::WAVE_VECS * EPV);
+                        look = ref_first_look_fast<Margins::below>(look_m, look_w, static_cast<uint32_t>(wave_tile), T::WAVE_VECS * EPV);
                         if (look) ref = load_ref_split<kDequantKernargRef>();   // one tile in a hundred
                     } else {
                         ref = load_ref_split<kDequantKernargRef>();
@@ -249,7 +261,7 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, uint
                 if (lane == 0) t_last = ld<NT_LD>(src + T::WAVE_IN_BYTES);   // the byte the last vector's bits run into
             }
             load_old();
-            ref_look();
+            if constexpr (!LOOK_LATE) ref_look();
             if constexpr (T::LANE_IN_BYTES >= 16) {
 #pragma unroll
                 for (int j = 0; j < N16; ++j) reinterpret_cast<u32x4*>(s)[j * 64 + lane] = t16[j];
@@ -266,6 +278,7 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, uint
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if constexpr (LOOK_LATE) ref_look();
 #pragma unroll
             for (int k = 0; k < U; ++k) {
                 const uint8_t* r = s + (k * 64 + lane) * IB;
@@ -401,17 +414,20 @@ inline void launch_dequantize_kernel(hipStream_t stream, const uint8_t* in, void
         fprintf(stderr, "dequantize: %lld tiles in one launch\n", static_cast<long long>(n_tiles));
         abort();
     }
-    const uint64_t ref_m = Ref::HAS_FORM ? ref_fast_look_constant(p.ref, Tile::BLOCK_ELEMS / Tile::WAVES, 8 / BITS, Ref::BLK) : 0;
+    const RefFastLook look = Ref::HAS_FORM ? ref_fast_look_constants(p.ref, Tile::BLOCK_ELEMS / Tile::WAVES, 8 / BITS, Ref::BLK) : RefFastLook {0, 0};
+    if (n_tiles != numel / Tile::BLOCK_ELEMS) {   // the kernel derives the tile count from numel
+        fprintf(stderr, "dequantize: %lld tiles for %lld elements\n", static_cast<long long>(n_tiles), static_cast<long long>(numel));
+        abort();
+    }
     const unsigned grid = n_tiles > 0 ? static_cast<unsigned>(n_tiles) : 1u;
-    const uint32_t tiles = static_cast<uint32_t>(n_tiles);
     if constexpr (BITS < 8) {
         if (((head >> 16) & 7) != 0) {   // the body starts inside a packed byte
-            PQ_LAUNCH((dequantize_kernel<BITS, DT_OUT, OP, U, STAGE, NT, BLOCK, true>), dim3(grid), dim3(BLOCK), 0, stream, in, out, numel, ref_m, p.scale, head, p.dyn, p.zp32,
-                      tiles, p);
+            PQ_LAUNCH((dequantize_kernel<BITS, DT_OUT, OP, U, STAGE, NT, BLOCK, true>), dim3(grid), dim3(BLOCK), 0, stream, in, out, numel, look.m, p.scale, head, p.dyn, p.zp32,
+                      look.w, p);
             return;
         }
     }
-    PQ_LAUNCH((dequantize_kernel<BITS, DT_OUT, OP, U, STAGE, NT, BLOCK>), dim3(grid), dim3(BLOCK), 0, stream, in, out, numel, ref_m, p.scale, head, p.dyn, p.zp32, tiles, p);
+    PQ_LAUNCH((dequantize_kernel<BITS, DT_OUT, OP, U, STAGE, NT, BLOCK>), dim3(grid), dim3(BLOCK), 0, stream, in, out, numel, look.m, p.scale, head, p.dyn, p.zp32, look.w, p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

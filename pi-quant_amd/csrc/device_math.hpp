@@ -286,18 +286,27 @@ __device__ __forceinline__ bool ref_first_look(const RefSplit& s, uint64_t wave_
     return s.always != 0 || f + s.w < f;
 }
 
-// The first look WITHOUT the RefSplit -- from one preloaded 64-bit constant, for the common launch (the call's element 0 is the launch's element 0, i.e.
+// The first look WITHOUT the RefSplit -- from two preloaded constants, for the common launch (the call's element 0 is the launch's element 0, i.e.
 // no peeled head and no staged chunk; at most 2^31 elements).  m = floor(2^64 T / n), so frac(x) of x = (tile * S - below) T / n is the low 64 bits of
-// (tile * S - below) * m, short by less than n * 2^-64 <= 2^-33 of a partition, and a tile's width is (S + below + above) * m; the two elements of slack
-// inside the margins are worth 2 m >= 2^34 T / n * 2^-33... in 64-bit fixed point: 2 m >= n whenever n <= 2^32 sqrt(T), which the host checks.  The
-// RefSplit itself -- 80 bytes of the kernarg segment, which lives in host memory -- is then fetched by the one tile in a hundred that passes the look:
+// (tile * S - below) * m, short by less than n * 2^-64 <= 2^-33 of a partition; the two elements of slack inside the margins are worth 2 m >= n whenever
+// n <= 2^32 sqrt(T), which the host checks.  Only the HIGH 32 bits of that fraction are formed -- the element index fits 32 bits, so they are
+// lo32(a * m_hi) + hi32(a * m_lo): two scalar multiplies -- and added to w = ceil((S + below + above) * m / 2^32), a tile's width with both margins
+// rounded UP to the same 32 bits: frac + width >= 1 implies hi32(frac) + w >= 2^32, so this look passes every tile the 64-bit one passes (and two in a
+// million more: tests/test_reference_layout_look.py).  Wave tile 0 starts at the call's element 0, boundary 0: always looked at.
+// Until the last session of round 6 the look carried all 64 bits and formed the width per wave (seven scalar multiplies) and ended in a VECTOR compare
+// and a branch on vcc; the carry below is taken on the scalar unit by hand because, written in C++ (f + w < f, f > ~w, a 64-bit sum), the compiler selects
+// a vector add-with-carry for it.  What the look costs depends on WHERE a kernel takes it far more than on its length: dequant_kernels.hpp has the numbers
+// (profiles/r06_ab_first_look.txt).
+// The RefSplit itself -- 80 bytes of the kernarg segment -- is then fetched by the one tile in a hundred that passes the look:
 // fetched by EVERY wave it cost uint4 -> bf16 SET, whose waves have a single 16-byte load in flight to hide it behind, 0.7 us of 12
 // (profiles/r06_ab_kernel_variants.txt, dq4 ref1 against uniform).
-template <int BELOW, int ABOVE>
-__device__ __forceinline__ bool ref_first_look_fast(uint64_t m, uint64_t wave_tile, uint32_t wave_tile_elems) {
-    const uint64_t f = (wave_tile * wave_tile_elems - static_cast<uint64_t>(BELOW)) * m;
-    const uint64_t w = (static_cast<uint64_t>(wave_tile_elems) + BELOW + ABOVE) * m;
-    return f + w < f;
+template <int BELOW>
+__device__ __forceinline__ bool ref_first_look_fast(uint64_t m, uint32_t w, uint32_t wave_tile, uint32_t wave_tile_elems) {
+    const uint32_t a = wave_tile * wave_tile_elems - static_cast<uint32_t>(BELOW);
+    const uint32_t f = a * static_cast<uint32_t>(m >> 32) + __umulhi(a, static_cast<uint32_t>(m));
+    uint32_t look;   // carry of f + w, or wave tile 0
+    asm volatile("s_add_u32 %0, %1, %2\n\ts_cselect_b32 %0, 1, 0\n\ts_cmp_eq_u32 %3, 0\n\ts_cselect_b32 %0, 1, %0" : "=&s"(look) : "s"(f), "s"(w), "s"(wave_tile) : "scc");
+    return look != 0;
 }
 
 template <int PACK, int BLK>
@@ -350,14 +359,20 @@ inline void ref_prepare_first_look(RefSplit& r, int64_t wave_tile, int pack, int
     r.always = 0;
 }
 
-// m of ref_first_look_fast for a launch whose wave tiles hold `wave_tile` elements, or 0 when the launch must take the look that reads the RefSplit
-// (a launch that does not start at the call's element 0, partitions no larger than a tile, more than 2^31 elements)
-inline uint64_t ref_fast_look_constant(const RefSplit& r, int64_t wave_tile, int pack, int blk) {
-    if (!r.on || r.always || r.index0 != 0 || r.n > (int64_t {1} << 31)) return 0;
+// m and w of ref_first_look_fast for a launch whose wave tiles hold `wave_tile` elements, or {0, 0} when the launch must take the look that reads the
+// RefSplit (a launch that does not start at the call's element 0, partitions no larger than a tile, more than 2^31 elements)
+struct RefFastLook {
+    uint64_t m;
+    uint32_t w;
+};
+inline RefFastLook ref_fast_look_constants(const RefSplit& r, int64_t wave_tile, int pack, int blk) {
+    if (!r.on || r.always || r.index0 != 0 || r.n > (int64_t {1} << 31)) return {0, 0};
     const unsigned __int128 m = ((static_cast<unsigned __int128>(r.T) << 64) / static_cast<unsigned __int128>(r.n));
     const int width = static_cast<int>(wave_tile) + (16 + pack + 2) + (blk + pack + 2);
-    if (m == 0 || 2 * m < static_cast<unsigned __int128>(r.n) || (m * static_cast<unsigned>(width)) >> 64 != 0) return 0;
-    return static_cast<uint64_t>(m);
+    if (m == 0 || 2 * m < static_cast<unsigned __int128>(r.n) || (m * static_cast<unsigned>(width)) >> 64 != 0) return {0, 0};
+    const unsigned __int128 w = (m * static_cast<unsigned>(width) + 0xffffffffu) >> 32;   // rounded up
+    if (w >> 32 != 0) return {0, 0};
+    return {static_cast<uint64_t>(m), static_cast<uint32_t>(w)};
 }
 
 // The RefSplit of a streaming kernel's by-value parameter struct, fetched from the kernarg segment HERE and nowhere earlier.  Read as an ordinary

@@ -448,7 +448,7 @@ struct QuantKernargs {
     float inv_scale;
     int32_t zp32;
     const ParamRecord* dyn;
-    uint32_t flags, n_tiles;
+    uint32_t flags, look_w;
     QuantParams p;
 };
 constexpr uint32_t kQuantKernargRef = static_cast<uint32_t>(__builtin_offsetof(QuantKernargs, p) + __builtin_offsetof(QuantParams, ref));
@@ -467,8 +467,11 @@ struct QuantTile {
 template <int DT_IN, int BITS, int MODE, int U, bool STAGE, int NT, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t numel, uint64_t look_m, float inv_scale, int32_t zp32,
-                const ParamRecord* dyn, uint32_t flags, uint32_t tiles, QuantParams p_arg) {
-    // One tile per block: the grid IS the tile count (`tiles`; 0 when the tensor is smaller than a tile and the one block only does the guarded work).
+                const ParamRecord* dyn, uint32_t flags, uint32_t look_w, QuantParams p_arg) {
+    // One tile per block: the grid IS the tile count -- numel / BLOCK_ELEMS, a shift (0 when the tensor is smaller than a tile and the one block only does
+    // the guarded work).  It travelled as a preloaded argument of its own until the reference layout's first look needed that dword for look_w.
+    static_assert((QuantTile<DT_IN, BITS, U, BLOCK>::BLOCK_ELEMS & (QuantTile<DT_IN, BITS, U, BLOCK>::BLOCK_ELEMS - 1)) == 0, "a shift");
+    const uint32_t tiles = static_cast<uint32_t>(static_cast<uint64_t>(numel) / static_cast<uint64_t>(QuantTile<DT_IN, BITS, U, BLOCK>::BLOCK_ELEMS));
     const int64_t n_tiles = tiles;
     const uint32_t tile_stride = tiles > 0 ? tiles : 1u;
     // `in` / `out` / `numel` / the positions in `p_arg` describe the BODY of the call: the launcher has peeled `head` leading elements (a whole
@@ -481,7 +484,7 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
     // first instruction and the next lgkmcnt wait -- in front of the first global loads -- waits for it: +0.4 us on every quantize launch.)
     const int head = static_cast<int>(flags >> 16);
     // flags bit 1: reference layout (only the nearest fast step has a scalar form of its own; every other step is one formula at every position);
-    // look_m != 0: the first look needs nothing but this preloaded constant (device_math.hpp, ref_first_look_fast)
+    // look_m != 0: the first look needs nothing but the two preloaded constants look_m, look_w (device_math.hpp, ref_first_look_fast)
     [[maybe_unused]] const bool ref_on = MODE == RM_NEAREST_FAST && (flags & 2u) != 0;
     p_arg.inv_scale = inv_scale;
     p_arg.zp32 = zp32;
@@ -505,8 +508,8 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
     const BoundedStep bstep = bounded_step_for<BITS>(p.zp32);
     const float abs_inv = __builtin_fabsf(p.inv_scale);
 
-    if (const int64_t turn = blockIdx.x; turn < n_tiles) {
-        const int64_t tile = turn;
+    if (blockIdx.x < tiles) {   // 32-bit on purpose: a 64-bit unsigned order compare is a vector instruction, and this one stands in front of the tile's loads
+        const int64_t tile = blockIdx.x;
         const int64_t v0 = (tile * T::WAVES + wave) * T::WAVE_VECS;   // first input vector of this wave tile
 
         u32x4 raw[U];
@@ -546,7 +549,7 @@ quantize_kernel(const void* __restrict__ in, uint8_t* __restrict__ out, int64_t 
                 const uint64_t wave_tile = static_cast<uint64_t>(tile) * T::WAVES + static_cast<uint32_t>(wave);
                 bool look;
                 if (look_m != 0) {
-                    look = ref_first_look_fast<Margins::below, Margins::above>(look_m, wave_tile, T::WAVE_VECS * EPV);
+                    look = ref_first_look_fast<Margins::below>(look_m, look_w, static_cast<uint32_t>(wave_tile), T::WAVE_VECS * EPV);
                     if (look) ref = load_ref_split<kQuantKernargRef>();   // one tile in a hundred
                 } else {
                     ref = load_ref_split<kQuantKernargRef>();   // behind the tile's loads, on purpose
@@ -715,10 +718,14 @@ inline void launch_quantize_kernel(hipStream_t stream, const void* in, uint8_t* 
         fprintf(stderr, "quantize: %lld tiles in one launch\n", static_cast<long long>(n_tiles));
         abort();
     }   // 2^41 elements: not on this device
-    const uint64_t ref_m = MODE == RM_NEAREST_FAST ? ref_fast_look_constant(p.ref, Tile::BLOCK_ELEMS / Tile::WAVES, 8 / BITS, QuantRefBlock<BITS>::value) : 0;
+    const RefFastLook look = MODE == RM_NEAREST_FAST ? ref_fast_look_constants(p.ref, Tile::BLOCK_ELEMS / Tile::WAVES, 8 / BITS, QuantRefBlock<BITS>::value) : RefFastLook {0, 0};
+    if (n_tiles != numel / Tile::BLOCK_ELEMS) {   // the kernel derives the tile count from numel
+        fprintf(stderr, "quantize: %lld tiles for %lld elements\n", static_cast<long long>(n_tiles), static_cast<long long>(numel));
+        abort();
+    }
     const unsigned grid = n_tiles > 0 ? static_cast<unsigned>(n_tiles) : 1u;
-    PQ_LAUNCH((quantize_kernel<DT_IN, BITS, MODE, U, STAGE, NT, BLOCK>), dim3(grid), dim3(BLOCK), 0, stream, in, out, numel, ref_m, p.inv_scale, p.zp32, p.dyn, flags,
-              static_cast<uint32_t>(n_tiles), p);
+    PQ_LAUNCH((quantize_kernel<DT_IN, BITS, MODE, U, STAGE, NT, BLOCK>), dim3(grid), dim3(BLOCK), 0, stream, in, out, numel, look.m, p.inv_scale, p.zp32, p.dyn, flags,
+              look.w, p);
 }
 
 }  // namespace pq
