@@ -157,6 +157,7 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, uint
 
     // the reference layout's first look behind the staging of the input instead of behind the loads (ref_look below has the measurement)
     constexpr bool LOOK_LATE = STAGE && OP == OP_SET && DT_OUT == DT_BF16 && BITS < 8;
+    constexpr bool PACE = STAGE && OP == OP_SET && DT_OUT == DT_BF16 && BITS == 4 && !SHIFTED;   // a measured pause, below
 
     constexpr int SLICE = T::WAVE_IN_BYTES + (SHIFTED ? 16 : 0);   // + the byte behind a wave's slice
     __shared__ __attribute__((aligned(16))) uint8_t lds[STAGE ? T::WAVES * SLICE : 16];
@@ -279,6 +280,13 @@ dequantize_kernel(const uint8_t* __restrict__ in, void* out, int64_t numel, uint
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if constexpr (LOOK_LATE) ref_look();
+            // uint4 -> bf16 SET only: 256 idle cycles between the staging of the input and its read-back.  Measured, not derived (profiles/r06_ab_pacing.txt,
+            // interleaved A/B, s_sleep 1 / 2 / 4 / 8 / 16 / 32 / 64 and nine tile geometries with and without it): this kernel -- one 16-byte load and four
+            // 16-byte non-temporal stores per lane, 256-thread blocks -- runs 11.45 instead of 11.72 us at numel 27 264 000 and 5.8 instead of 6.9 us at
+            // 13 632 000 (what one of two GPUs gets) when its waves pause here, 0.1 us each; the late look above had shown the effect first: a launch that took
+            // it ran FASTER than one that skipped it.  Longer pauses lose (8: even, 16: +1 us).  No other streaming kernel gains from a pause anywhere (both
+            // sub-byte -> bf16 SET geometries, uint8 inputs, every ADD, fp32 outputs and the fp32 / bf16 quantizers were tried at two sizes).
+            if constexpr (PACE) __builtin_amdgcn_s_sleep(4);
 #pragma unroll
             for (int k = 0; k < U; ++k) {
                 const uint8_t* r = s + (k * 64 + lane) * IB;

@@ -32,7 +32,8 @@ int main(int argc, char** argv) {
     const int64_t n = argc > 1 ? atoll(argv[1]) : 27264000;
     const int reps = argc > 2 ? atoi(argv[2]) : 2000;
     const char* label = argc > 3 ? argv[3] : "variant";
-    constexpr int SETS = 24, ESIZE = AB_OUT == DT_F32 ? 4 : 2, PACK = 8 / AB_BITS;
+    const int SETS = getenv("AB_SETS") ? atoi(getenv("AB_SETS")) : 24;
+    constexpr int ESIZE = AB_OUT == DT_F32 ? 4 : 2, PACK = 8 / AB_BITS;
     std::vector<uint8_t*> in(SETS);
     std::vector<void*> out(SETS);
     for (int s = 0; s < SETS; ++s) {
@@ -48,7 +49,12 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     constexpr int kBitsIndex = AB_BITS == 8 ? 0 : (AB_BITS == 4 ? 1 : 2);
+#if defined(AB_U) && defined(AB_BLOCK)
+    constexpr KernelTune t0 = AB_OP == OP_ADD ? kDequantAddTune[AB_OUT][kBitsIndex] : kDequantTune[AB_OUT][kBitsIndex];
+    constexpr KernelTune t = {AB_U, true, t0.nt, AB_BLOCK, 0};   // a geometry other than the table's
+#else
     constexpr KernelTune t = AB_OP == OP_ADD ? kDequantAddTune[AB_OUT][kBitsIndex] : kDequantTune[AB_OUT][kBitsIndex];
+#endif
     using Tile = DequantTile<AB_BITS, AB_OUT, t.u, t.block>;
     const int64_t n_tiles = n / Tile::BLOCK_ELEMS;
     std::vector<int> threads = {0, 1, 255};

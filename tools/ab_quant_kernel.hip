@@ -44,7 +44,7 @@ int main(int argc, char** argv) {
     const int64_t n = argc > 1 ? atoll(argv[1]) : 27264000;
     const int reps = argc > 2 ? atoi(argv[2]) : 2000;
     const char* label = argc > 3 ? argv[3] : "variant";
-    constexpr int SETS = 24;
+    const int SETS = getenv("AB_SETS") ? atoi(getenv("AB_SETS")) : 24;   // rotate over more sets for small tensors (24 x the buffers must exceed the 256 MiB Infinity Cache)
     std::vector<float*> in(SETS);
     std::vector<uint8_t*> out(SETS);
     for (int s = 0; s < SETS; ++s) {
@@ -59,7 +59,11 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     constexpr int kBitsIndex = AB_BITS == 8 ? 0 : (AB_BITS == 4 ? 1 : 2);
+#ifdef AB_SMALL
+    constexpr KernelTune t = kQuantTuneSmallF32U8;   // the tile the library takes below 2^24 elements
+#else
     constexpr KernelTune t = kQuantTune[AB_DT][kBitsIndex];
+#endif
     using Tile = QuantTile<AB_DT, AB_BITS, t.u, t.block>;
     const int64_t all_tiles = n / Tile::BLOCK_ELEMS;
     // modes: uniform, then the reference layout for 1 and 255 pool threads -- or for the thread counts given as further arguments
