@@ -51,7 +51,10 @@ int main(int argc, char** argv) {
     constexpr int kBitsIndex = AB_BITS == 8 ? 0 : (AB_BITS == 4 ? 1 : 2);
 #if defined(AB_U) && defined(AB_BLOCK)
     constexpr KernelTune t0 = AB_OP == OP_ADD ? kDequantAddTune[AB_OUT][kBitsIndex] : kDequantTune[AB_OUT][kBitsIndex];
-    constexpr KernelTune t = {AB_U, true, t0.nt, AB_BLOCK, 0};   // a geometry other than the table's
+#ifndef AB_NT
+#define AB_NT t0.nt
+#endif
+    constexpr KernelTune t = {AB_U, true, AB_NT, AB_BLOCK, 0};   // a geometry / memory policy other than the table's
 #else
     constexpr KernelTune t = AB_OP == OP_ADD ? kDequantAddTune[AB_OUT][kBitsIndex] : kDequantTune[AB_OUT][kBitsIndex];
 #endif
