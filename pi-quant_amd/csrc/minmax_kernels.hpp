@@ -270,11 +270,62 @@ __device__ __forceinline__ void minmax_block_end_gather(float lo, float hi, cons
         if (lane == 0) __hip_atomic_store(words + me, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    // The sweeping block: all its waves sweep, wave w the slot groups w, w + WAVES, ... of 512 slots each (8 loads per lane in flight),
+    constexpr int LPL = 8;
+    if (G - 1 <= 64u * LPL) {
+        // The usual grid (one or two blocks per CU): ONE wave can hold every word, so ALL waves of the block sweep all of them, out of phase.  A sweep is a
+        // round trip through the fabric (~1 us), and the slowest block's word becomes visible at a random moment of it: one sweeping wave sees it half a
+        // round trip late on average, WAVES staggered ones a sixteenth.  The first wave that has seen every word folds them, re-arms the slots and runs the
+        // epilogue; the others leave when they see its flag.  Until the last session of round 6 wave 0 swept alone (seven waves had no slots to sweep in a
+        // 256-block grid): fp32 19.06 -> 18.75 us, bf16 11.63 -> 11.37 us at numel 27 264 000, two executables alternated (profiles/r06_ab_scan_end.txt);
+        // a stagger of 128 instead of 256 cycles was better in one process and worse in the next.
+        __shared__ uint32_t s_done;
+        if (threadIdx.x == 0) s_done = 0;
+        __syncthreads();   // block-uniform: every thread of the sweeping block is here
+        float blo = s_lo[0], bhi = s_hi[0];   // the block's own result never travels through memory
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) {
+            blo = __builtin_fminf(blo, s_lo[w]);
+            bhi = __builtin_fmaxf(bhi, s_hi[w]);
+        }
+        int32_t k0 = float_to_key(blo), k1 = float_to_key(-bhi);
+        unsigned long long w[LPL];
+#pragma unroll
+        for (int j = 0; j < LPL; ++j) w[j] = static_cast<uint32_t>(j * 64 + lane) + 1 < G ? kMinmaxNotArrived : ~0ull;
+        for (int i = 0; i < wave; ++i) __builtin_amdgcn_s_sleep(4);   // 256 cycles per wave: WAVES x 0.1 us ~ one round trip
+        const uint64_t t_begin = wall_clock64();
+        for (;;) {
+            if (__hip_atomic_load(&s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) return;
+            bool missing = false;
+#pragma unroll
+            for (int j = 0; j < LPL; ++j) {
+                if (w[j] == kMinmaxNotArrived) {
+                    w[j] = __hip_atomic_load(words + j * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    missing |= w[j] == kMinmaxNotArrived;
+                }
+            }
+            if (!__any(missing ? 1 : 0)) break;
+            if (wall_clock64() - t_begin > 1000000000ull) __builtin_trap();   // ten seconds without a block: a bug or a wedged device (below)
+        }
+        uint32_t won = 0;
+        if (lane == 0) won = __hip_atomic_exchange(&s_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0 ? 1u : 0u;
+        if (__builtin_amdgcn_readfirstlane(won) == 0) return;
+#pragma unroll
+        for (int j = 0; j < LPL; ++j) {
+            if (static_cast<uint32_t>(j * 64 + lane) + 1 < G) {
+                __hip_atomic_store(words + j * 64 + lane, kMinmaxNotArrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // armed for the next scan
+                k0 = min(k0, static_cast<int32_t>(static_cast<uint32_t>(w[j])));
+                k1 = min(k1, static_cast<int32_t>(static_cast<uint32_t>(w[j] >> 32)));
+            }
+        }
+        k0 = wave_min_i32(k0);
+        k1 = wave_min_i32(k1);
+        if (lane == 0) minmax_action(k0, k1, ep);
+        return;
+    }
+    // Larger grids: all waves sweep, wave w the slot groups w, w + WAVES, ... of 512 slots each (8 loads per lane in flight),
     // so that grids up to WAVES x 512 blocks are swept in ONE pass of loads; then the waves' results meet in LDS.
     int32_t k0 = float_to_key(lo), k1 = float_to_key(-hi);   // this wave's own scan result never travels through memory
     const uint64_t t_begin = wall_clock64();
-    constexpr int LPL = 8;
     for (uint32_t base = static_cast<uint32_t>(wave) * 64 * LPL; base + 1 < G; base += WAVES * 64 * LPL) {   // slots [0, G - 1)
         unsigned long long w[LPL];
 #pragma unroll

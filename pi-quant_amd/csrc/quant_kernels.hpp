@@ -12,9 +12,10 @@
 // bytes (global_store_dwordx4, 1 KiB per wave-instruction) -- the "LDS-staged int4 packing" of the design.
 // Without STAGE each lane stores its OB bytes directly (still contiguous across the wave).
 //
-// The kernel is a grid-stride loop over block tiles (WAVES wave tiles); the ragged tail (numel not a
-// multiple of the block tile) is done by a guarded per-byte path inside the SAME launch, dealt over the threads of
-// the whole grid, so a call is always exactly one kernel (a second launch would cost ~1.5 us on a ~20 us kernel).
+// One block tile (WAVES wave tiles) per block -- the grid is the tile count; until round 6 a grid-stride loop, whose end waited for a tile's
+// stores before the next tile's loads could issue.  The ragged tail (numel not a multiple of the block tile) is done by a guarded per-byte
+// path inside the SAME launch, dealt over the threads of the whole grid, so a call is always exactly one kernel (a second launch would
+// cost ~1.5 us on a ~20 us kernel).
 #pragma once
 
 #include <cstdio>

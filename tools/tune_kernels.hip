@@ -609,6 +609,20 @@ int main(int argc, char** argv) {
 
 
 
+    if (only == "mmend") {
+        // the production scans alone, fp32 then bf16 on bf16 data (numel = fp32 elements; the bf16 scan reads 2 * numel elements = the same bytes... no:
+        // numel bf16 elements, half the bytes, as bench.py's minmax_bf16), for A/B work on the end of a scan: build against two header directories
+        g_rounds = 1;
+        g_mm_caps = {1};
+        for (int pass = 0; pass < 6; ++pass) run_minmax<DT_F32, 4, true, 512, true>(b, numel, num_cu, keys);
+        for (int s_ = 0; s_ < SETS; ++s_)
+            hipLaunchKernelGGL(fill_uniform_bf16, dim3(4096), dim3(256), 0, g_stream, static_cast<uint16_t*>(b.in[s_]), numel, 0x9e3779b9u * (s_ + 1));
+        CK(hipStreamSynchronize(g_stream));
+        for (int pass = 0; pass < 6; ++pass) run_minmax<DT_BF16, 4, true, 512, true>(b, numel, num_cu, keys);
+        g_mm_caps = {1, 2, 4, 8, 16, 32};
+        g_rounds = 3;
+        return 0;
+    }
     if (only == "mmbf") {
         // round 6: the bf16 scan alone, on bf16 DATA (the fp32 buffers read as bf16 are random patterns, a NaN in every wave's share -- which the
         // packed-integer fold answers with a second, float pass).  numel = bf16 elements; run with TUNE_SETS=40 so that 2.2 GB rotate.
