@@ -61,6 +61,12 @@ int main(int argc, char** argv) {
     constexpr int kBitsIndex = AB_BITS == 8 ? 0 : (AB_BITS == 4 ? 1 : 2);
 #ifdef AB_SMALL
     constexpr KernelTune t = kQuantTuneSmallF32U8;   // the tile the library takes below 2^24 elements
+#elif defined(AB_U) && defined(AB_BLOCK)
+    constexpr KernelTune t0 = kQuantTune[AB_DT][kBitsIndex];
+#ifndef AB_NT
+#define AB_NT t0.nt
+#endif
+    constexpr KernelTune t = {AB_U, true, AB_NT, AB_BLOCK, 0};   // a geometry / memory policy other than the table's
 #else
     constexpr KernelTune t = kQuantTune[AB_DT][kBitsIndex];
 #endif
