@@ -609,6 +609,10 @@ def single_gpu(B):
             return round(bytes_per_elem * n / (ev_s / reps) / 1e9, 1)
 
         reps = 200
+
+        def time_loop(fn, reps_, stream_, _one=time_loop):   # noqa: F811 -- the per-kernel extras below: median of five windows of `reps` launches, not one
+            es = sorted(_one(fn, reps_, stream_)[1] for _ in range(5))   # window (a single window of a 12 us kernel is 2.4 ms: one slow start moves it by 3 %)
+            return None, es[2]
         # config 3 moves 68 MB per launch: as many buffer sets as the headline (1.6 GB) -- with the 4 sets of round 1 (272 MB) the 256 MiB
         # Infinity Cache served a good part of the traffic and both kernels looked 1-1.5 us faster than they are from HBM
         nb = nsets
