@@ -93,9 +93,12 @@ void quantize_bits(const QuantLaunch& q, const QuantParams& p, hipStream_t strea
     }
 }
 
-template <int BITS, int DT_OUT, int OP>
+// LARGE: the tile and store policy of the two sub-byte -> bf16 SET pairs for tensors beyond tuning.hpp's thresholds
+template <int BITS, int DT_OUT, int OP, bool LARGE = false>
 void dequantize_t(const DequantLaunch& d, const DequantParams& p, hipStream_t stream, int num_cu) {
-    constexpr KernelTune t = OP == OP_ADD ? kDequantAddTune[DT_OUT][bits_index(BITS)] : kDequantTune[DT_OUT][bits_index(BITS)];
+    static_assert(!LARGE || (OP == OP_SET && DT_OUT == DT_BF16 && BITS < 8), "only those two have a second entry");
+    constexpr KernelTune t = LARGE ? (BITS == 4 ? kDequantTuneLargeU4Bf16 : kDequantTuneLargeU2Bf16)
+                                   : (OP == OP_ADD ? kDequantAddTune[DT_OUT][bits_index(BITS)] : kDequantTune[DT_OUT][bits_index(BITS)]);
     using Tile = DequantTile<BITS, DT_OUT, t.u, t.block>;
     const uint8_t* in = static_cast<const uint8_t*>(d.in);
     constexpr int PACK = 8 / BITS, ESIZE = DT_OUT == DT_F32 ? 4 : 2;
@@ -123,7 +126,15 @@ void dequantize_t(const DequantLaunch& d, const DequantParams& p, hipStream_t st
 template <int BITS, int DT_OUT>
 void dequantize_op(const DequantLaunch& d, const DequantParams& p, hipStream_t stream, int num_cu) {
     switch (d.op) {
-        case OP_SET: dequantize_t<BITS, DT_OUT, OP_SET>(d, p, stream, num_cu); return;
+        case OP_SET:
+            if constexpr (DT_OUT == DT_BF16 && BITS < 8) {
+                if (d.numel >= (BITS == 4 ? kDequantLargeNumelU4Bf16 : kDequantLargeNumelU2Bf16)) {
+                    dequantize_t<BITS, DT_OUT, OP_SET, true>(d, p, stream, num_cu);
+                    return;
+                }
+            }
+            dequantize_t<BITS, DT_OUT, OP_SET>(d, p, stream, num_cu);
+            return;
         case OP_ADD: dequantize_t<BITS, DT_OUT, OP_ADD>(d, p, stream, num_cu); return;
         default: panic("invalid reduce op %d", d.op);
     }

@@ -68,6 +68,15 @@ constexpr KernelTune kDequantTune[2][3] = {
     {{2, true, kStream, 128, 0}, {4, true, kStream, 256, 0}, {4, true, kStream, 256, 0}},
     {{2, true, kStream, 64, 0}, {4, true, kStreamNT, 256, 0}, {4, true, kStreamNT, 256, 0}},
 };
+// LARGE tensors (round 6, last session; profiles/r06_ab_large_tensors.txt): the two sub-byte -> bf16 SET entries above were swept at numel 27 264 000, and
+// their non-temporal stores fall behind as a launch grows -- uint4 -> bf16 at 109 M elements 46.2 us (5.9 TB/s) against 43.0 for 128-thread / U = 2 tiles
+// with write-through stores, at 218 M 96 against 84 us (5.7 vs 6.5 TB/s); uint2 -> bf16 with the same tile and write-through stores 39.3 against 42.9 us at
+// 109 M, 79.5 against 88.5 at 218 M.  The crossovers are near 54 M (uint4) and 35 M (uint2) elements; below them the table's entries win by up to 10 %.  The
+// ADD kernels and uint8 -> bf16 keep their policy at every size (measured to 218 M: non-temporal stores stay ahead for the ADDs).
+constexpr KernelTune kDequantTuneLargeU4Bf16 = {2, true, kStream, 128, 0};
+constexpr KernelTune kDequantTuneLargeU2Bf16 = {4, true, kStream, 256, 0};
+constexpr int64_t kDequantLargeNumelU4Bf16 = int64_t {1} << 26;
+constexpr int64_t kDequantLargeNumelU2Bf16 = int64_t {1} << 25;
 // ADD, cold sweep of the pairs above plus profiles/r02_tune_dequant_add.csv for the rest: small tiles everywhere (the accumulator is a second
 // input stream); uint2 -> bf16 19.6 us with 64-thread tiles and non-temporal stores against 23.3 with the 128-thread write-through tiles it had,
 // uint2 -> fp32 35.7 vs 38.3, uint4 -> fp32 36.8 vs 37.8, uint8 -> bf16 22.7 vs 23.2.

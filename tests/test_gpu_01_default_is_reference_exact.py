@@ -101,6 +101,22 @@ def test_default_calls_equal_the_reference_context_of_the_same_thread_count_at_f
     assert moved >= (3 if threads > 1 else 1), "no dequantize tail differed from the SIMD-body form: nothing was tested"   # one partition: one tail per call
 
 
+@pytest.mark.parametrize("threads", [1, 255])
+def test_large_tensors_take_another_tile_and_write_the_same_bytes(O, threads):
+    """Beyond 2^26 (uint4) / 2^25 (uint2) elements the two sub-byte -> bf16 SET dequantizers switch tile and store policy (csrc/tuning.hpp,
+    kDequantTuneLarge*): the bytes are the oracle's threaded reference form on both sides of the thresholds, aligned and with the output one element off."""
+    import piquant
+
+    ctx = piquant.Context(threads)
+    rng = np.random.default_rng(2600 + threads)
+    for dt_q, threshold in ((O.UINT4, 1 << 26), (O.UINT2, 1 << 25)):
+        for n, off in ((threshold + 4099, 0), (threshold + 4099, 2), (threshold - 1, 0)):   # off: bytes -- one bf16 element, the body then starts inside a packed byte
+            q = rng.integers(0, 256, O.packed_numel(n, dt_q), dtype=np.uint8)
+            want = O.dequantize(q, dt_q, O.BF16, n, 0.3, 2, 0, form=O.FORM_REFERENCE, threads=threads)
+            got = gpu_dequantize(ctx, q, dt_q, O.BF16, n, 0.3, 2, 0, offset_out=off)
+            assert same_floats(got, want), (threads, dt_q, n, off, np.nonzero(got != want)[0][:8])
+
+
 def test_small_tensors_and_more_threads_than_simd_blocks(O):
     """Partitions much smaller than a wave tile -- down to contexts with more pool threads than the tensor has elements -- take the element-by-element
     second look inside the same launch: still the reference's bytes."""
