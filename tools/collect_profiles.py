@@ -103,7 +103,7 @@ def main():
         d = json.loads(pmc.read_text())
         (PROF / f"{R}_pmc_all_kernels.json").write_text(json.dumps({
             "command": "bash tools/pmc_all_kernels.sh: rocprofv3 --kernel-trace {--stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_* (two groups)} -- python tools/config_kernels_workload.py "
-                       "(60 stream-ordered launches of every kernel of the BASELINE configs at numel 27264000, rotating buffers); separate passes, kernel-trace only",
+                       "(200 stream-ordered launches of every kernel of the BASELINE configs at numel 27264000, rotating buffers); separate passes, kernel-trace only",
             "units": "per launch: median of the counters over the launches; fetch_MB = FETCH_SIZE KiB x 2 (gfx950: 128-B requests tallied at 64 B, guides/MI355X_MICROARCH.md HBM section), "
                      "write_MB = WRITE_SIZE KiB; avg/min/max_us from the --stats pass; X/SQ_WAVE_CYCLES = share of the waves' resident cycles",
             "kernels": d}, indent=1) + "\n")
@@ -113,7 +113,7 @@ def main():
             (PROF / "hbm_traffic.json").write_text(json.dumps({"quantize_f32_u8": {
                 "bytes_per_launch": round((k["fetch_MB"] + k["write_MB"]) * 1e6), "fetch_bytes": round(k["fetch_MB"] * 1e6), "write_bytes": round(k["write_MB"] * 1e6),
                 "algorithmic_bytes": 136320000,
-                "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, kernel-trace only) over tools/config_kernels_workload.py; median over 60 launches at numel "
+                "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, kernel-trace only) over tools/config_kernels_workload.py; median over 200 launches at numel "
                           "27264000; FETCH_SIZE KiB x2 (gfx950 128-B requests tallied at 64 B, guides/MI355X_MICROARCH.md HBM section), WRITE_SIZE KiB as reported; "
                           f"raw summaries in profiles/{R}_pmc_all_kernels.json"}}, indent=1) + "\n")
             done.append("hbm_traffic.json")

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Workload for counter passes over EVERY kernel the BASELINE configs use: 60 stream-ordered launches each, at
+"""Workload for counter passes over EVERY kernel the BASELINE configs use: 200 stream-ordered launches each (60 until round 6: the first launches of a process weighed 2-3 % in the averages), at
 numel 27 264 000 on rotating buffer sets (> 256 MiB in total, so the Infinity Cache cannot serve them).
 
   configs[1]  quantize fp32 -> uint8 nearest
@@ -25,7 +25,7 @@ from piquant import DataType, ReduceOp, RoundMode  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--numel", type=int, default=27_264_000)
-ap.add_argument("--calls", type=int, default=60)
+ap.add_argument("--calls", type=int, default=200)
 ap.add_argument("--big", action="store_true")
 args = ap.parse_args()
 N, SETS, CALLS = args.numel, 12, args.calls   # 12 sets: the 68 MB bf16/uint4 launches also rotate over > 3x the 256 MiB Infinity Cache
